@@ -1,0 +1,75 @@
+"""Build libdtc_hip.so (hand-written HIP kernels + C ABI) for gfx950, in-tree.
+
+    python deep-tracking-control_amd/build.py [--force] [--save-temps]
+
+hipcc cross-compiles without a GPU.  Objects land in deep-tracking-control_amd/build/, the
+shared library in deep-tracking-control_amd/dtc_amd/lib/libdtc_hip.so (git-ignored; it travels
+to the GPU box with the gpurun snapshot).
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIBDIR = os.path.join(HERE, "dtc_amd", "lib")
+LIB = os.path.join(LIBDIR, "libdtc_hip.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-fhip-fp32-correctly-rounded-divide-sqrt", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+# bit-exact kernels: no fused multiply-add contraction (see oracle/foothold.py, oracle/gae.py)
+PER_FILE = {"foothold.hip": ["-ffp-contract=off"], "gae.hip": ["-ffp-contract=off"]}
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, force, save_temps):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers.append(os.path.join(ROOT, "include", "dtc_hip.h"))
+    if not force and not _stale(obj, [os.path.join(CSRC, src), __file__] + headers):
+        return obj, ""
+    cmd = [HIPCC, *COMMON, *PER_FILE.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+    if save_temps:
+        cmd.insert(1, "-save-temps=obj")
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJ)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+    return obj, r.stderr
+
+
+def build(force=False, save_temps=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = sources()
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force, save_temps), srcs))
+    objs = [o for o, _ in results]
+    for (_, warn), s in zip(results, srcs):
+        if warn.strip() and verbose:
+            print(f"[{s}]\n{warn}", file=sys.stderr)
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    if verbose:
+        print(f"built {LIB} ({os.path.getsize(LIB) / 1024:.0f} KiB) from {len(srcs)} sources")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)

@@ -1,0 +1,176 @@
+// GAE(lambda) scan + advantage normalisation + mini-batch row gather for gfx950.
+//
+//  * dtc_gae            rsl_rl/rsl_rl/storage/rollout_storage.py:138-150  (24-iteration Python loop
+//                       of [N,1] torch ops -> one kernel, lane per env, time loop in registers;
+//                       every load/store is coalesced over envs: 17 B/env-step)
+//  * dtc_adv_sqdev /    rollout_storage.py:151-152  (mean, unbiased std over all T*N samples; the
+//    dtc_adv_normalize  two reductions are exposed separately so data-parallel ranks can all-reduce
+//                       the two scalars in between -- SURVEY.md 8e item 2)
+//  * dtc_gather_rows    rollout_storage.py:195-209  (`tensor.flatten(0,1)[batch_idx]`)
+//
+// Compiled with -ffp-contract=off: the scan reproduces oracle/gae.py bit for bit.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) t += sh[w];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
+                                                  const uint8_t* __restrict__ dones,
+                                                  const float* __restrict__ last_values, float gamma, float lam,
+                                                  float* __restrict__ returns, float* __restrict__ adv_out,
+                                                  double* __restrict__ partials, int T, int N) {
+    __shared__ double sh[4];
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    double local = 0.0;
+    if (n < N) {
+        float adv = 0.0f;
+        float next_v = last_values[n];
+        for (int t = T - 1; t >= 0; --t) {
+            const int64_t o = (int64_t)t * N + n;
+            const float v = values[o];
+            const float nnt = 1.0f - (float)dones[o];
+            const float ng = nnt * gamma;
+            const float delta = (rewards[o] + ng * next_v) - v;
+            adv = delta + (ng * lam) * adv;
+            const float ret = adv + v;
+            returns[o] = ret;
+            const float a = ret - v;
+            adv_out[o] = a;
+            local += (double)a;
+            next_v = v;
+        }
+    }
+    const double tot = block_sum(local, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// stats[slot] = sum(partials[0..np))   (single block; deterministic order)
+__global__ __launch_bounds__(256) void finalize_sum_kernel(const double* __restrict__ partials, int np,
+                                                           double* __restrict__ stats, int slot) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) v += partials[i];
+    const double tot = block_sum(v, sh);
+    if (threadIdx.x == 0) stats[slot] = tot;
+}
+
+__global__ __launch_bounds__(256) void sqdev_kernel(const float* __restrict__ adv, const double* __restrict__ stats,
+                                                    double count, double* __restrict__ partials, int64_t n) {
+    __shared__ double sh[4];
+    const double mean = stats[0] / count;
+    double v = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double d = (double)adv[i] - mean;
+        v += d * d;
+    }
+    const double tot = block_sum(v, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ adv, const double* __restrict__ stats,
+                                                        double count, int64_t n) {
+    const float mean = (float)(stats[0] / count);
+    const float stdv = (float)sqrt(stats[1] / (count - 1.0));
+    const float den = stdv + 1e-8f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        adv[i] = (adv[i] - mean) / den;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ idx,
+                                                          T* __restrict__ dst, int64_t rows, int64_t row_elems) {
+    const int64_t total = rows * row_elems;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / row_elems;
+        const int64_t c = e - r * row_elems;
+        dst[e] = src[idx[r] * row_elems + c];
+    }
+}
+
+constexpr int MAX_PARTIALS = 4096;
+// Scratch for the reduction partials lives behind stats: callers pass double[4 + MAX_PARTIALS]?
+// No: keep the ABI small -- partials use a lazily allocated per-process device buffer.
+double* partial_buffer() {
+    static double* buf = nullptr;
+    if (!buf) {
+        if (hipMalloc(&buf, sizeof(double) * MAX_PARTIALS) != hipSuccess) buf = nullptr;
+    }
+    return buf;
+}
+
+}  // namespace
+
+extern "C" int dtc_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values,
+                       float gamma, float lam, float* returns, float* advantages, double* stats, int T, int N,
+                       void* stream) {
+    DTC_REQUIRE(T > 0 && N > 0, "bad shape T=%d N=%d", T, N);
+    DTC_REQUIRE(rewards && values && dones && last_values && returns && advantages && stats, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    double* partials = partial_buffer();
+    DTC_REQUIRE(partials != nullptr, "partial buffer allocation failed");
+    const int grid = (int)dtc::ceil_div(N, 256);
+    DTC_REQUIRE(grid <= MAX_PARTIALS, "N too large for one call (max %d envs)", MAX_PARTIALS * 256);
+    {
+        dtc::ProfScope prof("gae_scan", (double)T * N * 17.0, s);
+        hipLaunchKernelGGL(gae_kernel, dim3(grid), dim3(256), 0, s, rewards, values, dones, last_values, gamma, lam,
+                           returns, advantages, partials, T, N);
+    }
+    hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, s, partials, grid, stats, 0);
+    return dtc::check_launch("gae");
+}
+
+extern "C" int dtc_adv_sqdev(const float* advantages, double* stats, int64_t n_local, double count, void* stream) {
+    DTC_REQUIRE(advantages && stats && n_local > 0 && count > 1.0, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    double* partials = partial_buffer();
+    DTC_REQUIRE(partials != nullptr, "partial buffer allocation failed");
+    const int grid = (int)(dtc::ceil_div(n_local, 256) < 1024 ? dtc::ceil_div(n_local, 256) : 1024);
+    hipLaunchKernelGGL(sqdev_kernel, dim3(grid), dim3(256), 0, s, advantages, stats, count, partials, n_local);
+    hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, s, partials, grid, stats, 1);
+    return dtc::check_launch("adv_sqdev");
+}
+
+extern "C" int dtc_adv_normalize(float* advantages, const double* stats, int64_t n_local, double count, void* stream) {
+    DTC_REQUIRE(advantages && stats && n_local > 0 && count > 1.0, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (int)(dtc::ceil_div(n_local, 256) < 2048 ? dtc::ceil_div(n_local, 256) : 2048);
+    hipLaunchKernelGGL(normalize_kernel, dim3(grid), dim3(256), 0, s, advantages, stats, count, n_local);
+    return dtc::check_launch("adv_normalize");
+}
+
+extern "C" int dtc_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t rows, int64_t row_bytes,
+                               void* stream) {
+    DTC_REQUIRE(rows >= 0 && row_bytes > 0, "bad shape");
+    if (rows == 0) return DTC_OK;
+    DTC_REQUIRE(src && idx && dst, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    dtc::ProfScope prof("gather_rows", 2.0 * (double)rows * (double)row_bytes, s);
+    auto grid_for = [](int64_t total) { return (unsigned)(dtc::ceil_div(total, 256) < 8192 ? dtc::ceil_div(total, 256) : 8192); };
+    if (row_bytes % 16 == 0 && dtc::aligned16(src) && dtc::aligned16(dst)) {
+        const int64_t re = row_bytes / 16;
+        hipLaunchKernelGGL(gather_rows_kernel<uint4>, dim3(grid_for(rows * re)), dim3(256), 0, s, (const uint4*)src, idx,
+                           (uint4*)dst, rows, re);
+    } else if (row_bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0 &&
+               (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+        const int64_t re = row_bytes / 4;
+        hipLaunchKernelGGL(gather_rows_kernel<uint32_t>, dim3(grid_for(rows * re)), dim3(256), 0, s,
+                           (const uint32_t*)src, idx, (uint32_t*)dst, rows, re);
+    } else {
+        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3(grid_for(rows * row_bytes)), dim3(256), 0, s,
+                           (const uint8_t*)src, idx, (uint8_t*)dst, rows, row_bytes);
+    }
+    return dtc::check_launch("gather_rows");
+}

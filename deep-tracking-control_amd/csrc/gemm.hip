@@ -1,0 +1,544 @@
+// fp32 MFMA dense layers for gfx950: forward, data-gradient and weight-gradient GEMMs of the
+// nn.Linear stacks of rsl_rl/rsl_rl/modules/actor_critic_decoder.py:98-188, 323-349 as they
+// are used by PPO.update (rsl_rl/rsl_rl/algorithms/ppo.py:197-218, 265, 289, 252, 333).
+//
+// All three products run on v_mfma_f32_32x32x2_f32 (exact fp32: bitwise a k-ordered fmaf
+// chain, 157.3 TFLOP/s peak, there is no xf32/TF32 on gfx950).  The instruction takes 64
+// cycles per issue, so the kernels are MFMA-bound by a wide margin (one 128x128x16 block step
+// = 2048 MFMA cycles per SIMD against 16 dword loads + 32 LDS reads per lane); the design
+// therefore spends its freedom on *removing HBM passes*, not on staging tricks:
+//   - torch.cat([...], dim=1) operands (ppo.py:201, actor_critic_decoder.py:431,550) and the
+//     mini-batch gather `tensor[batch_idx]` (rollout_storage.py:195-209) are folded into the
+//     operand loader through a "segmented matrix" descriptor (DtcSegMat): up to 4 column
+//     blocks, each optionally row-gathered.  Neither the cat nor the gathered batch exists in HBM.
+//   - bias + ReLU/ELU are fused into the forward epilogue; the activation derivative is fused
+//     into the data-gradient epilogue (needs only the saved post-activation output); the bias
+//     gradient (column sums of dZ) is accumulated by the weight-gradient kernel while it stages
+//     dZ, so no extra pass over dZ exists.
+//   - K and N tails (53, 265, 531, 584, 693, 752, 12, 1 ...) are zero-padded in LDS, never in HBM.
+// Tiling: 256 threads = 4 waves; block tile 128 x {128,64,32}; each wave owns 32x32 MFMA
+// sub-tiles (2x2, 1x2 or 1x1); K step 16; LDS tiles are stored [k][row] (+4 pad) so every MFMA
+// operand read is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave;
+// double-buffered LDS with register-staged prefetch -> one barrier per K step.
+// Workgroup -> tile mapping is XCD-aware (block b runs on XCD b%8): all column tiles of one row
+// panel are issued on the same XCD so the panel is fetched from HBM once and re-read from
+// that XCD's L2.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 16;
+constexpr int PAD = 4;
+
+struct SegDev {
+    float* ptr;
+    long long ld;
+    int col0, start, width, gather, accumulate;
+};
+struct SegMatDev {
+    int nseg, cols;
+    const long long* idx;
+    SegDev s[4];
+};
+
+__device__ __forceinline__ int find_seg(const SegMatDev& X, int k) {
+    int s = 0;
+    if (X.nseg > 1 && k >= X.s[1].start) s = 1;
+    if (X.nseg > 2 && k >= X.s[2].start) s = 2;
+    if (X.nseg > 3 && k >= X.s[3].start) s = 3;
+    return s;
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == DTC_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DTC_ACT_ELU) return v > 0.f ? v : expm1f(v);
+    return v;
+}
+// derivative expressed through the saved post-activation output y
+__device__ __forceinline__ float act_bwd(float g, float y, int act) {
+    if (act == DTC_ACT_RELU) return y > 0.f ? g : 0.f;
+    if (act == DTC_ACT_ELU) return y > 0.f ? g : g * (y + 1.0f);
+    return g;
+}
+
+template <int BN>
+struct Cfg {
+    static constexpr int WM = (BN == 128) ? 2 : 4;      // waves along the row dimension
+    static constexpr int WN = 4 / WM;                   // waves along the column dimension
+    static constexpr int TM = BM / (32 * WM);           // 32x32 MFMA tiles per wave (rows)
+    static constexpr int TN = BN / (32 * WN);           // 32x32 MFMA tiles per wave (cols)
+    static constexpr int LDA = BM + PAD;
+    static constexpr int LDB = BN + PAD;
+};
+
+// XCD-aware tile mapping: returns false for padding blocks.
+__device__ __forceinline__ bool map_tile(int b, int row_tiles, int col_tiles, int& tr, int& tc) {
+    const int xcd = b & 7;
+    const int j = b >> 3;
+    const int local = j / col_tiles;
+    tc = j - local * col_tiles;
+    tr = xcd + 8 * local;
+    return tr < row_tiles;
+}
+inline int grid_for(int row_tiles, int col_tiles) { return 8 * (int)dtc::ceil_div(row_tiles, 8) * col_tiles; }
+
+template <int BN>
+__device__ __forceinline__ void mfma_step(const float* __restrict__ As, const float* __restrict__ Bs,
+                                          f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN], int lane, int wm_off, int wn_off) {
+    using C = Cfg<BN>;
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+        float a[C::TM], b[C::TN];
+        const float* ap = As + (2 * kp + half) * C::LDA + wm_off + l31;
+        const float* bp = Bs + (2 * kp + half) * C::LDB + wn_off + l31;
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) a[i] = ap[32 * i];
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) b[j] = bp[32 * j];
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward: Y[M,N] = act(X[M,K] W[N,K]^T + b)
+// ------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ Y,
+                                                         long long ldy, int M, int N, int K, int act) {
+    using C = Cfg<BN>;
+    __shared__ float As[2][BK][C::LDA];
+    __shared__ float Bs[2][BK][C::LDB];
+    int tr, tc;
+    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, tr, tc)) return;
+    const int m0 = tr * BM, n0 = tc * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
+
+    // loader coordinates: thread owns k = kk and rows rbase + 16*i
+    const int kk = tid & 15, rbase = tid >> 4;
+    constexpr int NA = BM / 16, NB = BN / 16;
+    long long arow[NA], grow[NA];
+    bool aval[NA];
+    bool any_gather = false;
+    for (int s = 0; s < X.nseg; ++s) any_gather |= X.s[s].gather != 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + rbase + 16 * i;
+        aval[i] = m < M;
+        arow[i] = m;
+        grow[i] = (any_gather && aval[i]) ? X.idx[m] : m;
+    }
+    float ra[NA], rb[NB];
+    auto load_tile = [&](int k0) {
+        const int k = k0 + kk;
+        if (k < K) {
+            const int s = find_seg(X, k);
+            const SegDev sd = X.s[s];
+            const float* p = sd.ptr + sd.col0 + (k - sd.start);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = aval[i] ? p[(sd.gather ? grow[i] : arow[i]) * sd.ld] : 0.f;
+            const float* w = W + k;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int n = n0 + rbase + 16 * i;
+                rb[i] = n < N ? w[(long long)n * K] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = 0.f;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Bs[buf][kk][rbase + 16 * i] = rb[i];
+    };
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = (K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tile((kt + 1) * BK);
+        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
+        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) {
+        const int col = n0 + wn_off + 32 * j + l31;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm_off + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M) Y[(long long)row * ldy + col] = act_fwd(acc[i][j][r] + bv, act);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Data gradient: dX[M,K] = (dZ[M,N] W[N,K]) * act'(Xsaved)   (reduction over N)
+// ------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dZ, long long lddz,
+                                                           const float* __restrict__ W, const SegMatDev dX,
+                                                           const float* __restrict__ Xs, long long ldxs, int M, int N,
+                                                           int K, int act) {
+    using C = Cfg<BN>;
+    __shared__ float As[2][BK][C::LDA];
+    __shared__ float Bs[2][BK][C::LDB];
+    int tr, tc;
+    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (K + BN - 1) / BN, tr, tc)) return;
+    const int m0 = tr * BM, c0 = tc * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
+
+    const int kk = tid & 15, rbase = tid >> 4;      // A loader (dZ rows, reduction index n contiguous)
+    constexpr int NA = BM / 16;
+    constexpr int RPP = 256 / BN;                   // B loader: reduction rows per pass
+    constexpr int NB = BK / RPP;
+    const int bj = tid % BN, bk0 = tid / BN;
+    const bool bcol_ok = c0 + bj < K;
+    float ra[NA], rb[NB];
+    auto load_tile = [&](int n_0) {
+        const int n = n_0 + kk;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + rbase + 16 * i;
+            ra[i] = (m < M && n < N) ? dZ[(long long)m * lddz + n] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int nr = n_0 + bk0 + RPP * i;
+            rb[i] = (bcol_ok && nr < N) ? W[(long long)nr * K + c0 + bj] : 0.f;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Bs[buf][bk0 + RPP * i][bj] = rb[i];
+    };
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = (N + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tile((kt + 1) * BK);
+        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
+        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) {
+        const int col = c0 + wn_off + 32 * j + l31;
+        if (col >= K) continue;
+        const SegDev sd = dX.s[find_seg(dX, col)];
+        if (sd.ptr == nullptr) continue;
+        float* dst = sd.ptr + sd.col0 + (col - sd.start);
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm_off + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M) {
+                    float v = acc[i][j][r];
+                    if (act != DTC_ACT_NONE) v = act_bwd(v, Xs[(long long)row * ldxs + col], act);
+                    float* q = dst + (long long)row * sd.ld;
+                    *q = sd.accumulate ? (*q + v) : v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient (split over the batch): part[s][n][c] = sum_{m in split s} dZ[m,n] X[m,c],
+// c == K holds the bias-gradient partial.  A second kernel reduces the splits.
+// ------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dZ, long long lddz,
+                                                           const SegMatDev X, float* __restrict__ part, int M, int N,
+                                                           int K, int rows_per_split) {
+    using C = Cfg<BN>;
+    __shared__ float As[2][BK][C::LDA];
+    __shared__ float Bs[2][BK][C::LDB];
+    const int row_tiles = (N + BM - 1) / BM, col_tiles = (K + BN - 1) / BN;
+    const int tiles = row_tiles * col_tiles;
+    const int split = blockIdx.x / tiles;
+    const int t = blockIdx.x - split * tiles;
+    const int tr = t / col_tiles, tc = t - tr * col_tiles;
+    const int n0 = tr * BM, c0 = tc * BN;
+    const int m_begin = split * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
+
+    // A loader: As[kk][i] = dZ[m][n0+i], i = tid % 128, two reduction rows per pass
+    const int ai = tid & 127, ak0 = tid >> 7;
+    constexpr int NA = BK / 2;
+    const bool arow_ok = n0 + ai < N;
+    // B loader: Bs[kk][j] = X[m][c0+j]; the column (and therefore the segment) is fixed per thread
+    constexpr int RPP = 256 / BN;
+    constexpr int NB = BK / RPP;
+    const int bj = tid % BN, bk0 = tid / BN;
+    const int bcol = c0 + bj;
+    const bool bcol_ok = bcol < K;
+    SegDev sd = X.s[0];
+    if (bcol_ok) sd = X.s[find_seg(X, bcol)];
+    const float* bp = sd.ptr + sd.col0 + (bcol - sd.start);
+
+    float ra[NA], rb[NB];
+    float bias_acc = 0.f;
+    auto load_tile = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = mb + ak0 + 2 * i;
+            ra[i] = (arow_ok && m < m_end) ? dZ[(long long)m * lddz + n0 + ai] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int m = mb + bk0 + RPP * i;
+            float v = 0.f;
+            if (bcol_ok && m < m_end) {
+                const long long r = sd.gather ? X.idx[m] : (long long)m;
+                v = bp[r * sd.ld];
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            As[buf][ak0 + 2 * i][ai] = ra[i];
+            bias_acc += ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Bs[buf][bk0 + RPP * i][bj] = rb[i];
+    };
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = (m_end - m_begin + BK - 1) / BK;
+    if (KT > 0) {
+        load_tile(m_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tile(m_begin + (kt + 1) * BK);
+        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
+        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    const long long ldp = K + 1;
+    float* P = part + (long long)split * N * ldp;
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) {
+        const int col = c0 + wn_off + 32 * j + l31;
+        if (col >= K) continue;
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm_off + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < N) P[(long long)row * ldp + col] = acc[i][j][r];
+            }
+        }
+    }
+    if (tc == 0) {   // bias-gradient partial: two threads staged each dZ column
+        float* red = &As[0][0][0];
+        __syncthreads();
+        if (ak0 == 1) red[ai] = bias_acc;
+        __syncthreads();
+        if (ak0 == 0 && arow_ok) P[(long long)(n0 + ai) * ldp + K] = bias_acc + red[ai];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
+                                                           float* __restrict__ db, int N, int K, int splits) {
+    const long long ldp = K + 1;
+    const long long total = (long long)N * ldp;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += part[(long long)s * total + e];
+        const long long n = e / ldp;
+        const int c = (int)(e - n * ldp);
+        if (c < K) dW[n * K + c] = v;
+        else if (db) db[n] = v;
+    }
+}
+
+int to_dev(const DtcSegMat* h, SegMatDev& d, int expect_cols, bool is_output) {
+    DTC_REQUIRE(h != nullptr, "segmented matrix is null");
+    DTC_REQUIRE(h->nseg >= 1 && h->nseg <= 4, "nseg=%d out of range", h->nseg);
+    d.nseg = h->nseg;
+    d.idx = (const long long*)h->idx;
+    int start = 0;
+    for (int i = 0; i < 4; ++i) {
+        SegDev& s = d.s[i];
+        if (i < h->nseg) {
+            const DtcSeg& hs = h->seg[i];
+            DTC_REQUIRE(hs.width > 0 && hs.col0 >= 0, "segment %d: bad width/col0", i);
+            DTC_REQUIRE(is_output || hs.ptr != nullptr, "segment %d: null source", i);
+            DTC_REQUIRE(!hs.gather || h->idx != nullptr, "segment %d: gather without idx", i);
+            DTC_REQUIRE(!(is_output && hs.gather), "segment %d: gathered destination unsupported", i);
+            s.ptr = hs.ptr;
+            s.ld = hs.ld;
+            s.col0 = hs.col0;
+            s.start = start;
+            s.width = hs.width;
+            s.gather = hs.gather;
+            s.accumulate = hs.accumulate;
+            start += hs.width;
+        } else {
+            s = SegDev{nullptr, 0, 0, 0x7fffffff, 0, 0, 0};
+        }
+    }
+    d.cols = start;
+    DTC_REQUIRE(start == expect_cols, "segments cover %d columns, expected %d", start, expect_cols);
+    return DTC_OK;
+}
+
+// column-tile width: the widest tile whose padding waste is within 5% of the best
+int pick_bn(int cols) {
+    auto waste = [&](int bn) { return (double)(dtc::ceil_div(cols, bn) * bn - cols) / cols; };
+    if (cols <= 32) return 32;
+    if (cols <= 64) return 64;
+    const double w128 = waste(128), w64 = waste(64);
+    return (w128 <= w64 + 0.05) ? 128 : 64;
+}
+
+int wgrad_splits(int M, int N, int K) {
+    const int bn = pick_bn(K);
+    const int tiles = (int)(dtc::ceil_div(N, BM) * dtc::ceil_div(K, bn));
+    int s = (int)dtc::ceil_div(768, tiles);
+    const int max_s = (int)dtc::ceil_div(M, BK * 8);
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    return s;
+}
+
+}  // namespace
+
+extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, int M, int N,
+                              int K, int act, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
+    DTC_REQUIRE(W && Y, "null pointer");
+    DTC_REQUIRE(act >= 0 && act <= 2, "bad activation %d", act);
+    SegMatDev xd;
+    int rc = to_dev(X, xd, K, false);
+    if (rc != DTC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int bn = pick_bn(N);
+    const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, bn));
+    dtc::ProfScope prof("linear_fwd", 2.0 * M * (double)N * K, s);
+    if (bn == 128) hipLaunchKernelGGL(linear_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
+    else if (bn == 64) hipLaunchKernelGGL(linear_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
+    else hipLaunchKernelGGL(linear_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
+    return dtc::check_launch("linear_fwd");
+}
+
+extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved,
+                                int64_t ldxs, int M, int N, int K, int act, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
+    DTC_REQUIRE(dZ && W, "null pointer");
+    DTC_REQUIRE(act >= 0 && act <= 2, "bad activation %d", act);
+    DTC_REQUIRE(act == DTC_ACT_NONE || (Xsaved != nullptr && ldxs >= K), "activation derivative needs Xsaved");
+    DTC_REQUIRE(act == DTC_ACT_NONE || (dX && dX->nseg == 1), "activation derivative needs a single-segment destination");
+    SegMatDev xd;
+    int rc = to_dev(dX, xd, K, true);
+    if (rc != DTC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int bn = pick_bn(K);
+    const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K, bn));
+    dtc::ProfScope prof("linear_dgrad", 2.0 * M * (double)N * K, s);
+    if (bn == 128) hipLaunchKernelGGL(linear_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act);
+    else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act);
+    return dtc::check_launch("linear_dgrad");
+}
+
+extern "C" int64_t dtc_linear_wgrad_workspace(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return (int64_t)wgrad_splits(M, N, K) * N * (K + 1) * (int64_t)sizeof(float);
+}
+
+extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* X, float* dW, float* db, void* workspace,
+                                int M, int N, int K, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
+    DTC_REQUIRE(dZ && dW && workspace, "null pointer");
+    SegMatDev xd;
+    int rc = to_dev(X, xd, K, false);
+    if (rc != DTC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int bn = pick_bn(K);
+    const int splits = wgrad_splits(M, N, K);
+    int rows_per_split = (int)dtc::ceil_div(M, splits);
+    rows_per_split = (int)dtc::ceil_div(rows_per_split, BK) * BK;
+    const int tiles = (int)(dtc::ceil_div(N, BM) * dtc::ceil_div(K, bn));
+    float* part = (float*)workspace;
+    {
+        dtc::ProfScope prof("linear_wgrad", 2.0 * M * (double)N * K, s);
+        const int grid = tiles * splits;
+        if (bn == 128) hipLaunchKernelGGL(linear_wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split);
+        else if (bn == 64) hipLaunchKernelGGL(linear_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split);
+        else hipLaunchKernelGGL(linear_wgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split);
+    }
+    {
+        const long long total = (long long)N * (K + 1);
+        dtc::ProfScope prof("wgrad_reduce", (double)total * 4.0 * (splits + 1), s);
+        const int grid = (int)(dtc::ceil_div(total, 256) < 4096 ? dtc::ceil_div(total, 256) : 4096);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, part, dW, db, N, K, splits);
+    }
+    return dtc::check_launch("linear_wgrad");
+}

@@ -1,0 +1,268 @@
+// CE-net latent block for gfx950: outlier -> median replacement + reparameterisation, fwd and bwd.
+//
+// Reference: rsl_rl/rsl_rl/modules/actor_critic_decoder.py:274-302
+//     mean = lv.mean(); std = lv.std(); out = (lv < mean-2std) | (lv > mean+2std)
+//     lv[out] = lv[~out].median()            (lower median, batch-global)
+//     z = eps * exp(0.5*lv) + mu[:, 3:]
+// The torch version is ~10 passes over lv plus a sort-based median on ~4e5 values.  Here:
+//   stats (sum, sum^2 in fp64)  ->  3-level MSB radix select (11+11+10 bits) over the
+//   non-outliers with LDS histograms  ->  one apply pass that also writes z and the mask.
+// Every pass reads the 1.5 MB lv column block (L2 resident); 5 short launches in total.
+// mulv is the [B,35] output of the fused (latent_mu | latent_var) head: cols 0..18 mu, 19..34 lv.
+#include "common.hpp"
+
+namespace {
+
+constexpr int LAT = 16, MU = 19, LD = 35;
+constexpr int NB1 = 2048, NB2 = 2048, NB3 = 1024;
+constexpr int MAX_BLK = 256;
+
+struct Ws {
+    double part[MAX_BLK * 2];
+    float gpart[MAX_BLK];
+    unsigned hist1[NB1];
+    unsigned hist2[NB2];
+    unsigned hist3[NB3];
+};
+
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void lat_stats_kernel(const float* __restrict__ mulv, long long n, Ws* ws) {
+    __shared__ double sh[4];
+    double s = 0.0, q = 0.0;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const double x = (double)mulv[(e >> 4) * LD + MU + (e & 15)];
+        s += x;
+        q += x * x;
+    }
+    s = block_sum_d(s, sh);
+    q = block_sum_d(q, sh);
+    if (threadIdx.x == 0) {
+        ws->part[blockIdx.x * 2] = s;
+        ws->part[blockIdx.x * 2 + 1] = q;
+    }
+}
+
+// thresholds from the fp64 moments (every block recomputes them: nblk <= 256 partials)
+__device__ __forceinline__ void thresholds(const Ws* ws, int nblk, long long n, float& lo, float& hi, double* sh) {
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        s += ws->part[i * 2];
+        q += ws->part[i * 2 + 1];
+    }
+    s = block_sum_d(s, sh);
+    q = block_sum_d(q, sh);
+    const double mean = s / (double)n;
+    double var = (q - s * s / (double)n) / (double)(n - 1);
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, thr = 2.0f * (float)sqrt(var);
+    lo = meanf - thr;
+    hi = meanf + thr;
+}
+
+// Block-wide: find the bin holding 0-based rank k in hist[nbins] (nbins = 256*per).  Returns the
+// bin and the rank inside it; also the histogram total.  All threads get the result.
+__device__ void find_bin(const unsigned* __restrict__ hist, int nbins, unsigned long long k, bool k_is_median,
+                         unsigned& bin, unsigned long long& krem, unsigned long long& total, unsigned long long* sh) {
+    const int per = nbins / 256;
+    unsigned long long mine = 0;
+    for (int i = 0; i < per; ++i) mine += hist[threadIdx.x * per + i];
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    // inclusive scan (Hillis-Steele) over 256 entries
+    for (int off = 1; off < 256; off <<= 1) {
+        unsigned long long v = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    total = sh[255];
+    if (k_is_median) k = total > 0 ? (total - 1) / 2 : 0;
+    const unsigned long long incl = sh[threadIdx.x], excl = incl - mine;
+    __syncthreads();
+    if (k >= excl && k < incl) {
+        unsigned long long c = excl;
+        for (int i = 0; i < per; ++i) {
+            const unsigned h = hist[threadIdx.x * per + i];
+            if (k < c + h) {
+                sh[256] = threadIdx.x * per + i;
+                sh[257] = k - c;
+                break;
+            }
+            c += h;
+        }
+    }
+    __syncthreads();
+    bin = (unsigned)sh[256];
+    krem = sh[257];
+    __syncthreads();
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(256) void lat_hist_kernel(const float* __restrict__ mulv, long long n, int nblk_stats,
+                                                       Ws* ws) {
+    __shared__ double shd[4];
+    __shared__ unsigned long long shs[258];
+    __shared__ unsigned lh[2048];
+    float lo, hi;
+    thresholds(ws, nblk_stats, n, lo, hi, shd);
+    unsigned b1 = 0, b2 = 0;
+    unsigned long long krem = 0, total = 0;
+    if (LEVEL >= 2) find_bin(ws->hist1, NB1, 0, true, b1, krem, total, shs);
+    if (LEVEL >= 3) find_bin(ws->hist2, NB2, krem, false, b2, krem, total, shs);
+    constexpr int NB = LEVEL == 3 ? NB3 : 2048;
+    for (int i = threadIdx.x; i < NB; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const float x = mulv[(e >> 4) * LD + MU + (e & 15)];
+        if (x < lo || x > hi) continue;
+        const unsigned key = f2key(x);
+        if (LEVEL == 1) atomicAdd(&lh[key >> 21], 1u);
+        if (LEVEL == 2 && (key >> 21) == b1) atomicAdd(&lh[(key >> 10) & 2047u], 1u);
+        if (LEVEL == 3 && (key >> 21) == b1 && ((key >> 10) & 2047u) == b2) atomicAdd(&lh[key & 1023u], 1u);
+    }
+    __syncthreads();
+    unsigned* gh = LEVEL == 1 ? ws->hist1 : (LEVEL == 2 ? ws->hist2 : ws->hist3);
+    for (int i = threadIdx.x; i < NB; i += blockDim.x)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+__global__ __launch_bounds__(256) void lat_apply_kernel(float* __restrict__ mulv, const float* __restrict__ eps,
+                                                        float* __restrict__ z, uint8_t* __restrict__ mask,
+                                                        int* __restrict__ info, long long n, int nblk_stats, Ws* ws) {
+    __shared__ double shd[4];
+    __shared__ unsigned long long shs[258];
+    __shared__ int cnt[4];
+    float lo, hi;
+    thresholds(ws, nblk_stats, n, lo, hi, shd);
+    unsigned b1, b2, b3;
+    unsigned long long krem, total;
+    find_bin(ws->hist1, NB1, 0, true, b1, krem, total, shs);
+    find_bin(ws->hist2, NB2, krem, false, b2, krem, total, shs);
+    find_bin(ws->hist3, NB3, krem, false, b3, krem, total, shs);
+    const unsigned mkey = (b1 << 21) | (b2 << 10) | b3;
+    const float median = key2f(mkey);
+    int nout = 0;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const long long b = e >> 4;
+        const int j = (int)(e & 15);
+        float x = mulv[b * LD + MU + j];
+        const bool out = (x < lo) || (x > hi);
+        if (out) {
+            x = median;
+            mulv[b * LD + MU + j] = x;
+            ++nout;
+        } else if (f2key(x) == mkey) {
+            atomicMin(&info[1], (int)e);
+        }
+        mask[e] = out ? 1 : 0;
+        z[e] = eps[e] * expf(0.5f * x) + mulv[b * LD + 3 + j];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) nout += __shfl_xor(nout, off, 64);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = nout;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&info[0], cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+        if (blockIdx.x == 0) info[2] = (int)__float_as_uint(median);
+    }
+}
+
+__global__ __launch_bounds__(256) void lat_bwd_kernel(float* __restrict__ dmulv, const float* __restrict__ dz,
+                                                      const float* __restrict__ eps, const float* __restrict__ mulv,
+                                                      const uint8_t* __restrict__ mask, long long n, Ws* ws) {
+    __shared__ float shf[4];
+    float acc = 0.f;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const long long b = e >> 4;
+        const int j = (int)(e & 15);
+        const float g = dz[e];
+        dmulv[b * LD + 3 + j] += g;                                   // z = ... + mu[:, 3:]
+        const float lv = mulv[b * LD + MU + j];
+        float glv = dmulv[b * LD + MU + j] + g * eps[e] * (0.5f * expf(0.5f * lv));
+        if (mask[e]) {
+            acc += glv;
+            glv = 0.f;
+        }
+        dmulv[b * LD + MU + j] = glv;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) shf[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ws->gpart[blockIdx.x] = (shf[0] + shf[1]) + (shf[2] + shf[3]);
+}
+
+// gradient of the median: the summed gradient of all replaced entries flows to the median element
+__global__ void lat_bwd_fix_kernel(float* __restrict__ dmulv, const int* __restrict__ info, int nblk, const Ws* ws) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < nblk; ++i) t += ws->gpart[i];
+        const int e = info[1];
+        if (e != 0x7f7f7f7f && e >= 0) dmulv[(long long)(e >> 4) * LD + MU + (e & 15)] += t;
+    }
+}
+
+int grid_for(long long n) {
+    long long g = dtc::ceil_div(n, 1024);
+    return (int)(g < 1 ? 1 : (g > MAX_BLK ? MAX_BLK : g));
+}
+
+}  // namespace
+
+extern "C" int64_t dtc_cenet_workspace(int B) {
+    (void)B;
+    return (int64_t)sizeof(Ws);
+}
+
+extern "C" int dtc_cenet_latent_fwd(float* mulv, const float* eps, float* z, uint8_t* mask, int32_t* info,
+                                    void* workspace, int B, void* stream) {
+    DTC_REQUIRE(B > 0 && (long long)B * LAT >= 2, "bad batch %d", B);
+    DTC_REQUIRE(mulv && eps && z && mask && info && workspace, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    Ws* ws = (Ws*)workspace;
+    const long long n = (long long)B * LAT;
+    const int g = grid_for(n);
+    dtc::ProfScope prof("cenet_latent_fwd", (double)n * 4.0 * 6, s);
+    (void)hipMemsetAsync(ws->hist1, 0, sizeof(unsigned) * (NB1 + NB2 + NB3), s);
+    (void)hipMemsetAsync(info, 0, sizeof(int32_t) * 4, s);
+    (void)hipMemsetAsync(info + 1, 0x7f, sizeof(int32_t), s);
+    hipLaunchKernelGGL(lat_stats_kernel, dim3(g), dim3(256), 0, s, mulv, n, ws);
+    hipLaunchKernelGGL(lat_hist_kernel<1>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
+    hipLaunchKernelGGL(lat_hist_kernel<2>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
+    hipLaunchKernelGGL(lat_hist_kernel<3>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
+    hipLaunchKernelGGL(lat_apply_kernel, dim3(g), dim3(256), 0, s, mulv, eps, z, mask, info, n, g, ws);
+    return dtc::check_launch("cenet_latent_fwd");
+}
+
+extern "C" int dtc_cenet_latent_bwd(float* dmulv, const float* dz, const float* eps, const float* mulv,
+                                    const uint8_t* mask, const int32_t* info, void* workspace, int B, void* stream) {
+    DTC_REQUIRE(B > 0, "bad batch %d", B);
+    DTC_REQUIRE(dmulv && dz && eps && mulv && mask && info && workspace, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    Ws* ws = (Ws*)workspace;
+    const long long n = (long long)B * LAT;
+    const int g = grid_for(n);
+    dtc::ProfScope prof("cenet_latent_bwd", (double)n * 4.0 * 6, s);
+    hipLaunchKernelGGL(lat_bwd_kernel, dim3(g), dim3(256), 0, s, dmulv, dz, eps, mulv, mask, n, ws);
+    hipLaunchKernelGGL(lat_bwd_fix_kernel, dim3(1), dim3(64), 0, s, dmulv, info, g, ws);
+    return dtc::check_launch("cenet_latent_bwd");
+}

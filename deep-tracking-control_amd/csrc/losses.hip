@@ -1,0 +1,318 @@
+// Fused loss forward + gradient kernels for gfx950.
+//
+//  * dtc_vae_loss      rsl_rl/rsl_rl/algorithms/ppo.py:205-247  (recons / height / vel / KLD losses of
+//                      the CE-net VAE step; torch runs ~25 elementwise + reduction ops and autograd
+//                      re-reads every operand; here: one pass producing the 4 scalars and the three
+//                      gradient tensors, with the gathered targets read through the mini-batch index)
+//  * dtc_ppo_loss      ppo.py:288-327  (Normal log-prob, entropy, KL-adaptive learning rate, clipped
+//                      surrogate + clipped value loss) -> 4 scalars, dL/dmean, dL/dvalue, dL/dstd, and
+//                      the learning-rate decision taken ON DEVICE (the reference syncs the host here)
+//  * dtc_gaussian_act  ppo.py:141-148 (rollout side: sample, log-prob, mu, sigma)
+//
+// All reductions: per-block partials in fp64 + a single-block finalize (deterministic order).
+#include "common.hpp"
+
+namespace {
+
+constexpr int OBS = 53, HGT = 693, PRIV = 1389, LD = 35, LAT = 16;
+constexpr int MAX_BLK = 4096;
+constexpr int MAX_ACT = 32;
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    __syncthreads();
+    return t;
+}
+
+// ---------------------------------------------------------------------------------- VAE losses
+// block ranges: [0, nb_h) height, [nb_h, nb_h+nb_r) recons, rest latent rows
+__global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ recons, const float* __restrict__ hrecon,
+                                                       const float* __restrict__ mulv, const float* __restrict__ next_obs,
+                                                       const float* __restrict__ priv, const float* __restrict__ base_vel,
+                                                       const long long* __restrict__ idx, float* __restrict__ d_recons,
+                                                       float* __restrict__ d_hrecon, float* __restrict__ dmulv,
+                                                       double* __restrict__ part, int B, int nb_h, int nb_r) {
+    __shared__ double sh[4];
+    const int blk = blockIdx.x;
+    double acc0 = 0.0, acc1 = 0.0;
+    int slot0 = 3, slot1 = -1;
+    if (blk < nb_h) {
+        const long long total = (long long)B * HGT;
+        const float scale = 2.0f / ((float)HGT * (float)B);
+        for (long long e = (long long)blk * 256 + threadIdx.x; e < total; e += (long long)nb_h * 256) {
+            const long long b = e / HGT;
+            const int c = (int)(e - b * HGT);
+            const float diff = hrecon[e] - priv[idx[b] * PRIV + (HGT + 3) + c];
+            acc0 += (double)diff * (double)diff;
+            d_hrecon[e] = diff * scale;
+        }
+        slot0 = 3;
+    } else if (blk < nb_h + nb_r) {
+        const long long total = (long long)B * OBS;
+        const float scale = 2.0f / ((float)OBS * (float)B);
+        for (long long e = (long long)(blk - nb_h) * 256 + threadIdx.x; e < total; e += (long long)nb_r * 256) {
+            const long long b = e / OBS;
+            const int c = (int)(e - b * OBS);
+            const float diff = recons[e] - next_obs[idx[b] * OBS + c];
+            acc0 += (double)diff * (double)diff;
+            d_recons[e] = diff * scale;
+        }
+        slot0 = 0;
+    } else {
+        const int b = (blk - nb_h - nb_r) * 256 + threadIdx.x;
+        slot0 = 1;
+        slot1 = 2;
+        if (b < B) {
+            const float* m = mulv + (long long)b * LD;
+            float* g = dmulv + (long long)b * LD;
+            const float invB = 1.0f / (float)B;
+            const float vscale = 2.0f / (3.0f * (float)B);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float diff = m[j] - base_vel[idx[b] * 3 + j];
+                acc0 += (double)diff * (double)diff;
+                g[j] = diff * vscale;
+            }
+            float row = 0.f;
+#pragma unroll
+            for (int j = 0; j < LAT; ++j) {
+                const float mu = m[3 + j], lv = m[19 + j];
+                const float ex = expf(lv);
+                row += ((1.0f + lv) - mu * mu) - ex;
+                g[3 + j] = (4.0f * mu) * invB;                 // d(4*kld)/dmu
+                g[19 + j] = (-2.0f * (1.0f - ex)) * invB;      // d(4*kld)/dlv = 4 * -0.5 * (1 - e^lv) / B
+            }
+            acc1 = (double)(-0.5f * row);
+        }
+    }
+    acc0 = block_sum_d(acc0, sh);
+    if (slot1 >= 0) acc1 = block_sum_d(acc1, sh);
+    if (threadIdx.x == 0) {
+        double* p = part + (long long)blk * 4;
+        p[0] = p[1] = p[2] = p[3] = 0.0;
+        p[slot0] = acc0;
+        if (slot1 >= 0) p[slot1] = acc1;
+    }
+}
+
+__global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const double* __restrict__ part, int nblk, int B,
+                                                                float* __restrict__ losses) {
+    __shared__ double sh[4];
+    double a[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x)
+        for (int k = 0; k < 4; ++k) a[k] += part[(long long)i * 4 + k];
+    for (int k = 0; k < 4; ++k) a[k] = block_sum_d(a[k], sh);
+    if (threadIdx.x == 0) {
+        losses[0] = (float)(a[0] / ((double)OBS * B));   // recons
+        losses[1] = (float)(a[1] / (3.0 * B));           // vel
+        losses[2] = (float)(a[2] / (double)B);           // kld
+        losses[3] = (float)(a[3] / ((double)HGT * B));   // height
+    }
+}
+
+// ---------------------------------------------------------------------------------- PPO losses
+// per-block partial layout: [0] surrogate sum, [1] value-loss sum, [2] kl sum, [3 .. 3+A) dstd sums
+__global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__ mean, const float* __restrict__ stdp,
+                                                       const float* __restrict__ value, const float* __restrict__ actions,
+                                                       const float* __restrict__ old_logp, const float* __restrict__ old_mu,
+                                                       const float* __restrict__ old_sigma, const float* __restrict__ adv,
+                                                       const float* __restrict__ returns, const float* __restrict__ old_values,
+                                                       const long long* __restrict__ idx, DtcPpoCfg cfg,
+                                                       float* __restrict__ dmean, float* __restrict__ dvalue,
+                                                       double* __restrict__ part, int B, int A) {
+    __shared__ double sh[4];
+    __shared__ float sstd[MAX_ACT];
+    if (threadIdx.x < A) sstd[threadIdx.x] = stdp[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = b < B;
+    const float invB = 1.0f / (float)B;
+    double s_sur = 0.0, s_val = 0.0, s_kl = 0.0;
+    float dlogp_scale = 0.f;                 // dL/dlogp of this row
+    long long r = 0;
+    if (ok) {
+        r = idx ? idx[b] : (long long)b;
+        float logp = 0.f, kl = 0.f;
+        for (int j = 0; j < A; ++j) {
+            const float sg = sstd[j], mu = mean[(long long)b * A + j], a = actions[r * A + j];
+            const float d = a - mu;
+            logp += (-(d * d) / (2.0f * (sg * sg)) - logf(sg)) - 0.918938533204672742f;
+            const float so = old_sigma[r * A + j], mo = old_mu[r * A + j];
+            const float dm = mo - mu;
+            kl += (logf(sg / so + 1.e-5f) + (so * so + dm * dm) / (2.0f * (sg * sg))) - 0.5f;
+        }
+        s_kl = (double)kl;
+        const float ratio = expf(logp - old_logp[r]);
+        const float ad = adv[r];
+        const float lo = 1.0f - cfg.clip_param, hi = 1.0f + cfg.clip_param;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = -ad * ratio, s2 = -ad * rc;
+        s_sur = (double)fmaxf(s1, s2);
+        const bool inrange = ratio >= lo && ratio <= hi;
+        float w = 0.f;                                            // weight of the d(-A*ratio) path
+        if (s1 > s2) w = 1.0f;
+        else if (s1 == s2) w = inrange ? 1.0f : 0.5f;            // tie: half to each branch of max()
+        dlogp_scale = w * (-ad) * ratio * invB;
+        const float v = value[b], ret = returns[r];
+        float dv;
+        if (cfg.use_clipped_value_loss) {
+            const float tv = old_values[r];
+            const float dlt = v - tv;
+            const float vc = tv + fminf(fmaxf(dlt, -cfg.clip_param), cfg.clip_param);
+            const float e1 = v - ret, e2 = vc - ret;
+            const float l1 = e1 * e1, l2 = e2 * e2;
+            s_val = (double)fmaxf(l1, l2);
+            const bool clip_pass = dlt >= -cfg.clip_param && dlt <= cfg.clip_param;
+            const float g1 = 2.0f * e1, g2 = clip_pass ? 2.0f * e2 : 0.f;
+            dv = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * (g1 + g2));
+        } else {
+            const float e1 = ret - v;
+            s_val = (double)(e1 * e1);
+            dv = -2.0f * e1;
+        }
+        dvalue[b] = cfg.value_loss_coef * dv * invB;
+    }
+    double* p = part + (long long)blockIdx.x * (3 + MAX_ACT);
+    const double t_sur = block_sum_d(s_sur, sh), t_val = block_sum_d(s_val, sh), t_kl = block_sum_d(s_kl, sh);
+    if (threadIdx.x == 0) {
+        p[0] = t_sur;
+        p[1] = t_val;
+        p[2] = t_kl;
+    }
+    for (int j = 0; j < A; ++j) {
+        double ds = 0.0;
+        if (ok) {
+            const float sg = sstd[j], mu = mean[(long long)b * A + j], a = actions[r * A + j];
+            const float d = a - mu;
+            dmean[(long long)b * A + j] = dlogp_scale * (d / (sg * sg));
+            ds = (double)(dlogp_scale * ((d * d) / (sg * sg * sg) - 1.0f / sg));
+        }
+        ds = block_sum_d(ds, sh);
+        if (threadIdx.x == 0) p[3 + j] = ds;
+    }
+}
+
+__global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(const double* __restrict__ part, int nblk, int B, int A,
+                                                                const float* __restrict__ stdp, DtcPpoCfg cfg,
+                                                                float* __restrict__ dstd, float* __restrict__ losses,
+                                                                double* __restrict__ lr) {
+    __shared__ double sh[4];
+    const int stride = 3 + MAX_ACT;
+    for (int k = 0; k < 3 + A; ++k) {
+        double a = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += blockDim.x) a += part[(long long)i * stride + k];
+        a = block_sum_d(a, sh);
+        if (threadIdx.x == 0) {
+            if (k == 0) losses[0] = (float)(a / B);
+            else if (k == 1) losses[1] = (float)(a / B);
+            else if (k == 2) {
+                const float klm = (float)(a / B);
+                losses[3] = klm;
+                if (cfg.adaptive_schedule && lr) {
+                    double cur = *lr;
+                    if (klm > cfg.desired_kl * 2.0f) cur = fmax(1e-5, cur / 1.5);
+                    else if (klm < cfg.desired_kl / 2.0f && klm > 0.0f) cur = fmin(1e-2, cur * 1.5);
+                    *lr = cur;
+                }
+            } else {
+                const int j = k - 3;
+                dstd[j] = (float)a - cfg.entropy_coef / stdp[j];
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        float h = 0.f;
+        for (int j = 0; j < A; ++j) h += 1.418938533204672742f + logf(stdp[j]);   // 0.5 + 0.5*ln(2*pi) + ln(sigma)
+        losses[2] = h;
+    }
+}
+
+__global__ __launch_bounds__(256) void gaussian_act_kernel(const float* __restrict__ mean, const float* __restrict__ stdp,
+                                                           const float* __restrict__ noise, float* __restrict__ actions,
+                                                           float* __restrict__ logp, float* __restrict__ mu_out,
+                                                           float* __restrict__ sigma_out, int B, int A) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float lp = 0.f;
+    for (int j = 0; j < A; ++j) {
+        const long long o = (long long)b * A + j;
+        const float sg = stdp[j], mu = mean[o];
+        const float a = noise[o] * sg + mu;
+        const float d = a - mu;
+        lp += (-(d * d) / (2.0f * (sg * sg)) - logf(sg)) - 0.918938533204672742f;
+        actions[o] = a;
+        if (mu_out) mu_out[o] = mu;
+        if (sigma_out) sigma_out[o] = sg;
+    }
+    logp[b] = lp;
+}
+
+}  // namespace
+
+extern "C" int64_t dtc_loss_workspace(int B) {
+    (void)B;
+    return (int64_t)sizeof(double) * MAX_BLK * (3 + MAX_ACT);
+}
+
+extern "C" int dtc_vae_loss(const float* recons, const float* hrecon, const float* mulv, const float* next_obs,
+                            const float* priv, const float* base_vel, const int64_t* idx, float* d_recons,
+                            float* d_hrecon, float* dmulv, float* losses, void* workspace, int B, void* stream) {
+    DTC_REQUIRE(B > 0, "bad batch %d", B);
+    DTC_REQUIRE(recons && hrecon && mulv && next_obs && priv && base_vel && idx, "null input");
+    DTC_REQUIRE(d_recons && d_hrecon && dmulv && losses && workspace, "null output");
+    hipStream_t s = (hipStream_t)stream;
+    int nb_h = (int)dtc::ceil_div((long long)B * HGT, 256 * 8);
+    int nb_r = (int)dtc::ceil_div((long long)B * OBS, 256 * 8);
+    const int nb_l = (int)dtc::ceil_div(B, 256);
+    if (nb_h > 2048) nb_h = 2048;
+    if (nb_r > 512) nb_r = 512;
+    const int nblk = nb_h + nb_r + nb_l;
+    DTC_REQUIRE(nblk <= MAX_BLK, "batch too large for the loss workspace");
+    double* part = (double*)workspace;
+    dtc::ProfScope prof("vae_loss", (double)B * (HGT * 12.0 + OBS * 12.0 + LD * 8.0), s);
+    hipLaunchKernelGGL(vae_loss_kernel, dim3(nblk), dim3(256), 0, s, recons, hrecon, mulv, next_obs, priv, base_vel,
+                       (const long long*)idx, d_recons, d_hrecon, dmulv, part, B, nb_h, nb_r);
+    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, B, losses);
+    return dtc::check_launch("vae_loss");
+}
+
+extern "C" int dtc_ppo_loss(const float* mean, const float* std, const float* value, const float* actions,
+                            const float* old_logp, const float* old_mu, const float* old_sigma, const float* advantages,
+                            const float* returns, const float* old_values, const int64_t* idx, const DtcPpoCfg* cfg,
+                            float* dmean, float* dvalue, float* dstd, float* losses, double* lr, void* workspace, int B,
+                            int num_actions, void* stream) {
+    DTC_REQUIRE(B > 0 && num_actions > 0 && num_actions <= MAX_ACT, "bad shape B=%d A=%d", B, num_actions);
+    DTC_REQUIRE(mean && std && value && actions && old_logp && old_mu && old_sigma && advantages && returns && old_values,
+                "null input");
+    DTC_REQUIRE(cfg && dmean && dvalue && dstd && losses && workspace, "null output");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (int)dtc::ceil_div(B, 256);
+    DTC_REQUIRE(nblk <= MAX_BLK, "batch too large for the loss workspace");
+    double* part = (double*)workspace;
+    dtc::ProfScope prof("ppo_loss", (double)B * num_actions * 24.0, s);
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(256), 0, s, mean, std, value, actions, old_logp, old_mu,
+                       old_sigma, advantages, returns, old_values, (const long long*)idx, *cfg, dmean, dvalue, part, B,
+                       num_actions);
+    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, B, num_actions, std, *cfg, dstd,
+                       losses, lr);
+    return dtc::check_launch("ppo_loss");
+}
+
+extern "C" int dtc_gaussian_act(const float* mean, const float* std, const float* noise, float* actions, float* logp,
+                                float* mu_out, float* sigma_out, int B, int num_actions, void* stream) {
+    DTC_REQUIRE(B > 0 && num_actions > 0, "bad shape");
+    DTC_REQUIRE(mean && std && noise && actions && logp, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gaussian_act_kernel, dim3((unsigned)dtc::ceil_div(B, 256)), dim3(256), 0, s, mean, std, noise,
+                       actions, logp, mu_out, sigma_out, B, num_actions);
+    return dtc::check_launch("gaussian_act");
+}

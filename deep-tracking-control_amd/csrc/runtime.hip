@@ -1,0 +1,104 @@
+// Error reporting + per-launch HIP-event profiler of libdtc_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+thread_local char g_err[512] = "";
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+struct Rec {
+    const char* name;
+    double work;
+    hipEvent_t a, b;
+};
+std::vector<Rec> g_recs;
+}  // namespace
+
+namespace dtc {
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return DTC_ERR_LAUNCH;
+    }
+    return DTC_OK;
+}
+
+ProfScope::ProfScope(const char* name, double work, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    Rec r{name, work, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    g_recs.push_back(r);
+    slot = (int)g_recs.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_recs[slot].b, stream);
+}
+
+}  // namespace dtc
+
+extern "C" {
+
+int dtc_version(void) { return 1; }
+const char* dtc_last_error(void) { return g_err; }
+
+void dtc_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+}
+
+void dtc_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+}
+
+int dtc_prof_report(DtcProfRec* out, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::map<std::string, DtcProfRec> agg;
+    for (auto& r : g_recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        DtcProfRec& d = agg[r.name];
+        if (d.launches == 0) {
+            memset(&d, 0, sizeof(d));
+            strncpy(d.name, r.name, sizeof(d.name) - 1);
+        }
+        d.ms_total += ms;
+        d.work += r.work;
+        d.launches += 1;
+    }
+    int n = 0;
+    for (auto& kv : agg) {
+        if (n < cap && out) out[n] = kv.second;
+        ++n;
+    }
+    return n;
+}
+
+}  // extern "C"

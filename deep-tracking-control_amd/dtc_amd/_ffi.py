@@ -1,0 +1,173 @@
+"""ctypes binding of libdtc_hip.so (the C ABI declared in include/dtc_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised.
+The library is built in-tree by `deep-tracking-control_amd/build.py` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdtc_hip.so")
+
+c_f32p, c_i64p, c_u8p, c_f64p, c_i32p, c_i16p = (C.c_void_p,) * 6   # device pointers travel as integers
+c_stream = C.c_void_p
+
+
+class DtcError(RuntimeError):
+    pass
+
+
+class DtcGridCfg(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("t_stance", C.c_float), ("fdbk_gain", C.c_float),
+                ("x", C.c_float * 64), ("y", C.c_float * 32)]
+
+
+class DtcSeg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int64), ("col0", C.c_int32), ("width", C.c_int32),
+                ("gather", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class DtcSegMat(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("cols", C.c_int32), ("idx", C.c_void_p), ("seg", DtcSeg * 4)]
+
+
+class DtcPpoCfg(C.Structure):
+    _fields_ = [("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float),
+                ("desired_kl", C.c_float), ("use_clipped_value_loss", C.c_int32),
+                ("adaptive_schedule", C.c_int32)]
+
+
+class DtcProfRec(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("ms_total", C.c_double), ("work", C.c_double),
+                ("launches", C.c_int64)]
+
+
+ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
+
+_SIGS = {
+    "dtc_version": (C.c_int, []),
+    "dtc_last_error": (C.c_char_p, []),
+    "dtc_foothold_plan": (C.c_int, [c_f32p] * 4 + [C.POINTER(DtcGridCfg), c_i64p] + [c_f32p] * 5 +
+                          [c_i64p, c_f32p, c_f32p, C.c_int, c_stream]),
+    "dtc_get_heights": (C.c_int, [c_i16p, C.c_int, C.c_int, c_f32p, C.POINTER(DtcGridCfg), C.c_float, C.c_float,
+                                  C.c_float, c_f32p, C.c_int, c_stream]),
+    "dtc_gae": (C.c_int, [c_f32p, c_f32p, c_u8p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_f64p, C.c_int,
+                          C.c_int, c_stream]),
+    "dtc_adv_sqdev": (C.c_int, [c_f32p, c_f64p, C.c_int64, C.c_double, c_stream]),
+    "dtc_adv_normalize": (C.c_int, [c_f32p, c_f64p, C.c_int64, C.c_double, c_stream]),
+    "dtc_gather_rows": (C.c_int, [C.c_void_p, c_i64p, C.c_void_p, C.c_int64, C.c_int64, c_stream]),
+    "dtc_linear_fwd": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, c_stream]),
+    "dtc_linear_dgrad": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_linear_wgrad_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "dtc_linear_wgrad": (C.c_int, [c_f32p, C.c_int64, C.POINTER(DtcSegMat), c_f32p, c_f32p, C.c_void_p, C.c_int,
+                                   C.c_int, C.c_int, c_stream]),
+    "dtc_cenet_workspace": (C.c_int64, [C.c_int]),
+    "dtc_cenet_latent_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int, c_stream]),
+    "dtc_cenet_latent_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int,
+                                       c_stream]),
+    "dtc_loss_workspace": (C.c_int64, [C.c_int]),
+    "dtc_vae_loss": (C.c_int, [c_f32p] * 6 + [c_i64p] + [c_f32p] * 4 + [C.c_void_p, C.c_int, c_stream]),
+    "dtc_ppo_loss": (C.c_int, [c_f32p] * 10 + [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 4 +
+                     [c_f64p, C.c_void_p, C.c_int, C.c_int, c_stream]),
+    "dtc_gaussian_act": (C.c_int, [c_f32p] * 7 + [C.c_int, C.c_int, c_stream]),
+    "dtc_adam_workspace": (C.c_int64, [C.c_int64]),
+    "dtc_clip_adam": (C.c_int, [c_f32p] * 4 + [C.c_int64, C.c_float, c_f64p, C.c_double, C.c_double, C.c_double,
+                                               C.c_int64, c_f32p, C.c_void_p, c_stream]),
+    "dtc_gru_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "dtc_gru_fwd": (C.c_int, [c_f32p] * 7 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_gru_bwd": (C.c_int, [c_f32p] * 10 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_prof_enable": (None, [C.c_int]),
+    "dtc_prof_reset": (None, []),
+    "dtc_prof_report": (C.c_int, [C.POINTER(DtcProfRec), C.c_int]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the shared library once; raise loudly if it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DtcError(f"{LIB_PATH} not found: run `python deep-tracking-control_amd/build.py` "
+                           "(the HIP library is mandatory; there is no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        missing = [name for name in _SIGS if not hasattr(_lib, name)]
+        if missing:
+            raise DtcError(f"{LIB_PATH} lacks symbols declared in include/dtc_hip.h: {missing}")
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGS)
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise DtcError(f"{what} failed (rc={rc}): {lib().dtc_last_error().decode()}")
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    """Device pointer of a CUDA/HIP tensor (None passes NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DtcError("dtc_amd kernels need device tensors (got a CPU tensor)")
+    return t.data_ptr()
+
+
+def cptr(t: torch.Tensor | None, dtype=None) -> int | None:
+    """Like ptr() but insists on a contiguous tensor (and optionally a dtype)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise DtcError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise DtcError(f"expected {dtype}, got {t.dtype}")
+    return ptr(t)
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def seg(t: torch.Tensor | None, col0: int, width: int, gather: bool = False, accumulate: bool = False,
+        ld: int | None = None) -> DtcSeg:
+    """Column block [col0, col0+width) of a 2-D row-major tensor `t` (row stride = t.stride(0))."""
+    s = DtcSeg()
+    if t is None:
+        s.ptr, s.ld = None, 0
+    else:
+        assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32
+        s.ptr, s.ld = ptr(t), (t.stride(0) if ld is None else ld)
+    s.col0, s.width, s.gather, s.accumulate = col0, width, int(gather), int(accumulate)
+    return s
+
+
+def segmat(segs, idx: torch.Tensor | None = None) -> DtcSegMat:
+    m = DtcSegMat()
+    assert 1 <= len(segs) <= 4
+    m.nseg = len(segs)
+    m.cols = sum(s.width for s in segs)
+    m.idx = cptr(idx, torch.int64) if idx is not None else None
+    for i, s in enumerate(segs):
+        m.seg[i] = s
+    return m
+
+
+def prof_report():
+    n = lib().dtc_prof_report(None, 0)
+    arr = (DtcProfRec * max(n, 1))()
+    n = lib().dtc_prof_report(arr, n)
+    return [dict(name=arr[i].name.decode(), ms_total=arr[i].ms_total, work=arr[i].work,
+                 launches=arr[i].launches) for i in range(n)]

@@ -1,0 +1,184 @@
+/* dtc_hip.h -- C ABI of libdtc_hip.so, the MI355X (gfx950) hot path of Deep-Tracking-Control.
+ *
+ * The reference has no FFI: its hot path is Python calling torch.  Each entry
+ * point below replaces the torch op sequence of the cited reference lines; the Python classes
+ * in deep-tracking-control_amd/dtc_amd keep the reference's signatures and call these through
+ * ctypes with `tensor.data_ptr()` (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is documented as host;
+ *   - the caller owns all buffers; nothing is retained after return;
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); calls are
+ *     asynchronous on it and never synchronise the host;
+ *   - return 0 on success, a negative DTC_ERR_* otherwise (bad argument / launch failure);
+ *     no exception crosses the boundary;
+ *   - all matrices are row-major fp32; `ld*` are leading dimensions in elements.
+ */
+#ifndef DTC_HIP_H
+#define DTC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTC_OK 0
+#define DTC_ERR_ARG (-1)      /* null pointer / bad shape / unsupported size            */
+#define DTC_ERR_LAUNCH (-2)   /* hipGetLastError() != hipSuccess after a launch           */
+#define DTC_ERR_ALIGN (-3)    /* a pointer that must be 16-byte aligned is not            */
+
+#define DTC_ACT_NONE 0
+#define DTC_ACT_RELU 1
+#define DTC_ACT_ELU 2
+
+/* library / device info ------------------------------------------------------------------ */
+int dtc_version(void);                       /* ABI version, bumped on signature changes  */
+const char* dtc_last_error(void);            /* host string describing the last failure   */
+
+/* ---- foothold planner: legged_gym/envs/base/legged_robot_dtc.py:98-201 ----------------- */
+typedef struct DtcGridCfg {
+    int nx, ny;            /* 33, 21: cfg.terrain.measured_points_{x,y} (lite3_dtc_config.py:32-36) */
+    float t_stance;        /* cfg.sim.dt * cfg.control.decimation = 0.02 (legged_robot_dtc.py:106)  */
+    float fdbk_gain;       /* 0.03 (legged_robot_dtc.py:107)                                        */
+    float x[64];           /* host copies of the grid coordinates                                   */
+    float y[32];
+} DtcGridCfg;
+
+/* One call = lines :98-201 for N envs.  idx is the reference's optimal_foothold_indice [N,1,4]
+ * (int64).  Optional outputs may be NULL: score [N,P,4] (self.foothold_score),
+ * nominal_idx [N,4] int64, slope [N,nx,ny], heights_world [N,P,3].  cfg is a HOST pointer. */
+int dtc_foothold_plan(const float* measured_heights /*[N,P]*/, const float* root_states /*[N,13]*/,
+                      const float* thigh_pos /*[N,4,3]*/, const float* commands /*[N,4]*/,
+                      const DtcGridCfg* cfg, int64_t* idx /*[N,4]*/, float* foothold_obs /*[N,8]*/,
+                      float* opt_world /*[N,4,3]*/, float* pred /*[N,4,3]*/, float* pred_to_robot /*[N,4,3]*/,
+                      float* score_or_null, int64_t* nominal_idx_or_null, float* slope_or_null,
+                      float* heights_world_or_null, int N, void* stream);
+
+/* LeggedRobot._get_heights: legged_gym/envs/base/legged_robot.py:1279-1317 (row f1). */
+int dtc_get_heights(const int16_t* height_samples /*[rows,cols]*/, int rows, int cols,
+                    const float* root_states /*[N,13]*/, const DtcGridCfg* cfg, float border_size,
+                    float horizontal_scale, float vertical_scale, float* measured_heights /*[N,P]*/,
+                    int N, void* stream);
+
+/* ---- RolloutStorage.compute_returns: rsl_rl/rsl_rl/storage/rollout_storage.py:138-152 --- */
+/* GAE scan; writes returns and the UN-normalised advantages (returns - values) and
+ * stats[0] = sum(advantages) (double).  stats is double[4] on the device. */
+int dtc_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values,
+            float gamma, float lam, float* returns, float* advantages, double* stats, int T, int N,
+            void* stream);
+/* stats[1] = sum((adv - stats[0]/count)^2).  `count` is the GLOBAL sample count (data-parallel
+ * callers all-reduce stats[0] first and pass world_size*T*N). */
+int dtc_adv_sqdev(const float* advantages, double* stats, int64_t n_local, double count, void* stream);
+/* adv = (adv - mean) / (std_unbiased + 1e-8) with mean = stats[0]/count, std from stats[1]. */
+int dtc_adv_normalize(float* advantages, const double* stats, int64_t n_local, double count, void* stream);
+
+/* ---- mini-batch gather: rollout_storage.py:195-209 (`tensor[batch_idx]`) ------------------ */
+int dtc_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t rows, int64_t row_bytes,
+                    void* stream);
+
+/* ---- dense layers (nn.Linear + ReLU/ELU and their autograd; actor_critic_decoder.py:98-188,
+ *      323-349).  A "segmented matrix" is the virtual concatenation torch.cat([...], dim=1) of
+ *      up to 4 column blocks, each optionally row-gathered by the mini-batch index
+ *      (ppo.py:201, actor_critic_decoder.py:431,550; rollout_storage.py:195-209) -- the cat and
+ *      the gather are never materialised. ------------------------------------------------- */
+typedef struct DtcSeg {
+    float* ptr;          /* base of the source matrix (NULL = segment absent for outputs)       */
+    int64_t ld;          /* leading dimension of the source matrix                              */
+    int32_t col0;        /* first column inside the source matrix                               */
+    int32_t width;       /* number of columns of this block                                     */
+    int32_t gather;      /* 1: row m of the virtual matrix is row idx[m] of the source          */
+    int32_t accumulate;  /* outputs only: 1 = add into the destination instead of overwriting   */
+} DtcSeg;
+
+typedef struct DtcSegMat {
+    int32_t nseg;        /* 1..4                                                                */
+    int32_t cols;        /* sum of widths                                                       */
+    const int64_t* idx;  /* mini-batch row indices for gathered segments (may be NULL)          */
+    DtcSeg seg[4];
+} DtcSegMat;
+
+/* Y[M,N] = act(X[M,K] W[N,K]^T + b).  X is segmented (host struct). */
+int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy,
+                   int M, int N, int K, int act, void* stream);
+/* dX[M,K] = (dZ[M,N] W[N,K]) * act'(Xsaved), written through the segmented destination dX
+ * (segments with ptr == NULL are skipped).  Xsaved (post-activation output of the previous
+ * layer, leading dimension ldxs) may be NULL when act == DTC_ACT_NONE. */
+int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX,
+                     const float* Xsaved, int64_t ldxs, int M, int N, int K, int act, void* stream);
+/* dW[N,K] = dZ^T X, db[N] = column sums of dZ.  workspace: >= dtc_linear_wgrad_workspace() bytes. */
+int64_t dtc_linear_wgrad_workspace(int M, int N, int K);
+int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* X, float* dW, float* db,
+                     void* workspace, int M, int N, int K, void* stream);
+
+/* ---- CE-net latent: actor_critic_decoder.py:274-302 ---------------------------------------- */
+/* mulv [B,35] = [latent_mu(19) | latent_var(16)].  In place: outlier -> lower median of the
+ * non-outliers (2-sigma rule on the batch statistics), then z = eps*exp(0.5*lv) + mu[:,3:].
+ * mask [B,16] uint8 receives the outlier mask, info (int32[4]) {n_outliers, median_flat_index,
+ * median bits, 0}.  workspace >= dtc_cenet_workspace() bytes. */
+int64_t dtc_cenet_workspace(int B);
+int dtc_cenet_latent_fwd(float* mulv, const float* eps, float* z, uint8_t* mask, int32_t* info,
+                         void* workspace, int B, void* stream);
+/* backward of the above: dmulv [B,35] holds the direct gradients w.r.t. (mu, lv_fixed) on entry
+ * and the gradients w.r.t. the raw head outputs on exit. */
+int dtc_cenet_latent_bwd(float* dmulv, const float* dz, const float* eps, const float* mulv,
+                         const uint8_t* mask, const int32_t* info, void* workspace, int B, void* stream);
+
+/* ---- losses (fused forward + gradient) ------------------------------------------------------ */
+/* VAE losses of ppo.py:205-247.  Gathered operands are read as src[idx[b]].  Outputs:
+ * d_recons [B,53], d_hrecon [B,693], dmulv [B,35] (vel + 4*kld parts) and
+ * losses[0..3] = {recons, vel, kld, height} (float, device). */
+int dtc_vae_loss(const float* recons, const float* hrecon, const float* mulv, const float* next_obs,
+                 const float* priv, const float* base_vel, const int64_t* idx, float* d_recons,
+                 float* d_hrecon, float* dmulv, float* losses, void* workspace, int B, void* stream);
+int64_t dtc_loss_workspace(int B);
+
+typedef struct DtcPpoCfg {
+    float clip_param, value_loss_coef, entropy_coef, desired_kl;
+    int32_t use_clipped_value_loss, adaptive_schedule;
+} DtcPpoCfg;
+/* PPO losses + KL-adaptive learning rate of ppo.py:288-327.  mean [B,12], std [12], value [B].
+ * Outputs: dmean [B,12], dvalue [B], dstd [12], losses[0..3] = {surrogate, value, entropy, kl_mean},
+ * lr (double, device; read-modify-write exactly as ppo.py:301-307). */
+int dtc_ppo_loss(const float* mean, const float* std, const float* value, const float* actions,
+                 const float* old_logp, const float* old_mu, const float* old_sigma, const float* advantages,
+                 const float* returns, const float* old_values, const int64_t* idx, const DtcPpoCfg* cfg,
+                 float* dmean, float* dvalue, float* dstd, float* losses, double* lr, void* workspace,
+                 int B, int num_actions, void* stream);
+/* log-prob / sampling side of PPO.act (ppo.py:137-150): actions = mean + std*noise,
+ * logp = sum_j log N(a; mean, std). */
+int dtc_gaussian_act(const float* mean, const float* std, const float* noise, float* actions,
+                     float* logp, float* mu_out, float* sigma_out, int B, int num_actions, void* stream);
+
+/* ---- clip_grad_norm_ + Adam over one flat parameter range (ppo.py:253-254, 334-335) --------- */
+/* gnorm_out (float, device) receives the pre-clip global L2 norm.  lr is a device double;
+ * step is the 1-based Adam step count of this range. */
+int dtc_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float max_grad_norm, const double* lr, double beta1, double beta2, double eps, int64_t step,
+                  float* gnorm_out, void* workspace, void* stream);
+int64_t dtc_adam_workspace(int64_t n);
+
+/* ---- GRU (torch.nn.GRU, 1 layer; actor_critic_recurrent.py:92-116) -------------------------- */
+/* gi [T,R,3H] = x W_ih^T + b_ih is computed by dtc_linear_fwd; this runs the recurrence
+ * h_t = GRU(gi_t, h_{t-1}) for t < T, writing hs [T,R,H] and the gate activations needed by
+ * the backward pass (gates [T,R,3H] = r, z, n; hn [T,R,H] = W_hn h + b_hn). */
+int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, const float* b_hh, float* hs,
+                float* gates, float* hn, void* workspace, int T, int R, int H, void* stream);
+/* BPTT: dhs [T,R,H] are the gradients w.r.t. the outputs; produces dgi [T,R,3H] (gradient w.r.t.
+ * gi, fed to dtc_linear_wgrad/dgrad for W_ih), dW_hh [3H,H], db_hh [3H] and dh0 [R,H]. */
+int dtc_gru_bwd(const float* dhs, const float* hs, const float* h0, const float* gates, const float* hn,
+                const float* W_hh, float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace,
+                int T, int R, int H, void* stream);
+int64_t dtc_gru_workspace(int T, int R, int H);
+
+/* ---- per-kernel timing (HIP events on `stream`) used by bench.py's roofline object ---------- */
+void dtc_prof_enable(int on);
+/* Fills up to `cap` records; returns the number of distinct kernel classes seen. */
+typedef struct DtcProfRec { char name[48]; double ms_total; double work; int64_t launches; } DtcProfRec;
+int dtc_prof_report(DtcProfRec* out, int cap);
+void dtc_prof_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTC_HIP_H */

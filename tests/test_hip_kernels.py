@@ -1,0 +1,305 @@
+"""HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from dtc_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------ scorer
+def _scorer_case(inp, debug=True):
+    from dtc_amd import foothold
+    from oracle import foothold as OF
+    o = OF.plan(_np(inp["measured_heights"]), _np(inp["root_states"]), _np(inp["thigh_pos"]), _np(inp["commands"]),
+                S.MEASURED_POINTS_X, S.MEASURED_POINTS_Y, want_debug=debug)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    h = foothold.plan(d["measured_heights"], d["root_states"], d["thigh_pos"], d["commands"], want_debug=debug)
+    torch.cuda.synchronize()
+    return o, h
+
+
+def _assert_scorer_equal(o, h, debug=True):
+    np.testing.assert_array_equal(_np(h["optimal_foothold_indice"]).squeeze(1), o["idx"])
+    np.testing.assert_array_equal(_np(h["foothold_obs"]), o["foothold_obs"])
+    np.testing.assert_array_equal(_np(h["optimal_footholds_world"]), o["optimal_footholds_world"])
+    np.testing.assert_array_equal(_np(h["pred_footholds"]), o["pred_footholds"])
+    np.testing.assert_array_equal(_np(h["pred_footholds_to_robot"]), o["pred_footholds_to_robot"])
+    if debug:
+        np.testing.assert_array_equal(_np(h["foothold_score"]), o["foothold_score"])
+        np.testing.assert_array_equal(_np(h["slope"]), o["slope"])
+        np.testing.assert_array_equal(_np(h["nominal_footholds_indice"]), o["nominal_idx"])
+        np.testing.assert_array_equal(_np(h["heights_world"])[:, :, :2], o["heights_world_xy"])
+
+
+@pytest.mark.parametrize("N", [1, 3, 4, 5, 257, 4096])
+def test_scorer_bit_exact_vs_oracle(N):
+    o, h = _scorer_case(S.scorer_inputs(N, seed=7 + N))
+    _assert_scorer_equal(o, h)
+
+
+def test_scorer_edge_cases_bit_exact():
+    from test_oracle_golden import scorer_edge_inputs
+    o, h = _scorer_case(scorer_edge_inputs())
+    _assert_scorer_equal(o, h)
+    assert (_np(h["optimal_foothold_indice"])[0:8] == 0).all()
+
+
+def test_scorer_matches_reference_golden(golden):
+    """HIP path against the fixture captured from the reference itself (knife-edge policy)."""
+    from dtc_amd import foothold
+    g = golden("scorer")
+    inp = {k: v.to(DEV) for k, v in S.scorer_inputs(8192, seed=7).items()}
+    h = foothold.plan(inp["measured_heights"], inp["root_states"], inp["thigh_pos"], inp["commands"])
+    idx = _np(h["optimal_foothold_indice"]).squeeze(1)
+    ref = g["main_idx"].astype(np.int64)
+    for e, l in np.argwhere(idx != ref):
+        assert g["main_gap"][e, l] <= 1e-5
+    np.testing.assert_allclose(_np(h["pred_footholds"])[::4], g["main_pred"], rtol=0, atol=4e-6)
+
+
+def test_scorer_unaligned_pointer_and_large():
+    """A view that is not 16-byte aligned takes the scalar-load path; 98304 maps = 24 recorded steps."""
+    from dtc_amd import foothold
+    from oracle import foothold as OF
+    inp = S.scorer_inputs(1024, seed=3)
+    buf = torch.empty(1024 * 693 + 1, device=DEV)
+    mh = buf[1:].view(1024, 693)
+    mh.copy_(inp["measured_heights"])
+    assert mh.data_ptr() % 16 != 0
+    h = foothold.plan(mh, inp["root_states"].to(DEV), inp["thigh_pos"].to(DEV), inp["commands"].to(DEV))
+    o = OF.plan(_np(inp["measured_heights"]), _np(inp["root_states"]), _np(inp["thigh_pos"]), _np(inp["commands"]),
+                S.MEASURED_POINTS_X, S.MEASURED_POINTS_Y)
+    np.testing.assert_array_equal(_np(h["optimal_foothold_indice"]).squeeze(1), o["idx"])
+    # full bench size: property check (index decodes to the returned world position; idempotent)
+    big = {k: v.to(DEV) for k, v in S.scorer_inputs(98304, seed=5).items()}
+    h1 = foothold.plan(big["measured_heights"], big["root_states"], big["thigh_pos"], big["commands"])
+    h2 = foothold.plan(big["measured_heights"], big["root_states"], big["thigh_pos"], big["commands"])
+    assert torch.equal(h1["optimal_foothold_indice"], h2["optimal_foothold_indice"])
+    idx = h1["optimal_foothold_indice"].squeeze(1)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 693
+    z = torch.gather(big["measured_heights"], 1, idx)
+    assert torch.equal(z, h1["optimal_footholds_world"][:, :, 2])
+
+
+def test_get_heights_bit_exact():
+    from dtc_amd import foothold
+    from oracle import heights as OH
+    gen = torch.Generator().manual_seed(31)
+    coarse = torch.randint(-60, 120, (1760 // 16, 1120 // 16), generator=gen)
+    tab = coarse.repeat_interleave(16, 0).repeat_interleave(16, 1)
+    tab = (tab + torch.randint(-2, 3, (1760, 1120), generator=gen)).to(torch.int16)
+    inp = S.scorer_inputs(2048, seed=9)
+    root = inp["root_states"]
+    root[:8, 0] = torch.tensor([-30., -19.99, 0., 67.9, 68.0, 100., 20., 20.])
+    root[:8, 1] = torch.tensor([-30., 0., -19.99, 35.9, 36.0, 100., -25., 40.])
+    ref = OH.get_heights(tab.numpy(), root.numpy(), S.MEASURED_POINTS_X, S.MEASURED_POINTS_Y)
+    got = foothold.get_heights(tab.to(DEV), root.to(DEV))
+    np.testing.assert_array_equal(_np(got), ref)
+
+
+# ------------------------------------------------------------------------------ GAE / gather
+@pytest.mark.parametrize("N", [1, 64, 1000, 4096])
+def test_gae_vs_oracle(N):
+    from dtc_amd import ops
+    from oracle import gae as OG
+    d = S.rollout(N, 24, seed=4)
+    d["last_values"] = torch.linspace(-1, 1, N).unsqueeze(1)
+    d["dones"][0, : max(1, N // 8)] = 1
+    d["dones"][23, : max(1, N // 4)] = 1
+    sq = lambda k: _np(d[k].squeeze(-1))
+    ret, adv = OG.compute_returns(sq("rewards"), sq("values"), sq("dones"), sq("last_values"))
+    g = {k: d[k].to(DEV).contiguous() for k in ("rewards", "values", "dones", "last_values")}
+    returns = torch.empty(24, N, 1, device=DEV)
+    advantages = torch.empty(24, N, 1, device=DEV)
+    stats = torch.zeros(4, dtype=torch.float64, device=DEV)
+    ops.gae(g["rewards"], g["values"], g["dones"], g["last_values"], 0.99, 0.95, returns, advantages, stats)
+    np.testing.assert_array_equal(_np(returns).squeeze(-1), ret)            # scan: bit exact
+    raw = _np(advantages).squeeze(-1).copy()
+    np.testing.assert_array_equal(raw, (ret - sq("values")).astype(np.float32))
+    if N > 1:
+        ops.adv_sqdev(advantages, stats, 24 * N)
+        ops.adv_normalize(advantages, stats, 24 * N)
+        np.testing.assert_allclose(_np(advantages).squeeze(-1), adv, rtol=2e-6, atol=2e-6)
+        st = _np(stats)
+        assert abs(st[0] - raw.astype(np.float64).sum()) <= 1e-9 * np.abs(raw).sum() + 1e-12
+
+
+@pytest.mark.parametrize("shape,dtype", [((1000, 1389), torch.float32), ((1000, 53), torch.float32),
+                                         ((1000, 12), torch.float32), ((1000, 1), torch.uint8),
+                                         ((1000, 3), torch.float32), ((777, 265), torch.float32)])
+def test_gather_rows(shape, dtype):
+    from dtc_amd import ops
+    g = torch.Generator().manual_seed(1)
+    src = (torch.randn(shape, generator=g) * 50).to(dtype).to(DEV)
+    idx = torch.randperm(shape[0], generator=g)[: shape[0] // 2].to(DEV)
+    out = ops.gather_rows(src, idx)
+    assert torch.equal(out, src[idx])
+    empty = ops.gather_rows(src, idx[:0])
+    assert empty.shape[0] == 0
+
+
+# ------------------------------------------------------------------------------ dense layers
+def _ref_act(z, act):
+    if act == "relu":
+        return torch.relu(z)
+    if act == "elu":
+        return torch.nn.functional.elu(z)
+    return z
+
+
+@pytest.mark.parametrize("M,N,K,act", [(384, 512, 693, "relu"), (384, 512, 512, "elu"), (300, 64, 128, "relu"),
+                                       (129, 35, 64, None), (384, 53, 128, None), (257, 12, 128, None),
+                                       (384, 1, 128, None), (128, 693, 512, None), (1000, 256, 512, "elu"),
+                                       (64, 128, 265, "relu")])
+def test_linear_fwd_plain(M, N, K, act):
+    from dtc_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = _ref_act(X.double() @ W.double().t() + b.double(), act)
+    Y = torch.full((M, N), float("nan"), device=DEV)
+    ops.linear_fwd(X.to(DEV), W.to(DEV), b.to(DEV), Y, act)
+    np.testing.assert_allclose(_np(Y), ref.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_linear_fwd_detects_transposed_output():
+    """A = I with an asymmetric W: catches a row/col swap in the MFMA C/D mapping."""
+    from dtc_amd import ops
+    K = 128
+    X = torch.eye(K)
+    W = torch.arange(K * K, dtype=torch.float32).view(K, K) / 100.0        # W[n,k] asymmetric
+    Y = torch.zeros(K, K, device=DEV)
+    ops.linear_fwd(X.to(DEV), W.to(DEV), None, Y, None)
+    np.testing.assert_array_equal(_np(Y), W.t().numpy())
+
+
+def test_linear_fwd_segments_and_gather():
+    """actor input = cat[obs[idx], z, mu[:, :3], l_t]  (actor_critic_decoder.py:431)."""
+    from dtc_amd import _ffi, ops
+    g = torch.Generator().manual_seed(5)
+    R, B = 2000, 384
+    obs_all = torch.randn(R, 53, generator=g)
+    idx = torch.randperm(R, generator=g)[:B]
+    z = torch.randn(B, 16, generator=g)
+    mulv = torch.randn(B, 35, generator=g)
+    l_t = torch.randn(B, 512, generator=g)
+    W = torch.randn(512, 584, generator=g) / 584 ** 0.5
+    b = torch.randn(512, generator=g)
+    cat = torch.cat([obs_all[idx], z, mulv[:, :3], l_t], dim=1)
+    ref = torch.nn.functional.elu(cat.double() @ W.double().t() + b.double())
+    d = lambda t: t.to(DEV)
+    obs_d, z_d, mulv_d, lt_d, idx_d = d(obs_all), d(z), d(mulv), d(l_t), d(idx)
+    X = _ffi.segmat([_ffi.seg(obs_d, 0, 53, gather=True), _ffi.seg(z_d, 0, 16), _ffi.seg(mulv_d, 0, 3),
+                     _ffi.seg(lt_d, 0, 512)], idx_d)
+    Y = torch.empty(B, 512, device=DEV)
+    ops.linear_fwd(X, d(W), d(b), Y, "elu")
+    np.testing.assert_allclose(_np(Y), ref.numpy(), rtol=2e-5, atol=2e-5)
+    # critic input = cat[obs[idx], base_vel[idx], priv[idx, 693:1389]]  (actor_critic_decoder.py:550)
+    priv = torch.randn(R, 1389, generator=g)
+    bv = torch.randn(R, 3, generator=g)
+    Wc = torch.randn(512, 752, generator=g) / 752 ** 0.5
+    catc = torch.cat([obs_all[idx], bv[idx], priv[idx, 693:]], dim=1)
+    refc = torch.nn.functional.elu(catc.double() @ Wc.double().t() + b.double())
+    priv_d, bv_d = d(priv), d(bv)
+    Xc = _ffi.segmat([_ffi.seg(obs_d, 0, 53, gather=True), _ffi.seg(bv_d, 0, 3, gather=True),
+                      _ffi.seg(priv_d, 693, 696, gather=True)], idx_d)
+    ops.linear_fwd(Xc, d(Wc), d(b), Y, "elu")
+    np.testing.assert_allclose(_np(Y), refc.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(384, 512, 512, "relu"), (300, 693, 512, "relu"), (257, 12, 128, "elu"),
+                                       (384, 1, 128, "elu"), (129, 64, 128, "relu"), (384, 128, 64, None),
+                                       (384, 35, 64, None)])
+def test_linear_dgrad_plain(M, N, K, act):
+    from dtc_amd import ops
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    dZ = torch.randn(M, N, generator=g)
+    W = torch.randn(N, K, generator=g) / N ** 0.5
+    Xs = _ref_act(torch.randn(M, K, generator=g), act)
+    ref = dZ.double() @ W.double()
+    if act == "relu":
+        ref = ref * (Xs > 0)
+    elif act == "elu":
+        ref = torch.where(Xs > 0, ref, ref * (Xs.double() + 1.0))
+    dX = torch.full((M, K), float("nan"), device=DEV)
+    ops.linear_dgrad(dZ.to(DEV), W.to(DEV), dX, Xs.to(DEV) if act else None, act)
+    np.testing.assert_allclose(_np(dX), ref.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_linear_dgrad_segments_accumulate():
+    """cenet_decoder layer 0: d[z | mu[:, :3] | l_t] with accumulation into existing gradients."""
+    from dtc_amd import _ffi, ops
+    g = torch.Generator().manual_seed(8)
+    B = 384
+    dZ = torch.randn(B, 64, generator=g)
+    W = torch.randn(64, 531, generator=g) / 8
+    dz0, dmulv0, dlt0 = torch.randn(B, 16, generator=g), torch.randn(B, 35, generator=g), torch.randn(B, 512, generator=g)
+    full = dZ.double() @ W.double()
+    dz, dmulv, dlt = dz0.to(DEV), dmulv0.to(DEV), dlt0.to(DEV)
+    dst = _ffi.segmat([_ffi.seg(dz, 0, 16), _ffi.seg(dmulv, 0, 3, accumulate=True),
+                       _ffi.seg(dlt, 0, 512, accumulate=True)])
+    ops.linear_dgrad(dZ.to(DEV), W.to(DEV), dst)
+    np.testing.assert_allclose(_np(dz), full[:, :16].numpy(), rtol=2e-5, atol=2e-5)
+    exp_mulv = dmulv0.double().clone()
+    exp_mulv[:, :3] += full[:, 16:19]
+    np.testing.assert_allclose(_np(dmulv), exp_mulv.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(_np(dlt), (dlt0.double() + full[:, 19:]).numpy(), rtol=2e-5, atol=2e-5)
+    # null segment (obs needs no gradient): actor layer 0
+    Wa = torch.randn(64, 584, generator=g) / 8
+    fulla = dZ.double() @ Wa.double()
+    dz2, dmulv2, dlt2 = torch.zeros(B, 16, device=DEV), torch.zeros(B, 35, device=DEV), torch.zeros(B, 512, device=DEV)
+    dsta = _ffi.segmat([_ffi.seg(None, 0, 53), _ffi.seg(dz2, 0, 16), _ffi.seg(dmulv2, 0, 3), _ffi.seg(dlt2, 0, 512)])
+    ops.linear_dgrad(dZ.to(DEV), Wa.to(DEV), dsta)
+    np.testing.assert_allclose(_np(dz2), fulla[:, 53:69].numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(_np(dmulv2)[:, :3], fulla[:, 69:72].numpy(), rtol=2e-5, atol=2e-5)
+    assert float(dmulv2[:, 3:].abs().max()) == 0.0
+    np.testing.assert_allclose(_np(dlt2), fulla[:, 72:].numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(1536, 512, 693), (1536, 512, 512), (1000, 64, 128), (384, 35, 64),
+                                   (1536, 693, 512), (777, 12, 128), (384, 1, 128), (24576, 128, 256)])
+def test_linear_wgrad_plain(M, N, K):
+    from dtc_amd import ops
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    dZ = torch.randn(M, N, generator=g) / M ** 0.5
+    X = torch.randn(M, K, generator=g)
+    ref_w = dZ.double().t() @ X.double()
+    ref_b = dZ.double().sum(0)
+    dW = torch.full((N, K), float("nan"), device=DEV)
+    db = torch.full((N,), float("nan"), device=DEV)
+    ws = torch.empty(ops.wgrad_workspace_bytes(M, N, K) // 4, device=DEV)
+    ops.linear_wgrad(dZ.to(DEV), X.to(DEV), dW, db, ws)
+    np.testing.assert_allclose(_np(dW), ref_w.numpy(), rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(_np(db), ref_b.numpy(), rtol=3e-5, atol=3e-5)
+
+
+def test_linear_wgrad_segments_and_gather():
+    from dtc_amd import _ffi, ops
+    g = torch.Generator().manual_seed(15)
+    R, B = 3000, 1536
+    obs_all = torch.randn(R, 53, generator=g)
+    priv = torch.randn(R, 1389, generator=g)
+    bv = torch.randn(R, 3, generator=g)
+    idx = torch.randperm(R, generator=g)[:B]
+    dZ = torch.randn(B, 512, generator=g) / B ** 0.5
+    cat = torch.cat([obs_all[idx], bv[idx], priv[idx, 693:]], dim=1)
+    ref_w = dZ.double().t() @ cat.double()
+    d = lambda t: t.to(DEV)
+    obs_d, bv_d, priv_d, idx_d = d(obs_all), d(bv), d(priv), d(idx)
+    X = _ffi.segmat([_ffi.seg(obs_d, 0, 53, gather=True), _ffi.seg(bv_d, 0, 3, gather=True),
+                     _ffi.seg(priv_d, 693, 696, gather=True)], idx_d)
+    dW = torch.empty(512, 752, device=DEV)
+    db = torch.empty(512, device=DEV)
+    ws = torch.empty(ops.wgrad_workspace_bytes(B, 512, 752) // 4, device=DEV)
+    ops.linear_wgrad(d(dZ), X, dW, db, ws)
+    np.testing.assert_allclose(_np(dW), ref_w.numpy(), rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(_np(db), dZ.double().sum(0).numpy(), rtol=3e-5, atol=3e-5)
