@@ -1,0 +1,180 @@
+"""Headline benchmark: env-steps/sec of the PPO-update + foothold-score hot path on pre-recorded
+(synthetic) rollouts, 4096 envs x 24 steps per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one recorded rollout of 4096 envs x 24 env-steps:
+    foothold planner over the 24*4096 recorded height maps  (legged_robot_dtc.py:98-201)
+  + RolloutStorage.compute_returns                          (rollout_storage.py:138-152)
+  + PPO.update: 5 epochs x 4 mini-batches of 24576          (ppo.py:174-357)
+Inputs are resident in HBM before the timed region.  Multi-GPU = data parallel, weak scaling
+(4096 envs per rank, RCCL all-reduce of the two flat gradient buckets + three scalars per step).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "deep-tracking-control_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+NUM_ENVS, NUM_STEPS = 4096, 24
+FLOP_PER_ENV_STEP = 102.03e6          # 20.405 MFLOP per sample-visit x 5 epochs
+PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, no xf32 on gfx950
+
+
+def cpu_baseline():
+    """The oracle (torch-CPU restatement of the reference's PPO.update + numpy foothold planner) timed on
+    the host cores on a bounded sample of the same workload."""
+    import numpy as np
+    from dtc_amd import synthetic as S
+    from oracle import foothold as OF
+    from oracle import ppo_ref as OP
+    cores = min(os.cpu_count() or 1, 32)      # torch-CPU GEMMs of this size stop scaling (and thrash) beyond ~32 threads
+    torch.set_num_threads(cores)
+    n_envs, n_maps = 512, 4096
+    torch.manual_seed(3)
+    ac = OP.RefActorCriticDecoder()
+    alg = OP.RefPPO(ac, learning_rate=1e-3, entropy_coef=0.003)
+    alg.init_storage(n_envs, NUM_STEPS)
+    d = S.rollout(n_envs, NUM_STEPS, seed=4)
+    for k, v in d.items():
+        if k != "last_values":
+            getattr(alg.storage, k).copy_(v)
+    perm, e1, e2 = S.update_noise(n_envs, NUM_STEPS, 4, 5, seed=123)
+    t0 = time.perf_counter()
+    alg.storage.compute_returns(d["last_values"], 0.99, 0.95)
+    alg.update(perm, e1, e2)
+    t_upd = time.perf_counter() - t0
+    inp = S.scorer_inputs(n_maps, seed=7)
+    args = [inp[k].numpy() for k in ("measured_heights", "root_states", "thigh_pos", "commands")]
+    t0 = time.perf_counter()
+    OF.plan(*args, S.MEASURED_POINTS_X, S.MEASURED_POINTS_Y)
+    t_sc = time.perf_counter() - t0
+    per_env_step = t_upd / (n_envs * NUM_STEPS) + t_sc / n_maps
+    return dict(value=1.0 / per_env_step, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"oracle/ppo_ref.py PPO.update on {n_envs} envs x {NUM_STEPS} steps ({t_upd:.1f} s) + "
+                       f"oracle/foothold.py on {n_maps} height maps ({t_sc:.1f} s), torch {torch.__version__} CPU, "
+                       f"{torch.get_num_threads()} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs a torch.distributed.run launch with WORLD_SIZE={a.gpus} (got {world})")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from dtc_amd import _ffi, foothold, synthetic as S
+    from dtc_amd.algorithms import PPO
+    from dtc_amd.modules import ActorCriticDecoder
+
+    torch.manual_seed(3)                      # identical initial weights on every rank
+    ac = ActorCriticDecoder(53, 1389, 12)
+    alg = PPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
+    alg.init_storage(NUM_ENVS, NUM_STEPS, [53], [1389], [265], [12])
+    data = S.rollout(NUM_ENVS, NUM_STEPS, seed=4 + rank, device=dev)
+    for k, v in data.items():
+        if k != "last_values":
+            getattr(alg.storage, k).copy_(v)
+    # recorded planner inputs of the same rollout: one height map per (step, env)
+    sc = S.scorer_inputs(NUM_ENVS * NUM_STEPS, seed=7 + rank, device=dev)
+    last = {k: data[k][-1] for k in ("observations", "privileged_observations", "base_vel")}
+    torch.manual_seed(123 + rank)
+
+    def step():
+        foothold.plan(sc["measured_heights"], sc["root_states"], sc["thigh_pos"], sc["commands"])
+        alg.compute_returns(last["observations"], last["privileged_observations"], last["base_vel"])
+        alg.storage.step = NUM_STEPS
+        return alg.update()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel HIP-event timing of one more step (same process, same stream) for the roofline object
+    roof, classes = None, None
+    if rank == 0:
+        lib = _ffi.lib()
+        lib.dtc_prof_reset()
+        lib.dtc_prof_enable(1)
+        step()
+        torch.cuda.synchronize()
+        lib.dtc_prof_enable(0)
+        rep = _ffi.prof_report()
+        lib.dtc_prof_reset()
+        gemm = [r for r in rep if r["name"] in ("linear_fwd", "linear_dgrad", "linear_wgrad")]
+        ms = sum(r["ms_total"] for r in gemm)
+        fl = sum(r["work"] for r in gemm)
+        n_launch = sum(r["launches"] for r in gemm)
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = dict(bound="mfma", kernel="linear_{fwd,dgrad,wgrad}_kernel (fp32 v_mfma_f32_32x32x2_f32 GEMM family)",
+                    achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP32_MFMA_TFLOPS,
+                    traffic=None, launches=n_launch, avg_launch_us=ms * 1e3 / max(1, n_launch),
+                    flop_per_launch=fl / max(1, n_launch))
+        classes = {r["name"]: dict(ms=round(r["ms_total"], 3), launches=r["launches"],
+                                   rate=(r["work"] / (r["ms_total"] * 1e-3) / 1e12) if r["ms_total"] > 0 else 0.0)
+                   for r in rep}
+
+    if rank == 0:
+        env_steps = NUM_ENVS * NUM_STEPS * world * a.steps
+        value = env_steps / elapsed
+        line = {
+            "metric": "env-steps/sec, PPO.update on pre-recorded rollouts, 4096 envs, 1/2/4/8 GPU",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 4096 envs x 24 steps per GPU, ActorCriticDecoder (CE-net + "
+                                   "terrain encoder latent 512 + MLP actor/critic): foothold planner over the 98304 "
+                                   "recorded height maps + compute_returns + PPO.update (5 epochs x 4 mini-batches of 24576)",
+                       "num_envs_per_gpu": NUM_ENVS, "num_steps_per_env": NUM_STEPS, "mini_batch": 24576,
+                       "epochs": 5, "parallelism": f"dp{world}" if world > 1 else "single",
+                       "mfma_frac_whole_step": (FLOP_PER_ENV_STEP * value / world) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
+            "roofline": roof,
+            "kernel_classes": classes,
+            "last_update": [float(x) for x in out],
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

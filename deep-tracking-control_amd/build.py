@@ -22,7 +22,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 # bit-exact kernels: no fused multiply-add contraction (see oracle/foothold.py, oracle/gae.py)
-PER_FILE = {"foothold.hip": ["-ffp-contract=off"], "gae.hip": ["-ffp-contract=off"]}
+PER_FILE = {"foothold.hip": ["-ffp-contract=off"], "gae.hip": ["-ffp-contract=off"],
+            "optim.hip": ["-ffp-contract=off"]}     # Adam mirrors torch's separately rounded ops
 
 
 def sources():

@@ -7,13 +7,26 @@
 // Mapping: one 64-lane wavefront per env, 4 envs per 256-thread workgroup.  The 4 height rows
 // of a workgroup are one contiguous, 16-byte aligned chunk of 4*P floats (P = nx*ny = 693),
 // so the workgroup streams it with float4 loads (16 B/lane, fully coalesced) into LDS; each
-// wave then works out of LDS: clamp -> mean/var by lane-strided partial sums + xor-butterfly,
-// central-difference slope from LDS neighbours, distance to the 4 nominal footholds, running
-// (min,index) per leg in registers, and a 64-lane (value,index) butterfly for the argmin with
-// ties resolved to the lowest index (torch.topk(k=1, largest=False) on CPU).
+// wave then works out of LDS:
+//   1. clamp -> mean / unbiased variance by lane-strided partial sums + xor-butterfly;
+//   2. CANDIDATE WINDOW (fast path): a grid point can only win the argmin with a "valid" score
+//      (< 0.148) if it lies within 0.16 m of the leg's nominal foothold, i.e. inside a <= 7x7 cell
+//      patch around it.  Each leg therefore evaluates ONE 8x8 patch (64 lanes = 64 candidates:
+//      central-difference slope from LDS neighbours, score, exception mask, distance, total) and
+//      reduces it with a 64-lane (value,index) butterfly -- ties resolve to the lowest flat index
+//      exactly like torch.topk(k=1, largest=False) on CPU;
+//   3. FULL SCAN (exact fallback + debug outputs): if a leg has no valid in-radius candidate
+//      (all 693 totals then belong to the sentinel classes 2.0-2.13 / 8.0 / 10 and the argmin is
+//      decided among them), or if the caller asks for the [N,693,4] score table, the wave scans
+//      all 693 points -- this is the reference's algorithm verbatim.
+// Both paths evaluate a point with the same device function, so the window result equals the
+// full-scan result whenever the window result is accepted (proof sketch in DESIGN.md 4.1).
 //
 // Numerics: compiled with -ffp-contract=off; every operation is a single IEEE float32 op in
 // the order of oracle/foothold.py + oracle/quat.py, so all outputs match the oracle bit for bit.
+// Division by the two grid-spacing constants uses q = fma(fma(-x*y, c, x), y, x*y) with y = 1/c,
+// which is bit-identical to IEEE x/c for every |x| in (1e-30, 1e30) (exhaustively verified for
+// c = 0.05f and 0.1f) and falls back to the IEEE division below that.
 #include "common.hpp"
 
 namespace {
@@ -62,7 +75,76 @@ __device__ __forceinline__ V3 quat_rotate_inverse(float qx, float qy, float qz, 
     return V3{(ax - bx) + ex, (ay - by) + ey, (az - bz) + ez};
 }
 
-template <bool VEC>
+// x / c, bit-identical to IEEE division (see header comment); inv = RN(1/c) (20.0f / 10.0f, exact)
+__device__ __forceinline__ float div_const(float x, float c, float inv) {
+    const float q0 = x * inv;
+    const float r = __builtin_fmaf(-q0, c, x);
+    float q = __builtin_fmaf(r, inv, q0);
+    if (fabsf(x) < 1e-30f) q = x / c;
+    return q;
+}
+
+struct EnvCtx {            // wave-uniform per-env quantities
+    float bx, by, bz, zq, wq, mean, edge;
+    int nx, ny;
+};
+
+struct PointEval {
+    float s, hx, hy, slope, rawv;
+    bool exc;
+};
+
+// terrain score + world xy of grid point i = ix*ny + iy  (legged_robot_dtc.py:127-160)
+__device__ __forceinline__ PointEval eval_point(const EnvCtx& c, const float* __restrict__ rawE,
+                                                const float* __restrict__ gE, const float* __restrict__ xs,
+                                                const float* __restrict__ ys, int i, int ix, int iy) {
+    PointEval o;
+    const int ny = c.ny;
+    const float gc = gE[i];
+    float dx, dy;
+    if (ix == 0) dx = div_const(gE[i + ny] - gc, 0.05f, 20.0f);
+    else if (ix == c.nx - 1) dx = div_const(gc - gE[i - ny], 0.05f, 20.0f);
+    else dx = div_const(gE[i + ny] - gE[i - ny], 0.1f, 10.0f);
+    if (iy == 0) dy = div_const(gE[i + 1] - gc, 0.05f, 20.0f);
+    else if (iy == ny - 1) dy = div_const(gc - gE[i - 1], 0.05f, 20.0f);
+    else dy = div_const(gE[i + 1] - gE[i - 1], 0.1f, 10.0f);
+    o.slope = sqrtf(dx * dx + dy * dy);
+    const float rough = fabsf(gc - c.mean);
+    const float s_raw = (0.2f * c.edge + o.slope) + 0.3f * rough;
+    o.s = s_raw < 0.1f ? s_raw : 10.0f;
+    o.rawv = rawE[i];
+    const float rel = o.rawv - c.bz;
+    o.exc = (rel > 1.0f) | (rel < -1.0f);
+    const float px = xs[ix], py = ys[iy];
+    const float t0 = -(c.zq * py) * 2.0f;
+    const float t1 = (c.zq * px) * 2.0f;
+    o.hx = ((px + c.wq * t0) + (-(c.zq * t1))) + c.bx;
+    o.hy = ((py + c.wq * t1) + (c.zq * t0)) + c.by;
+    return o;
+}
+
+__device__ __forceinline__ float total_score(const PointEval& p, float predx, float predy, float& d_out) {
+    const float ddx = predx - p.hx, ddy = predy - p.hy;
+    float d = sqrtf(ddx * ddx + ddy * ddy);
+    d = d < 0.16f ? d : 10.0f;
+    d_out = d;
+    float tot = p.s * 0.2f + d * 0.8f;
+    return p.exc ? 10.0f : tot;
+}
+
+__device__ __forceinline__ void wave_argmin(float& best, int& bidx) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (ov < best || (ov == best && oi < bidx)) {
+            best = ov;
+            bidx = oi;
+        }
+    }
+}
+
+template <bool VEC, bool DEBUG>
 __global__ __launch_bounds__(256) void foothold_plan_kernel(
     const float* __restrict__ mh, const float* __restrict__ root, const float* __restrict__ thigh,
     const float* __restrict__ cmd, const GridParams gp, int64_t* __restrict__ idx_out,
@@ -107,7 +189,12 @@ __global__ __launch_bounds__(256) void foothold_plan_kernel(
 
     // ---- per-env state (same address in every lane -> broadcast loads)
     const float* rs = root + nn * 13;
-    const float bx = rs[0], by = rs[1], bz = rs[2];
+    EnvCtx c;
+    c.nx = nx;
+    c.ny = ny;
+    c.bx = rs[0];
+    c.by = rs[1];
+    c.bz = rs[2];
     const float qx = rs[3], qy = rs[4], qz = rs[5], qw = rs[6];
     const V3 vw{rs[7], rs[8], rs[9]};
     const float c0 = cmd[nn * 4 + 0], c1 = cmd[nn * 4 + 1], c2 = cmd[nn * 4 + 2];
@@ -120,158 +207,155 @@ __global__ __launch_bounds__(256) void foothold_plan_kernel(
     const float symy = gp.t_half * vb.y + gp.k_fb * (vb.y - c1);
     const float symz = gp.t_half * vb.z + gp.k_fb * (vb.z - 0.0f);
     float predx[4], predy[4], predz[4];
-    V3 p2r[4];
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
-        const float hx = thigh[nn * 12 + l * 3 + 0] - bx;
-        const float hy = thigh[nn * 12 + l * 3 + 1] - by;
-        const float hz = thigh[nn * 12 + l * 3 + 2] - bz;
+        const float hx = thigh[nn * 12 + l * 3 + 0] - c.bx;
+        const float hy = thigh[nn * 12 + l * 3 + 1] - c.by;
+        const float hz = thigh[nn * 12 + l * 3 + 2] - c.bz;
         const float rx = cs * hx + (-sn) * hy;
         const float ry = sn * hx + cs * hy;
-        predx[l] = (bx + rx) + symx;
-        predy[l] = (by + ry) + symy;
-        predz[l] = (bz + hz) + symz;
-        p2r[l] = quat_rotate_inverse(qx, qy, qz, qw, V3{predx[l] - bx, predy[l] - by, predz[l] - bz});
+        predx[l] = (c.bx + rx) + symx;
+        predy[l] = (c.by + ry) + symy;
+        predz[l] = (c.bz + hz) + symz;
     }
 
     // ---- clamp + mean / unbiased variance (legged_robot_dtc.py:127-141)
     float psum = 0.0f;
     for (int i = lane; i < P; i += 64) {
-        const float v = rawE[i] - bz;
+        const float v = rawE[i] - c.bz;
         const float gc = fminf(fmaxf(v, -0.5f), 0.5f);
         gE[i] = gc;
         psum = psum + gc;
     }
-    const float mean = wave_sum(psum) / (float)P;
+    c.mean = wave_sum(psum) / (float)P;
     float qsum = 0.0f;
     for (int i = lane; i < P; i += 64) {
-        const float d = gE[i] - mean;
+        const float d = gE[i] - c.mean;
         qsum = qsum + d * d;
     }
     const float var = wave_sum(qsum) / (float)(P - 1);
-    const float edge = fminf(fmaxf(sqrtf(var), 0.0f), 0.3f);
+    c.edge = fminf(fmaxf(sqrtf(var), 0.0f), 0.3f);
     __syncthreads();   // gE written by other lanes is read below
 
     // ---- yaw-only attitude (math.py:8-12)
     float nq = sqrtf(qz * qz + qw * qw);
     nq = fmaxf(nq, 1e-9f);
-    const float zq = qz / nq, wq = qw / nq;
+    c.zq = qz / nq;
+    c.wq = qw / nq;
 
-    float best[4], nbest[4];
-    int bidx[4], nidx[4];
+    float best[4];
+    int bidx[4];
+    bool need_full = DEBUG;
+    if (!DEBUG) {
+        // ---- fast path: one 8x8 candidate patch per leg
+        const int wx = lane >> 3, wy = lane & 7;
+        // grid spacing from the coordinate tables (uniform grids; used only to PLACE the patch)
+        const float x0 = xs[0], y0 = ys[0];
+        const float inv_dx = (float)(nx - 1) / (xs[nx - 1] - x0), inv_dy = (float)(ny - 1) / (ys[ny - 1] - y0);
+        const float rad_x = 0.16f * inv_dx + 0.05f, rad_y = 0.16f * inv_dy + 0.05f;   // radius in cells + slack
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        best[l] = __builtin_inff();
-        nbest[l] = __builtin_inff();
-        bidx[l] = 0x7fffffff;
-        nidx[l] = 0x7fffffff;
+        for (int l = 0; l < 4; ++l) {
+            // nominal foothold in the yaw frame of the grid: R(-yaw) * (pred - base)
+            const float rx = predx[l] - c.bx, ry = predy[l] - c.by;
+            const float cyaw = c.wq * c.wq - c.zq * c.zq, syaw = 2.0f * c.wq * c.zq;
+            const float lx = cyaw * rx + syaw * ry, ly = -syaw * rx + cyaw * ry;
+            const float u = (lx - x0) * inv_dx, v = (ly - y0) * inv_dy;
+            // all in-radius cells have |iu - u| < rad: they fit in 8 consecutive cells iff 2*rad < 7
+            const bool fits = (2.0f * rad_x < 7.0f) && (2.0f * rad_y < 7.0f) && (fabsf(u) < 1e6f) && (fabsf(v) < 1e6f);
+            const int sx = (int)floorf(u - rad_x) + 1, sy = (int)floorf(v - rad_y) + 1;
+            const int ix = sx + wx, iy = sy + wy;
+            float tot = __builtin_inff();
+            int ii = 0x7fffffff;
+            if (fits && ix >= 0 && ix < nx && iy >= 0 && iy < ny) {
+                ii = ix * ny + iy;
+                const PointEval p = eval_point(c, rawE, gE, xs, ys, ii, ix, iy);
+                float d;
+                tot = total_score(p, predx[l], predy[l], d);
+            }
+            wave_argmin(tot, ii);
+            best[l] = tot;
+            bidx[l] = ii;
+            // accept only a "valid" winner: every total < 1 is an in-radius, non-sentinel point, and all
+            // such points lie inside the patch, so the patch minimum is then the global minimum
+            need_full |= !(tot < 1.0f);
+        }
     }
-    const bool want_nom = nom_out != nullptr;
 
-    for (int i = lane; i < P; i += 64) {
-        const int ix = i / ny, iy = i - ix * ny;
-        const float gc = gE[i];
-        float dx, dy;
-        if (ix == 0) dx = (gE[i + ny] - gc) / 0.05f;
-        else if (ix == nx - 1) dx = (gc - gE[i - ny]) / 0.05f;
-        else dx = (gE[i + ny] - gE[i - ny]) / 0.1f;
-        if (iy == 0) dy = (gE[i + 1] - gc) / 0.05f;
-        else if (iy == ny - 1) dy = (gc - gE[i - 1]) / 0.05f;
-        else dy = (gE[i + 1] - gE[i - 1]) / 0.1f;
-        const float slope = sqrtf(dx * dx + dy * dy);
-        const float rough = fabsf(gc - mean);
-        const float s_raw = (0.2f * edge + slope) + 0.3f * rough;
-        const float s = s_raw < 0.1f ? s_raw : 10.0f;
-        const float rawv = rawE[i];
-        const float rel = rawv - bz;
-        const bool exc = (rel > 1.0f) | (rel < -1.0f);
-        const float px = xs[ix], py = ys[iy];
-        const float t0 = -(zq * py) * 2.0f;
-        const float t1 = (zq * px) * 2.0f;
-        const float hx = ((px + wq * t0) + (-(zq * t1))) + bx;
-        const float hy = ((py + wq * t1) + (zq * t0)) + by;
-        if (active && slope_out) slope_out[nn * P + i] = slope;
-        if (active && hw_out) {
-            float* o = hw_out + (nn * P + i) * 3;
-            o[0] = hx;
-            o[1] = hy;
-            o[2] = rawv;
+    if (need_full) {      // wave-uniform
+        float nbest[4];
+        int nidx[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            best[l] = __builtin_inff();
+            nbest[l] = __builtin_inff();
+            bidx[l] = 0x7fffffff;
+            nidx[l] = 0x7fffffff;
+        }
+        for (int i = lane; i < P; i += 64) {
+            const int ix = i / ny, iy = i - ix * ny;
+            const PointEval p = eval_point(c, rawE, gE, xs, ys, i, ix, iy);
+            if (DEBUG) {
+                if (active && slope_out) slope_out[nn * P + i] = p.slope;
+                if (active && hw_out) {
+                    float* o = hw_out + (nn * P + i) * 3;
+                    o[0] = p.hx;
+                    o[1] = p.hy;
+                    o[2] = p.rawv;
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                float d;
+                const float tot = total_score(p, predx[l], predy[l], d);
+                if (tot < best[l]) {
+                    best[l] = tot;
+                    bidx[l] = i;
+                }
+                if (DEBUG) {
+                    if (d < nbest[l]) {
+                        nbest[l] = d;
+                        nidx[l] = i;
+                    }
+                    if (active && score_out) score_out[(nn * P + i) * 4 + l] = tot;
+                }
+            }
         }
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            const float ddx = predx[l] - hx, ddy = predy[l] - hy;
-            float d = sqrtf(ddx * ddx + ddy * ddy);
-            d = d < 0.16f ? d : 10.0f;
-            float tot = s * 0.2f + d * 0.8f;
-            tot = exc ? 10.0f : tot;
-            if (tot < best[l]) {
-                best[l] = tot;
-                bidx[l] = i;
+            wave_argmin(best[l], bidx[l]);
+            if (bidx[l] == 0x7fffffff) bidx[l] = 0;
+            if (DEBUG) {
+                wave_argmin(nbest[l], nidx[l]);
+                if (nidx[l] == 0x7fffffff) nidx[l] = 0;
+                if (active && nom_out && lane == 0) nom_out[nn * 4 + l] = (int64_t)nidx[l];
             }
-            if (want_nom && d < nbest[l]) {
-                nbest[l] = d;
-                nidx[l] = i;
-            }
-            if (active && score_out) score_out[(nn * P + i) * 4 + l] = tot;
-        }
-    }
-
-    // ---- 64-lane (value, index) butterfly: min value, ties -> lowest index
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(best[l], off, 64);
-            const int oi = __shfl_xor(bidx[l], off, 64);
-            if (ov < best[l] || (ov == best[l] && oi < bidx[l])) {
-                best[l] = ov;
-                bidx[l] = oi;
-            }
-        }
-        if (bidx[l] == 0x7fffffff) bidx[l] = 0;
-        if (want_nom) {
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ov = __shfl_xor(nbest[l], off, 64);
-                const int oi = __shfl_xor(nidx[l], off, 64);
-                if (ov < nbest[l] || (ov == nbest[l] && oi < nidx[l])) {
-                    nbest[l] = ov;
-                    nidx[l] = oi;
-                }
-            }
-            if (nidx[l] == 0x7fffffff) nidx[l] = 0;
         }
     }
 
     // ---- decode (legged_robot_dtc.py:184-201); lane l < 4 writes leg l
-    if (active && lane < 4) {
-        const int l = lane;
-        const int bi = l == 0 ? bidx[0] : (l == 1 ? bidx[1] : (l == 2 ? bidx[2] : bidx[3]));
-        const float pxl = l == 0 ? predx[0] : (l == 1 ? predx[1] : (l == 2 ? predx[2] : predx[3]));
-        const float pyl = l == 0 ? predy[0] : (l == 1 ? predy[1] : (l == 2 ? predy[2] : predy[3]));
-        const float pzl = l == 0 ? predz[0] : (l == 1 ? predz[1] : (l == 2 ? predz[2] : predz[3]));
-        const V3 pr = l == 0 ? p2r[0] : (l == 1 ? p2r[1] : (l == 2 ? p2r[2] : p2r[3]));
-        idx_out[nn * 4 + l] = (int64_t)bi;
-        if (want_nom) {
-            const int ni = l == 0 ? nidx[0] : (l == 1 ? nidx[1] : (l == 2 ? nidx[2] : nidx[3]));
-            nom_out[nn * 4 + l] = (int64_t)ni;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        if (active && lane == l) {
+            const int bi = bidx[l];
+            idx_out[nn * 4 + l] = (int64_t)bi;
+            const int xi = bi % ny, yi = bi / ny;
+            // the reference gathers the x table with the y-index and vice versa (sic)
+            obs_out[nn * 8 + l] = xs[xi % nx];
+            obs_out[nn * 8 + 4 + l] = ys[yi % ny];
+            const float px = xs[yi], py = ys[xi];
+            const float t0 = -(c.zq * py) * 2.0f;
+            const float t1 = (c.zq * px) * 2.0f;
+            world_out[nn * 12 + l * 3 + 0] = ((px + c.wq * t0) + (-(c.zq * t1))) + c.bx;
+            world_out[nn * 12 + l * 3 + 1] = ((py + c.wq * t1) + (c.zq * t0)) + c.by;
+            world_out[nn * 12 + l * 3 + 2] = rawE[bi];
+            pred_out[nn * 12 + l * 3 + 0] = predx[l];
+            pred_out[nn * 12 + l * 3 + 1] = predy[l];
+            pred_out[nn * 12 + l * 3 + 2] = predz[l];
+            const V3 pr = quat_rotate_inverse(qx, qy, qz, qw, V3{predx[l] - c.bx, predy[l] - c.by, predz[l] - c.bz});
+            p2r_out[nn * 12 + l * 3 + 0] = pr.x;
+            p2r_out[nn * 12 + l * 3 + 1] = pr.y;
+            p2r_out[nn * 12 + l * 3 + 2] = pr.z;
         }
-        const int xi = bi % ny, yi = bi / ny;
-        // the reference gathers the x table with the y-index and vice versa (sic)
-        obs_out[nn * 8 + l] = xs[xi % nx];
-        obs_out[nn * 8 + 4 + l] = ys[yi % ny];
-        const float px = xs[yi], py = ys[xi];
-        const float t0 = -(zq * py) * 2.0f;
-        const float t1 = (zq * px) * 2.0f;
-        world_out[nn * 12 + l * 3 + 0] = ((px + wq * t0) + (-(zq * t1))) + bx;
-        world_out[nn * 12 + l * 3 + 1] = ((py + wq * t1) + (zq * t0)) + by;
-        world_out[nn * 12 + l * 3 + 2] = rawE[bi];
-        pred_out[nn * 12 + l * 3 + 0] = pxl;
-        pred_out[nn * 12 + l * 3 + 1] = pyl;
-        pred_out[nn * 12 + l * 3 + 2] = pzl;
-        p2r_out[nn * 12 + l * 3 + 0] = pr.x;
-        p2r_out[nn * 12 + l * 3 + 1] = pr.y;
-        p2r_out[nn * 12 + l * 3 + 2] = pr.z;
     }
 }
 
@@ -323,6 +407,14 @@ int make_params(const DtcGridCfg* cfg, GridParams& gp) {
     return DTC_OK;
 }
 
+template <bool VEC, bool DEBUG>
+void launch(int grid, size_t lds, hipStream_t s, const float* mh, const float* rs, const float* th, const float* cmd,
+            const GridParams& gp, int64_t* idx, float* obs, float* world, float* pred, float* p2r, float* score,
+            int64_t* nom, float* slope, float* hw, int N) {
+    hipLaunchKernelGGL((foothold_plan_kernel<VEC, DEBUG>), dim3(grid), dim3(256), lds, s, mh, rs, th, cmd, gp, idx, obs,
+                       world, pred, p2r, score, nom, slope, hw, N);
+}
+
 }  // namespace
 
 extern "C" int dtc_foothold_plan(const float* measured_heights, const float* root_states, const float* thigh_pos,
@@ -342,16 +434,16 @@ extern "C" int dtc_foothold_plan(const float* measured_heights, const float* roo
     const size_t lds = (size_t)(2 * P4 + 96) * sizeof(float);
     const int grid = (int)dtc::ceil_div(N, ENVS_PER_BLOCK);
     const double bytes = (double)N * (gp.P * 4.0 + 13 * 4 + 4 * 4 + 12 * 4 + 32 + 32 + 48 + 96);
-    dtc::ProfScope prof("foothold_plan", bytes, s);
-    if (dtc::aligned16(measured_heights)) {
-        hipLaunchKernelGGL(foothold_plan_kernel<true>, dim3(grid), dim3(256), lds, s, measured_heights, root_states,
-                           thigh_pos, commands, gp, idx, foothold_obs, opt_world, pred, pred_to_robot, score_or_null,
-                           nominal_idx_or_null, slope_or_null, heights_world_or_null, N);
-    } else {
-        hipLaunchKernelGGL(foothold_plan_kernel<false>, dim3(grid), dim3(256), lds, s, measured_heights, root_states,
-                           thigh_pos, commands, gp, idx, foothold_obs, opt_world, pred, pred_to_robot, score_or_null,
-                           nominal_idx_or_null, slope_or_null, heights_world_or_null, N);
-    }
+    const bool debug = score_or_null || nominal_idx_or_null || slope_or_null || heights_world_or_null;
+    const bool vec = dtc::aligned16(measured_heights);
+    dtc::ProfScope prof(debug ? "foothold_plan_debug" : "foothold_plan", bytes, s);
+#define DTC_FH_ARGS grid, lds, s, measured_heights, root_states, thigh_pos, commands, gp, idx, foothold_obs, opt_world, \
+                    pred, pred_to_robot, score_or_null, nominal_idx_or_null, slope_or_null, heights_world_or_null, N
+    if (vec && debug) launch<true, true>(DTC_FH_ARGS);
+    else if (vec) launch<true, false>(DTC_FH_ARGS);
+    else if (debug) launch<false, true>(DTC_FH_ARGS);
+    else launch<false, false>(DTC_FH_ARGS);
+#undef DTC_FH_ARGS
     return dtc::check_launch("foothold_plan");
 }
 

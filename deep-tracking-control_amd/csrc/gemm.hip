@@ -90,20 +90,32 @@ __device__ __forceinline__ void mfma_step(const float* __restrict__ As, const fl
                                           f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN], int lane, int wm_off, int wn_off) {
     using C = Cfg<BN>;
     const int half = lane >> 5, l31 = lane & 31;
+    const float* ap = As + half * C::LDA + wm_off + l31;
+    const float* bp = Bs + half * C::LDB + wn_off + l31;
+    // Software pipeline over the 8 k-pairs of the K step: the LDS reads of k-pair kp+1 are issued BEFORE
+    // the MFMAs of k-pair kp (sched_barrier pins that order; hipcc otherwise sinks every read next to
+    // its use and exposes the LDS latency 8 times per step), so each wait is a counted lgkmcnt.
+    float a[2][C::TM], b[2][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) a[0][i] = ap[32 * i];
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) b[0][j] = bp[32 * j];
 #pragma unroll
     for (int kp = 0; kp < BK / 2; ++kp) {
-        float a[C::TM], b[C::TN];
-        const float* ap = As + (2 * kp + half) * C::LDA + wm_off + l31;
-        const float* bp = Bs + (2 * kp + half) * C::LDB + wn_off + l31;
+        const int cur = kp & 1, nxt = cur ^ 1;
+        if (kp + 1 < BK / 2) {
 #pragma unroll
-        for (int i = 0; i < C::TM; ++i) a[i] = ap[32 * i];
+            for (int i = 0; i < C::TM; ++i) a[nxt][i] = ap[(2 * (kp + 1)) * C::LDA + 32 * i];
 #pragma unroll
-        for (int j = 0; j < C::TN; ++j) b[j] = bp[32 * j];
+            for (int j = 0; j < C::TN; ++j) b[nxt][j] = bp[(2 * (kp + 1)) * C::LDB + 32 * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)
 #pragma unroll
             for (int j = 0; j < C::TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -126,44 +138,48 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const SegMatDev X, cons
     // loader coordinates: thread owns k = kk and rows rbase + 16*i
     const int kk = tid & 15, rbase = tid >> 4;
     constexpr int NA = BM / 16, NB = BN / 16;
-    long long arow[NA], grow[NA];
-    bool aval[NA];
+    // All loads are UNCONDITIONAL on clamped addresses and masked afterwards: a predicated load makes
+    // hipcc wrap every load in its own exec-mask branch with a wait in between (serialised latency).
+    int arow[NA], grow[NA], wrow[NB];
+    bool aval[NA], wval[NB];
     bool any_gather = false;
     for (int s = 0; s < X.nseg; ++s) any_gather |= X.s[s].gather != 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + rbase + 16 * i;
         aval[i] = m < M;
-        arow[i] = m;
-        grow[i] = (any_gather && aval[i]) ? X.idx[m] : m;
+        arow[i] = aval[i] ? m : M - 1;
+        grow[i] = any_gather ? (int)X.idx[arow[i]] : arow[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + rbase + 16 * i;
+        wval[i] = n < N;
+        wrow[i] = wval[i] ? n : N - 1;
     }
     float ra[NA], rb[NB];
     auto load_tile = [&](int k0) {
         const int k = k0 + kk;
-        if (k < K) {
-            const int s = find_seg(X, k);
-            const SegDev sd = X.s[s];
-            const float* p = sd.ptr + sd.col0 + (k - sd.start);
+        const bool kval = k < K;
+        const int kc = kval ? k : K - 1;
+        const SegDev sd = X.s[find_seg(X, kc)];
+        const float* p = sd.ptr + sd.col0 + (kc - sd.start);
 #pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = aval[i] ? p[(sd.gather ? grow[i] : arow[i]) * sd.ld] : 0.f;
-            const float* w = W + k;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int n = n0 + rbase + 16 * i;
-                rb[i] = n < N ? w[(long long)n * K] : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = 0.f;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = 0.f;
+        for (int i = 0; i < NA; ++i) {
+            ra[i] = p[(long long)(sd.gather ? grow[i] : arow[i]) * sd.ld];
         }
+        const float* w = W + kc;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = w[(long long)wrow[i] * K];
+        return kval;
     };
-    auto store_tile = [&](int buf) {
+    // the bounds masks are applied when the registers are written to LDS, i.e. AFTER the MFMAs of the
+    // current tile, so the global loads stay in flight behind the matrix work
+    auto store_tile = [&](int buf, bool kval) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = ra[i];
+        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = (aval[i] && kval) ? ra[i] : 0.f;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[buf][kk][rbase + 16 * i] = rb[i];
+        for (int i = 0; i < NB; ++i) Bs[buf][kk][rbase + 16 * i] = (wval[i] && kval) ? rb[i] : 0.f;
     };
 
     f32x16 acc[C::TM][C::TN];
@@ -175,14 +191,15 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const SegMatDev X, cons
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int KT = (K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    bool kv = load_tile(0);
+    store_tile(0, kv);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) load_tile((kt + 1) * BK);
+        if (kt + 1 < KT) kv = load_tile((kt + 1) * BK);
         mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < KT) store_tile(buf ^ 1, kv);
         __syncthreads();
     }
 
@@ -226,25 +243,37 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
     constexpr int NB = BK / RPP;
     const int bj = tid % BN, bk0 = tid / BN;
     const bool bcol_ok = c0 + bj < K;
+    int arow[NA];
+    bool aval[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + rbase + 16 * i;
+        aval[i] = m < M;
+        arow[i] = aval[i] ? m : M - 1;
+    }
+    const int bcol = bcol_ok ? c0 + bj : K - 1;
     float ra[NA], rb[NB];
     auto load_tile = [&](int n_0) {
         const int n = n_0 + kk;
+        const bool nval = n < N;
+        const int nc = nval ? n : N - 1;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int m = m0 + rbase + 16 * i;
-            ra[i] = (m < M && n < N) ? dZ[(long long)m * lddz + n] : 0.f;
+            ra[i] = dZ[(long long)arow[i] * lddz + nc];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int nr = n_0 + bk0 + RPP * i;
-            rb[i] = (bcol_ok && nr < N) ? W[(long long)nr * K + c0 + bj] : 0.f;
+            rb[i] = W[(long long)(nr < N ? nr : N - 1) * K + bcol];
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int n_0) {
+        const bool nval = n_0 + kk < N;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = ra[i];
+        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = (aval[i] && nval) ? ra[i] : 0.f;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[buf][bk0 + RPP * i][bj] = rb[i];
+        for (int i = 0; i < NB; ++i)
+            Bs[buf][bk0 + RPP * i][bj] = (bcol_ok && n_0 + bk0 + RPP * i < N) ? rb[i] : 0.f;
     };
 
     f32x16 acc[C::TM][C::TN];
@@ -257,13 +286,14 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
 
     const int KT = (N + BK - 1) / BK;
     load_tile(0);
-    store_tile(0);
+    store_tile(0, 0);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < KT) load_tile((kt + 1) * BK);
         mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < KT) store_tile(buf ^ 1, (kt + 1) * BK);
         __syncthreads();
     }
 
@@ -304,8 +334,11 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     __shared__ float Bs[2][BK][C::LDB];
     const int row_tiles = (N + BM - 1) / BM, col_tiles = (K + BN - 1) / BN;
     const int tiles = row_tiles * col_tiles;
-    const int split = blockIdx.x / tiles;
-    const int t = blockIdx.x - split * tiles;
+    // block b runs on XCD b%8: every XCD owns whole batch slices (splits), so each slice of dZ / X is
+    // pulled from HBM into ONE L2 and shared there by all output tiles
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int split = xcd + 8 * (jb / tiles);
+    const int t = jb % tiles;
     const int tr = t / col_tiles, tc = t - tr * col_tiles;
     const int n0 = tr * BM, c0 = tc * BN;
     const int m_begin = split * rows_per_split;
@@ -323,37 +356,38 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     const int bj = tid % BN, bk0 = tid / BN;
     const int bcol = c0 + bj;
     const bool bcol_ok = bcol < K;
-    SegDev sd = X.s[0];
-    if (bcol_ok) sd = X.s[find_seg(X, bcol)];
-    const float* bp = sd.ptr + sd.col0 + (bcol - sd.start);
+    const int bcolc = bcol_ok ? bcol : K - 1;
+    const SegDev sd = X.s[find_seg(X, bcolc)];
+    const float* bp = sd.ptr + sd.col0 + (bcolc - sd.start);
 
     float ra[NA], rb[NB];
     float bias_acc = 0.f;
+    const int acol = arow_ok ? n0 + ai : N - 1;
+    const int m_last = m_end > m_begin ? m_end - 1 : 0;
     auto load_tile = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = mb + ak0 + 2 * i;
-            ra[i] = (arow_ok && m < m_end) ? dZ[(long long)m * lddz + n0 + ai] : 0.f;
+            ra[i] = dZ[(long long)(m < m_end ? m : m_last) * lddz + acol];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int m = mb + bk0 + RPP * i;
-            float v = 0.f;
-            if (bcol_ok && m < m_end) {
-                const long long r = sd.gather ? X.idx[m] : (long long)m;
-                v = bp[r * sd.ld];
-            }
-            rb[i] = v;
+            const int mc = m < m_end ? m : m_last;
+            const long long r = sd.gather ? X.idx[mc] : (long long)mc;
+            rb[i] = bp[r * sd.ld];
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int mb) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            As[buf][ak0 + 2 * i][ai] = ra[i];
-            bias_acc += ra[i];
+            const float v = (arow_ok && mb + ak0 + 2 * i < m_end) ? ra[i] : 0.f;
+            As[buf][ak0 + 2 * i][ai] = v;
+            bias_acc += v;
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[buf][bk0 + RPP * i][bj] = rb[i];
+        for (int i = 0; i < NB; ++i)
+            Bs[buf][bk0 + RPP * i][bj] = (bcol_ok && mb + bk0 + RPP * i < m_end) ? rb[i] : 0.f;
     };
 
     f32x16 acc[C::TM][C::TN];
@@ -367,14 +401,15 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     const int KT = (m_end - m_begin + BK - 1) / BK;
     if (KT > 0) {
         load_tile(m_begin);
-        store_tile(0);
+        store_tile(0, m_begin);
     }
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < KT) load_tile(m_begin + (kt + 1) * BK);
         mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < KT) store_tile(buf ^ 1, m_begin + (kt + 1) * BK);
         __syncthreads();
     }
 
@@ -405,15 +440,22 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
                                                            float* __restrict__ db, int N, int K, int splits) {
-    const long long ldp = K + 1;
+    const int ldp = K + 1;
     const long long total = (long long)N * ldp;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int s = 0; s < splits; ++s) v += part[(long long)s * total + e];
-        const long long n = e / ldp;
-        const int c = (int)(e - n * ldp);
-        if (c < K) dW[n * K + c] = v;
+    const int n = blockIdx.y;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ldp; c += gridDim.x * blockDim.x) {
+        const float* p = part + (long long)n * ldp + c;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int s = 0;
+        for (; s + 4 <= splits; s += 4) {
+            v0 += p[(long long)s * total];
+            v1 += p[(long long)(s + 1) * total];
+            v2 += p[(long long)(s + 2) * total];
+            v3 += p[(long long)(s + 3) * total];
+        }
+        for (; s < splits; ++s) v0 += p[(long long)s * total];
+        const float v = (v0 + v1) + (v2 + v3);
+        if (c < K) dW[(long long)n * K + c] = v;
         else if (db) db[n] = v;
     }
 }
@@ -461,10 +503,10 @@ int pick_bn(int cols) {
 int wgrad_splits(int M, int N, int K) {
     const int bn = pick_bn(K);
     const int tiles = (int)(dtc::ceil_div(N, BM) * dtc::ceil_div(K, bn));
-    int s = (int)dtc::ceil_div(768, tiles);
+    int s = (int)dtc::ceil_div(640, tiles);
     const int max_s = (int)dtc::ceil_div(M, BK * 8);
     if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
+    s = (int)dtc::ceil_div(s, 8) * 8;          // whole splits per XCD
     return s;
 }
 
@@ -537,8 +579,8 @@ extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* 
     {
         const long long total = (long long)N * (K + 1);
         dtc::ProfScope prof("wgrad_reduce", (double)total * 4.0 * (splits + 1), s);
-        const int grid = (int)(dtc::ceil_div(total, 256) < 4096 ? dtc::ceil_div(total, 256) : 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, part, dW, db, N, K, splits);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dtc::ceil_div(K + 1, 256), (unsigned)N), dim3(256), 0, s,
+                           part, dW, db, N, K, splits);
     }
     return dtc::check_launch("linear_wgrad");
 }

@@ -236,6 +236,16 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(const double* __
     }
 }
 
+__global__ void lr_adapt_kernel(const float* __restrict__ kl_mean, double* __restrict__ lr, float desired_kl) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float klm = *kl_mean;
+        double cur = *lr;
+        if (klm > desired_kl * 2.0f) cur = fmax(1e-5, cur / 1.5);
+        else if (klm < desired_kl / 2.0f && klm > 0.0f) cur = fmin(1e-2, cur * 1.5);
+        *lr = cur;
+    }
+}
+
 __global__ __launch_bounds__(256) void gaussian_act_kernel(const float* __restrict__ mean, const float* __restrict__ stdp,
                                                            const float* __restrict__ noise, float* __restrict__ actions,
                                                            float* __restrict__ logp, float* __restrict__ mu_out,
@@ -315,4 +325,10 @@ extern "C" int dtc_gaussian_act(const float* mean, const float* std, const float
     hipLaunchKernelGGL(gaussian_act_kernel, dim3((unsigned)dtc::ceil_div(B, 256)), dim3(256), 0, s, mean, std, noise,
                        actions, logp, mu_out, sigma_out, B, num_actions);
     return dtc::check_launch("gaussian_act");
+}
+
+extern "C" int dtc_lr_adapt(const float* kl_mean, double* lr, float desired_kl, void* stream) {
+    DTC_REQUIRE(kl_mean && lr, "null pointer");
+    hipLaunchKernelGGL(lr_adapt_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_mean, lr, desired_kl);
+    return dtc::check_launch("lr_adapt");
 }

@@ -75,6 +75,7 @@ _SIGS = {
     "dtc_vae_loss": (C.c_int, [c_f32p] * 6 + [c_i64p] + [c_f32p] * 4 + [C.c_void_p, C.c_int, c_stream]),
     "dtc_ppo_loss": (C.c_int, [c_f32p] * 10 + [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 4 +
                      [c_f64p, C.c_void_p, C.c_int, C.c_int, c_stream]),
+    "dtc_lr_adapt": (C.c_int, [c_f32p, c_f64p, C.c_float, c_stream]),
     "dtc_gaussian_act": (C.c_int, [c_f32p] * 7 + [C.c_int, C.c_int, c_stream]),
     "dtc_adam_workspace": (C.c_int64, [C.c_int64]),
     "dtc_clip_adam": (C.c_int, [c_f32p] * 4 + [C.c_int64, C.c_float, c_f64p, C.c_double, C.c_double, C.c_double,

@@ -1,0 +1,402 @@
+"""PPO with the CE-net VAE step, on hand-written HIP kernels.
+
+Class surface = rsl_rl/rsl_rl/algorithms/ppo.py:42-381 (`PPO.__init__` keyword list, `init_storage`,
+`act`, `process_env_step`, `compute_returns`, `update` returning the 7-tuple of ppo.py:356-357,
+attributes `actor_critic`, `optimizer`, `vae_optimizer`, `storage`, `learning_rate`, `transition`).
+
+`update()` executes, per mini-batch, exactly the two optimisation steps of ppo.py:189-338
+(SURVEY.md Appendix B), but as an explicit forward / backward kernel schedule:
+  * no autograd graph: forward activations are kept in a reusable workspace, the backward pass is
+    a fixed sequence of weight-gradient / data-gradient GEMMs with fused activation derivatives;
+  * the mini-batch gather and every torch.cat are folded into the GEMM operand loaders;
+  * both optimisers are one fused clip+Adam launch over a contiguous parameter range;
+  * no host synchronisation inside the update: losses accumulate in a device table, the adaptive
+    learning rate lives in device memory, and ONE device->host copy at the end yields the returned
+    means and the new `learning_rate` (the reference syncs 7x per mini-batch);
+  * under torch.distributed (one process per GPU, RCCL over xGMI) gradients of each optimiser
+    range are all-reduced as one flat bucket and the KL statistic is averaged so that every rank
+    takes the same learning-rate branch.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .. import _ffi, ops
+from .._ffi import seg, segmat
+from ..modules.actor_critic_decoder import AC_Args, ActorCriticDecoder
+from ..storage import RolloutStorage
+
+# columns of the per-step statistics table
+S_RECONS, S_VEL, S_KLD, S_HEIGHT, S_VAE_GNORM, S_SURR, S_VALUE, S_ENTROPY, S_KL, S_GNORM = range(10)
+STAT_COLS = 12
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics (default betas/eps, no weight decay) over ONE contiguous range of
+    the parameter arena; `state_dict()` / `load_state_dict()` use torch's Adam layout so that
+    checkpoints written by the reference's `OnPolicyRunner.save` load (and vice versa)."""
+
+    def __init__(self, arena, rng, params, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.arena, self.range = arena, rng
+        lo, hi = rng
+        dev = arena.flat.device
+        self.p, self.g = arena.flat[lo:hi], arena.grad[lo:hi]
+        self.exp_avg = torch.zeros(hi - lo, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(hi - lo, dtype=torch.float32, device=dev)
+        self.lr_dev = torch.tensor([lr], dtype=torch.float64, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.ws = ops.workspace(_ffi.lib().dtc_adam_workspace(hi - lo), dev)
+        self.step_count = 0
+        self.params = list(params)
+        self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False,
+                                  maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)]
+        names = {id(p): k for k, p in arena_named(arena)}
+        self._inside = []          # (param position, arena offset, numel) of params inside the fused range
+        for i, p in enumerate(self.params):
+            off, n, _ = arena.offsets[names[id(p)]]
+            if lo <= off and off + n <= hi:
+                self._inside.append((i, off - lo, n, tuple(p.shape)))
+
+    def set_lr(self, lr: float):
+        self.lr_dev.fill_(lr)
+        for g in self.param_groups:
+            g['lr'] = lr
+
+    def zero_grad(self, set_to_none=True):
+        self.g.zero_()
+
+    def step(self, max_grad_norm: float, gnorm_out=None):
+        """clip_grad_norm_(range, max_grad_norm) + Adam step, one fused launch pair."""
+        self.step_count += 1
+        g = self.param_groups[0]
+        ops.clip_adam(self.p, self.g, self.exp_avg, self.exp_avg_sq, max_grad_norm, self.lr_dev, g['betas'][0],
+                      g['betas'][1], g['eps'], self.step_count, gnorm_out if gnorm_out is not None else self.gnorm,
+                      self.ws)
+
+    def state_dict(self):
+        state = {}
+        if self.step_count > 0:
+            for i, off, n, shape in self._inside:
+                state[i] = dict(step=torch.tensor(float(self.step_count)),
+                                exp_avg=self.exp_avg[off:off + n].view(shape).clone(),
+                                exp_avg_sq=self.exp_avg_sq[off:off + n].view(shape).clone())
+        groups = [{k: v for k, v in self.param_groups[0].items() if k != 'params'}]
+        groups[0]['params'] = list(range(len(self.params)))
+        return dict(state=state, param_groups=groups)
+
+    def load_state_dict(self, sd):
+        steps = []
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, off, n, shape in self._inside:
+            st = sd['state'].get(i, sd['state'].get(str(i)))
+            if st is None:
+                continue
+            self.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.append(int(float(st['step'])))
+        self.step_count = max(steps) if steps else 0
+        if sd.get('param_groups'):
+            self.set_lr(float(sd['param_groups'][0]['lr']))
+
+
+def arena_named(arena):
+    return [(k, p) for k, p in arena._named]
+
+
+class _TrainWorkspace:
+    """Activation / gradient buffers of one mini-batch step (allocated once per batch size)."""
+
+    def __init__(self, B, dev, num_actions):
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.B = B
+        # VAE-only forward activations
+        self.c1, self.c2, self.rec = e(B, 64), e(B, 128), e(B, 53)
+        self.d1, self.d2, self.hr = e(B, 512), e(B, 512), e(B, 693)
+        # gradients
+        self.g_rec, self.g_hr = e(B, 53), e(B, 693)
+        self.gA, self.gB, self.dlt = e(B, 512), e(B, 512), e(B, 512)
+        self.g256, self.g128, self.g64 = e(B, 256), e(B, 128), e(B, 64)
+        self.dmulv, self.dz = e(B, 35), e(B, 16)
+        self.dmean, self.dval = e(B, num_actions), e(B, 1)
+        lib = _ffi.lib()
+        shapes = [(512, 693), (512, 512), (693, 512), (512, 584), (512, 752), (256, 512), (128, 256), (64, 531),
+                  (128, 64), (53, 128), (128, 265), (64, 128), (35, 64), (num_actions, 128), (1, 128)]
+        self.wg = ops.workspace(max(lib.dtc_linear_wgrad_workspace(B, n, k) for n, k in shapes), dev)
+        self.loss_ws = ops.workspace(lib.dtc_loss_workspace(B), dev)
+
+
+class PPO:
+    actor_critic: ActorCriticDecoder
+
+    def __init__(self, actor_critic, num_learning_epochs=5, num_mini_batches=4, clip_param=0.2, gamma=0.99, lam=0.95,
+                 value_loss_coef=1.0, entropy_coef=0.01, learning_rate=5.e-4, max_grad_norm=1.0,
+                 use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01, device='cpu'):
+        self.device = device
+        self.desired_kl = desired_kl
+        self.schedule = schedule
+        self.learning_rate = learning_rate
+        self.actor_critic = actor_critic
+        self.actor_critic.to(self.device)
+        self.storage = None
+        if not hasattr(actor_critic, "vae"):
+            # same failure the reference has (ppo.py:79) -- only ActorCriticDecoder-like models train here
+            raise AttributeError(f"'{type(actor_critic).__name__}' object has no attribute 'vae'")
+        self.optimizer = None
+        self.vae_optimizer = None
+        if torch.device(device).type == "cuda":
+            self._build_optimizers()
+        self.transition = RolloutStorage.Transition()
+        self.clip_param = clip_param
+        self.num_learning_epochs = num_learning_epochs
+        self.num_mini_batches = num_mini_batches
+        self.value_loss_coef = value_loss_coef
+        self.entropy_coef = entropy_coef
+        self.gamma = gamma
+        self.lam = lam
+        self.max_grad_norm = max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+        self.num_adaptation_module_substeps = 1
+        self._tws = {}
+        self.capture_grads, self.captured = False, {}      # tests: snapshot of the (pre-clip) gradient arena
+        self.last_update_stats = None      # [steps, STAT_COLS] table of the last update (host tensor)
+
+    def _build_optimizers(self):
+        ac = self.actor_critic
+        arena = ac.ensure_arena()
+        arena._named = list(ac.named_parameters())
+        self.optimizer = FusedAdam(arena, arena.main_range, ac.parameters(), lr=self.learning_rate)   # ppo.py:78
+        self.vae_optimizer = FusedAdam(arena, arena.vae_range, ac.vae.parameters(), lr=5.e-4)          # ppo.py:79
+
+    def _require_gpu(self):
+        if self.optimizer is None:
+            raise _ffi.DtcError("dtc_amd.PPO computes on an MI355X only (device='cuda:N'); there is no CPU fallback")
+
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape,
+                     obs_history_shape, action_shape):
+        self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape,
+                                      obs_history_shape, action_shape, self.device)
+
+    def test_mode(self):
+        self.actor_critic.eval()
+
+    def train_mode(self):
+        self.actor_critic.train()
+
+    # ---------------------------------------------------------------- rollout side (ppo.py:137-172)
+    def act(self, obs, privileged_obs, obs_history, base_vel, rew_buf=None):
+        self._require_gpu()
+        ac, tr = self.actor_critic, self.transition
+        tr.actions = ac.act(obs, obs_history, privileged_obs, rew_buf).detach()
+        tr.values = ac.evaluate(obs, privileged_obs, base_vel).detach()
+        tr.actions_log_prob = ac.get_actions_log_prob(tr.actions).detach()
+        tr.action_mean = ac.action_mean.detach()
+        tr.action_sigma = ac.action_std.detach()
+        tr.observations = obs
+        tr.critic_observations = obs
+        tr.privileged_observations = privileged_obs
+        tr.observation_histories = obs_history
+        tr.base_vel = base_vel
+        return tr.actions
+
+    def process_env_step(self, rewards, dones, next_obs, infos):
+        tr = self.transition
+        tr.rewards = rewards.clone()
+        tr.dones = dones
+        tr.next_observations = next_obs
+        if 'time_outs' in infos:   # bootstrapping on time outs (ppo.py:162-163)
+            tr.rewards += self.gamma * torch.squeeze(tr.values * infos['time_outs'].unsqueeze(1).to(self.device), 1)
+        self.storage.add_transitions(tr)
+        tr.clear()
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs, last_critic_privileged_obs, last_base_vel):
+        self._require_gpu()
+        last_values = self.actor_critic.evaluate(last_critic_obs, last_critic_privileged_obs, last_base_vel).detach()
+        self.storage.compute_returns(last_values, self.gamma, self.lam)
+
+    # ---------------------------------------------------------------- update (ppo.py:174-357)
+    def _train_ws(self, B):
+        ws = self._tws.get(B)
+        if ws is None:
+            ws = self._tws[B] = _TrainWorkspace(B, self.actor_critic.std.device, self.actor_critic.num_actions)
+        return ws
+
+    @staticmethod
+    def _world():
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _allreduce_grads(self, opt):
+        w = self._world()
+        if w > 1:
+            dist.all_reduce(opt.g)
+            opt.g.mul_(1.0 / w)
+
+    def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None):
+        ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wg, M=tw.B)
+        if dX is not None:
+            ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B)
+
+    def _encoder_backward(self, fw, tw, flat, idx):
+        """Shared tail of both steps: d l_t -> terrain_encoder, d(mu|lv) -> heads -> cenet_encoder."""
+        L = self.actor_critic.L
+        self._bwd(tw, L["te2"], tw.dlt, fw.t2, tw.gA, fw.t2, "relu")
+        self._bwd(tw, L["te1"], tw.gA, fw.t1, tw.gB, fw.t1, "relu")
+        self._bwd(tw, L["te0"], tw.gB, segmat([seg(flat["privileged_observations"], 0, 693, gather=True)], idx))
+        self._bwd(tw, L["head"], tw.dmulv, fw.e, tw.g64, None, None)
+        self._bwd(tw, L["ce1"], tw.g64, fw.e1, tw.g128, fw.e1, "relu")
+        self._bwd(tw, L["ce0"], tw.g128, segmat([seg(flat["observation_histories"], 0, flat["observation_histories"].shape[1],
+                                                     gather=True)], idx))
+
+    def _vae_step(self, fw, tw, flat, idx, eps, stats):
+        """ppo.py:197-254: CE-net / terrain auto-encoder losses, backward, clip, Adam(5e-4)."""
+        ac = self.actor_critic
+        L = ac.L
+        ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
+        dec_in = segmat([seg(fw.z, 0, 16), seg(fw.mulv, 0, 3), seg(fw.lt, 0, 512)])
+        ops.linear_fwd(dec_in, L["cd0"].W, L["cd0"].b, tw.c1, "relu", M=tw.B)
+        ops.linear_fwd(tw.c1, L["cd1"].W, L["cd1"].b, tw.c2, "relu")
+        ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None)
+        ops.linear_fwd(fw.lt, L["td0"].W, L["td0"].b, tw.d1, "relu")
+        ops.linear_fwd(tw.d1, L["td1"].W, L["td1"].b, tw.d2, "relu")
+        ops.linear_fwd(tw.d2, L["td2"].W, L["td2"].b, tw.hr, None)
+        ops.vae_loss(tw.rec, tw.hr, fw.mulv, flat["next_observations"], flat["privileged_observations"],
+                     flat["base_vel"], idx, tw.g_rec, tw.g_hr, tw.dmulv, stats[S_RECONS:S_RECONS + 4], tw.loss_ws)
+        # terrain decoder
+        self._bwd(tw, L["td2"], tw.g_hr, tw.d2, tw.gA, tw.d2, "relu")
+        self._bwd(tw, L["td1"], tw.gA, tw.d1, tw.gB, tw.d1, "relu")
+        self._bwd(tw, L["td0"], tw.gB, fw.lt, tw.dlt, None, None)
+        # CE-net decoder; its input gradient fans out to z, mu[:, :3] and l_t
+        self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, tw.g128, tw.c2, "relu")
+        self._bwd(tw, L["cd1"], tw.g128, tw.c1, tw.g64, tw.c1, "relu")
+        dst = segmat([seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3, accumulate=True), seg(tw.dlt, 0, 512, accumulate=True)])
+        self._bwd(tw, L["cd0"], tw.g64, dec_in, dst, None, None)
+        ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
+        self._encoder_backward(fw, tw, flat, idx)
+        self._allreduce_grads(self.vae_optimizer)
+        if self.capture_grads:
+            self.captured["vae"] = ac.arena.grad.clone()
+        self.vae_optimizer.step(self.max_grad_norm, stats[S_VAE_GNORM:S_VAE_GNORM + 1])
+
+    def _ppo_step(self, fw, tw, flat, idx, eps, stats, cfg):
+        """ppo.py:265-335: policy / value forward with the freshly updated VAE, PPO losses, backward,
+        clip, Adam(adaptive lr)."""
+        ac = self.actor_critic
+        L = ac.L
+        act = AC_Args.activation
+        ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
+        ac.actor_forward_(fw, flat["observations"], idx)
+        ac.critic_forward_(fw, flat["observations"], flat["base_vel"], flat["privileged_observations"], idx)
+        world = self._world()
+        ops.ppo_loss(fw.mean, ac.std_view, fw.val, flat["actions"], flat["actions_log_prob"], flat["mu"],
+                     flat["sigma"], flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval,
+                     ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
+        if world > 1 and cfg.adaptive_schedule == 0 and self._adaptive():
+            dist.all_reduce(stats[S_KL:S_KL + 1])
+            stats[S_KL:S_KL + 1].mul_(1.0 / world)
+            ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
+        # critic
+        self._bwd(tw, L["c3"], tw.dval, fw.v3, tw.g128, fw.v3, act)
+        self._bwd(tw, L["c2"], tw.g128, fw.v2, tw.g256, fw.v2, act)
+        self._bwd(tw, L["c1"], tw.g256, fw.v1, tw.gA, fw.v1, act)
+        self._bwd(tw, L["c0"], tw.gA, ac.critic_input(flat["observations"], flat["base_vel"],
+                                                      flat["privileged_observations"], idx))
+        # actor; layer-0 input gradient fans out to z, mu[:, :3], l_t (observations need none)
+        self._bwd(tw, L["a3"], tw.dmean, fw.a3, tw.g128, fw.a3, act)
+        self._bwd(tw, L["a2"], tw.g128, fw.a2, tw.g256, fw.a2, act)
+        self._bwd(tw, L["a1"], tw.g256, fw.a1, tw.gA, fw.a1, act)
+        tw.dmulv.zero_()
+        dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
+        self._bwd(tw, L["a0"], tw.gA, ac.actor_input(fw, flat["observations"], idx), dst, None, None)
+        ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
+        self._encoder_backward(fw, tw, flat, idx)
+        self._allreduce_grads(self.optimizer)
+        if self.capture_grads:
+            self.captured["main"] = ac.arena.grad.clone()
+        self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])
+
+    def _adaptive(self):
+        return self.desired_kl is not None and self.schedule == 'adaptive'
+
+    def step_minibatch(self, idx, eps1, eps2, which="both", stats=None):
+        """One mini-batch of `update` on the stored rollout: the VAE step, the PPO step, or both
+        (`which` in {"vae", "ppo", "both"}); returns the statistics row (host tensor, columns S_*) and the
+        learning rate after adaptation.  Used by teacher-forced parity tests."""
+        self._require_gpu()
+        st, ac = self.storage, self.actor_critic
+        ac.ensure_arena()
+        dev = ac.std.device
+        idx = idx.to(dev).contiguous()
+        B = idx.numel()
+        flat = {k: st.flat(k) for k in self._FLAT_NAMES}
+        fw, tw = ac._fwd_ws(B), self._train_ws(B)
+        self.optimizer.set_lr(self.learning_rate)
+        stats = torch.zeros(STAT_COLS, dtype=torch.float32, device=dev) if stats is None else stats.to(dev)
+        if which in ("vae", "both"):
+            self._vae_step(fw, tw, flat, idx, eps1.to(dev).contiguous(), stats)
+        if which in ("ppo", "both"):
+            self._ppo_step(fw, tw, flat, idx, eps2.to(dev).contiguous(), stats, self._loss_cfg())
+        self.learning_rate = float(self.optimizer.lr_dev.item())
+        for g in self.optimizer.param_groups:
+            g['lr'] = self.learning_rate
+        return stats.cpu(), self.learning_rate
+
+    _FLAT_NAMES = ("observations", "next_observations", "privileged_observations", "observation_histories", "actions",
+                   "values", "advantages", "returns", "actions_log_prob", "mu", "sigma", "base_vel")
+
+    def _loss_cfg(self):
+        cfg = _ffi.DtcPpoCfg()
+        cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef = self.clip_param, self.value_loss_coef, self.entropy_coef
+        cfg.desired_kl = float(self.desired_kl) if self.desired_kl is not None else 0.0
+        cfg.use_clipped_value_loss = int(bool(self.use_clipped_value_loss))
+        cfg.adaptive_schedule = int(self._adaptive() and self._world() == 1)
+        return cfg
+
+    def update(self, perm=None, eps1=None, eps2=None, return_stats=False):
+        """One PPO update over the stored rollout.  `perm` / `eps1` / `eps2` optionally inject the random
+        draws the reference takes from torch's generator (rollout_storage.py:165, actor_critic_decoder.py:283)
+        so that parity tests can feed both implementations the same numbers."""
+        self._require_gpu()
+        st, ac = self.storage, self.actor_critic
+        ac.ensure_arena()
+        dev = ac.std.device
+        nmb, epochs = self.num_mini_batches, self.num_learning_epochs
+        B = (st.num_envs * st.num_transitions_per_env) // nmb
+        steps = nmb * epochs
+        if perm is None:
+            perm = torch.randperm(nmb * B, device=dev)
+        if eps1 is None:
+            eps1 = torch.randn(steps, B, 16, device=dev)
+        if eps2 is None:
+            eps2 = torch.randn(steps, B, 16, device=dev)
+        perm = perm.to(dev).contiguous()
+        flat = {k: st.flat(k) for k in self._FLAT_NAMES}
+        fw, tw = ac._fwd_ws(B), self._train_ws(B)
+        cfg = self._loss_cfg()
+        self.optimizer.set_lr(self.learning_rate)
+        stats = torch.zeros(steps, STAT_COLS, dtype=torch.float32, device=dev)
+        lr_hist = torch.zeros(steps, dtype=torch.float64, device=dev) if return_stats else None
+        k = 0
+        for _ in range(epochs):
+            for i in range(nmb):
+                idx = perm[i * B:(i + 1) * B]
+                self._vae_step(fw, tw, flat, idx, eps1[k], stats[k])
+                self._ppo_step(fw, tw, flat, idx, eps2[k], stats[k], cfg)
+                if lr_hist is not None:
+                    lr_hist[k:k + 1].copy_(self.optimizer.lr_dev)
+                k += 1
+        # the single device -> host synchronisation of the update
+        host = stats.cpu()
+        self.learning_rate = float(self.optimizer.lr_dev.item())
+        for g in self.optimizer.param_groups:
+            g['lr'] = self.learning_rate
+        self.last_update_stats = host
+        m = host.double().mean(dim=0)
+        st.clear()
+        out = (float(m[S_VALUE]), float(m[S_SURR]), 0.0, 0, float(m[S_RECONS]), float(m[S_VEL]), float(m[S_KLD]))
+        if return_stats:
+            return out, host, lr_hist.cpu()
+        return out

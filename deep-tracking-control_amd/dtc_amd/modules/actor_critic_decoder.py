@@ -1,0 +1,378 @@
+"""ActorCriticDecoder on hand-written HIP kernels.
+
+Same constructor, attribute names, `state_dict()` keys and initialisation order as the
+reference (rsl_rl/rsl_rl/modules/actor_critic_decoder.py:91-302 `Vae`, :305-451, :540-551
+`ActorCriticDecoder`), so reference checkpoints load and `torch.manual_seed(s)` gives the same
+initial weights.  Differences in *how* it computes:
+
+  * all parameters live in ONE flat fp32 device buffer (`ParamArena`) ordered so that each of
+    PPO's two optimisers (ppo.py:78-79) owns one contiguous range -> one fused clip+Adam launch,
+    one RCCL all-reduce per optimiser step; `nn.Parameter.data` are views into it;
+  * `latent_mu` and `latent_var` are adjacent in the arena and run as one [35,64] head GEMM;
+  * forward passes (`act`, `evaluate`, `act_inference`) call the C ABI (no autograd graph);
+    the training step (manual backward) is driven by `dtc_amd.algorithms.ppo.PPO`.
+There is no CPU path: calling a compute method without a GPU + libdtc_hip.so raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _ffi, ops
+from .._ffi import seg, segmat
+
+
+class AC_Args:
+    """Dimensions of the reference's AC_Args (actor_critic_decoder.py:11-88) that the hot path uses."""
+    init_noise_std = 1.0
+    actor_hidden_dims = [512, 256, 128]
+    critic_hidden_dims = [512, 256, 128]
+    activation = 'elu'
+    terrain_latent = 512
+    terrain_encoder_branch_input_dims = [693]
+    terrain_encoder_branch_latent_dims = [terrain_latent]
+    terrain_encoder_branch_hidden_dims = [[512, 512]]
+    terrain_decoder_branch_input_dims = [terrain_latent]
+    terrain_decoder_branch_output_dims = [693]
+    terrain_decoder_branch_hidden_dims = [[512, 512]]
+    cenet_encoder_branch_input_dims = [53 * 5]
+    cenet_encoder_branch_latent_dims = [64]
+    cenet_encoder_branch_hidden_dims = [[128]]
+    cenet_decoder_branch_input_dims = [19 + terrain_latent]
+    cenet_decoder_branch_output_dims = [53]
+    cenet_decoder_branch_hidden_dims = [[64, 128]]
+    gb_encoder_input_dims = [128]
+    gb_encoder_hidden_dims = [[128]]
+    gb_encoder_latent_dims = [64]
+    memory_mlp_input_dims = [53 * 5 + terrain_latent]
+    memory_mlp_hidden_dims = [[256, 128]]
+    memory_mlp_latent_dims = [terrain_latent]
+    rnn_type = 'gru'
+    rnn_num_layers = 2
+    rnn_hidden_size = 50
+
+
+def _layer_init(layer, std=np.sqrt(2), bias_const=0.0):
+    torch.nn.init.orthogonal_(layer.weight, std)
+    torch.nn.init.constant_(layer.bias, bias_const)
+    return layer
+
+
+def _branch(in_dim, hidden, out_dim, act):
+    """Linear(default init) -> act -> [Linear(orthogonal 0.01) -> act]* -> Linear(orthogonal 0.01)."""
+    dims = [in_dim] + list(hidden) + [out_dim]
+    mods = [nn.Linear(dims[0], dims[1]), act]
+    for i in range(1, len(dims) - 1):
+        mods.append(_layer_init(nn.Linear(dims[i], dims[i + 1]), 0.01))
+        if i < len(dims) - 2:
+            mods.append(act)
+    return nn.Sequential(*mods)
+
+
+def get_activation(act_name):
+    table = dict(elu=nn.ELU, selu=nn.SELU, relu=nn.ReLU, crelu=nn.ReLU, lrelu=nn.LeakyReLU, tanh=nn.Tanh,
+                 sigmoid=nn.Sigmoid)
+    if act_name not in table:
+        print("invalid activation function!")
+        return None
+    return table[act_name]()
+
+
+class Dense:
+    """One nn.Linear as seen by the kernels: views of weight/bias/grads inside the arena."""
+    __slots__ = ("W", "b", "gW", "gb", "act", "n_out", "n_in")
+
+    def __init__(self, W, b, gW, gb, act):
+        self.W, self.b, self.gW, self.gb, self.act = W, b, gW, gb, act
+        self.n_out, self.n_in = W.shape
+
+
+class ParamArena:
+    """Flat parameter / gradient buffers.  Layout (element offsets):
+        [ main-only: actor_body, critic_body, std | shared: cenet_encoder, (latent_mu|latent_var),
+          terrain_encoder | vae-only: cenet_decoder, terrain_decoder | unused: memory_mlp, gb_encoder ]
+    main optimiser range = [0, end(shared));  VAE optimiser range = [start(shared), end(vae-only)).
+    The parameters of `unused` never receive a gradient in PPO.update."""
+
+    def __init__(self, model: "ActorCriticDecoder"):
+        named = dict(model.named_parameters())
+        order, groups = [], {}
+
+        def take(prefix):
+            return [k for k in named if k.startswith(prefix)]
+
+        main_only = take("actor_body.") + take("critic_body.") + ["std"]
+        heads = ["vae.latent_mu.weight", "vae.latent_var.weight", "vae.latent_mu.bias", "vae.latent_var.bias"]
+        shared = take("vae.cenet_encoder.") + heads + take("vae.terrain_encoder.")
+        vae_only = take("vae.cenet_decoder.") + take("vae.terrain_decoder.")
+        unused = take("vae.memory_mlp.") + take("vae.gb_encoder.")
+        order = main_only + shared + vae_only + unused
+        assert sorted(order) == sorted(named), "parameter partition is incomplete"
+        device = named["std"].device
+        total = sum(named[k].numel() for k in order)
+        self.flat = torch.empty(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.offsets, off = {}, 0
+        for k in order:
+            p = named[k]
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view(p.shape)
+            self.offsets[k] = (off, n, tuple(p.shape))
+            off += n
+        n_main = sum(named[k].numel() for k in main_only)
+        n_shared = sum(named[k].numel() for k in shared)
+        n_vae = sum(named[k].numel() for k in vae_only)
+        self.main_range = (0, n_main + n_shared)
+        self.vae_range = (n_main, n_main + n_shared + n_vae)
+        self.order = order
+
+    def view(self, buf, name):
+        off, n, shape = self.offsets[name]
+        return buf[off:off + n].view(shape)
+
+    def dense(self, wname, bname, act, rows=None):
+        W, gW = self.view(self.flat, wname), self.view(self.grad, wname)
+        b, gb = self.view(self.flat, bname), self.view(self.grad, bname)
+        return Dense(W, b, gW, gb, act)
+
+    def fused_head(self):
+        """latent_mu (19) and latent_var (16) as one [35,64] layer (adjacent in the arena)."""
+        o_w = self.offsets["vae.latent_mu.weight"][0]
+        o_b = self.offsets["vae.latent_mu.bias"][0]
+        assert self.offsets["vae.latent_var.weight"][0] == o_w + 19 * 64
+        assert self.offsets["vae.latent_var.bias"][0] == o_b + 19
+        mk = lambda buf: (buf[o_w:o_w + 35 * 64].view(35, 64), buf[o_b:o_b + 35])
+        (W, b), (gW, gb) = mk(self.flat), mk(self.grad)
+        return Dense(W, b, gW, gb, None)
+
+
+class Vae(nn.Module):
+    def __init__(self, **kwargs):
+        super().__init__()
+        A = AC_Args
+        relu = nn.ReLU()
+        self.cenet_encoder = _branch(A.cenet_encoder_branch_input_dims[0], A.cenet_encoder_branch_hidden_dims[0],
+                                     A.cenet_encoder_branch_latent_dims[0], relu)
+        self.latent_mu = _layer_init(nn.Linear(16 * 4, 19), 0.01)
+        self.latent_var = _layer_init(nn.Linear(16 * 4, 16), 0.01)
+        self.cenet_decoder = _branch(A.cenet_decoder_branch_input_dims[0], A.cenet_decoder_branch_hidden_dims[0],
+                                     A.cenet_decoder_branch_output_dims[0], relu)
+        self.terrain_encoder = _branch(A.terrain_encoder_branch_input_dims[0], A.terrain_encoder_branch_hidden_dims[0],
+                                       A.terrain_encoder_branch_latent_dims[0], relu)
+        self.terrain_decoder = _branch(A.terrain_decoder_branch_input_dims[0], A.terrain_decoder_branch_hidden_dims[0],
+                                       A.terrain_decoder_branch_output_dims[0], relu)
+        self.memory_mlp = _branch(A.memory_mlp_input_dims[0], A.memory_mlp_hidden_dims[0],
+                                  A.memory_mlp_latent_dims[0], relu)
+        # the reference builds and discards a 64->128->693 stack at this point
+        # (actor_critic_decoder.py:209-228); it draws from the init RNG, so the same draws are made here
+        _branch(64, [128], 693, relu)
+        self.gb_encoder = _branch(A.gb_encoder_input_dims[0], A.gb_encoder_hidden_dims[0],
+                                  A.gb_encoder_latent_dims[0], relu)
+
+    @staticmethod
+    def layer_init(layer, std=np.sqrt(2), bias_const=0.0):
+        return _layer_init(layer, std, bias_const)
+
+
+class ActorCriticDecoder(nn.Module):
+    is_recurrent = False
+
+    def __init__(self, num_obs, num_critic_obs, num_actions, **kwargs):
+        if kwargs:
+            print("ActorCritic.__init__ got unexpected arguments, which will be ignored: "
+                  + str([key for key in kwargs.keys()]))
+        super().__init__()
+        A = AC_Args
+        act = get_activation(A.activation)
+        self.num_obs, self.num_critic_obs, self.num_actions = num_obs, num_critic_obs, num_actions
+        self.vae = Vae()
+        self.bootstrap_threshold = 0.1
+        self.actor_body = _branch(num_obs + 16 + 3 + A.terrain_encoder_branch_latent_dims[0], A.actor_hidden_dims,
+                                  num_actions, act)
+        self.critic_body = _branch(693 + num_obs + 3 + 15 + 12 - 24, A.critic_hidden_dims, 1, act)
+        self.std = nn.Parameter(A.init_noise_std * torch.ones(num_actions))
+        self.distribution = None
+        self.arena: ParamArena | None = None
+        self._fw = {}            # forward workspaces keyed by batch size
+        self._dist = None        # (mean, sigma) of the last update_distribution
+
+    # ------------------------------------------------------------------ arena management
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.arena = None        # .to()/.cuda() re-allocates parameter storage; rebuild lazily
+        self._fw = {}
+        return out
+
+    def ensure_arena(self) -> ParamArena:
+        if self.arena is None or self.arena.flat.device != self.std.device or \
+                self.std.data_ptr() != self.arena.view(self.arena.flat, "std").data_ptr():
+            if not self.std.is_cuda:
+                raise _ffi.DtcError("ActorCriticDecoder computes on the GPU only: move it to a HIP device "
+                                    "(there is no CPU fallback)")
+            self.arena = ParamArena(self)
+            ar = self.arena
+            relu, elu = "relu", AC_Args.activation
+            d = ar.dense
+            self.L = dict(
+                ce0=d("vae.cenet_encoder.0.weight", "vae.cenet_encoder.0.bias", relu),
+                ce1=d("vae.cenet_encoder.2.weight", "vae.cenet_encoder.2.bias", None),
+                head=ar.fused_head(),
+                te0=d("vae.terrain_encoder.0.weight", "vae.terrain_encoder.0.bias", relu),
+                te1=d("vae.terrain_encoder.2.weight", "vae.terrain_encoder.2.bias", relu),
+                te2=d("vae.terrain_encoder.4.weight", "vae.terrain_encoder.4.bias", None),
+                cd0=d("vae.cenet_decoder.0.weight", "vae.cenet_decoder.0.bias", relu),
+                cd1=d("vae.cenet_decoder.2.weight", "vae.cenet_decoder.2.bias", relu),
+                cd2=d("vae.cenet_decoder.4.weight", "vae.cenet_decoder.4.bias", None),
+                td0=d("vae.terrain_decoder.0.weight", "vae.terrain_decoder.0.bias", relu),
+                td1=d("vae.terrain_decoder.2.weight", "vae.terrain_decoder.2.bias", relu),
+                td2=d("vae.terrain_decoder.4.weight", "vae.terrain_decoder.4.bias", None),
+                a0=d("actor_body.0.weight", "actor_body.0.bias", elu),
+                a1=d("actor_body.2.weight", "actor_body.2.bias", elu),
+                a2=d("actor_body.4.weight", "actor_body.4.bias", elu),
+                a3=d("actor_body.6.weight", "actor_body.6.bias", None),
+                c0=d("critic_body.0.weight", "critic_body.0.bias", elu),
+                c1=d("critic_body.2.weight", "critic_body.2.bias", elu),
+                c2=d("critic_body.4.weight", "critic_body.4.bias", elu),
+                c3=d("critic_body.6.weight", "critic_body.6.bias", None),
+            )
+            self.std_view = ar.view(ar.flat, "std")
+            self.std_grad = ar.view(ar.grad, "std")
+        return self.arena
+
+    # ------------------------------------------------------------------ forward workspace
+    class _Fwd:
+        def __init__(self, B, dev, num_actions):
+            e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            self.B = B
+            self.e1, self.e, self.mulv, self.z = e(B, 128), e(B, 64), e(B, 35), e(B, 16)
+            self.mask = torch.empty(B, 16, dtype=torch.uint8, device=dev)
+            self.info = torch.zeros(4, dtype=torch.int32, device=dev)
+            self.t1, self.t2, self.lt = e(B, 512), e(B, 512), e(B, 512)
+            self.a1, self.a2, self.a3, self.mean = e(B, 512), e(B, 256), e(B, 128), e(B, num_actions)
+            self.v1, self.v2, self.v3, self.val = e(B, 512), e(B, 256), e(B, 128), e(B, 1)
+            self.lat_ws = torch.empty(int(_ffi.lib().dtc_cenet_workspace(B)) // 8 + 1, dtype=torch.float64, device=dev)
+
+    def _fwd_ws(self, B):
+        ws = self._fw.get(B)
+        if ws is None:
+            ws = self._fw[B] = ActorCriticDecoder._Fwd(B, self.std.device, self.num_actions)
+        return ws
+
+    # ------------------------------------------------------------------ kernel-level forward pieces
+    def cenet_forward_(self, ws, hist, eps, idx=None):
+        """vae.cenet_forward (actor_critic_decoder.py:286-302) into ws.mulv / ws.z."""
+        L = self.L
+        X = segmat([seg(hist, 0, hist.shape[1], gather=idx is not None)], idx)
+        ops.linear_fwd(X, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=ws.B)
+        ops.linear_fwd(ws.e1, L["ce1"].W, L["ce1"].b, ws.e, None)
+        ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None)
+        ops.cenet_latent_fwd(ws.mulv, eps, ws.z, ws.mask, ws.info, ws.lat_ws)
+
+    def terrain_encoder_(self, ws, priv, idx=None):
+        L = self.L
+        X = segmat([seg(priv, 0, 693, gather=idx is not None)], idx)
+        ops.linear_fwd(X, L["te0"].W, L["te0"].b, ws.t1, "relu", M=ws.B)
+        ops.linear_fwd(ws.t1, L["te1"].W, L["te1"].b, ws.t2, "relu")
+        ops.linear_fwd(ws.t2, L["te2"].W, L["te2"].b, ws.lt, None)
+
+    def actor_input(self, ws, obs, idx=None):
+        return segmat([seg(obs, 0, self.num_obs, gather=idx is not None), seg(ws.z, 0, 16), seg(ws.mulv, 0, 3),
+                       seg(ws.lt, 0, 512)], idx)
+
+    def critic_input(self, obs, base_vel, priv, idx=None):
+        g = idx is not None
+        return segmat([seg(obs, 0, self.num_obs, gather=g), seg(base_vel, 0, 3, gather=g),
+                       seg(priv, 693, 696, gather=g)], idx)
+
+    def actor_forward_(self, ws, obs, idx=None):
+        L, act = self.L, AC_Args.activation
+        ops.linear_fwd(self.actor_input(ws, obs, idx), L["a0"].W, L["a0"].b, ws.a1, act, M=ws.B)
+        ops.linear_fwd(ws.a1, L["a1"].W, L["a1"].b, ws.a2, act)
+        ops.linear_fwd(ws.a2, L["a2"].W, L["a2"].b, ws.a3, act)
+        ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None)
+
+    def critic_forward_(self, ws, obs, base_vel, priv, idx=None):
+        L, act = self.L, AC_Args.activation
+        ops.linear_fwd(self.critic_input(obs, base_vel, priv, idx), L["c0"].W, L["c0"].b, ws.v1, act, M=ws.B)
+        ops.linear_fwd(ws.v1, L["c1"].W, L["c1"].b, ws.v2, act)
+        ops.linear_fwd(ws.v2, L["c2"].W, L["c2"].b, ws.v3, act)
+        ops.linear_fwd(ws.v3, L["c3"].W, L["c3"].b, ws.val, None)
+
+    # ------------------------------------------------------------------ reference API
+    def reset(self, dones=None):
+        pass
+
+    def forward(self):
+        raise NotImplementedError
+
+    @property
+    def action_mean(self):
+        return self._dist[0]
+
+    @property
+    def action_std(self):
+        return self._dist[1]
+
+    @property
+    def entropy(self):
+        s = self._dist[1]
+        return (0.5 + 0.5 * float(np.log(2 * np.pi)) + torch.log(s)).sum(dim=-1)
+
+    def _prep(self, t):
+        return t.contiguous().float()
+
+    def update_distribution(self, observations, observations_history, privileged_obs, eps=None):
+        """actor_critic_decoder.py:409-437.  `eps` ([B,16], optional) injects the reparameterisation noise."""
+        self.ensure_arena()
+        obs, hist, priv = self._prep(observations), self._prep(observations_history), self._prep(privileged_obs)
+        B = obs.shape[0]
+        ws = self._fwd_ws(B)
+        if eps is None:
+            eps = torch.randn(B, 16, device=obs.device)
+        self.cenet_forward_(ws, hist, eps)
+        self.terrain_encoder_(ws, priv)
+        self.actor_forward_(ws, obs)
+        self.latent_mu, self.latent_var, self.z = ws.mulv[:, :19], ws.mulv[:, 19:], ws.z
+        mean = ws.mean.clone()
+        self._dist = (mean, self.std_view.detach().expand_as(mean))
+        self.distribution = self._dist
+
+    def act(self, observations, observations_history, privileged_obs, rew_buf=None, eps=None, noise=None, **kwargs):
+        """actor_critic_decoder.py:439-447: sample from N(mean, std)."""
+        self.update_distribution(observations, observations_history, privileged_obs, eps=eps)
+        mean = self._dist[0]
+        B, A = mean.shape
+        if noise is None:
+            noise = torch.randn(B, A, device=mean.device)
+        actions = torch.empty_like(mean)
+        self._logp = torch.empty(B, device=mean.device)
+        ops.gaussian_act(mean, self.std_view, noise, actions, self._logp)
+        self._last_actions = actions
+        return actions
+
+    def get_actions_log_prob(self, actions):
+        """actor_critic_decoder.py:450-451."""
+        mean, sigma = self._dist
+        if getattr(self, "_last_actions", None) is actions:
+            return self._logp
+        return (-((actions - mean) ** 2) / (2 * sigma * sigma) - torch.log(sigma)
+                - float(np.log(np.sqrt(2 * np.pi)))).sum(dim=-1)
+
+    def act_expert(self, ob):
+        return self.act_teacher(ob["obs"], ob["obs_history"], ob["privileged_obs"])
+
+    def act_inference(self, ob):
+        """Deterministic policy output (mean action) for deployment-style evaluation."""
+        self.update_distribution(ob["obs"], ob["obs_history"], ob["privileged_obs"],
+                                 eps=torch.zeros(ob["obs"].shape[0], 16, device=ob["obs"].device))
+        return self._dist[0]
+
+    def evaluate(self, critic_observations, privileged_observations, base_vel, **kwargs):
+        """actor_critic_decoder.py:540-551."""
+        self.ensure_arena()
+        obs, priv, bv = self._prep(critic_observations), self._prep(privileged_observations), self._prep(base_vel)
+        ws = self._fwd_ws(obs.shape[0])
+        self.critic_forward_(ws, obs, bv, priv)
+        return ws.val.clone()

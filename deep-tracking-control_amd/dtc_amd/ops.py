@@ -85,3 +85,55 @@ def linear_wgrad(dZ, X, dW, db, workspace, M=None):
         raise _ffi.DtcError(f"wgrad workspace too small: {workspace.numel() * workspace.element_size()} < {need}")
     check(lib().dtc_linear_wgrad(ptr(dZ), dZ.stride(0), Xs, cptr(dW, f32), cptr(db, f32) if db is not None else None,
                                  ptr(workspace), M, N, K, stream()), "dtc_linear_wgrad")
+
+
+# ---------------------------------------------------------------- CE-net latent / losses / optimiser
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """8-byte aligned scratch of at least `nbytes` bytes."""
+    return torch.empty(max(1, (int(nbytes) + 7) // 8), dtype=torch.float64, device=device)
+
+
+def cenet_latent_fwd(mulv, eps, z, mask, info, ws):
+    B = mulv.shape[0]
+    check(lib().dtc_cenet_latent_fwd(cptr(mulv, f32), cptr(eps, f32), cptr(z, f32), cptr(mask, torch.uint8),
+                                     cptr(info, torch.int32), ptr(ws), B, stream()), "dtc_cenet_latent_fwd")
+
+
+def cenet_latent_bwd(dmulv, dz, eps, mulv, mask, info, ws):
+    B = mulv.shape[0]
+    check(lib().dtc_cenet_latent_bwd(cptr(dmulv, f32), cptr(dz, f32), cptr(eps, f32), cptr(mulv, f32),
+                                     cptr(mask, torch.uint8), cptr(info, torch.int32), ptr(ws), B, stream()),
+          "dtc_cenet_latent_bwd")
+
+
+def vae_loss(recons, hrecon, mulv, next_obs, priv, base_vel, idx, d_recons, d_hrecon, dmulv, losses, ws):
+    B = recons.shape[0]
+    check(lib().dtc_vae_loss(cptr(recons, f32), cptr(hrecon, f32), cptr(mulv, f32), cptr(next_obs, f32),
+                             cptr(priv, f32), cptr(base_vel, f32), cptr(idx, torch.int64), cptr(d_recons, f32),
+                             cptr(d_hrecon, f32), cptr(dmulv, f32), ptr(losses), ptr(ws), B, stream()), "dtc_vae_loss")
+
+
+def ppo_loss(mean, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, old_values, idx, cfg,
+             dmean, dvalue, dstd, losses, lr, ws):
+    B, A = mean.shape
+    check(lib().dtc_ppo_loss(cptr(mean, f32), ptr(std), cptr(value, f32), cptr(actions, f32), cptr(old_logp, f32),
+                             cptr(old_mu, f32), cptr(old_sigma, f32), cptr(advantages, f32), cptr(returns, f32),
+                             cptr(old_values, f32), cptr(idx, torch.int64) if idx is not None else None, cfg,
+                             cptr(dmean, f32), cptr(dvalue, f32), ptr(dstd), ptr(losses), ptr(lr), ptr(ws), B, A,
+                             stream()), "dtc_ppo_loss")
+
+
+def gaussian_act(mean, std, noise, actions, logp, mu_out=None, sigma_out=None):
+    B, A = mean.shape
+    check(lib().dtc_gaussian_act(cptr(mean, f32), ptr(std), cptr(noise, f32), cptr(actions, f32), cptr(logp, f32),
+                                 ptr(mu_out), ptr(sigma_out), B, A, stream()), "dtc_gaussian_act")
+
+
+def clip_adam(params, grads, exp_avg, exp_avg_sq, max_grad_norm, lr, beta1, beta2, eps, step, gnorm_out, ws):
+    n = params.numel()
+    check(lib().dtc_clip_adam(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), n, max_grad_norm, ptr(lr),
+                              beta1, beta2, eps, step, ptr(gnorm_out), ptr(ws), stream()), "dtc_clip_adam")
+
+
+def lr_adapt(kl_mean, lr, desired_kl):
+    check(lib().dtc_lr_adapt(ptr(kl_mean), ptr(lr), desired_kl, stream()), "dtc_lr_adapt")

@@ -1,0 +1,78 @@
+"""Debug helper: run one mini-batch step with both learning rates at 0 and check the backward
+intermediates of the terrain-encoder chain against fp64 torch matmuls on the device."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "deep-tracking-control_amd"))
+from dtc_amd import synthetic as S
+from dtc_amd.algorithms import PPO
+from dtc_amd.modules import ActorCriticDecoder
+from oracle import ppo_ref as OP
+
+DEV = "cuda:0"
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+torch.manual_seed(3)
+ref_ac = OP.fill_parameters_(OP.RefActorCriticDecoder(), 11)
+ac = ActorCriticDecoder(53, 1389, 12)
+alg = PPO(ac, learning_rate=0.0, entropy_coef=0.003, schedule="fixed", device=DEV)
+alg.init_storage(N, 24, [53], [1389], [265], [12])
+ac.load_state_dict(ref_ac.state_dict())
+d = S.rollout(N, 24, seed=4)
+for k, v in d.items():
+    if k != "last_values":
+        getattr(alg.storage, k).copy_(v.to(DEV))
+alg.storage.compute_returns(d["last_values"].to(DEV), 0.99, 0.95)
+perm, e1, e2 = S.update_noise(N, 24, 4, 5, seed=123)
+B = N * 24 // 4
+alg.vae_optimizer.set_lr(0.0)
+alg.capture_grads = True
+alg.step_minibatch(perm[:B], e1[0], e2[0])
+fw, tw, L = ac._fwd_ws(B), alg._train_ws(B), ac.L
+g = alg.captured["main"]
+ar = ac.arena
+def rel(a, b):
+    return float((a.double() - b).abs().max() / (b.abs().max() + 1e-30))
+D = lambda t: t.double()
+gA_exp = (D(tw.dlt) @ D(L["te2"].W)) * (fw.t2 > 0)
+print("gA (te2 dgrad)     rel err", rel(tw.gA, gA_exp))
+gB_exp = (D(tw.gA) @ D(L["te1"].W)) * (fw.t1 > 0)
+print("gB (te1 dgrad)     rel err", rel(tw.gB, gB_exp), " vs chained exp", rel(tw.gB, (gA_exp @ D(L["te1"].W)) * (fw.t1 > 0)))
+print("gW te2             rel err", rel(ar.view(g, "vae.terrain_encoder.4.weight"), D(tw.dlt).t() @ D(fw.t2)))
+print("gW te1 (from gA)   rel err", rel(ar.view(g, "vae.terrain_encoder.2.weight"), D(tw.gA).t() @ D(fw.t1)))
+print("gW te1 (from exp)  rel err", rel(ar.view(g, "vae.terrain_encoder.2.weight"), gA_exp.t() @ D(fw.t1)))
+priv = alg.storage.flat("privileged_observations")[perm[:B].to(DEV)][:, :693]
+print("gW te0 (from gB)   rel err", rel(ar.view(g, "vae.terrain_encoder.0.weight"), D(tw.gB).t() @ D(priv)))
+print("gb te1             rel err", rel(ar.view(g, "vae.terrain_encoder.2.bias"), D(tw.gA).sum(0)))
+# where is gA wrong?
+bad = ((tw.gA.double() - gA_exp).abs() > 1e-6 * gA_exp.abs().max()).nonzero()
+print("bad gA elements:", bad.shape[0], bad[:10].tolist())
+if bad.shape[0]:
+    r, c = bad[0].tolist()
+    print("  got", float(tw.gA[r, c]), "exp", float(gA_exp[r, c]), "t2", float(fw.t2[r, c]), "unmasked", float((D(tw.dlt) @ D(L['te2'].W))[r, c]))
+
+# ---- compare with the oracle at lr = 0 (weights never move)
+ref = OP.RefPPO(ref_ac, learning_rate=0.0, entropy_coef=0.003, schedule="fixed")
+for gph in ref.vae_optimizer.param_groups:
+    gph["lr"] = 0.0
+ref.init_storage(N, 24)
+for k, v in d.items():
+    if k != "last_values":
+        getattr(ref.storage, k).copy_(v)
+ref.storage.compute_returns(d["last_values"], 0.99, 0.95)
+ref.capture_grads = True
+rec = ref.step(perm[:B], e1[0], e2[0])
+rows = []
+for which, key in (("vae", "vae_grads"), ("main", "grads")):
+    for name, g_ref in rec.extra[key].items():
+        gm = ar.view(alg.captured[which], name).cpu()
+        scale = float(g_ref.abs().max()) + 1e-30
+        rows.append((float((gm - g_ref).abs().max()) / scale, which, name))
+rows.sort(reverse=True)
+for r in rows[:6]:
+    print("grad err vs oracle @lr=0:", r)
+with torch.no_grad():
+    pr = ref.storage.privileged_observations.flatten(0, 1)[perm[:B]][:, :693]
+    te = ref_ac.vae.terrain_encoder
+    t1r = torch.relu(te[0](pr)); t2r = torch.relu(te[2](t1r)); ltr = te[4](t2r)
+print("t1 mask mismatches", int(((fw.t1.cpu() > 0) != (t1r > 0)).sum()), "t2:", int(((fw.t2.cpu() > 0) != (t2r > 0)).sum()),
+      "max|t2 diff|", float((fw.t2.cpu() - t2r).abs().max()), "lt diff", float((fw.lt.cpu() - ltr).abs().max()))

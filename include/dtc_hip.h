@@ -145,6 +145,9 @@ int dtc_ppo_loss(const float* mean, const float* std, const float* value, const 
                  const float* returns, const float* old_values, const int64_t* idx, const DtcPpoCfg* cfg,
                  float* dmean, float* dvalue, float* dstd, float* losses, double* lr, void* workspace,
                  int B, int num_actions, void* stream);
+/* The learning-rate rule of ppo.py:301-307 alone (data-parallel callers run dtc_ppo_loss with
+ * adaptive_schedule = 0, all-reduce the KL mean, then call this so every rank takes the same branch). */
+int dtc_lr_adapt(const float* kl_mean, double* lr, float desired_kl, void* stream);
 /* log-prob / sampling side of PPO.act (ppo.py:137-150): actions = mean + std*noise,
  * logp = sum_j log N(a; mean, std). */
 int dtc_gaussian_act(const float* mean, const float* std, const float* noise, float* actions,

@@ -67,6 +67,7 @@ class RefVae(nn.Module):
         thr = 2 * std
         outliers = (lv < (mean - thr)) | (lv > (mean + thr))
         median = lv[~outliers].median()
+        self.last_outliers, self.last_median = int(outliers.sum()), float(median)     # for the parity tests
         lv[outliers] = median
         z = eps * torch.exp(0.5 * lv) + mu[:, 3:]
         return mu, lv, z
@@ -177,6 +178,11 @@ class RefPPO:
         self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
         self.schedule, self.desired_kl = schedule, desired_kl
         self.storage = None
+        self.capture_grads = False      # tests: keep the pre-clip gradients of both steps in StepRecord.extra
+        self.relu_masks = {}            # tests: name -> (output > 0) of every ReLU of the VAE, last forward
+        for name, mod in actor_critic.vae.named_modules():
+            if isinstance(mod, nn.ReLU):
+                mod.register_forward_hook(lambda m, i, o, name=name: self.relu_masks.__setitem__(name, (o > 0).detach()))
 
     def init_storage(self, num_envs, num_steps):
         self.storage = RefStorage(num_envs, num_steps)
@@ -199,12 +205,17 @@ class RefPPO:
 
     # ---- one mini-batch of PPO.update (ppo.py:189-338) ---------------------------------
     def step(self, idx, eps1, eps2) -> StepRecord:
+        rec = StepRecord()
+        self.vae_step(idx, eps1, rec)
+        self.ppo_step(idx, eps2, rec)
+        return rec
+
+    def vae_step(self, idx, eps1, rec: StepRecord) -> StepRecord:
+        """First half of a mini-batch (ppo.py:197-258)."""
         ac, vae = self.actor_critic, self.actor_critic.vae
         (obs, critic_obs, priv, hist, actions, target_values, advantages, returns, old_logp, old_mu,
          old_sigma, base_vel, next_obs, _, _, _) = self.storage.gather(idx)
-        rec = StepRecord()
 
-        # -- VAE step (ppo.py:197-258)
         mu, lv, z = vae.cenet_forward(hist, eps1)
         l_t = vae.terrain_encoder(priv[:, :N_HEIGHT])
         recons = vae.cenet_decoder(torch.cat([z, mu[:, :3], l_t], dim=1))
@@ -216,12 +227,20 @@ class RefPPO:
         vae_loss = recons_loss + vel_loss + 4 * kld_loss + height_loss
         self.vae_optimizer.zero_grad()
         vae_loss.backward()
+        if self.capture_grads:
+            rec.extra["vae_grads"] = {k: p.grad.clone() for k, p in ac.named_parameters()
+                                      if p.grad is not None and k.startswith("vae.")}
         rec.vae_gnorm = float(nn.utils.clip_grad_norm_(vae.parameters(), self.max_grad_norm))
         self.vae_optimizer.step()
         rec.recons, rec.vel, rec.kld, rec.height = (recons_loss.item(), vel_loss.item(), kld_loss.item(),
                                                     height_loss.item())
+        return rec
 
-        # -- PPO step (ppo.py:265-338); weights of the VAE are the freshly updated ones
+    def ppo_step(self, idx, eps2, rec: StepRecord) -> StepRecord:
+        """Second half of a mini-batch (ppo.py:265-338); the VAE weights are the freshly updated ones."""
+        ac, vae = self.actor_critic, self.actor_critic.vae
+        (obs, critic_obs, priv, hist, actions, target_values, advantages, returns, old_logp, old_mu,
+         old_sigma, base_vel, next_obs, _, _, _) = self.storage.gather(idx)
         mean = ac.policy_mean(obs, hist, priv, eps2)
         dist = torch.distributions.Normal(mean, mean * 0. + ac.std)
         logp = dist.log_prob(actions).sum(dim=-1)
@@ -256,6 +275,8 @@ class RefPPO:
         loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
         self.optimizer.zero_grad()
         loss.backward()
+        if self.capture_grads:
+            rec.extra["grads"] = {k: p.grad.clone() for k, p in ac.named_parameters() if p.grad is not None}
         rec.gnorm = float(nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm))
         self.optimizer.step()
         rec.surrogate, rec.value, rec.entropy = surrogate_loss.item(), value_loss.item(), entropy.mean().item()
