@@ -4,34 +4,45 @@
 //
 // All three products run on v_mfma_f32_32x32x2_f32 (exact fp32: bitwise a k-ordered fmaf
 // chain, 157.3 TFLOP/s peak, there is no xf32/TF32 on gfx950).  The instruction takes 64
-// cycles per issue, so the kernels are MFMA-bound by a wide margin (one 128x128x16 block step
-// = 2048 MFMA cycles per SIMD against 16 dword loads + 32 LDS reads per lane); the design
-// therefore spends its freedom on *removing HBM passes*, not on staging tricks:
-//   - torch.cat([...], dim=1) operands (ppo.py:201, actor_critic_decoder.py:431,550) and the
-//     mini-batch gather `tensor[batch_idx]` (rollout_storage.py:195-209) are folded into the
-//     operand loader through a "segmented matrix" descriptor (DtcSegMat): up to 4 column
-//     blocks, each optionally row-gathered.  Neither the cat nor the gathered batch exists in HBM.
-//   - bias + ReLU/ELU are fused into the forward epilogue; the activation derivative is fused
-//     into the data-gradient epilogue (needs only the saved post-activation output); the bias
-//     gradient (column sums of dZ) is accumulated by the weight-gradient kernel while it stages
-//     dZ, so no extra pass over dZ exists.
-//   - K and N tails (53, 265, 531, 584, 693, 752, 12, 1 ...) are zero-padded in LDS, never in HBM.
-// Tiling: 256 threads = 4 waves; block tile 128 x {128,64,32}; each wave owns 32x32 MFMA
-// sub-tiles (2x2, 1x2 or 1x1); K step 16; LDS tiles are stored [k][row] (+4 pad) so every MFMA
-// operand read is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave;
-// double-buffered LDS with register-staged prefetch -> one barrier per K step.
-// Workgroup -> tile mapping is XCD-aware (block b runs on XCD b%8): all column tiles of one row
-// panel are issued on the same XCD so the panel is fetched from HBM once and re-read from
-// that XCD's L2.
+// cycles per issue, so one 128x128x16 block step is 2048 MFMA cycles per SIMD against 16 dword
+// loads + 16 LDS writes + 16 LDS reads per lane: the kernels are MFMA-bound *if* the non-matrix
+// instructions stay out of the way.  The design therefore
+//   (1) removes HBM passes instead of polishing them:
+//       - torch.cat([...], dim=1) operands (ppo.py:201, actor_critic_decoder.py:431,550) and the
+//         mini-batch gather `tensor[batch_idx]` (rollout_storage.py:195-209) are folded into the
+//         operand loader through a "segmented matrix" descriptor (DtcSegMat): up to 4 column
+//         blocks, each optionally row-gathered.  Neither the cat nor the gathered batch exists in HBM;
+//       - bias + ReLU/ELU are fused into the forward epilogue; the activation derivative is fused
+//         into the data-gradient epilogue (needs only the saved post-activation output); the bias
+//         gradient (column sums of dZ) is accumulated by the weight-gradient kernel while it stages
+//         dZ, so no extra pass over dZ exists;
+//       - K and N tails (53, 265, 531, 584, 693, 752, 12, 1 ...) are zero-padded in LDS, never in HBM;
+//   (2) keeps address arithmetic out of the K loop: every operand load is a raw buffer load
+//       `descriptor (SGPRs) + uniform step offset (SGPR) + loop-invariant 32-bit lane offset (VGPR)`; the K
+//       loop of a segmented operand runs segment by segment (tiles are aligned to segment starts); row and
+//       k tails use an out-of-range lane offset, for which the hardware returns 0 without touching memory
+//       (no clamps, no masks, no over-reads);
+//   (3) loads are unconditional (a predicated load makes hipcc wrap each load in its own exec branch
+//       with a wait in between) and are issued one K step ahead of the MFMAs that consume them.
+// Tiling: 256 threads = 4 waves; block tile 128 x {128,64,32}; each wave owns 32x32 MFMA sub-tiles
+// (2x2, 1x2 or 1x1); K step 16; LDS tiles are stored [k][row] (+4 pad) so every MFMA operand read is a
+// conflict-free ds_read of 32 consecutive floats per half-wave; double-buffered LDS, one barrier per step.
+// Workgroup -> tile mapping is XCD-aware (block b runs on XCD b%8): all column tiles of one row panel
+// (fwd/dgrad) resp. all output tiles of one batch slice (wgrad) run on the same XCD, so the panel is
+// fetched from HBM into ONE L2 and shared there.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32;
 
 constexpr int BM = 128;
 constexpr int BK = 16;
 constexpr int PAD = 4;
+constexpr int GEMM_PIPE = 0;          // LDS->MFMA pipeline variant used by dgrad / wgrad (see mfma_step)
 
 struct SegDev {
     float* ptr;
@@ -64,6 +75,25 @@ __device__ __forceinline__ float act_bwd(float g, float y, int act) {
     return g;
 }
 
+// Buffer loads: `buffer_load_dword v, voff, s[rsrc], soff offen` -- 128-bit descriptor + uniform byte offset in
+// SGPRs, 32-bit lane offset in a VGPR: zero address arithmetic per load inside the K loop.  A lane offset of
+// INVALID (>= num_records) makes the hardware return 0 without touching memory: that is how row / k tails
+// are zero-filled (no clamps, no masks, no over-reads).  All valid offsets must stay below 2 GiB.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr u32 INVALID = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)INVALID, 0x00020000);
+}
+// sign-bit mask: INVALID when x > limit (both < 2^31), else 0 -- pure arithmetic, because hipcc turns a
+// `cond ? INVALID : off` select feeding a load into two predicated loads behind exec-mask branches
+__device__ __forceinline__ u32 oob_mask(int x, int limit) { return (u32)(limit - x) & INVALID; }
+__device__ __forceinline__ float bload(rsrc_t r, u32 voff, u32 soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
 template <int BN>
 struct Cfg {
     static constexpr int WM = (BN == 128) ? 2 : 4;      // waves along the row dimension
@@ -85,16 +115,16 @@ __device__ __forceinline__ bool map_tile(int b, int row_tiles, int col_tiles, in
 }
 inline int grid_for(int row_tiles, int col_tiles) { return 8 * (int)dtc::ceil_div(row_tiles, 8) * col_tiles; }
 
-template <int BN>
+// PIPE selects how the LDS->MFMA software pipeline is expressed (hipcc sinks every LDS read next to its
+// use unless told otherwise): 0 = leave it to the compiler, 1 = pin "reads of k-pair kp+1, then MFMAs of
+// k-pair kp" with sched_barrier fences, 2 = describe the same interleave with sched_group_barrier.
+template <int BN, int PIPE>
 __device__ __forceinline__ void mfma_step(const float* __restrict__ As, const float* __restrict__ Bs,
                                           f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN], int lane, int wm_off, int wn_off) {
     using C = Cfg<BN>;
     const int half = lane >> 5, l31 = lane & 31;
     const float* ap = As + half * C::LDA + wm_off + l31;
     const float* bp = Bs + half * C::LDB + wn_off + l31;
-    // Software pipeline over the 8 k-pairs of the K step: the LDS reads of k-pair kp+1 are issued BEFORE
-    // the MFMAs of k-pair kp (sched_barrier pins that order; hipcc otherwise sinks every read next to
-    // its use and exposes the LDS latency 8 times per step), so each wait is a counted lgkmcnt.
     float a[2][C::TM], b[2][C::TN];
 #pragma unroll
     for (int i = 0; i < C::TM; ++i) a[0][i] = ap[32 * i];
@@ -109,23 +139,43 @@ __device__ __forceinline__ void mfma_step(const float* __restrict__ As, const fl
 #pragma unroll
             for (int j = 0; j < C::TN; ++j) b[nxt][j] = bp[(2 * (kp + 1)) * C::LDB + 32 * j];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (PIPE == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)
 #pragma unroll
             for (int j = 0; j < C::TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        if (PIPE == 1) __builtin_amdgcn_sched_barrier(0);
     }
+    if (PIPE == 2) {
+        constexpr int NDS = (C::TM + C::TN + 1) / 2;          // ds_read2_b32 pairs per k-pair
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);  // fragments of k-pair 0
+#pragma unroll
+        for (int kp = 0; kp < BK / 2 - 1; ++kp) {
+            __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);              // fragments of k-pair kp+1
+            __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);    // MFMAs of k-pair kp
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);
+    }
+}
+
+template <int BN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN]) {
+#pragma unroll
+    for (int i = 0; i < Cfg<BN>::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg<BN>::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------
 // Forward: Y[M,N] = act(X[M,K] W[N,K]^T + b)
 // ------------------------------------------------------------------------------------------
-template <int BN>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
+template <int BN, int PIPE>
+__global__ __launch_bounds__(256, 3) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ Y,
-                                                         long long ldy, int M, int N, int K, int act) {
+                                                         long long ldy, int M, int N, int K, int act, int ablate) {
     using C = Cfg<BN>;
     __shared__ float As[2][BK][C::LDA];
     __shared__ float Bs[2][BK][C::LDB];
@@ -135,86 +185,105 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const SegMatDev X, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
 
-    // loader coordinates: thread owns k = kk and rows rbase + 16*i
+    // loader geometry: thread owns k = kk and rows rbase + 16*i of both operand tiles
     const int kk = tid & 15, rbase = tid >> 4;
     constexpr int NA = BM / 16, NB = BN / 16;
-    // All loads are UNCONDITIONAL on clamped addresses and masked afterwards: a predicated load makes
-    // hipcc wrap every load in its own exec-mask branch with a wait in between (serialised latency).
-    int arow[NA], grow[NA], wrow[NB];
-    bool aval[NA], wval[NB];
+    int arow[NA], grow[NA];
+    u32 woff[NB];                                   // lane byte offset into W (loop invariant)
     bool any_gather = false;
     for (int s = 0; s < X.nseg; ++s) any_gather |= X.s[s].gather != 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + rbase + 16 * i;
-        aval[i] = m < M;
-        arow[i] = aval[i] ? m : M - 1;
-        grow[i] = any_gather ? (int)X.idx[arow[i]] : arow[i];
+        arow[i] = m < M ? m : -1;
+        grow[i] = (any_gather && m < M) ? (int)X.idx[m] : arow[i];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int n = n0 + rbase + 16 * i;
-        wval[i] = n < N;
-        wrow[i] = wval[i] ? n : N - 1;
+        woff[i] = n < N ? (u32)(n * K + kk) * 4u : INVALID;
     }
-    float ra[NA], rb[NB];
-    auto load_tile = [&](int k0) {
-        const int k = k0 + kk;
-        const bool kval = k < K;
-        const int kc = kval ? k : K - 1;
-        const SegDev sd = X.s[find_seg(X, kc)];
-        const float* p = sd.ptr + sd.col0 + (kc - sd.start);
+    const rsrc_t wres = make_rsrc(W);
+
+    // K-tile iterator over the segments (uniform state)
+    int seg = 0, kt = 0;
+    SegDev sd = X.s[0];
+    int seg_tiles = (sd.width + BK - 1) / BK;
+    rsrc_t ares = make_rsrc(sd.ptr);
+    u32 aoff[NA];                                   // lane byte offset of the A element inside the segment
+    auto enter_segment = [&]() {
+        ares = make_rsrc(sd.ptr);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            ra[i] = p[(long long)(sd.gather ? grow[i] : arow[i]) * sd.ld];
+            const int r = sd.gather ? grow[i] : arow[i];
+            aoff[i] = r >= 0 ? ((u32)r * (u32)sd.ld + (u32)(sd.col0 + kk)) * 4u : INVALID;
         }
-        const float* w = W + kc;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = w[(long long)wrow[i] * K];
-        return kval;
     };
-    // the bounds masks are applied when the registers are written to LDS, i.e. AFTER the MFMAs of the
-    // current tile, so the global loads stay in flight behind the matrix work
-    auto store_tile = [&](int buf, bool kval) {
+    enter_segment();
+    int total_tiles = 0;
+    for (int s = 0; s < X.nseg; ++s) total_tiles += (X.s[s].width + BK - 1) / BK;
+
+    float ra[NA], rb[NB];
+    auto load_tile = [&]() {            // tile (seg, kt) -> registers; lanes past the segment width read 0
+        const u32 kmask = oob_mask(kt * BK + kk, sd.width - 1);
+        const u32 ka = (u32)(kt * BK) * 4u, kw = (u32)(sd.start + kt * BK) * 4u;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = (aval[i] && kval) ? ra[i] : 0.f;
+        for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | kmask, ka);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[buf][kk][rbase + 16 * i] = (wval[i] && kval) ? rb[i] : 0.f;
+        for (int i = 0; i < NB; ++i) rb[i] = bload(wres, woff[i] | kmask, kw);
+    };
+    auto advance = [&]() {
+        if (++kt == seg_tiles) {
+            kt = 0;
+            ++seg;
+            if (seg < X.nseg) {
+                sd = X.s[seg];
+                seg_tiles = (sd.width + BK - 1) / BK;
+                enter_segment();
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Bs[buf][kk][rbase + 16 * i] = rb[i];
     };
 
     f32x16 acc[C::TM][C::TN];
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    zero_acc<BN>(acc);
 
-    const int KT = (K + BK - 1) / BK;
-    bool kv = load_tile(0);
-    store_tile(0, kv);
+    load_tile();
+    store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) kv = load_tile((kt + 1) * BK);
-        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < KT) store_tile(buf ^ 1, kv);
-        __syncthreads();
+    for (int t = 0; t < total_tiles; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < total_tiles;
+        if (more) {
+            advance();
+            if (!(ablate & 1)) load_tile();
+        }
+        if (!(ablate & 2)) mfma_step<BN, PIPE>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
+        if (more && !(ablate & 4)) store_tile(buf ^ 1);
+        if (!(ablate & 8)) __syncthreads();
     }
 
     const int half = lane >> 5, l31 = lane & 31;
+    const bool full = (m0 + BM <= M) && (n0 + BN <= N);
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
         const int col = n0 + wn_off + 32 * j + l31;
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
+        const bool cok = col < N;
+        const float bv = (bias && cok) ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < C::TM; ++i) {
+            float* yp = Y + (long long)(m0 + wm_off + 32 * i + 4 * half) * ldy + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm_off + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < M) Y[(long long)row * ldy + col] = act_fwd(acc[i][j][r] + bv, act);
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const float v = act_fwd(acc[i][j][r] + bv, act);
+                if (full) yp[(long long)ro * ldy] = v;
+                else if (cok && m0 + wm_off + 32 * i + 4 * half + ro < M) yp[(long long)ro * ldy] = v;
             }
         }
     }
@@ -224,7 +293,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const SegMatDev X, cons
 // Data gradient: dX[M,K] = (dZ[M,N] W[N,K]) * act'(Xsaved)   (reduction over N)
 // ------------------------------------------------------------------------------------------
 template <int BN>
-__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dZ, long long lddz,
+__global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __restrict__ dZ, long long lddz,
                                                            const float* __restrict__ W, const SegMatDev dX,
                                                            const float* __restrict__ Xs, long long ldxs, int M, int N,
                                                            int K, int act) {
@@ -242,47 +311,35 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
     constexpr int RPP = 256 / BN;                   // B loader: reduction rows per pass
     constexpr int NB = BK / RPP;
     const int bj = tid % BN, bk0 = tid / BN;
-    const bool bcol_ok = c0 + bj < K;
-    int arow[NA];
-    bool aval[NA];
+    u32 aoff[NA], boff[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + rbase + 16 * i;
-        aval[i] = m < M;
-        arow[i] = aval[i] ? m : M - 1;
+        aoff[i] = m < M ? (u32)((long long)m * lddz + kk) * 4u : INVALID;
     }
-    const int bcol = bcol_ok ? c0 + bj : K - 1;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        boff[i] = c0 + bj < K ? (u32)((bk0 + RPP * i) * K + c0 + bj) * 4u : INVALID;
+    const rsrc_t ares = make_rsrc(dZ), bres = make_rsrc(W);
+
     float ra[NA], rb[NB];
     auto load_tile = [&](int n_0) {
-        const int n = n_0 + kk;
-        const bool nval = n < N;
-        const int nc = nval ? n : N - 1;
+        const u32 nmask = oob_mask(n_0 + kk, N - 1);
+        const u32 sa = (u32)n_0 * 4u, sb = (u32)n_0 * (u32)K * 4u;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            ra[i] = dZ[(long long)arow[i] * lddz + nc];
-        }
+        for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | nmask, sa);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int nr = n_0 + bk0 + RPP * i;
-            rb[i] = W[(long long)(nr < N ? nr : N - 1) * K + bcol];
-        }
+        for (int i = 0; i < NB; ++i) rb[i] = bload(bres, boff[i] | oob_mask(n_0 + bk0 + RPP * i, N - 1), sb);
     };
-    auto store_tile = [&](int buf, int n_0) {
-        const bool nval = n_0 + kk < N;
+    auto store_tile = [&](int buf, int) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = (aval[i] && nval) ? ra[i] : 0.f;
+        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = ra[i];
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-            Bs[buf][bk0 + RPP * i][bj] = (bcol_ok && n_0 + bk0 + RPP * i < N) ? rb[i] : 0.f;
+        for (int i = 0; i < NB; ++i) Bs[buf][bk0 + RPP * i][bj] = rb[i];
     };
 
     f32x16 acc[C::TM][C::TN];
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    zero_acc<BN>(acc);
 
     const int KT = (N + BK - 1) / BK;
     load_tile(0);
@@ -291,8 +348,7 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < KT) load_tile((kt + 1) * BK);
-        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-        __builtin_amdgcn_sched_barrier(0);
+        mfma_step<BN, GEMM_PIPE>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
         if (kt + 1 < KT) store_tile(buf ^ 1, (kt + 1) * BK);
         __syncthreads();
     }
@@ -356,47 +412,60 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     const int bj = tid % BN, bk0 = tid / BN;
     const int bcol = c0 + bj;
     const bool bcol_ok = bcol < K;
-    const int bcolc = bcol_ok ? bcol : K - 1;
-    const SegDev sd = X.s[find_seg(X, bcolc)];
-    const float* bp = sd.ptr + sd.col0 + (bcolc - sd.start);
+    const SegDev sd = X.s[find_seg(X, bcol_ok ? bcol : K - 1)];
+    const u32 ldb = (u32)sd.ld * 4u;
+    const u32 bcolb = (u32)(sd.col0 + ((bcol_ok ? bcol : K - 1) - sd.start)) * 4u;
+    // the segment pointer differs between lanes when a tile straddles two segments -> lane addresses
+    const float* bptr = sd.ptr;
+    u32 aoff[NA], boff[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) aoff[i] = arow_ok ? (u32)((long long)(ak0 + 2 * i) * lddz + n0 + ai) * 4u : INVALID;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) boff[i] = (u32)(bk0 + RPP * i) * ldb + bcolb;
+    const rsrc_t ares = make_rsrc(dZ);
+    // uniform fast path for the X operand: the whole column tile lies in ONE non-gathered segment
+    const SegDev sd_first = X.s[find_seg(X, c0)];
+    const int last_col = (c0 + BN - 1 < K ? c0 + BN - 1 : K - 1);
+    const bool b_uniform = (find_seg(X, c0) == find_seg(X, last_col)) && !sd_first.gather;
+    const rsrc_t bres = make_rsrc(sd_first.ptr);
+    const u32 bcmask = bcol_ok ? 0u : INVALID;
 
     float ra[NA], rb[NB];
     float bias_acc = 0.f;
-    const int acol = arow_ok ? n0 + ai : N - 1;
-    const int m_last = m_end > m_begin ? m_end - 1 : 0;
     auto load_tile = [&](int mb) {
+        const u32 sa = (u32)mb * (u32)lddz * 4u;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int m = mb + ak0 + 2 * i;
-            ra[i] = dZ[(long long)(m < m_end ? m : m_last) * lddz + acol];
-        }
+        for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | oob_mask(mb + ak0 + 2 * i, m_end - 1), sa);
+        if (b_uniform) {
+            const u32 sb = (u32)mb * (u32)sd_first.ld * 4u;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int m = mb + bk0 + RPP * i;
-            const int mc = m < m_end ? m : m_last;
-            const long long r = sd.gather ? X.idx[mc] : (long long)mc;
-            rb[i] = bp[r * sd.ld];
+            for (int i = 0; i < NB; ++i)
+                rb[i] = bload(bres, boff[i] | bcmask | oob_mask(mb + bk0 + RPP * i, m_end - 1), sb);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int m = mb + bk0 + RPP * i;
+                const bool ok = bcol_ok && m < m_end;
+                const int mc = m < m_end ? m : (m_end > m_begin ? m_end - 1 : 0);
+                const u32 r = sd.gather ? (u32)X.idx[mc] : (u32)mc;
+                const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bptr) +
+                                                                (unsigned long long)r * ldb + bcolb);
+                rb[i] = ok ? v : 0.f;
+            }
         }
     };
-    auto store_tile = [&](int buf, int mb) {
+    auto store_tile = [&](int buf, int) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const float v = (arow_ok && mb + ak0 + 2 * i < m_end) ? ra[i] : 0.f;
-            As[buf][ak0 + 2 * i][ai] = v;
-            bias_acc += v;
+            As[buf][ak0 + 2 * i][ai] = ra[i];
+            bias_acc += ra[i];
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-            Bs[buf][bk0 + RPP * i][bj] = (bcol_ok && mb + bk0 + RPP * i < m_end) ? rb[i] : 0.f;
+        for (int i = 0; i < NB; ++i) Bs[buf][bk0 + RPP * i][bj] = rb[i];
     };
 
     f32x16 acc[C::TM][C::TN];
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    zero_acc<BN>(acc);
 
     const int KT = (m_end - m_begin + BK - 1) / BK;
     if (KT > 0) {
@@ -407,8 +476,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < KT) load_tile(m_begin + (kt + 1) * BK);
-        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-        __builtin_amdgcn_sched_barrier(0);
+        mfma_step<BN, GEMM_PIPE>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
         if (kt + 1 < KT) store_tile(buf ^ 1, m_begin + (kt + 1) * BK);
         __syncthreads();
     }
@@ -460,7 +528,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-int to_dev(const DtcSegMat* h, SegMatDev& d, int expect_cols, bool is_output) {
+constexpr long long MAX_ELEMS = (1ll << 29) - 1;     // lane byte offsets must stay below 2 GiB (INVALID = 2^31)
+
+int to_dev(const DtcSegMat* h, SegMatDev& d, int expect_cols, bool is_output, long long rows_bound) {
     DTC_REQUIRE(h != nullptr, "segmented matrix is null");
     DTC_REQUIRE(h->nseg >= 1 && h->nseg <= 4, "nseg=%d out of range", h->nseg);
     d.nseg = h->nseg;
@@ -474,6 +544,7 @@ int to_dev(const DtcSegMat* h, SegMatDev& d, int expect_cols, bool is_output) {
             DTC_REQUIRE(is_output || hs.ptr != nullptr, "segment %d: null source", i);
             DTC_REQUIRE(!hs.gather || h->idx != nullptr, "segment %d: gather without idx", i);
             DTC_REQUIRE(!(is_output && hs.gather), "segment %d: gathered destination unsupported", i);
+            DTC_REQUIRE(hs.gather || hs.ld * rows_bound <= MAX_ELEMS, "segment %d: matrix exceeds 2^29 elements (2 GiB)", i);
             s.ptr = hs.ptr;
             s.ld = hs.ld;
             s.col0 = hs.col0;
@@ -500,6 +571,14 @@ int pick_bn(int cols) {
     return (w128 <= w64 + 0.05) ? 128 : 64;
 }
 
+// fwd / dgrad: 128x64 tiles measured faster than 128x128 at every layer width of this model (twice the
+// workgroups -> prologue / epilogue of one block overlap the MFMA phase of its neighbours, 4 waves/SIMD)
+int pick_bn_rows(int cols) {
+    static const char* force = getenv("DTC_GEMM_BN");
+    if (force && cols > 64) return atoi(force);
+    return cols <= 32 ? 32 : 64;
+}
+
 int wgrad_splits(int M, int N, int K) {
     const int bn = pick_bn(K);
     const int tiles = (int)(dtc::ceil_div(N, BM) * dtc::ceil_div(K, bn));
@@ -512,21 +591,32 @@ int wgrad_splits(int M, int N, int K) {
 
 }  // namespace
 
+// NOTE on sizes: lane offsets are 32-bit byte offsets below 2 GiB, so every operand matrix must stay below
+// 2^29 elements; gathered sources are bounded by the caller (row index * ld < 2^29), which holds for the
+// rollouts of up to ~15000 envs x 24 steps per GPU this path is designed for (4096 x 24 x 1389 = 1.4e8).
+
 extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, int M, int N,
                               int K, int act, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
     DTC_REQUIRE(W && Y, "null pointer");
     DTC_REQUIRE(act >= 0 && act <= 2, "bad activation %d", act);
+    DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * ldy <= MAX_ELEMS * 4, "matrix too large");
     SegMatDev xd;
-    int rc = to_dev(X, xd, K, false);
+    int rc = to_dev(X, xd, K, false, M);
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int bn = pick_bn(N);
+    const int bn = pick_bn_rows(N);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, bn));
     dtc::ProfScope prof("linear_fwd", 2.0 * M * (double)N * K, s);
-    if (bn == 128) hipLaunchKernelGGL(linear_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
-    else if (bn == 64) hipLaunchKernelGGL(linear_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
-    else hipLaunchKernelGGL(linear_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
+    static const char* abl_env = getenv("DTC_GEMM_ABLATE");      // profiling aid: skip phases of the K loop
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    static const char* pipe_env = getenv("DTC_GEMM_PIPE");
+    const int pipe = pipe_env ? atoi(pipe_env) : GEMM_PIPE;
+#define DTC_FWD(BN_, P_) hipLaunchKernelGGL((linear_fwd_kernel<BN_, P_>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, abl)
+    if (bn == 128) { if (pipe == 1) DTC_FWD(128, 1); else if (pipe == 2) DTC_FWD(128, 2); else DTC_FWD(128, 0); }
+    else if (bn == 64) { if (pipe == 1) DTC_FWD(64, 1); else if (pipe == 2) DTC_FWD(64, 2); else DTC_FWD(64, 0); }
+    else { if (pipe == 1) DTC_FWD(32, 1); else if (pipe == 2) DTC_FWD(32, 2); else DTC_FWD(32, 0); }
+#undef DTC_FWD
     return dtc::check_launch("linear_fwd");
 }
 
@@ -537,11 +627,12 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
     DTC_REQUIRE(act >= 0 && act <= 2, "bad activation %d", act);
     DTC_REQUIRE(act == DTC_ACT_NONE || (Xsaved != nullptr && ldxs >= K), "activation derivative needs Xsaved");
     DTC_REQUIRE(act == DTC_ACT_NONE || (dX && dX->nseg == 1), "activation derivative needs a single-segment destination");
+    DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * lddz <= MAX_ELEMS, "matrix too large");
     SegMatDev xd;
-    int rc = to_dev(dX, xd, K, true);
+    int rc = to_dev(dX, xd, K, true, 0);
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int bn = pick_bn(K);
+    const int bn = pick_bn_rows(K);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K, bn));
     dtc::ProfScope prof("linear_dgrad", 2.0 * M * (double)N * K, s);
     if (bn == 128) hipLaunchKernelGGL(linear_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act);
@@ -559,8 +650,9 @@ extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* 
                                 int M, int N, int K, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
     DTC_REQUIRE(dZ && dW && workspace, "null pointer");
+    DTC_REQUIRE((long long)M * lddz <= MAX_ELEMS, "matrix too large");
     SegMatDev xd;
-    int rc = to_dev(X, xd, K, false);
+    int rc = to_dev(X, xd, K, false, M);
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int bn = pick_bn(K);

@@ -1,0 +1,4 @@
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/t13.log; cat gpurun_out/t13.log
+timeout 200 python deep-tracking-control_amd/tools/microbench.py gemm scorer > gpurun_out/mb4.log 2>&1; cat gpurun_out/mb4.log
+for A in 0 1 2 3 4 5 7 8 15; do DTC_GEMM_ABLATE=$A timeout 100 python deep-tracking-control_amd/tools/microbench.py ablate 2>&1 | grep ABLATE; done | tee gpurun_out/ablate1.log

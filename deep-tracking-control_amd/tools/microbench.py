@@ -49,6 +49,18 @@ def gemm():
               f" | wgrad {t3*1e3:8.1f} us {fl/t3/1e9:7.1f} TF | torch.mm {t4*1e3:8.1f} us {fl/t4/1e9:7.1f} TF", flush=True)
 
 
+def ablate():
+    """fwd GEMM with phases of the K loop removed (DTC_GEMM_ABLATE bits: 1 no global loads, 2 no MFMA,
+    4 no LDS stores, 8 no barrier): which phase bounds the kernel?  Set per process via the env var."""
+    M, N, K = 24576, 512, 693
+    X = torch.randn(M, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    b = torch.randn(N, device=DEV)
+    Y = torch.empty(M, N, device=DEV)
+    t = timed(lambda: ops.linear_fwd(X, W, b, Y, "relu"), iters=30)
+    print(f"ABLATE={os.environ.get('DTC_GEMM_ABLATE', '0')}: fwd {t*1e3:.1f} us  ({2.0*M*N*K/t/1e9:.1f} TF equivalent)", flush=True)
+
+
 def scorer():
     for N in (4096, 32768, 98304):
         inp = {k: v.to(DEV) for k, v in S.scorer_inputs(N, seed=1).items()}

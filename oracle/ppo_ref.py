@@ -67,7 +67,9 @@ class RefVae(nn.Module):
         thr = 2 * std
         outliers = (lv < (mean - thr)) | (lv > (mean + thr))
         median = lv[~outliers].median()
-        self.last_outliers, self.last_median = int(outliers.sum()), float(median)     # for the parity tests
+        with torch.no_grad():     # bookkeeping for the parity tests (which element IS the median)
+            self.last_outliers, self.last_median = int(outliers.sum()), float(median)
+            self.last_median_index = int(((lv == median) & ~outliers).flatten().nonzero()[0])
         lv[outliers] = median
         z = eps * torch.exp(0.5 * lv) + mu[:, 3:]
         return mu, lv, z

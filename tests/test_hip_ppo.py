@@ -94,8 +94,9 @@ def _compare_grads(k, which, grads_ref, ref, alg, n_expected, strict=False):
     # concentrated gradient lands elsewhere: the CE-net encoder gradients are then not comparable.
     fw = alg.actor_critic._fwd_ws(B)
     vae = ref.actor_critic.vae
-    same_median = int(fw.info[0]) == vae.last_outliers and \
-        abs(float(fw.info[2:3].view(torch.float32)) - vae.last_median) <= 2e-6      # same element, fp32 GEMM noise
+    # ... and at B = 24576 the 3.7e5 non-outliers are ~2e-6 apart around the median, so fp32 GEMM noise
+    # (3e-7) can even swap WHICH element is the median: compare the element index, not just the value.
+    same_median = int(fw.info[0]) == vae.last_outliers and int(fw.info[1]) == vae.last_median_index
     if strict:
         assert n_mis == 0 and same_median, (n_mis, int(fw.info[0]), vae.last_outliers,
                                             float(fw.info[2:3].view(torch.float32)), vae.last_median)
