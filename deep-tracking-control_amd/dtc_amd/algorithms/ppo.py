@@ -20,9 +20,8 @@ attributes `actor_critic`, `optimizer`, `vae_optimizer`, `storage`, `learning_ra
 from __future__ import annotations
 
 import torch
-import torch.distributed as dist
 
-from .. import _ffi, ops
+from .. import _ffi, distributed as dp, ops
 from .._ffi import seg, segmat
 from ..modules.actor_critic_decoder import AC_Args, ActorCriticDecoder
 from ..storage import RolloutStorage
@@ -225,13 +224,10 @@ class PPO:
 
     @staticmethod
     def _world():
-        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        return dp.world_size()
 
     def _allreduce_grads(self, opt):
-        w = self._world()
-        if w > 1:
-            dist.all_reduce(opt.g)
-            opt.g.mul_(1.0 / w)
+        dp.allreduce_mean_(opt.g)        # one flat bucket per optimiser step (no-op on a single rank)
 
     def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None):
         ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wg, M=tw.B)
@@ -295,8 +291,7 @@ class PPO:
                      flat["sigma"], flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval,
                      ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
         if world > 1 and cfg.adaptive_schedule == 0 and self._adaptive():
-            dist.all_reduce(stats[S_KL:S_KL + 1])
-            stats[S_KL:S_KL + 1].mul_(1.0 / world)
+            dp.allreduce_mean_(stats[S_KL:S_KL + 1])
             ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
         # critic
         self._bwd(tw, L["c3"], tw.dval, fw.v3, tw.g128, fw.v3, act)

@@ -137,3 +137,22 @@ def clip_adam(params, grads, exp_avg, exp_avg_sq, max_grad_norm, lr, beta1, beta
 
 def lr_adapt(kl_mean, lr, desired_kl):
     check(lib().dtc_lr_adapt(ptr(kl_mean), ptr(lr), desired_kl, stream()), "dtc_lr_adapt")
+
+
+# ---------------------------------------------------------------- GRU
+def gru_workspace_bytes(T, R, H) -> int:
+    return int(lib().dtc_gru_workspace(T, R, H))
+
+
+def gru_fwd(gi, h0, W_hh, b_hh, hs_all, gates, hn, ws):
+    """gi [T,R,3H], h0 [R,H] -> hs_all [T+1,R,H] (slot 0 = h0), gates [T,R,3H], hn [T,R,H]."""
+    T, R, H3 = gi.shape
+    check(lib().dtc_gru_fwd(cptr(gi, f32), cptr(h0, f32), cptr(W_hh, f32), cptr(b_hh, f32), cptr(hs_all, f32),
+                            cptr(gates, f32), cptr(hn, f32), ptr(ws), T, R, H3 // 3, stream()), "dtc_gru_fwd")
+
+
+def gru_bwd(dhs, hs_all, gates, hn, W_hh, dgi, dW_hh, db_hh, dh0, ws):
+    T, R, H = dhs.shape
+    check(lib().dtc_gru_bwd(cptr(dhs, f32), cptr(hs_all, f32), cptr(gates, f32), cptr(hn, f32), cptr(W_hh, f32),
+                            cptr(dgi, f32), cptr(dW_hh, f32), cptr(db_hh, f32), cptr(dh0, f32), ptr(ws), T, R, H,
+                            stream()), "dtc_gru_bwd")

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import torch
 
+from .. import distributed as dp
 from .. import ops
 from ..utils import split_and_pad_trajectories
 
@@ -114,15 +115,11 @@ class RolloutStorage:
             self._stats = torch.zeros(4, dtype=torch.float64, device=self.device)
         ops.gae(self.rewards, self.values, self.dones, last_values.contiguous().float(), gamma, lam, self.returns,
                 self.advantages, self._stats)
-        world = 1
-        dist = torch.distributed
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            world = dist.get_world_size()
-            dist.all_reduce(self._stats[0:1])
+        world = dp.world_size()
+        dp.allreduce_sum_(self._stats[0:1])
         count = float(T * N * world)
         ops.adv_sqdev(self.advantages, self._stats, count)
-        if world > 1:
-            dist.all_reduce(self._stats[1:2])
+        dp.allreduce_sum_(self._stats[1:2])
         ops.adv_normalize(self.advantages, self._stats, count)
 
     def get_statistics(self):

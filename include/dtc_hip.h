@@ -161,18 +161,22 @@ int dtc_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq
                   float* gnorm_out, void* workspace, void* stream);
 int64_t dtc_adam_workspace(int64_t n);
 
-/* ---- GRU (torch.nn.GRU, 1 layer; actor_critic_recurrent.py:92-116) -------------------------- */
-/* gi [T,R,3H] = x W_ih^T + b_ih is computed by dtc_linear_fwd; this runs the recurrence
- * h_t = GRU(gi_t, h_{t-1}) for t < T, writing hs [T,R,H] and the gate activations needed by
- * the backward pass (gates [T,R,3H] = r, z, n; hn [T,R,H] = W_hn h + b_hn). */
-int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, const float* b_hh, float* hs,
-                float* gates, float* hn, void* workspace, int T, int R, int H, void* stream);
-/* BPTT: dhs [T,R,H] are the gradients w.r.t. the outputs; produces dgi [T,R,3H] (gradient w.r.t.
- * gi, fed to dtc_linear_wgrad/dgrad for W_ih), dW_hh [3H,H], db_hh [3H] and dh0 [R,H]. */
-int dtc_gru_bwd(const float* dhs, const float* hs, const float* h0, const float* gates, const float* hn,
-                const float* W_hh, float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace,
-                int T, int R, int H, void* stream);
+/* ---- GRU (torch.nn.GRU, 1 layer, gate order r,z,n; actor_critic_recurrent.py:92-116 `Memory`) ---- */
+/* gi [T,R,3H] = x W_ih^T + b_ih is computed by dtc_linear_fwd over all T*R rows; this runs the recurrence
+ *     r = sig(gi_r + gh_r), z = sig(gi_z + gh_z), n = tanh(gi_n + r*gh_n), h_t = (1-z)*n + z*h_{t-1},
+ *     gh = h_{t-1} W_hh^T + b_hh
+ * for t < T over R sequences (R = padded trajectories of utils.py:33-64, or envs during the rollout).
+ * hs_all is [T+1,R,H]: slot 0 receives h0, slot t+1 = h_t (so hs_all[1:] is nn.GRU's output and hs_all[:T]
+ * the h_{t-1} operand of the backward pass).  gates [T,R,3H] receives (r, z, n), hn [T,R,H] = gh_n.
+ * workspace >= dtc_gru_workspace() bytes. */
 int64_t dtc_gru_workspace(int T, int R, int H);
+int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, const float* b_hh, float* hs_all,
+                float* gates, float* hn, void* workspace, int T, int R, int H, void* stream);
+/* BPTT.  dhs [T,R,H] = gradient w.r.t. the outputs h_1..h_T.  Produces dgi [T,R,3H] (gradient w.r.t. gi:
+ * feed it to dtc_linear_wgrad with x for W_ih / b_ih), dW_hh [3H,H], db_hh [3H] and dh0 [R,H]. */
+int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* gates, const float* hn, const float* W_hh,
+                float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace, int T, int R, int H,
+                void* stream);
 
 /* ---- per-kernel timing (HIP events on `stream`) used by bench.py's roofline object ---------- */
 void dtc_prof_enable(int on);
