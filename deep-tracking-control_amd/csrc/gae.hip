@@ -100,6 +100,16 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                           float* __restrict__ dst, int64_t rows, int64_t row_elems) {
+    const int64_t total = rows * row_elems;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / row_elems;
+        dst[idx[r] * row_elems + (e - r * row_elems)] = src[e];
+    }
+}
+
 constexpr int MAX_PARTIALS = 4096;
 // Scratch for the reduction partials lives behind stats: callers pass double[4 + MAX_PARTIALS]?
 // No: keep the ABI small -- partials use a lazily allocated per-process device buffer.
@@ -173,4 +183,15 @@ extern "C" int dtc_gather_rows(const void* src, const int64_t* idx, void* dst, i
                            (const uint8_t*)src, idx, (uint8_t*)dst, rows, row_bytes);
     }
     return dtc::check_launch("gather_rows");
+}
+
+extern "C" int dtc_scatter_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int64_t row_floats,
+                                void* stream) {
+    DTC_REQUIRE(rows >= 0 && row_floats > 0, "bad shape");
+    if (rows == 0) return DTC_OK;
+    DTC_REQUIRE(src && idx && dst, "null pointer");
+    const int64_t total = rows * row_floats;
+    const unsigned grid = (unsigned)(dtc::ceil_div(total, 256) < 8192 ? dtc::ceil_div(total, 256) : 8192);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, idx, dst, rows, row_floats);
+    return dtc::check_launch("scatter_rows");
 }

@@ -60,6 +60,7 @@ _SIGS = {
     "dtc_adv_sqdev": (C.c_int, [c_f32p, c_f64p, C.c_int64, C.c_double, c_stream]),
     "dtc_adv_normalize": (C.c_int, [c_f32p, c_f64p, C.c_int64, C.c_double, c_stream]),
     "dtc_gather_rows": (C.c_int, [C.c_void_p, c_i64p, C.c_void_p, C.c_int64, C.c_int64, c_stream]),
+    "dtc_scatter_rows": (C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int64, C.c_int64, c_stream]),
     "dtc_linear_fwd": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_stream]),
     "dtc_linear_dgrad": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_int,

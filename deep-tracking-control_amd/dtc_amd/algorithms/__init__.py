@@ -1,1 +1,2 @@
 from .ppo import PPO
+from .recurrent_ppo import RecurrentPPO

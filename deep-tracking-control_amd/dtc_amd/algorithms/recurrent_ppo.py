@@ -1,0 +1,188 @@
+"""PPO for the recurrent (GRU) actor-critic -- BASELINE.json config 3 ("ActorCriticRecurrent (GRU hidden
+512) BPTT over 24 steps").
+
+The reference's `PPO` cannot drive `ActorCriticRecurrent` at this commit (it needs `.vae`, ppo.py:79, and its
+update unpacks 16 items where the recurrent generator yields 11 -- SURVEY.md F2), so this class is the upstream
+rsl_rl PPO step the code base was forked from: ppo.py:288-335 (log-prob / entropy / KL-adaptive learning rate /
+clipped surrogate + clipped value loss / clip_grad_norm_ / Adam) fed by `reccurent_mini_batch_generator`
+(rollout_storage.py:217-267), with hidden states recorded BEFORE each rollout step (the convention of the
+commented lines ppo.py:138-139).  Same constructor keywords and method names as `PPO`.
+
+Kernel schedule per mini-batch (N/4 envs x all 24 steps): input projection GEMM -> dtc_gru_fwd -> MLP with the
+un-padding folded in as a row gather -> fused PPO loss -> MLP backward -> row scatter -> dtc_gru_bwd (BPTT) ->
+input-projection weight gradient -> one fused clip+Adam over the flat parameter arena.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _ffi, distributed as dp, ops
+from .._ffi import seg, segmat
+from ..modules.actor_critic_recurrent import ActorCriticRecurrent
+from ..storage import RolloutStorage
+from .ppo import FusedAdam, S_ENTROPY, S_GNORM, S_KL, S_SURR, S_VALUE, STAT_COLS
+
+
+class RecurrentPPO:
+    actor_critic: ActorCriticRecurrent
+
+    def __init__(self, actor_critic, num_learning_epochs=5, num_mini_batches=4, clip_param=0.2, gamma=0.99, lam=0.95,
+                 value_loss_coef=1.0, entropy_coef=0.01, learning_rate=5.e-4, max_grad_norm=1.0,
+                 use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01, device='cpu'):
+        self.device = device
+        self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
+        self.actor_critic = actor_critic
+        self.actor_critic.to(self.device)
+        self.storage = None
+        self.optimizer = None
+        if torch.device(device).type == "cuda":
+            arena = actor_critic.ensure_arena()
+            self.optimizer = FusedAdam(arena, arena.main_range, actor_critic.parameters(), lr=learning_rate)
+        self.transition = RolloutStorage.Transition()
+        self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
+        self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
+        self.gamma, self.lam, self.max_grad_norm = gamma, lam, max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+        self.capture_grads, self.captured = False, {}
+        self.last_update_stats = None
+
+    def _require_gpu(self):
+        if self.optimizer is None:
+            raise _ffi.DtcError("dtc_amd.RecurrentPPO computes on an MI355X only (device='cuda:N')")
+
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
+        self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, [1],
+                                      action_shape, self.device)
+
+    def test_mode(self):
+        self.actor_critic.eval()
+
+    def train_mode(self):
+        self.actor_critic.train()
+
+    # ---------------------------------------------------------------- rollout side
+    def act(self, obs, critic_obs):
+        self._require_gpu()
+        ac, tr = self.actor_critic, self.transition
+        N, H = obs.shape[0], ac.rnn_hidden_size
+        for m in (ac.memory_a, ac.memory_c):
+            if m.hidden_states is None:
+                m.hidden_states = torch.zeros(1, N, H, device=obs.device)
+        tr.hidden_states = tuple(h.clone() for h in ac.get_hidden_states())     # state BEFORE this step
+        tr.actions = ac.act(obs).detach()
+        tr.values = ac.evaluate(critic_obs).detach()
+        tr.actions_log_prob = ac.get_actions_log_prob(tr.actions).detach()
+        tr.action_mean, tr.action_sigma = ac.action_mean.detach(), ac.action_std.detach()
+        tr.observations, tr.critic_observations, tr.privileged_observations = obs, critic_obs, critic_obs
+        tr.observation_histories = torch.zeros(N, 1, device=obs.device)
+        tr.base_vel = torch.zeros(N, 3, device=obs.device)
+        return tr.actions
+
+    def process_env_step(self, rewards, dones, infos, next_obs=None):
+        tr = self.transition
+        tr.rewards, tr.dones = rewards.clone(), dones
+        tr.next_observations = next_obs if next_obs is not None else tr.observations
+        if 'time_outs' in infos:
+            tr.rewards += self.gamma * torch.squeeze(tr.values * infos['time_outs'].unsqueeze(1).to(self.device), 1)
+        self.storage.add_transitions(tr)
+        tr.clear()
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs):
+        self._require_gpu()
+        ac = self.actor_critic
+        keep = ac.memory_c.hidden_states.clone() if ac.memory_c.hidden_states is not None else None
+        last_values = ac.evaluate(last_critic_obs).detach()
+        ac.memory_c.hidden_states = keep            # the bootstrap value must not advance the critic's state
+        self.storage.compute_returns(last_values, self.gamma, self.lam)
+
+    # ---------------------------------------------------------------- update
+    def _loss_cfg(self):
+        cfg = _ffi.DtcPpoCfg()
+        cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef = self.clip_param, self.value_loss_coef, self.entropy_coef
+        cfg.desired_kl = float(self.desired_kl) if self.desired_kl is not None else 0.0
+        cfg.use_clipped_value_loss = int(bool(self.use_clipped_value_loss))
+        cfg.adaptive_schedule = int(self.desired_kl is not None and self.schedule == 'adaptive' and dp.world_size() == 1)
+        return cfg
+
+    def _mlp_backward(self, layers, outs, dOut, X0, M, dev, wg):
+        """Backward through an MLP given the saved layer outputs; returns the gradient w.r.t. its input rows."""
+        dZ = dOut
+        for li in range(len(layers) - 1, -1, -1):
+            L = layers[li]
+            X = outs[li - 1] if li > 0 else X0
+            ops.linear_wgrad(dZ, X, L.gW, L.gb, wg, M=M)
+            dX = torch.empty(M, L.n_in, device=dev)
+            if li > 0:
+                ops.linear_dgrad(dZ, L.W, dX, outs[li - 1], layers[li - 1].act, M=M)
+            else:
+                ops.linear_dgrad(dZ, L.W, dX, None, None, M=M)
+            dZ = dX
+        return dZ
+
+    def step_minibatch(self, batch, start, stop, stats=None):
+        """One recurrent mini-batch: `batch` = 11-tuple of reccurent_mini_batch_generator, envs [start, stop)."""
+        self._require_gpu()
+        ac, st = self.actor_critic, self.storage
+        (obs_b, cobs_b, _a, _v, _adv, _r, _lp, _mu, _sg, (hid_a, hid_c), masks) = batch
+        dev = obs_b.device
+        T, R = masks.shape
+        N, Nmb = st.num_envs, stop - start
+        M = T * Nmb
+        # un-padding as a row map: padded row (pos*R + traj) of each (t, env) in time-major order
+        traj, pos = masks.transpose(1, 0).nonzero(as_tuple=True)
+        unpad_idx = (pos * R + traj).view(Nmb, T).transpose(1, 0).reshape(-1).contiguous()
+        store_idx = (torch.arange(T, device=dev).unsqueeze(1) * N + torch.arange(start, stop, device=dev)).reshape(-1).contiguous()
+        stats = torch.zeros(STAT_COLS, device=dev) if stats is None else stats
+        self.optimizer.set_lr(self.learning_rate)
+        # forward
+        ac.act(obs_b, masks, hid_a, unpad_idx)
+        a_outs, a_saved = ac._actor_outs, ac.memory_a.saved
+        ac.evaluate(cobs_b, masks, hid_c, unpad_idx)
+        c_outs, c_saved = ac._critic_outs, ac.memory_c.saved
+        mean, value = a_outs[-1], c_outs[-1]
+        # loss (rows of the rollout tensors are addressed through store_idx -- no slicing copies)
+        dmean, dval = torch.empty_like(mean), torch.empty(M, 1, device=dev)
+        lws = ops.workspace(_ffi.lib().dtc_loss_workspace(M), dev)
+        flat = lambda k: st.flat(k)
+        ops.ppo_loss(mean, ac.std_view, value, flat("actions"), flat("actions_log_prob"), flat("mu"), flat("sigma"),
+                     flat("advantages"), flat("returns"), flat("values"), store_idx, self._loss_cfg(), dmean, dval,
+                     ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, lws)
+        if dp.world_size() > 1 and self.desired_kl is not None and self.schedule == 'adaptive':
+            dp.allreduce_mean_(stats[S_KL:S_KL + 1])
+            ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
+        # backward: MLPs -> scatter into the padded layout -> BPTT
+        H = ac.rnn_hidden_size
+        wg = ops.workspace(max(ops.wgrad_workspace_bytes(M, L.n_out, L.n_in) for L in ac.A + ac.Cr), dev)
+        for layers, outs, saved, mem, dOut in ((ac.A, a_outs, a_saved, ac.memory_a, dmean),
+                                               (ac.Cr, c_outs, c_saved, ac.memory_c, dval)):
+            hs_flat = saved["hs_all"][1:].reshape(T * R, H)
+            X0 = segmat([seg(hs_flat, 0, H, gather=True)], unpad_idx)
+            d_in = self._mlp_backward(layers, outs, dOut, X0, M, dev, wg)
+            dhs = torch.zeros(T * R, H, device=dev)
+            ops.scatter_rows(d_in, unpad_idx, dhs)
+            mem.backward(saved, dhs.view(T, R, H))
+        dp.allreduce_mean_(self.optimizer.g)
+        if self.capture_grads:
+            self.captured["main"] = ac.arena.grad.clone()
+        self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])
+        return stats
+
+    def update(self):
+        self._require_gpu()
+        st = self.storage
+        nmb, epochs = self.num_mini_batches, self.num_learning_epochs
+        mb = st.num_envs // nmb
+        dev = self.actor_critic.std.device
+        stats = torch.zeros(nmb * epochs, STAT_COLS, device=dev)
+        k = 0
+        for batch in st.reccurent_mini_batch_generator(nmb, epochs):
+            i = k % nmb
+            self.step_minibatch(batch, i * mb, (i + 1) * mb, stats[k])
+            k += 1
+        host = stats.cpu()
+        self.learning_rate = float(self.optimizer.lr_dev.item())
+        self.last_update_stats = host
+        m = host.double().mean(dim=0)
+        st.clear()
+        return float(m[S_VALUE]), float(m[S_SURR])

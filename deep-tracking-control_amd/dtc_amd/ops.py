@@ -156,3 +156,9 @@ def gru_bwd(dhs, hs_all, gates, hn, W_hh, dgi, dW_hh, db_hh, dh0, ws):
     check(lib().dtc_gru_bwd(cptr(dhs, f32), cptr(hs_all, f32), cptr(gates, f32), cptr(hn, f32), cptr(W_hh, f32),
                             cptr(dgi, f32), cptr(dW_hh, f32), cptr(db_hh, f32), cptr(dh0, f32), ptr(ws), T, R, H,
                             stream()), "dtc_gru_bwd")
+
+
+def scatter_rows(src, idx, dst):
+    """dst[idx[r]] = src[r] for 2-D fp32 tensors (rows of src.shape[1] floats)."""
+    check(lib().dtc_scatter_rows(cptr(src, f32), cptr(idx, torch.int64), cptr(dst, f32), src.shape[0], src.shape[1],
+                                 stream()), "dtc_scatter_rows")

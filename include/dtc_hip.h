@@ -76,6 +76,10 @@ int dtc_adv_normalize(float* advantages, const double* stats, int64_t n_local, d
 /* ---- mini-batch gather: rollout_storage.py:195-209 (`tensor[batch_idx]`) ------------------ */
 int dtc_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t rows, int64_t row_bytes,
                     void* stream);
+/* inverse map, dst[idx[r]] = src[r] (fp32 rows): the backward of `unpad_trajectories`
+ * (rsl_rl/rsl_rl/utils/utils.py:67-70) -- gradients of the valid steps go back into the padded layout. */
+int dtc_scatter_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int64_t row_floats,
+                     void* stream);
 
 /* ---- dense layers (nn.Linear + ReLU/ELU and their autograd; actor_critic_decoder.py:98-188,
  *      323-349).  A "segmented matrix" is the virtual concatenation torch.cat([...], dim=1) of

@@ -336,7 +336,56 @@ def gen_heights():
     save("heights", heights=h.numpy()[::4], root_override=root[:8, :2].numpy())
 
 
-TASKS = dict(gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
+# ------------------------------------------------------------------------------------ G5
+def gru_case(N=16, seed=4):
+    """Synthetic recurrent rollout: storage fields + hand-fed hidden states (the reference never records them, F2)."""
+    data = S.rollout(N, 24, seed=seed)
+    data["dones"][:, 0] = 0                                   # one env without resets -> a full-length trajectory
+    g = torch.Generator().manual_seed(77)
+    hid_a = 0.1 * torch.randn(24, 1, N, 512, generator=g)
+    hid_c = 0.1 * torch.randn(24, 1, N, 512, generator=g)
+    return data, hid_a, hid_c
+
+
+def gen_gru():
+    torch.set_num_threads(GOLDEN_THREADS)
+    from rsl_rl.modules import ActorCriticRecurrent
+    from rsl_rl.storage import RolloutStorage
+    N = 16
+    with H.quiet():
+        torch.manual_seed(3)
+        ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+                                  activation='elu', rnn_type='gru', rnn_hidden_size=512, rnn_num_layers=1)
+    fill_parameters_(ac, 21)
+    data, hid_a, hid_c = gru_case(N)
+    st = RolloutStorage(N, 24, [53], [1389], [265], [12])
+    fill_ref_storage(st, data)
+    st.saved_hidden_states_a, st.saved_hidden_states_c = [hid_a.clone()], [hid_c.clone()]
+    out = dict(keys=np.array(list(ac.state_dict().keys())))
+    for i, b in enumerate(st.reccurent_mini_batch_generator(4, 1)):
+        (obs_b, cobs_b, act_b, val_b, adv_b, ret_b, lp_b, mu_b, sg_b, (ha, hc), masks) = b
+        with torch.no_grad():
+            ac.act(obs_b, masks=masks, hidden_states=ha)
+            mean = ac.action_mean.clone()
+            value = ac.evaluate(cobs_b, masks=masks, hidden_states=hc)
+        out[f"mb{i}_shape"] = np.array(list(obs_b.shape) + list(masks.shape) + list(ha.shape))
+        out[f"mb{i}_mask_sum"] = np.array([int(masks.sum())])
+        out[f"mb{i}_mean"] = mean.numpy()
+        out[f"mb{i}_value"] = value.numpy()
+        out[f"mb{i}_obs_sum"] = np.array([obs_b.double().sum().item(), cobs_b.double().sum().item()])
+    # rollout-mode (inference) forward over 3 consecutive steps
+    ac.memory_a.hidden_states = None
+    ac.memory_c.hidden_states = None
+    seq = []
+    with torch.no_grad():
+        for t in range(3):
+            ac.act(data["observations"][t])
+            seq.append(ac.action_mean.clone().numpy())
+    out["rollout_means"] = np.stack(seq)
+    save("gru", **out)
+
+
+TASKS = dict(gru=gen_gru, gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
 
 if __name__ == "__main__":
     for t in (sys.argv[1:] or list(TASKS)):

@@ -1,0 +1,152 @@
+"""Recurrent (GRU) actor-critic path, BASELINE config 3.
+CPU: oracle/gru_ref.py against the fixture captured from the reference's own ActorCriticRecurrent / Memory /
+split_and_pad / reccurent_mini_batch_generator (tests/golden/gru.npz).
+GPU: dtc_amd ActorCriticRecurrent + RecurrentPPO against the oracle (forward, every parameter gradient of the
+BPTT step, scalars, learning rate)."""
+import numpy as np
+import pytest
+import torch
+
+from dtc_amd import synthetic as S
+from oracle import gru_ref as GR
+from oracle import ppo_ref as OP
+
+DEV = "cuda:0"
+N = 16
+
+
+def gru_case(seed=4):
+    data = S.rollout(N, 24, seed=seed)
+    data["dones"][:, 0] = 0
+    g = torch.Generator().manual_seed(77)
+    hid_a = 0.1 * torch.randn(24, 1, N, 512, generator=g)
+    hid_c = 0.1 * torch.randn(24, 1, N, 512, generator=g)
+    return data, hid_a, hid_c
+
+
+def oracle_model():
+    torch.manual_seed(3)
+    return OP.fill_parameters_(GR.RefActorCriticRecurrent(), 21)
+
+
+def oracle_storage(data):
+    st = OP.RefStorage(N, 24)
+    for k, v in data.items():
+        if k != "last_values":
+            getattr(st, k).copy_(v)
+    st.compute_returns(data["last_values"], 0.99, 0.95)
+    return st
+
+
+def test_oracle_matches_reference_modules(golden):
+    g = golden("gru")
+    ac = oracle_model()
+    assert list(ac.state_dict().keys()) == [str(k) for k in g["keys"]]
+    data, hid_a, hid_c = gru_case()
+    st = oracle_storage(data)
+    alg = GR.RefRecurrentPPO(ac)
+    for i, b in enumerate(GR.recurrent_batches(st, hid_a, hid_c, 4)):
+        shape = g[f"mb{i}_shape"]
+        assert list(b["obs"].shape) == list(shape[:3]) and list(b["masks"].shape) == list(shape[3:5])
+        assert list(b["hid_a"].shape) == list(shape[5:8]) and int(b["masks"].sum()) == int(g[f"mb{i}_mask_sum"][0])
+        sums = g[f"mb{i}_obs_sum"]
+        assert abs(b["obs"].double().sum().item() - sums[0]) < 1e-6 and abs(b["cobs"].double().sum().item() - sums[1]) < 1e-5
+        with torch.no_grad():
+            mean, value = alg.forward(b)
+        np.testing.assert_allclose(mean.numpy(), g[f"mb{i}_mean"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(value.numpy(), g[f"mb{i}_value"], rtol=1e-5, atol=1e-6)
+    # rollout mode: state carried across steps
+    h = None
+    with torch.no_grad():
+        for t in range(3):
+            out, h = ac.memory_a.rnn(data["observations"][t].unsqueeze(0), h)
+            np.testing.assert_allclose(ac.actor(out.squeeze(0)).numpy(), g["rollout_means"][t], rtol=1e-5, atol=1e-6)
+
+
+def _hip_pair(**kw):
+    from dtc_amd.algorithms import RecurrentPPO
+    from dtc_amd.modules import ActorCriticRecurrent
+    ref_ac = oracle_model()
+    ref = GR.RefRecurrentPPO(ref_ac, learning_rate=1e-3, entropy_coef=0.003, **kw)
+    ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+                              activation='elu', rnn_type='gru', rnn_hidden_size=512, rnn_num_layers=1)
+    alg = RecurrentPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV, **kw)
+    alg.init_storage(N, 24, [53], [1389], [12])
+    ac.load_state_dict(ref_ac.state_dict())
+    data, hid_a, hid_c = gru_case()
+    st = oracle_storage(data)
+    for k, v in data.items():
+        if k not in ("last_values", "observation_histories"):      # the recurrent storage keeps no obs history
+            getattr(alg.storage, k).copy_(v.to(DEV))
+    alg.storage.compute_returns(data["last_values"].to(DEV), 0.99, 0.95)
+    alg.storage.saved_hidden_states_a = [hid_a.to(DEV)]
+    alg.storage.saved_hidden_states_c = [hid_c.to(DEV)]
+    return ref, alg, st, hid_a, hid_c
+
+
+@pytest.mark.gpu
+def test_state_dict_and_rollout_forward():
+    ref, alg, st, _, _ = _hip_pair()
+    ac = alg.actor_critic
+    assert list(ac.state_dict().keys()) == list(ref.ac.state_dict().keys())
+    h = None
+    for t in range(3):
+        obs = st.observations[t]
+        with torch.no_grad():
+            out, h = ref.ac.memory_a.rnn(obs.unsqueeze(0), h)
+            exp = ref.ac.actor(out.squeeze(0))
+        got = ac.act_inference(obs.to(DEV))
+        np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(schedule="fixed", use_clipped_value_loss=False)])
+def test_recurrent_minibatch_step_vs_oracle(kw):
+    """All four mini-batches of one epoch, teacher-forced: forward, scalars, LR, every parameter gradient (BPTT)."""
+    from dtc_amd.algorithms import ppo as P
+    ref, alg, st, hid_a, hid_c = _hip_pair(**kw)
+    ref.capture_grads = alg.capture_grads = True
+    gen = alg.storage.reccurent_mini_batch_generator(4, 1)
+    for i, (b_ref, b_hip) in enumerate(zip(GR.recurrent_batches(st, hid_a, hid_c, 4), gen)):
+        alg.actor_critic.load_state_dict(ref.ac.state_dict())
+        alg.optimizer.load_state_dict(ref.optimizer.state_dict())
+        alg.learning_rate = ref.learning_rate
+        assert torch.equal(b_hip[0].cpu(), b_ref["obs"]) and torch.equal(b_hip[10].cpu(), b_ref["masks"])
+        rec = ref.step(st, b_ref)
+        row = alg.step_minibatch(b_hip, i * 4, (i + 1) * 4).cpu()
+        ac = alg.actor_critic
+        np.testing.assert_allclose(ac._actor_outs[-1].cpu().numpy().reshape(24, 4, 12), rec["mean"].numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(ac._critic_outs[-1].cpu().numpy().reshape(24, 4, 1), rec["value_out"].numpy(), rtol=1e-5, atol=2e-6)
+        for key, col in (("surrogate", P.S_SURR), ("value", P.S_VALUE), ("entropy", P.S_ENTROPY), ("gnorm", P.S_GNORM)):
+            assert abs(float(row[col]) - rec[key]) <= 1e-5 * max(1.0, abs(rec[key])), (i, key, float(row[col]), rec[key])
+        if "kl_mean" in rec:
+            assert abs(float(row[P.S_KL]) - rec["kl_mean"]) <= 1e-5 * max(1.0, abs(rec["kl_mean"]))
+        assert float(alg.optimizer.lr_dev.item()) == rec["lr"]
+        for name, g_ref in rec["grads"].items():
+            g = ac.arena.view(alg.captured["main"], name).cpu()
+            scale = float(g_ref.abs().max()) + 1e-30
+            err = float((g - g_ref).abs().max()) / scale
+            assert err <= 5e-5, (i, name, err, scale)
+        assert len(rec["grads"]) == 25
+
+
+@pytest.mark.gpu
+def test_recurrent_update_and_rollout_api():
+    from dtc_amd.algorithms import RecurrentPPO
+    from dtc_amd.modules import ActorCriticRecurrent
+    torch.manual_seed(0)
+    ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+                              rnn_type='gru', rnn_hidden_size=512)
+    alg = RecurrentPPO(ac, device=DEV, learning_rate=1e-3)
+    alg.init_storage(32, 24, [53], [1389], [12])
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for t in range(24):
+        obs = torch.randn(32, 53, device=DEV, generator=g)
+        cobs = torch.randn(32, 1389, device=DEV, generator=g)
+        alg.act(obs, cobs)
+        dones = (torch.rand(32, device=DEV, generator=g) < 0.05)
+        alg.process_env_step(0.1 * torch.randn(32, device=DEV, generator=g), dones, {})
+    alg.compute_returns(torch.randn(32, 1389, device=DEV, generator=g))
+    v, s = alg.update()
+    assert np.isfinite(v) and np.isfinite(s) and alg.storage.step == 0
+    assert alg.last_update_stats.shape[0] == 20
