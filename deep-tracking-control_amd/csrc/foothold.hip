@@ -393,6 +393,27 @@ __global__ __launch_bounds__(256) void get_heights_kernel(const int16_t* __restr
     out[e] = (float)h * vscale;
 }
 
+// legged_robot_dtc.py:577-586 / :536-539 -- one thread per env
+__global__ __launch_bounds__(256) void foothold_rewards_kernel(const float* __restrict__ foot, const float* __restrict__ opt,
+                                                               const uint8_t* __restrict__ contact, float* __restrict__ tracking,
+                                                               float* __restrict__ miss, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float sum = 0.0f, minz = __builtin_inff();
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const float* f = foot + (long long)n * 12 + l * 3;
+        const float* o = opt + (long long)n * 12 + l * 3;
+        const float dx = f[0] - o[0], dy = f[1] - o[1];
+        const float dis = sqrtf(dx * dx + dy * dy);
+        const float r = -logf(0.8f + dis);
+        sum = sum + (contact[n * 4 + l] ? r : 0.0f);
+        minz = fminf(minz, f[2]);
+    }
+    if (tracking) tracking[n] = sum;
+    if (miss) miss[n] = minz < 0.0f ? 1.0f : 0.0f;
+}
+
 int make_params(const DtcGridCfg* cfg, GridParams& gp) {
     DTC_REQUIRE(cfg != nullptr, "grid cfg is null");
     DTC_REQUIRE(cfg->nx >= 2 && cfg->nx <= 64 && cfg->ny >= 2 && cfg->ny <= 32, "grid %dx%d unsupported (nx<=64, ny<=32)",
@@ -462,4 +483,14 @@ extern "C" int dtc_get_heights(const int16_t* height_samples, int rows, int cols
     hipLaunchKernelGGL(get_heights_kernel, dim3((unsigned)dtc::ceil_div(total, 256)), dim3(256), 0, s, height_samples,
                        rows, cols, root_states, gp, border_size, horizontal_scale, vertical_scale, measured_heights, N);
     return dtc::check_launch("get_heights");
+}
+
+extern "C" int dtc_foothold_rewards(const float* foot_positions, const float* opt_world, const uint8_t* contact,
+                                    float* tracking, float* miss, int N, void* stream) {
+    DTC_REQUIRE(N >= 0, "N < 0");
+    if (N == 0) return DTC_OK;
+    DTC_REQUIRE(foot_positions && opt_world && contact && (tracking || miss), "null pointer");
+    hipLaunchKernelGGL(foothold_rewards_kernel, dim3((unsigned)dtc::ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       foot_positions, opt_world, contact, tracking, miss, N);
+    return dtc::check_launch("foothold_rewards");
 }

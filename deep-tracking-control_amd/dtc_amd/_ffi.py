@@ -53,6 +53,7 @@ _SIGS = {
     "dtc_last_error": (C.c_char_p, []),
     "dtc_foothold_plan": (C.c_int, [c_f32p] * 4 + [C.POINTER(DtcGridCfg), c_i64p] + [c_f32p] * 5 +
                           [c_i64p, c_f32p, c_f32p, C.c_int, c_stream]),
+    "dtc_foothold_rewards": (C.c_int, [c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, C.c_int, c_stream]),
     "dtc_get_heights": (C.c_int, [c_i16p, C.c_int, C.c_int, c_f32p, C.POINTER(DtcGridCfg), C.c_float, C.c_float,
                                   C.c_float, c_f32p, C.c_int, c_stream]),
     "dtc_gae": (C.c_int, [c_f32p, c_f32p, c_u8p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_f64p, C.c_int,

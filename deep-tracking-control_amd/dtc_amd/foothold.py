@@ -99,6 +99,19 @@ def get_heights(height_samples: torch.Tensor, root_states: torch.Tensor, grid: G
     return out
 
 
+def rewards(foot_positions: torch.Tensor, optimal_footholds_world: torch.Tensor, contact_filt: torch.Tensor):
+    """(_reward_tracking_optimal_footholds, _reward_foothold_miss) of legged_robot_dtc.py:577-586 / :536-539."""
+    N = foot_positions.shape[0]
+    dev = foot_positions.device
+    tracking, miss = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    c = contact_filt.to(torch.uint8).contiguous()
+    rc = _ffi.lib().dtc_foothold_rewards(_ffi.cptr(foot_positions.contiguous(), torch.float32),
+                                         _ffi.cptr(optimal_footholds_world.contiguous(), torch.float32), _ffi.ptr(c),
+                                         _ffi.ptr(tracking), _ffi.ptr(miss), N, _ffi.stream())
+    _ffi.check(rc, "dtc_foothold_rewards")
+    return tracking, miss
+
+
 def patch_env(env, grid: GridConfig | None = None):
     """Attach `env.plan_footholds()` that performs lines :98-201 of post_physics_step on `env`'s
     own buffers (rigid_body_state, base_pos/quat via root_states, commands, measured_heights)."""

@@ -55,6 +55,14 @@ int dtc_foothold_plan(const float* measured_heights /*[N,P]*/, const float* root
                       float* score_or_null, int64_t* nominal_idx_or_null, float* slope_or_null,
                       float* heights_world_or_null, int N, void* stream);
 
+/* Consumers of the planner output in the same env step (legged_robot_dtc.py:577-586 and :536-539):
+ * tracking[n] = sum_legs contact ? -log(0.8 + ||foot_xy - optimal_xy||) : 0   (_reward_tracking_optimal_footholds)
+ * miss[n]     = min_legs foot_z < 0 ? 1 : 0                                    (_reward_foothold_miss)
+ * contact is the env's contact_filt as uint8 [N,4]; either output may be NULL. */
+int dtc_foothold_rewards(const float* foot_positions /*[N,4,3]*/, const float* opt_world /*[N,4,3]*/,
+                         const uint8_t* contact /*[N,4]*/, float* tracking /*[N]*/, float* miss /*[N]*/, int N,
+                         void* stream);
+
 /* LeggedRobot._get_heights: legged_gym/envs/base/legged_robot.py:1279-1317 (row f1). */
 int dtc_get_heights(const int16_t* height_samples /*[rows,cols]*/, int rows, int cols,
                     const float* root_states /*[N,13]*/, const DtcGridCfg* cfg, float border_size,

@@ -127,3 +127,16 @@ def plan(measured_heights, root_states, thigh_pos, commands, points_x, points_y,
         dm = np.abs(np.sqrt(ddx * ddx + ddy * ddy) - F(0.16)).min(axis=1)
         out["threshold_margin"] = np.minimum(marg[:, None], dm).astype(F)
     return out
+
+
+def rewards(foot_positions, optimal_footholds_world, contact_filt):
+    """legged_robot_dtc.py:577-586 (_reward_tracking_optimal_footholds) and :536-539 (_reward_foothold_miss)."""
+    fp = np.asarray(foot_positions, dtype=F)
+    ow = np.asarray(optimal_footholds_world, dtype=F)
+    d = fp[:, :, :2] - ow[:, :, :2]
+    dis = np.sqrt(d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]).astype(F)
+    per_foot = -np.log(F(0.8) + dis).astype(F)
+    filt = np.where(np.asarray(contact_filt).astype(bool), per_foot, F(0.0)).astype(F)
+    tracking = ((filt[:, 0] + filt[:, 1]) + filt[:, 2]) + filt[:, 3]
+    miss = np.where(fp[:, :, 2].min(axis=1) < 0, F(1.0), F(0.0)).astype(F)
+    return tracking.astype(F), miss

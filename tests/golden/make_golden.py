@@ -306,6 +306,17 @@ def gen_scorer():
         out[tag + "_pred_to_robot"] = m.pred_footholds_to_robot.numpy()[::4]
         out[tag + "_slope_sample"] = m.slope.numpy()[::64]
         out[tag + "_score_sample"] = sc[::64]
+    # a10 / f3: rewards consuming the planner output (run as unbound methods on a tiny mock)
+    inp = S.scorer_inputs(512, seed=7)
+    m = _ref_scorer(inp)
+    g = torch.Generator().manual_seed(5)
+    mock = types.SimpleNamespace(device="cpu", optimal_footholds_world=m.optimal_footholds_world,
+                                 foot_positions=m.optimal_footholds_world + 0.05 * torch.randn(512, 4, 3, generator=g),
+                                 contact_filt=torch.rand(512, 4, generator=g) < 0.6)
+    mock.foot_positions[:, :, 2] = 0.02 * torch.randn(512, 4, generator=g)
+    from legged_gym.envs.base.legged_robot_dtc import LeggedRobotDTC
+    out["rew_tracking"] = LeggedRobotDTC._reward_tracking_optimal_footholds(mock).numpy()
+    out["rew_miss"] = LeggedRobotDTC._reward_foothold_miss(mock).numpy()
     save("scorer", **out)
 
 

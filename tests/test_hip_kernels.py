@@ -303,3 +303,14 @@ def test_linear_wgrad_segments_and_gather():
     ops.linear_wgrad(d(dZ), X, dW, db, ws)
     np.testing.assert_allclose(_np(dW), ref_w.numpy(), rtol=3e-5, atol=3e-5)
     np.testing.assert_allclose(_np(db), dZ.double().sum(0).numpy(), rtol=3e-5, atol=3e-5)
+
+
+def test_foothold_rewards_vs_oracle():
+    from dtc_amd import foothold
+    from oracle import foothold as OF
+    from test_oracle_golden import _reward_case
+    foot, world, contact = _reward_case()
+    tr, miss = OF.rewards(foot.numpy(), world.numpy(), contact.numpy())
+    t, m = foothold.rewards(foot.to(DEV), world.to(DEV), contact.to(DEV))
+    np.testing.assert_allclose(_np(t), tr, rtol=2e-6, atol=2e-6)
+    np.testing.assert_array_equal(_np(m), miss)

@@ -198,3 +198,22 @@ def test_update_4096_first_steps_match_reference(golden):
     alg = _oracle_alg(4096)
     recs = _run_oracle(alg, 4096, 1)
     _check(recs, g, "u4096_", lambda k: 2e-5)
+
+
+def _reward_case():
+    inp = S.scorer_inputs(512, seed=7)
+    o = _oracle_scorer(inp)
+    g = torch.Generator().manual_seed(5)
+    world = torch.from_numpy(o["optimal_footholds_world"])
+    foot = world + 0.05 * torch.randn(512, 4, 3, generator=g)
+    contact = torch.rand(512, 4, generator=g) < 0.6
+    foot[:, :, 2] = 0.02 * torch.randn(512, 4, generator=g)
+    return foot, world, contact
+
+
+def test_foothold_rewards_match_reference(golden):
+    g = golden("scorer")
+    foot, world, contact = _reward_case()
+    tr, miss = OF.rewards(foot.numpy(), world.numpy(), contact.numpy())
+    np.testing.assert_allclose(tr, g["rew_tracking"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_array_equal(miss, g["rew_miss"])
