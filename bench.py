@@ -138,7 +138,7 @@ def main():
         lib.dtc_prof_enable(0)
         rep = _ffi.prof_report()
         lib.dtc_prof_reset()
-        gemm = [r for r in rep if r["name"] in ("linear_fwd", "linear_dgrad", "linear_wgrad")]
+        gemm = [r for r in rep if r["name"].split("[")[0] in ("linear_fwd", "linear_dgrad", "linear_wgrad")]
         ms = sum(r["ms_total"] for r in gemm)
         fl = sum(r["work"] for r in gemm)
         n_launch = sum(r["launches"] for r in gemm)

@@ -19,6 +19,8 @@ struct ProfScope {
     hipStream_t stream;
 };
 
+const char* prof_shape_name(const char* base, int M, int N, int K);
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

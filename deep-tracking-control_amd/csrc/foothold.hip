@@ -40,10 +40,32 @@ struct GridParams {
     float y[32];
 };
 
+// 64-lane reductions on DPP (no LDS round trips): quad_perm xor1, xor2, row_half_mirror, row_mirror leave the
+// 16-lane row total in every lane of the row; row_bcast15 / row_bcast31 fold the four rows into lane 63.
+// For a sum this is exactly the xor-butterfly with offsets 1,2,4,8,16,32 (the order oracle/foothold.py uses):
+// every step adds two values that are uniform over the sub-group they came from, and a+b == b+a bitwise.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
-    return v;
+    v = v + dpp_f<0xB1, 0xF>(0.f, v);
+    v = v + dpp_f<0x4E, 0xF>(0.f, v);
+    v = v + dpp_f<0x141, 0xF>(0.f, v);
+    v = v + dpp_f<0x140, 0xF>(0.f, v);
+    v = v + dpp_f<0x142, 0xA>(0.f, v);
+    v = v + dpp_f<0x143, 0xC>(0.f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_min(float v) {
+    const float inf = __builtin_inff();
+    v = fminf(v, dpp_f<0xB1, 0xF>(inf, v));
+    v = fminf(v, dpp_f<0x4E, 0xF>(inf, v));
+    v = fminf(v, dpp_f<0x141, 0xF>(inf, v));
+    v = fminf(v, dpp_f<0x140, 0xF>(inf, v));
+    v = fminf(v, dpp_f<0x142, 0xA>(inf, v));
+    v = fminf(v, dpp_f<0x143, 0xC>(inf, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Cody-Waite reduction + minimax polynomials; constants/order == oracle/quat.py:sincos
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(256) void foothold_plan_kernel(
     c.wq = qw / nq;
 
     float best[4];
-    int bidx[4];
+    int bidx[4], bix[4], biy[4];          // winner per leg: flat index and its (ix, iy)
     bool need_full = DEBUG;
     if (!DEBUG) {
         // ---- fast path: one 8x8 candidate patch per leg
@@ -261,7 +283,8 @@ __global__ __launch_bounds__(256) void foothold_plan_kernel(
             const float lx = cyaw * rx + syaw * ry, ly = -syaw * rx + cyaw * ry;
             const float u = (lx - x0) * inv_dx, v = (ly - y0) * inv_dy;
             // all in-radius cells have |iu - u| < rad: they fit in 8 consecutive cells iff 2*rad < 7
-            const bool fits = (2.0f * rad_x < 7.0f) && (2.0f * rad_y < 7.0f) && (fabsf(u) < 1e6f) && (fabsf(v) < 1e6f);
+            const bool fits = (2.0f * rad_x < 7.0f) && (2.0f * rad_y < 7.0f) && (fabsf(u) < 1e6f) && (fabsf(v) < 1e6f) &&
+                              ny >= 8;   // flat index must grow with the lane id inside the patch (see below)
             const int sx = (int)floorf(u - rad_x) + 1, sy = (int)floorf(v - rad_y) + 1;
             const int ix = sx + wx, iy = sy + wy;
             float tot = __builtin_inff();
@@ -272,12 +295,19 @@ __global__ __launch_bounds__(256) void foothold_plan_kernel(
                 float d;
                 tot = total_score(p, predx[l], predy[l], d);
             }
-            wave_argmin(tot, ii);
-            best[l] = tot;
-            bidx[l] = ii;
+            // argmin = DPP min of the totals, then the LOWEST lane holding it (lane = wx*8 + wy and ny >= 8,
+            // so the flat index ix*ny + iy grows with the lane id: lowest lane == lowest index == torch's tie rule)
+            const float mn = wave_min(tot);
+            const unsigned long long hit = __ballot(tot == mn);
+            const int src = hit ? __ffsll((long long)hit) - 1 : 0;
+            best[l] = mn;
+            const int srcu = __builtin_amdgcn_readfirstlane(src);
+            bidx[l] = __builtin_amdgcn_readlane(ii, srcu);
+            bix[l] = __builtin_amdgcn_readlane(ix, srcu);
+            biy[l] = __builtin_amdgcn_readlane(iy, srcu);
             // accept only a "valid" winner: every total < 1 is an in-radius, non-sentinel point, and all
             // such points lie inside the patch, so the patch minimum is then the global minimum
-            need_full |= !(tot < 1.0f);
+            need_full |= !(mn < 1.0f);
         }
     }
 
@@ -324,6 +354,8 @@ __global__ __launch_bounds__(256) void foothold_plan_kernel(
         for (int l = 0; l < 4; ++l) {
             wave_argmin(best[l], bidx[l]);
             if (bidx[l] == 0x7fffffff) bidx[l] = 0;
+            bix[l] = bidx[l] / ny;
+            biy[l] = bidx[l] - bix[l] * ny;
             if (DEBUG) {
                 wave_argmin(nbest[l], nidx[l]);
                 if (nidx[l] == 0x7fffffff) nidx[l] = 0;
@@ -333,29 +365,29 @@ __global__ __launch_bounds__(256) void foothold_plan_kernel(
     }
 
     // ---- decode (legged_robot_dtc.py:184-201); lane l < 4 writes leg l
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        if (active && lane == l) {
-            const int bi = bidx[l];
-            idx_out[nn * 4 + l] = (int64_t)bi;
-            const int xi = bi % ny, yi = bi / ny;
-            // the reference gathers the x table with the y-index and vice versa (sic)
-            obs_out[nn * 8 + l] = xs[xi % nx];
-            obs_out[nn * 8 + 4 + l] = ys[yi % ny];
-            const float px = xs[yi], py = ys[xi];
-            const float t0 = -(c.zq * py) * 2.0f;
-            const float t1 = (c.zq * px) * 2.0f;
-            world_out[nn * 12 + l * 3 + 0] = ((px + c.wq * t0) + (-(c.zq * t1))) + c.bx;
-            world_out[nn * 12 + l * 3 + 1] = ((py + c.wq * t1) + (c.zq * t0)) + c.by;
-            world_out[nn * 12 + l * 3 + 2] = rawE[bi];
-            pred_out[nn * 12 + l * 3 + 0] = predx[l];
-            pred_out[nn * 12 + l * 3 + 1] = predy[l];
-            pred_out[nn * 12 + l * 3 + 2] = predz[l];
-            const V3 pr = quat_rotate_inverse(qx, qy, qz, qw, V3{predx[l] - c.bx, predy[l] - c.by, predz[l] - c.bz});
-            p2r_out[nn * 12 + l * 3 + 0] = pr.x;
-            p2r_out[nn * 12 + l * 3 + 1] = pr.y;
-            p2r_out[nn * 12 + l * 3 + 2] = pr.z;
-        }
+    if (active && lane < 4) {
+        const int l = lane;
+        auto pick_i = [&](const int (&a)[4]) { return l == 0 ? a[0] : (l == 1 ? a[1] : (l == 2 ? a[2] : a[3])); };
+        auto pick_f = [&](const float (&a)[4]) { return l == 0 ? a[0] : (l == 1 ? a[1] : (l == 2 ? a[2] : a[3])); };
+        const int bi = pick_i(bidx), xi = pick_i(biy), yi = pick_i(bix);      // xi = idx % ny, yi = idx / ny
+        const float pxl = pick_f(predx), pyl = pick_f(predy), pzl = pick_f(predz);
+        idx_out[nn * 4 + l] = (int64_t)bi;
+        // the reference gathers the x table with the y-index and vice versa (sic); xi < ny, yi < nx
+        obs_out[nn * 8 + l] = xs[xi < nx ? xi : xi % nx];
+        obs_out[nn * 8 + 4 + l] = ys[yi < ny ? yi : yi % ny];
+        const float px = xs[yi], py = ys[xi];
+        const float t0 = -(c.zq * py) * 2.0f;
+        const float t1 = (c.zq * px) * 2.0f;
+        world_out[nn * 12 + l * 3 + 0] = ((px + c.wq * t0) + (-(c.zq * t1))) + c.bx;
+        world_out[nn * 12 + l * 3 + 1] = ((py + c.wq * t1) + (c.zq * t0)) + c.by;
+        world_out[nn * 12 + l * 3 + 2] = rawE[bi];
+        pred_out[nn * 12 + l * 3 + 0] = pxl;
+        pred_out[nn * 12 + l * 3 + 1] = pyl;
+        pred_out[nn * 12 + l * 3 + 2] = pzl;
+        const V3 pr = quat_rotate_inverse(qx, qy, qz, qw, V3{pxl - c.bx, pyl - c.by, pzl - c.bz});
+        p2r_out[nn * 12 + l * 3 + 0] = pr.x;
+        p2r_out[nn * 12 + l * 3 + 1] = pr.y;
+        p2r_out[nn * 12 + l * 3 + 2] = pr.z;
     }
 }
 

@@ -381,22 +381,35 @@ __global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __res
 // Weight gradient (split over the batch): part[s][n][c] = sum_{m in split s} dZ[m,n] X[m,c],
 // c == K holds the bias-gradient partial.  A second kernel reduces the splits.
 // ------------------------------------------------------------------------------------------
+// Column tiles are aligned to the segments of X (tile = (segment, tile inside the segment)), so every block
+// reads ONE source matrix: uniform descriptor, and -- because all lanes of a wave stage the same batch row --
+// the (optionally gathered) row offset is a SCALAR: idx[m] comes in through s_load, row*ld goes into the
+// SGPR offset of the buffer load, the lane offset is just the column.  Zero VALU per load.
 template <int BN>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dZ, long long lddz,
                                                            const SegMatDev X, float* __restrict__ part, int M, int N,
-                                                           int K, int rows_per_split) {
+                                                           int K, int rows_per_split, int col_tiles) {
     using C = Cfg<BN>;
     __shared__ float As[2][BK][C::LDA];
     __shared__ float Bs[2][BK][C::LDB];
-    const int row_tiles = (N + BM - 1) / BM, col_tiles = (K + BN - 1) / BN;
+    const int row_tiles = (N + BM - 1) / BM;
     const int tiles = row_tiles * col_tiles;
     // block b runs on XCD b%8: every XCD owns whole batch slices (splits), so each slice of dZ / X is
     // pulled from HBM into ONE L2 and shared there by all output tiles
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int split = xcd + 8 * (jb / tiles);
     const int t = jb % tiles;
-    const int tr = t / col_tiles, tc = t - tr * col_tiles;
-    const int n0 = tr * BM, c0 = tc * BN;
+    const int tr = t / col_tiles;
+    int tc = t - tr * col_tiles;
+    // (segment, local tile) of this column tile
+    int seg = 0;
+    for (; seg < X.nseg - 1; ++seg) {
+        const int nt = (X.s[seg].width + BN - 1) / BN;
+        if (tc < nt) break;
+        tc -= nt;
+    }
+    const SegDev sd = X.s[seg];
+    const int n0 = tr * BM, lc0 = tc * BN;           // lc0: first column inside the segment
     const int m_begin = split * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -406,29 +419,19 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     const int ai = tid & 127, ak0 = tid >> 7;
     constexpr int NA = BK / 2;
     const bool arow_ok = n0 + ai < N;
-    // B loader: Bs[kk][j] = X[m][c0+j]; the column (and therefore the segment) is fixed per thread
+    // B loader: Bs[kk][j] = X[m][col]; RPP batch rows per pass
     constexpr int RPP = 256 / BN;
     constexpr int NB = BK / RPP;
+    constexpr bool ROW_UNIFORM = BN >= 64;          // all lanes of a wave stage the same batch row
     const int bj = tid % BN, bk0 = tid / BN;
-    const int bcol = c0 + bj;
-    const bool bcol_ok = bcol < K;
-    const SegDev sd = X.s[find_seg(X, bcol_ok ? bcol : K - 1)];
+    const int bk0u = ROW_UNIFORM ? __builtin_amdgcn_readfirstlane(bk0) : bk0;
+    const bool bcol_ok = lc0 + bj < sd.width;
     const u32 ldb = (u32)sd.ld * 4u;
-    const u32 bcolb = (u32)(sd.col0 + ((bcol_ok ? bcol : K - 1) - sd.start)) * 4u;
-    // the segment pointer differs between lanes when a tile straddles two segments -> lane addresses
-    const float* bptr = sd.ptr;
-    u32 aoff[NA], boff[NB];
+    const u32 bcolb = bcol_ok ? (u32)(sd.col0 + lc0 + bj) * 4u : INVALID;
+    u32 aoff[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) aoff[i] = arow_ok ? (u32)((long long)(ak0 + 2 * i) * lddz + n0 + ai) * 4u : INVALID;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) boff[i] = (u32)(bk0 + RPP * i) * ldb + bcolb;
-    const rsrc_t ares = make_rsrc(dZ);
-    // uniform fast path for the X operand: the whole column tile lies in ONE non-gathered segment
-    const SegDev sd_first = X.s[find_seg(X, c0)];
-    const int last_col = (c0 + BN - 1 < K ? c0 + BN - 1 : K - 1);
-    const bool b_uniform = (find_seg(X, c0) == find_seg(X, last_col)) && !sd_first.gather;
-    const rsrc_t bres = make_rsrc(sd_first.ptr);
-    const u32 bcmask = bcol_ok ? 0u : INVALID;
+    const rsrc_t ares = make_rsrc(dZ), bres = make_rsrc(sd.ptr);
 
     float ra[NA], rb[NB];
     float bias_acc = 0.f;
@@ -436,22 +439,12 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
         const u32 sa = (u32)mb * (u32)lddz * 4u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | oob_mask(mb + ak0 + 2 * i, m_end - 1), sa);
-        if (b_uniform) {
-            const u32 sb = (u32)mb * (u32)sd_first.ld * 4u;
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
-                rb[i] = bload(bres, boff[i] | bcmask | oob_mask(mb + bk0 + RPP * i, m_end - 1), sb);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int m = mb + bk0 + RPP * i;
-                const bool ok = bcol_ok && m < m_end;
-                const int mc = m < m_end ? m : (m_end > m_begin ? m_end - 1 : 0);
-                const u32 r = sd.gather ? (u32)X.idx[mc] : (u32)mc;
-                const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bptr) +
-                                                                (unsigned long long)r * ldb + bcolb);
-                rb[i] = ok ? v : 0.f;
-            }
+        for (int i = 0; i < NB; ++i) {
+            const int m = mb + bk0u + RPP * i;
+            const int mc = m < m_end ? m : (m_end > m_begin ? m_end - 1 : 0);
+            const u32 r = sd.gather ? (u32)X.idx[mc] : (u32)mc;          // scalar when ROW_UNIFORM
+            rb[i] = bload(bres, bcolb | oob_mask(m, m_end - 1), r * ldb);
         }
     };
     auto store_tile = [&](int buf, int) {
@@ -486,8 +479,9 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
-        const int col = c0 + wn_off + 32 * j + l31;
-        if (col >= K) continue;
+        const int lcol = lc0 + wn_off + 32 * j + l31;
+        if (lcol >= sd.width) continue;
+        const int col = sd.start + lcol;
 #pragma unroll
         for (int i = 0; i < C::TM; ++i) {
 #pragma unroll
@@ -497,7 +491,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
             }
         }
     }
-    if (tc == 0) {   // bias-gradient partial: two threads staged each dZ column
+    if (seg == 0 && tc == 0) {   // bias-gradient partial: two threads staged each dZ column
         float* red = &As[0][0][0];
         __syncthreads();
         if (ak0 == 1) red[ai] = bias_acc;
@@ -581,6 +575,8 @@ int pick_bn_rows(int cols) {
 
 int wgrad_splits(int M, int N, int K) {
     const int bn = pick_bn(K);
+    // +3: segment-aligned column tiles add at most one tile per extra segment (the split count only has to
+    // be an upper bound for the workspace and a sane work division)
     const int tiles = (int)(dtc::ceil_div(N, BM) * dtc::ceil_div(K, bn));
     int s = (int)dtc::ceil_div(640, tiles);
     const int max_s = (int)dtc::ceil_div(M, BK * 8);
@@ -607,7 +603,7 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     hipStream_t s = (hipStream_t)stream;
     const int bn = pick_bn_rows(N);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, bn));
-    dtc::ProfScope prof("linear_fwd", 2.0 * M * (double)N * K, s);
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s);
     static const char* abl_env = getenv("DTC_GEMM_ABLATE");      // profiling aid: skip phases of the K loop
     const int abl = abl_env ? atoi(abl_env) : 0;
     static const char* pipe_env = getenv("DTC_GEMM_PIPE");
@@ -634,7 +630,7 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
     hipStream_t s = (hipStream_t)stream;
     const int bn = pick_bn_rows(K);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K, bn));
-    dtc::ProfScope prof("linear_dgrad", 2.0 * M * (double)N * K, s);
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * K, s);
     if (bn == 128) hipLaunchKernelGGL(linear_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act);
     else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act);
     else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act);
@@ -659,18 +655,20 @@ extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* 
     const int splits = wgrad_splits(M, N, K);
     int rows_per_split = (int)dtc::ceil_div(M, splits);
     rows_per_split = (int)dtc::ceil_div(rows_per_split, BK) * BK;
-    const int tiles = (int)(dtc::ceil_div(N, BM) * dtc::ceil_div(K, bn));
+    int col_tiles = 0;
+    for (int i = 0; i < xd.nseg; ++i) col_tiles += (int)dtc::ceil_div(xd.s[i].width, bn);
+    const int tiles = (int)dtc::ceil_div(N, BM) * col_tiles;
     float* part = (float*)workspace;
     {
-        dtc::ProfScope prof("linear_wgrad", 2.0 * M * (double)N * K, s);
+        dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, N, K), 2.0 * M * (double)N * K, s);
         const int grid = tiles * splits;
-        if (bn == 128) hipLaunchKernelGGL(linear_wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split);
-        else if (bn == 64) hipLaunchKernelGGL(linear_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split);
-        else hipLaunchKernelGGL(linear_wgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split);
+        if (bn == 128) hipLaunchKernelGGL(linear_wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split, col_tiles);
+        else if (bn == 64) hipLaunchKernelGGL(linear_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split, col_tiles);
+        else hipLaunchKernelGGL(linear_wgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split, col_tiles);
     }
     {
         const long long total = (long long)N * (K + 1);
-        dtc::ProfScope prof("wgrad_reduce", (double)total * 4.0 * (splits + 1), s);
+        dtc::ProfScope prof(dtc::prof_shape_name("wgrad_reduce", splits, N, K), (double)total * 4.0 * (splits + 1), s);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dtc::ceil_div(K + 1, 256), (unsigned)N), dim3(256), 0, s,
                            part, dW, db, N, K, splits);
     }

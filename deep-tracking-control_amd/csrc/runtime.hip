@@ -1,6 +1,7 @@
 // Error reporting + per-launch HIP-event profiler of libdtc_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -38,6 +39,18 @@ int check_launch(const char* what) {
         return DTC_ERR_LAUNCH;
     }
     return DTC_OK;
+}
+
+const char* prof_shape_name(const char* base, int M, int N, int K) {
+    // interned "base[MxNxK]" names when DTC_PROF_SHAPES is set (per-layer breakdown of the GEMM classes)
+    static const bool on = getenv("DTC_PROF_SHAPES") != nullptr;
+    if (!on || !g_prof_on) return base;
+    static std::map<std::string, std::string> pool;
+    char buf[96];
+    snprintf(buf, sizeof(buf), "%s[%dx%dx%d]", base, M, N, K);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    auto it = pool.emplace(buf, buf).first;
+    return it->second.c_str();
 }
 
 ProfScope::ProfScope(const char* name, double work, hipStream_t s) : slot(-1), stream(s) {

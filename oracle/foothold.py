@@ -14,7 +14,7 @@ Canonical operation order.  The reference's own result is insensitive to the red
 of the two per-env reductions (mean / var of 693 values; SURVEY.md F5: three orders gave
 identical indices on 32768/32768 cases), so this oracle FIXES the order to the one the HIP
 kernel uses -- 64 lane-strided partial sums (i = lane + 64*j, ascending j) followed by an
-xor-butterfly (offsets 32,16,8,4,2,1) -- and every other operation is a single correctly
+xor-butterfly (offsets 1,2,4,8,16,32 = the kernel's DPP quad / half-row / row / cross-row steps) -- and every other operation is a single correctly
 rounded float32 op in reference order.  The HIP kernel is therefore expected to agree with
 this file BIT FOR BIT on every output; this file in turn is pinned against the imported
 reference by tests/golden/scorer_*.npz (knife-edge policy: SURVEY.md §8c G4).
@@ -25,7 +25,7 @@ from . import quat
 
 F = np.float32
 NX, NY, NP = 33, 21, 693
-_BFLY = [np.arange(64) ^ o for o in (32, 16, 8, 4, 2, 1)]
+_BFLY = [np.arange(64) ^ o for o in (1, 2, 4, 8, 16, 32)]
 
 
 def wave_sum(v, valid=None):
