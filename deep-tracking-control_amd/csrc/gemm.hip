@@ -40,9 +40,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32;
 
 constexpr int BM = 128;
-constexpr int BK = 16;
+#ifndef DTC_BK
+#define DTC_BK 16
+#endif
+constexpr int BK = DTC_BK;             // K step; loaders derive their geometry from it
+constexpr int RP = 256 / BK;           // tile rows covered per loader pass of the k-contiguous operands
 constexpr int PAD = 4;
-constexpr int GEMM_PIPE = 0;          // LDS->MFMA pipeline variant used by dgrad / wgrad (see mfma_step)
 
 struct SegDev {
     float* ptr;
@@ -115,49 +118,30 @@ __device__ __forceinline__ bool map_tile(int b, int row_tiles, int col_tiles, in
 }
 inline int grid_for(int row_tiles, int col_tiles) { return 8 * (int)dtc::ceil_div(row_tiles, 8) * col_tiles; }
 
-// PIPE selects how the LDS->MFMA software pipeline is expressed (hipcc sinks every LDS read next to its
-// use unless told otherwise): 0 = leave it to the compiler, 1 = pin "reads of k-pair kp+1, then MFMAs of
-// k-pair kp" with sched_barrier fences, 2 = describe the same interleave with sched_group_barrier.
-template <int BN, int PIPE>
+template <int BN>
 __device__ __forceinline__ void mfma_step(const float* __restrict__ As, const float* __restrict__ Bs,
                                           f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN], int lane, int wm_off, int wn_off) {
     using C = Cfg<BN>;
     const int half = lane >> 5, l31 = lane & 31;
     const float* ap = As + half * C::LDA + wm_off + l31;
     const float* bp = Bs + half * C::LDB + wn_off + l31;
-    float a[2][C::TM], b[2][C::TN];
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i) a[0][i] = ap[32 * i];
-#pragma unroll
-    for (int j = 0; j < C::TN; ++j) b[0][j] = bp[32 * j];
 #pragma unroll
     for (int kp = 0; kp < BK / 2; ++kp) {
-        const int cur = kp & 1, nxt = cur ^ 1;
-        if (kp + 1 < BK / 2) {
+        float a[C::TM], b[C::TN];
 #pragma unroll
-            for (int i = 0; i < C::TM; ++i) a[nxt][i] = ap[(2 * (kp + 1)) * C::LDA + 32 * i];
+        for (int i = 0; i < C::TM; ++i) a[i] = ap[2 * kp * C::LDA + 32 * i];
 #pragma unroll
-            for (int j = 0; j < C::TN; ++j) b[nxt][j] = bp[(2 * (kp + 1)) * C::LDB + 32 * j];
-        }
-        if (PIPE == 1) __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < C::TN; ++j) b[j] = bp[2 * kp * C::LDB + 32 * j];
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)
 #pragma unroll
             for (int j = 0; j < C::TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-        if (PIPE == 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    if (PIPE == 2) {
-        constexpr int NDS = (C::TM + C::TN + 1) / 2;          // ds_read2_b32 pairs per k-pair
-        __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);  // fragments of k-pair 0
-#pragma unroll
-        for (int kp = 0; kp < BK / 2 - 1; ++kp) {
-            __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);              // fragments of k-pair kp+1
-            __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);    // MFMAs of k-pair kp
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
 }
+
+struct Masked { static constexpr bool value = true; };
+struct Full { static constexpr bool value = false; };
 
 template <int BN>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN]) {
@@ -172,10 +156,10 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN]
 // ------------------------------------------------------------------------------------------
 // Forward: Y[M,N] = act(X[M,K] W[N,K]^T + b)
 // ------------------------------------------------------------------------------------------
-template <int BN, int PIPE>
+template <int BN>
 __global__ __launch_bounds__(256, 3) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ Y,
-                                                         long long ldy, int M, int N, int K, int act, int ablate) {
+                                                         long long ldy, int M, int N, int K, int act) {
     using C = Cfg<BN>;
     __shared__ float As[2][BK][C::LDA];
     __shared__ float Bs[2][BK][C::LDB];
@@ -186,30 +170,30 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_kernel(const SegMatDev X, c
     const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
 
     // loader geometry: thread owns k = kk and rows rbase + 16*i of both operand tiles
-    const int kk = tid & 15, rbase = tid >> 4;
-    constexpr int NA = BM / 16, NB = BN / 16;
+    const int kk = tid & (BK - 1), rbase = tid / BK;
+    constexpr int NA = BM / RP, NB = BN / RP;
     int arow[NA], grow[NA];
     u32 woff[NB];                                   // lane byte offset into W (loop invariant)
     bool any_gather = false;
     for (int s = 0; s < X.nseg; ++s) any_gather |= X.s[s].gather != 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + rbase + 16 * i;
+        const int m = m0 + rbase + RP * i;
         arow[i] = m < M ? m : -1;
         grow[i] = (any_gather && m < M) ? (int)X.idx[m] : arow[i];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int n = n0 + rbase + 16 * i;
+        const int n = n0 + rbase + RP * i;
         woff[i] = n < N ? (u32)(n * K + kk) * 4u : INVALID;
     }
     const rsrc_t wres = make_rsrc(W);
 
-    // K-tile iterator over the segments (uniform state)
-    int seg = 0, kt = 0;
+    // K loop: segment by segment.  The steady-state loop over the full tiles of a segment is ONE basic
+    // block (loads of tile kt+1, MFMAs of tile kt, LDS stores, barrier) with no masks and no branches; the
+    // last tile of a segment (k tail -> masked) and the hop into the next segment are peeled copies.
     SegDev sd = X.s[0];
-    int seg_tiles = (sd.width + BK - 1) / BK;
-    rsrc_t ares = make_rsrc(sd.ptr);
+    rsrc_t ares;
     u32 aoff[NA];                                   // lane byte offset of the A element inside the segment
     auto enter_segment = [&]() {
         ares = make_rsrc(sd.ptr);
@@ -219,54 +203,47 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_kernel(const SegMatDev X, c
             aoff[i] = r >= 0 ? ((u32)r * (u32)sd.ld + (u32)(sd.col0 + kk)) * 4u : INVALID;
         }
     };
-    enter_segment();
-    int total_tiles = 0;
-    for (int s = 0; s < X.nseg; ++s) total_tiles += (X.s[s].width + BK - 1) / BK;
-
     float ra[NA], rb[NB];
-    auto load_tile = [&]() {            // tile (seg, kt) -> registers; lanes past the segment width read 0
-        const u32 kmask = oob_mask(kt * BK + kk, sd.width - 1);
+    auto load_tile = [&](auto masked, int kt) {     // tile kt of the current segment -> registers
+        const u32 kmask = decltype(masked)::value ? oob_mask(kt * BK + kk, sd.width - 1) : 0u;
         const u32 ka = (u32)(kt * BK) * 4u, kw = (u32)(sd.start + kt * BK) * 4u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | kmask, ka);
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = bload(wres, woff[i] | kmask, kw);
     };
-    auto advance = [&]() {
-        if (++kt == seg_tiles) {
-            kt = 0;
-            ++seg;
-            if (seg < X.nseg) {
-                sd = X.s[seg];
-                seg_tiles = (sd.width + BK - 1) / BK;
-                enter_segment();
-            }
-        }
-    };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = ra[i];
+        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + RP * i] = ra[i];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[buf][kk][rbase + 16 * i] = rb[i];
+        for (int i = 0; i < NB; ++i) Bs[buf][kk][rbase + RP * i] = rb[i];
     };
 
     f32x16 acc[C::TM][C::TN];
     zero_acc<BN>(acc);
 
-    load_tile();
+    int buf = 0;
+    auto step = [&](auto masked, int kt_next) {     // stage tile kt_next while the MFMAs consume LDS[buf]
+        load_tile(masked, kt_next);
+        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
+        store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    };
+    enter_segment();
+    load_tile(Masked{}, 0);
     store_tile(0);
     __syncthreads();
-    for (int t = 0; t < total_tiles; ++t) {
-        const int buf = t & 1;
-        const bool more = t + 1 < total_tiles;
-        if (more) {
-            advance();
-            if (!(ablate & 1)) load_tile();
-        }
-        if (!(ablate & 2)) mfma_step<BN, PIPE>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-        if (more && !(ablate & 4)) store_tile(buf ^ 1);
-        if (!(ablate & 8)) __syncthreads();
+    for (int seg = 0;;) {
+        const int n = (sd.width + BK - 1) / BK;
+        for (int kt = 1; kt + 1 < n; ++kt) step(Full{}, kt);
+        if (n > 1) step(Masked{}, n - 1);
+        if (++seg == X.nseg) break;
+        sd = X.s[seg];
+        enter_segment();
+        step(Masked{}, 0);
     }
+    mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
 
     const int half = lane >> 5, l31 = lane & 31;
     const bool full = (m0 + BM <= M) && (n0 + BN <= N);
@@ -306,15 +283,15 @@ __global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
 
-    const int kk = tid & 15, rbase = tid >> 4;      // A loader (dZ rows, reduction index n contiguous)
-    constexpr int NA = BM / 16;
+    const int kk = tid & (BK - 1), rbase = tid / BK;      // A loader (dZ rows, reduction index n contiguous)
+    constexpr int NA = BM / RP;
     constexpr int RPP = 256 / BN;                   // B loader: reduction rows per pass
     constexpr int NB = BK / RPP;
     const int bj = tid % BN, bk0 = tid / BN;
     u32 aoff[NA], boff[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + rbase + 16 * i;
+        const int m = m0 + rbase + RP * i;
         aoff[i] = m < M ? (u32)((long long)m * lddz + kk) * 4u : INVALID;
     }
 #pragma unroll
@@ -323,17 +300,18 @@ __global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __res
     const rsrc_t ares = make_rsrc(dZ), bres = make_rsrc(W);
 
     float ra[NA], rb[NB];
-    auto load_tile = [&](int n_0) {
-        const u32 nmask = oob_mask(n_0 + kk, N - 1);
+    auto load_tile = [&](auto masked, int n_0) {
+        constexpr bool MK = decltype(masked)::value;
+        const u32 nmask = MK ? oob_mask(n_0 + kk, N - 1) : 0u;
         const u32 sa = (u32)n_0 * 4u, sb = (u32)n_0 * (u32)K * 4u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | nmask, sa);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = bload(bres, boff[i] | oob_mask(n_0 + bk0 + RPP * i, N - 1), sb);
+        for (int i = 0; i < NB; ++i) rb[i] = bload(bres, boff[i] | (MK ? oob_mask(n_0 + bk0 + RPP * i, N - 1) : 0u), sb);
     };
-    auto store_tile = [&](int buf, int) {
+    auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + 16 * i] = ra[i];
+        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + RP * i] = ra[i];
 #pragma unroll
         for (int i = 0; i < NB; ++i) Bs[buf][bk0 + RPP * i][bj] = rb[i];
     };
@@ -341,17 +319,21 @@ __global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __res
     f32x16 acc[C::TM][C::TN];
     zero_acc<BN>(acc);
 
-    const int KT = (N + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) load_tile((kt + 1) * BK);
-        mfma_step<BN, GEMM_PIPE>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-        if (kt + 1 < KT) store_tile(buf ^ 1, (kt + 1) * BK);
+    int buf = 0;
+    auto step = [&](auto masked, int kt_next) {
+        load_tile(masked, kt_next * BK);
+        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
+        store_tile(buf ^ 1);
         __syncthreads();
-    }
+        buf ^= 1;
+    };
+    const int KT = (N + BK - 1) / BK;
+    load_tile(Masked{}, 0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 1; kt + 1 < KT; ++kt) step(Full{}, kt);      // branch-free steady state (full tiles)
+    if (KT > 1) step(Masked{}, KT - 1);                        // N tail
+    mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
 
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -435,19 +417,20 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 
     float ra[NA], rb[NB];
     float bias_acc = 0.f;
-    auto load_tile = [&](int mb) {
+    auto load_tile = [&](auto masked, int mb) {
+        constexpr bool MK = decltype(masked)::value;
         const u32 sa = (u32)mb * (u32)lddz * 4u;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | oob_mask(mb + ak0 + 2 * i, m_end - 1), sa);
+        for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | (MK ? oob_mask(mb + ak0 + 2 * i, m_end - 1) : 0u), sa);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int m = mb + bk0u + RPP * i;
-            const int mc = m < m_end ? m : (m_end > m_begin ? m_end - 1 : 0);
+            const int mc = (!MK || m < m_end) ? m : m_end - 1;
             const u32 r = sd.gather ? (u32)X.idx[mc] : (u32)mc;          // scalar when ROW_UNIFORM
-            rb[i] = bload(bres, bcolb | oob_mask(m, m_end - 1), r * ldb);
+            rb[i] = bload(bres, bcolb | (MK ? oob_mask(m, m_end - 1) : 0u), r * ldb);
         }
     };
-    auto store_tile = [&](int buf, int) {
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             As[buf][ak0 + 2 * i][ai] = ra[i];
@@ -461,17 +444,21 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     zero_acc<BN>(acc);
 
     const int KT = (m_end - m_begin + BK - 1) / BK;
-    if (KT > 0) {
-        load_tile(m_begin);
-        store_tile(0, m_begin);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) load_tile(m_begin + (kt + 1) * BK);
-        mfma_step<BN, GEMM_PIPE>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-        if (kt + 1 < KT) store_tile(buf ^ 1, m_begin + (kt + 1) * BK);
+    if (KT > 0) {                                   // uniform per block (an empty trailing split writes zeros)
+        int buf = 0;
+        auto step = [&](auto masked, int kt_next) {
+            load_tile(masked, m_begin + kt_next * BK);
+            mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
+            store_tile(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        };
+        load_tile(Masked{}, m_begin);
+        store_tile(0);
         __syncthreads();
+        for (int kt = 1; kt + 1 < KT; ++kt) step(Full{}, kt);  // branch-free steady state (full tiles)
+        if (KT > 1) step(Masked{}, KT - 1);                    // batch tail of the split
+        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
     }
 
     const long long ldp = K + 1;
@@ -604,15 +591,9 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     const int bn = pick_bn_rows(N);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, bn));
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s);
-    static const char* abl_env = getenv("DTC_GEMM_ABLATE");      // profiling aid: skip phases of the K loop
-    const int abl = abl_env ? atoi(abl_env) : 0;
-    static const char* pipe_env = getenv("DTC_GEMM_PIPE");
-    const int pipe = pipe_env ? atoi(pipe_env) : GEMM_PIPE;
-#define DTC_FWD(BN_, P_) hipLaunchKernelGGL((linear_fwd_kernel<BN_, P_>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, abl)
-    if (bn == 128) { if (pipe == 1) DTC_FWD(128, 1); else if (pipe == 2) DTC_FWD(128, 2); else DTC_FWD(128, 0); }
-    else if (bn == 64) { if (pipe == 1) DTC_FWD(64, 1); else if (pipe == 2) DTC_FWD(64, 2); else DTC_FWD(64, 0); }
-    else { if (pipe == 1) DTC_FWD(32, 1); else if (pipe == 2) DTC_FWD(32, 2); else DTC_FWD(32, 0); }
-#undef DTC_FWD
+    if (bn == 128) hipLaunchKernelGGL(linear_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
+    else if (bn == 64) hipLaunchKernelGGL(linear_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
+    else hipLaunchKernelGGL(linear_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
     return dtc::check_launch("linear_fwd");
 }
 

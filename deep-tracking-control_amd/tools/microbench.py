@@ -13,7 +13,7 @@ from dtc_amd import _ffi, foothold, ops, synthetic as S  # noqa: E402
 DEV = "cuda:0"
 
 
-def timed(fn, iters=20, warm=3):
+def timed(fn, iters=50, warm=25):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -41,12 +41,13 @@ def gemm():
         db = torch.empty(N, device=DEV)
         ws = torch.empty(ops.wgrad_workspace_bytes(M, N, K) // 4, device=DEV)
         fl = 2.0 * M * N * K
+        t0 = timed(lambda: torch.mm(X, W.t()))
         t1 = timed(lambda: ops.linear_fwd(X, W, b, Y, "relu"))
         t2 = timed(lambda: ops.linear_dgrad(dZ, W, dX, X, "relu"))
         t3 = timed(lambda: ops.linear_wgrad(dZ, X, dW, db, ws))
         t4 = timed(lambda: torch.mm(X, W.t()))
         print(f"M={M} N={N:4d} K={K:4d}  fwd {t1*1e3:8.1f} us {fl/t1/1e9:7.1f} TF | dgrad {t2*1e3:8.1f} us {fl/t2/1e9:7.1f} TF"
-              f" | wgrad {t3*1e3:8.1f} us {fl/t3/1e9:7.1f} TF | torch.mm {t4*1e3:8.1f} us {fl/t4/1e9:7.1f} TF", flush=True)
+              f" | wgrad {t3*1e3:8.1f} us {fl/t3/1e9:7.1f} TF | torch.mm {t4*1e3:8.1f} us {fl/t4/1e9:7.1f} TF (first {fl/t0/1e9:6.1f})", flush=True)
 
 
 def ablate():
