@@ -90,6 +90,12 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
     void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)INVALID, 0x00020000);
 }
+__device__ __forceinline__ rsrc_t make_rsrc_bytes(const void* p, long long bytes) {   // loads past `bytes` return 0
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)(u32)bytes, 0x00020000);
+}
 // sign-bit mask: INVALID when x > limit (both < 2^31), else 0 -- pure arithmetic, because hipcc turns a
 // `cond ? INVALID : off` select feeding a load into two predicated loads behind exec-mask branches
 __device__ __forceinline__ u32 oob_mask(int x, int limit) { return (u32)(limit - x) & INVALID; }
@@ -335,22 +341,34 @@ __global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __res
     if (KT > 1) step(Masked{}, KT - 1);                        // N tail
     mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
 
+    // epilogue: the saved activations come in through unconditional buffer loads (rows >= M fall past the
+    // descriptor's size, columns >= K get the INVALID offset -> 0), so all 16 loads of a 32x32 tile are in
+    // flight together instead of one exec-guarded load -> select -> store chain per element
     const int half = lane >> 5, l31 = lane & 31;
+    const rsrc_t xres = make_rsrc_bytes(Xs, (long long)M * ldxs * 4);
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
         const int col = c0 + wn_off + 32 * j + l31;
-        if (col >= K) continue;
-        const SegDev sd = dX.s[find_seg(dX, col)];
-        if (sd.ptr == nullptr) continue;
+        const bool cok = col < K;
+        const SegDev sd = dX.s[find_seg(dX, cok ? col : 0)];
+        const bool live = cok && sd.ptr != nullptr;
         float* dst = sd.ptr + sd.col0 + (col - sd.start);
 #pragma unroll
         for (int i = 0; i < C::TM; ++i) {
+            const int row0 = m0 + wm_off + 32 * i + 4 * half;
+            float y[16];
+            if (act != DTC_ACT_NONE) {
+                const u32 xoff = ((u32)row0 * (u32)ldxs + (u32)col) * 4u | (cok ? 0u : INVALID);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    y[r] = bload(xres, xoff, (u32)(((r & 3) + 8 * (r >> 2)) * (int)ldxs) * 4u);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm_off + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < M) {
-                    float v = acc[i][j][r];
-                    if (act != DTC_ACT_NONE) v = act_bwd(v, Xs[(long long)row * ldxs + col], act);
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r];
+                if (act != DTC_ACT_NONE) v = act_bwd(v, y[r], act);
+                if (live && row < M) {
                     float* q = dst + (long long)row * sd.ld;
                     *q = sd.accumulate ? (*q + v) : v;
                 }
@@ -543,13 +561,12 @@ int to_dev(const DtcSegMat* h, SegMatDev& d, int expect_cols, bool is_output, lo
     return DTC_OK;
 }
 
-// column-tile width: the widest tile whose padding waste is within 5% of the best
+// wgrad column-tile width: 64 measured at least as fast as 128 on every layer of this model (sweep in
+// tools/microbench.py wgrad); DTC_WGRAD_BN overrides for experiments
 int pick_bn(int cols) {
-    auto waste = [&](int bn) { return (double)(dtc::ceil_div(cols, bn) * bn - cols) / cols; };
-    if (cols <= 32) return 32;
-    if (cols <= 64) return 64;
-    const double w128 = waste(128), w64 = waste(64);
-    return (w128 <= w64 + 0.05) ? 128 : 64;
+    static const char* force = getenv("DTC_WGRAD_BN");
+    if (force && cols > 64) return atoi(force);
+    return cols <= 32 ? 32 : 64;
 }
 
 // fwd / dgrad: 128x64 tiles measured faster than 128x128 at every layer width of this model (twice the
@@ -560,16 +577,20 @@ int pick_bn_rows(int cols) {
     return cols <= 32 ? 32 : 64;
 }
 
-int wgrad_splits(int M, int N, int K) {
-    const int bn = pick_bn(K);
-    // +3: segment-aligned column tiles add at most one tile per extra segment (the split count only has to
-    // be an upper bound for the workspace and a sane work division)
-    const int tiles = (int)(dtc::ceil_div(N, BM) * dtc::ceil_div(K, bn));
-    int s = (int)dtc::ceil_div(640, tiles);
-    const int max_s = (int)dtc::ceil_div(M, BK * 8);
+// Batch splits of the weight gradient: whole splits per XCD (multiple of 8), as many as keep all blocks
+// co-resident in ONE wave of workgroups (256 CUs x 4 blocks): a few blocks past that run alone at the end.
+int wgrad_splits(int M, int tiles) {
+    static const char* target_env = getenv("DTC_WGRAD_BLOCKS");
+    const int target = target_env ? atoi(target_env) : 1024;
+    int s = target / tiles / 8 * 8;
+    if (s < 8) s = 8;
+    const int max_s = (int)dtc::ceil_div(dtc::ceil_div(M, BK * 8), 8) * 8;
     if (s > max_s) s = max_s;
-    s = (int)dtc::ceil_div(s, 8) * 8;          // whole splits per XCD
     return s;
+}
+// upper bound over every segmentation of X (segment-aligned column tiles only add tiles -> fewer splits)
+int wgrad_splits_bound(int M, int N, int K) {
+    return wgrad_splits(M, (int)(dtc::ceil_div(N, BM) * dtc::ceil_div(K, pick_bn(K))));
 }
 
 }  // namespace
@@ -605,6 +626,7 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
     DTC_REQUIRE(act == DTC_ACT_NONE || (Xsaved != nullptr && ldxs >= K), "activation derivative needs Xsaved");
     DTC_REQUIRE(act == DTC_ACT_NONE || (dX && dX->nseg == 1), "activation derivative needs a single-segment destination");
     DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * lddz <= MAX_ELEMS, "matrix too large");
+    DTC_REQUIRE(act == DTC_ACT_NONE || (long long)M * ldxs <= MAX_ELEMS, "saved activation matrix too large");
     SegMatDev xd;
     int rc = to_dev(dX, xd, K, true, 0);
     if (rc != DTC_OK) return rc;
@@ -620,7 +642,7 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
 
 extern "C" int64_t dtc_linear_wgrad_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return (int64_t)wgrad_splits(M, N, K) * N * (K + 1) * (int64_t)sizeof(float);
+    return (int64_t)wgrad_splits_bound(M, N, K) * N * (K + 1) * (int64_t)sizeof(float);
 }
 
 extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* X, float* dW, float* db, void* workspace,
@@ -633,12 +655,12 @@ extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* 
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int bn = pick_bn(K);
-    const int splits = wgrad_splits(M, N, K);
-    int rows_per_split = (int)dtc::ceil_div(M, splits);
-    rows_per_split = (int)dtc::ceil_div(rows_per_split, BK) * BK;
     int col_tiles = 0;
     for (int i = 0; i < xd.nseg; ++i) col_tiles += (int)dtc::ceil_div(xd.s[i].width, bn);
     const int tiles = (int)dtc::ceil_div(N, BM) * col_tiles;
+    const int splits = wgrad_splits(M, tiles);
+    int rows_per_split = (int)dtc::ceil_div(M, splits);
+    rows_per_split = (int)dtc::ceil_div(rows_per_split, BK) * BK;
     float* part = (float*)workspace;
     {
         dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, N, K), 2.0 * M * (double)N * K, s);

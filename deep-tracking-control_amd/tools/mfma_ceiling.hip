@@ -173,5 +173,12 @@ int main() {
     run<5, 64, 4, 3, true>(src, out, "real operands", 32, 1536);
     run<5, 128, 4, 2, true>(src, out, "real operands", 32, 768);
     run<5, 128, 4, 3, true>(src, out, "real operands", 32, 768);
+    // tail / balance: one exact wave of blocks, and 2 tiles' worth of K per block at 3 blocks per CU
+    run<5, 64, 4, 4, true>(src, out, "one wave", 32, 1024);
+    run<5, 64, 4, 4, true>(src, out, "one wave, 1.5x K", 48, 1024);
+    run<5, 64, 4, 3, true>(src, out, "3/CU, 2x K", 64, 768);
+    run<5, 64, 4, 2, true>(src, out, "2/CU, 3x K", 96, 512);
+    run<5, 64, 4, 4, true>(src, out, "1.25 waves", 32, 1280);
+    run<5, 64, 4, 6, true>(src, out, "occ 6", 32, 1536);
     return 0;
 }

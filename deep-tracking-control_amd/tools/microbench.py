@@ -50,6 +50,19 @@ def gemm():
               f" | wgrad {t3*1e3:8.1f} us {fl/t3/1e9:7.1f} TF | torch.mm {t4*1e3:8.1f} us {fl/t4/1e9:7.1f} TF (first {fl/t0/1e9:6.1f})", flush=True)
 
 
+def wgrad():
+    M = 24576
+    for N, K in [(512, 512), (512, 693), (512, 752), (512, 584), (256, 512), (693, 512)]:
+        X = torch.randn(M, K, device=DEV)
+        dZ = torch.randn(M, N, device=DEV)
+        dW = torch.empty(N, K, device=DEV)
+        db = torch.empty(N, device=DEV)
+        ws = torch.empty(ops.wgrad_workspace_bytes(M, N, K) // 4, device=DEV)
+        t = timed(lambda: ops.linear_wgrad(dZ, X, dW, db, ws))
+        print(f"BN={os.environ.get('DTC_WGRAD_BN', '-')} BLOCKS={os.environ.get('DTC_WGRAD_BLOCKS', '-')} N={N} K={K}: "
+              f"wgrad+reduce {t*1e3:7.1f} us {2.0*M*N*K/t/1e9:6.1f} TF", flush=True)
+
+
 def ablate():
     """fwd GEMM with phases of the K loop removed (DTC_GEMM_ABLATE bits: 1 no global loads, 2 no MFMA,
     4 no LDS stores, 8 no barrier): which phase bounds the kernel?  Set per process via the env var."""
