@@ -127,15 +127,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel HIP-event timing of one more step (same process, same stream) for the roofline object
+    # per-kernel HIP-event timing of one more step (same process, each kernel on the stream it is launched on)
+    # for the roofline object.  The timed region above overlaps the weight-gradient GEMMs with the
+    # data-gradient chain on a second stream; a kernel that shares the chip has no duration of its own, so this
+    # pass runs the same kernels serialised (overlap off) -- rocprofv3 cross-check: DTC_OVERLAP_WGRAD=0.
     roof, classes = None, None
     if rank == 0:
         lib = _ffi.lib()
+        overlap = alg.overlap_wgrad
+        alg.overlap_wgrad = False
+        step()
+        torch.cuda.synchronize()
         lib.dtc_prof_reset()
         lib.dtc_prof_enable(1)
         step()
         torch.cuda.synchronize()
         lib.dtc_prof_enable(0)
+        alg.overlap_wgrad = overlap
         rep = _ffi.prof_report()
         lib.dtc_prof_reset()
         gemm = [r for r in rep if r["name"].split("[")[0] in ("linear_fwd", "linear_dgrad", "linear_wgrad")]
@@ -145,7 +153,7 @@ def main():
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof = dict(bound="mfma", kernel="linear_{fwd,dgrad,wgrad}_kernel (fp32 v_mfma_f32_32x32x2_f32 GEMM family)",
                     achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP32_MFMA_TFLOPS,
-                    traffic=None, launches=n_launch, avg_launch_us=ms * 1e3 / max(1, n_launch),
+                    traffic=None, launches=n_launch, measured="HIP events per launch, kernels serialised on one stream", avg_launch_us=ms * 1e3 / max(1, n_launch),
                     flop_per_launch=fl / max(1, n_launch))
         classes = {r["name"]: dict(ms=round(r["ms_total"], 3), launches=r["launches"],
                                    rate=(r["work"] / (r["ms_total"] * 1e-3) / 1e12) if r["ms_total"] > 0 else 0.0)
@@ -163,7 +171,7 @@ def main():
                                    "terrain encoder latent 512 + MLP actor/critic): foothold planner over the 98304 "
                                    "recorded height maps + compute_returns + PPO.update (5 epochs x 4 mini-batches of 24576)",
                        "num_envs_per_gpu": NUM_ENVS, "num_steps_per_env": NUM_STEPS, "mini_batch": 24576,
-                       "epochs": 5, "parallelism": f"dp{world}" if world > 1 else "single",
+                       "epochs": 5, "wgrad_overlap_stream": bool(alg.overlap_wgrad), "parallelism": f"dp{world}" if world > 1 else "single",
                        "mfma_frac_whole_step": (FLOP_PER_ENV_STEP * value / world) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
             "roofline": roof,
             "kernel_classes": classes,

@@ -19,6 +19,8 @@ attributes `actor_critic`, `optimizer`, `vae_optimizer`, `storage`, `learning_ra
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _ffi, distributed as dp, ops
@@ -105,25 +107,47 @@ def arena_named(arena):
 
 
 class _TrainWorkspace:
-    """Activation / gradient buffers of one mini-batch step (allocated once per batch size)."""
+    """Activation / gradient buffers of one mini-batch step (allocated once per batch size).
+
+    Every layer's input-gradient gets its OWN buffer (`g(name, width)`): the weight gradients run on a side
+    stream concurrently with the data-gradient chain (see PPO._bwd), so a buffer that a later layer's dgrad
+    would overwrite may still be being read.  26 buffers x B x <=693 floats ~ 1 GB at B = 24576."""
 
     def __init__(self, B, dev, num_actions):
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        self.B = B
+        self.B, self._dev = B, dev
         # VAE-only forward activations
         self.c1, self.c2, self.rec = e(B, 64), e(B, 128), e(B, 53)
         self.d1, self.d2, self.hr = e(B, 512), e(B, 512), e(B, 693)
-        # gradients
+        # loss gradients
         self.g_rec, self.g_hr = e(B, 53), e(B, 693)
-        self.gA, self.gB, self.dlt = e(B, 512), e(B, 512), e(B, 512)
-        self.g256, self.g128, self.g64 = e(B, 256), e(B, 128), e(B, 64)
+        self.dlt = e(B, 512)
         self.dmulv, self.dz = e(B, 35), e(B, 16)
         self.dmean, self.dval = e(B, num_actions), e(B, 1)
+        self._g = {}
         lib = _ffi.lib()
         shapes = [(512, 693), (512, 512), (693, 512), (512, 584), (512, 752), (256, 512), (128, 256), (64, 531),
                   (128, 64), (53, 128), (128, 265), (64, 128), (35, 64), (num_actions, 128), (1, 128)]
         self.wg = ops.workspace(max(lib.dtc_linear_wgrad_workspace(B, n, k) for n, k in shapes), dev)
         self.loss_ws = ops.workspace(lib.dtc_loss_workspace(B), dev)
+        # weight-gradient side stream
+        self.side = torch.cuda.Stream(device=dev)
+        self._events, self._ev_next = [], 0
+        self.joined = torch.cuda.Event()
+        self.side_busy = False
+
+    def g(self, name, width):
+        t = self._g.get(name)
+        if t is None:
+            t = self._g[name] = torch.empty(self.B, width, dtype=torch.float32, device=self._dev)
+        return t
+
+    def event(self):
+        if self._ev_next == len(self._events):
+            self._events.append(torch.cuda.Event())
+        ev = self._events[self._ev_next]
+        self._ev_next += 1
+        return ev
 
 
 class PPO:
@@ -158,6 +182,8 @@ class PPO:
         self.use_clipped_value_loss = use_clipped_value_loss
         self.num_adaptation_module_substeps = 1
         self._tws = {}
+        # weight gradients on a side stream, concurrent with the data-gradient chain (DTC_OVERLAP_WGRAD=0: serial)
+        self.overlap_wgrad = os.environ.get("DTC_OVERLAP_WGRAD", "1") != "0"
         self.capture_grads, self.captured = False, {}      # tests: snapshot of the (pre-clip) gradient arena
         self.last_update_stats = None      # [steps, STAT_COLS] table of the last update (host tensor)
 
@@ -230,20 +256,40 @@ class PPO:
         dp.allreduce_mean_(opt.g)        # one flat bucket per optimiser step (no-op on a single rank)
 
     def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None):
-        ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wg, M=tw.B)
+        """Backward of one dense layer.  The weight gradient (dW = dZ^T X, + split reduction) is off the critical
+        path -- only the optimiser step needs it -- so it goes to the side stream and overlaps with the
+        data-gradient chain of the layers below: small layers, launch gaps and kernel tails get filled."""
+        if self.overlap_wgrad:
+            ev = tw.event()
+            ev.record()                          # dZ and X are final on the main stream here
+            tw.side.wait_event(ev)
+            ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wg, M=tw.B, stream_ptr=tw.side.cuda_stream)
+            tw.side_busy = True
+        else:
+            ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wg, M=tw.B)
         if dX is not None:
             ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B)
+
+    def _join_wgrads(self, tw):
+        """Main stream waits for every weight gradient of this optimiser step."""
+        if tw.side_busy:
+            tw.joined.record(tw.side)
+            torch.cuda.current_stream().wait_event(tw.joined)
+            tw.side_busy = False
+        tw._ev_next = 0
 
     def _encoder_backward(self, fw, tw, flat, idx):
         """Shared tail of both steps: d l_t -> terrain_encoder, d(mu|lv) -> heads -> cenet_encoder."""
         L = self.actor_critic.L
-        self._bwd(tw, L["te2"], tw.dlt, fw.t2, tw.gA, fw.t2, "relu")
-        self._bwd(tw, L["te1"], tw.gA, fw.t1, tw.gB, fw.t1, "relu")
-        self._bwd(tw, L["te0"], tw.gB, segmat([seg(flat["privileged_observations"], 0, 693, gather=True)], idx))
-        self._bwd(tw, L["head"], tw.dmulv, fw.e, tw.g64, None, None)
-        self._bwd(tw, L["ce1"], tw.g64, fw.e1, tw.g128, fw.e1, "relu")
-        self._bwd(tw, L["ce0"], tw.g128, segmat([seg(flat["observation_histories"], 0, flat["observation_histories"].shape[1],
-                                                     gather=True)], idx))
+        g_te2, g_te1 = tw.g("te2", 512), tw.g("te1", 512)
+        self._bwd(tw, L["te2"], tw.dlt, fw.t2, g_te2, fw.t2, "relu")
+        self._bwd(tw, L["te1"], g_te2, fw.t1, g_te1, fw.t1, "relu")
+        self._bwd(tw, L["te0"], g_te1, segmat([seg(flat["privileged_observations"], 0, 693, gather=True)], idx))
+        g_head, g_ce1 = tw.g("head", 64), tw.g("ce1", 128)
+        self._bwd(tw, L["head"], tw.dmulv, fw.e, g_head, None, None)
+        self._bwd(tw, L["ce1"], g_head, fw.e1, g_ce1, fw.e1, "relu")
+        self._bwd(tw, L["ce0"], g_ce1, segmat([seg(flat["observation_histories"], 0, flat["observation_histories"].shape[1],
+                                                   gather=True)], idx))
 
     def _vae_step(self, fw, tw, flat, idx, eps, stats):
         """ppo.py:197-254: CE-net / terrain auto-encoder losses, backward, clip, Adam(5e-4)."""
@@ -261,16 +307,19 @@ class PPO:
         ops.vae_loss(tw.rec, tw.hr, fw.mulv, flat["next_observations"], flat["privileged_observations"],
                      flat["base_vel"], idx, tw.g_rec, tw.g_hr, tw.dmulv, stats[S_RECONS:S_RECONS + 4], tw.loss_ws)
         # terrain decoder
-        self._bwd(tw, L["td2"], tw.g_hr, tw.d2, tw.gA, tw.d2, "relu")
-        self._bwd(tw, L["td1"], tw.gA, tw.d1, tw.gB, tw.d1, "relu")
-        self._bwd(tw, L["td0"], tw.gB, fw.lt, tw.dlt, None, None)
+        g_td2, g_td1 = tw.g("td2", 512), tw.g("td1", 512)
+        self._bwd(tw, L["td2"], tw.g_hr, tw.d2, g_td2, tw.d2, "relu")
+        self._bwd(tw, L["td1"], g_td2, tw.d1, g_td1, tw.d1, "relu")
+        self._bwd(tw, L["td0"], g_td1, fw.lt, tw.dlt, None, None)
         # CE-net decoder; its input gradient fans out to z, mu[:, :3] and l_t
-        self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, tw.g128, tw.c2, "relu")
-        self._bwd(tw, L["cd1"], tw.g128, tw.c1, tw.g64, tw.c1, "relu")
+        g_cd2, g_cd1 = tw.g("cd2", 128), tw.g("cd1", 64)
+        self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu")
+        self._bwd(tw, L["cd1"], g_cd2, tw.c1, g_cd1, tw.c1, "relu")
         dst = segmat([seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3, accumulate=True), seg(tw.dlt, 0, 512, accumulate=True)])
-        self._bwd(tw, L["cd0"], tw.g64, dec_in, dst, None, None)
+        self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None)
         ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
         self._encoder_backward(fw, tw, flat, idx)
+        self._join_wgrads(tw)
         self._allreduce_grads(self.vae_optimizer)
         if self.capture_grads:
             self.captured["vae"] = ac.arena.grad.clone()
@@ -294,20 +343,23 @@ class PPO:
             dp.allreduce_mean_(stats[S_KL:S_KL + 1])
             ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
         # critic
-        self._bwd(tw, L["c3"], tw.dval, fw.v3, tw.g128, fw.v3, act)
-        self._bwd(tw, L["c2"], tw.g128, fw.v2, tw.g256, fw.v2, act)
-        self._bwd(tw, L["c1"], tw.g256, fw.v1, tw.gA, fw.v1, act)
-        self._bwd(tw, L["c0"], tw.gA, ac.critic_input(flat["observations"], flat["base_vel"],
-                                                      flat["privileged_observations"], idx))
+        g_c3, g_c2, g_c1 = tw.g("c3", 128), tw.g("c2", 256), tw.g("c1", 512)
+        self._bwd(tw, L["c3"], tw.dval, fw.v3, g_c3, fw.v3, act)
+        self._bwd(tw, L["c2"], g_c3, fw.v2, g_c2, fw.v2, act)
+        self._bwd(tw, L["c1"], g_c2, fw.v1, g_c1, fw.v1, act)
+        self._bwd(tw, L["c0"], g_c1, ac.critic_input(flat["observations"], flat["base_vel"],
+                                                     flat["privileged_observations"], idx))
         # actor; layer-0 input gradient fans out to z, mu[:, :3], l_t (observations need none)
-        self._bwd(tw, L["a3"], tw.dmean, fw.a3, tw.g128, fw.a3, act)
-        self._bwd(tw, L["a2"], tw.g128, fw.a2, tw.g256, fw.a2, act)
-        self._bwd(tw, L["a1"], tw.g256, fw.a1, tw.gA, fw.a1, act)
+        g_a3, g_a2, g_a1 = tw.g("a3", 128), tw.g("a2", 256), tw.g("a1", 512)
+        self._bwd(tw, L["a3"], tw.dmean, fw.a3, g_a3, fw.a3, act)
+        self._bwd(tw, L["a2"], g_a3, fw.a2, g_a2, fw.a2, act)
+        self._bwd(tw, L["a1"], g_a2, fw.a1, g_a1, fw.a1, act)
         tw.dmulv.zero_()
         dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
-        self._bwd(tw, L["a0"], tw.gA, ac.actor_input(fw, flat["observations"], idx), dst, None, None)
+        self._bwd(tw, L["a0"], g_a1, ac.actor_input(fw, flat["observations"], idx), dst, None, None)
         ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
         self._encoder_backward(fw, tw, flat, idx)
+        self._join_wgrads(tw)
         self._allreduce_grads(self.optimizer)
         if self.capture_grads:
             self.captured["main"] = ac.arena.grad.clone()

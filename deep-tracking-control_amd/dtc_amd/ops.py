@@ -75,8 +75,9 @@ def wgrad_workspace_bytes(M, N, K) -> int:
     return int(lib().dtc_linear_wgrad_workspace(M, N, K))
 
 
-def linear_wgrad(dZ, X, dW, db, workspace, M=None):
-    """dW = dZ^T X, db = colsum(dZ).  X: tensor or DtcSegMat."""
+def linear_wgrad(dZ, X, dW, db, workspace, M=None, stream_ptr=None):
+    """dW = dZ^T X, db = colsum(dZ).  X: tensor or DtcSegMat.  `stream_ptr`: raw HIP stream to launch on
+    (default: torch's current stream)."""
     Xs = as_segmat(X)
     N, K = dW.shape
     M = dZ.shape[0] if M is None else M
@@ -84,7 +85,8 @@ def linear_wgrad(dZ, X, dW, db, workspace, M=None):
     if workspace.numel() * workspace.element_size() < need:
         raise _ffi.DtcError(f"wgrad workspace too small: {workspace.numel() * workspace.element_size()} < {need}")
     check(lib().dtc_linear_wgrad(ptr(dZ), dZ.stride(0), Xs, cptr(dW, f32), cptr(db, f32) if db is not None else None,
-                                 ptr(workspace), M, N, K, stream()), "dtc_linear_wgrad")
+                                 ptr(workspace), M, N, K, stream() if stream_ptr is None else stream_ptr),
+          "dtc_linear_wgrad")
 
 
 # ---------------------------------------------------------------- CE-net latent / losses / optimiser
