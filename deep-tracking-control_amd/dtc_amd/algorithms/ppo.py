@@ -19,6 +19,7 @@ attributes `actor_critic`, `optimizer`, `vae_optimizer`, `storage`, `learning_ra
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -130,8 +131,12 @@ class _TrainWorkspace:
                   (128, 64), (53, 128), (128, 265), (64, 128), (35, 64), (num_actions, 128), (1, 128)]
         self.wg = ops.workspace(max(lib.dtc_linear_wgrad_workspace(B, n, k) for n, k in shapes), dev)
         self.loss_ws = ops.workspace(lib.dtc_loss_workspace(B), dev)
-        # weight-gradient side stream
+        # streams: `side` runs the weight gradients, `aux` is a second compute lane for the branch of the
+        # layer graph that is independent of the one on the main stream (CE-net vs terrain encoder, critic vs actor)
         self.side = torch.cuda.Stream(device=dev)
+        self.aux = torch.cuda.Stream(device=dev)
+        self.main = None                    # torch's current stream at the start of the step
+        self.two_lanes = False
         self._events, self._ev_next = [], 0
         self.joined = torch.cuda.Event()
         self.side_busy = False
@@ -141,6 +146,29 @@ class _TrainWorkspace:
         if t is None:
             t = self._g[name] = torch.empty(self.B, width, dtype=torch.float32, device=self._dev)
         return t
+
+    def begin(self, two_lanes):
+        self.main = torch.cuda.current_stream()
+        self.two_lanes = two_lanes
+        if two_lanes:
+            self.order("main", "aux")
+
+    def _stream(self, which):
+        return self.aux if which == "aux" else self.main
+
+    def lane(self, which):
+        """Context: launches inside go to the named lane ("main" | "aux"); a no-op with one lane."""
+        if self.two_lanes and which == "aux":
+            return torch.cuda.stream(self.aux)
+        return contextlib.nullcontext()
+
+    def order(self, src, dst):
+        """Everything launched so far on lane `src` happens before whatever lane `dst` launches next."""
+        if not self.two_lanes or src == dst:
+            return
+        ev = self.event()
+        ev.record(self._stream(src))
+        self._stream(dst).wait_event(ev)
 
     def event(self):
         if self._ev_next == len(self._events):
@@ -184,6 +212,8 @@ class PPO:
         self._tws = {}
         # weight gradients on a side stream, concurrent with the data-gradient chain (DTC_OVERLAP_WGRAD=0: serial)
         self.overlap_wgrad = os.environ.get("DTC_OVERLAP_WGRAD", "1") != "0"
+        # two compute lanes (needs the side stream: both lanes' weight gradients share one partials workspace)
+        self.overlap_lanes = os.environ.get("DTC_OVERLAP_LANES", "1") != "0"
         self.capture_grads, self.captured = False, {}      # tests: snapshot of the (pre-clip) gradient arena
         self.last_update_stats = None      # [steps, STAT_COLS] table of the last update (host tensor)
 
@@ -270,21 +300,24 @@ class PPO:
         if dX is not None:
             ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B)
 
-    def _join_wgrads(self, tw):
-        """Main stream waits for every weight gradient of this optimiser step."""
+    def _join(self, tw):
+        """Main stream waits for the second lane and for every weight gradient of this optimiser step."""
+        tw.order("aux", "main")
         if tw.side_busy:
             tw.joined.record(tw.side)
-            torch.cuda.current_stream().wait_event(tw.joined)
+            tw.main.wait_event(tw.joined)
             tw.side_busy = False
         tw._ev_next = 0
 
-    def _encoder_backward(self, fw, tw, flat, idx):
-        """Shared tail of both steps: d l_t -> terrain_encoder, d(mu|lv) -> heads -> cenet_encoder."""
+    def _terrain_encoder_backward(self, fw, tw, flat, idx):
         L = self.actor_critic.L
         g_te2, g_te1 = tw.g("te2", 512), tw.g("te1", 512)
         self._bwd(tw, L["te2"], tw.dlt, fw.t2, g_te2, fw.t2, "relu")
         self._bwd(tw, L["te1"], g_te2, fw.t1, g_te1, fw.t1, "relu")
         self._bwd(tw, L["te0"], g_te1, segmat([seg(flat["privileged_observations"], 0, 693, gather=True)], idx))
+
+    def _cenet_encoder_backward(self, fw, tw, flat, idx):
+        L = self.actor_critic.L
         g_head, g_ce1 = tw.g("head", 64), tw.g("ce1", 128)
         self._bwd(tw, L["head"], tw.dmulv, fw.e, g_head, None, None)
         self._bwd(tw, L["ce1"], g_head, fw.e1, g_ce1, fw.e1, "relu")
@@ -292,34 +325,50 @@ class PPO:
                                                    gather=True)], idx))
 
     def _vae_step(self, fw, tw, flat, idx, eps, stats):
-        """ppo.py:197-254: CE-net / terrain auto-encoder losses, backward, clip, Adam(5e-4)."""
+        """ppo.py:197-254: CE-net / terrain auto-encoder losses, backward, clip, Adam(5e-4).
+
+        Two compute lanes: the CE-net branch (encoder -> latent -> decoder; small layers) runs on `aux` next to
+        the terrain auto-encoder (512-wide layers) on the main stream; `tw.order(a, b)` marks each point where
+        one branch needs the other's result."""
         ac = self.actor_critic
         L = ac.L
-        ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
-        ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
+        tw.begin(self.overlap_lanes and self.overlap_wgrad)
         dec_in = segmat([seg(fw.z, 0, 16), seg(fw.mulv, 0, 3), seg(fw.lt, 0, 512)])
-        ops.linear_fwd(dec_in, L["cd0"].W, L["cd0"].b, tw.c1, "relu", M=tw.B)
-        ops.linear_fwd(tw.c1, L["cd1"].W, L["cd1"].b, tw.c2, "relu")
-        ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None)
+        with tw.lane("aux"):
+            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
+        tw.order("main", "aux")                                    # l_t feeds the CE-net decoder
+        with tw.lane("aux"):
+            ops.linear_fwd(dec_in, L["cd0"].W, L["cd0"].b, tw.c1, "relu", M=tw.B)
+            ops.linear_fwd(tw.c1, L["cd1"].W, L["cd1"].b, tw.c2, "relu")
+            ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None)
         ops.linear_fwd(fw.lt, L["td0"].W, L["td0"].b, tw.d1, "relu")
         ops.linear_fwd(tw.d1, L["td1"].W, L["td1"].b, tw.d2, "relu")
         ops.linear_fwd(tw.d2, L["td2"].W, L["td2"].b, tw.hr, None)
+        tw.order("aux", "main")
         ops.vae_loss(tw.rec, tw.hr, fw.mulv, flat["next_observations"], flat["privileged_observations"],
                      flat["base_vel"], idx, tw.g_rec, tw.g_hr, tw.dmulv, stats[S_RECONS:S_RECONS + 4], tw.loss_ws)
-        # terrain decoder
+        tw.order("main", "aux")
+        # terrain decoder (main)
         g_td2, g_td1 = tw.g("td2", 512), tw.g("td1", 512)
         self._bwd(tw, L["td2"], tw.g_hr, tw.d2, g_td2, tw.d2, "relu")
         self._bwd(tw, L["td1"], g_td2, tw.d1, g_td1, tw.d1, "relu")
         self._bwd(tw, L["td0"], g_td1, fw.lt, tw.dlt, None, None)
-        # CE-net decoder; its input gradient fans out to z, mu[:, :3] and l_t
+        # CE-net decoder (aux); its input gradient fans out to z, mu[:, :3] and (accumulating) l_t
         g_cd2, g_cd1 = tw.g("cd2", 128), tw.g("cd1", 64)
-        self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu")
-        self._bwd(tw, L["cd1"], g_cd2, tw.c1, g_cd1, tw.c1, "relu")
         dst = segmat([seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3, accumulate=True), seg(tw.dlt, 0, 512, accumulate=True)])
-        self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None)
-        ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
-        self._encoder_backward(fw, tw, flat, idx)
-        self._join_wgrads(tw)
+        with tw.lane("aux"):
+            self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu")
+            self._bwd(tw, L["cd1"], g_cd2, tw.c1, g_cd1, tw.c1, "relu")
+        tw.order("main", "aux")                                    # d l_t of the terrain decoder is written first
+        with tw.lane("aux"):
+            self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None)
+        tw.order("aux", "main")                                    # d l_t complete
+        self._terrain_encoder_backward(fw, tw, flat, idx)
+        with tw.lane("aux"):
+            ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
+            self._cenet_encoder_backward(fw, tw, flat, idx)
+        self._join(tw)
         self._allreduce_grads(self.vae_optimizer)
         if self.capture_grads:
             self.captured["vae"] = ac.arena.grad.clone()
@@ -327,14 +376,19 @@ class PPO:
 
     def _ppo_step(self, fw, tw, flat, idx, eps, stats, cfg):
         """ppo.py:265-335: policy / value forward with the freshly updated VAE, PPO losses, backward,
-        clip, Adam(adaptive lr)."""
+        clip, Adam(adaptive lr).  Lanes: CE-net encoder + critic on `aux`, terrain encoder + actor on main."""
         ac = self.actor_critic
         L = ac.L
         act = AC_Args.activation
-        ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
+        tw.begin(self.overlap_lanes and self.overlap_wgrad)
+        with tw.lane("aux"):
+            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
         ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
+        tw.order("aux", "main")                                    # z, mu feed the actor
+        with tw.lane("aux"):
+            ac.critic_forward_(fw, flat["observations"], flat["base_vel"], flat["privileged_observations"], idx)
         ac.actor_forward_(fw, flat["observations"], idx)
-        ac.critic_forward_(fw, flat["observations"], flat["base_vel"], flat["privileged_observations"], idx)
+        tw.order("aux", "main")
         world = self._world()
         ops.ppo_loss(fw.mean, ac.std_view, fw.val, flat["actions"], flat["actions_log_prob"], flat["mu"],
                      flat["sigma"], flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval,
@@ -342,14 +396,16 @@ class PPO:
         if world > 1 and cfg.adaptive_schedule == 0 and self._adaptive():
             dp.allreduce_mean_(stats[S_KL:S_KL + 1])
             ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
-        # critic
+        tw.order("main", "aux")
+        # critic (aux)
         g_c3, g_c2, g_c1 = tw.g("c3", 128), tw.g("c2", 256), tw.g("c1", 512)
-        self._bwd(tw, L["c3"], tw.dval, fw.v3, g_c3, fw.v3, act)
-        self._bwd(tw, L["c2"], g_c3, fw.v2, g_c2, fw.v2, act)
-        self._bwd(tw, L["c1"], g_c2, fw.v1, g_c1, fw.v1, act)
-        self._bwd(tw, L["c0"], g_c1, ac.critic_input(flat["observations"], flat["base_vel"],
-                                                     flat["privileged_observations"], idx))
-        # actor; layer-0 input gradient fans out to z, mu[:, :3], l_t (observations need none)
+        with tw.lane("aux"):
+            self._bwd(tw, L["c3"], tw.dval, fw.v3, g_c3, fw.v3, act)
+            self._bwd(tw, L["c2"], g_c3, fw.v2, g_c2, fw.v2, act)
+            self._bwd(tw, L["c1"], g_c2, fw.v1, g_c1, fw.v1, act)
+            self._bwd(tw, L["c0"], g_c1, ac.critic_input(flat["observations"], flat["base_vel"],
+                                                         flat["privileged_observations"], idx))
+        # actor (main); layer-0 input gradient fans out to z, mu[:, :3], l_t (observations need none)
         g_a3, g_a2, g_a1 = tw.g("a3", 128), tw.g("a2", 256), tw.g("a1", 512)
         self._bwd(tw, L["a3"], tw.dmean, fw.a3, g_a3, fw.a3, act)
         self._bwd(tw, L["a2"], g_a3, fw.a2, g_a2, fw.a2, act)
@@ -358,8 +414,11 @@ class PPO:
         dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
         self._bwd(tw, L["a0"], g_a1, ac.actor_input(fw, flat["observations"], idx), dst, None, None)
         ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
-        self._encoder_backward(fw, tw, flat, idx)
-        self._join_wgrads(tw)
+        tw.order("main", "aux")                                    # d(mu|lv) ready for the CE-net encoder
+        self._terrain_encoder_backward(fw, tw, flat, idx)
+        with tw.lane("aux"):
+            self._cenet_encoder_backward(fw, tw, flat, idx)
+        self._join(tw)
         self._allreduce_grads(self.optimizer)
         if self.capture_grads:
             self.captured["main"] = ac.arena.grad.clone()
