@@ -40,7 +40,7 @@ def cpu_baseline():
     from oracle import ppo_ref as OP
     cores = min(os.cpu_count() or 1, 32)      # torch-CPU GEMMs of this size stop scaling (and thrash) beyond ~32 threads
     torch.set_num_threads(cores)
-    n_envs, n_maps = 512, 4096
+    n_envs, n_maps = 2048, 32768            # ~10-15 s of CPU work on the GPU box's host
     torch.manual_seed(3)
     ac = OP.RefActorCriticDecoder()
     alg = OP.RefPPO(ac, learning_rate=1e-3, entropy_coef=0.003)

@@ -4,8 +4,8 @@
 //
 // All three products run on v_mfma_f32_32x32x2_f32 (exact fp32: bitwise a k-ordered fmaf
 // chain, 157.3 TFLOP/s peak, there is no xf32/TF32 on gfx950).  The instruction takes 64
-// cycles per issue, so one 128x128x16 block step is 2048 MFMA cycles per SIMD against 16 dword
-// loads + 16 LDS writes + 16 LDS reads per lane: the kernels are MFMA-bound *if* the non-matrix
+// cycles per issue, so one 128x64x16 block step is 1024 MFMA cycles per SIMD against 12 dword
+// loads + 12 LDS writes + 24 LDS reads per lane: the kernels are MFMA-bound *if* the non-matrix
 // instructions stay out of the way.  The design therefore
 //   (1) removes HBM passes instead of polishing them:
 //       - torch.cat([...], dim=1) operands (ppo.py:201, actor_critic_decoder.py:431,550) and the
@@ -18,15 +18,17 @@
 //         dZ, so no extra pass over dZ exists;
 //       - K and N tails (53, 265, 531, 584, 693, 752, 12, 1 ...) are zero-padded in LDS, never in HBM;
 //   (2) keeps address arithmetic out of the K loop: every operand load is a raw buffer load
-//       `descriptor (SGPRs) + uniform step offset (SGPR) + loop-invariant 32-bit lane offset (VGPR)`; the K
-//       loop of a segmented operand runs segment by segment (tiles are aligned to segment starts); row and
+//       `descriptor (SGPRs) + uniform step offset (SGPR) + loop-invariant 32-bit lane offset (VGPR)`; row and
 //       k tails use an out-of-range lane offset, for which the hardware returns 0 without touching memory
 //       (no clamps, no masks, no over-reads);
-//   (3) loads are unconditional (a predicated load makes hipcc wrap each load in its own exec branch
-//       with a wait in between) and are issued one K step ahead of the MFMAs that consume them.
-// Tiling: 256 threads = 4 waves; block tile 128 x {128,64,32}; each wave owns 32x32 MFMA sub-tiles
-// (2x2, 1x2 or 1x1); K step 16; LDS tiles are stored [k][row] (+4 pad) so every MFMA operand read is a
-// conflict-free ds_read of 32 consecutive floats per half-wave; double-buffered LDS, one barrier per step.
+//   (3) keeps control flow out of the K loop: the steady state (full tiles of one segment) is ONE basic block --
+//       loads of tile k+1, MFMAs of tile k, LDS stores, barrier; the masked last tile of a segment and the hop
+//       into the next segment are peeled copies of that block.  Loads are unconditional (a predicated load
+//       makes hipcc wrap each load in its own exec branch with a wait in between).
+// Tiling: 256 threads = 4 waves; block tile 128 x {64,32}; each wave owns 32x32 MFMA sub-tiles; K step 16; LDS
+// tiles are stored [k][row] (+4 pad) so every MFMA operand read is a conflict-free ds_read of 32 consecutive
+// floats per half-wave; double-buffered LDS, one barrier per step, 4 workgroups per CU (latency is hidden by
+// the other three -- tools/mfma_ceiling.hip measures what each ingredient of this loop costs).
 // Workgroup -> tile mapping is XCD-aware (block b runs on XCD b%8): all column tiles of one row panel
 // (fwd/dgrad) resp. all output tiles of one batch slice (wgrad) run on the same XCD, so the panel is
 // fetched from HBM into ONE L2 and shared there.
