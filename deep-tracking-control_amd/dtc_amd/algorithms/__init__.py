@@ -1,2 +1,3 @@
 from .ppo import PPO
 from .recurrent_ppo import RecurrentPPO
+from .recurrent_decoder_ppo import RecurrentDecoderPPO

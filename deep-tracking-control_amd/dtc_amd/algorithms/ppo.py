@@ -141,6 +141,14 @@ class _TrainWorkspace:
         self.joined = torch.cuda.Event()
         self.side_busy = False
 
+    def wgrad_ws(self, N, K):
+        """Split-partials workspace, grown on demand (rare: first use of a larger layer shape)."""
+        need = ops.wgrad_workspace_bytes(self.B, N, K)
+        if self.wg.numel() * self.wg.element_size() < need:
+            torch.cuda.synchronize()            # nothing may still be reading the buffer being replaced
+            self.wg = ops.workspace(need, self._dev)
+        return self.wg
+
     def g(self, name, width):
         t = self._g.get(name)
         if t is None:
@@ -293,10 +301,10 @@ class PPO:
             ev = tw.event()
             ev.record()                          # dZ and X are final on the main stream here
             tw.side.wait_event(ev)
-            ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wg, M=tw.B, stream_ptr=tw.side.cuda_stream)
+            ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wgrad_ws(L.n_out, L.n_in), M=tw.B, stream_ptr=tw.side.cuda_stream)
             tw.side_busy = True
         else:
-            ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wg, M=tw.B)
+            ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wgrad_ws(L.n_out, L.n_in), M=tw.B)
         if dX is not None:
             ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B)
 

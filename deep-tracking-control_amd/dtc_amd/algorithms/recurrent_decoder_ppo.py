@@ -1,0 +1,198 @@
+"""PPO for the GRU + CE-net composite (ActorCriticDecoderRecurrent) -- BASELINE.json config 5.
+
+Per recurrent mini-batch (N/4 envs x all 24 steps, rollout_storage.py:217-267) exactly the two optimisation steps
+of ppo.py:189-338 (SURVEY.md §8a "Config 5"):
+  1. the VAE step of `PPO` (inherited unchanged) on the valid (t, env) rows of the env slice -- the outlier
+     statistics of the CE-net never see padding;
+  2. the policy step with BPTT: CE-net / terrain encoder features -> GRU input projections on the valid rows
+     (feature blocks are segments of the GEMM operand, nothing is concatenated) -> row scatter into the padded
+     [T, n_traj] layout -> dtc_gru_fwd -> MLP heads with the un-padding folded in as a row gather -> fused PPO loss
+     -> MLP backward -> row scatter -> dtc_gru_bwd -> row gather -> input-projection backward, whose data gradient
+     fans out to z, mu[:, :3] and l_t -> CE-net / terrain encoder backward -> clip + Adam.
+Hidden states are recorded BEFORE each rollout step (the convention of the commented lines ppo.py:138-139) and the
+mini-batch takes the states at its trajectory starts, as `reccurent_mini_batch_generator` does.
+Same constructor keywords / method names as `PPO`; weight gradients run on the side stream (see PPO._bwd).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _ffi, distributed as dp, ops
+from .._ffi import seg, segmat
+from ..modules.actor_critic_decoder_recurrent import ActorCriticDecoderRecurrent
+from ..utils import split_and_pad_trajectories
+from .ppo import PPO, S_GNORM, S_KL, S_RECONS, S_SURR, S_VALUE, S_VEL, S_KLD, STAT_COLS
+
+
+class RecurrentDecoderPPO(PPO):
+    actor_critic: ActorCriticDecoderRecurrent
+
+    # ---------------------------------------------------------------- rollout side
+    def act(self, obs, privileged_obs, obs_history, base_vel, rew_buf=None):
+        self._require_gpu()
+        ac = self.actor_critic
+        ac.ensure_arena()
+        ac._ensure_hidden(obs.shape[0], obs.device)
+        hidden = tuple(h.clone() for h in ac.get_hidden_states())          # state BEFORE this step
+        actions = super().act(obs, privileged_obs, obs_history, base_vel, rew_buf)
+        self.transition.hidden_states = hidden
+        return actions
+
+    def compute_returns(self, last_critic_obs, last_critic_privileged_obs, last_base_vel):
+        self._require_gpu()
+        ac = self.actor_critic
+        keep = ac.memory_c.hidden_states.clone() if ac.memory_c.hidden_states is not None else None
+        last_values = ac.evaluate(last_critic_obs, last_critic_privileged_obs, last_base_vel).detach()
+        ac.memory_c.hidden_states = keep            # the bootstrap value must not advance the critic's state
+        self.storage.compute_returns(last_values, self.gamma, self.lam)
+
+    # ---------------------------------------------------------------- recurrent mini-batches as index data
+    def recurrent_slices(self, hid_a=None, hid_c=None):
+        """Yield, per mini-batch of envs [a, b): time-major flat row indices of its samples, the padded-layout
+        row of each sample (`unpad_idx`), T, n_traj and the hidden states at the trajectory starts."""
+        st = self.storage
+        T, N = st.num_transitions_per_env, st.num_envs
+        dev = st.dones.device
+        hid_a = st.saved_hidden_states_a[0] if hid_a is None else hid_a
+        hid_c = st.saved_hidden_states_c[0] if hid_c is None else hid_c
+        mb = N // self.num_mini_batches
+        _, masks_all = split_and_pad_trajectories(st.dones, st.dones)
+        dones = st.dones.squeeze(-1)
+        lwd = torch.zeros_like(dones, dtype=torch.bool)
+        lwd[1:] = dones[:-1].bool()
+        lwd[0] = True
+        counts = lwd.view(T, self.num_mini_batches, mb).sum(dim=(0, 2)).tolist()     # one host sync per update
+        first = 0
+        for i in range(self.num_mini_batches):
+            a, b = i * mb, (i + 1) * mb
+            last = first + int(counts[i])
+            masks = masks_all[:, first:last]
+            R = last - first
+            traj, pos = masks.transpose(1, 0).nonzero(as_tuple=True)
+            unpad_idx = (pos * R + traj).view(mb, T).transpose(1, 0).reshape(-1).contiguous()
+            idx = (torch.arange(T, device=dev).unsqueeze(1) * N + torch.arange(a, b, device=dev)).reshape(-1).contiguous()
+            pick = lambda h: h[:, :, a:b].permute(2, 0, 1, 3)[lwd[:, a:b].permute(1, 0)][:, 0].contiguous()   # [R, H]
+            yield dict(a=a, b=b, idx=idx, unpad_idx=unpad_idx, T=T, R=R, hid_a=pick(hid_a), hid_c=pick(hid_c))
+            first = last
+
+    # ---------------------------------------------------------------- policy step with BPTT
+    def _padded(self, tw, name, rows, width):
+        key = ("pad", name)
+        t = tw._g.get(key)
+        if t is None or t.shape[0] != rows:
+            t = tw._g[key] = torch.zeros(rows, width, dtype=torch.float32, device=tw._dev)
+        return t
+
+    def _ppo_step_recurrent(self, fw, tw, flat, bt, eps, stats, cfg):
+        ac = self.actor_critic
+        H, M = ac.rnn_hidden_size, tw.B
+        idx, unpad_idx, T, R = bt["idx"], bt["unpad_idx"], bt["T"], bt["R"]
+        dev = idx.device
+        tw.begin(False)
+        ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
+        Xa = ac.actor_input(fw, flat["observations"], idx)
+        Xc = ac.critic_input(flat["observations"], flat["base_vel"], flat["privileged_observations"], idx)
+        heads = []
+        for name, X, mem, proj, layers, h0 in (("a", Xa, ac.memory_a, ac.proj_a, ac.A, bt["hid_a"]),
+                                               ("c", Xc, ac.memory_c, ac.proj_c, ac.Cr, bt["hid_c"])):
+            gi_v = tw.g("gi_" + name, 3 * H)
+            ops.linear_fwd(X, proj.W, proj.b, gi_v, None, M=M)
+            gi_p = self._padded(tw, "gi_" + name, T * R, 3 * H)     # padded steps keep finite stale values (never used)
+            ops.scatter_rows(gi_v, unpad_idx, gi_p)
+            hs_all = torch.empty(T + 1, R, H, device=dev)
+            gates, hn = torch.empty(T, R, 3 * H, device=dev), torch.empty(T, R, H, device=dev)
+            ws = ops.workspace(ops.gru_workspace_bytes(T, R, H), dev)
+            ops.gru_fwd(gi_p.view(T, R, 3 * H), h0.contiguous(), mem.W_hh, mem.b_hh, hs_all, gates, hn, ws)
+            X0 = segmat([seg(hs_all[1:].reshape(T * R, H), 0, H, gather=True)], unpad_idx)
+            outs, cur = [], X0
+            for li, L in enumerate(layers):
+                o = tw.g(f"{name}_o{li}", L.n_out)
+                ops.linear_fwd(cur, L.W, L.b, o, L.act, M=M)
+                outs.append(o)
+                cur = o
+            heads.append(dict(name=name, X=X, mem=mem, proj=proj, layers=layers, hs_all=hs_all, gates=gates, hn=hn,
+                              ws=ws, X0=X0, outs=outs))
+        mean, value = heads[0]["outs"][-1], heads[1]["outs"][-1]
+        ops.ppo_loss(mean, ac.std_view, value, flat["actions"], flat["actions_log_prob"], flat["mu"], flat["sigma"],
+                     flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval, ac.std_grad,
+                     stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
+        if self._world() > 1 and cfg.adaptive_schedule == 0 and self._adaptive():
+            dp.allreduce_mean_(stats[S_KL:S_KL + 1])
+            ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
+        for hd, dOut in zip(heads, (tw.dmean, tw.dval)):
+            name, layers, outs = hd["name"], hd["layers"], hd["outs"]
+            dZ = dOut
+            for li in range(len(layers) - 1, -1, -1):
+                dX = tw.g(f"{name}_d{li}", layers[li].n_in)
+                if li > 0:
+                    self._bwd(tw, layers[li], dZ, outs[li - 1], dX, outs[li - 1], layers[li - 1].act)
+                else:
+                    self._bwd(tw, layers[li], dZ, hd["X0"], dX, None, None)
+                dZ = dX
+            dhs = self._padded(tw, "dhs_" + name, T * R, H)
+            dhs.zero_()
+            ops.scatter_rows(dZ, unpad_idx, dhs)
+            dgi_p, dh0 = torch.empty(T, R, 3 * H, device=dev), torch.empty(R, H, device=dev)
+            mem = hd["mem"]
+            ops.gru_bwd(dhs.view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], mem.W_hh, dgi_p, mem.gW_hh, mem.gb_hh,
+                        dh0, hd["ws"])
+            dgi_v = ops.gather_rows(dgi_p.view(T * R, 3 * H), unpad_idx, out=tw.g("dgi_" + name, 3 * H))
+            if name == "a":       # the features' gradient fans out to z, mu[:, :3], l_t (observations need none)
+                tw.dmulv.zero_()
+                dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
+                self._bwd(tw, hd["proj"], dgi_v, hd["X"], dst, None, None)
+            else:
+                self._bwd(tw, hd["proj"], dgi_v, hd["X"])
+        ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
+        self._terrain_encoder_backward(fw, tw, flat, idx)
+        self._cenet_encoder_backward(fw, tw, flat, idx)
+        self._join(tw)
+        self._allreduce_grads(self.optimizer)
+        if self.capture_grads:
+            self.captured["main"] = ac.arena.grad.clone()
+        self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])
+
+    def step_minibatch(self, bt, eps1, eps2, which="both", stats=None):
+        """One recurrent mini-batch `bt` (an item of `recurrent_slices`): VAE step, policy step, or both."""
+        self._require_gpu()
+        st, ac = self.storage, self.actor_critic
+        ac.ensure_arena()
+        dev = ac.std.device
+        B = bt["idx"].numel()
+        flat = {k: st.flat(k) for k in self._FLAT_NAMES}
+        fw, tw = ac._fwd_ws(B), self._train_ws(B)
+        self.optimizer.set_lr(self.learning_rate)
+        stats = torch.zeros(STAT_COLS, dtype=torch.float32, device=dev) if stats is None else stats
+        if which in ("vae", "both"):
+            self._vae_step(fw, tw, flat, bt["idx"], eps1.to(dev).contiguous(), stats)
+        if which in ("ppo", "both"):
+            self._ppo_step_recurrent(fw, tw, flat, bt, eps2.to(dev).contiguous(), stats, self._loss_cfg())
+        return stats
+
+    def update(self, eps1=None, eps2=None, return_stats=False):
+        self._require_gpu()
+        st, ac = self.storage, self.actor_critic
+        ac.ensure_arena()
+        dev = ac.std.device
+        nmb, epochs = self.num_mini_batches, self.num_learning_epochs
+        B = (st.num_envs // nmb) * st.num_transitions_per_env
+        steps = nmb * epochs
+        eps1 = torch.randn(steps, B, 16, device=dev) if eps1 is None else eps1
+        eps2 = torch.randn(steps, B, 16, device=dev) if eps2 is None else eps2
+        stats = torch.zeros(steps, STAT_COLS, dtype=torch.float32, device=dev)
+        slices = list(self.recurrent_slices())
+        k = 0
+        for _ in range(epochs):
+            for bt in slices:
+                self.step_minibatch(bt, eps1[k], eps2[k], "both", stats[k])
+                k += 1
+        host = stats.cpu()                       # the single device -> host synchronisation of the update
+        self.learning_rate = float(self.optimizer.lr_dev.item())
+        for g in self.optimizer.param_groups:
+            g['lr'] = self.learning_rate
+        self.last_update_stats = host
+        m = host.double().mean(dim=0)
+        st.clear()
+        out = (float(m[S_VALUE]), float(m[S_SURR]), 0.0, 0, float(m[S_RECONS]), float(m[S_VEL]), float(m[S_KLD]))
+        return (out, host) if return_stats else out

@@ -90,7 +90,7 @@ class Dense:
 
 class ParamArena:
     """Flat parameter / gradient buffers.  Layout (element offsets):
-        [ main-only: actor_body, critic_body, std | shared: cenet_encoder, (latent_mu|latent_var),
+        [ main-only: actor_body, critic_body, std (or std, actor, critic, memory_a, memory_c) | shared: cenet_encoder, (latent_mu|latent_var),
           terrain_encoder | vae-only: cenet_decoder, terrain_decoder | unused: memory_mlp, gb_encoder ]
     main optimiser range = [0, end(shared));  VAE optimiser range = [start(shared), end(vae-only)).
     The parameters of `unused` never receive a gradient in PPO.update."""
@@ -102,7 +102,8 @@ class ParamArena:
         def take(prefix):
             return [k for k in named if k.startswith(prefix)]
 
-        main_only = take("actor_body.") + take("critic_body.") + ["std"]
+        # actor / critic bodies (+ the GRU memories of the recurrent composite), then std
+        main_only = [k for k in named if not k.startswith("vae.") and k != "std"] + ["std"]
         heads = ["vae.latent_mu.weight", "vae.latent_var.weight", "vae.latent_mu.bias", "vae.latent_var.bias"]
         shared = take("vae.cenet_encoder.") + heads + take("vae.terrain_encoder.")
         vae_only = take("vae.cenet_decoder.") + take("vae.terrain_decoder.")
@@ -213,9 +214,16 @@ class ActorCriticDecoder(nn.Module):
                                     "(there is no CPU fallback)")
             self.arena = ParamArena(self)
             ar = self.arena
-            relu, elu = "relu", AC_Args.activation
-            d = ar.dense
-            self.L = dict(
+            self._build_layers(ar)
+            self.std_view = ar.view(ar.flat, "std")
+            self.std_grad = ar.view(ar.grad, "std")
+        return self.arena
+
+    @staticmethod
+    def _vae_layers(ar):
+        relu = "relu"
+        d = ar.dense
+        return dict(
                 ce0=d("vae.cenet_encoder.0.weight", "vae.cenet_encoder.0.bias", relu),
                 ce1=d("vae.cenet_encoder.2.weight", "vae.cenet_encoder.2.bias", None),
                 head=ar.fused_head(),
@@ -227,7 +235,13 @@ class ActorCriticDecoder(nn.Module):
                 cd2=d("vae.cenet_decoder.4.weight", "vae.cenet_decoder.4.bias", None),
                 td0=d("vae.terrain_decoder.0.weight", "vae.terrain_decoder.0.bias", relu),
                 td1=d("vae.terrain_decoder.2.weight", "vae.terrain_decoder.2.bias", relu),
-                td2=d("vae.terrain_decoder.4.weight", "vae.terrain_decoder.4.bias", None),
+                td2=d("vae.terrain_decoder.4.weight", "vae.terrain_decoder.4.bias", None))
+
+    def _build_layers(self, ar):
+        elu = AC_Args.activation
+        d = ar.dense
+        self.L = self._vae_layers(ar)
+        self.L.update(
                 a0=d("actor_body.0.weight", "actor_body.0.bias", elu),
                 a1=d("actor_body.2.weight", "actor_body.2.bias", elu),
                 a2=d("actor_body.4.weight", "actor_body.4.bias", elu),
@@ -237,9 +251,6 @@ class ActorCriticDecoder(nn.Module):
                 c2=d("critic_body.4.weight", "critic_body.4.bias", elu),
                 c3=d("critic_body.6.weight", "critic_body.6.bias", None),
             )
-            self.std_view = ar.view(ar.flat, "std")
-            self.std_grad = ar.view(ar.grad, "std")
-        return self.arena
 
     # ------------------------------------------------------------------ forward workspace
     class _Fwd:

@@ -244,9 +244,14 @@ class RefPPO:
         (obs, critic_obs, priv, hist, actions, target_values, advantages, returns, old_logp, old_mu,
          old_sigma, base_vel, next_obs, _, _, _) = self.storage.gather(idx)
         mean = ac.policy_mean(obs, hist, priv, eps2)
+        value = ac.evaluate(critic_obs, priv, base_vel)
+        return self._ppo_tail(mean, value, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, rec)
+
+    def _ppo_tail(self, mean, value, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, rec):
+        """ppo.py:288-338: log-prob / entropy / KL-adaptive learning rate / losses / backward / clip / Adam."""
+        ac = self.actor_critic
         dist = torch.distributions.Normal(mean, mean * 0. + ac.std)
         logp = dist.log_prob(actions).sum(dim=-1)
-        value = ac.evaluate(critic_obs, priv, base_vel)
         sigma = dist.stddev
         entropy = dist.entropy().sum(dim=-1)
 

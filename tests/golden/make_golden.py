@@ -1,7 +1,7 @@
 """Generate the committed golden fixtures by RUNNING THE REFERENCE (read-only import from
 /root/reference) on the deterministic synthetic inputs of dtc_amd.synthetic.
 
-    python tests/golden/make_golden.py [gae ppo scorer heights init gru dp]
+    python tests/golden/make_golden.py [gae ppo scorer heights init gru composite]
 
 Runs only in the build container (the reference does not exist on the GPU box).  The fixtures
 hold outputs only -- inputs are regenerated from seeds on the test side -- so they stay small.
@@ -396,7 +396,88 @@ def gen_gru():
     save("gru", **out)
 
 
-TASKS = dict(gru=gen_gru, gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
+# ------------------------------------------------------------------------------------ config 5 composite
+def composite_case(N=16, seed=4):
+    data, hid_a, hid_c = gru_case(N, seed)
+    g = torch.Generator().manual_seed(78)
+    eps = torch.randn(4, 24 * (N // 4), 16, generator=g)
+    G1 = torch.randn(24 * (N // 4), 12, generator=g)          # cotangents of the probe functional
+    G2 = torch.randn(24 * (N // 4), 1, generator=g)
+    return data, hid_a, hid_c, eps, G1, G2
+
+
+def gen_composite():
+    """BASELINE config 5 (build-defined): imported `Vae` feature builders feeding the imported
+    `ActorCriticRecurrent(584, 752, 12, gru 512)` over the imported pad / un-pad helpers.  Outputs: action mean /
+    value / log-prob / entropy per recurrent mini-batch and the parameter gradients of the probe functional
+    sum(mean*G1) + sum(value*G2) (autograd through the imported modules: GRU BPTT -> features -> encoders)."""
+    torch.set_num_threads(GOLDEN_THREADS)
+    import torch.nn as nn
+    from rsl_rl.modules import ActorCriticRecurrent
+    from rsl_rl.modules.actor_critic_decoder import Vae
+    from rsl_rl.utils import split_and_pad_trajectories, unpad_trajectories
+    N, nmb = 16, 4
+
+    class Comp(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.vae = Vae()
+            self.acr = ActorCriticRecurrent(584, 752, 12, actor_hidden_dims=[512, 256, 128],
+                                            critic_hidden_dims=[512, 256, 128], activation='elu', rnn_type='gru',
+                                            rnn_hidden_size=512, rnn_num_layers=1)
+
+    with H.quiet():
+        torch.manual_seed(3)
+        m = Comp()
+    fill_parameters_(m, 23)
+    data, hid_a, hid_c, eps_all, G1, G2 = composite_case(N)
+    T, mb = 24, N // nmb
+    dones = data["dones"]
+    lwd = torch.zeros(T, N, dtype=torch.bool)
+    lwd[1:] = dones[:-1, :, 0].bool()
+    lwd[0] = True
+    out = dict(keys=np.array([k.replace("acr.", "") for k in m.state_dict().keys()]))
+    randn_like = torch.randn_like
+    for i in range(nmb):
+        a, b = i * mb, (i + 1) * mb
+        sl = lambda k: data[k][:, a:b].flatten(0, 1)
+        obs, hist, priv, bv = sl("observations"), sl("observation_histories"), sl("privileged_observations"), sl("base_vel")
+        eps = eps_all[i]
+        torch.randn_like = lambda t: eps                       # reparameterize (actor_critic_decoder.py:283) draws here
+        try:
+            mu, lv, z = m.vae.cenet_forward(hist)
+        finally:
+            torch.randn_like = randn_like
+        l_t = m.vae.terrain_encoder(priv[:, :693])
+        fa = torch.cat((obs, z, mu[:, :3], l_t), dim=-1).view(T, mb, -1)
+        fc = torch.cat((obs, bv, priv[:, 693:696], priv[:, 696:]), dim=-1).view(T, mb, -1)
+        d = dones[:, a:b]
+        pa, masks = split_and_pad_trajectories(fa, d)
+        pc, _ = split_and_pad_trajectories(fc, d)
+        pick = lambda h: h[:, :, a:b].permute(2, 0, 1, 3)[lwd[:, a:b].permute(1, 0)].transpose(1, 0).contiguous()
+        actions = m.acr.act(pa, masks=masks, hidden_states=pick(hid_a))
+        mean = m.acr.action_mean
+        value = m.acr.evaluate(pc, masks=masks, hidden_states=pick(hid_c))
+        logp = m.acr.get_actions_log_prob(data["actions"][:, a:b])
+        ent = m.acr.entropy
+        m.zero_grad()
+        ((mean.flatten(0, 1) * G1).sum() + (value.flatten(0, 1) * G2).sum()).backward()
+        out[f"mb{i}_mean"] = mean.detach().flatten(0, 1).numpy()
+        out[f"mb{i}_value"] = value.detach().flatten(0, 1).numpy()
+        out[f"mb{i}_logp"] = logp.detach().flatten(0, 1).numpy()
+        out[f"mb{i}_entropy"] = ent.detach().flatten(0, 1).numpy()
+        out[f"mb{i}_ntraj"] = np.array([masks.shape[1]])
+        if i == 0:
+            for k, p in m.named_parameters():
+                if p.grad is not None:
+                    gname = k.replace("acr.", "")
+                    out["g_" + gname] = p.grad.numpy().copy() if p.grad.numel() <= 4096 else \
+                        np.concatenate([p.grad.flatten()[_sample_idx(p.grad.numel())].numpy(),
+                                        np.array([p.grad.double().sum().item(), p.grad.double().pow(2).sum().item()])]).astype(np.float64)
+    save("composite", **out)
+
+
+TASKS = dict(composite=gen_composite, gru=gen_gru, gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
 
 if __name__ == "__main__":
     for t in (sys.argv[1:] or list(TASKS)):

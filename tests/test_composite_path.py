@@ -1,0 +1,219 @@
+"""BASELINE config 5: GRU + CE-net + foothold-obs composite model (build-defined).
+CPU: oracle/composite_ref.py against tests/golden/composite.npz -- the same composition built from the IMPORTED
+reference classes (Vae, ActorCriticRecurrent, split_and_pad_trajectories, unpad_trajectories): forward outputs of
+every recurrent mini-batch and the parameter gradients of a probe functional (BPTT -> features -> encoders).
+GPU: dtc_amd ActorCriticDecoderRecurrent + RecurrentDecoderPPO against the oracle (teacher-forced mini-batch steps)."""
+import numpy as np
+import pytest
+import torch
+
+from dtc_amd import synthetic as S
+from oracle import composite_ref as CR
+from oracle import ppo_ref as OP
+
+DEV = "cuda:0"
+N, NMB, T = 16, 4, 24
+
+
+def composite_case(seed=4):
+    data = S.rollout(N, T, seed=seed)
+    data["dones"][:, 0] = 0
+    g = torch.Generator().manual_seed(77)
+    hid_a = 0.1 * torch.randn(T, 1, N, 512, generator=g)
+    hid_c = 0.1 * torch.randn(T, 1, N, 512, generator=g)
+    g = torch.Generator().manual_seed(78)
+    eps = torch.randn(4, T * (N // NMB), 16, generator=g)
+    G1 = torch.randn(T * (N // NMB), 12, generator=g)
+    G2 = torch.randn(T * (N // NMB), 1, generator=g)
+    return data, hid_a, hid_c, eps, G1, G2
+
+
+def oracle_model():
+    torch.manual_seed(3)
+    return OP.fill_parameters_(CR.RefCompositeAC(), 23)
+
+
+def oracle_alg(data, **kw):
+    alg = CR.RefCompositePPO(oracle_model(), learning_rate=1e-3, entropy_coef=0.003, **kw)
+    alg.init_storage(N, T)
+    st = alg.storage
+    for k, v in data.items():
+        if k != "last_values":
+            getattr(st, k).copy_(v)
+    st.compute_returns(data["last_values"], 0.99, 0.95)
+    return alg
+
+
+def _sample_idx(numel, k=64):
+    return (np.arange(k, dtype=np.int64) * 2654435761 % numel).astype(np.int64)
+
+
+def test_oracle_matches_reference_composition(golden):
+    g = golden("composite")
+    data, hid_a, hid_c, eps, G1, G2 = composite_case()
+    alg = oracle_alg(data)
+    ac = alg.actor_critic
+    assert [k.replace("acr.", "") for k in ac.state_dict().keys()] == [str(k) for k in g["keys"]]
+    for i, bt in enumerate(CR.recurrent_slices(alg.storage, hid_a, hid_c, NMB)):
+        mean, value = alg.forward(bt, eps[i])
+        assert bt["hid_a"].shape[1] == int(g[f"mb{i}_ntraj"][0])
+        np.testing.assert_allclose(mean.detach().numpy(), g[f"mb{i}_mean"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(value.detach().numpy(), g[f"mb{i}_value"], rtol=1e-5, atol=1e-6)
+        dist = torch.distributions.Normal(mean, mean * 0. + ac.std)
+        actions = alg.storage.actions.flatten(0, 1)[bt["idx"]]
+        np.testing.assert_allclose(dist.log_prob(actions).sum(-1).detach().numpy(), g[f"mb{i}_logp"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(dist.entropy().sum(-1).detach().numpy(), g[f"mb{i}_entropy"], rtol=1e-6, atol=1e-6)
+        if i == 0:
+            ac.zero_grad()
+            ((mean * G1).sum() + (value * G2).sum()).backward()
+            n_checked = 0
+            for k, p in ac.named_parameters():
+                k = k.replace("acr.", "")
+                if p.grad is None:
+                    assert "g_" + k not in g.files, k
+                    continue
+                ref = g["g_" + k]
+                if p.grad.numel() <= 4096:
+                    np.testing.assert_allclose(p.grad.numpy(), ref, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+                else:
+                    got = p.grad.flatten()[_sample_idx(p.grad.numel())].numpy()
+                    scale = max(1.0, float(np.abs(ref[:64]).max()))
+                    np.testing.assert_allclose(got, ref[:64], rtol=2e-4, atol=2e-5 * scale, err_msg=k)
+                    np.testing.assert_allclose(p.grad.double().sum().item(), ref[64], rtol=1e-4, atol=1e-3 * scale, err_msg=k)
+                    np.testing.assert_allclose(p.grad.double().pow(2).sum().item(), ref[65], rtol=1e-4, err_msg=k)
+                n_checked += 1
+            # every trainable block takes part: encoders (through the GRU input), both GRUs, both MLPs
+            assert n_checked >= 30
+
+
+# ------------------------------------------------------------------------------------------ GPU (HIP path)
+def _strip(sd):
+    return {k.replace("acr.", ""): v for k, v in sd.items()}
+
+
+def _hip_alg(ref, data, **kw):
+    from dtc_amd.algorithms import RecurrentDecoderPPO
+    from dtc_amd.modules import ActorCriticDecoderRecurrent
+    ac = ActorCriticDecoderRecurrent(53, 1389, 12)
+    alg = RecurrentDecoderPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV, **kw)
+    alg.init_storage(N, T, [53], [1389], [265], [12])
+    ac.load_state_dict(_strip(ref.actor_critic.state_dict()))
+    for k, v in data.items():
+        if k != "last_values":
+            getattr(alg.storage, k).copy_(v.to(DEV))
+    alg.storage.compute_returns(data["last_values"].to(DEV), 0.99, 0.95)
+    return alg
+
+
+def _grad_report(grads_ref, alg, which, tol, skip=()):
+    arena = alg.actor_critic.arena
+    worst = []
+    for name, g_ref in grads_ref.items():
+        name = name.replace("acr.", "")
+        if name.startswith(skip):
+            continue
+        g = arena.view(alg.captured[which], name).cpu()
+        scale = float(g_ref.abs().max()) + 1e-30
+        err = float(((g - g_ref).abs() / scale).max())
+        l2 = float((g - g_ref).norm() / (g_ref.norm() + 1e-30))
+        worst.append((max(err, l2), name))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= tol, worst[:6]
+    return len(worst)
+
+
+@pytest.mark.gpu
+def test_hip_rollout_mode_forward_carries_state():
+    data, hid_a, hid_c, eps, _, _ = composite_case()
+    ref = oracle_alg(data)
+    alg = _hip_alg(ref, data)
+    rac, ac = ref.actor_critic, alg.actor_critic
+    ha = hc = None
+    g = torch.Generator().manual_seed(5)
+    for t in range(3):
+        e = torch.randn(N, 16, generator=g)
+        obs, hist, priv, bv = (data[k][t] for k in ("observations", "observation_histories", "privileged_observations", "base_vel"))
+        with torch.no_grad():
+            out, ha = rac.memory_a.rnn(rac.actor_features(obs, hist, priv, e).unsqueeze(0), ha)
+            mean_ref = rac.actor(out.squeeze(0))
+            out, hc = rac.memory_c.rnn(rac.critic_features(obs, priv, bv).unsqueeze(0), hc)
+            val_ref = rac.critic(out.squeeze(0))
+        ac.update_distribution(obs.to(DEV), hist.to(DEV), priv.to(DEV), eps=e.to(DEV))
+        val = ac.evaluate(obs.to(DEV), priv.to(DEV), bv.to(DEV))
+        np.testing.assert_allclose(ac.action_mean.cpu().numpy(), mean_ref.numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(val.cpu().numpy(), val_ref.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ac.memory_a.hidden_states.cpu().numpy(), ha.numpy(), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(schedule="fixed", use_clipped_value_loss=False)])
+def test_hip_teacher_forced_minibatches_vs_oracle(kw):
+    """Each of the 4 recurrent mini-batches, both optimisation steps, from identical weights and fresh Adam states:
+    per-step scalars to 1e-5 rel, every parameter gradient (BPTT through both GRUs, through the feature blocks into
+    the CE-net / terrain encoders) to 2e-5 of the tensor's max."""
+    from dtc_amd.algorithms import ppo as P
+    data, hid_a, hid_c, eps, _, _ = composite_case()
+    g = torch.Generator().manual_seed(79)
+    eps2 = torch.randn(4, T * (N // NMB), 16, generator=g)
+    for i in range(NMB):
+        ref = oracle_alg(data, **kw)
+        ref.capture_grads = True
+        alg = _hip_alg(ref, data, **kw)
+        alg.capture_grads = True
+        bt_ref = list(CR.recurrent_slices(ref.storage, hid_a, hid_c, NMB))[i]
+        bt = list(alg.recurrent_slices(hid_a.to(DEV), hid_c.to(DEV)))[i]
+        assert bt["R"] == bt_ref["hid_a"].shape[1] and torch.equal(bt["idx"].cpu(), bt_ref["idx"])
+        rec = OP.StepRecord()
+        # VAE step
+        ref.vae_step(bt_ref["idx"], eps[i], rec)
+        stats = alg.step_minibatch(bt, eps[i].to(DEV), eps2[i].to(DEV), which="vae")
+        row = stats.cpu()
+        for key, col in (("recons", P.S_RECONS), ("vel", P.S_VEL), ("kld", P.S_KLD), ("height", P.S_HEIGHT),
+                         ("vae_gnorm", P.S_VAE_GNORM)):
+            assert abs(float(row[col]) - getattr(rec, key)) <= 1e-5 * max(1.0, abs(getattr(rec, key))), (i, key)
+        fw = alg.actor_critic._fwd_ws(bt["idx"].numel())
+        same_median = int(fw.info[0]) == ref.actor_critic.vae.last_outliers and \
+            int(fw.info[1]) == ref.actor_critic.vae.last_median_index
+        skip = () if same_median else ("vae.cenet_encoder", "vae.latent_")
+        assert _grad_report(rec.extra["vae_grads"], alg, "vae", 2e-5, skip) >= 20
+        # policy step (BPTT) from the oracle's post-VAE-step weights
+        alg.actor_critic.load_state_dict(_strip(ref.actor_critic.state_dict()))
+        ref.ppo_step(bt_ref, eps2[i], rec)
+        stats = alg.step_minibatch(bt, eps[i].to(DEV), eps2[i].to(DEV), which="ppo")
+        row = stats.cpu()
+        keys = [("surrogate", P.S_SURR), ("value", P.S_VALUE), ("entropy", P.S_ENTROPY), ("gnorm", P.S_GNORM)]
+        if ref.schedule == "adaptive":
+            keys.append(("kl_mean", P.S_KL))
+        for key, col in keys:
+            assert abs(float(row[col]) - getattr(rec, key)) <= 1e-5 * max(1.0, abs(getattr(rec, key))), (i, key, float(row[col]), getattr(rec, key))
+        assert abs(float(alg.optimizer.lr_dev.item()) - ref.learning_rate) <= 1e-12
+        same_median = int(fw.info[0]) == ref.actor_critic.vae.last_outliers and \
+            int(fw.info[1]) == ref.actor_critic.vae.last_median_index
+        skip = () if same_median else ("vae.cenet_encoder", "vae.latent_")
+        n = _grad_report(rec.extra["grads"], alg, "main", 2e-5, skip)
+        assert n >= 35            # std, 2 MLPs, 2 GRUs, CE-net encoder + heads, terrain encoder
+
+
+@pytest.mark.gpu
+def test_hip_rollout_and_update_end_to_end():
+    """act / process_env_step record the hidden states, update() consumes them; 2 updates stay finite."""
+    from dtc_amd.algorithms import RecurrentDecoderPPO
+    from dtc_amd.modules import ActorCriticDecoderRecurrent
+    torch.manual_seed(3)
+    n = 64
+    ac = ActorCriticDecoderRecurrent(53, 1389, 12)
+    alg = RecurrentDecoderPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV)
+    alg.init_storage(n, T, [53], [1389], [265], [12])
+    d = S.rollout(n, T, seed=9, device=DEV)
+    for it in range(2):
+        for t in range(T):
+            alg.act(d["observations"][t], d["privileged_observations"][t], d["observation_histories"][t], d["base_vel"][t])
+            alg.process_env_step(d["rewards"][t, :, 0], d["dones"][t, :, 0], d["next_observations"][t], {})
+        assert alg.storage.saved_hidden_states_a[0].shape == (T, 1, n, 512)
+        if it == 0:
+            assert float(alg.storage.saved_hidden_states_a[0][0].abs().max()) == 0.0       # first step starts from zeros
+            assert float(alg.storage.saved_hidden_states_a[0][5].abs().max()) > 0.0
+        alg.compute_returns(d["observations"][-1], d["privileged_observations"][-1], d["base_vel"][-1])
+        out = alg.update()
+        assert all(np.isfinite(out)), out
+    assert 1e-5 <= alg.learning_rate <= 1e-2
