@@ -41,6 +41,18 @@ class DtcPpoCfg(C.Structure):
                 ("adaptive_schedule", C.c_int32)]
 
 
+class DtcObsCfg(C.Structure):
+    _fields_ = [("ang_vel", C.c_float), ("dof_pos", C.c_float), ("dof_vel", C.c_float),
+                ("height_measurements", C.c_float), ("force", C.c_float), ("commands_scale", C.c_float * 3),
+                ("base_height_target", C.c_float), ("height_noise", C.c_float), ("term_height", C.c_float),
+                ("num_dof", C.c_int32), ("num_foothold_obs", C.c_int32), ("num_points", C.c_int32),
+                ("term_row0", C.c_int32), ("term_row1", C.c_int32)]
+
+
+class DtcRowCopy(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_stride_bytes", C.c_int64), ("width_bytes", C.c_int32)]
+
+
 class DtcProfRec(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms_total", C.c_double), ("work", C.c_double),
                 ("launches", C.c_int64)]
@@ -56,6 +68,13 @@ _SIGS = {
     "dtc_foothold_rewards": (C.c_int, [c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, C.c_int, c_stream]),
     "dtc_get_heights": (C.c_int, [c_i16p, C.c_int, C.c_int, c_f32p, C.POINTER(DtcGridCfg), C.c_float, C.c_float,
                                   C.c_float, c_f32p, C.c_int, c_stream]),
+    "dtc_compute_observations": (C.c_int, [c_f32p] * 11 + [C.c_int64] + [c_f32p] * 4 + [C.POINTER(DtcObsCfg)] +
+                                 [c_f32p] * 3 + [C.c_int, c_stream]),
+    "dtc_check_termination": (C.c_int, [c_f32p, C.c_int, c_i32p, C.c_int, c_i64p, C.c_int64, c_f32p, c_f32p, c_f32p,
+                                        C.POINTER(DtcObsCfg), c_u8p, c_u8p, c_f32p, C.c_int, c_stream]),
+    "dtc_store_transition": (C.c_int, [C.POINTER(DtcRowCopy), C.c_int, c_f32p, c_f32p, c_u8p, C.c_float, c_f32p,
+                                       C.c_int, c_stream]),
+    "dtc_history_roll": (C.c_int, [c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_gae": (C.c_int, [c_f32p, c_f32p, c_u8p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_f64p, C.c_int,
                           C.c_int, c_stream]),
     "dtc_adv_sqdev": (C.c_int, [c_f32p, c_f64p, C.c_int64, C.c_double, c_stream]),

@@ -265,12 +265,12 @@ class PPO:
 
     def process_env_step(self, rewards, dones, next_obs, infos):
         tr = self.transition
-        tr.rewards = rewards.clone()
+        tr.rewards = rewards
         tr.dones = dones
         tr.next_observations = next_obs
-        if 'time_outs' in infos:   # bootstrapping on time outs (ppo.py:162-163)
-            tr.rewards += self.gamma * torch.squeeze(tr.values * infos['time_outs'].unsqueeze(1).to(self.device), 1)
-        self.storage.add_transitions(tr)
+        # bootstrapping on time outs (ppo.py:162-163) happens inside the fused store: r + gamma * V * time_out
+        time_outs = infos['time_outs'] if 'time_outs' in infos else None
+        self.storage.add_transitions(tr, time_outs=time_outs, gamma=self.gamma)
         tr.clear()
         self.actor_critic.reset(dones)
 

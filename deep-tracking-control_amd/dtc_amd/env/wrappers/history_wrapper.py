@@ -1,7 +1,11 @@
 """HistoryWrapper: dict-observation packaging + 5-step observation history roll
 (rsl_rl/rsl_rl/env/wrappers/history_wrapper.py:6-53).  No gym dependency: attribute access falls
-through to the wrapped env."""
+through to the wrapped env.  On a HIP device the roll is one dtc_history_roll launch between two ping-pong
+buffers (the reference returns a NEW tensor each step and callers hold the previous one until the transition is
+stored, so the roll must not happen in place)."""
 import torch
+
+from ... import ops
 
 
 class HistoryWrapper:
@@ -16,7 +20,7 @@ class HistoryWrapper:
         return getattr(self.__dict__["env"], name)
 
     def __setattr__(self, name, value):
-        if name in ("env", "obs_history_length", "num_obs_history", "obs_history") or "env" not in self.__dict__:
+        if name in ("env", "obs_history_length", "num_obs_history", "obs_history", "_spare") or "env" not in self.__dict__:
             object.__setattr__(self, name, value)
         elif hasattr(self.__dict__["env"], name) and name not in self.__dict__:
             setattr(self.__dict__["env"], name, value)      # e.g. runner sets env.episode_length_buf
@@ -24,7 +28,14 @@ class HistoryWrapper:
             object.__setattr__(self, name, value)
 
     def _roll(self, obs):
-        self.obs_history = torch.cat((self.obs_history[:, self.env.num_obs:], obs), dim=-1)
+        if self.obs_history.is_cuda:
+            spare = self.__dict__.get("_spare")
+            if spare is None or spare.shape != self.obs_history.shape:
+                spare = torch.empty_like(self.obs_history)
+            ops.history_roll(self.obs_history, obs.contiguous().float(), spare, self.obs_history_length)
+            self._spare, self.obs_history = self.obs_history, spare
+        else:
+            self.obs_history = torch.cat((self.obs_history[:, self.env.num_obs:], obs), dim=-1)
 
     def _pack(self, obs, privileged_obs):
         return {'obs': obs, 'privileged_obs': privileged_obs, 'obs_history': self.obs_history,

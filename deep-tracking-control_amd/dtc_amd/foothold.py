@@ -112,6 +112,79 @@ def rewards(foot_positions: torch.Tensor, optimal_footholds_world: torch.Tensor,
     return tracking, miss
 
 
+@dataclass
+class ObsConfig:
+    """Scales / sizes consumed by compute_observations and check_termination (defaults = Lite3DTCCfg:
+    legged_robot_config.py:181-188, lite3_dtc_config.py:139, legged_robot_dtc.py:244-246, 278)."""
+    ang_vel: float = 0.25
+    dof_pos: float = 1.0
+    dof_vel: float = 0.05
+    height_measurements: float = 5.0
+    force: float = 0.005
+    lin_vel: float = 2.0
+    base_height_target: float = 0.32
+    height_noise: float = 0.1
+    term_height: float = 0.15
+    num_dof: int = 12
+    num_foothold_obs: int = 8
+    num_points: int = len(MEASURED_POINTS_X) * len(MEASURED_POINTS_Y)
+    term_row0: int = 10 * 21
+    term_row1: int = (33 - 10) * 21
+
+    def c_struct(self) -> _ffi.DtcObsCfg:
+        c = _ffi.DtcObsCfg()
+        for k in ("ang_vel", "dof_pos", "dof_vel", "height_measurements", "force", "base_height_target", "height_noise",
+                  "term_height", "num_dof", "num_foothold_obs", "num_points", "term_row0", "term_row1"):
+            setattr(c, k, getattr(self, k))
+        c.commands_scale[0], c.commands_scale[1], c.commands_scale[2] = self.lin_vel, self.lin_vel, self.ang_vel
+        return c
+
+
+def compute_observations(base_ang_vel, projected_gravity, commands, dof_pos, default_dof_pos, dof_vel, actions,
+                         foothold_obs, root_states, measured_heights, forces, height_noise_offset=None, u_obs=None,
+                         noise_scale_vec=None, u_heights=None, cfg: ObsConfig | None = None):
+    """LeggedRobotDTC.compute_observations (legged_robot_dtc.py:255-288) as one kernel.  `forces` is the env's
+    [N, num_bodies, 3] force buffer (body 0 is used); `u_obs` / `u_heights` are the uniform [0,1) draws the reference
+    takes with torch.rand_like (pass None to omit the noise term).  Returns dict(obs_buf, privileged_obs_buf, heights)."""
+    cfg = cfg or ObsConfig()
+    N, dev, P = root_states.shape[0], root_states.device, cfg.num_points
+    c = lambda t: None if t is None else _ffi.cptr(t.contiguous().float(), torch.float32)
+    n_obs = 9 + 3 * cfg.num_dof + cfg.num_foothold_obs
+    obs = torch.empty(N, n_obs, device=dev)
+    priv = torch.empty(N, 2 * P + 3, device=dev)
+    heights = torch.empty(N, P, device=dev)
+    forces = forces.contiguous().float()
+    ld_f = forces[0].numel()
+    keep = [t.contiguous().float() if t is not None else None for t in
+            (base_ang_vel, projected_gravity, commands, dof_pos, default_dof_pos.reshape(-1), dof_vel, actions, foothold_obs,
+             root_states, measured_heights)]
+    opt = [t.contiguous().float() if t is not None else None for t in (height_noise_offset, u_obs, noise_scale_vec, u_heights)]
+    rc = _ffi.lib().dtc_compute_observations(*[_ffi.ptr(t) for t in keep], _ffi.ptr(forces), ld_f, _ffi.ptr(opt[0]),
+                                             _ffi.ptr(opt[1]), _ffi.ptr(opt[2]), _ffi.ptr(opt[3]), cfg.c_struct(),
+                                             _ffi.ptr(obs), _ffi.ptr(priv), _ffi.ptr(heights), N, _ffi.stream())
+    _ffi.check(rc, "dtc_compute_observations")
+    return dict(obs_buf=obs, privileged_obs_buf=priv, heights=heights)
+
+
+def check_termination(contact_forces, termination_contact_indices, episode_length_buf, max_episode_length,
+                      projected_gravity, root_states, measured_heights, cfg: ObsConfig | None = None):
+    """LeggedRobotDTC.check_termination (legged_robot_dtc.py:229-248).  Returns (reset_buf, time_out_buf) as bool
+    tensors and the base-height mean of the last test."""
+    cfg = cfg or ObsConfig()
+    N, dev = root_states.shape[0], root_states.device
+    cf = contact_forces.contiguous().float()
+    idx = termination_contact_indices.to(device=dev, dtype=torch.int32).contiguous()
+    ep = episode_length_buf.to(torch.int64).contiguous()
+    reset, tout = torch.empty(N, dtype=torch.uint8, device=dev), torch.empty(N, dtype=torch.uint8, device=dev)
+    mean = torch.empty(N, device=dev)
+    g, r, h = projected_gravity.contiguous().float(), root_states.contiguous().float(), measured_heights.contiguous().float()
+    rc = _ffi.lib().dtc_check_termination(_ffi.ptr(cf), cf.shape[1], _ffi.ptr(idx), idx.numel(), _ffi.ptr(ep),
+                                          int(max_episode_length), _ffi.ptr(g), _ffi.ptr(r), _ffi.ptr(h), cfg.c_struct(),
+                                          _ffi.ptr(reset), _ffi.ptr(tout), _ffi.ptr(mean), N, _ffi.stream())
+    _ffi.check(rc, "dtc_check_termination")
+    return reset.bool(), tout.bool(), mean
+
+
 def patch_env(env, grid: GridConfig | None = None):
     """Attach `env.plan_footholds()` that performs lines :98-201 of post_physics_step on `env`'s
     own buffers (rigid_body_state, base_pos/quat via root_states, commands, measured_heights)."""

@@ -43,6 +43,31 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: torch.Tensor | None =
     return out
 
 
+def store_transition(copies, rewards=None, values=None, time_outs=None, gamma=0.0, rewards_dst=None):
+    """RolloutStorage.add_transitions as one launch.  copies: list of (src [N, ...], dst [N, ...]) tensor pairs
+    (src may be a broadcast view with row stride 0); rewards_dst = rewards + gamma * values * time_outs."""
+    n_rows = copies[0][1].shape[0] if copies else rewards_dst.shape[0]
+    items = (_ffi.DtcRowCopy * max(1, len(copies)))()
+    for i, (src, dst) in enumerate(copies):
+        assert dst.is_contiguous() and src.shape[0] == n_rows and dst.shape[0] == n_rows
+        width = dst[0].numel() * dst.element_size()
+        assert src.dtype == dst.dtype and src[0].numel() == dst[0].numel() and (src.dim() == 1 or src[0].is_contiguous())
+        items[i].src, items[i].dst = src.data_ptr(), dst.data_ptr()
+        items[i].src_stride_bytes = src.stride(0) * src.element_size()
+        items[i].width_bytes = width
+    check(lib().dtc_store_transition(items, len(copies), ptr(rewards), ptr(values), ptr(time_outs), float(gamma),
+                                     ptr(rewards_dst), n_rows, stream()), "dtc_store_transition")
+
+
+def history_roll(obs_history, obs, out, history_len, reset=None):
+    """out <- cat(obs_history[:, D:], obs); `out` may be `obs_history` itself."""
+    N, D = obs.shape
+    check(lib().dtc_history_roll(cptr(obs_history, f32), cptr(obs, f32), cptr(out, f32),
+                                 cptr(reset, torch.uint8) if reset is not None else None, N, history_len, D, stream()),
+          "dtc_history_roll")
+    return out
+
+
 # ---------------------------------------------------------------- dense layers
 def as_segmat(x, idx=None):
     """Accept a plain 2-D tensor or an already built DtcSegMat."""

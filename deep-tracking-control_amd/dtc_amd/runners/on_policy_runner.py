@@ -8,17 +8,17 @@ from collections import deque
 
 import torch
 
-from ..algorithms import PPO
+from ..algorithms import PPO, RecurrentDecoderPPO
 from ..env import HistoryWrapper
-from ..modules import ActorCriticDecoder  # noqa: F401  (resolved by name from train_cfg)
+from ..modules import ActorCriticDecoder, ActorCriticDecoderRecurrent  # resolved by name from train_cfg
 
 try:                                       # not installed in every image
     from torch.utils.tensorboard import SummaryWriter
 except Exception:                          # pragma: no cover
     SummaryWriter = None
 
-_POLICIES = {"ActorCriticDecoder": ActorCriticDecoder}
-_ALGORITHMS = {"PPO": PPO}
+_POLICIES = {"ActorCriticDecoder": ActorCriticDecoder, "ActorCriticDecoderRecurrent": ActorCriticDecoderRecurrent}
+_ALGORITHMS = {"PPO": PPO, "RecurrentDecoderPPO": RecurrentDecoderPPO}
 
 
 class OnPolicyRunner:

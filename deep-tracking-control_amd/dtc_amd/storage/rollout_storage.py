@@ -72,23 +72,45 @@ class RolloutStorage:
         self.step = 0
         self._stats = None
 
-    def add_transitions(self, transition: "RolloutStorage.Transition"):
+    def add_transitions(self, transition: "RolloutStorage.Transition", time_outs=None, gamma=0.0):
+        """rollout_storage.py:99-116.  On a HIP device the 13 copies are ONE dtc_store_transition launch, which also
+        applies the time-out bootstrap of PPO.process_env_step (ppo.py:162-163) when `time_outs` is given."""
         if self.step >= self.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
-        s = self.step
-        self.observations[s].copy_(transition.observations)
-        self.next_observations[s].copy_(transition.next_observations)
-        self.privileged_observations[s].copy_(transition.privileged_observations)
-        self.observation_histories[s].copy_(transition.observation_histories)
-        self.actions[s].copy_(transition.actions)
-        self.rewards[s].copy_(transition.rewards.view(-1, 1))
-        self.dones[s].copy_(transition.dones.view(-1, 1))
-        self.values[s].copy_(transition.values)
-        self.actions_log_prob[s].copy_(transition.actions_log_prob.view(-1, 1))
-        self.mu[s].copy_(transition.action_mean)
-        self.base_vel[s].copy_(transition.base_vel)
-        self.sigma[s].copy_(transition.action_sigma)
-        self._save_hidden_states(transition.hidden_states)
+        s, tr = self.step, transition
+        if self.observations.is_cuda:
+            f = lambda t: t if t.dtype == torch.float32 else t.float()
+            dones = tr.dones if tr.dones.dtype in (torch.uint8, torch.bool) else tr.dones.to(torch.uint8)
+            if dones.dtype == torch.bool:
+                dones = dones.view(torch.uint8)
+            copies = [(f(tr.observations), self.observations[s]), (f(tr.next_observations), self.next_observations[s]),
+                      (f(tr.privileged_observations), self.privileged_observations[s]),
+                      (f(tr.observation_histories), self.observation_histories[s]), (f(tr.actions), self.actions[s]),
+                      (dones.reshape(-1), self.dones[s]), (f(tr.values), self.values[s]),
+                      (f(tr.actions_log_prob).reshape(-1), self.actions_log_prob[s]), (f(tr.action_mean), self.mu[s]),
+                      (f(tr.base_vel), self.base_vel[s]), (f(tr.action_sigma), self.sigma[s])]
+            to = None
+            if time_outs is not None:
+                to = time_outs.to(self.device)
+                to = to.view(torch.uint8) if to.dtype == torch.bool else to.to(torch.uint8)
+            ops.store_transition(copies, f(tr.rewards).reshape(-1).contiguous(), f(tr.values).reshape(-1), to, gamma,
+                                 self.rewards[s])
+        else:
+            if time_outs is not None:
+                tr.rewards = tr.rewards + gamma * torch.squeeze(tr.values * time_outs.unsqueeze(1).to(self.device), 1)
+            self.observations[s].copy_(tr.observations)
+            self.next_observations[s].copy_(tr.next_observations)
+            self.privileged_observations[s].copy_(tr.privileged_observations)
+            self.observation_histories[s].copy_(tr.observation_histories)
+            self.actions[s].copy_(tr.actions)
+            self.rewards[s].copy_(tr.rewards.view(-1, 1))
+            self.dones[s].copy_(tr.dones.view(-1, 1))
+            self.values[s].copy_(tr.values)
+            self.actions_log_prob[s].copy_(tr.actions_log_prob.view(-1, 1))
+            self.mu[s].copy_(tr.action_mean)
+            self.base_vel[s].copy_(tr.base_vel)
+            self.sigma[s].copy_(tr.action_sigma)
+        self._save_hidden_states(tr.hidden_states)
         self.step += 1
 
     def _save_hidden_states(self, hidden_states):

@@ -103,3 +103,27 @@ def scorer_inputs(num_envs: int, seed: int = 7, device="cpu") -> dict:
     heights = (root[:, 2:3] - 0.32) + torch.where(flat, torch.zeros_like(steps), steps)
     return dict(root_states=root, thigh_pos=thigh.contiguous(), commands=commands,
                 measured_heights=heights.contiguous())
+
+
+def env_state(num_envs: int, seed: int = 13, device="cpu") -> dict:
+    """Mock env state consumed by compute_observations / check_termination (legged_robot_dtc.py:229-288):
+    the scorer inputs of `scorer_inputs(seed)` plus joint state, actions, contacts, forces and the uniform draws
+    the reference takes from torch.rand_like (inputs here, so that both sides use the same numbers)."""
+    d = scorer_inputs(num_envs, seed=seed, device=device)
+    g = _gen(seed + 1000, device)
+    N = num_envs
+    ru = lambda *s: torch.rand(*s, generator=g, device=device)
+    rn = lambda *s: torch.randn(*s, generator=g, device=device)
+    grav = torch.stack([0.1 * rn(N), 0.1 * rn(N), -1.0 + 0.05 * rn(N).abs()], dim=1)
+    grav[: N // 32, 2] = 0.3                                   # fallen over -> terminated by the gravity test
+    d.update(base_ang_vel=0.5 * rn(N, 3), projected_gravity=grav, dof_pos=0.3 * rn(N, 12),
+             default_dof_pos=torch.tensor([0.0, -0.8, 1.6] * 4, device=device), dof_vel=2.0 * rn(N, 12),
+             actions=rn(N, 12), foothold_obs=0.5 * rn(N, 8), forces=10.0 * rn(N, 17, 3),
+             height_noise_offset=0.02 * rn(N, 1).expand(N, N_POINTS).contiguous(),
+             u_obs=ru(N, 53), u_heights=ru(N, N_POINTS),
+             noise_scale_vec=torch.cat([0.05 * ru(45), torch.zeros(8, device=device)]),
+             contact_forces=40.0 * rn(N, 17, 3), episode_length_buf=torch.randint(0, 1100, (N,), generator=g, device=device),
+             termination_contact_indices=torch.tensor([0, 1, 5, 9, 13], device=device))
+    # a few robots sunk into the terrain -> the base-height termination test fires
+    d["root_states"][N // 32: N // 16, 2] -= 0.25
+    return d

@@ -69,6 +69,64 @@ int dtc_get_heights(const int16_t* height_samples /*[rows,cols]*/, int rows, int
                     float horizontal_scale, float vertical_scale, float* measured_heights /*[N,P]*/,
                     int N, void* stream);
 
+/* ---- env-step consumers of the planner output (row f3) ----------------------------------
+ * LeggedRobotDTC.compute_observations, legged_gym/envs/base/legged_robot_dtc.py:255-288, and
+ * LeggedRobotDTC.check_termination, legged_gym/envs/base/legged_robot_dtc.py:229-248. */
+typedef struct DtcObsCfg {
+    float ang_vel, dof_pos, dof_vel, height_measurements, force;   /* cfg.normalization.obs_scales (legged_robot_config.py:181-188) */
+    float commands_scale[3];     /* [lin_vel, lin_vel, ang_vel] (legged_robot.py:810)                                    */
+    float base_height_target;    /* cfg.rewards.base_height_target (lite3_dtc_config.py:139)                             */
+    float height_noise;          /* 0.1: amplitude of the uniform height noise of the privileged obs (:278)              */
+    float term_height;           /* 0.15: base-height termination threshold (:244-246)                                   */
+    int num_dof, num_foothold_obs, num_points;      /* 12, 8, 693                                                        */
+    int term_row0, term_row1;    /* slice of measured_heights averaged by the height test: 10*21, (33-10)*21             */
+} DtcObsCfg;
+
+/* obs_buf [N, 9 + 3*num_dof + num_foothold_obs] = cat(ang_vel*s, gravity, commands[:, :3]*s, (dof_pos-default)*s,
+ * dof_vel*s, actions, foothold_obs) (+ (2*u_obs-1)*noise_scale_vec when u_obs != NULL: the torch.rand_like draw of :287
+ * is an INPUT); heights [N,P] = clip(root_z - target - measured_heights, -1, 1)*s (may be NULL);
+ * privileged_obs_buf [N, 2P+3] = cat(heights + (2*u_heights-1)*0.1 + height_noise_offset, forces[:,0,:]*s, heights)
+ * (u_heights / height_noise_offset may be NULL = term omitted).  forces: first body's force of env n at
+ * forces + n*ld_forces.  commands is [N,4].  cfg is a HOST pointer. */
+int dtc_compute_observations(const float* base_ang_vel, const float* projected_gravity, const float* commands,
+                             const float* dof_pos, const float* default_dof_pos /*[num_dof]*/, const float* dof_vel,
+                             const float* actions, const float* foothold_obs, const float* root_states /*[N,13]*/,
+                             const float* measured_heights /*[N,P]*/, const float* forces, int64_t ld_forces,
+                             const float* height_noise_offset /*[N,P]*/, const float* u_obs, const float* noise_scale_vec,
+                             const float* u_heights /*[N,P]*/, const DtcObsCfg* cfg, float* obs_buf,
+                             float* privileged_obs_buf, float* heights, int N, void* stream);
+
+/* reset_buf[n] = any_j |contact_forces[n, idx_j]| > 100  |  episode_length > max  |  gravity_z > 0.2  |
+ * mean(root_z - max(measured_heights[n, term_row0:term_row1], 0)) < term_height;  time_out_buf[n] = episode_length > max.
+ * contact_forces [N,num_bodies,3]; indices int32 (device); episode_length_buf int64; outputs uint8. */
+int dtc_check_termination(const float* contact_forces, int num_bodies, const int32_t* termination_contact_indices,
+                          int n_term, const int64_t* episode_length_buf, int64_t max_episode_length,
+                          const float* projected_gravity /*[N,3]*/, const float* root_states /*[N,13]*/,
+                          const float* measured_heights /*[N,P]*/, const DtcObsCfg* cfg, uint8_t* reset_buf,
+                          uint8_t* time_out_buf /*or NULL*/, float* height_mean_or_null, int N, void* stream);
+
+/* ---- rollout-side store (row f2) ---------------------------------------------------------
+ * RolloutStorage.add_transitions, rsl_rl/rsl_rl/storage/rollout_storage.py:99-116: the 13 `copy_` of one env step as
+ * ONE launch (each item: N rows of width_bytes, source row stride src_stride_bytes -- 0 for a broadcast row such as
+ * action_sigma -- into a dense destination), plus the time-out bootstrap of PPO.process_env_step, ppo.py:162-163:
+ * rewards_dst[n] = rewards[n] + gamma * values[n] * time_outs[n] (time_outs NULL = plain copy; rewards_dst NULL = skip).
+ * `items` is a HOST array of at most 16 descriptors holding DEVICE pointers. */
+typedef struct DtcRowCopy {
+    const void* src;
+    void* dst;
+    int64_t src_stride_bytes;
+    int32_t width_bytes;
+} DtcRowCopy;
+int dtc_store_transition(const DtcRowCopy* items, int n_items, const float* rewards, const float* values,
+                         const uint8_t* time_outs_or_null, float gamma, float* rewards_dst, int N, void* stream);
+
+/* HistoryWrapper.step / get_observations, rsl_rl/rsl_rl/env/wrappers/history_wrapper.py:23,37:
+ * out = cat(obs_history[:, num_obs:], obs) ([N, history_len*num_obs] <= 1024 floats per row); `out` may alias
+ * `obs_history`.  The reference builds a NEW tensor every step and callers keep the old one until the transition is
+ * stored, so the host wrapper ping-pongs two buffers.  Rows with reset[n] != 0 are cleared first (reset_idx, :42). */
+int dtc_history_roll(const float* obs_history, const float* obs, float* out, const uint8_t* reset_or_null, int N,
+                     int history_len, int num_obs, void* stream);
+
 /* ---- RolloutStorage.compute_returns: rsl_rl/rsl_rl/storage/rollout_storage.py:138-152 --- */
 /* GAE scan; writes returns and the UN-normalised advantages (returns - values) and
  * stats[0] = sum(advantages) (double).  stats is double[4] on the device. */

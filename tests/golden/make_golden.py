@@ -1,7 +1,7 @@
 """Generate the committed golden fixtures by RUNNING THE REFERENCE (read-only import from
 /root/reference) on the deterministic synthetic inputs of dtc_amd.synthetic.
 
-    python tests/golden/make_golden.py [gae ppo scorer heights init gru composite]
+    python tests/golden/make_golden.py [gae ppo scorer heights init gru composite observations]
 
 Runs only in the build container (the reference does not exist on the GPU box).  The fixtures
 hold outputs only -- inputs are regenerated from seeds on the test side -- so they stay small.
@@ -396,6 +396,43 @@ def gen_gru():
     save("gru", **out)
 
 
+# ------------------------------------------------------------------------------------ f3: observations / termination
+def gen_observations():
+    """`LeggedRobotDTC.compute_observations` and `.check_termination` (legged_robot_dtc.py:229-288) run as
+    unbound methods on a mock env built from dtc_amd.synthetic.env_state; the two torch.rand_like draws are
+    replaced by the generator's uniforms."""
+    from legged_gym.envs.base.legged_robot_dtc import LeggedRobotDTC
+    from legged_gym.envs.lite3.lite3_dtc_config import Lite3DTCCfg
+    N = 1024
+    s = S.env_state(N, seed=13)
+    cfg = Lite3DTCCfg()
+    m = types.SimpleNamespace(cfg=cfg, device="cpu", num_envs=N)
+    m.obs_scales = cfg.normalization.obs_scales
+    m.commands_scale = torch.tensor([m.obs_scales.lin_vel, m.obs_scales.lin_vel, m.obs_scales.ang_vel])
+    m.cpg_phase_information = None
+    for k in ("base_ang_vel", "projected_gravity", "commands", "dof_pos", "dof_vel", "actions", "foothold_obs",
+              "root_states", "measured_heights", "forces", "height_noise_offset", "noise_scale_vec", "contact_forces",
+              "episode_length_buf", "termination_contact_indices"):
+        setattr(m, k, s[k].clone())
+    m.default_dof_pos = s["default_dof_pos"].unsqueeze(0)
+    m.add_noise = True
+    m.max_episode_length = 1000
+    draws = [s["u_heights"], s["u_obs"]]              # order of the calls at :278 and :287
+    orig = torch.rand_like
+    torch.rand_like = lambda t, *a, **k: draws.pop(0).clone()
+    try:
+        LeggedRobotDTC.compute_observations(m)
+    finally:
+        torch.rand_like = orig
+    assert not draws
+    LeggedRobotDTC.check_termination(m)
+    mean = torch.mean(m.root_states[:, 2].unsqueeze(1) - m.measured_heights[:, 210:483].clip(min=-0.), dim=1)
+    save("observations", obs=m.obs_buf.numpy(), priv_sample=m.privileged_obs_buf.numpy()[::32],
+         priv_sum=m.privileged_obs_buf.double().sum(dim=1).numpy(), heights_sample=m.heights.numpy()[::32],
+         reset=m.reset_buf.numpy().astype(np.uint8), time_out=m.time_out_buf.numpy().astype(np.uint8),
+         height_mean=mean.numpy(), base_height_target=np.array([cfg.rewards.base_height_target]))
+
+
 # ------------------------------------------------------------------------------------ config 5 composite
 def composite_case(N=16, seed=4):
     data, hid_a, hid_c = gru_case(N, seed)
@@ -477,7 +514,7 @@ def gen_composite():
     save("composite", **out)
 
 
-TASKS = dict(composite=gen_composite, gru=gen_gru, gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
+TASKS = dict(observations=gen_observations, composite=gen_composite, gru=gen_gru, gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
 
 if __name__ == "__main__":
     for t in (sys.argv[1:] or list(TASKS)):
