@@ -52,7 +52,8 @@ class FusedAdam:
         self.step_count = 0
         self.params = list(params)
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False,
-                                  maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)]
+                                  maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                                  decoupled_weight_decay=False)]     # the key set of torch 2.10's Adam
         names = {id(p): k for k, p in arena_named(arena)}
         self._inside = []          # (param position, arena offset, numel) of params inside the fused range
         for i, p in enumerate(self.params):

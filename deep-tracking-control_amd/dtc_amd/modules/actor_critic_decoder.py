@@ -374,6 +374,36 @@ class ActorCriticDecoder(nn.Module):
     def act_expert(self, ob):
         return self.act_teacher(ob["obs"], ob["obs_history"], ob["privileged_obs"])
 
+    def act_teacher(self, observations, observations_history, privileged_obs):
+        """actor_critic_decoder.py:504-538 (deployment path of `get_inference_policy(env_t=True)`): mean action from
+        latent_mu (no sampling) and the belief b_t = m + l_t * m, m = memory_mlp(cat[hist, l_t]).  `memory_mlp` never
+        receives a gradient in PPO.update, so this path runs on whatever weights the checkpoint holds."""
+        ar = self.ensure_arena()
+        obs, hist, priv = self._prep(observations), self._prep(observations_history), self._prep(privileged_obs)
+        B, dev = obs.shape[0], obs.device
+        ws, L = self._fwd_ws(B), self.L
+        if "mm0" not in L:
+            d = ar.dense
+            L.update(mm0=d("vae.memory_mlp.0.weight", "vae.memory_mlp.0.bias", "relu"),
+                     mm1=d("vae.memory_mlp.2.weight", "vae.memory_mlp.2.bias", "relu"),
+                     mm2=d("vae.memory_mlp.4.weight", "vae.memory_mlp.4.bias", None))
+        ops.linear_fwd(hist, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=B)
+        ops.linear_fwd(ws.e1, L["ce1"].W, L["ce1"].b, ws.e, None)
+        ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None)          # [:, :19] = latent_mu
+        self.terrain_encoder_(ws, priv)
+        m1, m2, m = (torch.empty(B, n, device=dev) for n in (L["mm0"].n_out, L["mm1"].n_out, L["mm2"].n_out))
+        ops.linear_fwd(segmat([seg(hist, 0, hist.shape[1]), seg(ws.lt, 0, 512)]), L["mm0"].W, L["mm0"].b, m1, "relu", M=B)
+        ops.linear_fwd(m1, L["mm1"].W, L["mm1"].b, m2, "relu")
+        ops.linear_fwd(m2, L["mm2"].W, L["mm2"].b, m, None)
+        b_t = m + ws.lt * m
+        X = segmat([seg(obs, 0, self.num_obs), seg(ws.mulv, 3, 16), seg(ws.mulv, 0, 3), seg(b_t, 0, 512)])
+        act = AC_Args.activation
+        ops.linear_fwd(X, L["a0"].W, L["a0"].b, ws.a1, act, M=B)
+        ops.linear_fwd(ws.a1, L["a1"].W, L["a1"].b, ws.a2, act)
+        ops.linear_fwd(ws.a2, L["a2"].W, L["a2"].b, ws.a3, act)
+        ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None)
+        return ws.mean.clone()
+
     def act_inference(self, ob):
         """Deterministic policy output (mean action) for deployment-style evaluation."""
         self.update_distribution(ob["obs"], ob["obs_history"], ob["privileged_obs"],

@@ -135,4 +135,6 @@ class OnPolicyRunner:
         self.alg.actor_critic.eval()
         if device is not None:
             self.alg.actor_critic.to(device)
+        if env_t == True:                      # noqa: E712  (on_policy_runner.py:269-272)
+            return self.alg.actor_critic.act_expert
         return self.alg.actor_critic.act_inference

@@ -91,6 +91,15 @@ class RefActorCriticDecoder(nn.Module):
         l_t = self.vae.terrain_encoder(priv[:, :N_HEIGHT])
         return self.actor_body(torch.cat((obs, z, mu[:, :3], l_t), dim=-1))
 
+    # actor_critic_decoder.py:504-538 (deployment path; `memory_mlp` never receives a gradient in PPO.update)
+    def act_teacher(self, obs, hist, priv):
+        vae = self.vae
+        latent = vae.latent_mu(vae.cenet_encoder(hist))
+        l_t = vae.terrain_encoder(priv[:, :N_HEIGHT])
+        b_t1 = vae.memory_mlp(torch.cat((hist, l_t), dim=-1))
+        b_t = b_t1 + torch.mul(l_t, b_t1)
+        return self.actor_body(torch.cat((obs, latent[:, 3:], latent[:, :3], b_t), dim=-1))
+
     # actor_critic_decoder.py:540-551
     def evaluate(self, obs, priv, base_vel):
         return self.critic_body(torch.cat((obs, base_vel, priv[:, 693:696], priv[:, 696:]), dim=-1))

@@ -396,6 +396,27 @@ def gen_gru():
     save("gru", **out)
 
 
+# ------------------------------------------------------------------------------------ f4: deployment path + checkpoint layout
+def gen_teacher():
+    """`ActorCriticDecoder.act_teacher` (actor_critic_decoder.py:504-538, reached through `act_expert` /
+    `get_inference_policy(env_t=True)`) at filled weights, and the layout of the checkpoint dictionary written by
+    `OnPolicyRunner.save` (on_policy_runner.py:249-255)."""
+    torch.set_num_threads(GOLDEN_THREADS)
+    alg = _ref_alg(64, seed_fill=11)
+    ac = alg.actor_critic
+    d = S.rollout(64, 24, seed=4)
+    obs, hist, priv = (d[k].flatten(0, 1)[:512] for k in ("observations", "observation_histories", "privileged_observations"))
+    with torch.no_grad():
+        mean = ac.act_expert(dict(obs=obs, obs_history=hist, privileged_obs=priv))
+    ckpt = {'model_state_dict': ac.state_dict(), 'optimizer_state_dict': alg.optimizer.state_dict(), 'iter': 7, 'infos': None}
+    osd = ckpt['optimizer_state_dict']
+    save("teacher", mean=mean.numpy(), ckpt_keys=np.array(list(ckpt.keys())),
+         model_keys=np.array(list(ckpt['model_state_dict'].keys())),
+         model_shapes=np.array([str(tuple(v.shape)) for v in ckpt['model_state_dict'].values()]),
+         opt_keys=np.array(list(osd.keys())), group_keys=np.array(sorted(osd['param_groups'][0].keys())),
+         n_group_params=np.array([len(osd['param_groups'][0]['params'])]))
+
+
 # ------------------------------------------------------------------------------------ f3: observations / termination
 def gen_observations():
     """`LeggedRobotDTC.compute_observations` and `.check_termination` (legged_robot_dtc.py:229-288) run as
@@ -514,7 +535,7 @@ def gen_composite():
     save("composite", **out)
 
 
-TASKS = dict(observations=gen_observations, composite=gen_composite, gru=gen_gru, gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
+TASKS = dict(teacher=gen_teacher, observations=gen_observations, composite=gen_composite, gru=gen_gru, gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
 
 if __name__ == "__main__":
     for t in (sys.argv[1:] or list(TASKS)):

@@ -366,3 +366,37 @@ def test_optimizer_state_dict_roundtrip_with_torch_adam():
 def jsonable(sd):
     return dict(state={k: {a: (b.cpu() if torch.is_tensor(b) else b) for a, b in v.items()} for k, v in sd["state"].items()},
                 param_groups=sd["param_groups"])
+
+
+def test_act_teacher_and_checkpoint_roundtrip(golden, tmp_path):
+    """f4: `act_expert` (deployment path through memory_mlp) vs the oracle, and OnPolicyRunner.save / load: the
+    dictionary has the reference's layout (tests/golden/teacher.npz) and restores model, optimiser and iteration."""
+    from dtc_amd.env import ReplayEnv
+    from dtc_amd.runners import OnPolicyRunner
+    g = golden("teacher")
+    ref, alg = _pair(64)
+    d = S.rollout(64, 24, seed=4)
+    obs, hist, priv = (d[k].flatten(0, 1)[:512] for k in ("observations", "observation_histories", "privileged_observations"))
+    with torch.no_grad():
+        want = ref.actor_critic.act_teacher(obs, hist, priv)
+    got = alg.actor_critic.act_expert(dict(obs=obs.to(DEV), obs_history=hist.to(DEV), privileged_obs=priv.to(DEV)))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(got.cpu().numpy(), g["mean"], rtol=1e-5, atol=2e-6)
+    cfg = dict(runner=dict(policy_class_name="ActorCriticDecoder", algorithm_class_name="PPO", num_steps_per_env=4,
+                           save_interval=10), algorithm=dict(learning_rate=1e-3), policy=dict())
+    r1 = OnPolicyRunner(ReplayEnv(32, DEV), cfg, log_dir=None, device=DEV)
+    r1.learn(2)
+    path = str(tmp_path / "model_2.pt")
+    r1.save(path, infos={"note": 1})
+    ck = torch.load(path, map_location="cpu")
+    assert list(ck.keys()) == [str(k) for k in g["ckpt_keys"]]
+    assert list(ck["model_state_dict"].keys()) == [str(k) for k in g["model_keys"]]
+    assert sorted(ck["optimizer_state_dict"].keys()) == sorted(str(k) for k in g["opt_keys"])
+    assert sorted(ck["optimizer_state_dict"]["param_groups"][0].keys()) == [str(k) for k in g["group_keys"]]
+    assert len(ck["optimizer_state_dict"]["param_groups"][0]["params"]) == int(g["n_group_params"][0])
+    torch.optim.Adam(ref.actor_critic.parameters()).load_state_dict(ck["optimizer_state_dict"])   # torch accepts it
+    r2 = OnPolicyRunner(ReplayEnv(32, DEV), cfg, log_dir=None, device=DEV)
+    assert r2.load(path) == {"note": 1} and r2.current_learning_iteration == 2
+    for (k, a), (_, b) in zip(r1.alg.actor_critic.state_dict().items(), r2.alg.actor_critic.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert r2.get_inference_policy(env_t=True) == r2.alg.actor_critic.act_expert

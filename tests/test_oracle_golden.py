@@ -239,3 +239,23 @@ def test_observations_and_termination_oracle_matches_reference(golden):
     assert knife.sum() == 0
     np.testing.assert_array_equal(reset.astype(np.uint8), g["reset"])
     assert 0 < reset.sum() < reset.size and time_out.sum() > 0
+
+
+def test_act_teacher_oracle_and_checkpoint_layout(golden):
+    """f4: deployment path act_teacher (actor_critic_decoder.py:504-538) and the model part of the checkpoint layout
+    of OnPolicyRunner.save (on_policy_runner.py:249-255)."""
+    from dtc_amd import synthetic as S
+    from dtc_amd.modules import ActorCriticDecoder
+    from oracle import ppo_ref as OP
+    g = golden("teacher")
+    torch.manual_seed(3)
+    ac = OP.fill_parameters_(OP.RefActorCriticDecoder(), 11)
+    d = S.rollout(64, 24, seed=4)
+    obs, hist, priv = (d[k].flatten(0, 1)[:512] for k in ("observations", "observation_histories", "privileged_observations"))
+    with torch.no_grad():
+        mean = ac.act_teacher(obs, hist, priv)
+    np.testing.assert_allclose(mean.numpy(), g["mean"], rtol=1e-5, atol=1e-6)
+    assert [str(k) for k in g["ckpt_keys"]] == ['model_state_dict', 'optimizer_state_dict', 'iter', 'infos']
+    mine = ActorCriticDecoder(53, 1389, 12).state_dict()
+    assert list(mine.keys()) == [str(k) for k in g["model_keys"]]
+    assert [str(tuple(v.shape)) for v in mine.values()] == [str(s) for s in g["model_shapes"]]
