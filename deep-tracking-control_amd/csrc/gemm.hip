@@ -49,6 +49,10 @@ constexpr int BK = DTC_BK;             // K step; loaders derive their geometry 
 constexpr int RP = 256 / BK;           // tile rows covered per loader pass of the k-contiguous operands
 constexpr int PAD = 4;
 
+// split partials: row n of a split holds dW[n, 0:K] and the bias-gradient partial at column K; rows are padded to a
+// multiple of 4 floats so that the reduction streams them with 16-byte loads
+__host__ __device__ __forceinline__ int part_ld(int K) { return (K + 1 + 3) & ~3; }
+
 struct SegDev {
     float* ptr;
     long long ld;
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
         mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
     }
 
-    const long long ldp = K + 1;
+    const long long ldp = part_ld(K);
     float* P = part + (long long)split * N * ldp;
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -507,25 +511,49 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
-                                                           float* __restrict__ db, int N, int K, int splits) {
-    const int ldp = K + 1;
+// Sum of the split partials in a FIXED order (deterministic): block = 64 float4 columns x G split groups; group g
+// adds splits g, g+G, g+2G, ... (4 loads in flight), the groups are then added in order 0..G-1 through LDS.
+template <int G>
+__global__ __launch_bounds__(64 * G) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
+                                                              float* __restrict__ db, int N, int K, int splits) {
+    __shared__ float4 red[G][64];
+    const int ldp = part_ld(K);
     const long long total = (long long)N * ldp;
     const int n = blockIdx.y;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ldp; c += gridDim.x * blockDim.x) {
-        const float* p = part + (long long)n * ldp + c;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        int s = 0;
-        for (; s + 4 <= splits; s += 4) {
-            v0 += p[(long long)s * total];
-            v1 += p[(long long)(s + 1) * total];
-            v2 += p[(long long)(s + 2) * total];
-            v3 += p[(long long)(s + 3) * total];
+    const int c4 = blockIdx.x * 64 + threadIdx.x;          // float4 column
+    const int g = threadIdx.y;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 * 4 < ldp) {
+        const float4* p = reinterpret_cast<const float4*>(part + (long long)n * ldp) + c4;
+        const long long step = total / 4;
+        int s = g;
+        for (; s + 3 * G < splits; s += 4 * G) {
+            const float4 v0 = p[(long long)s * step], v1 = p[(long long)(s + G) * step];
+            const float4 v2 = p[(long long)(s + 2 * G) * step], v3 = p[(long long)(s + 3 * G) * step];
+            acc.x = (((acc.x + v0.x) + v1.x) + v2.x) + v3.x;
+            acc.y = (((acc.y + v0.y) + v1.y) + v2.y) + v3.y;
+            acc.z = (((acc.z + v0.z) + v1.z) + v2.z) + v3.z;
+            acc.w = (((acc.w + v0.w) + v1.w) + v2.w) + v3.w;
         }
-        for (; s < splits; ++s) v0 += p[(long long)s * total];
-        const float v = (v0 + v1) + (v2 + v3);
-        if (c < K) dW[(long long)n * K + c] = v;
-        else if (db) db[n] = v;
+        for (; s < splits; s += G) {
+            const float4 v = p[(long long)s * step];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[g][threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && c4 * 4 < ldp) {
+        for (int j = 1; j < G; ++j) {
+            const float4 v = red[j][threadIdx.x];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const float out[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c4 * 4 + i;
+            if (c < K) dW[(long long)n * K + c] = out[i];
+            else if (c == K && db) db[n] = out[i];
+        }
     }
 }
 
@@ -644,13 +672,14 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
 
 extern "C" int64_t dtc_linear_wgrad_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return (int64_t)wgrad_splits_bound(M, N, K) * N * (K + 1) * (int64_t)sizeof(float);
+    return (int64_t)wgrad_splits_bound(M, N, K) * N * part_ld(K) * (int64_t)sizeof(float);
 }
 
 extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* X, float* dW, float* db, void* workspace,
                                 int M, int N, int K, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
     DTC_REQUIRE(dZ && dW && workspace, "null pointer");
+    DTC_REQUIRE(dtc::aligned16(workspace), "wgrad workspace must be 16-byte aligned");
     DTC_REQUIRE((long long)M * lddz <= MAX_ELEMS, "matrix too large");
     SegMatDev xd;
     int rc = to_dev(X, xd, K, false, M);
@@ -672,10 +701,14 @@ extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* 
         else hipLaunchKernelGGL(linear_wgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split, col_tiles);
     }
     {
-        const long long total = (long long)N * (K + 1);
+        const long long total = (long long)N * part_ld(K);
         dtc::ProfScope prof(dtc::prof_shape_name("wgrad_reduce", splits, N, K), (double)total * 4.0 * (splits + 1), s);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dtc::ceil_div(K + 1, 256), (unsigned)N), dim3(256), 0, s,
-                           part, dW, db, N, K, splits);
+        const dim3 grid((unsigned)dtc::ceil_div(part_ld(K) / 4, 64), (unsigned)N);
+        // more split groups when the output is small (few blocks): the sum over splits is then the latency chain
+        if (total >= (1 << 17) || splits <= 16)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<4>, grid, dim3(64, 4), 0, s, part, dW, db, N, K, splits);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel<16>, grid, dim3(64, 16), 0, s, part, dW, db, N, K, splits);
     }
     return dtc::check_launch("linear_wgrad");
 }

@@ -90,7 +90,7 @@ extern "C" int64_t dtc_gru_workspace(int T, int R, int H) {
     if (T <= 0 || R <= 0 || H <= 0) return 0;
     const int64_t a = (int64_t)R * 3 * H * sizeof(float);
     const int64_t b = (int64_t)T * R * 3 * H * sizeof(float);
-    return a + b + dtc_linear_wgrad_workspace(T * R, 3 * H, H);
+    return a + b + 16 + dtc_linear_wgrad_workspace(T * R, 3 * H, H);     // +16: the partials start 16-byte aligned
 }
 
 extern "C" int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, const float* b_hh, float* hs_all,
@@ -125,7 +125,7 @@ extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* g
     hipStream_t s = (hipStream_t)stream;
     const size_t RH = (size_t)R * H, R3H = (size_t)R * 3 * H;
     float* dgh_all = (float*)workspace + R3H;
-    void* wg_ws = (void*)(dgh_all + (size_t)T * R3H);
+    void* wg_ws = (void*)(((uintptr_t)(dgh_all + (size_t)T * R3H) + 15) & ~(uintptr_t)15);
     if (hipMemsetAsync(dh0, 0, RH * sizeof(float), s) != hipSuccess) {
         dtc::set_error("gru_bwd: memset failed");
         return DTC_ERR_LAUNCH;
