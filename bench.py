@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="decoder", choices=["decoder", "composite"],
+                    help="decoder = BASELINE configs[1] (the headline, default); composite = configs[4]'s model "
+                         "(GRU + CE-net + foothold obs, build-defined) on the same rollout shapes -- informative only")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,17 +89,21 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from dtc_amd import _ffi, foothold, synthetic as S
-    from dtc_amd.algorithms import PPO
-    from dtc_amd.modules import ActorCriticDecoder
+    from dtc_amd.algorithms import PPO, RecurrentDecoderPPO
+    from dtc_amd.modules import ActorCriticDecoder, ActorCriticDecoderRecurrent
 
     torch.manual_seed(3)                      # identical initial weights on every rank
-    ac = ActorCriticDecoder(53, 1389, 12)
-    alg = PPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
+    composite = a.workload == "composite"
+    ac = (ActorCriticDecoderRecurrent if composite else ActorCriticDecoder)(53, 1389, 12)
+    alg = (RecurrentDecoderPPO if composite else PPO)(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
     alg.init_storage(NUM_ENVS, NUM_STEPS, [53], [1389], [265], [12])
     data = S.rollout(NUM_ENVS, NUM_STEPS, seed=4 + rank, device=dev)
     for k, v in data.items():
         if k != "last_values":
             getattr(alg.storage, k).copy_(v)
+    if composite:                             # recorded GRU states at every (step, env): the storage's saved_hidden_states
+        g = torch.Generator(device=dev).manual_seed(77 + rank)
+        hid = [0.1 * torch.randn(NUM_STEPS, 1, NUM_ENVS, 512, generator=g, device=dev) for _ in range(2)]
     # recorded planner inputs of the same rollout: one height map per (step, env)
     sc = S.scorer_inputs(NUM_ENVS * NUM_STEPS, seed=7 + rank, device=dev)
     last = {k: data[k][-1] for k in ("observations", "privileged_observations", "base_vel")}
@@ -106,6 +113,8 @@ def main():
         foothold.plan(sc["measured_heights"], sc["root_states"], sc["thigh_pos"], sc["commands"])
         alg.compute_returns(last["observations"], last["privileged_observations"], last["base_vel"])
         alg.storage.step = NUM_STEPS
+        if composite:
+            alg.storage.saved_hidden_states_a, alg.storage.saved_hidden_states_c = [hid[0]], [hid[1]]
         return alg.update()
 
     def fence():
@@ -147,6 +156,7 @@ def main():
         rep = _ffi.prof_report()
         lib.dtc_prof_reset()
         gemm = [r for r in rep if r["name"].split("[")[0] in ("linear_fwd", "linear_dgrad", "linear_wgrad")]
+        # (the composite's GRU steps call the same three kernels from inside dtc_gru_fwd / dtc_gru_bwd)
         ms = sum(r["ms_total"] for r in gemm)
         fl = sum(r["work"] for r in gemm)
         n_launch = sum(r["launches"] for r in gemm)
@@ -167,12 +177,17 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 4096 envs x 24 steps per GPU, ActorCriticDecoder (CE-net + "
-                                   "terrain encoder latent 512 + MLP actor/critic): foothold planner over the 98304 "
-                                   "recorded height maps + compute_returns + PPO.update (5 epochs x 4 mini-batches of 24576)",
+            "config": {"workload": ("BASELINE configs[1]: 4096 envs x 24 steps per GPU, ActorCriticDecoder (CE-net + "
+                                    "terrain encoder latent 512 + MLP actor/critic): foothold planner over the 98304 "
+                                    "recorded height maps + compute_returns + PPO.update (5 epochs x 4 mini-batches of 24576)")
+                       if not composite else
+                       ("BASELINE configs[4] model (build-defined GRU + CE-net + foothold obs composite), 4096 envs x 24 "
+                        "steps per GPU: planner over 98304 maps + compute_returns + RecurrentDecoderPPO.update (5 epochs x "
+                        "4 recurrent mini-batches of 1024 envs x 24 steps, BPTT)"),
                        "num_envs_per_gpu": NUM_ENVS, "num_steps_per_env": NUM_STEPS, "mini_batch": 24576,
                        "epochs": 5, "wgrad_overlap_stream": bool(alg.overlap_wgrad), "parallelism": f"dp{world}" if world > 1 else "single",
-                       "mfma_frac_whole_step": (FLOP_PER_ENV_STEP * value / world) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
+                       "mfma_frac_whole_step": None if composite else
+                       (FLOP_PER_ENV_STEP * value / world) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
             "roofline": roof,
             "kernel_classes": classes,
             "last_update": [float(x) for x in out],

@@ -600,15 +600,19 @@ int pick_bn(int cols) {
 }
 
 // fwd / dgrad: 128x64 tiles measured faster than 128x128 at every layer width of this model (twice the
-// workgroups -> prologue / epilogue of one block overlap the MFMA phase of its neighbours, 4 waves/SIMD)
-int pick_bn_rows(int cols) {
+// workgroups -> prologue / epilogue of one block overlap the MFMA phase of its neighbours, 4 waves/SIMD);
+// when even those leave the chip short of workgroups (narrow layers, the ~1500-row GEMMs of one GRU time
+// step) 128x32 tiles double the count again
+int pick_bn_rows(int rows, int cols) {
     static const char* force = getenv("DTC_GEMM_BN");
     if (force && cols > 64) return atoi(force);
-    return cols <= 32 ? 32 : 64;
+    if (cols <= 32) return 32;
+    static const char* thr_env = getenv("DTC_GEMM_MIN_BLOCKS");
+    const long long min_blocks = thr_env ? atoi(thr_env) : 320;     // measured: tools/jobs/job20.sh
+    return dtc::ceil_div(rows, BM) * dtc::ceil_div(cols, 64) >= min_blocks ? 64 : 32;
 }
 
-// Batch splits of the weight gradient: whole splits per XCD (multiple of 8), as many as keep all blocks
-// co-resident in ONE wave of workgroups (256 CUs x 4 blocks): a few blocks past that run alone at the end.
+// wgrad split heuristic -------------------------------------------------------------------------------------
 int wgrad_splits(int M, int tiles) {
     static const char* target_env = getenv("DTC_WGRAD_BLOCKS");
     const int target = target_env ? atoi(target_env) : 1024;
@@ -639,7 +643,7 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     int rc = to_dev(X, xd, K, false, M);
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int bn = pick_bn_rows(N);
+    const int bn = pick_bn_rows(M, N);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, bn));
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s);
     if (bn == 128) hipLaunchKernelGGL(linear_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
@@ -661,7 +665,7 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
     int rc = to_dev(dX, xd, K, true, 0);
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int bn = pick_bn_rows(K);
+    const int bn = pick_bn_rows(M, K);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K, bn));
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * K, s);
     if (bn == 128) hipLaunchKernelGGL(linear_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act);

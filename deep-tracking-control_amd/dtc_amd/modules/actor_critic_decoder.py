@@ -294,6 +294,7 @@ class ActorCriticDecoder(nn.Module):
 
     def critic_input(self, obs, base_vel, priv, idx=None):
         g = idx is not None
+        # cat[obs, base_vel, priv[:, 693:696], priv[:, 696:]] -- the last two are adjacent columns of `priv`
         return segmat([seg(obs, 0, self.num_obs, gather=g), seg(base_vel, 0, 3, gather=g),
                        seg(priv, 693, 696, gather=g)], idx)
 
