@@ -45,26 +45,30 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
     const int blk = blockIdx.x;
     double acc0 = 0.0, acc1 = 0.0;
     int slot0 = 3, slot1 = -1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (blk < nb_h) {
-        const long long total = (long long)B * HGT;
+        // one wavefront per batch row: the gather index is a scalar, no per-element division, 64 consecutive floats
+        // per load instruction
         const float scale = 2.0f / ((float)HGT * (float)B);
-        for (long long e = (long long)blk * 256 + threadIdx.x; e < total; e += (long long)nb_h * 256) {
-            const long long b = e / HGT;
-            const int c = (int)(e - b * HGT);
-            const float diff = hrecon[e] - priv[idx[b] * PRIV + (HGT + 3) + c];
-            acc0 += (double)diff * (double)diff;
-            d_hrecon[e] = diff * scale;
+        for (int b = blk * 4 + wv; b < B; b += nb_h * 4) {
+            const float* src = priv + idx[b] * PRIV + (HGT + 3);
+            const float* hr = hrecon + (long long)b * HGT;
+            float* dh = d_hrecon + (long long)b * HGT;
+            for (int c = lane; c < HGT; c += 64) {
+                const float diff = hr[c] - src[c];
+                acc0 += (double)diff * (double)diff;
+                dh[c] = diff * scale;
+            }
         }
         slot0 = 3;
     } else if (blk < nb_h + nb_r) {
-        const long long total = (long long)B * OBS;
         const float scale = 2.0f / ((float)OBS * (float)B);
-        for (long long e = (long long)(blk - nb_h) * 256 + threadIdx.x; e < total; e += (long long)nb_r * 256) {
-            const long long b = e / OBS;
-            const int c = (int)(e - b * OBS);
-            const float diff = recons[e] - next_obs[idx[b] * OBS + c];
-            acc0 += (double)diff * (double)diff;
-            d_recons[e] = diff * scale;
+        for (int b = (blk - nb_h) * 4 + wv; b < B; b += nb_r * 4) {
+            if (lane < OBS) {
+                const float diff = recons[(long long)b * OBS + lane] - next_obs[idx[b] * OBS + lane];
+                acc0 += (double)diff * (double)diff;
+                d_recons[(long long)b * OBS + lane] = diff * scale;
+            }
         }
         slot0 = 0;
     } else {
@@ -280,8 +284,8 @@ extern "C" int dtc_vae_loss(const float* recons, const float* hrecon, const floa
     DTC_REQUIRE(recons && hrecon && mulv && next_obs && priv && base_vel && idx, "null input");
     DTC_REQUIRE(d_recons && d_hrecon && dmulv && losses && workspace, "null output");
     hipStream_t s = (hipStream_t)stream;
-    int nb_h = (int)dtc::ceil_div((long long)B * HGT, 256 * 8);
-    int nb_r = (int)dtc::ceil_div((long long)B * OBS, 256 * 8);
+    int nb_h = (int)dtc::ceil_div(B, 4 * 3);          // 4 rows per block pass, ~3 passes
+    int nb_r = (int)dtc::ceil_div(B, 4 * 16);
     const int nb_l = (int)dtc::ceil_div(B, 256);
     if (nb_h > 2048) nb_h = 2048;
     if (nb_r > 512) nb_r = 512;
