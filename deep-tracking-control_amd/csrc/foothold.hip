@@ -75,7 +75,11 @@ __device__ __forceinline__ float div_const(float x, float c, float inv) {
     const float q0 = x * inv;
     const float r = __builtin_fmaf(-q0, c, x);
     float q = __builtin_fmaf(r, inv, q0);
-    if (fabsf(x) < 1e-30f) q = x / c;
+    // tiny NON-ZERO numerators (never produced by heights quantised to 5 mm) take the IEEE division; the test is a
+    // wave-level vote so that the ~13-instruction division is branched over, not if-converted into every call.
+    // x = +-0 stays on the fast path: it yields +-0 / +0, which every consumer squares.
+    const bool tiny = fabsf(x) < 1e-30f && x != 0.0f;
+    if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) q = tiny ? x / c : q;
     return q;
 }
 
