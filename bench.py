@@ -72,9 +72,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="decoder", choices=["decoder", "composite"],
+    ap.add_argument("--workload", default="decoder", choices=["decoder", "composite", "gru"],
                     help="decoder = BASELINE configs[1] (the headline, default); composite = configs[4]'s model "
-                         "(GRU + CE-net + foothold obs, build-defined) on the same rollout shapes -- informative only")
+                         "(GRU + CE-net + foothold obs, build-defined); gru = configs[2] (ActorCriticRecurrent, GRU 512, BPTT); "
+                         "both on the same rollout shapes -- informative only")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,19 +90,25 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from dtc_amd import _ffi, foothold, synthetic as S
-    from dtc_amd.algorithms import PPO, RecurrentDecoderPPO
-    from dtc_amd.modules import ActorCriticDecoder, ActorCriticDecoderRecurrent
+    from dtc_amd.algorithms import PPO, RecurrentDecoderPPO, RecurrentPPO
+    from dtc_amd.modules import ActorCriticDecoder, ActorCriticDecoderRecurrent, ActorCriticRecurrent
 
     torch.manual_seed(3)                      # identical initial weights on every rank
-    composite = a.workload == "composite"
-    ac = (ActorCriticDecoderRecurrent if composite else ActorCriticDecoder)(53, 1389, 12)
-    alg = (RecurrentDecoderPPO if composite else PPO)(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
-    alg.init_storage(NUM_ENVS, NUM_STEPS, [53], [1389], [265], [12])
+    composite, gru = a.workload == "composite", a.workload == "gru"
+    if gru:
+        ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+                                  activation='elu', rnn_type='gru', rnn_hidden_size=512, rnn_num_layers=1)
+        alg = RecurrentPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
+        alg.init_storage(NUM_ENVS, NUM_STEPS, [53], [1389], [12])
+    else:
+        ac = (ActorCriticDecoderRecurrent if composite else ActorCriticDecoder)(53, 1389, 12)
+        alg = (RecurrentDecoderPPO if composite else PPO)(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
+        alg.init_storage(NUM_ENVS, NUM_STEPS, [53], [1389], [265], [12])
     data = S.rollout(NUM_ENVS, NUM_STEPS, seed=4 + rank, device=dev)
     for k, v in data.items():
-        if k != "last_values":
+        if k != "last_values" and not (gru and k == "observation_histories"):
             getattr(alg.storage, k).copy_(v)
-    if composite:                             # recorded GRU states at every (step, env): the storage's saved_hidden_states
+    if composite or gru:                             # recorded GRU states at every (step, env): the storage's saved_hidden_states
         g = torch.Generator(device=dev).manual_seed(77 + rank)
         hid = [0.1 * torch.randn(NUM_STEPS, 1, NUM_ENVS, 512, generator=g, device=dev) for _ in range(2)]
     # recorded planner inputs of the same rollout: one height map per (step, env)
@@ -111,9 +118,12 @@ def main():
 
     def step():
         foothold.plan(sc["measured_heights"], sc["root_states"], sc["thigh_pos"], sc["commands"])
-        alg.compute_returns(last["observations"], last["privileged_observations"], last["base_vel"])
+        if gru:
+            alg.compute_returns(last["privileged_observations"])
+        else:
+            alg.compute_returns(last["observations"], last["privileged_observations"], last["base_vel"])
         alg.storage.step = NUM_STEPS
-        if composite:
+        if composite or gru:
             alg.storage.saved_hidden_states_a, alg.storage.saved_hidden_states_c = [hid[0]], [hid[1]]
         return alg.update()
 
@@ -143,7 +153,7 @@ def main():
     roof, classes = None, None
     if rank == 0:
         lib = _ffi.lib()
-        overlap = alg.overlap_wgrad
+        overlap = getattr(alg, "overlap_wgrad", False)
         alg.overlap_wgrad = False
         step()
         torch.cuda.synchronize()
@@ -180,13 +190,15 @@ def main():
             "config": {"workload": ("BASELINE configs[1]: 4096 envs x 24 steps per GPU, ActorCriticDecoder (CE-net + "
                                     "terrain encoder latent 512 + MLP actor/critic): foothold planner over the 98304 "
                                     "recorded height maps + compute_returns + PPO.update (5 epochs x 4 mini-batches of 24576)")
-                       if not composite else
+                       if not (composite or gru) else
+                       ("BASELINE configs[2]: ActorCriticRecurrent (GRU hidden 512), 4096 envs x 24 steps: planner + compute_returns "
+                        "+ RecurrentPPO.update (5 epochs x 4 recurrent mini-batches of 1024 envs x 24 steps, BPTT)") if gru else
                        ("BASELINE configs[4] model (build-defined GRU + CE-net + foothold obs composite), 4096 envs x 24 "
                         "steps per GPU: planner over 98304 maps + compute_returns + RecurrentDecoderPPO.update (5 epochs x "
                         "4 recurrent mini-batches of 1024 envs x 24 steps, BPTT)"),
                        "num_envs_per_gpu": NUM_ENVS, "num_steps_per_env": NUM_STEPS, "mini_batch": 24576,
-                       "epochs": 5, "wgrad_overlap_stream": bool(alg.overlap_wgrad), "parallelism": f"dp{world}" if world > 1 else "single",
-                       "mfma_frac_whole_step": None if composite else
+                       "epochs": 5, "wgrad_overlap_stream": bool(getattr(alg, "overlap_wgrad", False)), "parallelism": f"dp{world}" if world > 1 else "single",
+                       "mfma_frac_whole_step": None if (composite or gru) else
                        (FLOP_PER_ENV_STEP * value / world) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
             "roofline": roof,
             "kernel_classes": classes,

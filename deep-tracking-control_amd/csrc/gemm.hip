@@ -285,12 +285,21 @@ template <int BN>
 __global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __restrict__ dZ, long long lddz,
                                                            const float* __restrict__ W, const SegMatDev dX,
                                                            const float* __restrict__ Xs, long long ldxs, int M, int N,
-                                                           int K, int act) {
+                                                           int K, int act, int split_n, long long split_dst) {
     using C = Cfg<BN>;
     __shared__ float As[2][BK][C::LDA];
     __shared__ float Bs[2][BK][C::LDB];
     int tr, tc;
     if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (K + BN - 1) / BN, tr, tc)) return;
+    // split reduction (dtc_linear_dgrad_split): grid.y = chunk g of the reduction index; chunk g multiplies columns
+    // [g*split_n, (g+1)*split_n) of dZ with the matching rows of W and writes its own destination matrix
+    long long dst_off = 0;
+    if (split_n > 0) {
+        dZ += (long long)blockIdx.y * split_n;
+        W += (long long)blockIdx.y * split_n * K;
+        N = split_n;
+        dst_off = (long long)blockIdx.y * split_dst;
+    }
     const int m0 = tr * BM, c0 = tc * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __res
         const bool cok = col < K;
         const SegDev sd = dX.s[find_seg(dX, cok ? col : 0)];
         const bool live = cok && sd.ptr != nullptr;
-        float* dst = sd.ptr + sd.col0 + (col - sd.start);
+        float* dst = sd.ptr + dst_off + sd.col0 + (col - sd.start);
 #pragma unroll
         for (int i = 0; i < C::TM; ++i) {
             const int row0 = m0 + wm_off + 32 * i + 4 * half;
@@ -668,10 +677,33 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
     const int bn = pick_bn_rows(M, K);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K, bn));
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * K, s);
-    if (bn == 128) hipLaunchKernelGGL(linear_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act);
-    else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act);
-    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act);
+    if (bn == 128) hipLaunchKernelGGL(linear_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll);
+    else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll);
     return dtc::check_launch("linear_dgrad");
+}
+
+extern "C" int dtc_linear_dgrad_split(const float* dZ, int64_t lddz, const float* W, float* dX, int64_t lddx,
+                                      int64_t split_stride, int M, int N, int K, int nsplit, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && nsplit >= 1 && N % nsplit == 0 && lddz >= N && lddx >= K, "bad shape");
+    DTC_REQUIRE(dZ && W && dX, "null pointer");
+    DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * lddz <= MAX_ELEMS, "matrix too large");
+    SegMatDev xd;
+    xd.nseg = 1;
+    xd.cols = K;
+    xd.idx = nullptr;
+    for (int i = 0; i < 4; ++i) xd.s[i] = SegDev{nullptr, 0, 0, 0x7fffffff, 0, 0, 0};
+    xd.s[0] = SegDev{dX, (long long)lddx, 0, 0, K, 0, 0};
+    hipStream_t s = (hipStream_t)stream;
+    const int chunk = N / nsplit;
+    // tile width from the work of ALL chunks (they run side by side in one launch)
+    const int row_tiles = (int)dtc::ceil_div(M, BM);
+    const int bn = (K <= 32 || (long long)row_tiles * dtc::ceil_div(K, 64) * nsplit < 320) ? 32 : 64;
+    const dim3 grid((unsigned)grid_for(row_tiles, (int)dtc::ceil_div(K, bn)), (unsigned)nsplit);
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * K, s);
+    if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride);
+    return dtc::check_launch("linear_dgrad_split");
 }
 
 extern "C" int64_t dtc_linear_wgrad_workspace(int M, int N, int K) {

@@ -9,7 +9,10 @@
 //   forward  t = 0..T-1 : gh = h_{t-1} W_hh^T + b_hh        (dtc_linear_fwd, M = R, N = 3H, K = H)
 //                         gates + state update              (gru_gate_fwd_kernel, fused, saves r,z,n and gh_n)
 //   backward t = T-1..0 : gate derivatives                  (gru_gate_bwd_kernel: dgi_t, dgh_t, dh*z)
-//                         dh_{t-1} += dgh_t W_hh            (dtc_linear_dgrad, accumulate)
+//                         dh_{t-1} += dgh_t W_hh            (dtc_linear_dgrad_split: the 3H-long reduction runs as three
+//                                                            H-long chunks side by side -- one step has only ~12 row
+//                                                            tiles -- and the next gate kernel adds the three partial
+//                                                            products in a fixed order)
 //            after loop : dW_hh, db_hh = [dgh_0..dgh_{T-1}]^T [h_{-1}..h_{T-2}]   (ONE dtc_linear_wgrad over T*R rows)
 // The input projection gi = x W_ih^T + b_ih (all T*R rows at once) and its weight gradient are plain
 // dtc_linear_fwd / dtc_linear_wgrad calls made by the caller.  Padded steps need no masks: their output
@@ -44,19 +47,24 @@ __global__ __launch_bounds__(256) void gru_gate_fwd_kernel(const float* __restri
     hn[e] = ghn;
 }
 
-// dh (in/out): on entry the gradient flowing into h_t from step t+1 (zero at t = T-1); dhs_t is added here.
-// On exit dh holds dh_t * z (the direct path to h_{t-1}); the W_hh path is added by the following dgrad.
+// dh (in/out): on entry the direct part (dh_{t+1} * z_{t+1}) of the gradient flowing into h_t from step t+1 (zero at
+// t = T-1); `part` holds the three chunks of its W_hh part (dgh_{t+1} W_hh, NULL at t = T-1); dhs_t is added here.
+// On exit dh holds dh_t * z (the direct path to h_{t-1}); the W_hh path is produced by the following split dgrad.
 __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restrict__ dhs_t, float* __restrict__ dh,
-                                                           const float* __restrict__ gates, const float* __restrict__ hn,
-                                                           const float* __restrict__ hprev, float* __restrict__ dgi,
-                                                           float* __restrict__ dgh, int R, int H) {
+                                                           const float* __restrict__ part, const float* __restrict__ gates,
+                                                           const float* __restrict__ hn, const float* __restrict__ hprev,
+                                                           float* __restrict__ dgi, float* __restrict__ dgh, int R, int H) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long long)R * H) return;
     const long long row = e / H;
     const int j = (int)(e - row * H);
     const float* g = gates + row * 3 * H;
     const float r = g[j], z = g[H + j], n = g[2 * H + j];
-    const float d = dhs_t[e] + dh[e];
+    float d = dhs_t[e] + dh[e];
+    if (part) {
+        const long long rh = (long long)R * H;
+        d = ((d + part[e]) + part[rh + e]) + part[2 * rh + e];
+    }
     const float ghn = hn[e];
     const float dn = d * (1.0f - z);
     const float dz = d * (hprev[e] - n);
@@ -72,6 +80,12 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restri
     gh_o[H + j] = da_z;
     gh_o[2 * H + j] = da_n * r;
     dh[e] = d * z;
+}
+
+// dh0 <- dh0 + the three chunks of the last W_hh product
+__global__ __launch_bounds__(256) void gru_add_parts_kernel(float* __restrict__ dh, const float* __restrict__ part, long long rh) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < rh) dh[e] = ((dh[e] + part[e]) + part[rh + e]) + part[2 * rh + e];
 }
 
 DtcSegMat plain(const float* p, int64_t ld, int cols) {
@@ -131,19 +145,19 @@ extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* g
         return DTC_ERR_LAUNCH;
     }
     const unsigned grid = (unsigned)dtc::ceil_div((int64_t)RH, 256);
-    DtcSegMat dst = plain(dh0, H, H);
-    dst.seg[0].accumulate = 1;
+    float* part = (float*)workspace;              // [3][R][H]: the region dtc_gru_fwd uses for gh
     for (int t = T - 1; t >= 0; --t) {
         float* dgh_t = dgh_all + (size_t)t * R3H;
         {
-            dtc::ProfScope prof("gru_gate_bwd", (double)RH * 4.0 * 14, s);
+            dtc::ProfScope prof("gru_gate_bwd", (double)RH * 4.0 * 17, s);
             hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(grid), dim3(256), 0, s, dhs + (size_t)t * RH, dh0,
-                               gates + (size_t)t * R3H, hn + (size_t)t * RH, hs_all + (size_t)t * RH,
-                               dgi + (size_t)t * R3H, dgh_t, R, H);
+                               t == T - 1 ? (const float*)nullptr : (const float*)part, gates + (size_t)t * R3H,
+                               hn + (size_t)t * RH, hs_all + (size_t)t * RH, dgi + (size_t)t * R3H, dgh_t, R, H);
         }
-        int rc = dtc_linear_dgrad(dgh_t, 3 * H, W_hh, &dst, nullptr, 0, R, 3 * H, H, DTC_ACT_NONE, stream);
+        int rc = dtc_linear_dgrad_split(dgh_t, 3 * H, W_hh, part, H, (int64_t)RH, R, 3 * H, H, 3, stream);
         if (rc != DTC_OK) return rc;
     }
+    hipLaunchKernelGGL(gru_add_parts_kernel, dim3(grid), dim3(256), 0, s, dh0, part, (long long)RH);
     const DtcSegMat Hprev = plain(hs_all, H, H);
     int rc = dtc_linear_wgrad(dgh_all, 3 * H, &Hprev, dW_hh, db_hh, wg_ws, T * R, 3 * H, H, stream);
     if (rc != DTC_OK) return rc;

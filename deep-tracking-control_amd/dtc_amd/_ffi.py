@@ -85,6 +85,8 @@ _SIGS = {
                                  C.c_int, c_stream]),
     "dtc_linear_dgrad": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_int,
                                    C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_linear_dgrad_split": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, c_stream]),
     "dtc_linear_wgrad_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dtc_linear_wgrad": (C.c_int, [c_f32p, C.c_int64, C.POINTER(DtcSegMat), c_f32p, c_f32p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, c_stream]),

@@ -176,6 +176,13 @@ int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b, float* Y,
  * layer, leading dimension ldxs) may be NULL when act == DTC_ACT_NONE. */
 int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX,
                      const float* Xsaved, int64_t ldxs, int M, int N, int K, int act, void* stream);
+/* Data gradient with the reduction index split into `nsplit` equal chunks that run side by side in ONE launch
+ * (for GEMMs with few rows, e.g. one GRU time step: M ~ 1500, N = 3H): chunk g computes
+ * dX + g*split_stride [M,K] (row stride lddx) = dZ[:, g*N/nsplit : (g+1)*N/nsplit] W[g*N/nsplit : (g+1)*N/nsplit, :];
+ * no activation, no accumulation -- the caller adds the chunks in a fixed order (deterministic). */
+int dtc_linear_dgrad_split(const float* dZ, int64_t lddz, const float* W, float* dX, int64_t lddx, int64_t split_stride,
+                           int M, int N, int K, int nsplit, void* stream);
+
 /* dW[N,K] = dZ^T X, db[N] = column sums of dZ.  workspace: >= dtc_linear_wgrad_workspace() bytes. */
 int64_t dtc_linear_wgrad_workspace(int M, int N, int K);
 int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* X, float* dW, float* db,
