@@ -108,32 +108,12 @@ def arena_named(arena):
     return [(k, p) for k, p in arena._named]
 
 
-class _TrainWorkspace:
-    """Activation / gradient buffers of one mini-batch step (allocated once per batch size).
+class _Lanes:
+    """Streams of one optimisation step: `main` (torch's current stream), `aux` = a second compute lane for the branch
+    of the layer graph that is independent of the one on main, `side` = weight gradients.  `order(a, b)` is the only
+    synchronisation primitive: everything launched so far on lane a happens before what lane b launches next."""
 
-    Every layer's input-gradient gets its OWN buffer (`g(name, width)`): the weight gradients run on a side
-    stream concurrently with the data-gradient chain (see PPO._bwd), so a buffer that a later layer's dgrad
-    would overwrite may still be being read.  26 buffers x B x <=693 floats ~ 1 GB at B = 24576."""
-
-    def __init__(self, B, dev, num_actions):
-        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        self.B, self._dev = B, dev
-        # VAE-only forward activations
-        self.c1, self.c2, self.rec = e(B, 64), e(B, 128), e(B, 53)
-        self.d1, self.d2, self.hr = e(B, 512), e(B, 512), e(B, 693)
-        # loss gradients
-        self.g_rec, self.g_hr = e(B, 53), e(B, 693)
-        self.dlt = e(B, 512)
-        self.dmulv, self.dz = e(B, 35), e(B, 16)
-        self.dmean, self.dval = e(B, num_actions), e(B, 1)
-        self._g = {}
-        lib = _ffi.lib()
-        shapes = [(512, 693), (512, 512), (693, 512), (512, 584), (512, 752), (256, 512), (128, 256), (64, 531),
-                  (128, 64), (53, 128), (128, 265), (64, 128), (35, 64), (num_actions, 128), (1, 128)]
-        self.wg = ops.workspace(max(lib.dtc_linear_wgrad_workspace(B, n, k) for n, k in shapes), dev)
-        self.loss_ws = ops.workspace(lib.dtc_loss_workspace(B), dev)
-        # streams: `side` runs the weight gradients, `aux` is a second compute lane for the branch of the
-        # layer graph that is independent of the one on the main stream (CE-net vs terrain encoder, critic vs actor)
+    def __init__(self, dev):
         self.side = torch.cuda.Stream(device=dev)
         self.aux = torch.cuda.Stream(device=dev)
         self.main = None                    # torch's current stream at the start of the step
@@ -141,20 +121,6 @@ class _TrainWorkspace:
         self._events, self._ev_next = [], 0
         self.joined = torch.cuda.Event()
         self.side_busy = False
-
-    def wgrad_ws(self, N, K):
-        """Split-partials workspace, grown on demand (rare: first use of a larger layer shape)."""
-        need = ops.wgrad_workspace_bytes(self.B, N, K)
-        if self.wg.numel() * self.wg.element_size() < need:
-            torch.cuda.synchronize()            # nothing may still be reading the buffer being replaced
-            self.wg = ops.workspace(need, self._dev)
-        return self.wg
-
-    def g(self, name, width):
-        t = self._g.get(name)
-        if t is None:
-            t = self._g[name] = torch.empty(self.B, width, dtype=torch.float32, device=self._dev)
-        return t
 
     def begin(self, two_lanes):
         self.main = torch.cuda.current_stream()
@@ -172,7 +138,6 @@ class _TrainWorkspace:
         return contextlib.nullcontext()
 
     def order(self, src, dst):
-        """Everything launched so far on lane `src` happens before whatever lane `dst` launches next."""
         if not self.two_lanes or src == dst:
             return
         ev = self.event()
@@ -185,6 +150,56 @@ class _TrainWorkspace:
         ev = self._events[self._ev_next]
         self._ev_next += 1
         return ev
+
+    def join(self):
+        """Main waits for the second lane and for every weight gradient of this optimiser step."""
+        self.order("aux", "main")
+        if self.side_busy:
+            self.joined.record(self.side)
+            self.main.wait_event(self.joined)
+            self.side_busy = False
+        self._ev_next = 0
+
+
+class _TrainWorkspace(_Lanes):
+    """Activation / gradient buffers of one mini-batch step (allocated once per batch size).
+
+    Every layer's input-gradient gets its OWN buffer (`g(name, width)`): the weight gradients run on a side
+    stream concurrently with the data-gradient chain (see PPO._bwd), so a buffer that a later layer's dgrad
+    would overwrite may still be being read.  26 buffers x B x <=693 floats ~ 1 GB at B = 24576."""
+
+    def __init__(self, B, dev, num_actions):
+        super().__init__(dev)
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.B, self._dev = B, dev
+        # VAE-only forward activations
+        self.c1, self.c2, self.rec = e(B, 64), e(B, 128), e(B, 53)
+        self.d1, self.d2, self.hr = e(B, 512), e(B, 512), e(B, 693)
+        # loss gradients
+        self.g_rec, self.g_hr = e(B, 53), e(B, 693)
+        self.dlt = e(B, 512)
+        self.dmulv, self.dz = e(B, 35), e(B, 16)
+        self.dmean, self.dval = e(B, num_actions), e(B, 1)
+        self._g = {}
+        lib = _ffi.lib()
+        shapes = [(512, 693), (512, 512), (693, 512), (512, 584), (512, 752), (256, 512), (128, 256), (64, 531),
+                  (128, 64), (53, 128), (128, 265), (64, 128), (35, 64), (num_actions, 128), (1, 128)]
+        self.wg = ops.workspace(max(lib.dtc_linear_wgrad_workspace(B, n, k) for n, k in shapes), dev)
+        self.loss_ws = ops.workspace(lib.dtc_loss_workspace(B), dev)
+
+    def wgrad_ws(self, N, K):
+        """Split-partials workspace, grown on demand (rare: first use of a larger layer shape)."""
+        need = ops.wgrad_workspace_bytes(self.B, N, K)
+        if self.wg.numel() * self.wg.element_size() < need:
+            torch.cuda.synchronize()            # nothing may still be reading the buffer being replaced
+            self.wg = ops.workspace(need, self._dev)
+        return self.wg
+
+    def g(self, name, width):
+        t = self._g.get(name)
+        if t is None:
+            t = self._g[name] = torch.empty(self.B, width, dtype=torch.float32, device=self._dev)
+        return t
 
 
 class PPO:
@@ -310,13 +325,7 @@ class PPO:
             ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B)
 
     def _join(self, tw):
-        """Main stream waits for the second lane and for every weight gradient of this optimiser step."""
-        tw.order("aux", "main")
-        if tw.side_busy:
-            tw.joined.record(tw.side)
-            tw.main.wait_event(tw.joined)
-            tw.side_busy = False
-        tw._ev_next = 0
+        tw.join()
 
     def _terrain_encoder_backward(self, fw, tw, flat, idx):
         L = self.actor_critic.L

@@ -88,14 +88,14 @@ class RecurrentDecoderPPO(PPO):
         H, M = ac.rnn_hidden_size, tw.B
         idx, unpad_idx, T, R = bt["idx"], bt["unpad_idx"], bt["T"], bt["R"]
         dev = idx.device
-        tw.begin(False)
-        ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
-        ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
+        # lanes: the critic head (raw-input features -> GRU -> MLP) is independent of the CE-net / terrain encoders and
+        # of the actor head until the loss, and again until the optimiser step: it runs on `aux`, the small per-time-
+        # step kernels of the two recurrences overlap
+        tw.begin(self.overlap_lanes and self.overlap_wgrad)
         Xa = ac.actor_input(fw, flat["observations"], idx)
         Xc = ac.critic_input(flat["observations"], flat["base_vel"], flat["privileged_observations"], idx)
-        heads = []
-        for name, X, mem, proj, layers, h0 in (("a", Xa, ac.memory_a, ac.proj_a, ac.A, bt["hid_a"]),
-                                               ("c", Xc, ac.memory_c, ac.proj_c, ac.Cr, bt["hid_c"])):
+
+        def head_forward(name, X, mem, proj, layers, h0):
             gi_v = tw.g("gi_" + name, 3 * H)
             ops.linear_fwd(X, proj.W, proj.b, gi_v, None, M=M)
             gi_p = self._padded(tw, "gi_" + name, T * R, 3 * H)     # padded steps keep finite stale values (never used)
@@ -111,16 +111,10 @@ class RecurrentDecoderPPO(PPO):
                 ops.linear_fwd(cur, L.W, L.b, o, L.act, M=M)
                 outs.append(o)
                 cur = o
-            heads.append(dict(name=name, X=X, mem=mem, proj=proj, layers=layers, hs_all=hs_all, gates=gates, hn=hn,
-                              ws=ws, X0=X0, outs=outs))
-        mean, value = heads[0]["outs"][-1], heads[1]["outs"][-1]
-        ops.ppo_loss(mean, ac.std_view, value, flat["actions"], flat["actions_log_prob"], flat["mu"], flat["sigma"],
-                     flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval, ac.std_grad,
-                     stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
-        if self._world() > 1 and cfg.adaptive_schedule == 0 and self._adaptive():
-            dp.allreduce_mean_(stats[S_KL:S_KL + 1])
-            ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
-        for hd, dOut in zip(heads, (tw.dmean, tw.dval)):
+            return dict(name=name, X=X, mem=mem, proj=proj, layers=layers, hs_all=hs_all, gates=gates, hn=hn, ws=ws,
+                        X0=X0, outs=outs)
+
+        def head_backward(hd, dOut):
             name, layers, outs = hd["name"], hd["layers"], hd["outs"]
             dZ = dOut
             for li in range(len(layers) - 1, -1, -1):
@@ -137,13 +131,29 @@ class RecurrentDecoderPPO(PPO):
             mem = hd["mem"]
             ops.gru_bwd(dhs.view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], mem.W_hh, dgi_p, mem.gW_hh, mem.gb_hh,
                         dh0, hd["ws"])
-            dgi_v = ops.gather_rows(dgi_p.view(T * R, 3 * H), unpad_idx, out=tw.g("dgi_" + name, 3 * H))
-            if name == "a":       # the features' gradient fans out to z, mu[:, :3], l_t (observations need none)
-                tw.dmulv.zero_()
-                dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
-                self._bwd(tw, hd["proj"], dgi_v, hd["X"], dst, None, None)
-            else:
-                self._bwd(tw, hd["proj"], dgi_v, hd["X"])
+            return ops.gather_rows(dgi_p.view(T * R, 3 * H), unpad_idx, out=tw.g("dgi_" + name, 3 * H))
+
+        with tw.lane("aux"):
+            hc = head_forward("c", Xc, ac.memory_c, ac.proj_c, ac.Cr, bt["hid_c"])
+        ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
+        ha = head_forward("a", Xa, ac.memory_a, ac.proj_a, ac.A, bt["hid_a"])
+        tw.order("aux", "main")
+        mean, value = ha["outs"][-1], hc["outs"][-1]
+        ops.ppo_loss(mean, ac.std_view, value, flat["actions"], flat["actions_log_prob"], flat["mu"], flat["sigma"],
+                     flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval, ac.std_grad,
+                     stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
+        if self._world() > 1 and cfg.adaptive_schedule == 0 and self._adaptive():
+            dp.allreduce_mean_(stats[S_KL:S_KL + 1])
+            ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
+        tw.order("main", "aux")
+        with tw.lane("aux"):
+            self._bwd(tw, hc["proj"], head_backward(hc, tw.dval), hc["X"])
+        dgi_a = head_backward(ha, tw.dmean)
+        # the actor features' gradient fans out to z, mu[:, :3], l_t (observations need none)
+        tw.dmulv.zero_()
+        dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
+        self._bwd(tw, ha["proj"], dgi_a, ha["X"], dst, None, None)
         ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
         self._terrain_encoder_backward(fw, tw, flat, idx)
         self._cenet_encoder_backward(fw, tw, flat, idx)

@@ -20,7 +20,9 @@ from .. import _ffi, distributed as dp, ops
 from .._ffi import seg, segmat
 from ..modules.actor_critic_recurrent import ActorCriticRecurrent
 from ..storage import RolloutStorage
-from .ppo import FusedAdam, S_ENTROPY, S_GNORM, S_KL, S_SURR, S_VALUE, STAT_COLS
+import os
+
+from .ppo import FusedAdam, S_ENTROPY, S_GNORM, S_KL, S_SURR, S_VALUE, STAT_COLS, _Lanes
 
 
 class RecurrentPPO:
@@ -45,6 +47,10 @@ class RecurrentPPO:
         self.use_clipped_value_loss = use_clipped_value_loss
         self.capture_grads, self.captured = False, {}
         self.last_update_stats = None
+        # actor and critic are independent recurrences until the loss and again until the optimiser step: the critic
+        # runs on a second stream, every weight gradient on a third (DTC_OVERLAP_LANES=0 / DTC_OVERLAP_WGRAD=0: serial)
+        self.overlap = os.environ.get("DTC_OVERLAP_LANES", "1") != "0" and os.environ.get("DTC_OVERLAP_WGRAD", "1") != "0"
+        self._lanes = None
 
     def _require_gpu(self):
         if self.optimizer is None:
@@ -105,14 +111,33 @@ class RecurrentPPO:
         cfg.adaptive_schedule = int(self.desired_kl is not None and self.schedule == 'adaptive' and dp.world_size() == 1)
         return cfg
 
-    def _mlp_backward(self, layers, outs, dOut, X0, M, dev, wg):
-        """Backward through an MLP given the saved layer outputs; returns the gradient w.r.t. its input rows."""
+    def _wgrad(self, ln, dZ, X, gW, gb, M):
+        """Weight gradient on the side stream (off the critical path until the optimiser step)."""
+        N, K = gW.shape
+        need = ops.wgrad_workspace_bytes(M, N, K)
+        if ln.wg is None or ln.wg.numel() * ln.wg.element_size() < need:
+            torch.cuda.synchronize()
+            ln.wg = ops.workspace(need, gW.device)
+        if self.overlap:
+            ev = ln.event()
+            ev.record()
+            ln.side.wait_event(ev)
+            ops.linear_wgrad(dZ, X, gW, gb, ln.wg, M=M, stream_ptr=ln.side.cuda_stream)
+            ln.side_busy = True
+        else:
+            ops.linear_wgrad(dZ, X, gW, gb, ln.wg, M=M)
+
+    def _mlp_backward(self, ln, layers, outs, dOut, X0, M, dev, keep):
+        """Backward through an MLP given the saved layer outputs; returns the gradient w.r.t. its input rows.
+        Every gradient buffer goes into `keep`: the side stream still reads it for the weight gradient after this
+        lane has moved on, so it must not return to the caching allocator before the join."""
         dZ = dOut
         for li in range(len(layers) - 1, -1, -1):
             L = layers[li]
             X = outs[li - 1] if li > 0 else X0
-            ops.linear_wgrad(dZ, X, L.gW, L.gb, wg, M=M)
+            self._wgrad(ln, dZ, X, L.gW, L.gb, M)
             dX = torch.empty(M, L.n_in, device=dev)
+            keep.append(dX)
             if li > 0:
                 ops.linear_dgrad(dZ, L.W, dX, outs[li - 1], layers[li - 1].act, M=M)
             else:
@@ -129,17 +154,24 @@ class RecurrentPPO:
         T, R = masks.shape
         N, Nmb = st.num_envs, stop - start
         M = T * Nmb
+        if self._lanes is None:
+            self._lanes = _Lanes(dev)
+            self._lanes.wg = None
+        ln = self._lanes
         # un-padding as a row map: padded row (pos*R + traj) of each (t, env) in time-major order
         traj, pos = masks.transpose(1, 0).nonzero(as_tuple=True)
         unpad_idx = (pos * R + traj).view(Nmb, T).transpose(1, 0).reshape(-1).contiguous()
         store_idx = (torch.arange(T, device=dev).unsqueeze(1) * N + torch.arange(start, stop, device=dev)).reshape(-1).contiguous()
         stats = torch.zeros(STAT_COLS, device=dev) if stats is None else stats
         self.optimizer.set_lr(self.learning_rate)
-        # forward
+        ln.begin(self.overlap)
+        # forward: critic recurrence on the second lane
+        with ln.lane("aux"):
+            ac.evaluate(cobs_b, masks, hid_c, unpad_idx)
+            c_outs, c_saved = ac._critic_outs, ac.memory_c.saved
         ac.act(obs_b, masks, hid_a, unpad_idx)
         a_outs, a_saved = ac._actor_outs, ac.memory_a.saved
-        ac.evaluate(cobs_b, masks, hid_c, unpad_idx)
-        c_outs, c_saved = ac._critic_outs, ac.memory_c.saved
+        ln.order("aux", "main")
         mean, value = a_outs[-1], c_outs[-1]
         # loss (rows of the rollout tensors are addressed through store_idx -- no slicing copies)
         dmean, dval = torch.empty_like(mean), torch.empty(M, 1, device=dev)
@@ -151,17 +183,24 @@ class RecurrentPPO:
         if dp.world_size() > 1 and self.desired_kl is not None and self.schedule == 'adaptive':
             dp.allreduce_mean_(stats[S_KL:S_KL + 1])
             ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
-        # backward: MLPs -> scatter into the padded layout -> BPTT
+        ln.order("main", "aux")
+        # backward: MLPs -> scatter into the padded layout -> BPTT -> input-projection weight gradient
         H = ac.rnn_hidden_size
-        wg = ops.workspace(max(ops.wgrad_workspace_bytes(M, L.n_out, L.n_in) for L in ac.A + ac.Cr), dev)
-        for layers, outs, saved, mem, dOut in ((ac.A, a_outs, a_saved, ac.memory_a, dmean),
-                                               (ac.Cr, c_outs, c_saved, ac.memory_c, dval)):
+        keep = []                                   # buffers read by the side stream stay alive until the join
+
+        def head_backward(layers, outs, saved, mem, dOut):
             hs_flat = saved["hs_all"][1:].reshape(T * R, H)
             X0 = segmat([seg(hs_flat, 0, H, gather=True)], unpad_idx)
-            d_in = self._mlp_backward(layers, outs, dOut, X0, M, dev, wg)
+            d_in = self._mlp_backward(ln, layers, outs, dOut, X0, M, dev, keep)
             dhs = torch.zeros(T * R, H, device=dev)
             ops.scatter_rows(d_in, unpad_idx, dhs)
-            mem.backward(saved, dhs.view(T, R, H))
+            dgi = mem.backward(saved, dhs.view(T, R, H), wgrad=lambda dZ, X, gW, gb: self._wgrad(ln, dZ, X, gW, gb, T * R))
+            keep.extend((d_in, dhs, dgi, X0, outs, saved))
+
+        with ln.lane("aux"):
+            head_backward(ac.Cr, c_outs, c_saved, ac.memory_c, dval)
+        head_backward(ac.A, a_outs, a_saved, ac.memory_a, dmean)
+        ln.join()
         dp.allreduce_mean_(self.optimizer.g)
         if self.capture_grads:
             self.captured["main"] = ac.arena.grad.clone()

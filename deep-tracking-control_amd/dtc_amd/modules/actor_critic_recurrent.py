@@ -193,17 +193,22 @@ class Memory(nn.Module):
         ops.gru_fwd(gi, h0.contiguous(), self.W_hh, self.b_hh, hs_all, gates, hn, ws)
         return dict(hs_all=hs_all, gates=gates, hn=hn, x2=x2, ws=ws, T=T, R=R)
 
-    def backward(self, saved, dhs):
-        """BPTT: dhs [T,R,H] -> parameter gradients into the arena (returns dh0)."""
+    def backward(self, saved, dhs, wgrad=None):
+        """BPTT: dhs [T,R,H] -> parameter gradients into the arena; returns dgi [T,R,3H] (gradient of the input
+        projection's output).  `wgrad(dZ, X, gW, gb)` optionally takes over the input-projection weight gradient
+        (the trainer runs it on its weight-gradient stream)."""
         T, R, H = saved["T"], saved["R"], self.hidden_size
         dev = dhs.device
         dgi = torch.empty(T, R, 3 * H, device=dev)
         dh0 = torch.empty(R, H, device=dev)
         ops.gru_bwd(dhs.contiguous(), saved["hs_all"], saved["gates"], saved["hn"], self.W_hh, dgi, self.gW_hh, self.gb_hh,
                     dh0, saved["ws"])
-        wws = ops.workspace(ops.wgrad_workspace_bytes(T * R, 3 * H, self.input_size), dev)
-        ops.linear_wgrad(dgi.view(T * R, 3 * H), saved["x2"], self.gW_ih, self.gb_ih, wws)
-        return dh0
+        if wgrad is not None:
+            wgrad(dgi.view(T * R, 3 * H), saved["x2"], self.gW_ih, self.gb_ih)
+        else:
+            wws = ops.workspace(ops.wgrad_workspace_bytes(T * R, 3 * H, self.input_size), dev)
+            ops.linear_wgrad(dgi.view(T * R, 3 * H), saved["x2"], self.gW_ih, self.gb_ih, wws)
+        return dgi
 
     def forward(self, input, masks=None, hidden_states=None):
         batch_mode = masks is not None
