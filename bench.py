@@ -40,7 +40,7 @@ def cpu_baseline():
     from oracle import ppo_ref as OP
     cores = min(os.cpu_count() or 1, 32)      # torch-CPU GEMMs of this size stop scaling (and thrash) beyond ~32 threads
     torch.set_num_threads(cores)
-    n_envs, n_maps = 2048, 32768            # ~10-15 s of CPU work on the GPU box's host
+    n_envs, n_maps = NUM_ENVS, NUM_ENVS * NUM_STEPS      # one whole step of the workload: ~20 s on the GPU box's host
     torch.manual_seed(3)
     ac = OP.RefActorCriticDecoder()
     alg = OP.RefPPO(ac, learning_rate=1e-3, entropy_coef=0.003)
@@ -153,8 +153,8 @@ def main():
     roof, classes = None, None
     if rank == 0:
         lib = _ffi.lib()
-        overlap = getattr(alg, "overlap_wgrad", False)
-        alg.overlap_wgrad = False
+        overlap, overlap_rec = getattr(alg, "overlap_wgrad", False), getattr(alg, "overlap", False)
+        alg.overlap_wgrad = alg.overlap = False
         step()
         torch.cuda.synchronize()
         lib.dtc_prof_reset()
@@ -162,7 +162,7 @@ def main():
         step()
         torch.cuda.synchronize()
         lib.dtc_prof_enable(0)
-        alg.overlap_wgrad = overlap
+        alg.overlap_wgrad, alg.overlap = overlap, overlap_rec
         rep = _ffi.prof_report()
         lib.dtc_prof_reset()
         gemm = [r for r in rep if r["name"].split("[")[0] in ("linear_fwd", "linear_dgrad", "linear_wgrad")]

@@ -13,3 +13,8 @@ for f in ('r01_bench_n1','rp_serial','rp_overlap'):
     d=json.load(open('$R/gpurun_out/'+f+'.json'))
     print(f, d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['avg_launch_us'], d.get('cpu_baseline',{}).get('value'))
 PY
+cd $R
+for w in gru composite; do
+timeout 600 python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01_bench_$w.json 2>/dev/null
+python -c "import json; d=json.load(open('gpurun_out/r01_bench_$w.json')); print('$w', d['value'], d['ms_per_step'], d['roofline']['achieved'])"
+done

@@ -68,6 +68,9 @@ __global__ __launch_bounds__(256, OCC) void probe(const float* __restrict__ src,
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[i][j], 0, 0, 0);
         } else {
+#ifdef PROBE_SETPRIO
+            __builtin_amdgcn_s_setprio(PROBE_SETPRIO);
+#endif
             const float* ap = &As[buf][0][0] + half * LDA + wm_off + l31;
             const float* bp = &Bs[buf][0][0] + half * LDB + wn_off + l31;
 #pragma unroll
@@ -83,6 +86,9 @@ __global__ __launch_bounds__(256, OCC) void probe(const float* __restrict__ src,
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
+#ifdef PROBE_SETPRIO
+        if (V >= 1) __builtin_amdgcn_s_setprio(0);
+#endif
         if (V >= 3) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) As[buf ^ 1][kk][rbase + 16 * i] = ra[i] + 1.0f;
