@@ -57,7 +57,8 @@ def cpu_baseline():
     inp = S.scorer_inputs(n_maps, seed=7)
     args = [inp[k].numpy() for k in ("measured_heights", "root_states", "thigh_pos", "commands")]
     t0 = time.perf_counter()
-    OF.plan(*args, S.MEASURED_POINTS_X, S.MEASURED_POINTS_Y)
+    for lo in range(0, n_maps, 8192):             # bounded temporaries ([chunk, 693, 4] arrays)
+        OF.plan(*[x[lo:lo + 8192] for x in args], S.MEASURED_POINTS_X, S.MEASURED_POINTS_Y)
     t_sc = time.perf_counter() - t0
     per_env_step = t_upd / (n_envs * NUM_STEPS) + t_sc / n_maps
     return dict(value=1.0 / per_env_step, unit="env-steps/s", cores=cores, kind="port",
