@@ -150,3 +150,44 @@ def test_recurrent_update_and_rollout_api():
     v, s = alg.update()
     assert np.isfinite(v) and np.isfinite(s) and alg.storage.step == 0
     assert alg.last_update_stats.shape[0] == 20
+
+
+@pytest.mark.gpu
+def test_recurrent_overlapped_schedule_equals_serial_bitwise():
+    """RecurrentPPO / RecurrentDecoderPPO: critic recurrence on the second stream + weight-gradient stream vs the
+    single-stream schedule, bit-identical weights after a full update (256 envs x 24)."""
+    from dtc_amd.algorithms import RecurrentDecoderPPO, RecurrentPPO
+    from dtc_amd.modules import ActorCriticDecoderRecurrent, ActorCriticRecurrent
+    n = 256
+    d = S.rollout(n, 24, seed=9, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    hid = [0.1 * torch.randn(24, 1, n, 512, generator=g, device=DEV) for _ in range(2)]
+    eps = [torch.randn(20, 24 * n // 4, 16, generator=g, device=DEV) for _ in range(2)]
+    for kind in ("gru", "composite"):
+        out = []
+        for overlap in (True, False):
+            torch.manual_seed(3)
+            if kind == "gru":
+                ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+                                          activation='elu', rnn_type='gru', rnn_hidden_size=512, rnn_num_layers=1)
+                alg = RecurrentPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV)
+                alg.init_storage(n, 24, [53], [1389], [12])
+                alg.overlap = overlap
+            else:
+                ac = ActorCriticDecoderRecurrent(53, 1389, 12)
+                alg = RecurrentDecoderPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV)
+                alg.init_storage(n, 24, [53], [1389], [265], [12])
+                alg.overlap_wgrad = alg.overlap_lanes = overlap
+            for k, v in d.items():
+                if k != "last_values" and not (kind == "gru" and k == "observation_histories"):
+                    getattr(alg.storage, k).copy_(v)
+            alg.storage.compute_returns(d["last_values"], 0.99, 0.95)
+            alg.storage.step = 24
+            alg.storage.saved_hidden_states_a, alg.storage.saved_hidden_states_c = [hid[0]], [hid[1]]
+            if kind == "gru":
+                alg.update()
+            else:
+                alg.update(eps[0], eps[1])
+            out.append({k: v.clone() for k, v in ac.state_dict().items()})
+        for k, v in out[0].items():
+            assert torch.equal(v, out[1][k]), (kind, k)

@@ -400,3 +400,32 @@ def test_act_teacher_and_checkpoint_roundtrip(golden, tmp_path):
     for (k, a), (_, b) in zip(r1.alg.actor_critic.state_dict().items(), r2.alg.actor_critic.state_dict().items()):
         assert torch.equal(a, b), k
     assert r2.get_inference_policy(env_t=True) == r2.alg.actor_critic.act_expert
+
+
+def test_overlapped_schedule_equals_serial_schedule_bitwise():
+    """Full-size update (4096 envs x 24, 20 mini-batch steps): the three-stream schedule (two compute lanes + the
+    weight-gradient stream) must give bit-identical weights / statistics to the single-stream schedule -- any missing
+    dependency between the lanes shows up here as a difference."""
+    from dtc_amd.algorithms import PPO
+    from dtc_amd.modules import ActorCriticDecoder
+    d = S.rollout(4096, 24, seed=4, device=DEV)
+    perm, e1, e2 = S.update_noise(4096, 24, 4, 5, seed=123)
+    results = []
+    for overlap in (True, False, True):
+        torch.manual_seed(3)
+        ac = ActorCriticDecoder(53, 1389, 12)
+        alg = PPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV)
+        alg.overlap_wgrad = alg.overlap_lanes = overlap
+        alg.init_storage(4096, 24, [53], [1389], [265], [12])
+        for k, v in d.items():
+            if k != "last_values":
+                getattr(alg.storage, k).copy_(v)
+        alg.storage.compute_returns(d["last_values"], 0.99, 0.95)
+        alg.storage.step = 24
+        out, stats, _ = alg.update(perm.to(DEV), e1.to(DEV), e2.to(DEV), return_stats=True)
+        results.append((out, stats.clone(), {k: v.clone() for k, v in ac.state_dict().items()}, alg.learning_rate))
+    for other in results[1:]:
+        assert results[0][0] == other[0] and results[0][3] == other[3]
+        assert torch.equal(results[0][1], other[1])
+        for k, v in results[0][2].items():
+            assert torch.equal(v, other[2][k]), k
