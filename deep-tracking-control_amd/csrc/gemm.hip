@@ -154,6 +154,8 @@ __device__ __forceinline__ void mfma_step(const float* __restrict__ As, const fl
 
 struct Masked { static constexpr bool value = true; };
 struct Full { static constexpr bool value = false; };
+struct S0 { static constexpr int value = 0; };      // register-set selectors of the two-step-ahead loaders
+struct S1 { static constexpr int value = 1; };
 
 template <int BN>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN]) {
@@ -274,6 +276,135 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_kernel(const SegMatDev X, c
                 if (full) yp[(long long)ro * ldy] = v;
                 else if (cok && m0 + wm_off + 32 * i + 4 * half + ro < M) yp[(long long)ro * ldy] = v;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One fused GRU time step (forward): gh = h_{t-1} W_hh^T + b_hh for the three gates of 32 hidden units,
+// then the gate math of torch.nn.GRU in the epilogue -- the [R,3H] recurrent pre-activations never touch HBM:
+//   r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h_t = (1 - z) * n + z * h_{t-1}
+// Block tile: 128 rows x (32 units x 3 gates); wave w owns rows 32w..32w+31 and three 32x32 MFMA tiles (r, z, n of
+// the same units), so every lane holds the three pre-activations of its (row, unit) pairs.  Same K loop as
+// linear_fwd_kernel (plain single-segment operands).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256, 3) void gru_step_fwd_kernel(const float* __restrict__ hprev, const float* __restrict__ Whh,
+                                                           const float* __restrict__ bhh, const float* __restrict__ gi,
+                                                           float* __restrict__ hout, float* __restrict__ gates,
+                                                           float* __restrict__ hn, int R, int H) {
+    constexpr int GB = 96, LDAg = BM + PAD, LDBg = GB + PAD;
+    __shared__ float As[2][BK][LDAg];
+    __shared__ float Bs[2][BK][LDBg];
+    int tr, tc;
+    if (!map_tile(blockIdx.x, (R + BM - 1) / BM, H / 32, tr, tc)) return;
+    const int m0 = tr * BM, j0 = tc * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm_off = wave * 32;
+    const int kk = tid & (BK - 1), rbase = tid / BK;
+    constexpr int NA = BM / RP, NB = GB / RP;
+    u32 aoff[NA], woff[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + rbase + RP * i;
+        aoff[i] = m < R ? (u32)(m * H + kk) * 4u : INVALID;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = rbase + RP * i;                       // 0..95: gate n / 32, unit j0 + n % 32
+        woff[i] = (u32)(((n >> 5) * H + j0 + (n & 31)) * H + kk) * 4u;
+    }
+    const rsrc_t ares = make_rsrc(hprev), wres = make_rsrc(Whh);
+    // One GRU step has ~12 row tiles x 16 unit tiles = 192 workgroups for 256 CUs: one wave per SIMD, nothing else to
+    // hide the load latency behind.  Loads therefore run TWO K steps ahead of the MFMAs (two register sets, loop
+    // unrolled by two): a tile has two MFMA phases (~1.5 us) to arrive instead of one.
+    float ra[2][NA], rb[2][NB];
+    auto load_tile = [&](auto set, int kt) {
+        constexpr int S = decltype(set)::value;
+        const u32 ko = (u32)(kt * BK) * 4u;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[S][i] = bload(ares, aoff[i], ko);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[S][i] = bload(wres, woff[i], ko);
+    };
+    auto store_tile = [&](auto set, int buf) {
+        constexpr int S = decltype(set)::value;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + RP * i] = ra[S][i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Bs[buf][kk][rbase + RP * i] = rb[S][i];
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    const int half = lane >> 5, l31 = lane & 31;
+    auto mfma = [&](int buf) {
+        const float* ap = &As[buf][0][0] + half * LDAg + wm_off + l31;
+        const float* bp = &Bs[buf][0][0] + half * LDBg + l31;
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            const float a = ap[2 * kp * LDAg];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * kp * LDBg + 32 * g], acc[g], 0, 0, 0);
+        }
+    };
+    const int KT = H / BK;                                  // even: H is a multiple of 32
+    int buf = 0;
+    load_tile(S0{}, 0);
+    store_tile(S0{}, 0);
+    __syncthreads();
+    load_tile(S1{}, 1);                                     // invariant: LDS[buf] = tile kt, set 1 = tile kt+1 in flight
+    for (int kt = 0; kt + 2 < KT; kt += 2) {
+        load_tile(S0{}, kt + 2);
+        mfma(buf);
+        store_tile(S1{}, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        load_tile(S1{}, kt + 3);
+        mfma(buf);
+        store_tile(S0{}, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    mfma(buf);
+    store_tile(S1{}, buf ^ 1);
+    __syncthreads();
+    mfma(buf ^ 1);
+
+    // epilogue: gate math; gi / h_{t-1} come in through unconditional buffer loads (rows >= R read 0)
+    const int j = j0 + l31;
+    const float br = bhh[j], bz = bhh[H + j], bn = bhh[2 * H + j];
+    const rsrc_t gres = make_rsrc_bytes(gi, (long long)R * 3 * H * 4), hres = make_rsrc_bytes(hprev, (long long)R * H * 4);
+    const int row0 = m0 + wm_off + 4 * half;
+    float gr[16], gz[16], gn[16], hp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ro = (r & 3) + 8 * (r >> 2);
+        const u32 go = (u32)((row0 + ro) * 3 * H + j) * 4u;
+        gr[r] = bload(gres, go, 0u);
+        gz[r] = bload(gres, go, (u32)H * 4u);
+        gn[r] = bload(gres, go, (u32)H * 8u);
+        hp[r] = bload(hres, (u32)((row0 + ro) * H + j) * 4u, 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        const float rg = sigmoid_f(gr[r] + (acc[0][r] + br));
+        const float zg = sigmoid_f(gz[r] + (acc[1][r] + bz));
+        const float ghn = acc[2][r] + bn;
+        const float ng = tanhf(gn[r] + rg * ghn);
+        if (row < R) {
+            const long long e = (long long)row * H + j;
+            float* gp = gates + (long long)row * 3 * H + j;
+            hout[e] = (1.0f - zg) * ng + zg * hp[r];
+            gp[0] = rg;
+            gp[H] = zg;
+            gp[2 * H] = ng;
+            hn[e] = ghn;
         }
     }
 }
@@ -659,6 +790,18 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     else if (bn == 64) hipLaunchKernelGGL(linear_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
     else hipLaunchKernelGGL(linear_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
     return dtc::check_launch("linear_fwd");
+}
+
+extern "C" int dtc_gru_step_fwd(const float* hprev, const float* W_hh, const float* b_hh, const float* gi_t, float* hout,
+                                float* gates_t, float* hn_t, int R, int H, void* stream) {
+    DTC_REQUIRE(R > 0 && H > 0 && H % 32 == 0, "bad shape R=%d H=%d (H must be a multiple of 32)", R, H);
+    DTC_REQUIRE(hprev && W_hh && b_hh && gi_t && hout && gates_t && hn_t, "null pointer");
+    DTC_REQUIRE((long long)R * 3 * H <= MAX_ELEMS && 3ll * H * H <= MAX_ELEMS, "matrix too large");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for((int)dtc::ceil_div(R, BM), H / 32);
+    dtc::ProfScope prof(dtc::prof_shape_name("gru_step_fwd", R, 3 * H, H), 2.0 * R * 3.0 * H * H, s);
+    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(grid), dim3(256), 0, s, hprev, W_hh, b_hh, gi_t, hout, gates_t, hn_t, R, H);
+    return dtc::check_launch("gru_step_fwd");
 }
 
 extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved,

@@ -6,8 +6,9 @@
 // over [1, N, .] during the rollout.
 //
 // Structure (all launches are issued from this C++ loop -- no Python between time steps):
-//   forward  t = 0..T-1 : gh = h_{t-1} W_hh^T + b_hh        (dtc_linear_fwd, M = R, N = 3H, K = H)
-//                         gates + state update              (gru_gate_fwd_kernel, fused, saves r,z,n and gh_n)
+//   forward  t = 0..T-1 : gh = h_{t-1} W_hh^T + b_hh and the gate math in its epilogue: ONE kernel per step
+//                         (dtc_gru_step_fwd in gemm.hip; saves r,z,n and gh_n; DTC_GRU_UNFUSED=1 selects the older
+//                         dtc_linear_fwd + gru_gate_fwd_kernel pair)
 //   backward t = T-1..0 : gate derivatives                  (gru_gate_bwd_kernel: dgi_t, dgh_t, dh*z)
 //                         dh_{t-1} += dgh_t W_hh            (dtc_linear_dgrad_split: the 3H-long reduction runs as three
 //                                                            H-long chunks side by side -- one step has only ~12 row
@@ -17,6 +18,8 @@
 // The input projection gi = x W_ih^T + b_ih (all T*R rows at once) and its weight gradient are plain
 // dtc_linear_fwd / dtc_linear_wgrad calls made by the caller.  Padded steps need no masks: their output
 // gradients are zero, so every quantity flowing backwards through them is zero as well.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -118,9 +121,16 @@ extern "C" int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, 
         dtc::set_error("gru_fwd: h0 copy failed");
         return DTC_ERR_LAUNCH;
     }
+    static const bool unfused = getenv("DTC_GRU_UNFUSED") != nullptr;      // two-kernel step (GEMM + gate kernel)
     const unsigned grid = (unsigned)dtc::ceil_div((int64_t)RH, 256);
     for (int t = 0; t < T; ++t) {
         const float* hprev = hs_all + (size_t)t * RH;
+        if (!unfused && H % 32 == 0) {
+            int rc = dtc_gru_step_fwd(hprev, W_hh, b_hh, gi + (size_t)t * R * 3 * H, hs_all + (size_t)(t + 1) * RH,
+                                      gates + (size_t)t * R * 3 * H, hn + (size_t)t * RH, R, H, stream);
+            if (rc != DTC_OK) return rc;
+            continue;
+        }
         const DtcSegMat X = plain(hprev, H, H);
         int rc = dtc_linear_fwd(&X, W_hh, b_hh, gh, 3 * H, R, 3 * H, H, DTC_ACT_NONE, stream);
         if (rc != DTC_OK) return rc;

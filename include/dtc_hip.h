@@ -239,6 +239,12 @@ int dtc_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq
 int64_t dtc_adam_workspace(int64_t n);
 
 /* ---- GRU (torch.nn.GRU, 1 layer, gate order r,z,n; actor_critic_recurrent.py:92-116 `Memory`) ---- */
+/* One fused GRU time step (forward), the building block of dtc_gru_fwd: the recurrent GEMM
+ * gh = hprev W_hh^T + b_hh and the gate math of torch.nn.GRU in its epilogue (gh never reaches HBM):
+ * hout [R,H], gates_t [R,3H] = (r | z | n), hn_t [R,H] = gh_n; gi_t [R,3H] = x_t W_ih^T + b_ih.  H % 32 == 0. */
+int dtc_gru_step_fwd(const float* hprev /*[R,H]*/, const float* W_hh /*[3H,H]*/, const float* b_hh, const float* gi_t,
+                     float* hout, float* gates_t, float* hn_t, int R, int H, void* stream);
+
 /* gi [T,R,3H] = x W_ih^T + b_ih is computed by dtc_linear_fwd over all T*R rows; this runs the recurrence
  *     r = sig(gi_r + gh_r), z = sig(gi_z + gh_z), n = tanh(gi_n + r*gh_n), h_t = (1-z)*n + z*h_{t-1},
  *     gh = h_{t-1} W_hh^T + b_hh
