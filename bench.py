@@ -151,7 +151,7 @@ def main():
     # for the roofline object.  The timed region above overlaps the weight-gradient GEMMs with the
     # data-gradient chain on a second stream; a kernel that shares the chip has no duration of its own, so this
     # pass runs the same kernels serialised (overlap off) -- rocprofv3 cross-check: DTC_OVERLAP_WGRAD=0.
-    roof, classes = None, None
+    roof, classes, planner = None, None, None
     if rank == 0:
         lib = _ffi.lib()
         overlap, overlap_rec = getattr(alg, "overlap_wgrad", False), getattr(alg, "overlap", False)
@@ -176,6 +176,15 @@ def main():
                     achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP32_MFMA_TFLOPS,
                     traffic=None, launches=n_launch, measured="HIP events per launch, kernels serialised on one stream", avg_launch_us=ms * 1e3 / max(1, n_launch),
                     flop_per_launch=fl / max(1, n_launch))
+        pl = [r for r in rep if r["name"].split("[")[0] == "foothold_plan"]
+        if pl:                                  # the HBM-side kernel of the path: bytes = 3096 B/env
+            pms, pby, pn = (sum(r[k] for r in pl) for k in ("ms_total", "work", "launches"))
+            planner = dict(bound="hbm", kernel="foothold_plan_kernel", achieved=pby / (pms * 1e-3) / 1e9, peak=8000.0,
+                           unit="GB/s", frac=pby / (pms * 1e-3) / 1e9 / 8000.0,
+                           traffic=306.3e6 * (pby / pn) / (3096.0 * 98304),
+                           traffic_source="rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_planner_pmc.md "
+                                          "(VALU-bound: SQ_ACTIVE_INST_VALU ~ 100 % of the kernel's cycles)",
+                           launches=pn, avg_launch_us=pms * 1e3 / pn, bytes_per_launch=pby / pn)
         classes = {r["name"]: dict(ms=round(r["ms_total"], 3), launches=r["launches"],
                                    rate=(r["work"] / (r["ms_total"] * 1e-3) / 1e12) if r["ms_total"] > 0 else 0.0)
                    for r in rep}
@@ -202,6 +211,7 @@ def main():
                        "mfma_frac_whole_step": None if (composite or gru) else
                        (FLOP_PER_ENV_STEP * value / world) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
             "roofline": roof,
+            "roofline_planner": planner,
             "kernel_classes": classes,
             "last_update": [float(x) for x in out],
         }
