@@ -100,13 +100,14 @@ __device__ __forceinline__ PointEval eval_point(const EnvCtx& c, const float* __
     PointEval o;
     const int ny = c.ny;
     const float gc = gE[i];
-    float dx, dy;
-    if (ix == 0) dx = div_const(gE[i + ny] - gc, 0.05f, 20.0f);
-    else if (ix == c.nx - 1) dx = div_const(gc - gE[i - ny], 0.05f, 20.0f);
-    else dx = div_const(gE[i + ny] - gE[i - ny], 0.1f, 10.0f);
-    if (iy == 0) dy = div_const(gE[i + 1] - gc, 0.05f, 20.0f);
-    else if (iy == ny - 1) dy = div_const(gc - gE[i - 1], 0.05f, 20.0f);
-    else dy = div_const(gE[i + 1] - gE[i - 1], 0.1f, 10.0f);
+    // torch.gradient: central difference (g[i+1] - g[i-1]) / 0.1 inside, one-sided (g[1] - g[0]) / 0.05 at the borders
+    // -- the same expression with the neighbour indices clamped to the grid, so ONE division per axis (the three-way
+    // branch made every lane of a border-touching patch evaluate all three forms)
+    const int xp = ix < c.nx - 1 ? ny : 0, xm = ix > 0 ? ny : 0;
+    const int yp = iy < ny - 1 ? 1 : 0, ym = iy > 0 ? 1 : 0;
+    const bool x_in = (xp != 0) & (xm != 0), y_in = (yp != 0) & (ym != 0);
+    const float dx = div_const(gE[i + xp] - gE[i - xm], x_in ? 0.1f : 0.05f, x_in ? 10.0f : 20.0f);
+    const float dy = div_const(gE[i + yp] - gE[i - ym], y_in ? 0.1f : 0.05f, y_in ? 10.0f : 20.0f);
     o.slope = sqrtf(dx * dx + dy * dy);
     const float rough = fabsf(gc - c.mean);
     const float s_raw = (0.2f * c.edge + o.slope) + 0.3f * rough;
