@@ -748,7 +748,7 @@ int pick_bn_rows(int rows, int cols) {
     if (force && cols > 64) return atoi(force);
     if (cols <= 32) return 32;
     static const char* thr_env = getenv("DTC_GEMM_MIN_BLOCKS");
-    const long long min_blocks = thr_env ? atoi(thr_env) : 320;     // measured: tools/jobs/job20.sh
+    const long long min_blocks = thr_env ? atoi(thr_env) : 320;     // measured with DTC_GEMM_MIN_BLOCKS sweeps of bench.py
     return dtc::ceil_div(rows, BM) * dtc::ceil_div(cols, 64) >= min_blocks ? 64 : 32;
 }
 
