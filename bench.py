@@ -84,11 +84,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs a torch.distributed.run launch with WORLD_SIZE={a.gpus} (got {world})")
+    # test hooks (a 1-GPU box can rehearse the N > 1 control flow): DTC_BENCH_DEVICE pins every rank to one device,
+    # DTC_BENCH_BACKEND=gloo replaces RCCL (two ranks cannot share a GPU under RCCL)
+    if "DTC_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["DTC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        backend = os.environ.get("DTC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     from dtc_amd import _ffi, foothold, synthetic as S
     from dtc_amd.algorithms import PPO, RecurrentDecoderPPO, RecurrentPPO
@@ -152,18 +160,22 @@ def main():
     # data-gradient chain on a second stream; a kernel that shares the chip has no duration of its own, so this
     # pass runs the same kernels serialised (overlap off) -- rocprofv3 cross-check: DTC_OVERLAP_WGRAD=0.
     roof, classes, planner = None, None, None
+    # EVERY rank runs these two extra steps (they contain the data-parallel collectives); only rank 0 records events
+    lib = _ffi.lib()
+    overlap, overlap_rec = getattr(alg, "overlap_wgrad", False), getattr(alg, "overlap", False)
+    alg.overlap_wgrad = alg.overlap = False
+    step()
+    torch.cuda.synchronize()
     if rank == 0:
-        lib = _ffi.lib()
-        overlap, overlap_rec = getattr(alg, "overlap_wgrad", False), getattr(alg, "overlap", False)
-        alg.overlap_wgrad = alg.overlap = False
-        step()
-        torch.cuda.synchronize()
         lib.dtc_prof_reset()
         lib.dtc_prof_enable(1)
-        step()
-        torch.cuda.synchronize()
-        lib.dtc_prof_enable(0)
-        alg.overlap_wgrad, alg.overlap = overlap, overlap_rec
+    step()
+    torch.cuda.synchronize()
+    lib.dtc_prof_enable(0)
+    alg.overlap_wgrad, alg.overlap = overlap, overlap_rec
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
         rep = _ffi.prof_report()
         lib.dtc_prof_reset()
         gemm = [r for r in rep if r["name"].split("[")[0] in ("linear_fwd", "linear_dgrad", "linear_wgrad")]

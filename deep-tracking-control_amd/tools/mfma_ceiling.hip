@@ -71,6 +71,9 @@ __global__ __launch_bounds__(256, OCC) void probe(const float* __restrict__ src,
 #ifdef PROBE_SETPRIO
             __builtin_amdgcn_s_setprio(PROBE_SETPRIO);
 #endif
+#ifdef PROBE_IGLP
+            __builtin_amdgcn_iglp_opt(PROBE_IGLP);
+#endif
             const float* ap = &As[buf][0][0] + half * LDA + wm_off + l31;
             const float* bp = &Bs[buf][0][0] + half * LDB + wn_off + l31;
 #pragma unroll
