@@ -26,6 +26,34 @@ if what in ("fwd", "dgrad", "wgrad"):
             ops.linear_dgrad(dZ, W, dX, X, "relu")
         else:
             ops.linear_wgrad(dZ, X, dW, db, ws)
+elif what == "traffic":
+    # HBM-traffic calibration + measurement for the GEMM loaders (dword buffer loads; MI355X_MICROARCH.md calibrates
+    # FETCH_SIZE only for 16 B/lane reads).  Calibration case: ONE column tile (N = 64) and an X far larger than the
+    # 256 MiB Infinity Cache, so every byte of X is fetched exactly once: known = M*K*4.
+    Mc, Kc = 393216, 512
+    Xc = torch.randn(Mc, Kc, device=DEV)
+    Wc = torch.randn(64, Kc, device=DEV)
+    Yc = torch.empty(Mc, 64, device=DEV)
+    for _ in range(4):
+        ops.linear_fwd(Xc, Wc, None, Yc, None)
+    del Xc, Yc
+    M, N, K = 24576, 512, 512
+    X = torch.randn(M, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    b = torch.randn(N, device=DEV)
+    Y = torch.empty(M, N, device=DEV)
+    dZ = torch.randn(M, N, device=DEV)
+    dX = torch.empty(M, K, device=DEV)
+    dW, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    ws = torch.empty(ops.wgrad_workspace_bytes(M, N, K) // 4, device=DEV)
+    flush = torch.empty(96 * 1024 * 1024, device=DEV)            # 384 MB: evicts L2 / Infinity Cache between launches
+    for _ in range(6):
+        flush.fill_(1.0)
+        ops.linear_fwd(X, W, b, Y, "relu")
+        flush.fill_(2.0)
+        ops.linear_dgrad(dZ, W, dX, X, "relu")
+        flush.fill_(3.0)
+        ops.linear_wgrad(dZ, X, dW, db, ws)
 elif what == "scorer":
     inp = {k: v.to(DEV) for k, v in S.scorer_inputs(98304, seed=1).items()}
     for _ in range(10):
