@@ -175,6 +175,7 @@ def seg(t: torch.Tensor | None, col0: int, width: int, gather: bool = False, acc
     else:
         assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32
         s.ptr, s.ld = ptr(t), (t.stride(0) if ld is None else ld)
+        s._keep = t                    # the descriptor holds a raw pointer: keep the tensor alive with it
     s.col0, s.width, s.gather, s.accumulate = col0, width, int(gather), int(accumulate)
     return s
 
@@ -187,6 +188,8 @@ def segmat(segs, idx: torch.Tensor | None = None) -> DtcSegMat:
     m.idx = cptr(idx, torch.int64) if idx is not None else None
     for i, s in enumerate(segs):
         m.seg[i] = s
+    # raw pointers inside: tie the lifetime of the tensors (incl. a temporary `idx.to(dev)`) to the descriptor
+    m._keep = (idx, [getattr(s, "_keep", None) for s in segs])
     return m
 
 
