@@ -59,6 +59,7 @@ class DtcProfRec(C.Structure):
 
 
 ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
+MAX_OPERAND_ELEMS = (1 << 29) - 1
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
@@ -174,6 +175,10 @@ def seg(t: torch.Tensor | None, col0: int, width: int, gather: bool = False, acc
         s.ptr, s.ld = None, 0
     else:
         assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32
+        if t.shape[0] * t.stride(0) > MAX_OPERAND_ELEMS:
+            # the GEMM loaders address an operand with 32-bit byte offsets (buffer loads): a source matrix, gathered
+            # or not, must stay below 2 GiB -- e.g. privileged observations [T*N, 1389]: T*N <= 386 000 rows per GPU
+            raise DtcError(f"operand of {t.shape[0]} x {t.stride(0)} floats exceeds 2^29 elements (2 GiB); shard the rollout")
         s.ptr, s.ld = ptr(t), (t.stride(0) if ld is None else ld)
         s._keep = t                    # the descriptor holds a raw pointer: keep the tensor alive with it
     s.col0, s.width, s.gather, s.accumulate = col0, width, int(gather), int(accumulate)

@@ -114,3 +114,24 @@ def test_synthetic_inputs_are_deterministic():
     assert sorted(p.tolist()) == list(range(192)) and e1.shape == (20, 48, 16)
     pts = S.height_points()
     assert pts.shape == (693, 3) and float(pts[21, 0]) == pytest.approx(-0.75) and float(pts[1, 1]) == pytest.approx(-0.45)
+
+
+def test_oversized_gemm_operand_is_rejected_loudly():
+    """32-bit buffer offsets: a source matrix above 2 GiB must raise, never wrap around (gathered sources cannot be
+    bounded by the C side, which does not know their row count)."""
+    import torch
+    from dtc_amd import _ffi
+    big = torch.empty(0, 1389).new_empty((0,))                      # no memory: a fake tensor-like with the right metadata
+
+    class Fake:
+        shape = (400000, 1389)
+        dtype = torch.float32
+        is_cuda = True
+        def dim(self): return 2
+        def stride(self, i): return (1389, 1)[i]
+        def data_ptr(self): return 4096
+    with pytest.raises(_ffi.DtcError, match="2 GiB"):
+        _ffi.seg(Fake(), 0, 693, gather=True)
+    ok = Fake()
+    ok.shape = (98304, 1389)
+    assert _ffi.seg(ok, 0, 693, gather=True).width == 693
