@@ -238,6 +238,10 @@ class PPO:
         self.overlap_wgrad = os.environ.get("DTC_OVERLAP_WGRAD", "1") != "0"
         # two compute lanes (needs the side stream: both lanes' weight gradients share one partials workspace)
         self.overlap_lanes = os.environ.get("DTC_OVERLAP_LANES", "1") != "0"
+        # rollout step (policy sample + value + log-prob) replayed from a HIP graph: OFF by default -- measured slower
+        # than the eager launches on ROCm 7.2 (793 k vs 829 k env-steps/s end to end, tools/soak.py); DTC_ROLLOUT_GRAPH=1
+        self.graph_rollout = os.environ.get("DTC_ROLLOUT_GRAPH", "0") == "1"
+        self._rollout_graphs = {}
         self.capture_grads, self.captured = False, {}      # tests: snapshot of the (pre-clip) gradient arena
         self.last_update_stats = None      # [steps, STAT_COLS] table of the last update (host tensor)
 
@@ -264,14 +268,46 @@ class PPO:
         self.actor_critic.train()
 
     # ---------------------------------------------------------------- rollout side (ppo.py:137-172)
+    def _policy_step(self, obs, privileged_obs, obs_history, base_vel, rew_buf=None):
+        """The kernels of one rollout step (ppo.py:137-155): policy sample, value, log-prob."""
+        ac = self.actor_critic
+        actions = ac.act(obs, obs_history, privileged_obs, rew_buf).detach()
+        values = ac.evaluate(obs, privileged_obs, base_vel).detach()
+        logp = ac.get_actions_log_prob(actions).detach()
+        return actions, values, logp, ac.action_mean.detach(), ac.action_std.detach()
+
+    def _policy_step_graphed(self, obs, privileged_obs, obs_history, base_vel):
+        """Same kernels replayed from a HIP graph (about 25 launch-bound kernels on [N, .] rows per env step):
+        captured once per batch size after a warm-up call; inputs are copied into the capture's static buffers."""
+        key = (obs.shape[0], obs.device)
+        g = self._rollout_graphs.get(key)
+        if g is None:
+            ins = [torch.empty_like(t, memory_format=torch.contiguous_format).float() for t in (obs, privileged_obs, obs_history, base_vel)]
+            for dst, src in zip(ins, (obs, privileged_obs, obs_history, base_vel)):
+                dst.copy_(src)
+            s = torch.cuda.Stream(device=obs.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):                               # warm-up: workspaces, lazy initialisation
+                self._policy_step(*ins)
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._policy_step(*ins)
+            g = self._rollout_graphs[key] = (graph, ins, outs)
+        graph, ins, outs = g
+        for dst, src in zip(ins, (obs, privileged_obs, obs_history, base_vel)):
+            dst.copy_(src)
+        graph.replay()
+        return outs
+
     def act(self, obs, privileged_obs, obs_history, base_vel, rew_buf=None):
         self._require_gpu()
-        ac, tr = self.actor_critic, self.transition
-        tr.actions = ac.act(obs, obs_history, privileged_obs, rew_buf).detach()
-        tr.values = ac.evaluate(obs, privileged_obs, base_vel).detach()
-        tr.actions_log_prob = ac.get_actions_log_prob(tr.actions).detach()
-        tr.action_mean = ac.action_mean.detach()
-        tr.action_sigma = ac.action_std.detach()
+        tr = self.transition
+        if self.graph_rollout and type(self).act is PPO.act and not self.actor_critic.is_recurrent:
+            out = self._policy_step_graphed(obs, privileged_obs, obs_history, base_vel)
+        else:
+            out = self._policy_step(obs, privileged_obs, obs_history, base_vel, rew_buf)
+        tr.actions, tr.values, tr.actions_log_prob, tr.action_mean, tr.action_sigma = out
         tr.observations = obs
         tr.critic_observations = obs
         tr.privileged_observations = privileged_obs

@@ -429,3 +429,35 @@ def test_overlapped_schedule_equals_serial_schedule_bitwise():
         assert torch.equal(results[0][1], other[1])
         for k, v in results[0][2].items():
             assert torch.equal(v, other[2][k]), k
+
+
+def test_graphed_rollout_step_matches_eager_kernels():
+    """PPO.act replays the rollout-step kernels from a HIP graph: the value head (no random draw) must equal the eager
+    launch bit for bit on fresh inputs at every replay, the sampled actions must be fresh draws with a consistent
+    log-probability, and the stored transition must hold exactly what act() returned."""
+    from dtc_amd.algorithms import PPO
+    from dtc_amd.modules import ActorCriticDecoder
+    n = 512
+    torch.manual_seed(3)
+    ac = ActorCriticDecoder(53, 1389, 12)
+    alg = PPO(ac, learning_rate=1e-3, device=DEV)
+    alg.graph_rollout = True                      # optional mode (off by default: not faster than eager launches)
+    alg.init_storage(n, 4, [53], [1389], [265], [12])
+    d = S.rollout(n, 4, seed=9, device=DEV)
+    prev = None
+    for t in range(4):
+        args = (d["observations"][t], d["privileged_observations"][t], d["observation_histories"][t], d["base_vel"][t])
+        actions = alg.act(*args)
+        tr = alg.transition
+        want_v = ac.evaluate(args[0], args[1], args[3])
+        assert torch.equal(tr.values, want_v)
+        mean, sigma = tr.action_mean, tr.action_sigma
+        logp = torch.distributions.Normal(mean, sigma).log_prob(actions).sum(-1)
+        np.testing.assert_allclose(tr.actions_log_prob.cpu().numpy(), logp.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        assert prev is None or not torch.equal(prev, actions)             # fresh noise at every replay
+        prev = actions.clone()
+        snap = {k: getattr(tr, k).clone() for k in ("actions", "values", "action_mean")}
+        alg.process_env_step(d["rewards"][t, :, 0], d["dones"][t, :, 0], d["next_observations"][t], {})
+        assert torch.equal(alg.storage.actions[t], snap["actions"]) and torch.equal(alg.storage.values[t], snap["values"])
+        assert torch.equal(alg.storage.mu[t], snap["action_mean"])
+    assert len(alg._rollout_graphs) == 1
