@@ -22,14 +22,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make(rank, world, full):
+def _make(rank, world, full, kind="decoder"):
     from dtc_amd import distributed as dp
-    from dtc_amd.algorithms import PPO
-    from dtc_amd.modules import ActorCriticDecoder
+    from dtc_amd.algorithms import PPO, RecurrentDecoderPPO
+    from dtc_amd.modules import ActorCriticDecoder, ActorCriticDecoderRecurrent
     dev = "cuda:0"
     torch.manual_seed(3)
-    ac = ActorCriticDecoder(53, 1389, 12)
-    alg = PPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
+    if kind == "composite":                       # BASELINE config 5: the 8-GPU data-parallel model
+        ac = ActorCriticDecoderRecurrent(53, 1389, 12)
+        alg = RecurrentDecoderPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
+    else:
+        ac = ActorCriticDecoder(53, 1389, 12)
+        alg = PPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
     alg.init_storage(N_PER_RANK, 24, [53], [1389], [265], [12])
     lo, hi = dp.shard_range(N_PER_RANK * world, rank, world)
     for k, v in full.items():
@@ -37,23 +41,30 @@ def _make(rank, world, full):
             getattr(alg.storage, k).copy_(v[:, lo:hi].to(dev))
     alg.storage.compute_returns(full["last_values"][lo:hi].to(dev), 0.99, 0.95)
     alg.storage.step = 24
+    if kind == "composite":
+        g = torch.Generator().manual_seed(55)
+        hid = [0.1 * torch.randn(24, 1, N_PER_RANK * world, 512, generator=g)[:, :, lo:hi].contiguous().to(dev) for _ in range(2)]
+        alg.storage.saved_hidden_states_a, alg.storage.saved_hidden_states_c = [hid[0]], [hid[1]]
     return alg
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, kind="decoder"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dtc_amd import synthetic as S
         torch.cuda.set_device(0)
         full = S.rollout(N_PER_RANK * world, 24, seed=4)
-        alg = _make(rank, world, full)
+        alg = _make(rank, world, full, kind)
         adv = alg.storage.advantages.cpu().clone()
         g = torch.Generator().manual_seed(100 + rank)                 # rank-local permutation and noise (§8e)
         B = N_PER_RANK * 24 // 4
         perm = torch.randperm(4 * B, generator=g)
         e1, e2 = torch.randn(20, B, 16, generator=g), torch.randn(20, B, 16, generator=g)
-        alg.update(perm.cuda(), e1.cuda(), e2.cuda())
+        if kind == "composite":
+            alg.update(e1.cuda(), e2.cuda())          # recurrent mini-batches: env slices, no permutation
+        else:
+            alg.update(perm.cuda(), e1.cuda(), e2.cuda())
         out[rank] = dict(flat=alg.actor_critic.arena.flat.cpu().clone(), lr=alg.learning_rate,
                          m=alg.optimizer.exp_avg.cpu().clone(), v=alg.vae_optimizer.exp_avg_sq.cpu().clone(), adv=adv,
                          perm=perm, e1=e1, e2=e2)
@@ -61,12 +72,13 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_ranks_stay_bit_identical_and_exchange_gradients():
+@pytest.mark.parametrize("kind", ["decoder", "composite"])
+def test_two_ranks_stay_bit_identical_and_exchange_gradients(kind):
     from dtc_amd import synthetic as S
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, out)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, out, kind)) for r in range(WORLD)]
     for p in procs:
         p.start()
     for p in procs:
@@ -81,6 +93,9 @@ def test_two_ranks_stay_bit_identical_and_exchange_gradients():
     assert abs(float(adv.mean())) < 1e-6 and abs(float(adv.std()) - 1.0) < 1e-5
     # a rank-local update on the same shard / permutation / noise ends elsewhere: the exchange happened
     full = S.rollout(N_PER_RANK * WORLD, 24, seed=4)
-    solo = _make(0, 1, {k: (v[:, :N_PER_RANK] if k != "last_values" else v[:N_PER_RANK]) for k, v in full.items()})
-    solo.update(a["perm"].cuda(), a["e1"].cuda(), a["e2"].cuda())
+    solo = _make(0, 1, {k: (v[:, :N_PER_RANK] if k != "last_values" else v[:N_PER_RANK]) for k, v in full.items()}, kind)
+    if kind == "composite":
+        solo.update(a["e1"].cuda(), a["e2"].cuda())
+    else:
+        solo.update(a["perm"].cuda(), a["e1"].cuda(), a["e2"].cuda())
     assert not torch.equal(solo.actor_critic.arena.flat.cpu(), a["flat"])
