@@ -98,6 +98,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if local_rank == 0 or "LOCAL_RANK" not in os.environ:     # in-tree library: (re)build when missing / stale (no-op otherwise)
+        import build as dtc_build
+        dtc_build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
     from dtc_amd import _ffi, foothold, synthetic as S
     from dtc_amd.algorithms import PPO, RecurrentDecoderPPO, RecurrentPPO
     from dtc_amd.modules import ActorCriticDecoder, ActorCriticDecoderRecurrent, ActorCriticRecurrent

@@ -22,3 +22,12 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The tests exercise libdtc_hip.so through its C ABI; (re)build it in-tree when it is missing or older than its
+    sources (hipcc cross-compiles gfx950 without a GPU).  The product itself never builds or falls back: a missing
+    library raises DtcError (tests/test_abi_and_host.py)."""
+    import build as dtc_build
+    dtc_build.build(verbose=False)
