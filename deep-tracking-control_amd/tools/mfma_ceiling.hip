@@ -60,6 +60,9 @@ __global__ __launch_bounds__(256, OCC) void probe(const float* __restrict__ src,
             for (int i = 0; i < NB; ++i)
                 rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res, (int)boff[i], (int)soff, 0));
         }
+#ifdef PROBE_FENCE
+        __builtin_amdgcn_sched_barrier(0);      // keep the global loads ahead of the MFMA phase
+#endif
         if (V == 0) {
 #pragma unroll
             for (int kp = 0; kp < BK / 2; ++kp)
