@@ -241,6 +241,9 @@ class PPO:
         # rollout step (policy sample + value + log-prob) replayed from a HIP graph: OFF by default -- measured slower
         # than the eager launches on ROCm 7.2 (793 k vs 829 k env-steps/s end to end, tools/soak.py); DTC_ROLLOUT_GRAPH=1
         self.graph_rollout = os.environ.get("DTC_ROLLOUT_GRAPH", "0") == "1"
+        # data parallel: per-bucket gradient all-reduce on the weight-gradient stream, overlapping the rest of the
+        # backward pass (DTC_DP_OVERLAP=0: one all-reduce per optimiser step after the join)
+        self.overlap_exchange = os.environ.get("DTC_DP_OVERLAP", "1") != "0"
         self._rollout_graphs = {}
         self.capture_grads, self.captured = False, {}      # tests: snapshot of the (pre-clip) gradient arena
         self.last_update_stats = None      # [steps, STAT_COLS] table of the last update (host tensor)
@@ -345,6 +348,19 @@ class PPO:
     def _allreduce_grads(self, opt):
         dp.allreduce_mean_(opt.g)        # one flat bucket per optimiser step (no-op on a single rank)
 
+    def _exchange_bucket(self, tw, name):
+        """Data parallel: average gradient bucket `name` of the arena over the ranks as soon as its last weight
+        gradient has been queued.  All weight gradients of this trainer run on the side stream, so the all-reduce is
+        issued THERE: it is ordered after them and overlaps the data-gradient chain still running on the compute lanes
+        (the decoders' / heads' bucket travels while the encoders run backward).  Returns True when it took place."""
+        if self._world() == 1 or not (self.overlap_exchange and self.overlap_wgrad):
+            return False
+        lo, hi = self.actor_critic.arena.buckets[name]
+        with torch.cuda.stream(tw.side):
+            dp.allreduce_mean_(self.actor_critic.arena.grad[lo:hi])
+        tw.side_busy = True
+        return True
+
     def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None):
         """Backward of one dense layer.  The weight gradient (dW = dZ^T X, + split reduction) is off the critical
         path -- only the optimiser step needs it -- so it goes to the side stream and overlaps with the
@@ -417,13 +433,17 @@ class PPO:
         tw.order("main", "aux")                                    # d l_t of the terrain decoder is written first
         with tw.lane("aux"):
             self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None)
+        early = self._exchange_bucket(tw, "vae_only")              # decoder gradients are complete (queued on `side`)
         tw.order("aux", "main")                                    # d l_t complete
         self._terrain_encoder_backward(fw, tw, flat, idx)
         with tw.lane("aux"):
             ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
             self._cenet_encoder_backward(fw, tw, flat, idx)
+        if early:
+            self._exchange_bucket(tw, "shared")
         self._join(tw)
-        self._allreduce_grads(self.vae_optimizer)
+        if not early:
+            self._allreduce_grads(self.vae_optimizer)
         if self.capture_grads:
             self.captured["vae"] = ac.arena.grad.clone()
         self.vae_optimizer.step(self.max_grad_norm, stats[S_VAE_GNORM:S_VAE_GNORM + 1])
@@ -467,13 +487,17 @@ class PPO:
         tw.dmulv.zero_()
         dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
         self._bwd(tw, L["a0"], g_a1, ac.actor_input(fw, flat["observations"], idx), dst, None, None)
+        early = self._exchange_bucket(tw, "main_only")             # actor + critic + std gradients are complete
         ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
         tw.order("main", "aux")                                    # d(mu|lv) ready for the CE-net encoder
         self._terrain_encoder_backward(fw, tw, flat, idx)
         with tw.lane("aux"):
             self._cenet_encoder_backward(fw, tw, flat, idx)
+        if early:
+            self._exchange_bucket(tw, "shared")
         self._join(tw)
-        self._allreduce_grads(self.optimizer)
+        if not early:
+            self._allreduce_grads(self.optimizer)
         if self.capture_grads:
             self.captured["main"] = ac.arena.grad.clone()
         self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])

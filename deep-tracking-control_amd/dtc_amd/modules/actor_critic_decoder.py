@@ -127,6 +127,9 @@ class ParamArena:
         n_vae = sum(named[k].numel() for k in vae_only)
         self.main_range = (0, n_main + n_shared)
         self.vae_range = (n_main, n_main + n_shared + n_vae)
+        # the three gradient buckets of the data-parallel exchange, in backward-pass completion order per step
+        self.buckets = dict(main_only=(0, n_main), shared=(n_main, n_main + n_shared),
+                            vae_only=(n_main + n_shared, n_main + n_shared + n_vae))
         self.order = order
 
     def view(self, buf, name):

@@ -48,7 +48,7 @@ def _make(rank, world, full, kind="decoder"):
     return alg
 
 
-def _worker(rank, world, port, out, kind="decoder"):
+def _worker(rank, world, port, out, kind="decoder", overlap_exchange=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -56,6 +56,7 @@ def _worker(rank, world, port, out, kind="decoder"):
         torch.cuda.set_device(0)
         full = S.rollout(N_PER_RANK * world, 24, seed=4)
         alg = _make(rank, world, full, kind)
+        alg.overlap_exchange = overlap_exchange
         adv = alg.storage.advantages.cpu().clone()
         g = torch.Generator().manual_seed(100 + rank)                 # rank-local permutation and noise (§8e)
         B = N_PER_RANK * 24 // 4
@@ -99,3 +100,24 @@ def test_two_ranks_stay_bit_identical_and_exchange_gradients(kind):
     else:
         solo.update(a["perm"].cuda(), a["e1"].cuda(), a["e2"].cuda())
     assert not torch.equal(solo.actor_critic.arena.flat.cpu(), a["flat"])
+
+
+def test_bucketed_exchange_on_the_side_stream_equals_one_exchange_after_the_join():
+    """PPO exchanges each gradient bucket on the weight-gradient stream as soon as its last weight gradient is queued
+    (overlapping the rest of the backward pass); the result must be bit-identical to one all-reduce per optimiser
+    step after the join."""
+    ctx = mp.get_context("spawn")
+    results = []
+    for overlap in (True, False):
+        out = ctx.Manager().dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, WORLD, port, out, "decoder", overlap)) for r in range(WORLD)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        assert torch.equal(out[0]["flat"], out[1]["flat"])
+        results.append(out[0])
+    assert torch.equal(results[0]["flat"], results[1]["flat"]) and results[0]["lr"] == results[1]["lr"]
+    assert torch.equal(results[0]["m"], results[1]["m"]) and torch.equal(results[0]["v"], results[1]["v"])
