@@ -121,3 +121,37 @@ def test_bucketed_exchange_on_the_side_stream_equals_one_exchange_after_the_join
         results.append(out[0])
     assert torch.equal(results[0]["flat"], results[1]["flat"]) and results[0]["lr"] == results[1]["lr"]
     assert torch.equal(results[0]["m"], results[1]["m"]) and torch.equal(results[0]["v"], results[1]["v"])
+
+
+def _rccl_worker(port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        side = torch.cuda.Stream()
+        g = torch.arange(1 << 20, dtype=torch.float32, device="cuda:0")
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(side):                     # the pattern of PPO._exchange_bucket on the real backend
+            g.mul_(2.0)
+            dist.all_reduce(g[1000:500000])
+            g[1000:500000].mul_(1.0)
+            ev.record(side)
+        torch.cuda.current_stream().wait_event(ev)
+        s = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+        dist.all_reduce(s)                                # the float64 statistics all-reduce of the storage
+        dist.barrier()
+        out["ok"] = bool(torch.equal(g.cpu(), torch.arange(1 << 20, dtype=torch.float32) * 2.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_accepts_the_collective_pattern_of_the_trainer():
+    """RCCL itself (backend "nccl"), one rank: an all-reduce of a slice of a flat buffer issued inside a side-stream
+    context, followed by an in-place scale, an event join, a float64 all-reduce and a barrier -- the exact call pattern
+    of the data-parallel trainer -- initialises and runs on this box."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0 and out.get("ok") is True
