@@ -170,15 +170,36 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN]
 // ------------------------------------------------------------------------------------------
 // Forward: Y[M,N] = act(X[M,K] W[N,K]^T + b)
 // ------------------------------------------------------------------------------------------
-template <int BN>
+// optional loss epilogue of the forward kernel (dtc_linear_fwd_mse): the layer output feeds an MSE against a
+// row-gathered target; the epilogue writes dL/dY instead of Y and one double partial of sum(e^2) per workgroup
+struct MseEpi {
+    const float* target;
+    const long long* tidx;
+    long long ldt;
+    long long target_bytes;
+    int tcol0;
+    float scale;
+    double* part;
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int BN, bool MSE = false>
 __global__ __launch_bounds__(256, 3) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ Y,
-                                                         long long ldy, int M, int N, int K, int act) {
+                                                         long long ldy, int M, int N, int K, int act, const MseEpi mse) {
     using C = Cfg<BN>;
     __shared__ float As[2][BK][C::LDA];
     __shared__ float Bs[2][BK][C::LDB];
     int tr, tc;
-    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, tr, tc)) return;
+    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, tr, tc)) {
+        if (MSE && threadIdx.x == 0) mse.part[blockIdx.x] = 0.0;      // padding block: its partial slot still gets summed
+        return;
+    }
     const int m0 = tr * BM, n0 = tc * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
@@ -261,6 +282,44 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_kernel(const SegMatDev X, c
 
     const int half = lane >> 5, l31 = lane & 31;
     const bool full = (m0 + BM <= M) && (n0 + BN <= N);
+    if (MSE) {
+        // e = (acc + bias) - target[tidx[row], tcol0 + col];  dY = e * scale;  partial = sum e^2 (double)
+        const rsrc_t tres = make_rsrc_bytes(mse.target, mse.target_bytes);
+        double sq = 0.0;
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) {
+            const int col = n0 + wn_off + 32 * j + l31;
+            const bool cok = col < N;
+            const float bv = (bias && cok) ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) {
+                const int row0 = m0 + wm_off + 32 * i + 4 * half;
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {          // 16 gathered target loads in flight (rows past M read row 0, masked below)
+                    const int row = row0 + (r & 3) + 8 * (r >> 2);
+                    const long long src = mse.tidx[row < M ? row : 0];
+                    t[r] = bload(tres, (u32)((src * mse.ldt + mse.tcol0 + col) * 4) | (cok ? 0u : INVALID), 0u);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2);
+                    if (cok && row < M) {
+                        const float e = (acc[i][j][r] + bv) - t[r];
+                        Y[(long long)row * ldy + col] = e * mse.scale;
+                        sq += (double)e * (double)e;
+                    }
+                }
+            }
+        }
+        sq = wave_sum_f64(sq);
+        double* red = reinterpret_cast<double*>(&As[0][0][0]);
+        __syncthreads();                                // all waves are past their last LDS read
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) mse.part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
         const int col = n0 + wn_off + 32 * j + l31;
@@ -791,10 +850,35 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     const int bn = pick_bn_rows(M, N);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, bn));
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s);
-    if (bn == 128) hipLaunchKernelGGL(linear_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
-    else if (bn == 64) hipLaunchKernelGGL(linear_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
-    else hipLaunchKernelGGL(linear_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act);
+    if (bn == 128) hipLaunchKernelGGL((linear_fwd_kernel<128, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, MseEpi{});
+    else if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, MseEpi{});
+    else hipLaunchKernelGGL((linear_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, MseEpi{});
     return dtc::check_launch("linear_fwd");
+}
+
+extern "C" int64_t dtc_linear_fwd_mse_parts(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 64));
+}
+
+extern "C" int dtc_linear_fwd_mse(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
+                                  int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
+                                  double* sq_part, int M, int N, int K, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N, "bad shape M=%d N=%d K=%d", M, N, K);
+    DTC_REQUIRE(W && target && tidx && dY && sq_part, "null pointer");
+    DTC_REQUIRE(tcol0 >= 0 && tcol0 + N <= ldt && target_rows > 0, "target columns [%d, %d) outside its %lld-wide rows", tcol0,
+                tcol0 + N, (long long)ldt);
+    DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * lddy <= MAX_ELEMS && target_rows * ldt <= MAX_ELEMS, "matrix too large");
+    SegMatDev xd;
+    int rc = to_dev(X, xd, K, false, M);
+    if (rc != DTC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 64));
+    const MseEpi mse{target, (const long long*)tidx, (long long)ldt, target_rows * ldt * 4, tcol0, scale, sq_part};
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s);
+    hipLaunchKernelGGL((linear_fwd_kernel<64, true>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy, M, N, K,
+                       (int)DTC_ACT_NONE, mse);
+    return dtc::check_launch("linear_fwd_mse");
 }
 
 extern "C" int dtc_gru_step_fwd(const float* hprev, const float* W_hh, const float* b_hh, const float* gi_t, float* hout,

@@ -108,12 +108,15 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
     }
 }
 
+// hpart / nh: optional extra partials of the height term (one double per workgroup of the fused terrain-decoder layer)
 __global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const double* __restrict__ part, int nblk, int B,
-                                                                float* __restrict__ losses) {
+                                                                float* __restrict__ losses,
+                                                                const double* __restrict__ hpart, int nh) {
     __shared__ double sh[4];
     double a[4] = {0, 0, 0, 0};
     for (int i = threadIdx.x; i < nblk; i += blockDim.x)
         for (int k = 0; k < 4; ++k) a[k] += part[(long long)i * 4 + k];
+    for (int i = threadIdx.x; i < nh; i += blockDim.x) a[3] += hpart[i];
     for (int k = 0; k < 4; ++k) a[k] = block_sum_d(a[k], sh);
     if (threadIdx.x == 0) {
         losses[0] = (float)(a[0] / ((double)OBS * B));   // recons
@@ -295,8 +298,28 @@ extern "C" int dtc_vae_loss(const float* recons, const float* hrecon, const floa
     dtc::ProfScope prof("vae_loss", (double)B * (HGT * 12.0 + OBS * 12.0 + LD * 8.0), s);
     hipLaunchKernelGGL(vae_loss_kernel, dim3(nblk), dim3(256), 0, s, recons, hrecon, mulv, next_obs, priv, base_vel,
                        (const long long*)idx, d_recons, d_hrecon, dmulv, part, B, nb_h, nb_r);
-    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, B, losses);
+    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, B, losses, (const double*)nullptr, 0);
     return dtc::check_launch("vae_loss");
+}
+
+extern "C" int dtc_vae_loss_fused(const float* recons, const float* mulv, const float* next_obs, const float* base_vel,
+                                  const int64_t* idx, float* d_recons, float* dmulv, const double* height_sq_part,
+                                  int n_height_part, float* losses, void* workspace, int B, void* stream) {
+    DTC_REQUIRE(B > 0 && n_height_part >= 0, "bad batch %d", B);
+    DTC_REQUIRE(recons && mulv && next_obs && base_vel && idx, "null input");
+    DTC_REQUIRE(d_recons && dmulv && losses && workspace && (height_sq_part || n_height_part == 0), "null output");
+    hipStream_t s = (hipStream_t)stream;
+    int nb_r = (int)dtc::ceil_div(B, 4 * 16);
+    const int nb_l = (int)dtc::ceil_div(B, 256);
+    if (nb_r > 512) nb_r = 512;
+    const int nblk = nb_r + nb_l;
+    DTC_REQUIRE(nblk <= MAX_BLK, "batch too large for the loss workspace");
+    double* part = (double*)workspace;
+    dtc::ProfScope prof("vae_loss", (double)B * (OBS * 12.0 + LD * 8.0), s);
+    hipLaunchKernelGGL(vae_loss_kernel, dim3(nblk), dim3(256), 0, s, recons, (const float*)nullptr, mulv, next_obs,
+                       (const float*)nullptr, base_vel, (const long long*)idx, d_recons, (float*)nullptr, dmulv, part, B, 0, nb_r);
+    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, B, losses, height_sq_part, n_height_part);
+    return dtc::check_launch("vae_loss_fused");
 }
 
 extern "C" int dtc_ppo_loss(const float* mean, const float* std, const float* value, const float* actions,

@@ -97,6 +97,11 @@ _SIGS = {
                                        c_stream]),
     "dtc_loss_workspace": (C.c_int64, [C.c_int]),
     "dtc_vae_loss": (C.c_int, [c_f32p] * 6 + [c_i64p] + [c_f32p] * 4 + [C.c_void_p, C.c_int, c_stream]),
+    "dtc_linear_fwd_mse_parts": (C.c_int64, [C.c_int, C.c_int]),
+    "dtc_linear_fwd_mse": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, c_i64p,
+                                     C.c_float, c_f32p, C.c_int64, c_f64p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_vae_loss_fused": (C.c_int, [c_f32p] * 4 + [c_i64p] + [c_f32p] * 2 + [c_f64p, C.c_int, c_f32p, C.c_void_p, C.c_int,
+                                                                             c_stream]),
     "dtc_ppo_loss": (C.c_int, [c_f32p] * 10 + [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 4 +
                      [c_f64p, C.c_void_p, C.c_int, C.c_int, c_stream]),
     "dtc_lr_adapt": (C.c_int, [c_f32p, c_f64p, C.c_float, c_stream]),

@@ -186,6 +186,7 @@ class _TrainWorkspace(_Lanes):
                   (128, 64), (53, 128), (128, 265), (64, 128), (35, 64), (num_actions, 128), (1, 128)]
         self.wg = ops.workspace(max(lib.dtc_linear_wgrad_workspace(B, n, k) for n, k in shapes), dev)
         self.loss_ws = ops.workspace(lib.dtc_loss_workspace(B), dev)
+        self.hpart = torch.zeros(int(lib.dtc_linear_fwd_mse_parts(B, 693)), dtype=torch.float64, device=dev)
 
     def wgrad_ws(self, N, K):
         """Split-partials workspace, grown on demand (rare: first use of a larger layer shape)."""
@@ -244,6 +245,8 @@ class PPO:
         # data parallel: per-bucket gradient all-reduce on the weight-gradient stream, overlapping the rest of the
         # backward pass (DTC_DP_OVERLAP=0: one all-reduce per optimiser step after the join)
         self.overlap_exchange = os.environ.get("DTC_DP_OVERLAP", "1") != "0"
+        # terrain-decoder output layer fused with the height loss (DTC_FUSE_HEIGHT_LOSS=0: separate layer + loss kernel)
+        self.fuse_height_loss = os.environ.get("DTC_FUSE_HEIGHT_LOSS", "1") != "0"
         self._rollout_graphs = {}
         self.capture_grads, self.captured = False, {}      # tests: snapshot of the (pre-clip) gradient arena
         self.last_update_stats = None      # [steps, STAT_COLS] table of the last update (host tensor)
@@ -414,10 +417,18 @@ class PPO:
             ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None)
         ops.linear_fwd(fw.lt, L["td0"].W, L["td0"].b, tw.d1, "relu")
         ops.linear_fwd(tw.d1, L["td1"].W, L["td1"].b, tw.d2, "relu")
-        ops.linear_fwd(tw.d2, L["td2"].W, L["td2"].b, tw.hr, None)
-        tw.order("aux", "main")
-        ops.vae_loss(tw.rec, tw.hr, fw.mulv, flat["next_observations"], flat["privileged_observations"],
-                     flat["base_vel"], idx, tw.g_rec, tw.g_hr, tw.dmulv, stats[S_RECONS:S_RECONS + 4], tw.loss_ws)
+        if self.fuse_height_loss:
+            # output layer of the terrain decoder + its MSE against priv[..., 696:] in one kernel: dL/d height_recon comes
+            # out of the GEMM epilogue, height_recon itself never reaches HBM
+            n_hp = ops.linear_fwd_mse(tw.d2, L["td2"].W, L["td2"].b, flat["privileged_observations"], 696, idx, tw.g_hr, tw.hpart)
+            tw.order("aux", "main")
+            ops.vae_loss_fused(tw.rec, fw.mulv, flat["next_observations"], flat["base_vel"], idx, tw.g_rec, tw.dmulv,
+                               tw.hpart, n_hp, stats[S_RECONS:S_RECONS + 4], tw.loss_ws)
+        else:
+            ops.linear_fwd(tw.d2, L["td2"].W, L["td2"].b, tw.hr, None)
+            tw.order("aux", "main")
+            ops.vae_loss(tw.rec, tw.hr, fw.mulv, flat["next_observations"], flat["privileged_observations"],
+                         flat["base_vel"], idx, tw.g_rec, tw.g_hr, tw.dmulv, stats[S_RECONS:S_RECONS + 4], tw.loss_ws)
         tw.order("main", "aux")
         # terrain decoder (main)
         g_td2, g_td1 = tw.g("td2", 512), tw.g("td1", 512)

@@ -140,6 +140,28 @@ def vae_loss(recons, hrecon, mulv, next_obs, priv, base_vel, idx, d_recons, d_hr
                              cptr(d_hrecon, f32), cptr(dmulv, f32), ptr(losses), ptr(ws), B, stream()), "dtc_vae_loss")
 
 
+def linear_fwd_mse(X, W, b, target, tcol0, tidx, dY, sq_part, M=None):
+    """Output layer fused with its MSE loss: dY = 2/(M*N) * ((X W^T + b) - target[tidx, tcol0:tcol0+N]); sum of squared
+    errors per workgroup into `sq_part` (float64, >= mse_parts(M, N) slots)."""
+    Xs = as_segmat(X)
+    N, K = W.shape
+    M = dY.shape[0] if M is None else M
+    n_part = int(lib().dtc_linear_fwd_mse_parts(M, N))
+    if sq_part.numel() < n_part or sq_part.dtype != torch.float64:
+        raise _ffi.DtcError(f"sq_part needs {n_part} float64 slots")
+    check(lib().dtc_linear_fwd_mse(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, cptr(target, f32),
+                                   target.stride(0), target.shape[0], tcol0, cptr(tidx, torch.int64), 2.0 / (M * N),
+                                   ptr(dY), dY.stride(0), ptr(sq_part), M, N, K, stream()), "dtc_linear_fwd_mse")
+    return n_part
+
+
+def vae_loss_fused(recons, mulv, next_obs, base_vel, idx, d_recons, dmulv, height_sq_part, n_height_part, losses, ws):
+    B = recons.shape[0]
+    check(lib().dtc_vae_loss_fused(cptr(recons, f32), cptr(mulv, f32), cptr(next_obs, f32), cptr(base_vel, f32),
+                                   cptr(idx, torch.int64), cptr(d_recons, f32), cptr(dmulv, f32), ptr(height_sq_part),
+                                   n_height_part, ptr(losses), ptr(ws), B, stream()), "dtc_vae_loss_fused")
+
+
 def ppo_loss(mean, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, old_values, idx, cfg,
              dmean, dvalue, dstd, losses, lr, ws):
     B, A = mean.shape

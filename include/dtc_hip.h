@@ -208,6 +208,19 @@ int dtc_cenet_latent_bwd(float* dmulv, const float* dz, const float* eps, const 
 int dtc_vae_loss(const float* recons, const float* hrecon, const float* mulv, const float* next_obs,
                  const float* priv, const float* base_vel, const int64_t* idx, float* d_recons,
                  float* d_hrecon, float* dmulv, float* losses, void* workspace, int B, void* stream);
+
+/* The terrain-decoder output layer fused with its loss (ppo.py:216-218: height_recon = terrain_decoder(l_t),
+ * height_loss = mse(height_recon, priv[..., 696:])): e = (X W^T + b) - target[tidx[m], tcol0 + n]; writes
+ * dY[m,n] = e * scale (scale = 2/(M*N): dL/d height_recon) and one double per workgroup, sum(e^2), into sq_part
+ * (dtc_linear_fwd_mse_parts(M, N) slots).  height_recon itself never reaches HBM.  dtc_vae_loss_fused is dtc_vae_loss
+ * without the height term; it adds the partials (in index order) into losses[3]. */
+int64_t dtc_linear_fwd_mse_parts(int M, int N);
+int dtc_linear_fwd_mse(const DtcSegMat* X, const float* W, const float* b, const float* target /*[target_rows, ldt]*/,
+                       int64_t ldt, int64_t target_rows, int tcol0, const int64_t* tidx /*[M]*/, float scale, float* dY,
+                       int64_t lddy, double* sq_part, int M, int N, int K, void* stream);
+int dtc_vae_loss_fused(const float* recons, const float* mulv, const float* next_obs, const float* base_vel,
+                       const int64_t* idx, float* d_recons, float* dmulv, const double* height_sq_part, int n_height_part,
+                       float* losses, void* workspace, int B, void* stream);
 int64_t dtc_loss_workspace(int B);
 
 typedef struct DtcPpoCfg {
