@@ -188,12 +188,15 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__
         }
         dvalue[b] = cfg.value_loss_coef * dv * invB;
     }
-    double* p = part + (long long)blockIdx.x * (3 + MAX_ACT);
-    const double t_sur = block_sum_d(s_sur, sh), t_val = block_sum_d(s_val, sh), t_kl = block_sum_d(s_kl, sh);
-    if (threadIdx.x == 0) {
-        p[0] = t_sur;
-        p[1] = t_val;
-        p[2] = t_kl;
+    // all 3 + A block sums with ONE barrier: every wave reduces its values with shuffles, lane 0 parks them in LDS, then
+    // thread k adds the (at most 4) wave results of value k in wave order
+    __shared__ double red[4][3 + MAX_ACT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    double v0 = wave_sum_d(s_sur), v1 = wave_sum_d(s_val), v2 = wave_sum_d(s_kl);
+    if (lane == 0) {
+        red[wv][0] = v0;
+        red[wv][1] = v1;
+        red[wv][2] = v2;
     }
     for (int j = 0; j < A; ++j) {
         double ds = 0.0;
@@ -203,22 +206,30 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__
             dmean[(long long)b * A + j] = dlogp_scale * (d / (sg * sg));
             ds = (double)(dlogp_scale * ((d * d) / (sg * sg * sg) - 1.0f / sg));
         }
-        ds = block_sum_d(ds, sh);
-        if (threadIdx.x == 0) p[3 + j] = ds;
+        ds = wave_sum_d(ds);
+        if (lane == 0) red[wv][3 + j] = ds;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 3 + A) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += red[w][threadIdx.x];
+        part[(long long)blockIdx.x * (3 + MAX_ACT) + threadIdx.x] = t;
     }
 }
 
+// wave w owns the values k = w, w + 4, ...: lanes add the per-block partials in a fixed stride order, one shuffle
+// reduction per value, no block barrier
 __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(const double* __restrict__ part, int nblk, int B, int A,
                                                                 const float* __restrict__ stdp, DtcPpoCfg cfg,
                                                                 float* __restrict__ dstd, float* __restrict__ losses,
                                                                 double* __restrict__ lr) {
-    __shared__ double sh[4];
     const int stride = 3 + MAX_ACT;
-    for (int k = 0; k < 3 + A; ++k) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = wv; k < 3 + A; k += 4) {
         double a = 0.0;
-        for (int i = threadIdx.x; i < nblk; i += blockDim.x) a += part[(long long)i * stride + k];
-        a = block_sum_d(a, sh);
-        if (threadIdx.x == 0) {
+        for (int i = lane; i < nblk; i += 64) a += part[(long long)i * stride + k];
+        a = wave_sum_d(a);
+        if (lane == 0) {
             if (k == 0) losses[0] = (float)(a / B);
             else if (k == 1) losses[1] = (float)(a / B);
             else if (k == 2) {
