@@ -499,10 +499,10 @@ class PPO:
         dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
         self._bwd(tw, L["a0"], g_a1, ac.actor_input(fw, flat["observations"], idx), dst, None, None)
         early = self._exchange_bucket(tw, "main_only")             # actor + critic + std gradients are complete
-        ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
-        tw.order("main", "aux")                                    # d(mu|lv) ready for the CE-net encoder
-        self._terrain_encoder_backward(fw, tw, flat, idx)
+        tw.order("main", "aux")                                    # dz, d mu[:, :3] (and d l_t) are written
+        self._terrain_encoder_backward(fw, tw, flat, idx)          # needs d l_t only: starts right away on main
         with tw.lane("aux"):
+            ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
             self._cenet_encoder_backward(fw, tw, flat, idx)
         if early:
             self._exchange_bucket(tw, "shared")
