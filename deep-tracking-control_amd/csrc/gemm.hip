@@ -475,12 +475,14 @@ template <int BN>
 __global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __restrict__ dZ, long long lddz,
                                                            const float* __restrict__ W, const SegMatDev dX,
                                                            const float* __restrict__ Xs, long long ldxs, int M, int N,
-                                                           int K, int act, int split_n, long long split_dst) {
+                                                           int K, int act, int split_n, long long split_dst, int col_skip) {
     using C = Cfg<BN>;
     __shared__ float As[2][BK][C::LDA];
     __shared__ float Bs[2][BK][C::LDB];
     int tr, tc;
-    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (K + BN - 1) / BN, tr, tc)) return;
+    // col_skip: leading columns whose destination is NULL (inputs that need no gradient, e.g. the raw observations in
+    // front of the actor's features) -- the column tiles start behind them, nothing is computed for them
+    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (K - col_skip + BN - 1) / BN, tr, tc)) return;
     // split reduction (dtc_linear_dgrad_split): grid.y = chunk g of the reduction index; chunk g multiplies columns
     // [g*split_n, (g+1)*split_n) of dZ with the matching rows of W and writes its own destination matrix
     long long dst_off = 0;
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __res
         N = split_n;
         dst_off = (long long)blockIdx.y * split_dst;
     }
-    const int m0 = tr * BM, c0 = tc * BN;
+    const int m0 = tr * BM, c0 = col_skip + tc * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
 
@@ -906,12 +908,15 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
     int rc = to_dev(dX, xd, K, true, 0);
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int bn = pick_bn_rows(M, K);
-    const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K, bn));
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * K, s);
-    if (bn == 128) hipLaunchKernelGGL(linear_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll);
-    else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll);
-    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll);
+    int col_skip = 0;
+    for (int i = 0; i < xd.nseg && xd.s[i].ptr == nullptr; ++i) col_skip += xd.s[i].width;
+    DTC_REQUIRE(col_skip < K, "every destination segment is NULL");
+    const int bn = pick_bn_rows(M, K - col_skip);
+    const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K - col_skip, bn));
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s);
+    if (bn == 128) hipLaunchKernelGGL(linear_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip);
+    else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip);
     return dtc::check_launch("linear_dgrad");
 }
 
@@ -933,8 +938,8 @@ extern "C" int dtc_linear_dgrad_split(const float* dZ, int64_t lddz, const float
     const int bn = (K <= 32 || (long long)row_tiles * dtc::ceil_div(K, 64) * nsplit < 320) ? 32 : 64;
     const dim3 grid((unsigned)grid_for(row_tiles, (int)dtc::ceil_div(K, bn)), (unsigned)nsplit);
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * K, s);
-    if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride);
-    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride);
+    if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride, 0);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride, 0);
     return dtc::check_launch("linear_dgrad_split");
 }
 
