@@ -98,7 +98,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if local_rank == 0 or "LOCAL_RANK" not in os.environ:     # in-tree library: (re)build when missing / stale (no-op otherwise)
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:            # in-tree library: (re)build when missing / stale (no-op otherwise)
         import build as dtc_build
         dtc_build.build(verbose=False)
     if world > 1:
