@@ -148,13 +148,12 @@ def compute_observations(base_ang_vel, projected_gravity, commands, dof_pos, def
     takes with torch.rand_like (pass None to omit the noise term).  Returns dict(obs_buf, privileged_obs_buf, heights)."""
     cfg = cfg or ObsConfig()
     N, dev, P = root_states.shape[0], root_states.device, cfg.num_points
-    c = lambda t: None if t is None else _ffi.cptr(t.contiguous().float(), torch.float32)
     n_obs = 9 + 3 * cfg.num_dof + cfg.num_foothold_obs
     obs = torch.empty(N, n_obs, device=dev)
     priv = torch.empty(N, 2 * P + 3, device=dev)
     heights = torch.empty(N, P, device=dev)
     forces = forces.contiguous().float()
-    ld_f = forces[0].numel()
+    ld_f = forces.stride(0) if forces.dim() > 1 else 3          # floats between consecutive envs (num_bodies * 3)
     keep = [t.contiguous().float() if t is not None else None for t in
             (base_ang_vel, projected_gravity, commands, dof_pos, default_dof_pos.reshape(-1), dof_vel, actions, foothold_obs,
              root_states, measured_heights)]

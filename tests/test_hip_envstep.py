@@ -111,3 +111,29 @@ def test_history_roll_and_wrapper_pingpong():
     od2, *_ = env.step(torch.zeros(64, 12, device=DEV))
     assert torch.equal(first, snap) and od2["obs_history"].data_ptr() != first.data_ptr()
     assert torch.equal(od2["obs_history"][:, :-53], snap[:, 53:]) and torch.equal(od2["obs_history"][:, -53:], od2["obs"])
+
+
+def test_zero_sized_and_invalid_calls():
+    """N = 0 is a no-op for every env-step entry point; invalid descriptors are rejected with DtcError (nothing is
+    launched, nothing wraps around)."""
+    from dtc_amd import _ffi
+    s = {k: v.to(DEV) for k, v in S.env_state(4, seed=13).items()}
+    e = lambda *shape, dt=torch.float32: torch.empty(*shape, dtype=dt, device=DEV)
+    out = foothold.compute_observations(e(0, 3), e(0, 3), e(0, 4), e(0, 12), s["default_dof_pos"], e(0, 12), e(0, 12), e(0, 8),
+                                        e(0, 13), e(0, 693), e(0, 17, 3))
+    assert out["obs_buf"].shape == (0, 53) and out["privileged_obs_buf"].shape == (0, 1389)
+    h = foothold.plan(e(0, 693), e(0, 13), e(0, 4, 3), e(0, 4))
+    assert h["optimal_foothold_indice"].shape[0] == 0
+    with pytest.raises(_ffi.DtcError):
+        ops.history_roll(e(8, 2000), e(8, 400), e(8, 2000), 5)                       # row longer than 1024 floats
+    cfg = foothold.ObsConfig(term_row0=600, term_row1=500)
+    with pytest.raises(_ffi.DtcError):
+        foothold.check_termination(s["contact_forces"], s["termination_contact_indices"], s["episode_length_buf"], 1000,
+                                   s["projected_gravity"], s["root_states"], s["measured_heights"], cfg)
+    X, W, b = e(64, 512), e(693, 512), e(693)
+    tgt, idx = e(100, 1389), torch.zeros(64, dtype=torch.int64, device=DEV)
+    with pytest.raises(_ffi.DtcError):                                              # target columns outside the row
+        _ffi.check(_ffi.lib().dtc_linear_fwd_mse(ops.as_segmat(X), W.data_ptr(), b.data_ptr(), tgt.data_ptr(), 1389, 100, 1000,
+                                                 idx.data_ptr(), 1.0, e(64, 693).data_ptr(), 693,
+                                                 torch.zeros(64, dtype=torch.float64, device=DEV).data_ptr(), 64, 693, 512,
+                                                 torch.cuda.current_stream().cuda_stream), "dtc_linear_fwd_mse")
