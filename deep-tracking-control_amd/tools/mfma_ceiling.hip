@@ -181,6 +181,8 @@ int main() {
     run<4, 128, 4, 3, true>(src, out, "short blocks + epilogue", 32, 768);
     run<4, 64, 4, 4, true>(src, out, "short blocks + epilogue", 128, 1536);
     run<4, 64, 4, 4, true>(src, out, "short blocks + epilogue", 512, 1536);
+    run<5, 64, 2, 4, true>(src, out, "real operands (pad 2)", 32, 1536);
+    run<5, 64, 2, 4, true>(src, out, "real operands (pad 2)", 44, 1536);
     run<5, 64, 4, 4, true>(src, out, "real operands", 32, 1536);
     run<5, 64, 4, 3, true>(src, out, "real operands", 32, 1536);
     run<5, 128, 4, 2, true>(src, out, "real operands", 32, 768);
