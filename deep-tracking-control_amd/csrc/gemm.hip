@@ -32,140 +32,9 @@
 // Workgroup -> tile mapping is XCD-aware (block b runs on XCD b%8): all column tiles of one row panel
 // (fwd/dgrad) resp. all output tiles of one batch slice (wgrad) run on the same XCD, so the panel is
 // fetched from HBM into ONE L2 and shared there.
-#include <stdlib.h>
-
-#include "common.hpp"
+#include "gemm_core.hpp"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32;
-
-constexpr int BM = 128;
-#ifndef DTC_BK
-#define DTC_BK 16
-#endif
-constexpr int BK = DTC_BK;             // K step; loaders derive their geometry from it
-constexpr int RP = 256 / BK;           // tile rows covered per loader pass of the k-contiguous operands
-constexpr int PAD = 4;
-
-// split partials: row n of a split holds dW[n, 0:K] and the bias-gradient partial at column K; rows are padded to a
-// multiple of 4 floats so that the reduction streams them with 16-byte loads
-__host__ __device__ __forceinline__ int part_ld(int K) { return (K + 1 + 3) & ~3; }
-
-struct SegDev {
-    float* ptr;
-    long long ld;
-    int col0, start, width, gather, accumulate;
-};
-struct SegMatDev {
-    int nseg, cols;
-    const long long* idx;
-    SegDev s[4];
-};
-
-__device__ __forceinline__ int find_seg(const SegMatDev& X, int k) {
-    int s = 0;
-    if (X.nseg > 1 && k >= X.s[1].start) s = 1;
-    if (X.nseg > 2 && k >= X.s[2].start) s = 2;
-    if (X.nseg > 3 && k >= X.s[3].start) s = 3;
-    return s;
-}
-
-__device__ __forceinline__ float act_fwd(float v, int act) {
-    if (act == DTC_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == DTC_ACT_ELU) return v > 0.f ? v : expm1f(v);
-    return v;
-}
-// derivative expressed through the saved post-activation output y
-__device__ __forceinline__ float act_bwd(float g, float y, int act) {
-    if (act == DTC_ACT_RELU) return y > 0.f ? g : 0.f;
-    if (act == DTC_ACT_ELU) return y > 0.f ? g : g * (y + 1.0f);
-    return g;
-}
-
-// Buffer loads: `buffer_load_dword v, voff, s[rsrc], soff offen` -- 128-bit descriptor + uniform byte offset in
-// SGPRs, 32-bit lane offset in a VGPR: zero address arithmetic per load inside the K loop.  A lane offset of
-// INVALID (>= num_records) makes the hardware return 0 without touching memory: that is how row / k tails
-// are zero-filled (no clamps, no masks, no over-reads).  All valid offsets must stay below 2 GiB.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr u32 INVALID = 0x80000000u;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
-    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)INVALID, 0x00020000);
-}
-__device__ __forceinline__ rsrc_t make_rsrc_bytes(const void* p, long long bytes) {   // loads past `bytes` return 0
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
-    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)(u32)bytes, 0x00020000);
-}
-// sign-bit mask: INVALID when x > limit (both < 2^31), else 0 -- pure arithmetic, because hipcc turns a
-// `cond ? INVALID : off` select feeding a load into two predicated loads behind exec-mask branches
-__device__ __forceinline__ u32 oob_mask(int x, int limit) { return (u32)(limit - x) & INVALID; }
-__device__ __forceinline__ float bload(rsrc_t r, u32 voff, u32 soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-}
-
-template <int BN>
-struct Cfg {
-    static constexpr int WM = (BN == 128) ? 2 : 4;      // waves along the row dimension
-    static constexpr int WN = 4 / WM;                   // waves along the column dimension
-    static constexpr int TM = BM / (32 * WM);           // 32x32 MFMA tiles per wave (rows)
-    static constexpr int TN = BN / (32 * WN);           // 32x32 MFMA tiles per wave (cols)
-    static constexpr int LDA = BM + PAD;
-    static constexpr int LDB = BN + PAD;
-};
-
-// XCD-aware tile mapping: returns false for padding blocks.
-__device__ __forceinline__ bool map_tile(int b, int row_tiles, int col_tiles, int& tr, int& tc) {
-    const int xcd = b & 7;
-    const int j = b >> 3;
-    const int local = j / col_tiles;
-    tc = j - local * col_tiles;
-    tr = xcd + 8 * local;
-    return tr < row_tiles;
-}
-inline int grid_for(int row_tiles, int col_tiles) { return 8 * (int)dtc::ceil_div(row_tiles, 8) * col_tiles; }
-
-template <int BN>
-__device__ __forceinline__ void mfma_step(const float* __restrict__ As, const float* __restrict__ Bs,
-                                          f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN], int lane, int wm_off, int wn_off) {
-    using C = Cfg<BN>;
-    const int half = lane >> 5, l31 = lane & 31;
-    const float* ap = As + half * C::LDA + wm_off + l31;
-    const float* bp = Bs + half * C::LDB + wn_off + l31;
-#pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp) {
-        float a[C::TM], b[C::TN];
-#pragma unroll
-        for (int i = 0; i < C::TM; ++i) a[i] = ap[2 * kp * C::LDA + 32 * i];
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j) b[j] = bp[2 * kp * C::LDB + 32 * j];
-#pragma unroll
-        for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-}
-
-struct Masked { static constexpr bool value = true; };
-struct Full { static constexpr bool value = false; };
-struct S0 { static constexpr int value = 0; };      // register-set selectors of the two-step-ahead loaders
-struct S1 { static constexpr int value = 1; };
-
-template <int BN>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN]) {
-#pragma unroll
-    for (int i = 0; i < Cfg<BN>::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < Cfg<BN>::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-}
 
 // ------------------------------------------------------------------------------------------
 // Forward: Y[M,N] = act(X[M,K] W[N,K]^T + b)
@@ -584,253 +453,17 @@ __global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __res
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Weight gradient (split over the batch): part[s][n][c] = sum_{m in split s} dZ[m,n] X[m,c],
-// c == K holds the bias-gradient partial.  A second kernel reduces the splits.
-// ------------------------------------------------------------------------------------------
-// Column tiles are aligned to the segments of X (tile = (segment, tile inside the segment)), so every block
-// reads ONE source matrix: uniform descriptor, and -- because all lanes of a wave stage the same batch row --
-// the (optionally gathered) row offset is a SCALAR: idx[m] comes in through s_load, row*ld goes into the
-// SGPR offset of the buffer load, the lane offset is just the column.  Zero VALU per load.
-template <int BN>
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dZ, long long lddz,
-                                                           const SegMatDev X, float* __restrict__ part, int M, int N,
-                                                           int K, int rows_per_split, int col_tiles, int splits) {
-    using C = Cfg<BN>;
-    __shared__ float As[2][BK][C::LDA];
-    __shared__ float Bs[2][BK][C::LDB];
-    const int row_tiles = (N + BM - 1) / BM;
-    const int tiles = row_tiles * col_tiles;
-    // block b runs on XCD b%8: every XCD owns whole batch slices (splits), so each slice of dZ / X is
-    // pulled from HBM into ONE L2 and shared there by all output tiles
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int split = xcd + 8 * (jb / tiles);
-    if (split >= splits) return;                    // padding block of the last (partial) group of 8 splits
-    const int t = jb % tiles;
-    const int tr = t / col_tiles;
-    int tc = t - tr * col_tiles;
-    // (segment, local tile) of this column tile
-    int seg = 0;
-    for (; seg < X.nseg - 1; ++seg) {
-        const int nt = (X.s[seg].width + BN - 1) / BN;
-        if (tc < nt) break;
-        tc -= nt;
-    }
-    const SegDev sd = X.s[seg];
-    const int n0 = tr * BM, lc0 = tc * BN;           // lc0: first column inside the segment
-    const int m_begin = split * rows_per_split;
-    const int m_end = min(M, m_begin + rows_per_split);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
-
-    // A loader: As[kk][i] = dZ[m][n0+i], i = tid % 128, two reduction rows per pass
-    const int ai = tid & 127, ak0 = tid >> 7;
-    constexpr int NA = BK / 2;
-    const bool arow_ok = n0 + ai < N;
-    // B loader: Bs[kk][j] = X[m][col]; RPP batch rows per pass
-    constexpr int RPP = 256 / BN;
-    constexpr int NB = BK / RPP;
-    constexpr bool ROW_UNIFORM = BN >= 64;          // all lanes of a wave stage the same batch row
-    const int bj = tid % BN, bk0 = tid / BN;
-    const int bk0u = ROW_UNIFORM ? __builtin_amdgcn_readfirstlane(bk0) : bk0;
-    const bool bcol_ok = lc0 + bj < sd.width;
-    const u32 ldb = (u32)sd.ld * 4u;
-    const u32 bcolb = bcol_ok ? (u32)(sd.col0 + lc0 + bj) * 4u : INVALID;
-    u32 aoff[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) aoff[i] = arow_ok ? (u32)((long long)(ak0 + 2 * i) * lddz + n0 + ai) * 4u : INVALID;
-    const rsrc_t ares = make_rsrc(dZ), bres = make_rsrc(sd.ptr);
-
-    float ra[NA], rb[NB];
-    float bias_acc = 0.f;
-    auto load_tile = [&](auto masked, int mb) {
-        constexpr bool MK = decltype(masked)::value;
-        const u32 sa = (u32)mb * (u32)lddz * 4u;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | (MK ? oob_mask(mb + ak0 + 2 * i, m_end - 1) : 0u), sa);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int m = mb + bk0u + RPP * i;
-            const int mc = (!MK || m < m_end) ? m : m_end - 1;
-            const u32 r = sd.gather ? (u32)X.idx[mc] : (u32)mc;          // scalar when ROW_UNIFORM
-            rb[i] = bload(bres, bcolb | (MK ? oob_mask(m, m_end - 1) : 0u), r * ldb);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            As[buf][ak0 + 2 * i][ai] = ra[i];
-            bias_acc += ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[buf][bk0 + RPP * i][bj] = rb[i];
-    };
-
-    f32x16 acc[C::TM][C::TN];
-    zero_acc<BN>(acc);
-
-    const int KT = (m_end - m_begin + BK - 1) / BK;
-    if (KT > 0) {                                   // uniform per block (an empty trailing split writes zeros)
-        int buf = 0;
-        auto step = [&](auto masked, int kt_next) {
-            load_tile(masked, m_begin + kt_next * BK);
-            mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-            store_tile(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
-        };
-        load_tile(Masked{}, m_begin);
-        store_tile(0);
-        __syncthreads();
-        for (int kt = 1; kt + 1 < KT; ++kt) step(Full{}, kt);  // branch-free steady state (full tiles)
-        if (KT > 1) step(Masked{}, KT - 1);                    // batch tail of the split
-        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-    }
-
-    const long long ldp = part_ld(K);
-    float* P = part + (long long)split * N * ldp;
-    const int half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int j = 0; j < C::TN; ++j) {
-        const int lcol = lc0 + wn_off + 32 * j + l31;
-        if (lcol >= sd.width) continue;
-        const int col = sd.start + lcol;
-#pragma unroll
-        for (int i = 0; i < C::TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = n0 + wm_off + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < N) P[(long long)row * ldp + col] = acc[i][j][r];
-            }
-        }
-    }
-    if (seg == 0 && tc == 0) {   // bias-gradient partial: two threads staged each dZ column
-        float* red = &As[0][0][0];
-        __syncthreads();
-        if (ak0 == 1) red[ai] = bias_acc;
-        __syncthreads();
-        if (ak0 == 0 && arow_ok) P[(long long)(n0 + ai) * ldp + K] = bias_acc + red[ai];
-    }
-}
-
-// Sum of the split partials in a FIXED order (deterministic): block = 64 float4 columns x G split groups; group g
-// adds splits g, g+G, g+2G, ... (4 loads in flight), the groups are then added in order 0..G-1 through LDS.
-template <int G>
-__global__ __launch_bounds__(64 * G) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
-                                                              float* __restrict__ db, int N, int K, int splits) {
-    __shared__ float4 red[G][64];
-    const int ldp = part_ld(K);
-    const long long total = (long long)N * ldp;
-    const int n = blockIdx.y;
-    const int c4 = blockIdx.x * 64 + threadIdx.x;          // float4 column
-    const int g = threadIdx.y;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c4 * 4 < ldp) {
-        const float4* p = reinterpret_cast<const float4*>(part + (long long)n * ldp) + c4;
-        const long long step = total / 4;
-        int s = g;
-        for (; s + 3 * G < splits; s += 4 * G) {
-            const float4 v0 = p[(long long)s * step], v1 = p[(long long)(s + G) * step];
-            const float4 v2 = p[(long long)(s + 2 * G) * step], v3 = p[(long long)(s + 3 * G) * step];
-            acc.x = (((acc.x + v0.x) + v1.x) + v2.x) + v3.x;
-            acc.y = (((acc.y + v0.y) + v1.y) + v2.y) + v3.y;
-            acc.z = (((acc.z + v0.z) + v1.z) + v2.z) + v3.z;
-            acc.w = (((acc.w + v0.w) + v1.w) + v2.w) + v3.w;
-        }
-        for (; s < splits; s += G) {
-            const float4 v = p[(long long)s * step];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-    }
-    red[g][threadIdx.x] = acc;
-    __syncthreads();
-    if (g == 0 && c4 * 4 < ldp) {
-        for (int j = 1; j < G; ++j) {
-            const float4 v = red[j][threadIdx.x];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-        const float out[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = c4 * 4 + i;
-            if (c < K) dW[(long long)n * K + c] = out[i];
-            else if (c == K && db) db[n] = out[i];
-        }
-    }
-}
-
-constexpr long long MAX_ELEMS = (1ll << 29) - 1;     // lane byte offsets must stay below 2 GiB (INVALID = 2^31)
-
-int to_dev(const DtcSegMat* h, SegMatDev& d, int expect_cols, bool is_output, long long rows_bound) {
-    DTC_REQUIRE(h != nullptr, "segmented matrix is null");
-    DTC_REQUIRE(h->nseg >= 1 && h->nseg <= 4, "nseg=%d out of range", h->nseg);
-    d.nseg = h->nseg;
-    d.idx = (const long long*)h->idx;
-    int start = 0;
-    for (int i = 0; i < 4; ++i) {
-        SegDev& s = d.s[i];
-        if (i < h->nseg) {
-            const DtcSeg& hs = h->seg[i];
-            DTC_REQUIRE(hs.width > 0 && hs.col0 >= 0, "segment %d: bad width/col0", i);
-            DTC_REQUIRE(is_output || hs.ptr != nullptr, "segment %d: null source", i);
-            DTC_REQUIRE(!hs.gather || h->idx != nullptr, "segment %d: gather without idx", i);
-            DTC_REQUIRE(!(is_output && hs.gather), "segment %d: gathered destination unsupported", i);
-            DTC_REQUIRE(hs.gather || hs.ld * rows_bound <= MAX_ELEMS, "segment %d: matrix exceeds 2^29 elements (2 GiB)", i);
-            s.ptr = hs.ptr;
-            s.ld = hs.ld;
-            s.col0 = hs.col0;
-            s.start = start;
-            s.width = hs.width;
-            s.gather = hs.gather;
-            s.accumulate = hs.accumulate;
-            start += hs.width;
-        } else {
-            s = SegDev{nullptr, 0, 0, 0x7fffffff, 0, 0, 0};
-        }
-    }
-    d.cols = start;
-    DTC_REQUIRE(start == expect_cols, "segments cover %d columns, expected %d", start, expect_cols);
-    return DTC_OK;
-}
-
-// wgrad column-tile width: 64 measured at least as fast as 128 on every layer of this model (sweep in
-// tools/microbench.py wgrad); DTC_WGRAD_BN overrides for experiments
-int pick_bn(int cols) {
-    static const char* force = getenv("DTC_WGRAD_BN");
-    if (force && cols > 64) return atoi(force);
-    return cols <= 32 ? 32 : 64;
-}
-
 // fwd / dgrad: 128x64 tiles measured faster than 128x128 at every layer width of this model (twice the
 // workgroups -> prologue / epilogue of one block overlap the MFMA phase of its neighbours, 4 waves/SIMD);
 // when even those leave the chip short of workgroups (narrow layers, the ~1500-row GEMMs of one GRU time
 // step) 128x32 tiles double the count again
 int pick_bn_rows(int rows, int cols) {
-    static const char* force = getenv("DTC_GEMM_BN");
-    if (force && cols > 64) return atoi(force);
+    static const char* force = getenv("DTC_GEMM_BN");          // tuning aid: 32 | 64 (128x128 tiles were measured slower and are not built)
+    if (force && cols > 64) return atoi(force) == 32 ? 32 : 64;
     if (cols <= 32) return 32;
     static const char* thr_env = getenv("DTC_GEMM_MIN_BLOCKS");
     const long long min_blocks = thr_env ? atoi(thr_env) : 320;     // measured with DTC_GEMM_MIN_BLOCKS sweeps of bench.py
     return dtc::ceil_div(rows, BM) * dtc::ceil_div(cols, 64) >= min_blocks ? 64 : 32;
-}
-
-// wgrad split heuristic -------------------------------------------------------------------------------------
-int wgrad_splits(int M, int tiles) {
-    static const char* target_env = getenv("DTC_WGRAD_BLOCKS");
-    const int target = target_env ? atoi(target_env) : 1024;
-    // whole splits per XCD (multiple of 8) measured 10-20 % faster than filling the wave with an arbitrary count
-    // (DTC_WGRAD_ANYSPLIT=1: 44 tiles x 23 splits = 1012 blocks ran slower than 44 x 16 = 704)
-    static const bool mult8 = getenv("DTC_WGRAD_ANYSPLIT") == nullptr;
-    int s = target / tiles;
-    if (mult8) s = s / 8 * 8;
-    if (s < 8) s = 8;
-    const int max_s = (int)dtc::ceil_div(dtc::ceil_div(M, BK * 8), 8) * 8;
-    if (s > max_s) s = max_s;
-    return s;
-}
-// upper bound over every segmentation of X (segment-aligned column tiles only add tiles -> fewer splits)
-int wgrad_splits_bound(int M, int N, int K) {
-    return wgrad_splits(M, (int)(dtc::ceil_div(N, BM) * dtc::ceil_div(K, pick_bn(K))));
 }
 
 }  // namespace
@@ -852,8 +485,7 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     const int bn = pick_bn_rows(M, N);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, bn));
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s);
-    if (bn == 128) hipLaunchKernelGGL((linear_fwd_kernel<128, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, MseEpi{});
-    else if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, MseEpi{});
+    if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, MseEpi{});
     else hipLaunchKernelGGL((linear_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, MseEpi{});
     return dtc::check_launch("linear_fwd");
 }
@@ -914,8 +546,7 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
     const int bn = pick_bn_rows(M, K - col_skip);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K - col_skip, bn));
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s);
-    if (bn == 128) hipLaunchKernelGGL(linear_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip);
-    else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip);
+    if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip);
     else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip);
     return dtc::check_launch("linear_dgrad");
 }
@@ -941,47 +572,4 @@ extern "C" int dtc_linear_dgrad_split(const float* dZ, int64_t lddz, const float
     if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride, 0);
     else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride, 0);
     return dtc::check_launch("linear_dgrad_split");
-}
-
-extern "C" int64_t dtc_linear_wgrad_workspace(int M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return (int64_t)wgrad_splits_bound(M, N, K) * N * part_ld(K) * (int64_t)sizeof(float);
-}
-
-extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* X, float* dW, float* db, void* workspace,
-                                int M, int N, int K, void* stream) {
-    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
-    DTC_REQUIRE(dZ && dW && workspace, "null pointer");
-    DTC_REQUIRE(dtc::aligned16(workspace), "wgrad workspace must be 16-byte aligned");
-    DTC_REQUIRE((long long)M * lddz <= MAX_ELEMS, "matrix too large");
-    SegMatDev xd;
-    int rc = to_dev(X, xd, K, false, M);
-    if (rc != DTC_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    const int bn = pick_bn(K);
-    int col_tiles = 0;
-    for (int i = 0; i < xd.nseg; ++i) col_tiles += (int)dtc::ceil_div(xd.s[i].width, bn);
-    const int tiles = (int)dtc::ceil_div(N, BM) * col_tiles;
-    const int splits = wgrad_splits(M, tiles);
-    int rows_per_split = (int)dtc::ceil_div(M, splits);
-    rows_per_split = (int)dtc::ceil_div(rows_per_split, BK) * BK;
-    float* part = (float*)workspace;
-    {
-        dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, N, K), 2.0 * M * (double)N * K, s);
-        const int grid = tiles * 8 * (int)dtc::ceil_div(splits, 8);
-        if (bn == 128) hipLaunchKernelGGL(linear_wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split, col_tiles, splits);
-        else if (bn == 64) hipLaunchKernelGGL(linear_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split, col_tiles, splits);
-        else hipLaunchKernelGGL(linear_wgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split, col_tiles, splits);
-    }
-    {
-        const long long total = (long long)N * part_ld(K);
-        dtc::ProfScope prof(dtc::prof_shape_name("wgrad_reduce", splits, N, K), (double)total * 4.0 * (splits + 1), s);
-        const dim3 grid((unsigned)dtc::ceil_div(part_ld(K) / 4, 64), (unsigned)N);
-        // more split groups when the output is small (few blocks): the sum over splits is then the latency chain
-        if (total >= (1 << 17) || splits <= 16)
-            hipLaunchKernelGGL(wgrad_reduce_kernel<4>, grid, dim3(64, 4), 0, s, part, dW, db, N, K, splits);
-        else
-            hipLaunchKernelGGL(wgrad_reduce_kernel<16>, grid, dim3(64, 16), 0, s, part, dW, db, N, K, splits);
-    }
-    return dtc::check_launch("linear_wgrad");
 }

@@ -35,6 +35,11 @@ class DtcSegMat(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("cols", C.c_int32), ("idx", C.c_void_p), ("seg", DtcSeg * 4)]
 
 
+class DtcWgradJob(C.Structure):
+    _fields_ = [("dZ", C.c_void_p), ("lddz", C.c_int64), ("X", DtcSegMat), ("dW", C.c_void_p), ("db", C.c_void_p),
+                ("N", C.c_int32), ("K", C.c_int32)]
+
+
 class DtcPpoCfg(C.Structure):
     _fields_ = [("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float),
                 ("desired_kl", C.c_float), ("use_clipped_value_loss", C.c_int32),
@@ -91,6 +96,8 @@ _SIGS = {
     "dtc_linear_wgrad_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dtc_linear_wgrad": (C.c_int, [c_f32p, C.c_int64, C.POINTER(DtcSegMat), c_f32p, c_f32p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, c_stream]),
+    "dtc_wgrad_group_workspace": (C.c_int64, [C.POINTER(DtcWgradJob), C.c_int, C.c_int]),
+    "dtc_wgrad_group": (C.c_int, [C.POINTER(DtcWgradJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_cenet_workspace": (C.c_int64, [C.c_int]),
     "dtc_cenet_latent_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int, c_stream]),
     "dtc_cenet_latent_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int,

@@ -187,6 +187,18 @@ class _TrainWorkspace(_Lanes):
         self.wg = ops.workspace(max(lib.dtc_linear_wgrad_workspace(B, n, k) for n, k in shapes), dev)
         self.loss_ws = ops.workspace(lib.dtc_loss_workspace(B), dev)
         self.hpart = torch.zeros(int(lib.dtc_linear_fwd_mse_parts(B, 693)), dtype=torch.float64, device=dev)
+        self.gws = None
+        self.pending, self.held = [], []      # queued weight-gradient jobs; operands of flushed jobs (alive until the join)
+
+    MAX_GROUP = 12           # jobs per grouped weight-gradient launch (MAX_JOBS of csrc/wgrad.hip)
+
+    def group_ws(self, jobs):
+        """Partial-slab workspace of a grouped weight-gradient launch, grown on demand."""
+        need = ops.wgrad_group_workspace_bytes(jobs, self.B)
+        if self.gws is None or self.gws.numel() * self.gws.element_size() < need:
+            torch.cuda.synchronize()            # nothing may still be reading the buffer being replaced
+            self.gws = ops.workspace(need, self._dev)
+        return self.gws
 
     def wgrad_ws(self, N, K):
         """Split-partials workspace, grown on demand (rare: first use of a larger layer shape)."""
@@ -239,6 +251,8 @@ class PPO:
         self.overlap_wgrad = os.environ.get("DTC_OVERLAP_WGRAD", "1") != "0"
         # two compute lanes (needs the side stream: both lanes' weight gradients share one partials workspace)
         self.overlap_lanes = os.environ.get("DTC_OVERLAP_LANES", "1") != "0"
+        # weight gradients queued per gradient bucket and run as one grouped launch (DTC_WGRAD_GROUP=0: per layer)
+        self.group_wgrad = os.environ.get("DTC_WGRAD_GROUP", "1") != "0"
         # rollout step (policy sample + value + log-prob) replayed from a HIP graph: OFF by default -- measured slower
         # than the eager launches on ROCm 7.2 (793 k vs 829 k env-steps/s end to end, tools/soak.py); DTC_ROLLOUT_GRAPH=1
         self.graph_rollout = os.environ.get("DTC_ROLLOUT_GRAPH", "0") == "1"
@@ -352,10 +366,11 @@ class PPO:
         dp.allreduce_mean_(opt.g)        # one flat bucket per optimiser step (no-op on a single rank)
 
     def _exchange_bucket(self, tw, name):
-        """Data parallel: average gradient bucket `name` of the arena over the ranks as soon as its last weight
+        """Weight gradients of the bucket: flushed here.  Data parallel: average gradient bucket `name` of the arena over the ranks as soon as its last weight
         gradient has been queued.  All weight gradients of this trainer run on the side stream, so the all-reduce is
         issued THERE: it is ordered after them and overlaps the data-gradient chain still running on the compute lanes
         (the decoders' / heads' bucket travels while the encoders run backward).  Returns True when it took place."""
+        self._flush_wgrads(tw)
         if self._world() == 1 or not (self.overlap_exchange and self.overlap_wgrad):
             return False
         lo, hi = self.actor_critic.arena.buckets[name]
@@ -365,10 +380,15 @@ class PPO:
         return True
 
     def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None):
-        """Backward of one dense layer.  The weight gradient (dW = dZ^T X, + split reduction) is off the critical
-        path -- only the optimiser step needs it -- so it goes to the side stream and overlaps with the
-        data-gradient chain of the layers below: small layers, launch gaps and kernel tails get filled."""
-        if self.overlap_wgrad:
+        """Backward of one dense layer.  The weight gradient (dW = dZ^T X) is off the critical path -- only the
+        optimiser step (and the data-parallel exchange) needs it -- so it is QUEUED: `_flush_wgrads` runs all queued
+        layers of a gradient bucket as one grouped launch on the side stream, where it overlaps with the data-gradient
+        chain of the layers below.  (DTC_WGRAD_GROUP=0: one launch pair per layer, issued right here.)"""
+        if self.group_wgrad:
+            tw.pending.append((dZ, X, L.gW, L.gb))
+            if len(tw.pending) == tw.MAX_GROUP:
+                self._flush_wgrads(tw)
+        elif self.overlap_wgrad:
             ev = tw.event()
             ev.record()                          # dZ and X are final on the main stream here
             tw.side.wait_event(ev)
@@ -379,8 +399,27 @@ class PPO:
         if dX is not None:
             ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B)
 
+    def _flush_wgrads(self, tw):
+        """Launch the queued weight gradients (everything both compute lanes have issued so far is their input)."""
+        if not tw.pending:
+            return
+        jobs, tw.pending = tw.pending, []
+        ws = tw.group_ws(jobs)
+        if self.overlap_wgrad:
+            lanes = (tw.main, tw.aux) if tw.two_lanes else (torch.cuda.current_stream(),)
+            for lane in lanes:
+                ev = tw.event()
+                ev.record(lane)
+                tw.side.wait_event(ev)
+            tw.held.append(ops.wgrad_group(jobs, tw.B, ws, stream_ptr=tw.side.cuda_stream))
+            tw.side_busy = True
+        else:
+            tw.held.append(ops.wgrad_group(jobs, tw.B, ws))
+
     def _join(self, tw):
+        self._flush_wgrads(tw)
         tw.join()
+        tw.held.clear()
 
     def _terrain_encoder_backward(self, fw, tw, flat, idx):
         L = self.actor_critic.L

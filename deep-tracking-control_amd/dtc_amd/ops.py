@@ -114,6 +114,39 @@ def linear_wgrad(dZ, X, dW, db, workspace, M=None, stream_ptr=None):
           "dtc_linear_wgrad")
 
 
+def _wgrad_jobs(jobs):
+    """jobs: list of (dZ, X (tensor or DtcSegMat), dW, db or None) -> ctypes array + the objects it points into."""
+    arr = (_ffi.DtcWgradJob * len(jobs))()
+    keep = []
+    for i, (dZ, X, dW, db) in enumerate(jobs):
+        Xs = as_segmat(X)
+        N, K = dW.shape
+        arr[i].dZ, arr[i].lddz = ptr(dZ), dZ.stride(0)
+        arr[i].X = Xs
+        arr[i].dW = cptr(dW, f32)
+        arr[i].db = cptr(db, f32) if db is not None else None
+        arr[i].N, arr[i].K = N, K
+        keep.append((dZ, Xs, dW, db))
+    return arr, keep
+
+
+def wgrad_group_workspace_bytes(jobs, M) -> int:
+    arr, _ = _wgrad_jobs(jobs)
+    n = int(lib().dtc_wgrad_group_workspace(arr, len(jobs), M))
+    if n < 0:
+        raise _ffi.DtcError(f"dtc_wgrad_group_workspace failed: {lib().dtc_last_error().decode()}")
+    return n
+
+
+def wgrad_group(jobs, M, workspace, stream_ptr=None):
+    """The weight gradients of several layers (one gradient bucket) in one partial launch + one reduce launch.
+    jobs: list of (dZ [M,N], X tensor | DtcSegMat [M,K], dW [N,K], db [N] | None)."""
+    arr, keep = _wgrad_jobs(jobs)
+    check(lib().dtc_wgrad_group(arr, len(jobs), M, ptr(workspace), stream() if stream_ptr is None else stream_ptr),
+          "dtc_wgrad_group")
+    return keep
+
+
 # ---------------------------------------------------------------- CE-net latent / losses / optimiser
 def workspace(nbytes: int, device) -> torch.Tensor:
     """8-byte aligned scratch of at least `nbytes` bytes."""

@@ -188,6 +188,22 @@ int64_t dtc_linear_wgrad_workspace(int M, int N, int K);
 int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* X, float* dW, float* db,
                      void* workspace, int M, int N, int K, void* stream);
 
+/* The weight gradients of ALL layers of one gradient bucket (ppo.py:252 / 333: the parameters one `loss.backward()`
+ * reaches; the decoders or the encoders of the VAE step, the actor + critic bodies or the encoders of the PPO step)
+ * in ONE partial-product launch + ONE reduce launch.  Every job shares the row count M (the mini-batch) and runs
+ * exactly as dtc_linear_wgrad would (same segmented / gathered X, same outputs); count <= 12.
+ * workspace >= dtc_wgrad_group_workspace() bytes, 16-byte aligned, private to the call until it has completed. */
+typedef struct DtcWgradJob {
+    const float* dZ;     /* [M, N], row stride lddz                                              */
+    int64_t lddz;
+    DtcSegMat X;         /* [M, K] segmented input of the layer                                  */
+    float* dW;           /* [N, K]                                                               */
+    float* db;           /* [N] or NULL                                                          */
+    int32_t N, K;
+} DtcWgradJob;
+int64_t dtc_wgrad_group_workspace(const DtcWgradJob* jobs, int count, int M);
+int dtc_wgrad_group(const DtcWgradJob* jobs, int count, int M, void* workspace, void* stream);
+
 /* ---- CE-net latent: actor_critic_decoder.py:274-302 ---------------------------------------- */
 /* mulv [B,35] = [latent_mu(19) | latent_var(16)].  In place: outlier -> lower median of the
  * non-outliers (2-sigma rule on the batch statistics), then z = eps*exp(0.5*lv) + mu[:,3:].

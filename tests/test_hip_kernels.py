@@ -305,6 +305,46 @@ def test_linear_wgrad_segments_and_gather():
     np.testing.assert_allclose(_np(db), dZ.double().sum(0).numpy(), rtol=3e-5, atol=3e-5)
 
 
+@pytest.mark.parametrize("M", [1536, 5000])
+def test_wgrad_group_matches_fp64(M):
+    """dtc_wgrad_group: the layers of one bucket (wide, narrow, 1-row, segmented + gathered) in one launch pair, against
+    the fp64 products; a second call on the same workspace must reproduce the first bit for bit."""
+    from dtc_amd import _ffi, ops
+    g = torch.Generator().manual_seed(100 + M)
+    R = M + 700
+    d = lambda t: t.to(DEV)
+    obs_all, priv, bv = torch.randn(R, 53, generator=g), torch.randn(R, 1389, generator=g), torch.randn(R, 3, generator=g)
+    idx = torch.randperm(R, generator=g)[:M]
+    obs_d, priv_d, bv_d, idx_d = d(obs_all), d(priv), d(bv), d(idx)
+    shapes = [(512, 752), (512, 512), (256, 512), (128, 256), (12, 128), (1, 128), (35, 64), (693, 512)]
+    jobs, refs = [], []
+    for li, (N, K) in enumerate(shapes):
+        dZ = torch.randn(M, N, generator=g) / M ** 0.5
+        if li == 0:
+            Xh = torch.cat([obs_all[idx], bv[idx], priv[idx, 693:]], dim=1)
+            X = _ffi.segmat([_ffi.seg(obs_d, 0, 53, gather=True), _ffi.seg(bv_d, 0, 3, gather=True),
+                             _ffi.seg(priv_d, 693, 696, gather=True)], idx_d)
+        else:
+            Xh = torch.randn(M, K, generator=g)
+            X = d(Xh)
+        dW = torch.full((N, K), float("nan"), device=DEV)
+        db = torch.full((N,), float("nan"), device=DEV) if li != 3 else None
+        jobs.append((d(dZ), X, dW, db))
+        refs.append((dZ.double().t() @ Xh.double(), dZ.double().sum(0)))
+    ws = ops.workspace(ops.wgrad_group_workspace_bytes(jobs, M), DEV)
+    ops.wgrad_group(jobs, M, ws)
+    first = [(j[2].clone(), None if j[3] is None else j[3].clone()) for j in jobs]
+    for (dZ, X, dW, db), (rw, rb) in zip(jobs, refs):
+        np.testing.assert_allclose(_np(dW), rw.numpy(), rtol=3e-5, atol=3e-5)
+        if db is not None:
+            np.testing.assert_allclose(_np(db), rb.numpy(), rtol=3e-5, atol=3e-5)
+    ops.wgrad_group(jobs, M, ws)
+    for (dZ, X, dW, db), (w0, b0) in zip(jobs, first):
+        assert torch.equal(dW, w0) and (db is None or torch.equal(db, b0))
+    with pytest.raises(_ffi.DtcError):
+        ops.wgrad_group(jobs * 2, M, ws)            # more than 12 jobs per launch
+
+
 def test_foothold_rewards_vs_oracle():
     from dtc_amd import foothold
     from oracle import foothold as OF
