@@ -312,7 +312,7 @@ int wgrad_splits_bound(int M, int N, int K) {
 // grouped launch: one split count for all jobs (every block then reduces the same number of batch rows)
 int group_splits(int M, int tiles_total) {
     static const char* target_env = getenv("DTC_WGRAD_GROUP_BLOCKS");
-    const int target = target_env ? atoi(target_env) : 2048;
+    const int target = target_env ? atoi(target_env) : 3072;      // sweep 1024 ... 4096 with bench.py: 3072 best (24 batch slices per layer)
     int s = target / (tiles_total > 0 ? tiles_total : 1) / 8 * 8;
     if (s < 8) s = 8;
     const int max_s = (int)dtc::ceil_div(dtc::ceil_div(M, BK * 8), 8) * 8;

@@ -456,35 +456,40 @@ class PPO:
             ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None)
         ops.linear_fwd(fw.lt, L["td0"].W, L["td0"].b, tw.d1, "relu")
         ops.linear_fwd(tw.d1, L["td1"].W, L["td1"].b, tw.d2, "relu")
+        # The loss kernel joins the two branches, but only the CE-net decoder's backward needs its output (dL/d recons,
+        # the direct part of d mulv): the terrain decoder's dL/dY comes out of its own output layer.  The loss therefore
+        # runs on `aux`; the main lane goes straight from the terrain decoder's forward into its backward.
         if self.fuse_height_loss:
             # output layer of the terrain decoder + its MSE against priv[..., 696:] in one kernel: dL/d height_recon comes
             # out of the GEMM epilogue, height_recon itself never reaches HBM
             n_hp = ops.linear_fwd_mse(tw.d2, L["td2"].W, L["td2"].b, flat["privileged_observations"], 696, idx, tw.g_hr, tw.hpart)
-            tw.order("aux", "main")
-            ops.vae_loss_fused(tw.rec, fw.mulv, flat["next_observations"], flat["base_vel"], idx, tw.g_rec, tw.dmulv,
-                               tw.hpart, n_hp, stats[S_RECONS:S_RECONS + 4], tw.loss_ws)
+            tw.order("main", "aux")
+            with tw.lane("aux"):
+                ops.vae_loss_fused(tw.rec, fw.mulv, flat["next_observations"], flat["base_vel"], idx, tw.g_rec, tw.dmulv,
+                                   tw.hpart, n_hp, stats[S_RECONS:S_RECONS + 4], tw.loss_ws)
         else:
             ops.linear_fwd(tw.d2, L["td2"].W, L["td2"].b, tw.hr, None)
+            tw.order("main", "aux")
+            with tw.lane("aux"):
+                ops.vae_loss(tw.rec, tw.hr, fw.mulv, flat["next_observations"], flat["privileged_observations"],
+                             flat["base_vel"], idx, tw.g_rec, tw.g_hr, tw.dmulv, stats[S_RECONS:S_RECONS + 4], tw.loss_ws)
             tw.order("aux", "main")
-            ops.vae_loss(tw.rec, tw.hr, fw.mulv, flat["next_observations"], flat["privileged_observations"],
-                         flat["base_vel"], idx, tw.g_rec, tw.g_hr, tw.dmulv, stats[S_RECONS:S_RECONS + 4], tw.loss_ws)
-        tw.order("main", "aux")
+        # CE-net decoder (aux, short): its input gradient fans out to z, mu[:, :3] (accumulating onto the loss's direct
+        # part) and l_t (plain write) -- it finishes long before the terrain decoder's chain on main reaches its last
+        # layer, whose input gradient is then ADDED to d l_t (a + b == b + a: same bits as the reverse order)
+        g_cd2, g_cd1 = tw.g("cd2", 128), tw.g("cd1", 64)
+        dst = segmat([seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3, accumulate=True), seg(tw.dlt, 0, 512)])
+        with tw.lane("aux"):
+            self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu")
+            self._bwd(tw, L["cd1"], g_cd2, tw.c1, g_cd1, tw.c1, "relu")
+            self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None)
         # terrain decoder (main)
         g_td2, g_td1 = tw.g("td2", 512), tw.g("td1", 512)
         self._bwd(tw, L["td2"], tw.g_hr, tw.d2, g_td2, tw.d2, "relu")
         self._bwd(tw, L["td1"], g_td2, tw.d1, g_td1, tw.d1, "relu")
-        self._bwd(tw, L["td0"], g_td1, fw.lt, tw.dlt, None, None)
-        # CE-net decoder (aux); its input gradient fans out to z, mu[:, :3] and (accumulating) l_t
-        g_cd2, g_cd1 = tw.g("cd2", 128), tw.g("cd1", 64)
-        dst = segmat([seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3, accumulate=True), seg(tw.dlt, 0, 512, accumulate=True)])
-        with tw.lane("aux"):
-            self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu")
-            self._bwd(tw, L["cd1"], g_cd2, tw.c1, g_cd1, tw.c1, "relu")
-        tw.order("main", "aux")                                    # d l_t of the terrain decoder is written first
-        with tw.lane("aux"):
-            self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None)
+        tw.order("aux", "main")                                    # d l_t of the CE-net decoder is written first
+        self._bwd(tw, L["td0"], g_td1, fw.lt, segmat([seg(tw.dlt, 0, 512, accumulate=True)]), None, None)
         early = self._exchange_bucket(tw, "vae_only")              # decoder gradients are complete (queued on `side`)
-        tw.order("aux", "main")                                    # d l_t complete
         self._terrain_encoder_backward(fw, tw, flat, idx)
         with tw.lane("aux"):
             ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
