@@ -111,14 +111,18 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
 }
 
 constexpr int MAX_PARTIALS = 4096;
-// Scratch for the reduction partials lives behind stats: callers pass double[4 + MAX_PARTIALS]?
-// No: keep the ABI small -- partials use a lazily allocated per-process device buffer.
+// Reduction partials: one lazily allocated scratch PER DEVICE (keyed by the device that is current at the call, which
+// is the device of the caller's tensors).  Calls that share a device must be ordered on one stream -- the storage
+// issues dtc_gae / dtc_adv_sqdev back to back on torch's current stream; they are not meant to run concurrently.
 double* partial_buffer() {
-    static double* buf = nullptr;
-    if (!buf) {
-        if (hipMalloc(&buf, sizeof(double) * MAX_PARTIALS) != hipSuccess) buf = nullptr;
+    constexpr int MAX_DEV = 64;
+    static double* buf[MAX_DEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    if (!buf[dev]) {
+        if (hipMalloc(&buf[dev], sizeof(double) * MAX_PARTIALS) != hipSuccess) buf[dev] = nullptr;
     }
-    return buf;
+    return buf[dev];
 }
 
 }  // namespace

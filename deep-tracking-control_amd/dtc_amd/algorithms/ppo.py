@@ -61,6 +61,15 @@ class FusedAdam:
             if lo <= off and off + n <= hi:
                 self._inside.append((i, off - lo, n, tuple(p.shape)))
 
+    def rebind(self, arena):
+        """The model re-built its arena (its parameters moved to another device): point the parameter / gradient
+        views at the new buffers and carry the Adam state over (the layout of an arena is a function of the model)."""
+        lo, hi = self.range
+        dev = arena.flat.device
+        self.arena, self.p, self.g = arena, arena.flat[lo:hi], arena.grad[lo:hi]
+        for name in ("exp_avg", "exp_avg_sq", "lr_dev", "gnorm", "ws"):
+            setattr(self, name, getattr(self, name).to(dev))
+
     def set_lr(self, lr: float):
         self.lr_dev.fill_(lr)
         for g in self.param_groups:
@@ -271,10 +280,22 @@ class PPO:
         arena._named = list(ac.named_parameters())
         self.optimizer = FusedAdam(arena, arena.main_range, ac.parameters(), lr=self.learning_rate)   # ppo.py:78
         self.vae_optimizer = FusedAdam(arena, arena.vae_range, ac.vae.parameters(), lr=5.e-4)          # ppo.py:79
+        # data parallel: every rank starts from rank 0's weights whatever its local seed was (the averaged gradient
+        # then keeps them identical); a no-op on one rank
+        dp.broadcast_parameters_(arena.flat)
 
     def _require_gpu(self):
         if self.optimizer is None:
             raise _ffi.DtcError("dtc_amd.PPO computes on an MI355X only (device='cuda:N'); there is no CPU fallback")
+
+    def _arena(self):
+        """The model's current arena; optimisers that still hold views of a replaced arena are re-bound."""
+        arena = self.actor_critic.ensure_arena()
+        for opt in (self.optimizer, self.vae_optimizer):
+            if opt is not None and opt.arena is not arena:
+                arena._named = list(self.actor_critic.named_parameters())
+                opt.rebind(arena)
+        return arena
 
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape,
                      obs_history_shape, action_shape):
@@ -291,9 +312,9 @@ class PPO:
     def _policy_step(self, obs, privileged_obs, obs_history, base_vel, rew_buf=None):
         """The kernels of one rollout step (ppo.py:137-155): policy sample, value, log-prob."""
         ac = self.actor_critic
-        actions = ac.act(obs, obs_history, privileged_obs, rew_buf).detach()
-        values = ac.evaluate(obs, privileged_obs, base_vel).detach()
-        logp = ac.get_actions_log_prob(actions).detach()
+        actions = ac.act(obs, obs_history, privileged_obs, rew_buf)        # no autograd graph exists: nothing to detach
+        values = ac.evaluate(obs, privileged_obs, base_vel)
+        logp = ac.get_actions_log_prob(actions)                            # the log-prob dtc_gaussian_act already produced
         return actions, values, logp, ac.action_mean.detach(), ac.action_std.detach()
 
     def _policy_step_graphed(self, obs, privileged_obs, obs_history, base_vel):
@@ -353,9 +374,10 @@ class PPO:
 
     # ---------------------------------------------------------------- update (ppo.py:174-357)
     def _train_ws(self, B):
-        ws = self._tws.get(B)
+        dev = self.actor_critic.std.device
+        ws = self._tws.get((B, dev))
         if ws is None:
-            ws = self._tws[B] = _TrainWorkspace(B, self.actor_critic.std.device, self.actor_critic.num_actions)
+            ws = self._tws[(B, dev)] = _TrainWorkspace(B, dev, self.actor_critic.num_actions)
         return ws
 
     @staticmethod
@@ -566,7 +588,7 @@ class PPO:
         learning rate after adaptation.  Used by teacher-forced parity tests."""
         self._require_gpu()
         st, ac = self.storage, self.actor_critic
-        ac.ensure_arena()
+        self._arena()
         dev = ac.std.device
         idx = idx.to(dev).contiguous()
         B = idx.numel()
@@ -600,7 +622,7 @@ class PPO:
         so that parity tests can feed both implementations the same numbers."""
         self._require_gpu()
         st, ac = self.storage, self.actor_critic
-        ac.ensure_arena()
+        self._arena()
         dev = ac.std.device
         nmb, epochs = self.num_mini_batches, self.num_learning_epochs
         B = (st.num_envs * st.num_transitions_per_env) // nmb

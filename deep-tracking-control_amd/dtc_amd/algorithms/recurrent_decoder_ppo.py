@@ -167,7 +167,7 @@ class RecurrentDecoderPPO(PPO):
         """One recurrent mini-batch `bt` (an item of `recurrent_slices`): VAE step, policy step, or both."""
         self._require_gpu()
         st, ac = self.storage, self.actor_critic
-        ac.ensure_arena()
+        self._arena()
         dev = ac.std.device
         B = bt["idx"].numel()
         flat = {k: st.flat(k) for k in self._FLAT_NAMES}
@@ -183,7 +183,7 @@ class RecurrentDecoderPPO(PPO):
     def update(self, eps1=None, eps2=None, return_stats=False):
         self._require_gpu()
         st, ac = self.storage, self.actor_critic
-        ac.ensure_arena()
+        self._arena()
         dev = ac.std.device
         nmb, epochs = self.num_mini_batches, self.num_learning_epochs
         B = (st.num_envs // nmb) * st.num_transitions_per_env

@@ -40,6 +40,8 @@ class RecurrentPPO:
         if torch.device(device).type == "cuda":
             arena = actor_critic.ensure_arena()
             self.optimizer = FusedAdam(arena, arena.main_range, actor_critic.parameters(), lr=learning_rate)
+            from .. import distributed as dp
+            dp.broadcast_parameters_(arena.flat)             # data parallel: all ranks start from rank 0's weights
         self.transition = RolloutStorage.Transition()
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
         self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
@@ -149,6 +151,10 @@ class RecurrentPPO:
         """One recurrent mini-batch: `batch` = 11-tuple of reccurent_mini_batch_generator, envs [start, stop)."""
         self._require_gpu()
         ac, st = self.actor_critic, self.storage
+        arena = ac.ensure_arena()
+        if self.optimizer.arena is not arena:            # the model moved: re-bind the optimiser's views
+            arena._named = list(ac.named_parameters())
+            self.optimizer.rebind(arena)
         (obs_b, cobs_b, _a, _v, _adv, _r, _lp, _mu, _sg, (hid_a, hid_c), masks) = batch
         dev = obs_b.device
         T, R = masks.shape

@@ -204,9 +204,14 @@ class ActorCriticDecoder(nn.Module):
 
     # ------------------------------------------------------------------ arena management
     def _apply(self, fn, *a, **k):
+        before = self.std.data_ptr()
         out = super()._apply(fn, *a, **k)
-        self.arena = None        # .to()/.cuda() re-allocates parameter storage; rebuild lazily
-        self._fw = {}
+        if self.std.data_ptr() != before:
+            # .to(other device) / .cuda() / a dtype change re-allocated the parameter storage: rebuild the arena lazily
+            # (trainers notice the new arena object and re-bind their optimiser views, see FusedAdam.rebind).  A no-op
+            # .to() -- e.g. OnPolicyRunner.get_inference_policy(device=same) -- leaves the parameters as arena views.
+            self.arena = None
+            self._fw = {}
         return out
 
     def ensure_arena(self) -> ParamArena:

@@ -79,8 +79,10 @@ class ActorCritic(nn.Module):
         self._dist = None
 
     def _apply(self, fn, *a, **k):
+        before = self.std.data_ptr()
         out = super()._apply(fn, *a, **k)
-        self.arena = None
+        if self.std.data_ptr() != before:        # storage really moved (see ActorCriticDecoder._apply)
+            self.arena = None
         return out
 
     def reset(self, dones=None):

@@ -2,9 +2,7 @@
 (rsl_rl/rsl_rl/runners/on_policy_runner.py:45-273).  The rollout loop and the checkpoint dictionary
 layout are kept; TensorBoard is optional (logging is not part of the hot path)."""
 import os
-import statistics
 import time
-from collections import deque
 
 import torch
 
@@ -19,6 +17,37 @@ except Exception:                          # pragma: no cover
 
 _POLICIES = {"ActorCriticDecoder": ActorCriticDecoder, "ActorCriticDecoderRecurrent": ActorCriticDecoderRecurrent}
 _ALGORITHMS = {"PPO": PPO, "RecurrentDecoderPPO": RecurrentDecoderPPO}
+
+
+class _EpisodeTracker:
+    """Return and length of the episode in flight per env; finished episodes go into a device-side ring of the most
+    recent `keep` (the numbers the reference's logger averages) -- no host round trip per env step, one at log time."""
+
+    def __init__(self, num_envs, device, keep=100):
+        self.keep = keep
+        self.ret = torch.zeros(num_envs, dtype=torch.float32, device=device)
+        self.length = torch.zeros(num_envs, dtype=torch.float32, device=device)
+        self.ring = torch.zeros(keep + 1, 2, dtype=torch.float32, device=device)     # slot `keep` absorbs the non-finished envs
+        self.finished = torch.zeros((), dtype=torch.long, device=device)
+
+    def step(self, rewards, dones):
+        self.ret += rewards
+        self.length += 1
+        done = dones > 0
+        order = torch.cumsum(done, 0) - 1                                   # 0, 1, ... among the envs finishing now
+        slot = torch.where(done, (self.finished + order) % self.keep, torch.full_like(order, self.keep))
+        self.ring[slot] = torch.stack((self.ret, self.length), dim=1)
+        self.finished += done.sum()
+        keep_going = (~done).to(self.ret.dtype)
+        self.ret *= keep_going
+        self.length *= keep_going
+
+    def means(self):
+        n = min(int(self.finished), self.keep)
+        if n == 0:
+            return None
+        m = self.ring[:n].mean(dim=0)
+        return float(m[0]), float(m[1])
 
 
 class OnPolicyRunner:
@@ -45,76 +74,75 @@ class OnPolicyRunner:
         self.current_learning_iteration = 0
         self.env.reset()
 
+    # ---------------------------------------------------------------- training loop
+    def _observe(self, obs_dict):
+        dev = self.device
+        return obs_dict["obs"].to(dev), obs_dict["privileged_obs"].to(dev), obs_dict["obs_history"].to(dev)
+
+    def _collect(self, state, tracker, ep_infos):
+        """One rollout of `num_steps_per_env` env steps into the storage, then the bootstrap values / returns."""
+        obs_dict, rew_buf = state["obs_dict"], state["rew_buf"]
+        obs, priv, hist = self._observe(obs_dict)
+        with torch.inference_mode():
+            for _ in range(self.num_steps_per_env):
+                actions = self.alg.act(obs, priv, hist, obs_dict['base_vel'], rew_buf)
+                obs_dict, rewards, dones, infos = self.env.step(actions)
+                obs, priv, hist = self._observe(obs_dict)
+                rewards, dones = rewards.to(self.device), dones.to(self.device)
+                self.alg.process_env_step(rewards, dones, next_obs=obs_dict['obs'], infos=infos)
+                if tracker is not None:
+                    tracker.step(rewards, dones)
+                    if 'episode' in infos:
+                        ep_infos.append(infos['episode'])
+            self.alg.compute_returns(obs, priv, obs_dict['base_vel'])
+        state["obs_dict"] = obs_dict
+
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
-        if self.log_dir is not None and self.writer is None and SummaryWriter is not None:
+        logging = self.log_dir is not None
+        if logging and self.writer is None and SummaryWriter is not None:
             self.writer = SummaryWriter(log_dir=self.log_dir, flush_secs=10)
         if init_at_random_ep_len:
             self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf,
                                                              high=int(self.env.max_episode_length))
-        obs_dict = self.env.get_observations()
-        to = lambda t: t.to(self.device)
-        obs, privileged_obs, obs_history = to(obs_dict["obs"]), to(obs_dict["privileged_obs"]), to(obs_dict["obs_history"])
         self.alg.actor_critic.train()
+        state = dict(obs_dict=self.env.get_observations(), rew_buf=self.env.get_reward_buf())
+        tracker = _EpisodeTracker(self.env.num_envs, self.device) if logging else None
         ep_infos = []
-        rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
-        cur_reward_sum = torch.zeros(self.env.num_envs, dtype=torch.float, device=self.device)
-        cur_episode_length = torch.zeros(self.env.num_envs, dtype=torch.float, device=self.device)
-        rew_buf = self.env.get_reward_buf()
-        tot_iter = self.current_learning_iteration + num_learning_iterations
-        for it in range(self.current_learning_iteration, tot_iter):
-            start = time.time()
-            with torch.inference_mode():
-                for i in range(self.num_steps_per_env):
-                    actions = self.alg.act(obs, privileged_obs, obs_history, obs_dict['base_vel'], rew_buf)
-                    obs_dict, rewards, dones, infos = self.env.step(actions)
-                    obs, privileged_obs, obs_history = to(obs_dict["obs"]), to(obs_dict["privileged_obs"]), to(obs_dict["obs_history"])
-                    rewards, dones = to(rewards), to(dones)
-                    self.alg.process_env_step(rewards, dones, next_obs=obs_dict['obs'], infos=infos)
-                    if self.log_dir is not None:
-                        if 'episode' in infos:
-                            ep_infos.append(infos['episode'])
-                        cur_reward_sum += rewards
-                        cur_episode_length += 1
-                        new_ids = (dones > 0).nonzero(as_tuple=False)
-                        rewbuffer.extend(cur_reward_sum[new_ids][:, 0].cpu().numpy().tolist())
-                        lenbuffer.extend(cur_episode_length[new_ids][:, 0].cpu().numpy().tolist())
-                        cur_reward_sum[new_ids] = 0
-                        cur_episode_length[new_ids] = 0
-                stop = time.time()
-                collection_time = stop - start
-                start = stop
-                self.alg.compute_returns(obs, privileged_obs, obs_dict['base_vel'])
-            (mean_value_loss, mean_surrogate_loss, mean_adaptation_module_loss, loss_decoder, mean_recons_loss,
-             mean_vel_loss, mean_kld_loss) = self.alg.update()
-            stop = time.time()
-            learn_time = stop - start
-            if self.log_dir is not None:
-                self.log(locals())
-            if it % self.save_interval == 0 and self.log_dir is not None:
-                self.save(os.path.join(self.log_dir, 'model_{}.pt'.format(it)))
+        first, last = self.current_learning_iteration, self.current_learning_iteration + num_learning_iterations
+        for it in range(first, last):
+            t0 = time.time()
+            self._collect(state, tracker, ep_infos)
+            t1 = time.time()
+            losses = self.alg.update()           # (value, surrogate, adaptation, decoder, recons, vel, kld) means
+            t2 = time.time()
+            if logging:
+                self.log(it, last, losses, collection_time=t1 - t0, learn_time=t2 - t1, tracker=tracker)
+                if it % self.save_interval == 0:
+                    self.save(os.path.join(self.log_dir, f'model_{it}.pt'))
             ep_infos.clear()
-        self.current_learning_iteration += num_learning_iterations
-        if self.log_dir is not None:
-            self.save(os.path.join(self.log_dir, 'model_{}.pt'.format(self.current_learning_iteration)))
+        self.current_learning_iteration = last
+        if logging:
+            self.save(os.path.join(self.log_dir, f'model_{last}.pt'))
 
-    def log(self, locs, width=80, pad=35):
-        self.tot_timesteps += self.num_steps_per_env * self.env.num_envs
-        self.tot_time += locs['collection_time'] + locs['learn_time']
-        fps = int(self.num_steps_per_env * self.env.num_envs / (locs['collection_time'] + locs['learn_time']))
+    def log(self, it, last, losses, collection_time, learn_time, tracker, width=80, pad=35):
+        value_loss, surrogate_loss, _adaptation, _decoder, recons_loss, vel_loss, kld_loss = losses
+        steps = self.num_steps_per_env * self.env.num_envs
+        self.tot_timesteps += steps
+        self.tot_time += collection_time + learn_time
         scalars = {
-            'Loss/value_function': locs['mean_value_loss'], 'Loss/surrogate': locs['mean_surrogate_loss'],
-            'Loss/recons_loss': locs['mean_recons_loss'], 'Loss/vel_loss': locs['mean_vel_loss'],
-            'Loss/kld_loss': locs['mean_kld_loss'], 'Loss/learning_rate': self.alg.learning_rate,
-            'Policy/mean_noise_std': float(self.alg.actor_critic.std.mean()), 'Perf/total_fps': fps,
-            'Perf/collection time': locs['collection_time'], 'Perf/learning_time': locs['learn_time']}
-        if len(locs['rewbuffer']) > 0:
-            scalars['Train/mean_reward'] = statistics.mean(locs['rewbuffer'])
-            scalars['Train/mean_episode_length'] = statistics.mean(locs['lenbuffer'])
+            'Loss/value_function': value_loss, 'Loss/surrogate': surrogate_loss, 'Loss/recons_loss': recons_loss,
+            'Loss/vel_loss': vel_loss, 'Loss/kld_loss': kld_loss, 'Loss/learning_rate': self.alg.learning_rate,
+            'Policy/mean_noise_std': float(self.alg.actor_critic.std.mean()),
+            'Perf/total_fps': int(steps / (collection_time + learn_time)),
+            'Perf/collection time': collection_time, 'Perf/learning_time': learn_time}
+        finished = tracker.means()
+        if finished is not None:
+            scalars['Train/mean_reward'], scalars['Train/mean_episode_length'] = finished
         if self.writer is not None:
             for k, v in scalars.items():
-                self.writer.add_scalar(k, v, locs['it'])
-        head = f" Learning iteration {locs['it']}/{self.current_learning_iteration + locs['num_learning_iterations']} "
-        lines = [head.center(width, ' ')] + [f"{k + ':':>{pad}} {v:.4f}" for k, v in scalars.items()]
+                self.writer.add_scalar(k, v, it)
+        lines = [f" Learning iteration {it}/{last} ".center(width, ' ')]
+        lines += [f"{k + ':':>{pad}} {v:.4f}" for k, v in scalars.items()]
         print("#" * width + "\n" + "\n".join(lines))
 
     def save(self, path, infos=None):

@@ -135,3 +135,32 @@ def test_oversized_gemm_operand_is_rejected_loudly():
     ok = Fake()
     ok.shape = (98304, 1389)
     assert _ffi.seg(ok, 0, 693, gather=True).width == 693
+
+
+def test_episode_tracker_matches_a_deque_of_finished_episodes():
+    """The runner's device-side episode book-keeping (ring of the last 100 finished episodes) against the plain
+    per-env Python loop it replaces."""
+    import collections
+    import torch
+    from dtc_amd.runners.on_policy_runner import _EpisodeTracker
+    g = torch.Generator().manual_seed(5)
+    n = 37
+    tr = _EpisodeTracker(n, "cpu", keep=100)
+    ret, length = [0.0] * n, [0] * n
+    rets, lens = collections.deque(maxlen=100), collections.deque(maxlen=100)
+    for _ in range(60):
+        r = torch.randn(n, generator=g)
+        d = (torch.rand(n, generator=g) < 0.08).to(torch.uint8)
+        tr.step(r, d)
+        for i in range(n):
+            ret[i] += float(r[i])
+            length[i] += 1
+            if d[i]:
+                rets.append(ret[i]); lens.append(length[i])
+                ret[i], length[i] = 0.0, 0
+        got = tr.means()
+        if not rets:
+            assert got is None
+        else:
+            assert abs(got[0] - sum(rets) / len(rets)) < 1e-4 and abs(got[1] - sum(lens) / len(lens)) < 1e-4
+    assert len(rets) == 100                   # the ring wrapped at least once

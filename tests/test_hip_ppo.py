@@ -431,6 +431,51 @@ def test_overlapped_schedule_equals_serial_schedule_bitwise():
             assert torch.equal(v, other[2][k]), k
 
 
+def test_training_survives_model_to_calls():
+    """`.to()` on the model must not orphan the optimiser's views of the parameter arena.  (a) a same-device
+    `.to()` (what OnPolicyRunner.get_inference_policy(device=...) does) keeps the arena; (b) a real round trip
+    cuda -> cpu -> cuda re-builds it and the optimisers are re-bound with their Adam state.  In both cases an update
+    afterwards must equal the update of an untouched twin bit for bit."""
+    from dtc_amd.algorithms import PPO
+    from dtc_amd.modules import ActorCriticDecoder
+    d = S.rollout(64, 24, seed=4, device=DEV)
+    perm, e1, e2 = S.update_noise(64, 24, 4, 5, seed=123)
+
+    def make():
+        torch.manual_seed(3)
+        ac = ActorCriticDecoder(53, 1389, 12)
+        alg = PPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV)
+        alg.init_storage(64, 24, [53], [1389], [265], [12])
+        return ac, alg
+
+    def run(alg):
+        for k, v in d.items():
+            if k != "last_values":
+                getattr(alg.storage, k).copy_(v)
+        alg.storage.compute_returns(d["last_values"], 0.99, 0.95)
+        alg.storage.step = 24
+        return alg.update(perm.to(DEV), e1.to(DEV), e2.to(DEV))
+
+    ac0, alg0 = make()
+    run(alg0), run(alg0)
+    want = {k: v.clone() for k, v in ac0.state_dict().items()}
+    for mode in ("same_device", "round_trip"):
+        ac, alg = make()
+        run(alg)
+        arena = ac.arena
+        if mode == "same_device":
+            ac.to(DEV)
+            assert ac.arena is arena
+        else:
+            ac.cpu()
+            ac.to(DEV)
+            assert ac.arena is None          # rebuilt lazily; the optimisers still point at the old buffers here
+        run(alg)
+        assert alg.optimizer.arena is ac.arena and alg.vae_optimizer.arena is ac.arena
+        for k, v in ac.state_dict().items():
+            assert torch.equal(v, want[k]), (mode, k)
+
+
 def test_graphed_rollout_step_matches_eager_kernels():
     """PPO.act replays the rollout-step kernels from a HIP graph: the value head (no random draw) must equal the eager
     launch bit for bit on fresh inputs at every replay, the sampled actions must be fresh draws with a consistent
