@@ -57,13 +57,63 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
+// ---- stage image of a reduction-contiguous operand (X rows, W rows of the forward product; dZ rows of the data
+// gradient).  Stage = 16 k.  Row r of the tile holds its 16 k-values as four 16-byte chunks, chunk c stored at position
+// c ^ ((r >> 2) & 3).  Loader thread t: row t / 4 (+ 64 per pass), chunk t % 4 -> ONE dwordx4 buffer load + ONE
+// ds_write_b128 per 4 k-values (the 8 lanes of a write group cover two rows x 4 chunks = banks 0-15 / 16-31: conflict
+// free).  MFMA lane (row i = lane & 31, half h = lane >> 5) reads chunk 2q + h of its row (q = 0, 1) with ONE
+// ds_read_b128 (the XOR spreads the 16 lanes of a read group over all 64 banks) and feeds the four values to four
+// consecutive MFMA k-steps; k-step (q, t) therefore multiplies k = 8q + t in half 0 and k = 8q + 4 + t in half 1.  Both
+// operands use the same assignment, every k of the stage is used exactly once: the sum is a permuted-order fp32 fma
+// chain (deterministic).  Against the [k][row] image + dword loads of round 1: 3 instead of 12 VMEM and LDS-write
+// instructions and 6 instead of 24 LDS reads per 16 MFMAs.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 bload4(rsrc_t r, u32 voff, u32 soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ int kslot(int r, int chunk) { return r * 4 + (chunk ^ ((r >> 2) & 3)); }
+
+// k tail of a stage: the chunk is loaded whole and the elements past the segment's last column are zeroed in the DATA
+// (v_cndmask), not by per-dword addresses -- one address register per chunk, same register footprint as a full stage.
+// The over-read (at most 12 bytes past the segment's columns) stays inside the source matrix or, behind its last row,
+// behind the descriptor's num_records, where the hardware returns 0 (gfx950 range-checks a dwordx4 buffer load per dword:
+// tools/probes/oob_x4.hip).
+__device__ __forceinline__ f32x4 ktail(f32x4 v, int k0, int klast) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (k0 + e <= klast) ? v[e] : 0.f;
+    return v;
+}
+
+// wide-store epilogue helper: a wave moves one 32x32 accumulator tile (lane = column, 16 rows per lane) through a
+// private LDS patch so that every lane ends up with 4 consecutive columns of one row (4 rows per lane): 4 dwordx4
+// accesses instead of 16 dword accesses per tile.  One wave's LDS operations execute in order: no barrier.
+constexpr int LDW = 36;
+__device__ __forceinline__ void patch_put(float* patch, const f32x16& v, int half, int l31) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * LDW + l31] = v[r];
+}
+__device__ __forceinline__ f32x4 patch_get(const float* patch, int row, int c4) {
+    return *reinterpret_cast<const f32x4*>(&patch[row * LDW + 4 * c4]);
+}
+
+#ifdef DTC_TRACE
+// tools/gemm_lab: per-block shader-clock stamps (start, after the first stage, after the K loop, end) of the forward kernel
+__device__ unsigned long long* g_trace = nullptr;
+#define DTC_STAMP(i) if (threadIdx.x == 0 && g_trace) g_trace[(size_t)blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define DTC_STAMP(i)
+#endif
+
 template <int BN, bool MSE = false>
-__global__ __launch_bounds__(256, 3) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
+__global__ __launch_bounds__(256, 5) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ Y,
-                                                         long long ldy, int M, int N, int K, int act, const MseEpi mse) {
-    using C = Cfg<BN>;
-    __shared__ float As[2][BK][C::LDA];
-    __shared__ float Bs[2][BK][C::LDB];
+                                                         long long ldy, int M, int N, int K, int act, int wide,
+                                                         const MseEpi mse) {
+    constexpr int TN = BN / 32;
+    constexpr int NA = BM / 64;                      // loader passes over the 128 X rows
+    DTC_STAMP(0);
+    __shared__ f32x4 As[2][BM * 4];
+    __shared__ f32x4 Bs[2][BN * 4];
     int tr, tc;
     if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, tr, tc)) {
         if (MSE && threadIdx.x == 0) mse.part[blockIdx.x] = 0.0;      // padding block: its partial slot still gets summed
@@ -71,139 +121,194 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_kernel(const SegMatDev X, c
     }
     const int m0 = tr * BM, n0 = tc * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
+    const int wm_off = wave * 32;
+    const int half = lane >> 5, l31 = lane & 31;
 
-    // loader geometry: thread owns k = kk and rows rbase + 16*i of both operand tiles
-    const int kk = tid & (BK - 1), rbase = tid / BK;
-    constexpr int NA = BM / RP, NB = BN / RP;
-    int arow[NA], grow[NA];
-    u32 woff[NB];                                   // lane byte offset into W (loop invariant)
-    bool any_gather = false;
-    for (int s = 0; s < X.nseg; ++s) any_gather |= X.s[s].gather != 0;
+    // loader geometry: thread owns chunk lch of rows lrow (+64) of X and of row lrow of W
+    const int lrow = tid >> 2, lch = tid & 3;
+    const bool bthread = BN >= 64 || tid < BN * 4;
+    int arow[NA], grow[NA], aslot[NA];
+    const bool any_gather = X.gathers != 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + rbase + RP * i;
+        const int r = lrow + 64 * i, m = m0 + r;
         arow[i] = m < M ? m : -1;
         grow[i] = (any_gather && m < M) ? (int)X.idx[m] : arow[i];
+        aslot[i] = kslot(r, lch);
     }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int n = n0 + rbase + RP * i;
-        woff[i] = n < N ? (u32)(n * K + kk) * 4u : INVALID;
-    }
-    const rsrc_t wres = make_rsrc(W);
+    const int wn = n0 + lrow;
+    const u32 woff = (bthread && wn < N) ? (u32)(wn * K + 4 * lch) * 4u : INVALID;
+    const int bslot = kslot(lrow, lch);
+    const rsrc_t wres = make_rsrc_bytes(W, (long long)N * K * 4);
 
-    // K loop: segment by segment.  The steady-state loop over the full tiles of a segment is ONE basic
-    // block (loads of tile kt+1, MFMAs of tile kt, LDS stores, barrier) with no masks and no branches; the
-    // last tile of a segment (k tail -> masked) and the hop into the next segment are peeled copies.
+    // K loop: segment by segment.  The steady-state loop over the full stages of a segment is ONE basic block (loads
+    // of stage kt+1, MFMAs of stage kt, LDS stores, barrier) with no masks and no branches; the last stage of a
+    // segment (k tail -> per-dword masks) and the hop into the next segment are peeled copies.
     SegDev sd = X.s[0];
     rsrc_t ares;
-    u32 aoff[NA];                                   // lane byte offset of the A element inside the segment
+    u32 aoff[NA];
     auto enter_segment = [&]() {
-        ares = make_rsrc(sd.ptr);
+        ares = make_rsrc_bytes(sd.ptr, (long long)sd.rows * sd.ld * 4);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int r = sd.gather ? grow[i] : arow[i];
-            aoff[i] = r >= 0 ? ((u32)r * (u32)sd.ld + (u32)(sd.col0 + kk)) * 4u : INVALID;
+            aoff[i] = r >= 0 ? ((u32)r * (u32)sd.ld + (u32)(sd.col0 + 4 * lch)) * 4u : INVALID;
         }
     };
-    float ra[NA], rb[NB];
-    auto load_tile = [&](auto masked, int kt) {     // tile kt of the current segment -> registers
-        const u32 kmask = decltype(masked)::value ? oob_mask(kt * BK + kk, sd.width - 1) : 0u;
+    f32x4 ra[NA], rb;
+    auto load_stage = [&](auto masked, int kt) {     // stage kt of the current segment -> registers
         const u32 ka = (u32)(kt * BK) * 4u, kw = (u32)(sd.start + kt * BK) * 4u;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | kmask, ka);
+        for (int i = 0; i < NA; ++i) ra[i] = bload4(ares, aoff[i], ka);
+        rb = bload4(wres, woff, kw);
+        if (decltype(masked)::value) {
+            const int k0 = kt * BK + 4 * lch;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = bload(wres, woff[i] | kmask, kw);
+            for (int i = 0; i < NA; ++i) ra[i] = ktail(ra[i], k0, sd.width - 1);
+            rb = ktail(rb, k0, sd.width - 1);
+        }
     };
-    auto store_tile = [&](int buf) {
+    auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + RP * i] = ra[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[buf][kk][rbase + RP * i] = rb[i];
+        for (int i = 0; i < NA; ++i) As[buf][aslot[i]] = ra[i];
+        if (BN >= 64 || bthread) Bs[buf][bslot] = rb;
     };
 
-    f32x16 acc[C::TM][C::TN];
-    zero_acc<BN>(acc);
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int frow = wm_off + l31, fsw = (frow >> 2) & 3;
+    auto mfma_stage = [&](int buf) {
+        f32x4 a[2], b[TN][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a[q] = As[buf][frow * 4 + ((2 * q + half) ^ fsw)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j][q] = Bs[buf][kslot(32 * j + l31, 2 * q + half)];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][t], b[j][q][t], acc[j], 0, 0, 0);
+    };
 
     int buf = 0;
-    auto step = [&](auto masked, int kt_next) {     // stage tile kt_next while the MFMAs consume LDS[buf]
-        load_tile(masked, kt_next);
-        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-        store_tile(buf ^ 1);
+    auto step = [&](auto masked, int kt_next) {     // stage kt_next in flight while the MFMAs consume LDS[buf]
+        load_stage(masked, kt_next);
+        mfma_stage(buf);
+        store_stage(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     };
     enter_segment();
-    load_tile(Masked{}, 0);
-    store_tile(0);
+    load_stage(Masked{}, 0);
+    store_stage(0);
     __syncthreads();
+    DTC_STAMP(1);
     for (int seg = 0;;) {
         const int n = (sd.width + BK - 1) / BK;
-        for (int kt = 1; kt + 1 < n; ++kt) step(Full{}, kt);
-        if (n > 1) step(Masked{}, n - 1);
+        const int nfull = sd.width / BK;                         // stages without a k tail
+        for (int kt = 1; kt < nfull; ++kt) step(Full{}, kt);
+        if (n > nfull && n > 1) step(Masked{}, n - 1);
         if (++seg == X.nseg) break;
         sd = X.s[seg];
         enter_segment();
         step(Masked{}, 0);
     }
-    mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
+    mfma_stage(buf);
+    DTC_STAMP(2);
 
-    const int half = lane >> 5, l31 = lane & 31;
     const bool full = (m0 + BM <= M) && (n0 + BN <= N);
     if (MSE) {
         // e = (acc + bias) - target[tidx[row], tcol0 + col];  dY = e * scale;  partial = sum e^2 (double)
         const rsrc_t tres = make_rsrc_bytes(mse.target, mse.target_bytes);
         double sq = 0.0;
 #pragma unroll
-        for (int j = 0; j < C::TN; ++j) {
-            const int col = n0 + wn_off + 32 * j + l31;
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + 32 * j + l31;
             const bool cok = col < N;
             const float bv = (bias && cok) ? bias[col] : 0.f;
+            const int row0 = m0 + wm_off + 4 * half;
+            float t[16];
 #pragma unroll
-            for (int i = 0; i < C::TM; ++i) {
-                const int row0 = m0 + wm_off + 32 * i + 4 * half;
-                float t[16];
+            for (int r = 0; r < 16; ++r) {          // 16 gathered target loads in flight (rows past M read row 0, masked below)
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                const long long src = mse.tidx[row < M ? row : 0];
+                t[r] = bload(tres, (u32)((src * mse.ldt + mse.tcol0 + col) * 4) | (cok ? 0u : INVALID), 0u);
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {          // 16 gathered target loads in flight (rows past M read row 0, masked below)
-                    const int row = row0 + (r & 3) + 8 * (r >> 2);
-                    const long long src = mse.tidx[row < M ? row : 0];
-                    t[r] = bload(tres, (u32)((src * mse.ldt + mse.tcol0 + col) * 4) | (cok ? 0u : INVALID), 0u);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + (r & 3) + 8 * (r >> 2);
-                    if (cok && row < M) {
-                        const float e = (acc[i][j][r] + bv) - t[r];
-                        Y[(long long)row * ldy + col] = e * mse.scale;
-                        sq += (double)e * (double)e;
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                if (cok && row < M) {
+                    const float e = (acc[j][r] + bv) - t[r];
+                    Y[(long long)row * ldy + col] = e * mse.scale;
+                    sq += (double)e * (double)e;
                 }
             }
         }
         sq = wave_sum_f64(sq);
-        double* red = reinterpret_cast<double*>(&As[0][0][0]);
+        double* red = reinterpret_cast<double*>(&As[0][0]);
         __syncthreads();                                // all waves are past their last LDS read
         if (lane == 0) red[wave] = sq;
         __syncthreads();
         if (tid == 0) mse.part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
         return;
     }
+    if (wide && full) {
+        // bias + activation in the accumulator layout, transpose through the wave's LDS patch, dwordx4 stores
+        __syncthreads();                                // every wave is past its last operand read
+        float* patch = reinterpret_cast<float*>(&As[0][0]) + wave * (32 * LDW);
+        const int prow = lane >> 3, pc4 = lane & 7;
 #pragma unroll
-    for (int j = 0; j < C::TN; ++j) {
-        const int col = n0 + wn_off + 32 * j + l31;
+        for (int j = 0; j < TN; ++j) {
+            const float bv = bias ? bias[n0 + 32 * j + l31] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] += bv;
+            patch_put(patch, acc[j], half, l31);
+            float* yp = &Y[(long long)(m0 + wm_off + prow) * ldy + n0 + 32 * j + 4 * pc4];
+            // the activation is wave-uniform: one branch per tile, not a select around expm1f per element
+            if (act == DTC_ACT_ELU) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    f32x4 v = patch_get(patch, prow + 8 * p, pc4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
+                    *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = v;
+                }
+            } else if (act == DTC_ACT_RELU) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    f32x4 v = patch_get(patch, prow + 8 * p, pc4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = v;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = patch_get(patch, prow + 8 * p, pc4);
+            }
+        }
+        DTC_STAMP(3);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + 32 * j + l31;
         const bool cok = col < N;
         const float bv = (bias && cok) ? bias[col] : 0.f;
+        float* yp = Y + (long long)(m0 + wm_off + 4 * half) * ldy + col;
 #pragma unroll
-        for (int i = 0; i < C::TM; ++i) {
-            float* yp = Y + (long long)(m0 + wm_off + 32 * i + 4 * half) * ldy + col;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ro = (r & 3) + 8 * (r >> 2);
-                const float v = act_fwd(acc[i][j][r] + bv, act);
-                if (full) yp[(long long)ro * ldy] = v;
-                else if (cok && m0 + wm_off + 32 * i + 4 * half + ro < M) yp[(long long)ro * ldy] = v;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            const float v = act_fwd(acc[j][r] + bv, act);
+            if (full) yp[(long long)ro * ldy] = v;
+            else if (cok && m0 + wm_off + 4 * half + ro < M) yp[(long long)ro * ldy] = v;
         }
     }
 }
@@ -472,6 +577,12 @@ int pick_bn_rows(int rows, int cols) {
 // 2^29 elements; gathered sources are bounded by the caller (row index * ld < 2^29), which holds for the
 // rollouts of up to ~15000 envs x 24 steps per GPU this path is designed for (4096 x 24 x 1389 = 1.4e8).
 
+#ifdef DTC_TRACE
+extern "C" int dtc_debug_set_trace(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, int M, int N,
                               int K, int act, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
@@ -485,8 +596,11 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     const int bn = pick_bn_rows(M, N);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, bn));
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s);
-    if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, MseEpi{});
-    else hipLaunchKernelGGL((linear_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, MseEpi{});
+    // dwordx4 stores of the output need 16-byte aligned rows (full tiles only; checked per block)
+    static const bool wide_off = getenv("DTC_GEMM_WIDE") && atoi(getenv("DTC_GEMM_WIDE")) == 0;      // A/B switch
+    const int wide = (!wide_off && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
+    if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
+    else hipLaunchKernelGGL((linear_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
     return dtc::check_launch("linear_fwd");
 }
 
@@ -511,7 +625,7 @@ extern "C" int dtc_linear_fwd_mse(const DtcSegMat* X, const float* W, const floa
     const MseEpi mse{target, (const long long*)tidx, (long long)ldt, target_rows * ldt * 4, tcol0, scale, sq_part};
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s);
     hipLaunchKernelGGL((linear_fwd_kernel<64, true>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy, M, N, K,
-                       (int)DTC_ACT_NONE, mse);
+                       (int)DTC_ACT_NONE, 0, mse);
     return dtc::check_launch("linear_fwd_mse");
 }
 
@@ -558,10 +672,10 @@ extern "C" int dtc_linear_dgrad_split(const float* dZ, int64_t lddz, const float
     DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * lddz <= MAX_ELEMS, "matrix too large");
     SegMatDev xd;
     xd.nseg = 1;
-    xd.cols = K;
+    xd.gathers = 0;
     xd.idx = nullptr;
-    for (int i = 0; i < 4; ++i) xd.s[i] = SegDev{nullptr, 0, 0, 0x7fffffff, 0, 0, 0};
-    xd.s[0] = SegDev{dX, (long long)lddx, 0, 0, K, 0, 0};
+    for (int i = 0; i < 4; ++i) xd.s[i] = SegDev{nullptr, 0, 0, 0x7fffffff, 0, 0, 0, 0};
+    xd.s[0] = SegDev{dX, (long long)lddx, 0, 0, K, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     const int chunk = N / nsplit;
     // tile width from the work of ALL chunks (they run side by side in one launch)

@@ -26,9 +26,10 @@ struct SegDev {
     float* ptr;
     long long ld;
     int col0, start, width, gather, accumulate;
+    int rows;           // inputs: rows of the source matrix (bounds the buffer descriptor: reads past it return 0)
 };
 struct SegMatDev {
-    int nseg, cols;
+    int nseg, gathers;      // gathers: number of row-gathered segments (host-computed: no kernarg walk in the kernels)
     const long long* idx;
     SegDev s[4];
 };
@@ -153,6 +154,10 @@ int to_dev(const DtcSegMat* h, SegMatDev& d, int expect_cols, bool is_output, lo
             DTC_REQUIRE(!hs.gather || h->idx != nullptr, "segment %d: gather without idx", i);
             DTC_REQUIRE(!(is_output && hs.gather), "segment %d: gathered destination unsupported", i);
             DTC_REQUIRE(hs.gather || hs.ld * rows_bound <= MAX_ELEMS, "segment %d: matrix exceeds 2^29 elements (2 GiB)", i);
+            DTC_REQUIRE(is_output || (hs.rows > 0 && hs.rows * hs.ld <= MAX_ELEMS && (hs.gather || hs.rows >= rows_bound)),
+                        "segment %d: rows=%lld (source matrix rows) missing, too small or beyond 2^29 elements", i, (long long)hs.rows);
+            DTC_REQUIRE(is_output || hs.col0 + hs.width <= hs.ld, "segment %d: columns [%d, %d) outside the %lld-wide source", i,
+                        hs.col0, hs.col0 + hs.width, (long long)hs.ld);
             s.ptr = hs.ptr;
             s.ld = hs.ld;
             s.col0 = hs.col0;
@@ -160,12 +165,14 @@ int to_dev(const DtcSegMat* h, SegMatDev& d, int expect_cols, bool is_output, lo
             s.width = hs.width;
             s.gather = hs.gather;
             s.accumulate = hs.accumulate;
+            s.rows = (int)hs.rows;
             start += hs.width;
         } else {
-            s = SegDev{nullptr, 0, 0, 0x7fffffff, 0, 0, 0};
+            s = SegDev{nullptr, 0, 0, 0x7fffffff, 0, 0, 0, 0};
         }
     }
-    d.cols = start;
+    d.gathers = 0;
+    for (int i = 0; i < h->nseg; ++i) d.gathers += h->seg[i].gather != 0;
     DTC_REQUIRE(start == expect_cols, "segments cover %d columns, expected %d", start, expect_cols);
     return DTC_OK;
 }

@@ -91,12 +91,12 @@ __global__ __launch_bounds__(256) void gru_add_parts_kernel(float* __restrict__ 
     if (e < rh) dh[e] = ((dh[e] + part[e]) + part[rh + e]) + part[2 * rh + e];
 }
 
-DtcSegMat plain(const float* p, int64_t ld, int cols) {
+DtcSegMat plain(const float* p, int64_t ld, int cols, int64_t rows) {
     DtcSegMat m;
     m.nseg = 1;
     m.cols = cols;
     m.idx = nullptr;
-    m.seg[0] = DtcSeg{const_cast<float*>(p), ld, 0, cols, 0, 0};
+    m.seg[0] = DtcSeg{const_cast<float*>(p), ld, 0, cols, 0, 0, rows};
     return m;
 }
 
@@ -131,7 +131,7 @@ extern "C" int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, 
             if (rc != DTC_OK) return rc;
             continue;
         }
-        const DtcSegMat X = plain(hprev, H, H);
+        const DtcSegMat X = plain(hprev, H, H, R);
         int rc = dtc_linear_fwd(&X, W_hh, b_hh, gh, 3 * H, R, 3 * H, H, DTC_ACT_NONE, stream);
         if (rc != DTC_OK) return rc;
         dtc::ProfScope prof("gru_gate_fwd", (double)RH * 4.0 * 12, s);
@@ -168,7 +168,7 @@ extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* g
         if (rc != DTC_OK) return rc;
     }
     hipLaunchKernelGGL(gru_add_parts_kernel, dim3(grid), dim3(256), 0, s, dh0, part, (long long)RH);
-    const DtcSegMat Hprev = plain(hs_all, H, H);
+    const DtcSegMat Hprev = plain(hs_all, H, H, (int64_t)T * R);
     int rc = dtc_linear_wgrad(dgh_all, 3 * H, &Hprev, dW_hh, db_hh, wg_ws, T * R, 3 * H, H, stream);
     if (rc != DTC_OK) return rc;
     return dtc::check_launch("gru_bwd");

@@ -28,7 +28,7 @@ class DtcGridCfg(C.Structure):
 
 class DtcSeg(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int64), ("col0", C.c_int32), ("width", C.c_int32),
-                ("gather", C.c_int32), ("accumulate", C.c_int32)]
+                ("gather", C.c_int32), ("accumulate", C.c_int32), ("rows", C.c_int64)]
 
 
 class DtcSegMat(C.Structure):
@@ -192,6 +192,7 @@ def seg(t: torch.Tensor | None, col0: int, width: int, gather: bool = False, acc
             # or not, must stay below 2 GiB -- e.g. privileged observations [T*N, 1389]: T*N <= 386 000 rows per GPU
             raise DtcError(f"operand of {t.shape[0]} x {t.stride(0)} floats exceeds 2^29 elements (2 GiB); shard the rollout")
         s.ptr, s.ld = ptr(t), (t.stride(0) if ld is None else ld)
+        s.rows = t.shape[0]
         s._keep = t                    # the descriptor holds a raw pointer: keep the tensor alive with it
     s.col0, s.width, s.gather, s.accumulate = col0, width, int(gather), int(accumulate)
     return s

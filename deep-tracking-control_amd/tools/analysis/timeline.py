@@ -57,3 +57,32 @@ for s, e, n, q, g in step:
     by[k][1] += e - s
 for k, (c, t) in sorted(by.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f"  {k:42s} {c:5d} {t / 1e6:8.3f} ms")
+
+# ---- exposed time: intervals in which no >=700-block GEMM runs; which kernels run there
+wide.sort()
+merged = []
+for s, e in wide:
+    if merged and s <= merged[-1][1]:
+        merged[-1][1] = max(merged[-1][1], e)
+    else:
+        merged.append([s, e])
+gaps = []
+prev = t0
+for s, e in merged:
+    if s > prev:
+        gaps.append((prev, s))
+    prev = max(prev, e)
+if prev < t1:
+    gaps.append((prev, t1))
+tot_gap = sum(e - s for s, e in gaps)
+print(f"  time with no wide GEMM in flight: {tot_gap / 1e6:.3f} ms in {len(gaps)} intervals")
+acc = collections.defaultdict(float)
+for s, e, n, q, g in step:
+    if g >= 700 and "linear_" in n:
+        continue
+    for gs, ge in gaps:
+        lo, hi = max(s, gs), min(e, ge)
+        if hi > lo:
+            acc[n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:40] + f" g{g}"] += hi - lo
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:30]:
+    print(f"    {k:50s} {v / 1e6:7.3f} ms")

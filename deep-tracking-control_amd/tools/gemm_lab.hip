@@ -13,7 +13,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
 #include <vector>
+
+#include "../../include/dtc_hip.h"
+typedef int (*fwd_fn)(const DtcSegMat*, const float*, const float*, float*, int64_t, int, int, int, int, void*);
+static fwd_fn g_prod_fwd = nullptr;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -149,6 +155,8 @@ __global__ __launch_bounds__(256, OCC) void fwd_v2(const float* __restrict__ X, 
     constexpr int NA = BM / 64, NB = (BN + 63) / 64;
     __shared__ f32x4 As[2][BM * 4];
     __shared__ f32x4 Bs[2][BN * 4];
+    extern __shared__ float dyn_pad[];          // residency cap for experiments (dynamic LDS bytes chosen by the host)
+    if (M < 0) dyn_pad[threadIdx.x] = 0.f;
     int tr, tc;
     if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, tr, tc)) return;
     const int m0 = tr * BM, n0 = tc * BN;
@@ -226,7 +234,25 @@ __global__ __launch_bounds__(256, OCC) void fwd_v2(const float* __restrict__ X, 
     if (KT == 1 && tail) load_masked(0); else load(0);
     store(0);
     __syncthreads();
+    unsigned long long t_pro = 0, t_loop = 0;
+    if (VAR == 1) t_pro = __builtin_amdgcn_s_memtime();
     const int full_end = tail ? KT - 1 : KT;
+    if (VAR == 2) {
+        // progress-based priority: a wave in an earlier quarter of its K loop outranks waves that are further along, so
+        // the blocks of a CU finish together instead of oldest-first (no long tail with 1-2 waves per SIMD)
+        const int q1 = KT / 4, q2 = KT / 2, q3 = (3 * KT) / 4;
+        __builtin_amdgcn_s_setprio(3);
+        for (int kt = 1; kt < full_end; ++kt) {
+            if (kt == q1) __builtin_amdgcn_s_setprio(2);
+            if (kt == q2) __builtin_amdgcn_s_setprio(1);
+            if (kt == q3) __builtin_amdgcn_s_setprio(0);
+            load(kt);
+            mfma(buf);
+            store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else
     for (int kt = 1; kt < full_end; ++kt) {
         load(kt);
         mfma(buf);
@@ -242,6 +268,32 @@ __global__ __launch_bounds__(256, OCC) void fwd_v2(const float* __restrict__ X, 
         buf ^= 1;
     }
     mfma(buf);
+    if (VAR == 1) t_loop = __builtin_amdgcn_s_memtime();
+    if (VAR == 3 && (N & 3) == 0 && m0 + BM <= M && n0 + BN <= N) {
+        // wide-store epilogue: each wave transposes its 32x32 sub-tiles through a private LDS patch (lane = column ->
+        // lane = 4 consecutive columns of one row) and writes dwordx4: 8 store instructions per wave instead of 32
+        constexpr int LDW = 36;
+        __syncthreads();                                  // every wave is past its last operand read
+        float* patch = reinterpret_cast<float*>(&As[0][0]) + wave * (32 * LDW);
+        const int rrow = lane >> 3, rc4 = lane & 7;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float bv = bias[n0 + 32 * j + l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[j][r] + bv;
+                patch[((r & 3) + 8 * (r >> 2) + 4 * half) * LDW + l31] = v > 0.f ? v : 0.f;
+            }
+            // same wave wrote and reads: LDS ops of one wave execute in order, no barrier needed
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = rrow + 8 * p;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&patch[row * LDW + 4 * rc4]);
+                *reinterpret_cast<f32x4*>(&Y[(long long)(m0 + wm_off + row) * N + n0 + 32 * j + 4 * rc4]) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + 32 * j + l31;
@@ -255,6 +307,8 @@ __global__ __launch_bounds__(256, OCC) void fwd_v2(const float* __restrict__ X, 
         }
     }
     if (VAR == 1 && threadIdx.x == 0) {
+        g_dbg[(size_t)gridDim.x * 6 + (size_t)blockIdx.x * 2] = t_pro;
+        g_dbg[(size_t)gridDim.x * 6 + (size_t)blockIdx.x * 2 + 1] = t_loop;
         unsigned long long* d = g_dbg + (size_t)blockIdx.x * 6;
         u32 hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -327,18 +381,104 @@ static float timeit(F f, int reps) {
     return ms / reps;
 }
 
-static void trace_run(Prob& p) {
+// calibration: N dependent MFMAs on ONE accumulator (64 cycles each, issue = latency) -> shader cycles by construction
+__global__ __launch_bounds__(256) void mfma_chain(float* out, unsigned long long* t, int n) {
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < n; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += acc[r];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (s == 12345.f) out[0] = s;
+    if (threadIdx.x == 0) { t[blockIdx.x * 2] = t1 - t0; t[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+
+static void calibrate(int blocks) {
+    unsigned long long* d;
+    float* o;
+    hipMalloc(&d, blocks * 16);
+    hipMalloc(&o, 64);
+    const int n = 1 << 16;
+    for (int rep = 0; rep < 3; ++rep) mfma_chain<<<blocks, 256>>>(o, d, n);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(blocks * 2);
+    hipMemcpy(h.data(), d, blocks * 16, hipMemcpyDeviceToHost);
+    double mt = 0, rt = 0;
+    for (int b = 0; b < blocks; ++b) { mt += h[2 * b]; rt += h[2 * b + 1]; }
+    printf("calibration %4d blocks x 4 waves: %d dependent MFMAs = %d MFMA cycles; s_memtime %.0f ticks (%.3f per MFMA cycle), "
+           "s_memrealtime %.0f ticks -> MFMA clock %.3f GHz if realtime = 100 MHz\n", blocks, n, n * 64, mt / blocks,
+           mt / blocks / (n * 64.0), rt / blocks, n * 64.0 / (rt / blocks) * 0.1);
+    hipFree(d);
+    hipFree(o);
+}
+
+static void product_trace(Prob& p) {
+    void* h = dlopen("deep-tracking-control_amd/tools/_bin/libdtc_hip_trace.so", RTLD_NOW);
+    if (!h) { printf("trace library missing\n"); return; }
+    fwd_fn fwd = (fwd_fn)dlsym(h, "dtc_linear_fwd");
+    typedef int (*set_fn)(unsigned long long*);
+    set_fn set = (set_fn)dlsym(h, "dtc_debug_set_trace");
     const int rt = (p.M + 127) / 128, grid = grid_for(rt, (p.N + 63) / 64);
     unsigned long long* d;
-    hipMalloc(&d, (size_t)grid * 6 * 8);
-    hipMemset(d, 0, (size_t)grid * 6 * 8);
-    hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &d, sizeof(d));
-    for (int i = 0; i < 1500; ++i) fwd_v2<64, 4, 1><<<grid, 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K);
+    hipMalloc(&d, (size_t)grid * 32);
+    hipMemset(d, 0, (size_t)grid * 32);
+    set(d);
+    DtcSegMat xs;
+    memset(&xs, 0, sizeof(xs));
+    xs.nseg = 1; xs.cols = p.K;
+    xs.seg[0].ptr = p.X; xs.seg[0].ld = p.K; xs.seg[0].col0 = 0; xs.seg[0].width = p.K; xs.seg[0].rows = p.M;
+    for (int i = 0; i < 1500; ++i) fwd(&xs, p.W, p.b, p.Y, p.N, p.M, p.N, p.K, DTC_ACT_RELU, nullptr);
     hipDeviceSynchronize();
-    std::vector<unsigned long long> h((size_t)grid * 6);
+    std::vector<unsigned long long> t((size_t)grid * 4);
+    hipMemcpy(t.data(), d, t.size() * 8, hipMemcpyDeviceToHost);
+    double pro = 0, loop = 0, epi = 0;
+    int n = 0;
+    for (int b = 0; b < grid; ++b) {
+        const unsigned long long* e = &t[(size_t)b * 4];
+        if (!e[3]) continue;
+        pro += (double)(e[1] - e[0]); loop += (double)(e[2] - e[1]); epi += (double)(e[3] - e[2]); ++n;
+    }
+    printf("[product] trace M=%d N=%d K=%d: %d blocks; phases per block (cycles): prologue %.0f  K loop %.0f  epilogue %.0f  total %.0f\n",
+           p.M, p.N, p.K, n, pro / n, loop / n, epi / n, (pro + loop + epi) / n);
+    set(nullptr);
+    hipFree(d);
+}
+
+template <int OCC>
+static void trace_run(Prob& p) {
+    const int rt = (p.M + 127) / 128, grid = grid_for(rt, (p.N + 63) / 64);
+    printf("[occ %d] ", OCC);
+    unsigned long long* d;
+    hipMalloc(&d, (size_t)grid * 8 * 8);
+    hipMemset(d, 0, (size_t)grid * 8 * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &d, sizeof(d));
+    for (int i = 0; i < 1500; ++i) fwd_v2<64, OCC, 1><<<grid, 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)grid * 8);
     hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    {   // phases per block and per-XCD spans, in shader cycles (XCD counters are not synchronised with each other)
+        double pro = 0, loop = 0, epi = 0;
+        unsigned long long xmin[8], xmax[8];
+        for (int x = 0; x < 8; ++x) { xmin[x] = ~0ull; xmax[x] = 0; }
+        int n = 0;
+        for (int b = 0; b < grid; ++b) {
+            const unsigned long long* e = &h[(size_t)b * 6];
+            if (e[1] == 0) continue;
+            const unsigned long long tp = h[(size_t)grid * 6 + (size_t)b * 2], tl = h[(size_t)grid * 6 + (size_t)b * 2 + 1];
+            pro += (double)(tp - e[0]); loop += (double)(tl - tp); epi += (double)(e[1] - tl);
+            const int x = (int)e[5] & 7;
+            if (e[0] < xmin[x]) xmin[x] = e[0];
+            if (e[1] > xmax[x]) xmax[x] = e[1];
+            ++n;
+        }
+        printf("  phases per block (cycles): prologue %.0f  K loop %.0f  epilogue %.0f;  per-XCD span:", pro / n, loop / n, epi / n);
+        for (int x = 0; x < 8; ++x) printf(" %llu", xmax[x] - xmin[x]);
+        printf("\n");
+    }
     unsigned long long tmin = ~0ull, tmax = 0, rmin = ~0ull, rmax = 0;
-    double dur = 0;
+    double dur = 0, rdur = 0;
     int nb = 0;
     std::vector<int> per_cu(8 * 256, 0);
     for (int b = 0; b < grid; ++b) {
@@ -350,13 +490,14 @@ static void trace_run(Prob& p) {
         if (e[2] < rmin) rmin = e[2];
         if (e[3] > rmax) rmax = e[3];
         dur += (double)(e[1] - e[0]);
+        rdur += (double)(e[3] - e[2]);
         const unsigned hw = (unsigned)e[4];
         const int cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;       // HW_ID: CU_ID[11:8] SH_ID[12] SE_ID[15:13]
         per_cu[((int)e[5] & 7) * 256 + ((se * 2 + sh) * 16 + cu) % 256] += 1;
     }
-    const double span_cyc = (double)(tmax - tmin), span_us = (double)(rmax - rmin) / 100.0;
-    printf("trace M=%d N=%d K=%d: %d blocks, span %.1f us (%.0f shader cycles -> %.3f GHz), mean block %.0f cycles (%.1f us)\n", p.M, p.N,
-           p.K, nb, span_us, span_cyc, span_cyc / span_us * 1e-3, dur / nb, dur / nb / (span_cyc / span_us));
+    const double span_us = (double)(rmax - rmin) / 100.0, ghz = dur / rdur * 0.1;
+    printf("trace M=%d N=%d K=%d: %d blocks, span %.1f us, shader clock %.3f GHz (s_memtime / s_memrealtime over all blocks), mean block %.0f cycles (%.1f us)\n", p.M, p.N,
+           p.K, nb, span_us, ghz, dur / nb, dur / nb / ghz * 1e-3);
     int hist[16] = {0}, used = 0;
     for (int c : per_cu) if (c) { ++used; hist[c < 15 ? c : 15]++; }
     printf("  CUs used %d; blocks-per-CU histogram:", used);
@@ -378,6 +519,11 @@ static void trace_run(Prob& p) {
 }
 
 int main(int argc, char** argv) {
+    {   // the product library (same directory layout as the repo): dtc_linear_fwd under the lab's clock
+        void* h = dlopen("deep-tracking-control_amd/dtc_amd/lib/libdtc_hip.so", RTLD_NOW);
+        if (h) g_prod_fwd = (fwd_fn)dlsym(h, "dtc_linear_fwd");
+        printf("product library: %s\n", g_prod_fwd ? "loaded" : "NOT loaded");
+    }
     const int shapes[][3] = {{24576, 512, 512}, {24576, 512, 693}, {24576, 693, 512}, {24576, 512, 752}, {24576, 512, 584},
                              {24576, 256, 512}, {24576, 128, 256}, {24576, 128, 265}, {24576, 64, 531}, {24576, 64, 128},
                              {24576, 35, 64}, {24576, 12, 128}, {1470, 512, 512}};
@@ -401,11 +547,20 @@ int main(int argc, char** argv) {
         };
         const int reps = 100;
         if (argc > 1 && !strcmp(argv[1], "trace")) {
-            if (p.N >= 256 && p.M > 2000) trace_run(p);
+            if (&s == &shapes[0]) { calibrate(1); calibrate(256); calibrate(1024); }
+            if (p.N >= 256 && p.M > 2000) { trace_run<4>(p); trace_run<6>(p); product_trace(p); }
             hipFree(p.X); hipFree(p.W); hipFree(p.b); hipFree(p.Y);
             continue;
         }
         for (int round = 0; round < 2; ++round) {
+            if (g_prod_fwd) {
+                DtcSegMat xs;
+                memset(&xs, 0, sizeof(xs));
+                xs.nseg = 1; xs.cols = p.K;
+                xs.seg[0].ptr = p.X; xs.seg[0].ld = p.K; xs.seg[0].col0 = 0; xs.seg[0].width = p.K; xs.seg[0].rows = p.M;
+                hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
+                report("product fwd", timeit([&] { g_prod_fwd(&xs, p.W, p.b, p.Y, p.N, p.M, p.N, p.K, DTC_ACT_RELU, nullptr); }, reps));
+            }
             if (p.N > 32) {
                 hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
                 report("v1 BN64", timeit([&] { fwd_v1<64><<<grid_for(rt, (p.N + 63) / 64), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
@@ -413,6 +568,17 @@ int main(int argc, char** argv) {
                 report("v2 BN64 occ3", timeit([&] { fwd_v2<64, 3, 0><<<grid_for(rt, (p.N + 63) / 64), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
                 hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
                 report("v2 BN64 occ4", timeit([&] { fwd_v2<64, 4, 0><<<grid_for(rt, (p.N + 63) / 64), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
+                report("v2 occ4 wide-st", timeit([&] { fwd_v2<64, 4, 3><<<grid_for(rt, (p.N + 63) / 64), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
+                report("v2 occ6 wide-st", timeit([&] { fwd_v2<64, 6, 3><<<grid_for(rt, (p.N + 63) / 64), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                for (int cap = 6; cap <= 6; ++cap) {         // blocks per CU capped through dynamic LDS: 160 KiB / cap - static 24 KiB
+                    const int dyn = cap == 6 ? 0 : (160 * 1024 / cap - 24 * 1024 - 512) & ~255;
+                    char tag[32];
+                    snprintf(tag, sizeof(tag), "v2 occ6 cap%d", cap);
+                    hipFuncSetAttribute((const void*)fwd_v2<64, 6, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+                    report(tag, timeit([&] { fwd_v2<64, 6, 0><<<grid_for(rt, (p.N + 63) / 64), 256, dyn>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                }
             }
             hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
             report("v1 BN32", timeit([&] { fwd_v1<32><<<grid_for(rt, (p.N + 31) / 32), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));

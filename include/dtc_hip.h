@@ -159,6 +159,9 @@ typedef struct DtcSeg {
     int32_t width;       /* number of columns of this block                                     */
     int32_t gather;      /* 1: row m of the virtual matrix is row idx[m] of the source          */
     int32_t accumulate;  /* outputs only: 1 = add into the destination instead of overwriting   */
+    int64_t rows;        /* inputs: number of rows of the source matrix (rows*ld floats behind ptr are readable: the
+                          * loaders read 16 bytes at a time and bound their buffer descriptor with it -- reads past
+                          * the last row return 0); outputs: unused                                              */
 } DtcSeg;
 
 typedef struct DtcSegMat {
