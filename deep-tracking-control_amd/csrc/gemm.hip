@@ -445,14 +445,22 @@ __global__ __launch_bounds__(256, 3) void gru_step_fwd_kernel(const float* __res
 // ------------------------------------------------------------------------------------------
 // Data gradient: dX[M,K] = (dZ[M,N] W[N,K]) * act'(Xsaved)   (reduction over N)
 // ------------------------------------------------------------------------------------------
+// A = dZ rows (reduction index n contiguous): the stage image of the forward kernel (dwordx4 loads, ds_read_b128
+// fragments, k-step (q, t) = n 8q + t / 8q + 4 + t in the two lane halves).  B = W[n][c] has the reduction index as its
+// ROW: float4 loads along c, LDS image [n][col] (+4 pad), one ds_read_b32 per MFMA step from row 8q + 4h + t.
+// Columns of B past K read the next row of W (or 0 behind its last row): they only feed output columns that are never
+// stored, so the B loads carry no column masks at all.
 template <int BN>
-__global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __restrict__ dZ, long long lddz,
+__global__ __launch_bounds__(256, 5) void linear_dgrad_kernel(const float* __restrict__ dZ, long long lddz,
                                                            const float* __restrict__ W, const SegMatDev dX,
                                                            const float* __restrict__ Xs, long long ldxs, int M, int N,
-                                                           int K, int act, int split_n, long long split_dst, int col_skip) {
-    using C = Cfg<BN>;
-    __shared__ float As[2][BK][C::LDA];
-    __shared__ float Bs[2][BK][C::LDB];
+                                                           int K, int act, int split_n, long long split_dst, int col_skip,
+                                                           int wide_segs) {
+    constexpr int TN = BN / 32;
+    constexpr int NA = BM / 64;
+    constexpr int LDB = BN + 4;
+    __shared__ f32x4 As[2][BM * 4];
+    __shared__ float Bs[2][BK][LDB];
     int tr, tc;
     // col_skip: leading columns whose destination is NULL (inputs that need no gradient, e.g. the raw observations in
     // front of the actor's features) -- the column tiles start behind them, nothing is computed for them
@@ -460,99 +468,166 @@ __global__ __launch_bounds__(256, 3) void linear_dgrad_kernel(const float* __res
     // split reduction (dtc_linear_dgrad_split): grid.y = chunk g of the reduction index; chunk g multiplies columns
     // [g*split_n, (g+1)*split_n) of dZ with the matching rows of W and writes its own destination matrix
     long long dst_off = 0;
+    int z0 = 0;                                      // first dZ column / W row of this chunk
+    const int n_total = N;
     if (split_n > 0) {
-        dZ += (long long)blockIdx.y * split_n;
-        W += (long long)blockIdx.y * split_n * K;
+        z0 = blockIdx.y * split_n;
         N = split_n;
         dst_off = (long long)blockIdx.y * split_dst;
     }
     const int m0 = tr * BM, c0 = col_skip + tc * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
+    const int wm_off = wave * 32;
+    const int half = lane >> 5, l31 = lane & 31;
 
-    const int kk = tid & (BK - 1), rbase = tid / BK;      // A loader (dZ rows, reduction index n contiguous)
-    constexpr int NA = BM / RP;
-    constexpr int RPP = 256 / BN;                   // B loader: reduction rows per pass
-    constexpr int NB = BK / RPP;
-    const int bj = tid % BN, bk0 = tid / BN;
-    u32 aoff[NA], boff[NB];
+    const int lrow = tid >> 2, lch = tid & 3;       // A loader: chunk lch of rows lrow (+64)
+    u32 aoff[NA];
+    int aslot[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + rbase + RP * i;
-        aoff[i] = m < M ? (u32)((long long)m * lddz + kk) * 4u : INVALID;
+        const int r = lrow + 64 * i, m = m0 + r;
+        aoff[i] = m < M ? (u32)((long long)m * lddz + z0 + 4 * lch) * 4u : INVALID;
+        aslot[i] = kslot(r, lch);
     }
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-        boff[i] = c0 + bj < K ? (u32)((bk0 + RPP * i) * K + c0 + bj) * 4u : INVALID;
-    const rsrc_t ares = make_rsrc(dZ), bres = make_rsrc(W);
+    constexpr int C4 = BN / 4;                      // float4 columns per B row
+    const bool bthread = tid < BK * C4;
+    const int bk = tid / C4, bc = 4 * (tid % C4);   // B loader: W row n_0 + bk, columns c0 + bc .. +3
+    const u32 boff = bthread ? (u32)((z0 + bk) * K + c0 + bc) * 4u : INVALID;
+    const rsrc_t ares = make_rsrc_bytes(dZ, (long long)M * lddz * 4), bres = make_rsrc_bytes(W, (long long)n_total * K * 4);
 
-    float ra[NA], rb[NB];
-    auto load_tile = [&](auto masked, int n_0) {
-        constexpr bool MK = decltype(masked)::value;
-        const u32 nmask = MK ? oob_mask(n_0 + kk, N - 1) : 0u;
+    f32x4 ra[NA], rb;
+    auto load_stage = [&](auto masked, int n_0) {
         const u32 sa = (u32)n_0 * 4u, sb = (u32)n_0 * (u32)K * 4u;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | nmask, sa);
+        for (int i = 0; i < NA; ++i) ra[i] = bload4(ares, aoff[i], sa);
+        if (decltype(masked)::value) {              // N tail: dZ columns past N are zeroed, W rows past N are not read
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = bload(bres, boff[i] | (MK ? oob_mask(n_0 + bk0 + RPP * i, N - 1) : 0u), sb);
+            for (int i = 0; i < NA; ++i) ra[i] = ktail(ra[i], n_0 + 4 * lch, N - 1);
+            rb = bload4(bres, boff | oob_mask(n_0 + bk, N - 1), sb);
+        } else {
+            rb = bload4(bres, boff, sb);
+        }
     };
-    auto store_tile = [&](int buf) {
+    auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[buf][kk][rbase + RP * i] = ra[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[buf][bk0 + RPP * i][bj] = rb[i];
+        for (int i = 0; i < NA; ++i) As[buf][aslot[i]] = ra[i];
+        if (BN >= 64 || bthread) *reinterpret_cast<f32x4*>(&Bs[buf][bk][bc]) = rb;
     };
 
-    f32x16 acc[C::TM][C::TN];
-    zero_acc<BN>(acc);
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int frow = wm_off + l31, fsw = (frow >> 2) & 3;
+    auto mfma_stage = [&](int buf) {
+        f32x4 a[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a[q] = As[buf][frow * 4 + ((2 * q + half) ^ fsw)];
+        const float* bp = &Bs[buf][4 * half][l31];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float b[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = bp[(8 * q + t) * LDB + 32 * j];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][t], b[j], acc[j], 0, 0, 0);
+            }
+    };
 
     int buf = 0;
     auto step = [&](auto masked, int kt_next) {
-        load_tile(masked, kt_next * BK);
-        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
-        store_tile(buf ^ 1);
+        load_stage(masked, kt_next * BK);
+        mfma_stage(buf);
+        store_stage(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     };
-    const int KT = (N + BK - 1) / BK;
-    load_tile(Masked{}, 0);
-    store_tile(0);
+    const int KT = (N + BK - 1) / BK, KF = N / BK;
+    if (KF >= 1) load_stage(Full{}, 0); else load_stage(Masked{}, 0);
+    store_stage(0);
     __syncthreads();
-    for (int kt = 1; kt + 1 < KT; ++kt) step(Full{}, kt);      // branch-free steady state (full tiles)
-    if (KT > 1) step(Masked{}, KT - 1);                        // N tail
-    mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
+    for (int kt = 1; kt < KF; ++kt) step(Full{}, kt);          // branch-free steady state (full stages)
+    if (KT > KF && KT > 1) step(Masked{}, KT - 1);             // N tail
+    mfma_stage(buf);
 
-    // epilogue: the saved activations come in through unconditional buffer loads (rows >= M fall past the
+    // ---- epilogue: activation derivative (through the saved post-activation output), segmented destination
+    const rsrc_t xres = make_rsrc_bytes(Xs, (long long)M * ldxs * 4);
+    if (m0 + BM <= M && c0 + BN <= K) {
+        // wide path per 32-column sub-tile that lies inside ONE destination segment with 16-byte aligned rows: transpose
+        // through the wave's LDS patch, then float4 loads of the saved activation / the accumulated destination and
+        // float4 stores (4 instead of 16 memory instructions per operand and sub-tile)
+        bool all_wide = true;
+        int segj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cj = c0 + 32 * j;
+            segj[j] = find_seg(dX, cj);
+            const SegDev& sd = dX.s[segj[j]];
+            all_wide = all_wide && ((wide_segs >> segj[j]) & 1) && cj + 32 <= sd.start + sd.width && ((cj - sd.start) & 3) == 0 &&
+                       (act == DTC_ACT_NONE || ((wide_segs >> 4) & 1));
+        }
+        if (all_wide) {
+            __syncthreads();                            // every wave is past its last operand read
+            float* patch = reinterpret_cast<float*>(&As[0][0]) + wave * (32 * LDW);
+            const int prow = lane >> 3, pc4 = lane & 7;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const SegDev sd = dX.s[segj[j]];
+                const int cj = c0 + 32 * j + 4 * pc4;
+                patch_put(patch, acc[j], half, l31);
+                if (sd.ptr == nullptr) continue;
+                float* dst = sd.ptr + dst_off + sd.col0 + (cj - sd.start) + (long long)(m0 + wm_off + prow) * sd.ld;
+                const float* ys = Xs + (long long)(m0 + wm_off + prow) * ldxs + cj;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    f32x4 v = patch_get(patch, prow + 8 * p, pc4);
+                    if (act != DTC_ACT_NONE) {
+                        const f32x4 y = *reinterpret_cast<const f32x4*>(ys + (long long)(8 * p) * ldxs);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_bwd(v[e], y[e], act);
+                    }
+                    f32x4* q = reinterpret_cast<f32x4*>(dst + (long long)(8 * p) * sd.ld);
+                    if (sd.accumulate) {
+                        const f32x4 o = *q;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = o[e] + v[e];
+                    }
+                    *q = v;
+                }
+            }
+            return;
+        }
+    }
+    // scalar path: the saved activations come in through unconditional buffer loads (rows >= M fall past the
     // descriptor's size, columns >= K get the INVALID offset -> 0), so all 16 loads of a 32x32 tile are in
     // flight together instead of one exec-guarded load -> select -> store chain per element
-    const int half = lane >> 5, l31 = lane & 31;
-    const rsrc_t xres = make_rsrc_bytes(Xs, (long long)M * ldxs * 4);
 #pragma unroll
-    for (int j = 0; j < C::TN; ++j) {
-        const int col = c0 + wn_off + 32 * j + l31;
+    for (int j = 0; j < TN; ++j) {
+        const int col = c0 + 32 * j + l31;
         const bool cok = col < K;
         const SegDev sd = dX.s[find_seg(dX, cok ? col : 0)];
         const bool live = cok && sd.ptr != nullptr;
         float* dst = sd.ptr + dst_off + sd.col0 + (col - sd.start);
+        const int row0 = m0 + wm_off + 4 * half;
+        float y[16];
+        if (act != DTC_ACT_NONE) {
+            const u32 xoff = ((u32)row0 * (u32)ldxs + (u32)col) * 4u | (cok ? 0u : INVALID);
 #pragma unroll
-        for (int i = 0; i < C::TM; ++i) {
-            const int row0 = m0 + wm_off + 32 * i + 4 * half;
-            float y[16];
-            if (act != DTC_ACT_NONE) {
-                const u32 xoff = ((u32)row0 * (u32)ldxs + (u32)col) * 4u | (cok ? 0u : INVALID);
+            for (int r = 0; r < 16; ++r)
+                y[r] = bload(xres, xoff, (u32)(((r & 3) + 8 * (r >> 2)) * (int)ldxs) * 4u);
+        }
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    y[r] = bload(xres, xoff, (u32)(((r & 3) + 8 * (r >> 2)) * (int)ldxs) * 4u);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r];
-                if (act != DTC_ACT_NONE) v = act_bwd(v, y[r], act);
-                if (live && row < M) {
-                    float* q = dst + (long long)row * sd.ld;
-                    *q = sd.accumulate ? (*q + v) : v;
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            float v = acc[j][r];
+            if (act != DTC_ACT_NONE) v = act_bwd(v, y[r], act);
+            if (live && row < M) {
+                float* q = dst + (long long)row * sd.ld;
+                *q = sd.accumulate ? (*q + v) : v;
             }
         }
     }
@@ -569,6 +644,21 @@ int pick_bn_rows(int rows, int cols) {
     static const char* thr_env = getenv("DTC_GEMM_MIN_BLOCKS");
     const long long min_blocks = thr_env ? atoi(thr_env) : 320;     // measured with DTC_GEMM_MIN_BLOCKS sweeps of bench.py
     return dtc::ceil_div(rows, BM) * dtc::ceil_div(cols, 64) >= min_blocks ? 64 : 32;
+}
+
+// dgrad wide-store eligibility: bit s = destination segment s can be read/written with float4 accesses (16-byte aligned
+// base + column origin, row stride a multiple of 4 floats, tile origin on a 4-column boundary); bit 4 = the same for
+// the saved-activation matrix
+int wide_mask(const SegMatDev& xd, const float* Xsaved, long long ldxs, int col_skip, long long split_stride) {
+    static const bool off = getenv("DTC_GEMM_WIDE") && atoi(getenv("DTC_GEMM_WIDE")) == 0;
+    if (off || (col_skip & 3) || (split_stride & 3)) return 0;
+    int m = 0;
+    for (int i = 0; i < xd.nseg; ++i) {
+        const SegDev& sd = xd.s[i];
+        if (sd.ptr == nullptr || (dtc::aligned16(sd.ptr) && (sd.ld & 3) == 0 && ((sd.col0 - sd.start) & 3) == 0)) m |= 1 << i;
+    }
+    if (Xsaved == nullptr || (dtc::aligned16(Xsaved) && (ldxs & 3) == 0)) m |= 1 << 4;
+    return m;
 }
 
 }  // namespace
@@ -659,9 +749,10 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
     DTC_REQUIRE(col_skip < K, "every destination segment is NULL");
     const int bn = pick_bn_rows(M, K - col_skip);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K - col_skip, bn));
+    const int wide = wide_mask(xd, Xsaved, ldxs, col_skip, 0);
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s);
-    if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip);
-    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip);
+    if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
     return dtc::check_launch("linear_dgrad");
 }
 
@@ -683,7 +774,8 @@ extern "C" int dtc_linear_dgrad_split(const float* dZ, int64_t lddz, const float
     const int bn = (K <= 32 || (long long)row_tiles * dtc::ceil_div(K, 64) * nsplit < 320) ? 32 : 64;
     const dim3 grid((unsigned)grid_for(row_tiles, (int)dtc::ceil_div(K, bn)), (unsigned)nsplit);
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * K, s);
-    if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride, 0);
-    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride, 0);
+    const int wide = wide_mask(xd, nullptr, 0, 0, split_stride);
+    if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride, 0, wide);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride, 0, wide);
     return dtc::check_launch("linear_dgrad_split");
 }
