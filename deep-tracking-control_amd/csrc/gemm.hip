@@ -67,12 +67,6 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // operands use the same assignment, every k of the stage is used exactly once: the sum is a permuted-order fp32 fma
 // chain (deterministic).  Against the [k][row] image + dword loads of round 1: 3 instead of 12 VMEM and LDS-write
 // instructions and 6 instead of 24 LDS reads per 16 MFMAs.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 bload4(rsrc_t r, u32 voff, u32 soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ int kslot(int r, int chunk) { return r * 4 + (chunk ^ ((r >> 2) & 3)); }
-
 // k tail of a stage: the chunk is loaded whole and the elements past the segment's last column are zeroed in the DATA
 // (v_cndmask), not by per-dword addresses -- one address register per chunk, same register footprint as a full stage.
 // The over-read (at most 12 bytes past the segment's columns) stays inside the source matrix or, behind its last row,
@@ -82,18 +76,6 @@ __device__ __forceinline__ f32x4 ktail(f32x4 v, int k0, int klast) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (k0 + e <= klast) ? v[e] : 0.f;
     return v;
-}
-
-// wide-store epilogue helper: a wave moves one 32x32 accumulator tile (lane = column, 16 rows per lane) through a
-// private LDS patch so that every lane ends up with 4 consecutive columns of one row (4 rows per lane): 4 dwordx4
-// accesses instead of 16 dword accesses per tile.  One wave's LDS operations execute in order: no barrier.
-constexpr int LDW = 36;
-__device__ __forceinline__ void patch_put(float* patch, const f32x16& v, int half, int l31) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * LDW + l31] = v[r];
-}
-__device__ __forceinline__ f32x4 patch_get(const float* patch, int row, int c4) {
-    return *reinterpret_cast<const f32x4*>(&patch[row * LDW + 4 * c4]);
 }
 
 #ifdef DTC_TRACE

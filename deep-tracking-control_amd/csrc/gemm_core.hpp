@@ -137,6 +137,28 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[Cfg<BN>::TM][Cfg<BN>::TN]
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 bload4(rsrc_t r, u32 voff, u32 soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ int kslot(int r, int chunk) { return r * 4 + (chunk ^ ((r >> 2) & 3)); }
+
+
+// wide-store epilogue helper: a wave moves one 32x32 accumulator tile (lane = column, 16 rows per lane) through a
+// private LDS patch so that every lane ends up with 4 consecutive columns of one row (4 rows per lane): 4 dwordx4
+// accesses instead of 16 dword accesses per tile.  One wave's LDS operations execute in order: no barrier.
+constexpr int LDW = 32;      // unpadded 128-byte rows: the b32 writes (32 consecutive floats per half-wave) and the b128 reads
+                             // (lane groups {0-3, 12-15, 20-27} -> rows 0..3 at chunks 0-3 / 4-7 / 4-7 / 0-3) are conflict free;
+                             // 4 waves x 32 x 32 floats = 16 KiB = the A stage buffers the patches live in
+__device__ __forceinline__ void patch_put(float* patch, const f32x16& v, int half, int l31) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * LDW + l31] = v[r];
+}
+__device__ __forceinline__ f32x4 patch_get(const float* patch, int row, int c4) {
+    return *reinterpret_cast<const f32x4*>(&patch[row * LDW + 4 * c4]);
+}
+
+
 constexpr long long MAX_ELEMS = (1ll << 29) - 1;     // lane byte offsets must stay below 2 GiB (INVALID = 2^31)
 
 int to_dev(const DtcSegMat* h, SegMatDev& d, int expect_cols, bool is_output, long long rows_bound) {

@@ -19,10 +19,12 @@ namespace {
 // Weight gradient (split over the batch): part[s][n][c] = sum_{m in split s} dZ[m,n] X[m,c],
 // c == K holds the bias-gradient partial.  A second kernel reduces the splits.
 // ------------------------------------------------------------------------------------------
-// Column tiles are aligned to the segments of X (tile = (segment, tile inside the segment)), so every block
-// reads ONE source matrix: uniform descriptor, and -- because all lanes of a wave stage the same batch row --
-// the (optionally gathered) row offset is a SCALAR: idx[m] comes in through s_load, row*ld goes into the
-// SGPR offset of the buffer load, the lane offset is just the column.  Zero VALU per load.
+// Column tiles are aligned to the segments of X (tile = (segment, tile inside the segment)), so every block reads ONE
+// source matrix.  Both operands have the reduction index (the batch row m) as their ROW and are contiguous along the
+// output dimensions: float4 loads along n (dZ) and c (X), LDS images [m][n] / [m][c], ds_read_b32 fragments.  Elements a
+// float4 drags in from beyond N / beyond the segment only feed output rows / columns that are never stored (behind the
+// last row of a source the descriptor returns 0), so the loads carry row masks only.  The gathered row index of X is a
+// per-lane 8-byte load issued one stage ahead of the tile it addresses.
 template <int BN>
 __device__ __forceinline__ void wgrad_block(const float* __restrict__ dZ, long long lddz, const SegMatDev& X,
                                             float* __restrict__ part, int M, int N, int K, int rows_per_split,
@@ -45,47 +47,43 @@ __device__ __forceinline__ void wgrad_block(const float* __restrict__ dZ, long l
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm_off = (wave / C::WN) * (32 * C::TM), wn_off = (wave % C::WN) * (32 * C::TN);
 
-    // A loader: As[kk][i] = dZ[m][n0+i], i = tid % 128, two reduction rows per pass
-    const int ai = tid & 127, ak0 = tid >> 7;
-    constexpr int NA = BK / 2;
-    const bool arow_ok = n0 + ai < N;
-    // B loader: Bs[kk][j] = X[m][col]; RPP batch rows per pass
-    constexpr int RPP = 256 / BN;
-    constexpr int NB = BK / RPP;
-    constexpr bool ROW_UNIFORM = BN >= 64;          // all lanes of a wave stage the same batch row
-    const int bj = tid % BN, bk0 = tid / BN;
-    const int bk0u = ROW_UNIFORM ? __builtin_amdgcn_readfirstlane(bk0) : bk0;
-    const bool bcol_ok = lc0 + bj < sd.width;
-    const u32 ldb = (u32)sd.ld * 4u;
-    const u32 bcolb = bcol_ok ? (u32)(sd.col0 + lc0 + bj) * 4u : INVALID;
+    // A loader: As[m][n0 + 4*an4 ..] = dZ[m][...], batch rows am and am + 8 of the stage
+    const int am = tid >> 5, an4 = 4 * (tid & 31);
+    constexpr int NA = BK / 8;
     u32 aoff[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) aoff[i] = arow_ok ? (u32)((long long)(ak0 + 2 * i) * lddz + n0 + ai) * 4u : INVALID;
-    const rsrc_t ares = make_rsrc(dZ), bres = make_rsrc(sd.ptr);
+    for (int i = 0; i < NA; ++i) aoff[i] = n0 + an4 < N ? (u32)((long long)(am + 8 * i) * lddz + n0 + an4) * 4u : INVALID;
+    // B loader: Bs[m][4*bc4 ..] = X[row(m)][col0 + lc0 + 4*bc4 ..], one batch row per thread and stage
+    constexpr int C4 = BN / 4;
+    const bool bthread = tid < BK * C4;
+    const int bm = tid / C4, bc = 4 * (tid % C4);
+    const u32 ldb = (u32)sd.ld * 4u;
+    const u32 bcolb = (bthread && lc0 + bc < sd.width) ? (u32)(sd.col0 + lc0 + bc) * 4u : INVALID;
+    const rsrc_t ares = make_rsrc_bytes(dZ, (long long)M * lddz * 4), bres = make_rsrc_bytes(sd.ptr, (long long)sd.rows * sd.ld * 4);
 
-    float ra[NA], rb[NB];
-    float bias_acc = 0.f;
+    f32x4 ra[NA], rb;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    auto row_of = [&](int m) -> u32 {                // source row of batch row m (clamped into the split: masked lanes)
+        const int mc = m < m_end ? m : m_end - 1;
+        return sd.gather ? (u32)X.idx[mc] : (u32)mc;
+    };
+    u32 rnext = row_of(m_begin + bm);                // row index of the first stage
     auto load_tile = [&](auto masked, int mb) {
         constexpr bool MK = decltype(masked)::value;
         const u32 sa = (u32)mb * (u32)lddz * 4u;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = bload(ares, aoff[i] | (MK ? oob_mask(mb + ak0 + 2 * i, m_end - 1) : 0u), sa);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int m = mb + bk0u + RPP * i;
-            const int mc = (!MK || m < m_end) ? m : m_end - 1;
-            const u32 r = sd.gather ? (u32)X.idx[mc] : (u32)mc;          // scalar when ROW_UNIFORM
-            rb[i] = bload(bres, bcolb | (MK ? oob_mask(m, m_end - 1) : 0u), r * ldb);
-        }
+        for (int i = 0; i < NA; ++i) ra[i] = bload4(ares, aoff[i] | (MK ? oob_mask(mb + am + 8 * i, m_end - 1) : 0u), sa);
+        rb = bload4(bres, (bcolb + rnext * ldb) | (MK ? oob_mask(mb + bm, m_end - 1) : 0u), 0u);
+        rnext = row_of(mb + BK + bm);                // for the next stage (a clamped re-read past the split's end)
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            As[buf][ak0 + 2 * i][ai] = ra[i];
-            bias_acc += ra[i];
-        }
+            *reinterpret_cast<f32x4*>(&As[buf][am + 8 * i][an4]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[buf][bk0 + RPP * i][bj] = rb[i];
+            for (int e = 0; e < 4; ++e) bias4[e] += ra[i][e];
+        }
+        if (BN >= 64 || bthread) *reinterpret_cast<f32x4*>(&Bs[buf][bm][bc]) = rb;
     };
 
     f32x16 acc[C::TM][C::TN];
@@ -112,29 +110,49 @@ __device__ __forceinline__ void wgrad_block(const float* __restrict__ dZ, long l
     const long long ldp = part_ld(K);
     float* P = part + (long long)split * N * ldp;
     const int half = lane >> 5, l31 = lane & 31;
+    const bool bias_block = seg == 0 && tc == 0;
+    __syncthreads();                                // every wave is past its last operand read (LDS is reused below)
+    if (n0 + BM <= N && lc0 + BN <= sd.width && ((sd.start + lc0) & 3) == 0) {
+        // wide stores: each wave transposes its 32x32 tiles through a private LDS patch -> dwordx4 rows of the slab
+        float* patch = &As[0][0][0] + wave * (32 * LDW);     // 4 x 4 KiB inside the A stage buffers
+        const int prow = lane >> 3, pc4 = lane & 7;
 #pragma unroll
-    for (int j = 0; j < C::TN; ++j) {
-        const int lcol = lc0 + wn_off + 32 * j + l31;
-        if (lcol >= sd.width) continue;
-        const int col = sd.start + lcol;
+        for (int j = 0; j < C::TN; ++j)
 #pragma unroll
-        for (int i = 0; i < C::TM; ++i) {
+            for (int i = 0; i < C::TM; ++i) {
+                patch_put(patch, acc[i][j], half, l31);
+                float* q = P + (long long)(n0 + wm_off + 32 * i + prow) * ldp + sd.start + lc0 + wn_off + 32 * j + 4 * pc4;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = n0 + wm_off + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < N) P[(long long)row * ldp + col] = acc[i][j][r];
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(q + (long long)(8 * p) * ldp) = patch_get(patch, prow + 8 * p, pc4);
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) {
+            const int lcol = lc0 + wn_off + 32 * j + l31;
+            if (lcol >= sd.width) continue;
+            const int col = sd.start + lcol;
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = n0 + wm_off + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < N) P[(long long)row * ldp + col] = acc[i][j][r];
+                }
             }
         }
     }
-    if (seg == 0 && tc == 0) {   // bias-gradient partial: two threads staged each dZ column
-        float* red = &As[0][0][0];
+    if (bias_block) {   // bias-gradient partial: 8 threads (batch-row groups) staged each group of 4 dZ columns
+        float* red = &Bs[0][0][0];                   // [8][128] floats, disjoint from the patches in As
+        *reinterpret_cast<f32x4*>(&red[am * BM + an4]) = bias4;
         __syncthreads();
-        if (ak0 == 1) red[ai] = bias_acc;
-        __syncthreads();
-        if (ak0 == 0 && arow_ok) P[(long long)(n0 + ai) * ldp + K] = bias_acc + red[ai];
+        if (tid < BM && n0 + tid < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += red[g * BM + tid];
+            P[(long long)(n0 + tid) * ldp + K] = s;
+        }
     }
 }
-
 
 template <int BN>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dZ, long long lddz,
