@@ -289,9 +289,19 @@ def scorer_edge_inputs():
     return inp
 
 
+from cases import scorer_extra_inputs  # noqa: E402  (shared with the tests; imports nothing of the reference)
+
+
 def gen_scorer():
     torch.set_num_threads(GOLDEN_THREADS)
     out = {}
+    for tag in ("seed2", "bench", "slopes"):
+        m = _ref_scorer(scorer_extra_inputs(tag))
+        srt = np.sort(m.foothold_score.numpy(), axis=1)
+        out[tag + "_idx"] = m.optimal_foothold_indice.squeeze(1).numpy().astype(np.int16)
+        out[tag + "_gap"] = (srt[:, 1, :] - srt[:, 0, :]).astype(np.float32)
+        out[tag + "_foothold_obs"] = m.foothold_obs.numpy()[::8]
+        out[tag + "_pred"] = m.pred_footholds.numpy()[::8]
     for tag, inp in (("main", S.scorer_inputs(8192, seed=7)), ("edge", scorer_edge_inputs())):
         m = _ref_scorer(inp)
         sc = m.foothold_score.numpy()

@@ -65,6 +65,30 @@ def test_scorer_matches_reference_golden(golden):
     np.testing.assert_allclose(_np(h["pred_footholds"])[::4], g["main_pred"], rtol=0, atol=4e-6)
 
 
+@pytest.mark.parametrize("tag", ["seed2", "bench", "slopes"])
+def test_scorer_matches_reference_golden_more_draws(golden, tag):
+    """HIP planner against further reference-captured draws: another seed, the bench distribution (every 24th of the
+    98304 maps bench.py plans over) and smooth tilted terrain."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from cases import scorer_extra_inputs
+    from dtc_amd import foothold
+    g = golden("scorer")
+    inp = {k: v.to(DEV) for k, v in scorer_extra_inputs(tag).items()}
+    h = foothold.plan(inp["measured_heights"], inp["root_states"], inp["thigh_pos"], inp["commands"])
+    idx = _np(h["optimal_foothold_indice"]).squeeze(1)
+    ref = g[tag + "_idx"].astype(np.int64)
+    mism = np.argwhere(idx != ref)
+    for e, l in mism:
+        assert g[tag + "_gap"][e, l] <= 1e-5
+    assert len(mism) <= 4
+    ok = np.ones(len(ref), bool)
+    ok[mism[:, 0]] = False
+    np.testing.assert_array_equal(_np(h["foothold_obs"])[::8][ok[::8]], g[tag + "_foothold_obs"][ok[::8]])
+    np.testing.assert_allclose(_np(h["pred_footholds"])[::8], g[tag + "_pred"], rtol=0, atol=4e-6)
+
+
 def test_scorer_unaligned_pointer_and_large():
     """A view that is not 16-byte aligned takes the scalar-load path; 98304 maps = 24 recorded steps."""
     from dtc_amd import foothold
