@@ -221,8 +221,8 @@ def gen_ppo():
     # G3b: same but 1 epoch x 4 mini-batches with fixed LR (slow error growth -> tight pin)
     r, _ = _run_ref_update(64, seed_fill=11, num_learning_epochs=1, schedule="fixed")
     out.update({"u64f_" + k: v for k, v in r.items()})
-    # G3c: config 2 (4096 x 24), first 2 mini-batch steps
-    r, _ = _run_ref_update(4096, seed_fill=11, max_steps=2)
+    # G3c: config 2 (4096 x 24), first 4 mini-batch steps
+    r, _ = _run_ref_update(4096, seed_fill=11, max_steps=4)
     out.update({"u4096_" + k: v for k, v in r.items()})
     save("ppo", **out)
 

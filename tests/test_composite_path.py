@@ -15,16 +15,16 @@ DEV = "cuda:0"
 N, NMB, T = 16, 4, 24
 
 
-def composite_case(seed=4):
-    data = S.rollout(N, T, seed=seed)
+def composite_case(seed=4, n=N):
+    data = S.rollout(n, T, seed=seed)
     data["dones"][:, 0] = 0
     g = torch.Generator().manual_seed(77)
-    hid_a = 0.1 * torch.randn(T, 1, N, 512, generator=g)
-    hid_c = 0.1 * torch.randn(T, 1, N, 512, generator=g)
+    hid_a = 0.1 * torch.randn(T, 1, n, 512, generator=g)
+    hid_c = 0.1 * torch.randn(T, 1, n, 512, generator=g)
     g = torch.Generator().manual_seed(78)
-    eps = torch.randn(4, T * (N // NMB), 16, generator=g)
-    G1 = torch.randn(T * (N // NMB), 12, generator=g)
-    G2 = torch.randn(T * (N // NMB), 1, generator=g)
+    eps = torch.randn(4, T * (n // NMB), 16, generator=g)
+    G1 = torch.randn(T * (n // NMB), 12, generator=g)
+    G2 = torch.randn(T * (n // NMB), 1, generator=g)
     return data, hid_a, hid_c, eps, G1, G2
 
 
@@ -33,9 +33,9 @@ def oracle_model():
     return OP.fill_parameters_(CR.RefCompositeAC(), 23)
 
 
-def oracle_alg(data, **kw):
+def oracle_alg(data, n=N, **kw):
     alg = CR.RefCompositePPO(oracle_model(), learning_rate=1e-3, entropy_coef=0.003, **kw)
-    alg.init_storage(N, T)
+    alg.init_storage(n, T)
     st = alg.storage
     for k, v in data.items():
         if k != "last_values":
@@ -91,12 +91,12 @@ def _strip(sd):
     return {k.replace("acr.", ""): v for k, v in sd.items()}
 
 
-def _hip_alg(ref, data, **kw):
+def _hip_alg(ref, data, n=N, **kw):
     from dtc_amd.algorithms import RecurrentDecoderPPO
     from dtc_amd.modules import ActorCriticDecoderRecurrent
     ac = ActorCriticDecoderRecurrent(53, 1389, 12)
     alg = RecurrentDecoderPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV, **kw)
-    alg.init_storage(N, T, [53], [1389], [265], [12])
+    alg.init_storage(n, T, [53], [1389], [265], [12])
     ac.load_state_dict(_strip(ref.actor_critic.state_dict()))
     for k, v in data.items():
         if k != "last_values":
@@ -192,6 +192,45 @@ def test_hip_teacher_forced_minibatches_vs_oracle(kw):
         skip = () if same_median else ("vae.cenet_encoder", "vae.latent_")
         n = _grad_report(rec.extra["grads"], alg, "main", 2e-5, skip)
         assert n >= 35            # std, 2 MLPs, 2 GRUs, CE-net encoder + heads, terrain encoder
+
+
+@pytest.mark.gpu
+def test_hip_teacher_forced_minibatch_full_size():
+    """BASELINE configs[4]'s model at 4096 envs per GPU: the first recurrent mini-batch (1024 envs x 24
+    steps, ~1500 padded trajectories), both optimisation steps, against the CPU oracle -- scalars 1e-5 rel, every
+    parameter gradient 5e-5 of its max (BPTT through both GRUs into the feature blocks and the encoders)."""
+    from dtc_amd.algorithms import ppo as P
+    n = 4096
+    data, hid_a, hid_c, eps, _, _ = composite_case(n=n)
+    g = torch.Generator().manual_seed(79)
+    eps2 = torch.randn(1, T * (n // NMB), 16, generator=g)
+    ref = oracle_alg(data, n)
+    ref.capture_grads = True
+    alg = _hip_alg(ref, data, n)
+    alg.capture_grads = True
+    bt_ref = next(iter(CR.recurrent_slices(ref.storage, hid_a, hid_c, NMB)))
+    bt = next(iter(alg.recurrent_slices(hid_a.to(DEV), hid_c.to(DEV))))
+    assert bt["R"] == bt_ref["hid_a"].shape[1] and bt["R"] > 1200 and torch.equal(bt["idx"].cpu(), bt_ref["idx"])
+    rec = OP.StepRecord()
+    ref.vae_step(bt_ref["idx"], eps[0], rec)
+    row = alg.step_minibatch(bt, eps[0].to(DEV), eps2[0].to(DEV), which="vae").cpu()
+    for key, col in (("recons", P.S_RECONS), ("vel", P.S_VEL), ("kld", P.S_KLD), ("height", P.S_HEIGHT), ("vae_gnorm", P.S_VAE_GNORM)):
+        assert abs(float(row[col]) - getattr(rec, key)) <= 1e-5 * max(1.0, abs(getattr(rec, key))), key
+    fw = alg.actor_critic._fwd_ws(bt["idx"].numel())
+    same_median = int(fw.info[0]) == ref.actor_critic.vae.last_outliers and int(fw.info[1]) == ref.actor_critic.vae.last_median_index
+    print("full-size composite, VAE step: CE-net encoder gradients", "compared" if same_median else "SKIPPED (median landed on another element)")
+    skip = () if same_median else ("vae.cenet_encoder", "vae.latent_")
+    assert _grad_report(rec.extra["vae_grads"], alg, "vae", 5e-5, skip) >= 20
+    alg.actor_critic.load_state_dict(_strip(ref.actor_critic.state_dict()))
+    ref.ppo_step(bt_ref, eps2[0], rec)
+    row = alg.step_minibatch(bt, eps[0].to(DEV), eps2[0].to(DEV), which="ppo").cpu()
+    for key, col in (("surrogate", P.S_SURR), ("value", P.S_VALUE), ("entropy", P.S_ENTROPY), ("gnorm", P.S_GNORM), ("kl_mean", P.S_KL)):
+        assert abs(float(row[col]) - getattr(rec, key)) <= 1e-5 * max(1.0, abs(getattr(rec, key))), (key, float(row[col]), getattr(rec, key))
+    assert abs(float(alg.optimizer.lr_dev.item()) - ref.learning_rate) <= 1e-12
+    same_median = int(fw.info[0]) == ref.actor_critic.vae.last_outliers and int(fw.info[1]) == ref.actor_critic.vae.last_median_index
+    print("full-size composite, policy step: CE-net encoder gradients", "compared" if same_median else "SKIPPED (median landed on another element)")
+    skip = () if same_median else ("vae.cenet_encoder", "vae.latent_")
+    assert _grad_report(rec.extra["grads"], alg, "main", 5e-5, skip) >= 35
 
 
 @pytest.mark.gpu

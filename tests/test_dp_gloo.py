@@ -21,7 +21,6 @@ import torch.multiprocessing as mp
 from dtc_amd import distributed as dp
 from dtc_amd import synthetic as S
 
-WORLD = 2
 N_PER_RANK = 16
 
 
@@ -132,12 +131,15 @@ def _worker(rank, world, port, ret_dict):
         dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def dp_results():
+@pytest.fixture(scope="module", params=[2, 8])      # K = 2 and K = 8 shards
+def dp_results(request):
+    world = request.param
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(WORLD, _free_port(), ret), nprocs=WORLD, join=True)
-    return dict(ret)
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    out = dict(ret)
+    out["world"] = world
+    return out
 
 
 def test_single_process_helpers_are_noops():
@@ -149,20 +151,23 @@ def test_single_process_helpers_are_noops():
 
 def test_advantage_normalisation_is_global(dp_results):
     from oracle import gae as OG
+    WORLD = dp_results["world"]
     full = S.rollout(N_PER_RANK * WORLD, 24, seed=4)
     sq = lambda k: full[k].squeeze(-1).numpy()
     ret, adv = OG.compute_returns(sq("rewards"), sq("values"), sq("dones"), full["last_values"][:, 0].numpy())
     got = np.concatenate([dp_results[r]["adv"] for r in range(WORLD)], axis=1)
     np.testing.assert_allclose(got, adv, rtol=2e-6, atol=2e-6)
-    assert dp_results[0]["mean"] == dp_results[1]["mean"] and dp_results[0]["std"] == dp_results[1]["std"]
+    assert all(dp_results[r]["mean"] == dp_results[0]["mean"] and dp_results[r]["std"] == dp_results[0]["std"] for r in range(WORLD))
 
 
 def test_ranks_stay_identical_after_a_step(dp_results):
-    a, b = dp_results[0], dp_results[1]
-    np.testing.assert_array_equal(a["params"], b["params"])           # same averaged gradient, same LR
-    assert a["lr"] == b["lr"] and a["kl"] == b["kl"]
-    np.testing.assert_array_equal(a["main_grad"], b["main_grad"])
-    np.testing.assert_array_equal(a["vae_grad"], b["vae_grad"])
+    a = dp_results[0]
+    for r in range(1, dp_results["world"]):
+        b = dp_results[r]
+        np.testing.assert_array_equal(a["params"], b["params"])           # same averaged gradient, same LR
+        assert a["lr"] == b["lr"] and a["kl"] == b["kl"]
+        np.testing.assert_array_equal(a["main_grad"], b["main_grad"])
+        np.testing.assert_array_equal(a["vae_grad"], b["vae_grad"])
 
 
 def test_gradient_bucket_equals_shard_emulation(dp_results):
@@ -170,6 +175,7 @@ def test_gradient_bucket_equals_shard_emulation(dp_results):
     from oracle import gae as OG
     from oracle import ppo_ref as OP
     torch.set_num_threads(1)
+    WORLD = dp_results["world"]
     full = S.rollout(N_PER_RANK * WORLD, 24, seed=4)
     sq = lambda k: full[k].squeeze(-1).numpy()
     ret, adv = OG.compute_returns(sq("rewards"), sq("values"), sq("dones"), full["last_values"][:, 0].numpy())

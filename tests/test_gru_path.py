@@ -15,12 +15,12 @@ DEV = "cuda:0"
 N = 16
 
 
-def gru_case(seed=4):
-    data = S.rollout(N, 24, seed=seed)
+def gru_case(seed=4, n=N):
+    data = S.rollout(n, 24, seed=seed)
     data["dones"][:, 0] = 0
     g = torch.Generator().manual_seed(77)
-    hid_a = 0.1 * torch.randn(24, 1, N, 512, generator=g)
-    hid_c = 0.1 * torch.randn(24, 1, N, 512, generator=g)
+    hid_a = 0.1 * torch.randn(24, 1, n, 512, generator=g)
+    hid_c = 0.1 * torch.randn(24, 1, n, 512, generator=g)
     return data, hid_a, hid_c
 
 
@@ -29,8 +29,8 @@ def oracle_model():
     return OP.fill_parameters_(GR.RefActorCriticRecurrent(), 21)
 
 
-def oracle_storage(data):
-    st = OP.RefStorage(N, 24)
+def oracle_storage(data, n=N):
+    st = OP.RefStorage(n, 24)
     for k, v in data.items():
         if k != "last_values":
             getattr(st, k).copy_(v)
@@ -63,7 +63,7 @@ def test_oracle_matches_reference_modules(golden):
             np.testing.assert_allclose(ac.actor(out.squeeze(0)).numpy(), g["rollout_means"][t], rtol=1e-5, atol=1e-6)
 
 
-def _hip_pair(**kw):
+def _hip_pair(n=N, **kw):
     from dtc_amd.algorithms import RecurrentPPO
     from dtc_amd.modules import ActorCriticRecurrent
     ref_ac = oracle_model()
@@ -71,10 +71,10 @@ def _hip_pair(**kw):
     ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
                               activation='elu', rnn_type='gru', rnn_hidden_size=512, rnn_num_layers=1)
     alg = RecurrentPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV, **kw)
-    alg.init_storage(N, 24, [53], [1389], [12])
+    alg.init_storage(n, 24, [53], [1389], [12])
     ac.load_state_dict(ref_ac.state_dict())
-    data, hid_a, hid_c = gru_case()
-    st = oracle_storage(data)
+    data, hid_a, hid_c = gru_case(n=n)
+    st = oracle_storage(data, n)
     for k, v in data.items():
         if k not in ("last_values", "observation_histories"):      # the recurrent storage keeps no obs history
             getattr(alg.storage, k).copy_(v.to(DEV))
@@ -128,6 +128,35 @@ def test_recurrent_minibatch_step_vs_oracle(kw):
             err = float((g - g_ref).abs().max()) / scale
             assert err <= 5e-5, (i, name, err, scale)
         assert len(rec["grads"]) == 25
+
+
+@pytest.mark.gpu
+def test_recurrent_minibatch_step_full_size():
+    """BASELINE configs[2] at its real size: 4096 envs x 24 steps, one recurrent mini-batch of 1024 envs
+    (~1500 padded trajectories) teacher-forced against the CPU oracle.  At this size the HIP path runs what the 16-env
+    cases never reach: 128x64 tiles on every layer, the three-chunk split data gradient of the GRU backward, the fused
+    GRU step at R ~ 1500 rows, the grouped weight gradients with 24 batch slices."""
+    from dtc_amd.algorithms import ppo as P
+    n = 4096
+    ref, alg, st, hid_a, hid_c = _hip_pair(n=n)
+    ref.capture_grads = alg.capture_grads = True
+    b_ref = next(iter(GR.recurrent_batches(st, hid_a, hid_c, 4)))
+    b_hip = next(iter(alg.storage.reccurent_mini_batch_generator(4, 1)))
+    assert torch.equal(b_hip[10].cpu(), b_ref["masks"]) and b_ref["masks"].shape[1] > 1200
+    rec = ref.step(st, b_ref)
+    row = alg.step_minibatch(b_hip, 0, n // 4).cpu()
+    ac = alg.actor_critic
+    np.testing.assert_allclose(ac._actor_outs[-1].cpu().numpy().reshape(24, n // 4, 12), rec["mean"].numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ac._critic_outs[-1].cpu().numpy().reshape(24, n // 4, 1), rec["value_out"].numpy(), rtol=1e-5, atol=2e-6)
+    for key, col in (("surrogate", P.S_SURR), ("value", P.S_VALUE), ("entropy", P.S_ENTROPY), ("gnorm", P.S_GNORM), ("kl_mean", P.S_KL)):
+        assert abs(float(row[col]) - rec[key]) <= 1e-5 * max(1.0, abs(rec[key])), (key, float(row[col]), rec[key])
+    assert float(alg.optimizer.lr_dev.item()) == rec["lr"]
+    for name, g_ref in rec["grads"].items():
+        g = ac.arena.view(alg.captured["main"], name).cpu()
+        scale = float(g_ref.abs().max()) + 1e-30
+        err = float((g - g_ref).abs().max()) / scale
+        assert err <= 5e-5, (name, err, scale)
+    assert len(rec["grads"]) == 25
 
 
 @pytest.mark.gpu

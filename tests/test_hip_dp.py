@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
-N_PER_RANK, WORLD = 64, 2
+N_PER_RANK, WORLD = 64, 2            # defaults; `n_per_rank` / `world` arguments override them per test
 
 
 def _free_port():
@@ -22,12 +22,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make(rank, world, full, kind="decoder"):
+def _make(rank, world, full, kind="decoder", n_per_rank=N_PER_RANK, seed=3):
     from dtc_amd import distributed as dp
     from dtc_amd.algorithms import PPO, RecurrentDecoderPPO
     from dtc_amd.modules import ActorCriticDecoder, ActorCriticDecoderRecurrent
     dev = "cuda:0"
-    torch.manual_seed(3)
+    N_PER_RANK = n_per_rank
+    torch.manual_seed(seed)
     if kind == "composite":                       # BASELINE config 5: the 8-GPU data-parallel model
         ac = ActorCriticDecoderRecurrent(53, 1389, 12)
         alg = RecurrentDecoderPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
@@ -48,14 +49,19 @@ def _make(rank, world, full, kind="decoder"):
     return alg
 
 
-def _worker(rank, world, port, out, kind="decoder", overlap_exchange=True):
+def _worker(rank, world, port, out, kind="decoder", overlap_exchange=True, n_per_rank=N_PER_RANK, rank_seeds=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from dtc_amd import distributed as dp
         from dtc_amd import synthetic as S
         torch.cuda.set_device(0)
+        N_PER_RANK = n_per_rank
+        dp.trace_collectives(True)
         full = S.rollout(N_PER_RANK * world, 24, seed=4)
-        alg = _make(rank, world, full, kind)
+        # rank_seeds: every rank initialises its model from ANOTHER seed -- the broadcast at optimiser construction
+        # must make them start from rank 0's weights
+        alg = _make(rank, world, full, kind, n_per_rank, seed=3 + (17 * rank if rank_seeds else 0))
         alg.overlap_exchange = overlap_exchange
         adv = alg.storage.advantages.cpu().clone()
         g = torch.Generator().manual_seed(100 + rank)                 # rank-local permutation and noise (§8e)
@@ -66,9 +72,11 @@ def _worker(rank, world, port, out, kind="decoder", overlap_exchange=True):
             alg.update(e1.cuda(), e2.cuda())          # recurrent mini-batches: env slices, no permutation
         else:
             alg.update(perm.cuda(), e1.cuda(), e2.cuda())
+        log = dp.assert_same_collective_sequence()     # same ops, sizes, dtypes, stream kinds, in the same order
         out[rank] = dict(flat=alg.actor_critic.arena.flat.cpu().clone(), lr=alg.learning_rate,
                          m=alg.optimizer.exp_avg.cpu().clone(), v=alg.vae_optimizer.exp_avg_sq.cpu().clone(), adv=adv,
-                         perm=perm, e1=e1, e2=e2)
+                         perm=perm if n_per_rank <= 64 else None, e1=e1 if n_per_rank <= 64 else None,
+                         e2=e2 if n_per_rank <= 64 else None, log=log, bytes=dp.bytes_reduced(log))
     finally:
         dist.destroy_process_group()
 
@@ -121,6 +129,47 @@ def test_bucketed_exchange_on_the_side_stream_equals_one_exchange_after_the_join
         results.append(out[0])
     assert torch.equal(results[0]["flat"], results[1]["flat"]) and results[0]["lr"] == results[1]["lr"]
     assert torch.equal(results[0]["m"], results[1]["m"]) and torch.equal(results[0]["v"], results[1]["v"])
+
+
+def _run(world, kind="decoder", overlap=True, n_per_rank=N_PER_RANK, rank_seeds=False, timeout=600):
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, kind, overlap, n_per_rank, rank_seeds)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+        assert p.exitcode == 0
+    return dict(out)
+
+
+def test_four_ranks_with_different_seeds_converge_on_rank0_weights():
+    """K = 4 ranks on one device; every rank seeds its model differently.  The rank-0 broadcast at optimiser
+    construction + the averaged gradients keep all four bit-identical, and every rank issued the same collective
+    sequence (asserted inside the workers)."""
+    out = _run(4, rank_seeds=True)
+    for r in range(1, 4):
+        assert torch.equal(out[0]["flat"], out[r]["flat"]) and out[0]["lr"] == out[r]["lr"]
+        assert torch.equal(out[0]["m"], out[r]["m"]) and torch.equal(out[0]["v"], out[r]["v"])
+    assert torch.isfinite(out[0]["flat"]).all()
+    ops = [e[0] for e in out[0]["log"]]
+    assert ops[0] == "broadcast" and ops.count("all_reduce_sum") == 2              # weights once, advantage statistics once
+    # per optimiser step two gradient buckets; per mini-batch one KL mean: 20 x (2 + 2 + 1) all-reduce-means
+    assert ops.count("all_reduce_mean") == 20 * 5
+    streams = {e[3] for e in out[0]["log"] if e[0] == "all_reduce_mean" and e[1] > 1}
+    assert streams == {"side"}                                                     # buckets travel on the weight-gradient stream
+
+
+def test_two_ranks_at_full_size_exchange_real_buckets():
+    """K = 2 at BASELINE's 4096 envs per rank (mini-batches of 24576): the bucketed exchange at its real sizes
+    (7.4 MB / 11.5 MB of gradients per optimiser step), ranks bit-identical afterwards."""
+    out = _run(2, n_per_rank=4096, timeout=900)
+    assert torch.equal(out[0]["flat"], out[1]["flat"]) and out[0]["lr"] == out[1]["lr"]
+    assert torch.equal(out[0]["m"], out[1]["m"]) and torch.equal(out[0]["v"], out[1]["v"])
+    assert torch.isfinite(out[0]["flat"]).all()
+    per_update = out[0]["bytes"]
+    assert 20 * (7.0e6 + 11.0e6) < per_update < 20 * (8.0e6 + 12.5e6), per_update
 
 
 def _rccl_worker(port, out):

@@ -215,10 +215,13 @@ def test_update_adaptive_20_steps_matches_reference(golden):
 
 
 def test_update_4096_first_steps_match_reference(golden):
+    """BASELINE config 2 (4096 envs x 24, B = 24576), free running: the first two of the four reference-captured
+    mini-batch steps (the fixture holds four, the HIP test is teacher-forced over all four)."""
     g = golden("ppo")
+    assert len(g["u4096_recons"]) == 4
     alg = _oracle_alg(4096)
-    recs = _run_oracle(alg, 4096, 1)
-    _check(recs, g, "u4096_", lambda k: 2e-5)
+    recs = _run_oracle(alg, 4096, 2)
+    _check(recs, g, "u4096_", lambda k: (2e-5, 2e-4)[k])
 
 
 def _reward_case():
