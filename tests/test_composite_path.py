@@ -105,20 +105,31 @@ def _hip_alg(ref, data, n=N, **kw):
     return alg
 
 
-def _grad_report(grads_ref, alg, which, tol, skip=()):
+def _grad_report(grads_ref, alg, which, tol, skip=(), knife_edges=None):
+    """Every parameter gradient against the oracle's: max element error relative to the tensor's max and relative L2,
+    both <= tol.  knife_edges = (n, B) (full-size mini-batches): n ReLU outputs are masked differently by the two
+    (correct) fp32 forwards -- pre-activations that are 0 within rounding, about one (sample, unit) pair per 4e5.  Each
+    moves every gradient upstream of it by that sample's share, so the bound becomes the one of
+    test_hip_ppo._compare_grads: 99th percentile of the element errors and L2 / 5 within tol + 3 n / B."""
     arena = alg.actor_critic.arena
     worst = []
+    if knife_edges is not None:
+        tol = tol + 3.0 * knife_edges[0] / knife_edges[1]
     for name, g_ref in grads_ref.items():
         name = name.replace("acr.", "")
         if name.startswith(skip):
             continue
         g = arena.view(alg.captured[which], name).cpu()
         scale = float(g_ref.abs().max()) + 1e-30
-        err = float(((g - g_ref).abs() / scale).max())
+        e = ((g - g_ref).abs() / scale).reshape(-1)
         l2 = float((g - g_ref).norm() / (g_ref.norm() + 1e-30))
-        worst.append((max(err, l2), name))
+        if knife_edges is not None:
+            q99 = float(torch.quantile(e, 0.99)) if e.numel() > 100 else float(e.max())
+            worst.append((max(q99, l2 / 5), name, f"q99={q99:.1e} l2={l2:.1e} max={float(e.max()):.1e}"))
+        else:
+            worst.append((max(float(e.max()), l2), name, ""))
     worst.sort(reverse=True)
-    assert worst[0][0] <= tol, worst[:6]
+    assert worst[0][0] <= tol, (tol, worst[:6])
     return len(worst)
 
 
@@ -220,7 +231,10 @@ def test_hip_teacher_forced_minibatch_full_size():
     same_median = int(fw.info[0]) == ref.actor_critic.vae.last_outliers and int(fw.info[1]) == ref.actor_critic.vae.last_median_index
     print("full-size composite, VAE step: CE-net encoder gradients", "compared" if same_median else "SKIPPED (median landed on another element)")
     skip = () if same_median else ("vae.cenet_encoder", "vae.latent_")
-    assert _grad_report(rec.extra["vae_grads"], alg, "vae", 5e-5, skip) >= 20
+    from test_hip_ppo import _relu_mask_mismatches
+    edges = _relu_mask_mismatches(ref, alg, "vae")
+    print("  ReLU knife edges:", edges[0])
+    assert _grad_report(rec.extra["vae_grads"], alg, "vae", 2e-5, skip, knife_edges=edges) >= 20
     alg.actor_critic.load_state_dict(_strip(ref.actor_critic.state_dict()))
     ref.ppo_step(bt_ref, eps2[0], rec)
     row = alg.step_minibatch(bt, eps[0].to(DEV), eps2[0].to(DEV), which="ppo").cpu()
@@ -230,7 +244,9 @@ def test_hip_teacher_forced_minibatch_full_size():
     same_median = int(fw.info[0]) == ref.actor_critic.vae.last_outliers and int(fw.info[1]) == ref.actor_critic.vae.last_median_index
     print("full-size composite, policy step: CE-net encoder gradients", "compared" if same_median else "SKIPPED (median landed on another element)")
     skip = () if same_median else ("vae.cenet_encoder", "vae.latent_")
-    assert _grad_report(rec.extra["grads"], alg, "main", 5e-5, skip) >= 35
+    edges = _relu_mask_mismatches(ref, alg, "ppo")
+    print("  ReLU knife edges:", edges[0])
+    assert _grad_report(rec.extra["grads"], alg, "main", 2e-5, skip, knife_edges=edges) >= 35
 
 
 @pytest.mark.gpu
