@@ -72,7 +72,9 @@ def cpu_baseline():
         return per_env_step, t_ret + t_epoch + t_sc
 
     warm = {}
-    for th in sorted({min(32, n_cpu), n_cpu}):
+    # all host cores only when that is a sane thread count for GEMMs of this size: on the 256-vCPU GPU box 256 threads ran
+    # this sample at 64 env-steps/s against 3700 at 32 (measured in round 2), i.e. minutes per run
+    for th in sorted({min(32, n_cpu), n_cpu if n_cpu <= 64 else min(32, n_cpu)}):
         torch.set_num_threads(th)
         warm[th] = one_run()[0]                       # doubles as the warm-up run
     cores = min(warm, key=warm.get)
@@ -93,10 +95,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="decoder", choices=["decoder", "composite", "gru"],
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--workload", default=os.environ.get("DTC_BENCH_WORKLOAD", "decoder"), choices=["decoder", "composite", "gru"],
                     help="decoder = BASELINE configs[1] (the headline, default); composite = configs[4]'s model "
                          "(GRU + CE-net + foothold obs, build-defined); gru = configs[2] (ActorCriticRecurrent, GRU 512, BPTT); "
-                         "both on the same rollout shapes -- informative only")
+                         "both on the same rollout shapes -- informative only.  Default from DTC_BENCH_WORKLOAD (a driver that "
+                         "cannot pass flags selects configs[4]'s model with DTC_BENCH_WORKLOAD=composite)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -167,18 +171,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from dtc_amd import distributed as dp
+    if world > 1:
+        # communicator set-up and the first exchange of every bucket size happen here, never inside the timed region
+        # (also with --warmup 0): one all-reduce of each gradient bucket + the scalar statistics, then a barrier
+        arena = alg.actor_critic.ensure_arena()
+        for lo, hi in getattr(arena, "buckets", dict(all=(0, arena.grad.numel()))).values():
+            dist.all_reduce(arena.grad[lo:hi])
+        arena.grad.zero_()
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev))
     for _ in range(a.warmup):
         step()
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0                  # this rank's own time (before the closing barrier)
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = [mine / a.steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        tl = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([mine / a.steps * 1e3], dtype=torch.float64, device=dev))
+        rank_ms = [float(x.item()) for x in tl]
 
     # per-kernel HIP-event timing of one more step (same process, each kernel on the stream it is launched on)
     # for the roofline object.  The timed region above overlaps the weight-gradient GEMMs with the
@@ -189,8 +208,11 @@ def main():
     lib = _ffi.lib()
     overlap, overlap_rec = getattr(alg, "overlap_wgrad", False), getattr(alg, "overlap", False)
     alg.overlap_wgrad = alg.overlap = False
+    dp.trace_collectives(True)                       # N > 1: what one step exchanges, and that all ranks issue the same sequence
     step()
     torch.cuda.synchronize()
+    coll_log = dp.assert_same_collective_sequence()
+    dp.trace_collectives(False)
     if rank == 0:
         lib.dtc_prof_reset()
         lib.dtc_prof_enable(1)
@@ -203,16 +225,38 @@ def main():
     if rank == 0:
         rep = _ffi.prof_report()
         lib.dtc_prof_reset()
-        gemm = [r for r in rep if r["name"].split("[")[0] in ("linear_fwd", "linear_dgrad", "linear_wgrad")]
+        # the GEMM family = forward / data-gradient / weight-gradient kernels AND the split-reduce kernels the weight
+        # gradients need (their time counts against the family's FLOP; they add no FLOP of their own)
+        fam = ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_reduce")
+        gemm = [r for r in rep if r["name"].split("[")[0] in fam]
         # (the composite's GRU steps call the same three kernels from inside dtc_gru_fwd / dtc_gru_bwd)
         ms = sum(r["ms_total"] for r in gemm)
-        fl = sum(r["work"] for r in gemm)
+        fl = sum(r["work"] for r in gemm if not r["name"].startswith("wgrad_reduce"))
         n_launch = sum(r["launches"] for r in gemm)
+        algo_bytes = sum(r["bytes"] for r in gemm)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roof = dict(bound="mfma", kernel="linear_{fwd,dgrad,wgrad}_kernel (fp32 v_mfma_f32_32x32x2_f32 GEMM family)",
+        roof = dict(bound="mfma", kernel="linear_{fwd,dgrad}_kernel, wgrad_group_kernel (+ its split-reduce kernel): fp32 "
+                                         "v_mfma_f32_32x32x2_f32 GEMM family",
                     achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP32_MFMA_TFLOPS,
-                    traffic=None, launches=n_launch, measured="HIP events per launch, kernels serialised on one stream", avg_launch_us=ms * 1e3 / max(1, n_launch),
-                    flop_per_launch=fl / max(1, n_launch))
+                    traffic=None, traffic_algorithmic=algo_bytes / max(1, n_launch), launches=n_launch,
+                    measured="HIP events per launch, kernels serialised on one stream; the split-reduce launches of the weight "
+                             "gradients are part of the family (time, no FLOP)",
+                    avg_launch_us=ms * 1e3 / max(1, n_launch), flop_per_launch=fl / max(1, n_launch),
+                    reduce_ms=sum(r["ms_total"] for r in gemm if r["name"].startswith("wgrad_reduce")))
+        if world == 1 and not a.no_traffic:
+            # HBM-side traffic of the same family over one serialised step: two rocprofv3 PMC passes over a child bench run
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "deep-tracking-control_amd", "tools", "analysis"))
+                import traffic as TR
+                tr = TR.collect(os.path.join(ROOT, "gpurun_out", "traffic_pmc"), a.workload)
+                roof["traffic"] = tr["step_bytes"] / max(1, tr["launches"])
+                roof["traffic_step_bytes"], roof["traffic_algorithmic_step_bytes"] = tr["step_bytes"], algo_bytes
+                roof["traffic_over_algorithmic"] = tr["step_bytes"] / algo_bytes if algo_bytes > 0 else None
+                roof["traffic_launches"] = tr["launches"]
+                roof["traffic_source"] = tr["method"]
+                roof["traffic_kernels"] = {k: dict(launches=v["launches"], MB=round(v["bytes"] / 1e6, 1)) for k, v in tr["kernels"].items()}
+            except Exception as e:                 # no rocprofv3 on this box / counters unavailable: say so, keep the line
+                roof["traffic_error"] = str(e)[-300:]
         pl = [r for r in rep if r["name"].split("[")[0] == "foothold_plan"]
         if pl:                                  # the HBM-side kernel of the path: bytes = 3096 B/env
             pms, pby, pn = (sum(r[k] for r in pl) for k in ("ms_total", "work", "launches"))
@@ -246,7 +290,10 @@ def main():
                        "num_envs_per_gpu": NUM_ENVS, "num_steps_per_env": NUM_STEPS, "mini_batch": 24576,
                        "epochs": 5, "wgrad_overlap_stream": bool(getattr(alg, "overlap_wgrad", False)), "parallelism": f"dp{world}" if world > 1 else "single",
                        "mfma_frac_whole_step": None if (composite or gru) else
-                       (FLOP_PER_ENV_STEP * value / world) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
+                       (FLOP_PER_ENV_STEP * value / world) / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                       "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+                       "allreduce_bytes_per_step_per_rank": dp.bytes_reduced(coll_log) if world > 1 else 0,
+                       "collectives_per_step": len(coll_log)},
             "roofline": roof,
             "roofline_planner": planner,
             "kernel_classes": classes,

@@ -13,7 +13,7 @@ int check_launch(const char* what);
 // Optional per-launch HIP-event timing (dtc_prof_enable).  `work` is the algorithmic work of
 // the launch in the unit of its roofline (FLOP for MFMA-bound kernels, bytes for HBM-bound).
 struct ProfScope {
-    ProfScope(const char* name, double work, hipStream_t s);
+    ProfScope(const char* name, double work, hipStream_t s, double bytes = 0.0);
     ~ProfScope();
     int slot;
     hipStream_t stream;

@@ -667,7 +667,7 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     hipStream_t s = (hipStream_t)stream;
     const int bn = pick_bn_rows(M, N);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, bn));
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s);
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     // dwordx4 stores of the output need 16-byte aligned rows (full tiles only; checked per block)
     static const bool wide_off = getenv("DTC_GEMM_WIDE") && atoi(getenv("DTC_GEMM_WIDE")) == 0;      // A/B switch
     const int wide = (!wide_off && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
@@ -695,7 +695,8 @@ extern "C" int dtc_linear_fwd_mse(const DtcSegMat* X, const float* W, const floa
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 64));
     const MseEpi mse{target, (const long long*)tidx, (long long)ldt, target_rows * ldt * 4, tcol0, scale, sq_part};
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s);
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s,
+                        4.0 * ((double)M * K + (double)N * K + 2.0 * M * N));      // X, W, the gathered target, dL/dY
     hipLaunchKernelGGL((linear_fwd_kernel<64, true>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy, M, N, K,
                        (int)DTC_ACT_NONE, 0, mse);
     return dtc::check_launch("linear_fwd_mse");
@@ -732,7 +733,11 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
     const int bn = pick_bn_rows(M, K - col_skip);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K - col_skip, bn));
     const int wide = wide_mask(xd, Xsaved, ldxs, col_skip, 0);
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s);
+    double bytes = 4.0 * ((double)M * N + (double)N * K);                           // dZ, W
+    for (int i = 0; i < xd.nseg; ++i)
+        if (xd.s[i].ptr) bytes += 4.0 * M * xd.s[i].width * (xd.s[i].accumulate ? 2.0 : 1.0);   // dX written (+ read when accumulated)
+    if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)K;                          // saved activations
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s, bytes);
     if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
     else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
     return dtc::check_launch("linear_dgrad");
@@ -755,7 +760,8 @@ extern "C" int dtc_linear_dgrad_split(const float* dZ, int64_t lddz, const float
     const int row_tiles = (int)dtc::ceil_div(M, BM);
     const int bn = (K <= 32 || (long long)row_tiles * dtc::ceil_div(K, 64) * nsplit < 320) ? 32 : 64;
     const dim3 grid((unsigned)grid_for(row_tiles, (int)dtc::ceil_div(K, bn)), (unsigned)nsplit);
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * K, s);
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * K, s,
+                        4.0 * ((double)M * N + (double)N * K + (double)nsplit * M * K));
     const int wide = wide_mask(xd, nullptr, 0, 0, split_stride);
     if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride, 0, wide);
     else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(256), 0, s, dZ, (long long)lddz, W, xd, nullptr, 0ll, M, N, K, (int)DTC_ACT_NONE, chunk, (long long)split_stride, 0, wide);

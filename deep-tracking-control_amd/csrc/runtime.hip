@@ -17,7 +17,7 @@ std::mutex g_prof_mu;
 bool g_prof_on = false;
 struct Rec {
     const char* name;
-    double work;
+    double work, bytes;
     hipEvent_t a, b;
 };
 std::vector<Rec> g_recs;
@@ -53,10 +53,10 @@ const char* prof_shape_name(const char* base, int M, int N, int K) {
     return it->second.c_str();
 }
 
-ProfScope::ProfScope(const char* name, double work, hipStream_t s) : slot(-1), stream(s) {
+ProfScope::ProfScope(const char* name, double work, hipStream_t s, double bytes) : slot(-1), stream(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    Rec r{name, work, nullptr, nullptr};
+    Rec r{name, work, bytes, nullptr, nullptr};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
@@ -104,6 +104,7 @@ int dtc_prof_report(DtcProfRec* out, int cap) {
         }
         d.ms_total += ms;
         d.work += r.work;
+        d.bytes += r.bytes;
         d.launches += 1;
     }
     int n = 0;

@@ -342,7 +342,7 @@ struct GroupPlan {
     WGroupDev dev;
     long long bytes;
     int red_blocks;
-    double flop;
+    double flop, algo_bytes;   // algo_bytes: dZ, X read once, dW + db written once (the partial slabs are overhead)
 };
 
 int plan_group(const DtcWgradJob* jobs, int count, int M, void* workspace, GroupPlan& P) {
@@ -376,7 +376,7 @@ int plan_group(const DtcWgradJob* jobs, int count, int M, void* workspace, Group
     G.rows_per_split = (int)dtc::ceil_div(dtc::ceil_div(M, G.splits), BK) * BK;
     long long off = 0;
     int red = 0;
-    P.flop = 0.0;
+    P.flop = P.algo_bytes = 0.0;
     for (int j = 0; j < count; ++j) {
         WJobDev& d = G.job[j];
         d.part = workspace ? (float*)((char*)workspace + off) : nullptr;
@@ -385,6 +385,7 @@ int plan_group(const DtcWgradJob* jobs, int count, int M, void* workspace, Group
         red += d.N * (int)dtc::ceil_div(ldp / 4, 64);
         d.red_end = red;
         P.flop += 2.0 * M * (double)d.N * d.K;
+        P.algo_bytes += 4.0 * ((double)M * d.N + (double)M * d.K + (double)d.N * (d.K + 1));
     }
     P.bytes = off;
     P.red_blocks = red;
@@ -417,7 +418,8 @@ extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* 
     rows_per_split = (int)dtc::ceil_div(rows_per_split, BK) * BK;
     float* part = (float*)workspace;
     {
-        dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, N, K), 2.0 * M * (double)N * K, s);
+        dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, N, K), 2.0 * M * (double)N * K, s,
+                            4.0 * ((double)M * N + (double)M * K + (double)N * (K + 1)));      // dZ, X, dW + db (partials are overhead)
         const int grid = tiles * 8 * (int)dtc::ceil_div(splits, 8);
         if (bn == 64) hipLaunchKernelGGL(linear_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split, col_tiles, splits);
         else hipLaunchKernelGGL(linear_wgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, xd, part, M, N, K, rows_per_split, col_tiles, splits);
@@ -449,7 +451,7 @@ extern "C" int dtc_wgrad_group(const DtcWgradJob* jobs, int count, int M, void* 
     hipStream_t s = (hipStream_t)stream;
     const WGroupDev& G = P.dev;
     {
-        dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, G.tiles_total, count), P.flop, s);
+        dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, G.tiles_total, count), P.flop, s, P.algo_bytes);
         const int grid = G.tiles_total * 8 * (int)dtc::ceil_div(G.splits, 8);
         hipLaunchKernelGGL(wgrad_group_kernel, dim3(grid), dim3(256), 0, s, G);
     }

@@ -60,7 +60,7 @@ class DtcRowCopy(C.Structure):
 
 class DtcProfRec(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms_total", C.c_double), ("work", C.c_double),
-                ("launches", C.c_int64)]
+                ("launches", C.c_int64), ("bytes", C.c_double)]
 
 
 ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
@@ -216,4 +216,4 @@ def prof_report():
     arr = (DtcProfRec * max(n, 1))()
     n = lib().dtc_prof_report(arr, n)
     return [dict(name=arr[i].name.decode(), ms_total=arr[i].ms_total, work=arr[i].work,
-                 launches=arr[i].launches) for i in range(n)]
+                 launches=arr[i].launches, bytes=arr[i].bytes) for i in range(n)]

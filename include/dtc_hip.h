@@ -296,7 +296,10 @@ int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* gates, const
 /* ---- per-kernel timing (HIP events on `stream`) used by bench.py's roofline object ---------- */
 void dtc_prof_enable(int on);
 /* Fills up to `cap` records; returns the number of distinct kernel classes seen. */
-typedef struct DtcProfRec { char name[48]; double ms_total; double work; int64_t launches; } DtcProfRec;
+/* work = algorithmic work of the launches in the unit of the kernel's roofline (FLOP for the MFMA-bound GEMMs, bytes for
+ * HBM-bound kernels); bytes = algorithmic HBM bytes of the GEMM launches (every operand read once, every output
+ * written once; 0 where not tracked) -- the denominator of bench.py's traffic ratio. */
+typedef struct DtcProfRec { char name[48]; double ms_total; double work; int64_t launches; double bytes; } DtcProfRec;
 int dtc_prof_report(DtcProfRec* out, int cap);
 void dtc_prof_reset(void);
 
