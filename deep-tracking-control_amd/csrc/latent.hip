@@ -7,8 +7,16 @@
 // The torch version is ~10 passes over lv plus a sort-based median on ~4e5 values.  Here:
 //   stats (sum, sum^2 in fp64)  ->  3-level MSB radix select (11+11+10 bits) over the
 //   non-outliers with LDS histograms  ->  one apply pass that also writes z and the mask.
-// Every pass reads the 1.5 MB lv column block (L2 resident); 5 short launches in total.
+// Every pass reads the 1.5 MB lv column block (L2 resident): 5 short launches + 1 memset.  (A single persistent launch
+// with device-scope counter barriers between the phases was built and measured in round 2: 56-92 us against 51 us --
+// with a few dozen workgroups the LDS histogram atomics on two or three hot bins serialise, with 256 workgroups the
+// barriers cost as much as the launch boundaries they replace; see DESIGN.md "measured and rejected".)
+// Backward = ONE kernel: the last workgroup to finish (arrival ticket) adds the replaced entries' gradient to the median
+// element; what it reads from other workgroups travels write-through (agent-scope relaxed stores / loads), no
+// cache-maintenance fence (an agent-scope release would write back the whole XCD L2).
 // mulv is the [B,35] output of the fused (latent_mu | latent_var) head: cols 0..18 mu, 19..34 lv.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -20,9 +28,11 @@ constexpr int MAX_BLK = 256;
 struct Ws {
     double part[MAX_BLK * 2];
     float gpart[MAX_BLK];
-    unsigned hist1[NB1];
+    unsigned hist1[NB1];        // hist1 .. ticket: zeroed by ONE memset before the forward kernel
     unsigned hist2[NB2];
     unsigned hist3[NB3];
+    unsigned spare;
+    unsigned ticket;            // arrival ticket of the backward kernel (the last workgroup resets it)
 };
 
 __device__ __forceinline__ unsigned f2key(float f) {
@@ -45,8 +55,10 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
     return t;
 }
 
-__global__ __launch_bounds__(256) void lat_stats_kernel(const float* __restrict__ mulv, long long n, Ws* ws) {
+__global__ __launch_bounds__(256) void lat_stats_kernel(const float* __restrict__ mulv, long long n, Ws* ws,
+                                                        int* __restrict__ info) {
     __shared__ double sh[4];
+    if (blockIdx.x == 0 && threadIdx.x < 4) info[threadIdx.x] = threadIdx.x == 1 ? 0x7f7f7f7f : 0;     // consumed 4 launches later
     double s = 0.0, q = 0.0;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
         const double x = (double)mulv[(e >> 4) * LD + MU + (e & 15)];
@@ -84,7 +96,11 @@ __device__ void find_bin(const unsigned* __restrict__ hist, int nbins, unsigned 
                          unsigned& bin, unsigned long long& krem, unsigned long long& total, unsigned long long* sh) {
     const int per = nbins / 256;
     unsigned long long mine = 0;
-    for (int i = 0; i < per; ++i) mine += hist[threadIdx.x * per + i];
+    unsigned hv[8];                                                // per <= 8
+    for (int i = 0; i < per; ++i) {
+        hv[i] = hist[threadIdx.x * per + i];
+        mine += hv[i];
+    }
     sh[threadIdx.x] = mine;
     __syncthreads();
     // inclusive scan (Hillis-Steele) over 256 entries
@@ -101,7 +117,7 @@ __device__ void find_bin(const unsigned* __restrict__ hist, int nbins, unsigned 
     if (k >= excl && k < incl) {
         unsigned long long c = excl;
         for (int i = 0; i < per; ++i) {
-            const unsigned h = hist[threadIdx.x * per + i];
+            const unsigned h = hv[i];
             if (k < c + h) {
                 sh[256] = threadIdx.x * per + i;
                 sh[257] = k - c;
@@ -186,11 +202,14 @@ __global__ __launch_bounds__(256) void lat_apply_kernel(float* __restrict__ mulv
     }
 }
 
+
 __global__ __launch_bounds__(256) void lat_bwd_kernel(float* __restrict__ dmulv, const float* __restrict__ dz,
                                                       const float* __restrict__ eps, const float* __restrict__ mulv,
-                                                      const uint8_t* __restrict__ mask, long long n, Ws* ws) {
+                                                      const uint8_t* __restrict__ mask, const int* __restrict__ info,
+                                                      long long n, Ws* ws) {
     __shared__ float shf[4];
     float acc = 0.f;
+    const int em = info[1];                           // flat index of the median element (written by the forward call)
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
         const long long b = e >> 4;
         const int j = (int)(e & 15);
@@ -202,22 +221,40 @@ __global__ __launch_bounds__(256) void lat_bwd_kernel(float* __restrict__ dmulv,
             acc += glv;
             glv = 0.f;
         }
-        dmulv[b * LD + MU + j] = glv;
+        // the median element is read again by the LAST workgroup of this launch: write it through (sc1), all others plain
+        if (e == (long long)em) __hip_atomic_store(&dmulv[b * LD + MU + j], glv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dmulv[b * LD + MU + j] = glv;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if ((threadIdx.x & 63) == 0) shf[threadIdx.x >> 6] = acc;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's stores (incl. the write-through one) have landed
     __syncthreads();
-    if (threadIdx.x == 0) ws->gpart[blockIdx.x] = (shf[0] + shf[1]) + (shf[2] + shf[3]);
-}
-
-// gradient of the median: the summed gradient of all replaced entries flows to the median element
-__global__ void lat_bwd_fix_kernel(float* __restrict__ dmulv, const int* __restrict__ info, int nblk, const Ws* ws) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float t = 0.f;
-        for (int i = 0; i < nblk; ++i) t += ws->gpart[i];
-        const int e = info[1];
-        if (e != 0x7f7f7f7f && e >= 0) dmulv[(long long)(e >> 4) * LD + MU + (e & 15)] += t;
+    // gradient of the median: the summed gradient of all replaced entries flows to the median element.  The last
+    // workgroup to arrive (ticket) adds the per-workgroup sums in index order (deterministic).  What it reads from other
+    // workgroups -- their partial sums and the median element's own gradient -- was written through (agent-scope relaxed
+    // stores) and is read with agent-scope loads: no cache-maintenance fence (see the header comment).
+    __shared__ unsigned last;
+    __shared__ float red[MAX_BLK];
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&ws->gpart[blockIdx.x], (shf[0] + shf[1]) + (shf[2] + shf[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(&ws->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last) {                                       // whole workgroup: one load per thread, then the sum in index order
+        red[threadIdx.x] = threadIdx.x < gridDim.x ? __hip_atomic_load(&ws->gpart[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+            for (unsigned i = 0; i < gridDim.x; ++i) tot += red[i];
+            if (em != 0x7f7f7f7f && em >= 0) {
+                float* p = &dmulv[(long long)(em >> 4) * LD + MU + (em & 15)];
+                const float cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *p = cur + tot;
+            }
+            __hip_atomic_store(&ws->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
+        }
     }
 }
 
@@ -242,10 +279,9 @@ extern "C" int dtc_cenet_latent_fwd(float* mulv, const float* eps, float* z, uin
     const long long n = (long long)B * LAT;
     const int g = grid_for(n);
     dtc::ProfScope prof("cenet_latent_fwd", (double)n * 4.0 * 6, s);
-    (void)hipMemsetAsync(ws->hist1, 0, sizeof(unsigned) * (NB1 + NB2 + NB3), s);
-    (void)hipMemsetAsync(info, 0, sizeof(int32_t) * 4, s);
-    (void)hipMemsetAsync(info + 1, 0x7f, sizeof(int32_t), s);
-    hipLaunchKernelGGL(lat_stats_kernel, dim3(g), dim3(256), 0, s, mulv, n, ws);
+    // scratch header (histograms + the backward kernel's ticket): one memset; `info` is initialised by the stats kernel
+    (void)hipMemsetAsync(ws->hist1, 0, sizeof(unsigned) * (NB1 + NB2 + NB3 + 2), s);
+    hipLaunchKernelGGL(lat_stats_kernel, dim3(g), dim3(256), 0, s, mulv, n, ws, info);
     hipLaunchKernelGGL(lat_hist_kernel<1>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
     hipLaunchKernelGGL(lat_hist_kernel<2>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
     hipLaunchKernelGGL(lat_hist_kernel<3>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
@@ -262,7 +298,6 @@ extern "C" int dtc_cenet_latent_bwd(float* dmulv, const float* dz, const float* 
     const long long n = (long long)B * LAT;
     const int g = grid_for(n);
     dtc::ProfScope prof("cenet_latent_bwd", (double)n * 4.0 * 6, s);
-    hipLaunchKernelGGL(lat_bwd_kernel, dim3(g), dim3(256), 0, s, dmulv, dz, eps, mulv, mask, n, ws);
-    hipLaunchKernelGGL(lat_bwd_fix_kernel, dim3(1), dim3(64), 0, s, dmulv, info, g, ws);
+    hipLaunchKernelGGL(lat_bwd_kernel, dim3(g), dim3(256), 0, s, dmulv, dz, eps, mulv, mask, info, n, ws);
     return dtc::check_launch("cenet_latent_bwd");
 }
