@@ -271,9 +271,17 @@ __global__ __launch_bounds__(256, 5) void linear_fwd_kernel(const SegMatDev X, c
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = v;
                 }
-            } else {
+            } else if (act == DTC_ACT_NONE) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = patch_get(patch, prow + 8 * p, pc4);
+            } else {                                // selu / lrelu / tanh / sigmoid: not on this model's path, generic form
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    f32x4 v = patch_get(patch, prow + 8 * p, pc4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], act);
+                    *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = v;
+                }
             }
         }
         DTC_STAMP(3);
@@ -659,7 +667,7 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
                               int K, int act, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
     DTC_REQUIRE(W && Y, "null pointer");
-    DTC_REQUIRE(act >= 0 && act <= 2, "bad activation %d", act);
+    DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
     DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * ldy <= MAX_ELEMS * 4, "matrix too large");
     SegMatDev xd;
     int rc = to_dev(X, xd, K, false, M);
@@ -718,7 +726,7 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
                                 int64_t ldxs, int M, int N, int K, int act, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
     DTC_REQUIRE(dZ && W, "null pointer");
-    DTC_REQUIRE(act >= 0 && act <= 2, "bad activation %d", act);
+    DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
     DTC_REQUIRE(act == DTC_ACT_NONE || (Xsaved != nullptr && ldxs >= K), "activation derivative needs Xsaved");
     DTC_REQUIRE(act == DTC_ACT_NONE || (dX && dX->nseg == 1), "activation derivative needs a single-segment destination");
     DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * lddz <= MAX_ELEMS, "matrix too large");

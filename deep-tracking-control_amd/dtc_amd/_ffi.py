@@ -63,7 +63,7 @@ class DtcProfRec(C.Structure):
                 ("launches", C.c_int64), ("bytes", C.c_double)]
 
 
-ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
+ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
 _SIGS = {

@@ -67,8 +67,9 @@ class ActorCritic(nn.Module):
             print("ActorCritic.__init__ got unexpected arguments, which will be ignored: " + str([key for key in kwargs.keys()]))
         super().__init__()
         self.activation_name = activation
-        if activation not in ("elu", "relu"):
-            raise NotImplementedError("the HIP layers implement 'elu' and 'relu'")
+        if activation not in _ffi.ACT:
+            raise NotImplementedError(f"unknown activation {activation!r} (the reference's get_activation table: "
+                                      "elu, selu, relu, crelu, lrelu, tanh, sigmoid)")
         act = get_activation(activation)
         self.num_actions = num_actions
         self.actor = _mlp(num_actor_obs, actor_hidden_dims, num_actions, act)

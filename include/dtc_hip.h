@@ -31,6 +31,11 @@ extern "C" {
 #define DTC_ACT_NONE 0
 #define DTC_ACT_RELU 1
 #define DTC_ACT_ELU 2
+/* the remaining entries of the reference's get_activation table (actor_critic_decoder.py:565-582; 'crelu' is nn.ReLU there) */
+#define DTC_ACT_SELU 3
+#define DTC_ACT_LRELU 4    /* nn.LeakyReLU(): negative slope 0.01 */
+#define DTC_ACT_TANH 5
+#define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
 int dtc_version(void);                       /* ABI version, bumped on signature changes  */

@@ -289,6 +289,34 @@ def test_linear_dgrad_segments_accumulate():
     np.testing.assert_allclose(_np(dlt2), fulla[:, 72:].numpy(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("act", ["relu", "crelu", "elu", "selu", "lrelu", "tanh", "sigmoid", None])
+@pytest.mark.parametrize("M,N,K", [(384, 128, 265), (1000, 70, 100)])
+def test_linear_activations_fwd_and_dgrad_vs_torch(act, M, N, K):
+    """Every entry of the reference's get_activation table (actor_critic_decoder.py:565-582): forward epilogue and the
+    derivative the data-gradient epilogue takes from the saved post-activation output, against torch autograd."""
+    from dtc_amd import ops
+    from dtc_amd.modules.actor_critic_decoder import get_activation
+    g = torch.Generator().manual_seed(M + N + K)
+    X = torch.randn(M, K, generator=g, dtype=torch.float64, requires_grad=True)
+    W = torch.randn(N, K, generator=g, dtype=torch.float64) / K ** 0.5
+    b = torch.randn(N, generator=g, dtype=torch.float64) * 0.3
+    W2 = torch.randn(32, N, generator=g, dtype=torch.float64) / N ** 0.5
+    dZ2 = torch.randn(M, 32, generator=g, dtype=torch.float64)
+    fn = get_activation(act) if act is not None else (lambda t: t)
+    Y = fn(X @ W.t() + b)
+    (Y @ W2.t() * dZ2).sum().backward()              # d/dY = dZ2 W2 ; then through the activation and the layer
+    f = lambda t: t.detach().float().to(DEV)
+    Yh = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(f(X), f(W), f(b), Yh, act)
+    np.testing.assert_allclose(_np(Yh), Y.detach().numpy(), rtol=2e-5, atol=2e-5)
+    # backward of the NEXT layer with this layer's activation derivative fused: dY_pre = (dZ2 W2) * act'(Y)
+    dpre = torch.empty(M, N, device=DEV)
+    ops.linear_dgrad(f(dZ2), f(W2), dpre, Yh, act)
+    dX = torch.empty(M, K, device=DEV)
+    ops.linear_dgrad(dpre, f(W), dX, None, None)
+    np.testing.assert_allclose(_np(dX), X.grad.numpy(), rtol=3e-4, atol=3e-5)
+
+
 @pytest.mark.parametrize("M,N,K", [(1536, 512, 693), (1536, 512, 512), (1000, 64, 128), (384, 35, 64),
                                    (1536, 693, 512), (777, 12, 128), (384, 1, 128), (24576, 128, 256)])
 def test_linear_wgrad_plain(M, N, K):
