@@ -154,16 +154,21 @@ def main():
     last = {k: data[k][-1] for k in ("observations", "privileged_observations", "base_vel")}
     torch.manual_seed(123 + rank)
 
+    from dtc_amd import tracing
+
     def step():
-        foothold.plan(sc["measured_heights"], sc["root_states"], sc["thigh_pos"], sc["commands"])
-        if gru:
-            alg.compute_returns(last["privileged_observations"])
-        else:
-            alg.compute_returns(last["observations"], last["privileged_observations"], last["base_vel"])
+        with tracing.span("foothold_plan"):
+            foothold.plan(sc["measured_heights"], sc["root_states"], sc["thigh_pos"], sc["commands"])
+        with tracing.span("compute_returns"):
+            if gru:
+                alg.compute_returns(last["privileged_observations"])
+            else:
+                alg.compute_returns(last["observations"], last["privileged_observations"], last["base_vel"])
         alg.storage.step = NUM_STEPS
         if composite or gru:
             alg.storage.saved_hidden_states_a, alg.storage.saved_hidden_states_c = [hid[0]], [hid[1]]
-        return alg.update()
+        with tracing.span("update"):
+            return alg.update()
 
     def fence():
         torch.cuda.synchronize()

@@ -54,6 +54,31 @@ def _compile(src, force, save_temps):
     return obj, r.stderr
 
 
+def build_asan(verbose=True):
+    """Host-side AddressSanitizer build of the same sources (device code unsanitised): libdtc_hip_asan.so.  Used by
+    tests/test_abi_and_host.py to run the argument-validation / descriptor-marshalling layer of the C ABI under ASan
+    (`LD_PRELOAD=<libclang_rt.asan> DTC_LIB=<this file>`); no GPU needed, the calls under test fail validation before
+    any HIP call."""
+    out = os.path.join(LIBDIR, "libdtc_hip_asan.so")
+    srcs = [os.path.join(CSRC, f) for f in sources()]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "dtc_hip.h")]
+    if _stale(out, deps):
+        os.makedirs(LIBDIR, exist_ok=True)
+        cmd = [HIPCC, *COMMON, "-O1", "-g", "-fsanitize=address", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-shared", *srcs, "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"ASan build failed:\n{r.stderr[-2000:]}")
+    if verbose:
+        print(f"built {out}")
+    return out
+
+
+def asan_runtime():
+    r = subprocess.run([os.path.join(os.path.dirname(HIPCC), "..", "lib", "llvm", "bin", "clang"), "-print-file-name=libclang_rt.asan-x86_64.so"],
+                       capture_output=True, text=True)
+    return r.stdout.strip()
+
+
 def build(force=False, save_temps=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -75,4 +100,7 @@ def build(force=False, save_temps=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)
+    if "--asan" in sys.argv:
+        build_asan()
+    else:
+        build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)

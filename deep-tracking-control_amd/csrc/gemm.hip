@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, 3) void gru_step_fwd_kernel(const float* __res
 // Columns of B past K read the next row of W (or 0 behind its last row): they only feed output columns that are never
 // stored, so the B loads carry no column masks at all.
 template <int BN>
-__global__ __launch_bounds__(256, 5) void linear_dgrad_kernel(const float* __restrict__ dZ, long long lddz,
+__global__ __launch_bounds__(256, 6) void linear_dgrad_kernel(const float* __restrict__ dZ, long long lddz,
                                                            const float* __restrict__ W, const SegMatDev dX,
                                                            const float* __restrict__ Xs, long long ldxs, int M, int N,
                                                            int K, int act, int split_n, long long split_dst, int col_skip,

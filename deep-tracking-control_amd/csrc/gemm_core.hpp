@@ -43,10 +43,10 @@ __device__ __forceinline__ int find_seg(const SegMatDev& X, int k) {
 }
 
 constexpr float SELU_L = 1.0507009873554804934193349852946f, SELU_LA = 1.0507009873554804934193349852946f * 1.6732632423543772848170429916717f;
-__device__ __forceinline__ float act_fwd(float v, int act) {
+// The model's own activations (none / ReLU / ELU) are inlined into the unrolled epilogues; the rest of the reference's
+// table goes through out-of-line functions so that the hot kernels keep their register budget.
+__device__ __attribute__((noinline)) float act_fwd_rare(float v, int act) {
     switch (act) {
-        case DTC_ACT_RELU: return v > 0.f ? v : 0.f;
-        case DTC_ACT_ELU: return v > 0.f ? v : expm1f(v);
         case DTC_ACT_SELU: return v > 0.f ? SELU_L * v : SELU_LA * expm1f(v);
         case DTC_ACT_LRELU: return v > 0.f ? v : 0.01f * v;
         case DTC_ACT_TANH: return tanhf(v);
@@ -54,17 +54,27 @@ __device__ __forceinline__ float act_fwd(float v, int act) {
         default: return v;
     }
 }
-// derivative expressed through the saved post-activation output y
-__device__ __forceinline__ float act_bwd(float g, float y, int act) {
+__device__ __attribute__((noinline)) float act_bwd_rare(float g, float y, int act) {
     switch (act) {
-        case DTC_ACT_RELU: return y > 0.f ? g : 0.f;
-        case DTC_ACT_ELU: return y > 0.f ? g : g * (y + 1.0f);
         case DTC_ACT_SELU: return y > 0.f ? g * SELU_L : g * (y + SELU_LA);
         case DTC_ACT_LRELU: return y > 0.f ? g : 0.01f * g;
         case DTC_ACT_TANH: return g * (1.0f - y * y);
         case DTC_ACT_SIGMOID: return g * (y * (1.0f - y));
         default: return g;
     }
+}
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == DTC_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DTC_ACT_ELU) return v > 0.f ? v : expm1f(v);
+    if (act > DTC_ACT_ELU) return act_fwd_rare(v, act);
+    return v;
+}
+// derivative expressed through the saved post-activation output y
+__device__ __forceinline__ float act_bwd(float g, float y, int act) {
+    if (act == DTC_ACT_RELU) return y > 0.f ? g : 0.f;
+    if (act == DTC_ACT_ELU) return y > 0.f ? g : g * (y + 1.0f);
+    if (act > DTC_ACT_ELU) return act_bwd_rare(g, y, act);
+    return g;
 }
 
 // Buffer loads: `buffer_load_dword v, voff, s[rsrc], soff offen` -- 128-bit descriptor + uniform byte offset in

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdtc_hip.so")
+LIB_PATH = os.environ.get("DTC_LIB") or os.path.join(_HERE, "lib", "libdtc_hip.so")      # DTC_LIB: e.g. the ASan build
 
 c_f32p, c_i64p, c_u8p, c_f64p, c_i32p, c_i16p = (C.c_void_p,) * 6   # device pointers travel as integers
 c_stream = C.c_void_p

@@ -24,7 +24,7 @@ import os
 
 import torch
 
-from .. import _ffi, distributed as dp, ops
+from .. import _ffi, distributed as dp, ops, tracing
 from .._ffi import seg, segmat
 from ..modules.actor_critic_decoder import AC_Args, ActorCriticDecoder
 from ..storage import RolloutStorage
@@ -644,8 +644,10 @@ class PPO:
         for _ in range(epochs):
             for i in range(nmb):
                 idx = perm[i * B:(i + 1) * B]
-                self._vae_step(fw, tw, flat, idx, eps1[k], stats[k])
-                self._ppo_step(fw, tw, flat, idx, eps2[k], stats[k], cfg)
+                with tracing.span("vae_step"):
+                    self._vae_step(fw, tw, flat, idx, eps1[k], stats[k])
+                with tracing.span("ppo_step"):
+                    self._ppo_step(fw, tw, flat, idx, eps2[k], stats[k], cfg)
                 if lr_hist is not None:
                     lr_hist[k:k + 1].copy_(self.optimizer.lr_dev)
                 k += 1

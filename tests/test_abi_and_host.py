@@ -164,3 +164,72 @@ def test_episode_tracker_matches_a_deque_of_finished_episodes():
         else:
             assert abs(got[0] - sum(rets) / len(rets)) < 1e-4 and abs(got[1] - sum(lens) / len(lens)) < 1e-4
     assert len(rets) == 100                   # the ring wrapped at least once
+
+
+def _bad_descriptor_calls():
+    """Host-side validation / marshalling paths of the C ABI that return before any HIP call: exercised plainly and,
+    in a child process, under AddressSanitizer (descriptor structs with embedded arrays, job tables, error strings)."""
+    import ctypes as C
+    from dtc_amd import _ffi
+    lib = _ffi.lib()
+    n_err = 0
+
+    def expect_err(rc, needle):
+        nonlocal n_err
+        assert rc == -1, rc
+        assert needle.encode() in lib.dtc_last_error(), (needle, lib.dtc_last_error())
+        n_err += 1
+
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+    m = _ffi.DtcSegMat()
+    m.nseg, m.cols = 5, 8                                       # nseg out of range
+    expect_err(lib.dtc_linear_fwd(m, p, p, p, 8, 4, 8, 8, 0, None), "nseg")
+    m.nseg = 2
+    for i, w in enumerate((5, 3)):
+        m.seg[i].ptr, m.seg[i].ld, m.seg[i].col0, m.seg[i].width, m.seg[i].rows = p.value, 8, 0, w, 4
+    expect_err(lib.dtc_linear_fwd(m, p, p, p, 8, 4, 8, 9, 0, None), "segments cover")     # 5 + 3 != 9
+    m.seg[1].gather = 1                                         # gather without an index vector
+    expect_err(lib.dtc_linear_fwd(m, p, p, p, 8, 4, 8, 8, 0, None), "gather without idx")
+    m.seg[1].gather, m.seg[1].rows = 0, 0                       # source rows missing
+    expect_err(lib.dtc_linear_fwd(m, p, p, p, 8, 4, 8, 8, 0, None), "rows")
+    m.seg[1].rows, m.seg[1].col0 = 4, 6                         # columns outside the source
+    expect_err(lib.dtc_linear_fwd(m, p, p, p, 8, 4, 8, 8, 0, None), "outside")
+    m.seg[1].col0 = 0
+    expect_err(lib.dtc_linear_fwd(m, p, p, p, 8, 4, 8, 8, 99, None), "activation")
+    expect_err(lib.dtc_linear_dgrad(p, 8, p, m, None, 0, 4, 8, 8, 1, None), "Xsaved")
+    jobs = (_ffi.DtcWgradJob * 13)()
+    expect_err(lib.dtc_wgrad_group(jobs, 13, 4, p, None), "job count")
+    expect_err(lib.dtc_wgrad_group(jobs, 2, 4, p, None), "bad shape")
+    assert lib.dtc_wgrad_group_workspace(jobs, 13, 4) == -1
+    for j in range(2):
+        jobs[j].dZ, jobs[j].lddz, jobs[j].X, jobs[j].dW, jobs[j].N, jobs[j].K = p.value, 8, m, p.value, 8, 8
+    assert lib.dtc_wgrad_group_workspace(jobs, 2, 4) > 0         # a valid plan: sizes only, no device access
+    expect_err(lib.dtc_wgrad_group(jobs, 2, 4, None, None), "workspace")
+    expect_err(lib.dtc_cenet_latent_fwd(None, None, None, None, None, None, 8, None), "null")
+    expect_err(lib.dtc_clip_adam(None, None, None, None, 8, 1.0, None, 0.9, 0.999, 1e-8, 1, None, None, None), "null")
+    rec = (_ffi.DtcProfRec * 4)()
+    assert lib.dtc_prof_report(rec, 4) == 0
+    return n_err
+
+
+def test_host_validation_paths():
+    assert _bad_descriptor_calls() >= 12
+
+
+def test_host_validation_paths_under_address_sanitizer():
+    """SURVEY.md §5 / VERDICT r1: the same calls against an -fsanitize=address build of the library's host side, in a child
+    process with the ASan runtime preloaded.  Any out-of-bounds access in the descriptor marshalling aborts the child."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "deep-tracking-control_amd"))
+    import build as dtc_build
+    lib = dtc_build.build_asan(verbose=False)
+    rt = dtc_build.asan_runtime()
+    assert os.path.exists(rt), rt
+    env = dict(os.environ, LD_PRELOAD=rt, DTC_LIB=lib, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "deep-tracking-control_amd"), os.path.join(ROOT, "tests")]))
+    code = "import test_abi_and_host as t; print('asan-ok', t._bad_descriptor_calls())"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "asan-ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert "AddressSanitizer" not in r.stderr
