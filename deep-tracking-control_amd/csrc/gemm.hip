@@ -684,6 +684,16 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     return dtc::check_launch("linear_fwd");
 }
 
+extern "C" int dtc_linear_fwd_list(const DtcFwdLayer* layers, int count, int M, void* stream) {
+    DTC_REQUIRE(layers != nullptr && count >= 1 && count <= 64, "layer list: count %d outside 1..64", count);
+    for (int i = 0; i < count; ++i) {
+        const DtcFwdLayer& L = layers[i];
+        const int rc = dtc_linear_fwd(&L.X, L.W, L.b, L.Y, L.ldy, M, L.N, L.K, L.act, stream);
+        if (rc != DTC_OK) return rc;
+    }
+    return DTC_OK;
+}
+
 extern "C" int64_t dtc_linear_fwd_mse_parts(int M, int N) {
     if (M <= 0 || N <= 0) return 0;
     return grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 64));

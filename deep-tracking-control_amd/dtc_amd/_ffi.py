@@ -40,6 +40,11 @@ class DtcWgradJob(C.Structure):
                 ("N", C.c_int32), ("K", C.c_int32)]
 
 
+class DtcFwdLayer(C.Structure):
+    _fields_ = [("X", DtcSegMat), ("W", C.c_void_p), ("b", C.c_void_p), ("Y", C.c_void_p), ("ldy", C.c_int64),
+                ("N", C.c_int32), ("K", C.c_int32), ("act", C.c_int32)]
+
+
 class DtcPpoCfg(C.Structure):
     _fields_ = [("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float),
                 ("desired_kl", C.c_float), ("use_clipped_value_loss", C.c_int32),
@@ -89,6 +94,7 @@ _SIGS = {
     "dtc_scatter_rows": (C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int64, C.c_int64, c_stream]),
     "dtc_linear_fwd": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_stream]),
+    "dtc_linear_fwd_list": (C.c_int, [C.POINTER(DtcFwdLayer), C.c_int, C.c_int, c_stream]),
     "dtc_linear_dgrad": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_int,
                                    C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_linear_dgrad_split": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,

@@ -222,6 +222,7 @@ class ActorCriticDecoder(nn.Module):
                                     "(there is no CPU fallback)")
             self.arena = ParamArena(self)
             ar = self.arena
+            self._fw = {}            # forward workspaces hold marshalled layer chains that point into the old arena
             self._build_layers(ar)
             self.std_view = ar.view(ar.flat, "std")
             self.std_grad = ar.view(ar.grad, "std")
@@ -278,6 +279,38 @@ class ActorCriticDecoder(nn.Module):
         if ws is None:
             ws = self._fw[B] = ActorCriticDecoder._Fwd(B, self.std.device, self.num_actions)
         return ws
+
+    def _rollout_chains(self, ws, obs, hist, priv, base_vel):
+        """The forward passes of one env step as three marshalled layer chains (ops.FwdChain, built once per batch size):
+        CE-net encoder + heads | terrain encoder + actor | critic.  Per step only the env's input tensors are re-pointed."""
+        ch = getattr(ws, "chains", None)
+        if ch is None:
+            L, act = self.L, AC_Args.activation
+            B = ws.B
+            lay = lambda name, X, Y, a: (X, L[name].W, L[name].b, Y, a)
+            ce = ops.FwdChain([lay("ce0", hist, ws.e1, "relu"), lay("ce1", ws.e1, ws.e, None), lay("head", ws.e, ws.mulv, None)], B)
+            ta = ops.FwdChain([lay("te0", segmat([seg(priv, 0, 693)]), ws.t1, "relu"), lay("te1", ws.t1, ws.t2, "relu"),
+                               lay("te2", ws.t2, ws.lt, None), lay("a0", self.actor_input(ws, obs), ws.a1, act),
+                               lay("a1", ws.a1, ws.a2, act), lay("a2", ws.a2, ws.a3, act), lay("a3", ws.a3, ws.mean, None)], B)
+            cr = None
+            if base_vel is not None:
+                cr = ops.FwdChain([lay("c0", self.critic_input(obs, base_vel, priv), ws.v1, act), lay("c1", ws.v1, ws.v2, act),
+                                   lay("c2", ws.v2, ws.v3, act), lay("c3", ws.v3, ws.val, None)], B)
+            ch = ws.chains = dict(ce=ce, ta=ta, cr=cr)
+        if hist is not None:
+            ch["ce"].set_input(0, 0, hist)
+            ch["ta"].set_input(0, 0, priv)
+            ch["ta"].set_input(3, 0, obs)
+        if base_vel is not None:
+            if ch["cr"] is None:
+                L, act = self.L, AC_Args.activation
+                lay = lambda name, X, Y, a: (X, L[name].W, L[name].b, Y, a)
+                ch["cr"] = ops.FwdChain([lay("c0", self.critic_input(obs, base_vel, priv), ws.v1, act), lay("c1", ws.v1, ws.v2, act),
+                                         lay("c2", ws.v2, ws.v3, act), lay("c3", ws.v3, ws.val, None)], ws.B)
+            ch["cr"].set_input(0, 0, obs)
+            ch["cr"].set_input(0, 1, base_vel)
+            ch["cr"].set_input(0, 2, priv)
+        return ch
 
     # ------------------------------------------------------------------ kernel-level forward pieces
     def cenet_forward_(self, ws, hist, eps, idx=None):
@@ -351,9 +384,10 @@ class ActorCriticDecoder(nn.Module):
         ws = self._fwd_ws(B)
         if eps is None:
             eps = torch.randn(B, 16, device=obs.device)
-        self.cenet_forward_(ws, hist, eps)
-        self.terrain_encoder_(ws, priv)
-        self.actor_forward_(ws, obs)
+        ch = self._rollout_chains(ws, obs, hist, priv, None)
+        ch["ce"].run()
+        ops.cenet_latent_fwd(ws.mulv, eps, ws.z, ws.mask, ws.info, ws.lat_ws)
+        ch["ta"].run()
         self.latent_mu, self.latent_var, self.z = ws.mulv[:, :19], ws.mulv[:, 19:], ws.z
         mean = ws.mean.clone()
         self._dist = (mean, self.std_view.detach().expand_as(mean))
@@ -424,5 +458,5 @@ class ActorCriticDecoder(nn.Module):
         self.ensure_arena()
         obs, priv, bv = self._prep(critic_observations), self._prep(privileged_observations), self._prep(base_vel)
         ws = self._fwd_ws(obs.shape[0])
-        self.critic_forward_(ws, obs, bv, priv)
+        self._rollout_chains(ws, obs, None, priv, bv)["cr"].run()
         return ws.val.clone()

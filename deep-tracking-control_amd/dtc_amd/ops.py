@@ -59,6 +59,12 @@ def store_transition(copies, rewards=None, values=None, time_outs=None, gamma=0.
                                      ptr(rewards_dst), n_rows, stream()), "dtc_store_transition")
 
 
+def store_transition_items(items, count, rewards, values, time_outs, gamma, rewards_dst, n_rows):
+    """dtc_store_transition on an already marshalled DtcRowCopy array (RolloutStorage keeps one and re-points it)."""
+    check(lib().dtc_store_transition(items, count, ptr(rewards), ptr(values), ptr(time_outs), float(gamma),
+                                     ptr(rewards_dst), n_rows, stream()), "dtc_store_transition")
+
+
 def history_roll(obs_history, obs, out, history_len, reset=None):
     """out <- cat(obs_history[:, D:], obs); `out` may be `obs_history` itself."""
     N, D = obs.shape
@@ -84,6 +90,37 @@ def linear_fwd(X, W, b, Y, act=None, M=None):
     check(lib().dtc_linear_fwd(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0), M, N,
                                K, ACT[act], stream()), "dtc_linear_fwd")
     return Y
+
+
+class FwdChain:
+    """A fixed chain of forward layers marshalled ONCE (dtc_linear_fwd_list): `layers` = list of (X, W, b, Y, act) with X a
+    tensor or DtcSegMat.  `run()` launches the whole chain with one FFI call.  Inputs that change between calls (the
+    env's observation tensors) are re-pointed with `set_input(layer, segment, tensor)` -- the shape must stay the same."""
+
+    def __init__(self, layers, M):
+        self.M = M
+        self.arr = (_ffi.DtcFwdLayer * len(layers))()
+        self._keep = []
+        for i, (X, W, b, Y, act) in enumerate(layers):
+            Xs = as_segmat(X)
+            N, K = W.shape
+            a = self.arr[i]
+            a.X = Xs
+            a.W, a.b, a.Y, a.ldy = cptr(W, f32), (cptr(b, f32) if b is not None else None), ptr(Y), Y.stride(0)
+            a.N, a.K, a.act = N, K, ACT[act]
+            self._keep.append((Xs, W, b, Y))
+        self._inputs = {}
+
+    def set_input(self, layer, segment, t):
+        s = self.arr[layer].X.seg[segment]
+        if t.dtype != f32 or t.stride(1) != 1:
+            t = t.contiguous().float()
+        s.ptr, s.ld, s.rows = ptr(t), t.stride(0), t.shape[0]
+        self._inputs[(layer, segment)] = t             # keep the tensor alive while the chain may run
+
+    def run(self, stream_ptr=None):
+        check(lib().dtc_linear_fwd_list(self.arr, len(self.arr), self.M, stream() if stream_ptr is None else stream_ptr),
+              "dtc_linear_fwd_list")
 
 
 def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None):

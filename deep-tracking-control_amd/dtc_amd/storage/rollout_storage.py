@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch
 
 from .. import distributed as dp
-from .. import ops
+from .. import _ffi, ops
 from ..utils import split_and_pad_trajectories
 
 
@@ -83,18 +83,27 @@ class RolloutStorage:
             dones = tr.dones if tr.dones.dtype in (torch.uint8, torch.bool) else tr.dones.to(torch.uint8)
             if dones.dtype == torch.bool:
                 dones = dones.view(torch.uint8)
-            copies = [(f(tr.observations), self.observations[s]), (f(tr.next_observations), self.next_observations[s]),
-                      (f(tr.privileged_observations), self.privileged_observations[s]),
-                      (f(tr.observation_histories), self.observation_histories[s]), (f(tr.actions), self.actions[s]),
-                      (dones.reshape(-1), self.dones[s]), (f(tr.values), self.values[s]),
-                      (f(tr.actions_log_prob).reshape(-1), self.actions_log_prob[s]), (f(tr.action_mean), self.mu[s]),
-                      (f(tr.base_vel), self.base_vel[s]), (f(tr.action_sigma), self.sigma[s])]
+            # the 11 destination rows of step s: addresses from a plan marshalled once (base pointer + s * step bytes),
+            # only the source pointers are filled in per step -- the env step is host-bound, every us of FFI glue counts
+            plan = self._store_plan()
+            srcs = (f(tr.observations), f(tr.next_observations), f(tr.privileged_observations), f(tr.observation_histories),
+                    f(tr.actions), dones.reshape(-1), f(tr.values), f(tr.actions_log_prob).reshape(-1), f(tr.action_mean),
+                    f(tr.base_vel), f(tr.action_sigma))
+            items = plan["items"]
+            if not plan["checked"]:                       # shapes are fixed for the life of the storage: validate once
+                for src, (base, step_bytes, width, numel) in zip(srcs, plan["dst"]):
+                    assert src.shape[0] == self.num_envs and src[0].numel() == numel and (src.dim() == 1 or src.stride(-1) == 1)
+                plan["checked"] = True
+            for i, (src, (base, step_bytes, width, numel)) in enumerate(zip(srcs, plan["dst"])):
+                it = items[i]
+                it.src, it.dst = src.data_ptr(), base + s * step_bytes
+                it.src_stride_bytes = src.stride(0) * src.element_size()
             to = None
             if time_outs is not None:
                 to = time_outs.to(self.device)
                 to = to.view(torch.uint8) if to.dtype == torch.bool else to.to(torch.uint8)
-            ops.store_transition(copies, f(tr.rewards).reshape(-1).contiguous(), f(tr.values).reshape(-1), to, gamma,
-                                 self.rewards[s])
+            ops.store_transition_items(items, len(srcs), f(tr.rewards).reshape(-1).contiguous(), f(tr.values).reshape(-1), to,
+                                       gamma, self.rewards[s], self.num_envs)
         else:
             if time_outs is not None:
                 tr.rewards = tr.rewards + gamma * torch.squeeze(tr.values * time_outs.unsqueeze(1).to(self.device), 1)
@@ -112,6 +121,20 @@ class RolloutStorage:
             self.sigma[s].copy_(tr.action_sigma)
         self._save_hidden_states(tr.hidden_states)
         self.step += 1
+
+    def _store_plan(self):
+        plan = getattr(self, "_plan", None)
+        if plan is None:
+            dsts = (self.observations, self.next_observations, self.privileged_observations, self.observation_histories,
+                    self.actions, self.dones, self.values, self.actions_log_prob, self.mu, self.base_vel, self.sigma)
+            items = (_ffi.DtcRowCopy * len(dsts))()
+            meta = []
+            for i, t in enumerate(dsts):
+                row = t[0, 0].numel() * t.element_size()
+                items[i].width_bytes = row
+                meta.append((t.data_ptr(), t.stride(0) * t.element_size(), row, t[0, 0].numel()))
+            plan = self._plan = dict(items=items, dst=meta, checked=False)
+        return plan
 
     def _save_hidden_states(self, hidden_states):
         if hidden_states is None or hidden_states == (None, None):

@@ -179,6 +179,20 @@ typedef struct DtcSegMat {
 /* Y[M,N] = act(X[M,K] W[N,K]^T + b).  X is segmented (host struct). */
 int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy,
                    int M, int N, int K, int act, void* stream);
+/* A chain of forward layers in ONE call (same kernels, same results as `count` dtc_linear_fwd calls issued in order on
+ * `stream`): the rollout side of PPO.act / evaluate (ppo.py:137-155) is launch-bound -- ~16 small layers per env step at
+ * M = num_envs rows -- and the host cost of marshalling each layer through the FFI is paid once per chain instead of
+ * once per layer.  The caller may keep the array and patch input pointers between steps. */
+typedef struct DtcFwdLayer {
+    DtcSegMat X;         /* [M, K] segmented input                                              */
+    const float* W;      /* [N, K]                                                               */
+    const float* b;      /* [N] or NULL                                                          */
+    float* Y;            /* [M, >= N]                                                            */
+    int64_t ldy;
+    int32_t N, K, act;
+} DtcFwdLayer;
+int dtc_linear_fwd_list(const DtcFwdLayer* layers, int count, int M, void* stream);
+
 /* dX[M,K] = (dZ[M,N] W[N,K]) * act'(Xsaved), written through the segmented destination dX
  * (segments with ptr == NULL are skipped).  Xsaved (post-activation output of the previous
  * layer, leading dimension ldxs) may be NULL when act == DTC_ACT_NONE. */
