@@ -281,32 +281,28 @@ class ActorCriticDecoder(nn.Module):
         return ws
 
     def _rollout_chains(self, ws, obs, hist, priv, base_vel):
-        """The forward passes of one env step as three marshalled layer chains (ops.FwdChain, built once per batch size):
-        CE-net encoder + heads | terrain encoder + actor | critic.  Per step only the env's input tensors are re-pointed."""
+        """The forward passes of one env step as marshalled layer chains (ops.FwdChain, built once per batch size on first
+        use): "ce" CE-net encoder + heads and "ta" terrain encoder + actor (when `hist` is given), "cr" critic (when
+        `base_vel` is given).  Per step only the env's input tensors are re-pointed."""
         ch = getattr(ws, "chains", None)
         if ch is None:
-            L, act = self.L, AC_Args.activation
-            B = ws.B
-            lay = lambda name, X, Y, a: (X, L[name].W, L[name].b, Y, a)
-            ce = ops.FwdChain([lay("ce0", hist, ws.e1, "relu"), lay("ce1", ws.e1, ws.e, None), lay("head", ws.e, ws.mulv, None)], B)
-            ta = ops.FwdChain([lay("te0", segmat([seg(priv, 0, 693)]), ws.t1, "relu"), lay("te1", ws.t1, ws.t2, "relu"),
-                               lay("te2", ws.t2, ws.lt, None), lay("a0", self.actor_input(ws, obs), ws.a1, act),
-                               lay("a1", ws.a1, ws.a2, act), lay("a2", ws.a2, ws.a3, act), lay("a3", ws.a3, ws.mean, None)], B)
-            cr = None
-            if base_vel is not None:
-                cr = ops.FwdChain([lay("c0", self.critic_input(obs, base_vel, priv), ws.v1, act), lay("c1", ws.v1, ws.v2, act),
-                                   lay("c2", ws.v2, ws.v3, act), lay("c3", ws.v3, ws.val, None)], B)
-            ch = ws.chains = dict(ce=ce, ta=ta, cr=cr)
+            ch = ws.chains = {}
+        L, act, B = self.L, AC_Args.activation, ws.B
+        lay = lambda name, X, Y, a: (X, L[name].W, L[name].b, Y, a)
         if hist is not None:
+            if "ce" not in ch:
+                ch["ce"] = ops.FwdChain([lay("ce0", hist, ws.e1, "relu"), lay("ce1", ws.e1, ws.e, None),
+                                         lay("head", ws.e, ws.mulv, None)], B)
+                ch["ta"] = ops.FwdChain([lay("te0", segmat([seg(priv, 0, 693)]), ws.t1, "relu"), lay("te1", ws.t1, ws.t2, "relu"),
+                                         lay("te2", ws.t2, ws.lt, None), lay("a0", self.actor_input(ws, obs), ws.a1, act),
+                                         lay("a1", ws.a1, ws.a2, act), lay("a2", ws.a2, ws.a3, act), lay("a3", ws.a3, ws.mean, None)], B)
             ch["ce"].set_input(0, 0, hist)
             ch["ta"].set_input(0, 0, priv)
             ch["ta"].set_input(3, 0, obs)
         if base_vel is not None:
-            if ch["cr"] is None:
-                L, act = self.L, AC_Args.activation
-                lay = lambda name, X, Y, a: (X, L[name].W, L[name].b, Y, a)
+            if "cr" not in ch:
                 ch["cr"] = ops.FwdChain([lay("c0", self.critic_input(obs, base_vel, priv), ws.v1, act), lay("c1", ws.v1, ws.v2, act),
-                                         lay("c2", ws.v2, ws.v3, act), lay("c3", ws.v3, ws.val, None)], ws.B)
+                                         lay("c2", ws.v2, ws.v3, act), lay("c3", ws.v3, ws.val, None)], B)
             ch["cr"].set_input(0, 0, obs)
             ch["cr"].set_input(0, 1, base_vel)
             ch["cr"].set_input(0, 2, priv)

@@ -39,7 +39,7 @@ for s, e, n, q, g in step:
 for q, v in sorted(perq.items()):
     print(f"  queue {q}: kernel time {v / 1e6:8.3f} ms")
 # time with at least one 'wide' GEMM (grid >= 700 blocks) running
-wide = [(s, e) for s, e, n, q, g in step if g >= 700 and "linear_" in n]
+wide = [(s, e) for s, e, n, q, g in step if g >= 700 and ("linear_" in n or "wgrad_group_kernel" in n)]
 wide.sort()
 u, ce = 0, None
 for s, e in wide:
@@ -78,7 +78,7 @@ tot_gap = sum(e - s for s, e in gaps)
 print(f"  time with no wide GEMM in flight: {tot_gap / 1e6:.3f} ms in {len(gaps)} intervals")
 acc = collections.defaultdict(float)
 for s, e, n, q, g in step:
-    if g >= 700 and "linear_" in n:
+    if g >= 700 and ("linear_" in n or "wgrad_group_kernel" in n):
         continue
     for gs, ge in gaps:
         lo, hi = max(s, gs), min(e, ge)

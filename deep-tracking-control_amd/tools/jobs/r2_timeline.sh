@@ -3,5 +3,5 @@ mkdir -p gpurun_out/r2
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/r2/timeline
-timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/r2/timeline -o tl --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/r2/timeline.json 2> $R/gpurun_out/r2/timeline.err
+timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/r2/timeline -o tl --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic > $R/gpurun_out/r2/timeline.json 2> $R/gpurun_out/r2/timeline.err
 ls -la $R/gpurun_out/r2/timeline

@@ -484,6 +484,20 @@ def test_training_survives_model_to_calls():
             assert torch.equal(v, want[k]), (mode, k)
 
 
+def test_evaluate_before_any_act_and_chain_inputs_follow_the_caller():
+    """The rollout-side layer chains are built on first use: `evaluate` alone (compute_returns on a loaded storage, as
+    bench.py does) must work, and re-pointed inputs must be read from the tensors of the CURRENT call."""
+    from dtc_amd.modules import ActorCriticDecoder
+    torch.manual_seed(3)
+    ac = ActorCriticDecoder(53, 1389, 12).to(DEV)
+    d = S.rollout(128, 3, seed=2, device=DEV)
+    v0 = ac.evaluate(d["observations"][0], d["privileged_observations"][0], d["base_vel"][0])
+    ac.act(d["observations"][1], d["observation_histories"][1], d["privileged_observations"][1])
+    v2 = ac.evaluate(d["observations"][2], d["privileged_observations"][2], d["base_vel"][2])
+    v0b = ac.evaluate(d["observations"][0].clone(), d["privileged_observations"][0].clone(), d["base_vel"][0].clone())
+    assert torch.equal(v0, v0b) and not torch.equal(v0, v2)
+
+
 def test_graphed_rollout_step_matches_eager_kernels():
     """PPO.act replays the rollout-step kernels from a HIP graph: the value head (no random draw) must equal the eager
     launch bit for bit on fresh inputs at every replay, the sampled actions must be fresh draws with a consistent
