@@ -318,6 +318,132 @@ __global__ __launch_bounds__(256, OCC) void fwd_v2(const float* __restrict__ X, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ v3
+// 512-thread workgroups: waves w and w+4 share the 32 x 64 output sub-tile of rows 32w and split the stage's k range
+// (wave group 0 multiplies k-steps q = 0, group 1 q = 1), each into its own accumulators; after the K loop the two
+// groups swap halves through LDS, add them, and each of the 8 waves finishes ONE 32 x 32 tile.  A workgroup then has two
+// waves per SIMD: a workgroup that is alone on its CU (the tail of a launch) still overlaps its own loads / LDS
+// traffic with MFMAs of its other wave.
+template <int OCC>
+__global__ __launch_bounds__(512, OCC) void fwd_v3(const float* __restrict__ X, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, float* __restrict__ Y, int M, int N, int K) {
+    constexpr int BM = 128, BN = 64, BK = 16, TN = 2;
+    __shared__ f32x4 As[2][BM * 4];
+    __shared__ f32x4 Bs[2][BN * 4];
+    int tr, tc;
+    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, tr, tc)) return;
+    const int m0 = tr * BM, n0 = tc * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, wm_off = (wave & 3) * 32;
+    // loaders: 512 A chunks (one per thread), 256 B chunks (threads 0..255)
+    const int lrow = tid >> 2, lch = tid & 3;
+    const int am = m0 + lrow;
+    const u32 aoff = am < M ? (u32)(am * K + 4 * lch) * 4u : INVALID;
+    const int aslot = lrow * 4 + (lch ^ ((lrow >> 2) & 3));
+    const bool bthread = tid < 256;
+    const int bn_ = n0 + (lrow & 63);
+    const u32 woff = (bthread && bn_ < N) ? (u32)(bn_ * K + 4 * lch) * 4u : INVALID;
+    const int bslot = (lrow & 63) * 4 + (lch ^ (((lrow & 63) >> 2) & 3));
+    const rsrc_t ares = make_rsrc(X), wres = make_rsrc(W);
+    f32x4 ra, rb;
+    f32x16 acc[TN];
+    for (int j = 0; j < TN; ++j)
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int half = lane >> 5, l31 = lane & 31;
+    auto load = [&](int kt) {
+        const u32 ko = (u32)(kt * BK) * 4u;
+        ra = bload4(ares, aoff, ko);
+        rb = bload4(wres, woff, ko);
+    };
+    auto store = [&](int buf) {
+        As[buf][aslot] = ra;
+        if (bthread) Bs[buf][bslot] = rb;
+    };
+    const int arow = wm_off + l31;
+    const int asw = (arow >> 2) & 3;
+    auto mfma = [&](int buf) {               // this wave group's half of the stage: chunk 2*grp + half
+        const f32x4 a = As[buf][arow * 4 + ((2 * grp + half) ^ asw)];
+        f32x4 b[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int br = 32 * j + l31;
+            b[j] = Bs[buf][br * 4 + ((2 * grp + half) ^ ((br >> 2) & 3))];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[j][t], acc[j], 0, 0, 0);
+    };
+    const int KT = K / BK;                   // lab: K % 16 == 0 only
+    int buf = 0;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int kt = 1; kt < KT; ++kt) {
+        load(kt);
+        mfma(buf);
+        store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    mfma(buf);
+    __syncthreads();
+    // swap halves: group g keeps sub-tile j = g and hands sub-tile 1-g to its partner wave (4 KiB per wave)
+    float* xch = reinterpret_cast<float*>(&As[0][0]);           // 8 waves x 1024 floats = 32 KiB: As (16) + Bs (8) is too small -> two rounds
+    f32x16 mine = grp == 0 ? acc[0] : acc[1];
+    const f32x16 give = grp == 0 ? acc[1] : acc[0];
+    // round 1: group 1 -> group 0 ; round 2: group 0 -> group 1  (4 waves x 4 KiB = 16 KiB per round)
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const int giver = 1 - round;
+        if (grp == giver) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[(wave & 3) * 1024 + r * 64 + lane] = give[r];
+        }
+        __syncthreads();
+        if (grp != giver) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r] += xch[(wave & 3) * 1024 + r * 64 + lane];
+        }
+        __syncthreads();
+    }
+    const int j = grp;
+    const int col = n0 + 32 * j + l31;
+    const bool cok = col < N;
+    const float bv = cok ? bias[col] : 0.f;
+    if ((N & 3) == 0 && m0 + BM <= M && n0 + BN <= N) {
+        float* patch = xch + wave * (32 * 32);                  // 8 x 4 KiB = 32 KiB > As+Bs: use 2 rounds of 4 waves
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            if (grp == round) {
+                float* pp = xch + (wave & 3) * (32 * 32);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = mine[r] + bv;
+                    pp[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = v > 0.f ? v : 0.f;
+                }
+                const int prow = lane >> 3, pc4 = lane & 7;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = prow + 8 * p;
+                    *reinterpret_cast<f32x4*>(&Y[(long long)(m0 + wm_off + row) * N + n0 + 32 * j + 4 * pc4]) =
+                        *reinterpret_cast<const f32x4*>(&pp[row * 32 + 4 * pc4]);
+                }
+            }
+            __syncthreads();
+        }
+        (void)patch;
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm_off + 4 * half + (r & 3) + 8 * (r >> 2);
+        const float v = mine[r] + bv;
+        if (cok && row < M) Y[(long long)row * N + col] = v > 0.f ? v : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static void fill(std::vector<float>& h, unsigned long long seed, float scale) {
     unsigned long long st = seed;
@@ -572,6 +698,12 @@ int main(int argc, char** argv) {
                 report("v2 occ4 wide-st", timeit([&] { fwd_v2<64, 4, 3><<<grid_for(rt, (p.N + 63) / 64), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
                 hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
                 report("v2 occ6 wide-st", timeit([&] { fwd_v2<64, 6, 3><<<grid_for(rt, (p.N + 63) / 64), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                if (p.K % 16 == 0) {
+                    hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
+                    report("v3 512thr occ2", timeit([&] { fwd_v3<2><<<grid_for(rt, (p.N + 63) / 64), 512>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                    hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
+                    report("v3 512thr occ3", timeit([&] { fwd_v3<3><<<grid_for(rt, (p.N + 63) / 64), 512>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                }
                 for (int cap = 6; cap <= 6; ++cap) {         // blocks per CU capped through dynamic LDS: 160 KiB / cap - static 24 KiB
                     const int dyn = cap == 6 ? 0 : (160 * 1024 / cap - 24 * 1024 - 512) & ~255;
                     char tag[32];

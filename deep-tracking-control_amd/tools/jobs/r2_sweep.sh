@@ -2,7 +2,7 @@
 mkdir -p gpurun_out/r2
 V=$1; shift
 for x in "$@"; do
-  env $V=$x timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+  env $V=$x timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-traffic 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernel_classes']
