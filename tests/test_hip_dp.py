@@ -163,7 +163,7 @@ def test_four_ranks_with_different_seeds_converge_on_rank0_weights():
 
 def test_two_ranks_at_full_size_exchange_real_buckets():
     """K = 2 at BASELINE's 4096 envs per rank (mini-batches of 24576): the bucketed exchange at its real sizes
-    (7.4 MB / 11.5 MB of gradients per optimiser step), ranks bit-identical afterwards."""
+    (7.42 MB / 7.76 MB of gradients per VAE / policy optimiser step), ranks bit-identical afterwards."""
     out = _run(2, n_per_rank=4096, timeout=900)
     assert torch.equal(out[0]["flat"], out[1]["flat"]) and out[0]["lr"] == out[1]["lr"]
     assert torch.equal(out[0]["m"], out[1]["m"]) and torch.equal(out[0]["v"], out[1]["v"])
