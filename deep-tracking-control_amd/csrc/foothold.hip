@@ -4,11 +4,15 @@
 // several [N,693,4,3] repeats) by ONE kernel.  HBM-bound: 2772 B heights row + 116 B of state
 // in, 208 B out per env (3096 B/env).
 //
-// Mapping: one 64-lane wavefront per env, 4 envs per 256-thread workgroup.  The 4 height rows
+// Two kernels share the per-point arithmetic:
+//   * foothold_plan_fast_kernel  -- the reference's 33 x 21 grid without debug outputs (the hot path; see its header);
+//   * foothold_plan_kernel       -- any grid up to 64 x 32 and the debug outputs (score table, nominal index, slope).
+//
+// Generic kernel: one 64-lane wavefront per env, 4 envs per 256-thread workgroup.  The 4 height rows
 // of a workgroup are one contiguous, 16-byte aligned chunk of 4*P floats (P = nx*ny = 693),
 // so the workgroup streams it with float4 loads (16 B/lane, fully coalesced) into LDS; each
 // wave then works out of LDS:
-//   1. clamp -> mean / unbiased variance by lane-strided partial sums + xor-butterfly;
+//   1. clamp -> mean / unbiased variance: per-lane partial sums in the canonical order (below) + xor-butterfly;
 //   2. CANDIDATE WINDOW (fast path): a grid point can only win the argmin with a "valid" score
 //      (< 0.148) if it lies within 0.16 m of the leg's nominal foothold, i.e. inside a <= 7x7 cell
 //      patch around it.  Each leg therefore evaluates ONE 8x8 patch (64 lanes = 64 candidates:
@@ -26,7 +30,14 @@
 // the order of oracle/foothold.py + oracle/quat.py, so all outputs match the oracle bit for bit.
 // Division by the two grid-spacing constants uses q = fma(fma(-x*y, c, x), y, x*y) with y = 1/c,
 // which is bit-identical to IEEE x/c for every |x| in (1e-30, 1e30) (exhaustively verified for
-// c = 0.05f and 0.1f) and falls back to the IEEE division below that.
+// c = 0.05f and 0.1f).  Below 1e-30 the quotient may differ in its low bits, but the ONLY consumer of the
+// two quotients is dx*dx + dy*dy, and any |d| < 2^-75 (2.6e-23) squares to +0 in float32 either way -- so the
+// slope, and everything after it, is still bit-identical (round 1 branched to an IEEE division there).
+//
+// Canonical reduction order (mean / variance of the P clamped heights; oracle/foothold.py:wave_sum states the same):
+// lane k owns the float4 chunks q = k + 64 j (elements 4q .. 4q+3), keeps TWO running sums -- elements 0, 2 of every
+// chunk in one, elements 1, 3 in the other, chunks in ascending j (that is what a packed v_pk_add_f32 does) -- adds
+// the two, and the 64 lane sums are folded by the xor-butterfly of wave_sum().
 #include "common.hpp"
 #include "wave.hpp"
 
@@ -37,6 +48,10 @@ constexpr int ENVS_PER_BLOCK = 4;
 struct GridParams {
     int nx, ny, P;
     float t_half, k_fb;
+    // placement of the 8 x 8 candidate patch (uniform grids; used only to PLACE the patch): origin, cells per metre,
+    // search radius in cells + slack, and whether every in-radius cell fits into 8 consecutive cells
+    float x0, y0, inv_dx, inv_dy, rad_x, rad_y;
+    int patch_ok;
     float x[64];
     float y[32];
 };
@@ -70,17 +85,11 @@ __device__ __forceinline__ V3 quat_rotate_inverse(float qx, float qy, float qz, 
     return V3{(ax - bx) + ex, (ay - by) + ey, (az - bz) + ez};
 }
 
-// x / c, bit-identical to IEEE division (see header comment); inv = RN(1/c) (20.0f / 10.0f, exact)
+// x / c, bit-identical to IEEE division wherever it matters (see header comment); inv = RN(1/c) (20.0f / 10.0f, exact)
 __device__ __forceinline__ float div_const(float x, float c, float inv) {
     const float q0 = x * inv;
     const float r = __builtin_fmaf(-q0, c, x);
-    float q = __builtin_fmaf(r, inv, q0);
-    // tiny NON-ZERO numerators (never produced by heights quantised to 5 mm) take the IEEE division; the test is a
-    // wave-level vote so that the ~13-instruction division is branched over, not if-converted into every call.
-    // x = +-0 stays on the fast path: it yields +-0 / +0, which every consumer squares.
-    const bool tiny = fabsf(x) < 1e-30f && x != 0.0f;
-    if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) q = tiny ? x / c : q;
-    return q;
+    return __builtin_fmaf(r, inv, q0);
 }
 
 struct EnvCtx {            // wave-uniform per-env quantities
@@ -219,21 +228,38 @@ __global__ __launch_bounds__(256) void foothold_plan_kernel(
         predz[l] = (c.bz + hz) + symz;
     }
 
-    // ---- clamp + mean / unbiased variance (legged_robot_dtc.py:127-141)
-    float psum = 0.0f;
-    for (int i = lane; i < P; i += 64) {
-        const float v = rawE[i] - c.bz;
-        const float gc = fminf(fmaxf(v, -0.5f), 0.5f);
-        gE[i] = gc;
-        psum = psum + gc;
+    // ---- clamp + mean / unbiased variance (legged_robot_dtc.py:127-141), canonical order (header)
+    float se = 0.0f, so = 0.0f;
+    for (int q = lane; 4 * q < P; q += 64) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int i = 4 * q + cc;
+            float gc = 0.0f;
+            if (i < P) {
+                gc = fminf(fmaxf(rawE[i] - c.bz, -0.5f), 0.5f);
+                gE[i] = gc;
+            }
+            if (cc & 1) so = so + gc;
+            else se = se + gc;
+        }
     }
-    c.mean = wave_sum(psum) / (float)P;
-    float qsum = 0.0f;
-    for (int i = lane; i < P; i += 64) {
-        const float d = gE[i] - c.mean;
-        qsum = qsum + d * d;
+    c.mean = wave_sum(se + so) / (float)P;
+    se = 0.0f;
+    so = 0.0f;
+    for (int q = lane; 4 * q < P; q += 64) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int i = 4 * q + cc;
+            float dd = 0.0f;
+            if (i < P) {
+                const float d = gE[i] - c.mean;
+                dd = d * d;
+            }
+            if (cc & 1) so = so + dd;
+            else se = se + dd;
+        }
     }
-    const float var = wave_sum(qsum) / (float)(P - 1);
+    const float var = wave_sum(se + so) / (float)(P - 1);
     c.edge = fminf(fmaxf(sqrtf(var), 0.0f), 0.3f);
     __syncthreads();   // gE written by other lanes is read below
 
@@ -250,9 +276,7 @@ __global__ __launch_bounds__(256) void foothold_plan_kernel(
         // ---- fast path: one 8x8 candidate patch per leg
         const int wx = lane >> 3, wy = lane & 7;
         // grid spacing from the coordinate tables (uniform grids; used only to PLACE the patch)
-        const float x0 = xs[0], y0 = ys[0];
-        const float inv_dx = (float)(nx - 1) / (xs[nx - 1] - x0), inv_dy = (float)(ny - 1) / (ys[ny - 1] - y0);
-        const float rad_x = 0.16f * inv_dx + 0.05f, rad_y = 0.16f * inv_dy + 0.05f;   // radius in cells + slack
+        const float x0 = gp.x0, y0 = gp.y0, inv_dx = gp.inv_dx, inv_dy = gp.inv_dy, rad_x = gp.rad_x, rad_y = gp.rad_y;
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             // nominal foothold in the yaw frame of the grid: R(-yaw) * (pred - base)
@@ -261,7 +285,7 @@ __global__ __launch_bounds__(256) void foothold_plan_kernel(
             const float lx = cyaw * rx + syaw * ry, ly = -syaw * rx + cyaw * ry;
             const float u = (lx - x0) * inv_dx, v = (ly - y0) * inv_dy;
             // all in-radius cells have |iu - u| < rad: they fit in 8 consecutive cells iff 2*rad < 7
-            const bool fits = (2.0f * rad_x < 7.0f) && (2.0f * rad_y < 7.0f) && (fabsf(u) < 1e6f) && (fabsf(v) < 1e6f) &&
+            const bool fits = gp.patch_ok && (fabsf(u) < 1e6f) && (fabsf(v) < 1e6f) &&
                               ny >= 8;   // flat index must grow with the lane id inside the patch (see below)
             const int sx = (int)floorf(u - rad_x) + 1, sy = (int)floorf(v - rad_y) + 1;
             const int ix = sx + wx, iy = sy + wy;
@@ -369,6 +393,382 @@ __global__ __launch_bounds__(256) void foothold_plan_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast planner for the reference's grid (NX x NY = 33 x 21, no debug outputs).  Same results as the generic kernel, bit
+// for bit; built around the instruction count, because the planner is VALU-bound (round 1: ~1500 vector instructions per
+// env, 182 us for 98 304 envs against a 40 us HBM floor):
+//   * persistent launch: the grid is what fits on the chip at once; every wave owns a contiguous range of envs and
+//     walks it in groups of four;
+//   * per-env scalar algebra (Raibert heuristic, quaternion rotations, sin/cos, yaw quaternion, patch placement, the
+//     pred / pred_to_robot outputs) runs ONCE per group with lane = (env of the group, leg) instead of once per env with all
+//     64 lanes doing the same thing; the per-env values travel to the scoring loop through v_readlane;
+//   * the height row comes in with three unaligned 16-byte buffer loads per lane (row-bounded descriptor: the tail reads
+//     0), is clamped and reduced from registers with packed fp32 adds / multiplies, and is written to LDS once; the next
+//     env's row is requested before the current one is scored;
+//   * a leg's 8 x 8 candidate patch that lies strictly inside the grid (the usual case) takes a branch-free path: fixed
+//     LDS offsets for the four neighbours, the constant 0.1 divisor, both axes in packed arithmetic;
+//   * the decode (index, observation, world position) runs once per group on 16 lanes.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f3 __attribute__((ext_vector_type(3)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef unsigned u3 __attribute__((ext_vector_type(3)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// min over the wave of NON-NEGATIVE floats (or +inf / NaN): their bit patterns order like unsigned integers, and
+// v_min_u32 takes the DPP operand directly (fminf costs a canonicalising v_max per step)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ float wave_min_nonneg(float f) {
+    unsigned v = (unsigned)__float_as_int(f);
+    v = min(v, dpp_u<0xB1, 0xF>(v));
+    v = min(v, dpp_u<0x4E, 0xF>(v));
+    v = min(v, dpp_u<0x141, 0xF>(v));
+    v = min(v, dpp_u<0x140, 0xF>(v));
+    v = min(v, dpp_u<0x142, 0xA>(v));
+    v = min(v, dpp_u<0x143, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane((int)v, 63));
+}
+__device__ __forceinline__ float rlf(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// x / C for the two point-count constants: the same two-fma quotient as div_const (exact for 1e-30 <= |x| <= 1e30, all
+// four constants checked over all 2^32 inputs by tools/probes/div_const_exact.hip); x is wave-uniform here, so the range
+// test is a scalar branch to the IEEE division
+template <int C>
+__device__ __forceinline__ float div_count(float x) {
+    constexpr float c = (float)C, inv = 1.0f / (float)C;
+    const float ax = fabsf(x);
+    if (__builtin_amdgcn_readfirstlane(ax >= 1e-30f && ax <= 1e30f)) return div_const(x, c, inv);
+    return x / c;
+}
+
+// xor-butterfly sum with the partner order of wave_sum() (1, 2, 4, 8 by DPP) and the two cross-row steps by gfx950's
+// v_permlane16_swap / v_permlane32_swap (each lane adds the same two partial sums wave_sum() adds: bit-identical);
+// every lane returns the total
+__device__ __forceinline__ float wave_sum_all(float v) {
+    v = v + dpp_f<0xB1, 0xF>(0.f, v);
+    v = v + dpp_f<0x4E, 0xF>(0.f, v);
+    v = v + dpp_f<0x141, 0xF>(0.f, v);
+    v = v + dpp_f<0x140, 0xF>(0.f, v);
+    u2 r = __builtin_amdgcn_permlane16_swap((unsigned)__float_as_int(v), (unsigned)__float_as_int(v), false, false);
+    v = __int_as_float((int)r.x) + __int_as_float((int)r.y);
+    r = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(v), (unsigned)__float_as_int(v), false, false);
+    return __int_as_float((int)r.x) + __int_as_float((int)r.y);
+}
+
+#ifndef DTC_FH_WAVES
+#define DTC_FH_WAVES 5      // waves per SIMD the register allocator aims at (tuning aid)
+#endif
+constexpr int FAST_ENVS_PER_WAVE = 4, FAST_ENVS_PER_BLOCK = 16;
+
+template <int NX, int NY>
+__global__ __launch_bounds__(256, DTC_FH_WAVES) void foothold_plan_fast_kernel(
+    const float* __restrict__ mh, const float* __restrict__ root, const float* __restrict__ thigh,
+    const float* __restrict__ cmd, const GridParams gp, int64_t* __restrict__ idx_out, float* __restrict__ obs_out,
+    float* __restrict__ world_out, float* __restrict__ pred_out, float* __restrict__ p2r_out, int N) {
+    constexpr int P = NX * NY, NCH = (P + 255) / 256, RS = (P + 3) & ~3;
+    constexpr int PX = (NX + 7) / 8, PY = (NY + 7) / 8;                // 8 x 8 patches that tile the grid (fallback)
+    static_assert(NY >= 10 && NX >= 10, "the flat index must grow with the lane id inside a patch");
+    __shared__ __attribute__((aligned(16))) float rows[4][2][RS];      // per wave: clamped heights | measured heights
+    __shared__ float xs[64], ys[32];
+    typedef __attribute__((address_space(3))) float lds_f;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 64) xs[tid] = gp.x[tid];
+    else if (tid < 96) ys[tid - 64] = gp.y[tid - 64];
+    __syncthreads();
+    float* gE = rows[wave][0];
+    float* rawE = rows[wave][1];
+
+    // the four envs of this wave
+    const int g0 = (blockIdx.x * 4 + wave) * FAST_ENVS_PER_WAVE;
+    const int cnt = N - g0 < FAST_ENVS_PER_WAVE ? N - g0 : FAST_ENVS_PER_WAVE;
+    if (cnt <= 0) return;
+
+    const int wx = lane >> 3, wy = lane & 7, L0 = wx * NY + wy;
+    const unsigned g_lds = (unsigned)(unsigned long long)(lds_f*)gE, L0x4 = 4u * (unsigned)L0;
+    const int e_l = (lane & 15) >> 2, l_l = lane & 3;
+    // tail masks of the last chunk (elements >= P read 0 from the bounded descriptor but must not enter the sums)
+    bool tail_ok[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) tail_ok[cc] = 4 * (lane + 64 * (NCH - 1)) + cc < P;
+
+    auto load_row = [&](int n, f4 (&v)[NCH]) {
+        const rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mh + (long long)n * P), 0, P * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            v[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (lane + 64 * j) * 16, 0, 0));
+    };
+    f4 cur[NCH];
+    load_row(g0, cur);
+
+    // per-(env, leg) inputs and outputs go through bounded buffer descriptors: lane offset (constant) + wave offset
+    // (SGPR) -- no 64-bit per-lane addresses; lanes past N read 0 and never store
+    auto whole = [&](const void* ptr, int bytes_per_env) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)((unsigned)N * (unsigned)bytes_per_env), 0x00020000);
+    };
+    const rsrc_t r_root = whole(root, 52), r_cmd = whole(cmd, 16), r_thigh = whole(thigh, 48), r_idx = whole(idx_out, 32),
+                 r_obs = whole(obs_out, 32), r_world = whole(world_out, 48), r_pred = whole(pred_out, 48),
+                 r_p2r = whole(p2r_out, 48);
+    const int vo_root = e_l * 52, vo_cmd = e_l * 16, vo_leg = e_l * 48 + l_l * 12, vo_idx = e_l * 32 + l_l * 8,
+              vo_obs = e_l * 32 + l_l * 4;
+    auto ld1 = [](rsrc_t r, int vo, int so) { return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); };
+    auto ld3 = [](rsrc_t r, int vo, int so) { return __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(r, vo, so, 0)); };
+    auto ld4 = [](rsrc_t r, int vo, int so) { return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0)); };
+    auto st3 = [](rsrc_t r, int vo, int so, float x, float y, float z) {
+        __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u3, f3{x, y, z}), r, vo, so, 0);
+    };
+
+    // ================= per-(env, leg) algebra on lanes 0..15 (the other lanes mirror them)
+    const bool lane_valid = lane < 16 && e_l < cnt;
+    const f4 ra = ld4(r_root, vo_root, g0 * 52), rb = ld4(r_root, vo_root + 16, g0 * 52);
+    const f2 rc = {ld1(r_root, vo_root + 32, g0 * 52), ld1(r_root, vo_root + 36, g0 * 52)};
+    const float bx_l = ra.x, by_l = ra.y, bz_l = ra.z;
+    const float qx = ra.w, qy = rb.x, qz = rb.y, qw = rb.z;
+    const V3 vw{rb.w, rc.x, rc.y};
+    const f3 cm = ld3(r_cmd, vo_cmd, g0 * 16);
+    const float c0 = cm.x, c1 = cm.y, c2 = cm.z;
+    const f3 thv = ld3(r_thigh, vo_leg, g0 * 48);
+    const float th0 = thv.x, th1 = thv.y, th2 = thv.z;
+    // Raibert nominal foothold of this leg (legged_robot_dtc.py:100-120)
+    const V3 vb = quat_rotate_inverse(qx, qy, qz, qw, vw);
+    float sn, cs;
+    sincos_cw(c2, sn, cs);
+    const float symx = gp.t_half * vb.x + gp.k_fb * (vb.x - c0);
+    const float symy = gp.t_half * vb.y + gp.k_fb * (vb.y - c1);
+    const float symz = gp.t_half * vb.z + gp.k_fb * (vb.z - 0.0f);
+    const float hx0 = th0 - bx_l, hy0 = th1 - by_l, hz0 = th2 - bz_l;
+    const float rx = cs * hx0 + (-sn) * hy0;
+    const float ry = sn * hx0 + cs * hy0;
+    const float predx_l = (bx_l + rx) + symx;
+    const float predy_l = (by_l + ry) + symy;
+    const float predz_l = (bz_l + hz0) + symz;
+    // yaw-only attitude (math.py:8-12)
+    float nq = sqrtf(qz * qz + qw * qw);
+    nq = fmaxf(nq, 1e-9f);
+    const float zq_l = qz / nq, wq_l = qw / nq;
+    // 8 x 8 candidate patch: nominal foothold in the yaw frame of the grid, R(-yaw) * (pred - base)
+    int sx_l, sy_l;
+    {
+        const float prx = predx_l - bx_l, pry = predy_l - by_l;
+        const float cyaw = wq_l * wq_l - zq_l * zq_l, syaw = 2.0f * wq_l * zq_l;
+        const float lx = cyaw * prx + syaw * pry, ly = -syaw * prx + cyaw * pry;
+        const float u = (lx - gp.x0) * gp.inv_dx, v = (ly - gp.y0) * gp.inv_dy;
+        // all in-radius cells have |iu - u| < rad: they fit in 8 consecutive cells iff 2*rad < 7 (patch_ok, host)
+        const bool fits = gp.patch_ok && (fabsf(u) < 1e6f) && (fabsf(v) < 1e6f);
+        sx_l = fits ? (int)floorf(u - gp.rad_x) + 1 : -(1 << 20);
+        sy_l = fits ? (int)floorf(v - gp.rad_y) + 1 : -(1 << 20);
+    }
+    if (lane_valid) {
+        st3(r_pred, vo_leg, g0 * 48, predx_l, predy_l, predz_l);
+        const V3 pr = quat_rotate_inverse(qx, qy, qz, qw, V3{predx_l - bx_l, predy_l - by_l, predz_l - bz_l});
+        st3(r_p2r, vo_leg, g0 * 48, pr.x, pr.y, pr.z);
+    }
+
+    int my_bi = 0;
+    float my_z = 0.0f;
+    for (int e = 0; e < cnt; ++e) {
+        const int src = e * 4;
+        const float bx = rlf(bx_l, src), by = rlf(by_l, src), bz = rlf(bz_l, src);
+        const float zq = rlf(zq_l, src), wq = rlf(wq_l, src);
+
+        // ================= clamp + mean / unbiased variance from registers (legged_robot_dtc.py:127-141)
+        f4 g[NCH];
+        f2 acc = {0.0f, 0.0f};
+        const f2 bz2 = {bz, bz};
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const f2 lo = cur[j].xy - bz2, hi = cur[j].zw - bz2;
+            f4 v = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                v[cc] = __builtin_amdgcn_fmed3f(v[cc], -0.5f, 0.5f);
+                if (j == NCH - 1) v[cc] = tail_ok[cc] ? v[cc] : 0.0f;
+            }
+            g[j] = v;
+            acc = acc + v.xy;
+            acc = acc + v.zw;
+        }
+        const float mean = div_count<P>(wave_sum_all(acc.x + acc.y));
+        acc = f2{0.0f, 0.0f};
+        const f2 mean2 = {mean, mean};
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            f2 lo = g[j].xy - mean2, hi = g[j].zw - mean2;
+            if (j == NCH - 1) {
+                lo.x = tail_ok[0] ? lo.x : 0.0f;
+                lo.y = tail_ok[1] ? lo.y : 0.0f;
+                hi.x = tail_ok[2] ? hi.x : 0.0f;
+                hi.y = tail_ok[3] ? hi.y : 0.0f;
+            }
+            acc = acc + lo * lo;
+            acc = acc + hi * hi;
+        }
+        const float var = div_count<P - 1>(wave_sum_all(acc.x + acc.y));
+        const float edge = fminf(fmaxf(sqrt_rn(var), 0.0f), 0.3f);
+        const float edge02 = 0.2f * edge;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int q4 = 4 * (lane + 64 * j);
+            if (q4 < RS) {
+                *reinterpret_cast<f4*>(gE + q4) = g[j];
+                *reinterpret_cast<f4*>(rawE + q4) = cur[j];
+            }
+        }
+        if (e + 1 < cnt) load_row(g0 + e + 1, cur);          // next env's row travels while this one is scored
+
+        // ================= scoring of one 8 x 8 patch whose candidates and their four neighbours are all grid points
+        // (1 <= sx, sx + 8 <= NX - 1, same in y): fixed LDS offsets, the constant 0.1 divisor, both axes packed
+        auto score_interior = [&](int sx, int sy, float pxl, float pyl, float& tot, int& ii) {
+            const int sbase = __builtin_amdgcn_readfirstlane(sx * NY + sy);
+            ii = sbase + L0;
+            // LDS byte address of g[ii - NY]: uniform part + lane part, so that the neighbours, the centre and the
+            // measured height are immediate offsets of ONE address register
+            const unsigned pa = (unsigned)__builtin_amdgcn_readfirstlane((int)(g_lds + 4u * (unsigned)(sbase - NY))) + L0x4;
+            const lds_f* p = (const lds_f*)pa;
+            const f2 num = f2{p[2 * NY], p[NY + 1]} - f2{p[0], p[NY - 1]};
+            const f2 q0 = num * 10.0f;
+            const f2 r = fma2(-q0, f2{0.1f, 0.1f}, num);
+            const f2 dv = fma2(r, f2{10.0f, 10.0f}, q0);          // == num / 0.1f (div_const)
+            const f2 sq = dv * dv;
+            const float slope = sqrt_rn(sq.x + sq.y);
+            const float rough = fabsf(p[NY] - mean);
+            const float s_raw = (edge02 + slope) + 0.3f * rough;
+            const float s = s_raw < 0.1f ? s_raw : 10.0f;
+            const float rel = p[RS + NY] - bz;
+            const bool exc = (rel > 1.0f) | (rel < -1.0f);
+            const f2 pp = {xs[sx + wx], ys[sy + wy]};
+            const f2 t = (zq * pp.yx) * f2{-2.0f, 2.0f};          // t0 = -(zq*py)*2, t1 = (zq*px)*2
+            const f2 u = pp + wq * t;
+            const f2 z2 = zq * t.yx;                              // (zq*t1, zq*t0)
+            const f2 h = (u + f2{-z2.x, z2.y}) + f2{bx, by};
+            const f2 dd = f2{pxl, pyl} - h;
+            const f2 d2 = dd * dd;
+            float d = sqrt_rn(d2.x + d2.y);
+            d = d < 0.16f ? d : 10.0f;
+            tot = s * 0.2f + d * 0.8f;
+            tot = exc ? 10.0f : tot;
+        };
+        auto interior = [&](int sx, int sy) { return sx >= 1 && sx + 8 <= NX - 1 && sy >= 1 && sy + 8 <= NY - 1; };
+
+        // ================= usual case: the four candidate patches are interior.  Score them, then ONE butterfly for the four
+        // minima: totals are sums of non-negative terms, so their bit patterns order like unsigned integers; after the
+        // xor-1 step the legs are interleaved by lane parity, after the xor-2 step by lane & 3, and the remaining steps
+        // (rotations by 4 and 8 inside a row, row / half swaps) keep lane & 3: lane k < 4 ends with the minimum of leg k
+        bool fast4 = true;
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            fast4 &= interior(__builtin_amdgcn_readlane(sx_l, src + l), __builtin_amdgcn_readlane(sy_l, src + l));
+        unsigned need = 0xFu;                  // legs that still have to take the general path below
+        if (fast4) {
+            float tot[4];
+            int ii[4];
+            unsigned key[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const int sl = src + l;
+                score_interior(__builtin_amdgcn_readlane(sx_l, sl), __builtin_amdgcn_readlane(sy_l, sl), rlf(predx_l, sl),
+                               rlf(predy_l, sl), tot[l], ii[l]);
+                key[l] = (unsigned)__float_as_int(tot[l]);
+                key[l] = min(key[l], dpp_u<0xB1, 0xF>(key[l]));
+            }
+            unsigned kab = (lane & 1) ? key[1] : key[0], kcd = (lane & 1) ? key[3] : key[2];
+            kab = min(kab, dpp_u<0x4E, 0xF>(kab));
+            kcd = min(kcd, dpp_u<0x4E, 0xF>(kcd));
+            unsigned kk = (lane & 2) ? kcd : kab;
+            kk = min(kk, dpp_u<0x124, 0xF>(kk));                 // row_ror:4
+            kk = min(kk, dpp_u<0x128, 0xF>(kk));                 // row_ror:8
+            u2 sw = __builtin_amdgcn_permlane16_swap(kk, kk, false, false);
+            kk = min(sw.x, sw.y);
+            sw = __builtin_amdgcn_permlane32_swap(kk, kk, false, false);
+            kk = min(sw.x, sw.y);
+            need = 0u;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const float best = __int_as_float(__builtin_amdgcn_readlane((int)kk, l));
+                // the LOWEST lane holding the minimum (the flat index grows with the lane id inside a patch: lowest lane
+                // == lowest index == torch's tie rule)
+                const unsigned long long hit = __ballot(tot[l] == best);
+                const int srcl = hit ? __ffsll((long long)hit) - 1 : 0;
+                const int bwin = __builtin_amdgcn_readlane(ii[l], __builtin_amdgcn_readfirstlane(srcl));
+                // a "valid" winner of the candidate patch is the global argmin (see the generic kernel)
+                if (best < 1.0f) {
+                    if (lane == src + l) {
+                        my_bi = bwin;
+                        my_z = rawE[bwin];
+                    }
+                } else {
+                    need |= 1u << l;
+                }
+            }
+        }
+        // ================= general path (rare), one leg at a time: the candidate patch when it touches the border or lies
+        // outside the grid, and -- if it holds no valid candidate -- the PX x PY patches that tile the whole grid, i.e. the
+        // reference's full argmin (ties: lowest flat index)
+        for (int l = 0; need != 0u && l < 4; ++l) {
+            if (!((need >> l) & 1u)) continue;
+            const int sl = src + l;
+            const float pxl = rlf(predx_l, sl), pyl = rlf(predy_l, sl);
+            int sx = __builtin_amdgcn_readlane(sx_l, sl), sy = __builtin_amdgcn_readlane(sy_l, sl);
+            float best = __builtin_inff();
+            int bwin = 0x7fffffff;
+            for (int k = fast4 ? 0 : -1; k < PX * PY; ++k) {
+                if (k >= 0) {
+                    sx = (k / PY) * 8;
+                    sy = (k % PY) * 8;
+                }
+                float tot = __builtin_inff();
+                int ii = 0x7fffffff;
+                if (interior(sx, sy)) {
+                    score_interior(sx, sy, pxl, pyl, tot, ii);
+                } else {
+                    const int ix = sx + wx, iy = sy + wy;
+                    if (ix >= 0 && ix < NX && iy >= 0 && iy < NY) {
+                        ii = ix * NY + iy;
+                        const EnvCtx c{bx, by, bz, zq, wq, mean, edge, NX, NY};
+                        const PointEval pe = eval_point(c, rawE, gE, xs, ys, ii, ix, iy);
+                        float d;
+                        tot = total_score(pe, pxl, pyl, d);
+                    }
+                }
+                const float mn = wave_min_nonneg(tot);
+                const unsigned long long hit = __ballot(tot == mn);
+                const int srcl = hit ? __ffsll((long long)hit) - 1 : 0;
+                const int win = __builtin_amdgcn_readlane(ii, __builtin_amdgcn_readfirstlane(srcl));
+                if (mn < best || (mn == best && win < bwin)) {
+                    best = mn;
+                    bwin = win;
+                }
+                if (k < 0 && mn < 1.0f) break;          // valid winner of the candidate patch
+            }
+            if (bwin == 0x7fffffff) bwin = 0;
+            if (lane == sl) {
+                my_bi = bwin;
+                my_z = rawE[bwin];
+            }
+        }
+    }
+
+    // ================= decode (legged_robot_dtc.py:184-201) on lanes (env of the wave, leg)
+    if (lane_valid) {
+        const int bi = my_bi, yi = bi / NY, xi = bi - yi * NY;       // xi = idx % ny, yi = idx / ny
+        __builtin_amdgcn_raw_buffer_store_b64(u2{(unsigned)bi, 0u}, r_idx, vo_idx, g0 * 32, 0);
+        // the reference gathers the x table with the y-index and vice versa (sic); xi < ny, yi < nx
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(xs[xi < NX ? xi : xi % NX]), r_obs, vo_obs, g0 * 32, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ys[yi < NY ? yi : yi % NY]), r_obs, vo_obs + 16, g0 * 32, 0);
+        const float px = xs[yi], py = ys[xi];
+        const float t0 = -(zq_l * py) * 2.0f;
+        const float t1 = (zq_l * px) * 2.0f;
+        st3(r_world, vo_leg, g0 * 48, ((px + wq_l * t0) + (-(zq_l * t1))) + bx_l, ((py + wq_l * t1) + (zq_l * t0)) + by_l, my_z);
+    }
+}
+
 // LeggedRobot._get_heights (legged_robot.py:1279-1317): one thread per (env, grid point).
 __global__ __launch_bounds__(256) void get_heights_kernel(const int16_t* __restrict__ hs, int rows, int cols,
                                                           const float* __restrict__ root, const GridParams gp,
@@ -435,6 +835,13 @@ int make_params(const DtcGridCfg* cfg, GridParams& gp) {
     gp.k_fb = cfg->fdbk_gain;
     for (int i = 0; i < 64; ++i) gp.x[i] = i < cfg->nx ? cfg->x[i] : 0.f;
     for (int i = 0; i < 32; ++i) gp.y[i] = i < cfg->ny ? cfg->y[i] : 0.f;
+    gp.x0 = gp.x[0];
+    gp.y0 = gp.y[0];
+    gp.inv_dx = (float)(gp.nx - 1) / (gp.x[gp.nx - 1] - gp.x0);
+    gp.inv_dy = (float)(gp.ny - 1) / (gp.y[gp.ny - 1] - gp.y0);
+    gp.rad_x = 0.16f * gp.inv_dx + 0.05f;
+    gp.rad_y = 0.16f * gp.inv_dy + 0.05f;
+    gp.patch_ok = (2.0f * gp.rad_x < 7.0f) && (2.0f * gp.rad_y < 7.0f) ? 1 : 0;
     return DTC_OK;
 }
 
@@ -466,6 +873,16 @@ extern "C" int dtc_foothold_plan(const float* measured_heights, const float* roo
     const int grid = (int)dtc::ceil_div(N, ENVS_PER_BLOCK);
     const double bytes = (double)N * (gp.P * 4.0 + 13 * 4 + 4 * 4 + 12 * 4 + 32 + 32 + 48 + 96);
     const bool debug = score_or_null || nominal_idx_or_null || slope_or_null || heights_world_or_null;
+    if (!debug && gp.nx == 33 && gp.ny == 21 && !getenv("DTC_PLANNER_GENERIC")) {
+        // four envs per wave, 16 per workgroup (a persistent split measured slower: without new workgroups to backfill, the
+        // chip drains unevenly); the descriptors of the per-env arrays need N * 52 bytes < 4 GiB
+        DTC_REQUIRE(N <= 40000000, "N too large for the 32-bit buffer offsets of the planner");
+        const int fgrid = (int)dtc::ceil_div((int64_t)N, FAST_ENVS_PER_BLOCK);
+        dtc::ProfScope prof("foothold_plan", bytes, s);
+        hipLaunchKernelGGL((foothold_plan_fast_kernel<33, 21>), dim3(fgrid), dim3(256), 0, s, measured_heights, root_states,
+                           thigh_pos, commands, gp, idx, foothold_obs, opt_world, pred, pred_to_robot, N);
+        return dtc::check_launch("foothold_plan");
+    }
     const bool vec = dtc::aligned16(measured_heights);
     dtc::ProfScope prof(debug ? "foothold_plan_debug" : "foothold_plan", bytes, s);
 #define DTC_FH_ARGS grid, lds, s, measured_heights, root_states, thigh_pos, commands, gp, idx, foothold_obs, opt_world, \

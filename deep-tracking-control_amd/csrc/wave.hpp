@@ -32,4 +32,21 @@ __device__ __forceinline__ float wave_min(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Correctly rounded sqrtf for the hot path.  hipcc's expansion of sqrtf (-fhip-fp32-correctly-rounded-divide-sqrt) is
+// v_sqrt_f32 + "try the two neighbours, keep the one whose residual changes sign" wrapped in a 2^32 pre-scale for
+// x < 2^-96 and a zero / inf fix-up (16 instructions).  This is the same core without the wrapper (10): the residual
+// test is exact for every x >= 2^-96 and leaves +-0, +inf, NaN and negative inputs as v_sqrt_f32 returns them (all
+// comparisons against the NaN residuals are false); a wave in which ANY lane holds a non-zero |x| < 2^-96 takes the
+// compiler's sqrtf instead.  tools/probes/sqrt_exact.hip checks all 2^32 inputs against sqrtf on the device.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    const unsigned xb = (unsigned)__float_as_int(x);
+    if (__builtin_amdgcn_ballot_w64((xb << 1) - 2u < (0x0F800000u << 1) - 2u) != 0ull) return sqrtf(x);   // 0 < |x| < 2^-96
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+    const float em = __builtin_fmaf(-sm, s, x), ep = __builtin_fmaf(-sp, s, x);
+    float r = em <= 0.0f ? sm : s;
+    r = ep > 0.0f ? sp : r;
+    return r;
+}
+
 }  // namespace

@@ -13,7 +13,7 @@ Constants: legged_robot_config.py:210 (dt), lite3_dtc_config.py:109 (decimation)
 Canonical operation order.  The reference's own result is insensitive to the reduction order
 of the two per-env reductions (mean / var of 693 values; SURVEY.md F5: three orders gave
 identical indices on 32768/32768 cases), so this oracle FIXES the order to the one the HIP
-kernel uses -- 64 lane-strided partial sums (i = lane + 64*j, ascending j) followed by an
+kernels use -- per lane two running sums over its float4 chunks (see wave_sum) followed by an
 xor-butterfly (offsets 1,2,4,8,16,32 = the kernel's DPP quad / half-row / row / cross-row steps) -- and every other operation is a single correctly
 rounded float32 op in reference order.  The HIP kernel is therefore expected to agree with
 this file BIT FOR BIT on every output; this file in turn is pinned against the imported
@@ -29,14 +29,23 @@ _BFLY = [np.arange(64) ^ o for o in (1, 2, 4, 8, 16, 32)]
 
 
 def wave_sum(v, valid=None):
-    """Sum over the last axis (693) in the kernel's order.  v [N,693] float32."""
+    """Sum over the last axis (693) in the kernel's canonical order.  v [N,693] float32.
+    Lane k owns the float4 chunks q = k + 64 j (elements 4q .. 4q+3, zero past 693) and keeps two running sums --
+    elements 0, 2 of every chunk in one, elements 1, 3 in the other (a packed add), chunks in ascending j, both
+    starting from +0 -- adds the two, and the 64 lane sums are folded by the xor-butterfly."""
     n = v.shape[0]
-    pad = np.zeros((n, 704), dtype=F)
+    nch = (NP + 255) // 256
+    pad = np.zeros((n, nch * 256), dtype=F)
     pad[:, :NP] = v
-    lanes = pad.reshape(n, 11, 64)
-    p = lanes[:, 0, :].copy()
-    for j in range(1, 11):
-        p = p + lanes[:, j, :]
+    ch = pad.reshape(n, nch, 64, 4)
+    se = np.zeros((n, 64), dtype=F)
+    so = np.zeros((n, 64), dtype=F)
+    for j in range(nch):
+        se = se + ch[:, j, :, 0]
+        so = so + ch[:, j, :, 1]
+        se = se + ch[:, j, :, 2]
+        so = so + ch[:, j, :, 3]
+    p = se + so
     for perm in _BFLY:
         p = p + p[:, perm]
     return p[:, 0]

@@ -45,11 +45,63 @@ def test_scorer_bit_exact_vs_oracle(N):
     _assert_scorer_equal(o, h)
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 7, 257, 4096, 5003])
+def test_scorer_fast_kernel_bit_exact_vs_oracle(N):
+    """Without debug outputs the 33 x 21 grid takes the persistent fast kernel (wave-owned env ranges, groups of 4)."""
+    o, h = _scorer_case(S.scorer_inputs(N, seed=11 + N), debug=False)
+    _assert_scorer_equal(o, h, debug=False)
+
+
+def _stress_inputs(kind, N=3072, seed=21):
+    inp = S.scorer_inputs(N, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    if kind == "border":          # fast base velocities / commands push the nominal footholds to and past the grid border
+        inp["root_states"][:, 7:10] *= 12.0
+        inp["commands"][:, :2] *= 8.0
+        inp["thigh_pos"][:, :, :2] += 0.5 * (torch.rand(N, 4, 2, generator=g) - 0.5)
+    elif kind == "rough":         # large random steps: most candidates are invalid (slope / roughness), many full scans
+        inp["measured_heights"] += 0.25 * (torch.rand(N, 693, generator=g) - 0.5) * (torch.rand(N, 1, generator=g) < 0.5)
+    elif kind == "exceptions":    # heights more than 1 m off the base: the exception mask decides
+        far = torch.rand(N, 693, generator=g) < 0.4
+        inp["measured_heights"] = torch.where(far, inp["measured_heights"] + 3.0, inp["measured_heights"])
+    elif kind == "flat":          # perfectly flat: slope 0 everywhere, exact ties resolved by the lowest index
+        inp["measured_heights"] = (inp["root_states"][:, 2:3] - 0.3).expand(N, 693).contiguous()
+    return {k: v.contiguous() for k, v in inp.items()}
+
+
+@pytest.mark.parametrize("kind", ["border", "rough", "exceptions", "flat"])
+def test_scorer_fast_kernel_stress_cases(kind):
+    """Patches on / outside the grid border, envs without a valid candidate (grid-tiling fallback), exception masks and
+    exact ties: fast kernel == oracle == generic kernel (debug call), bit for bit."""
+    inp = _stress_inputs(kind)
+    o, h = _scorer_case(inp, debug=False)
+    _assert_scorer_equal(o, h, debug=False)
+    _, hd = _scorer_case(inp, debug=True)
+    for k in ("optimal_foothold_indice", "foothold_obs", "optimal_footholds_world", "pred_footholds", "pred_footholds_to_robot"):
+        assert torch.equal(h[k], hd[k]), k
+    if kind == "rough":           # the fallback really ran: some winners are not "valid" totals
+        tot = torch.gather(hd["foothold_score"], 1, hd["optimal_foothold_indice"].expand(-1, 1, 4)).squeeze(1)
+        assert int((tot >= 1.0).sum()) > 0
+
+
+def test_scorer_fast_equals_generic_at_bench_size(monkeypatch):
+    from dtc_amd import foothold
+    big = {k: v.to(DEV) for k, v in S.scorer_inputs(98304, seed=7).items()}
+    fast = foothold.plan(big["measured_heights"], big["root_states"], big["thigh_pos"], big["commands"])
+    monkeypatch.setenv("DTC_PLANNER_GENERIC", "1")
+    gen = foothold.plan(big["measured_heights"], big["root_states"], big["thigh_pos"], big["commands"])
+    torch.cuda.synchronize()
+    for k in ("optimal_foothold_indice", "foothold_obs", "optimal_footholds_world", "pred_footholds", "pred_footholds_to_robot"):
+        assert torch.equal(fast[k], gen[k]), k
+
+
 def test_scorer_edge_cases_bit_exact():
     from test_oracle_golden import scorer_edge_inputs
     o, h = _scorer_case(scorer_edge_inputs())
     _assert_scorer_equal(o, h)
     assert (_np(h["optimal_foothold_indice"])[0:8] == 0).all()
+    o, h = _scorer_case(scorer_edge_inputs(), debug=False)        # the fast kernel on the same cases
+    _assert_scorer_equal(o, h, debug=False)
 
 
 def test_scorer_matches_reference_golden(golden):
