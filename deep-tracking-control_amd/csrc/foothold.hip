@@ -413,6 +413,7 @@ typedef float f3 __attribute__((ext_vector_type(3)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 typedef unsigned u3 __attribute__((ext_vector_type(3)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -467,11 +468,21 @@ __device__ __forceinline__ float wave_sum_all(float v) {
 #endif
 constexpr int FAST_ENVS_PER_WAVE = 4, FAST_ENVS_PER_BLOCK = 16;
 
-template <int NX, int NY>
-__global__ __launch_bounds__(256, DTC_FH_WAVES) void foothold_plan_fast_kernel(
-    const float* __restrict__ mh, const float* __restrict__ root, const float* __restrict__ thigh,
-    const float* __restrict__ cmd, const GridParams gp, int64_t* __restrict__ idx_out, float* __restrict__ obs_out,
-    float* __restrict__ world_out, float* __restrict__ pred_out, float* __restrict__ p2r_out, int N) {
+// terrain table of LeggedRobot._get_heights (legged_robot.py:1279-1317) for the fused variant (TABLE = true): the kernel
+// samples the int16 height field itself, writes the measured heights out (the observations need them) and plans from
+// the registers it just filled -- one launch and no read-back of the [N, P] matrix
+struct TableParams {
+    const int16_t* hs;
+    int rows, cols;
+    float border, hscale, vscale;
+};
+
+template <int NX, int NY, bool TABLE>
+__global__ __launch_bounds__(256, TABLE ? 3 : DTC_FH_WAVES) void foothold_plan_fast_kernel(
+    float* __restrict__ mh, const float* __restrict__ root, const float* __restrict__ thigh,
+    const float* __restrict__ cmd, const GridParams gp, const TableParams tp, int64_t* __restrict__ idx_out,
+    float* __restrict__ obs_out, float* __restrict__ world_out, float* __restrict__ pred_out, float* __restrict__ p2r_out,
+    int N) {
     constexpr int P = NX * NY, NCH = (P + 255) / 256, RS = (P + 3) & ~3;
     constexpr int PX = (NX + 7) / 8, PY = (NY + 7) / 8;                // 8 x 8 patches that tile the grid (fallback)
     static_assert(NY >= 10 && NX >= 10, "the flat index must grow with the lane id inside a patch");
@@ -500,13 +511,59 @@ __global__ __launch_bounds__(256, DTC_FH_WAVES) void foothold_plan_fast_kernel(
     for (int cc = 0; cc < 4; ++cc) tail_ok[cc] = 4 * (lane + 64 * (NCH - 1)) + cc < P;
 
     auto load_row = [&](int n, f4 (&v)[NCH]) {
-        const rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mh + (long long)n * P), 0, P * 4, 0x00020000);
+        const rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(mh + (long long)n * P, 0, P * 4, 0x00020000);
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
             v[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (lane + 64 * j) * 16, 0, 0));
     };
+    // TABLE: lane k samples the grid points of its chunks (the same float32 operations, in the same order, as
+    // get_heights_kernel), keeps them as the row and writes them to the measured-heights matrix
+    auto sample_row = [&](int n, float bx, float by, float zq, float wq, f4 (&v)[NCH]) {
+        const rsrc_t r_hs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(tp.hs), 0, tp.rows * tp.cols * 2, 0x00020000);
+        const rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(mh + (long long)n * P, 0, P * 4, 0x00020000);
+        const bool fast_div = tp.hscale == 0.05f || tp.hscale == 0.1f;      // constants covered by div_const_exact.hip
+        const float inv = 1.0f / tp.hscale;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int i = 4 * (lane + 64 * j) + cc;
+                const int ix = i / NY, iy = i - ix * NY;
+                const float px = xs[ix & 63], py = ys[iy];
+                const float t0 = -(zq * py) * 2.0f;
+                const float t1 = (zq * px) * 2.0f;
+                const float ax = (((px + wq * t0) + (-(zq * t1))) + bx) + tp.border;
+                const float ay = (((py + wq * t1) + (zq * t0)) + by) + tp.border;
+                float qx = div_const(ax, tp.hscale, inv), qy = div_const(ay, tp.hscale, inv);
+                // outside the verified range of div_const (and for any other scale) take the IEEE quotient; below 1e-30 both
+                // quotients truncate to 0
+                if (__builtin_amdgcn_ballot_w64(!fast_div || fabsf(ax) > 1e30f || fabsf(ay) > 1e30f) != 0ull) {
+                    qx = ax / tp.hscale;
+                    qy = ay / tp.hscale;
+                }
+                long long cx = (long long)qx, cy = (long long)qy;        // .long(): truncation toward zero
+                cx = cx < 0 ? 0 : (cx > tp.rows - 2 ? tp.rows - 2 : cx);
+                cy = cy < 0 ? 0 : (cy > tp.cols - 2 ? tp.cols - 2 : cy);
+                const int o = ((int)cx * tp.cols + (int)cy) * 2;
+                const int16_t h1 = (int16_t)__builtin_amdgcn_raw_buffer_load_b16(r_hs, o, 0, 0);
+                const int16_t h2 = (int16_t)__builtin_amdgcn_raw_buffer_load_b16(r_hs, o + tp.cols * 2, 0, 0);
+                const int16_t h3 = (int16_t)__builtin_amdgcn_raw_buffer_load_b16(r_hs, o + 2, 0, 0);
+                int16_t h = h1 < h2 ? h1 : h2;
+                h = h < h3 ? h : h3;
+                v[j][cc] = i < P ? (float)h * tp.vscale : 0.0f;          // past the row: what the bounded load returns
+            }
+            if (4 * (lane + 64 * j) + 3 < P) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v[j]), r_out, (lane + 64 * j) * 16, 0, 0);
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    if (4 * (lane + 64 * j) + cc < P)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v[j][cc]), r_out, (lane + 64 * j) * 16 + 4 * cc, 0, 0);
+            }
+        }
+    };
     f4 cur[NCH];
-    load_row(g0, cur);
+    if (!TABLE) load_row(g0, cur);
 
     // per-(env, leg) inputs and outputs go through bounded buffer descriptors: lane offset (constant) + wave offset
     // (SGPR) -- no 64-bit per-lane addresses; lanes past N read 0 and never store
@@ -577,6 +634,7 @@ __global__ __launch_bounds__(256, DTC_FH_WAVES) void foothold_plan_fast_kernel(
         const int src = e * 4;
         const float bx = rlf(bx_l, src), by = rlf(by_l, src), bz = rlf(bz_l, src);
         const float zq = rlf(zq_l, src), wq = rlf(wq_l, src);
+        if (TABLE) sample_row(g0 + e, bx, by, zq, wq, cur);
 
         // ================= clamp + mean / unbiased variance from registers (legged_robot_dtc.py:127-141)
         f4 g[NCH];
@@ -621,7 +679,7 @@ __global__ __launch_bounds__(256, DTC_FH_WAVES) void foothold_plan_fast_kernel(
                 *reinterpret_cast<f4*>(rawE + q4) = cur[j];
             }
         }
-        if (e + 1 < cnt) load_row(g0 + e + 1, cur);          // next env's row travels while this one is scored
+        if (!TABLE && e + 1 < cnt) load_row(g0 + e + 1, cur);          // next env's row travels while this one is scored
 
         // ================= scoring of one 8 x 8 patch whose candidates and their four neighbours are all grid points
         // (1 <= sx, sx + 8 <= NX - 1, same in y): fixed LDS offsets, the constant 0.1 divisor, both axes packed
@@ -879,8 +937,9 @@ extern "C" int dtc_foothold_plan(const float* measured_heights, const float* roo
         DTC_REQUIRE(N <= 40000000, "N too large for the 32-bit buffer offsets of the planner");
         const int fgrid = (int)dtc::ceil_div((int64_t)N, FAST_ENVS_PER_BLOCK);
         dtc::ProfScope prof("foothold_plan", bytes, s);
-        hipLaunchKernelGGL((foothold_plan_fast_kernel<33, 21>), dim3(fgrid), dim3(256), 0, s, measured_heights, root_states,
-                           thigh_pos, commands, gp, idx, foothold_obs, opt_world, pred, pred_to_robot, N);
+        hipLaunchKernelGGL((foothold_plan_fast_kernel<33, 21, false>), dim3(fgrid), dim3(256), 0, s,
+                           const_cast<float*>(measured_heights), root_states, thigh_pos, commands, gp, TableParams{}, idx,
+                           foothold_obs, opt_world, pred, pred_to_robot, N);
         return dtc::check_launch("foothold_plan");
     }
     const bool vec = dtc::aligned16(measured_heights);
@@ -910,6 +969,37 @@ extern "C" int dtc_get_heights(const int16_t* height_samples, int rows, int cols
     hipLaunchKernelGGL(get_heights_kernel, dim3((unsigned)dtc::ceil_div(total, 256)), dim3(256), 0, s, height_samples,
                        rows, cols, root_states, gp, border_size, horizontal_scale, vertical_scale, measured_heights, N);
     return dtc::check_launch("get_heights");
+}
+
+extern "C" int dtc_foothold_plan_from_table(const int16_t* height_samples, int rows, int cols, float border_size,
+                                            float horizontal_scale, float vertical_scale, const float* root_states,
+                                            const float* thigh_pos, const float* commands, const DtcGridCfg* cfg,
+                                            float* measured_heights, int64_t* idx, float* foothold_obs, float* opt_world,
+                                            float* pred, float* pred_to_robot, int N, void* stream) {
+    GridParams gp;
+    int rc = make_params(cfg, gp);
+    if (rc != DTC_OK) return rc;
+    DTC_REQUIRE(N >= 0 && rows >= 2 && cols >= 2, "bad shape");
+    if (N == 0) return DTC_OK;
+    DTC_REQUIRE(height_samples && root_states && thigh_pos && commands && measured_heights, "null pointer");
+    DTC_REQUIRE(idx && foothold_obs && opt_world && pred && pred_to_robot, "null output");
+    if (gp.nx != 33 || gp.ny != 21 || (int64_t)rows * cols >= (1ll << 30) || getenv("DTC_PLANNER_GENERIC")) {
+        // any other grid: the two launches the fused kernel replaces
+        rc = dtc_get_heights(height_samples, rows, cols, root_states, cfg, border_size, horizontal_scale, vertical_scale,
+                             measured_heights, N, stream);
+        if (rc != DTC_OK) return rc;
+        return dtc_foothold_plan(measured_heights, root_states, thigh_pos, commands, cfg, idx, foothold_obs, opt_world, pred,
+                                 pred_to_robot, nullptr, nullptr, nullptr, nullptr, N, stream);
+    }
+    DTC_REQUIRE(N <= 40000000, "N too large for the 32-bit buffer offsets of the planner");
+    hipStream_t s = (hipStream_t)stream;
+    const double bytes = (double)N * (gp.P * 4.0 + 13 * 4 + 4 * 4 + 12 * 4 + 32 + 32 + 48 + 96);
+    dtc::ProfScope prof("foothold_plan_from_table", bytes, s);
+    const TableParams tp{height_samples, rows, cols, border_size, horizontal_scale, vertical_scale};
+    hipLaunchKernelGGL((foothold_plan_fast_kernel<33, 21, true>), dim3((unsigned)dtc::ceil_div((int64_t)N, FAST_ENVS_PER_BLOCK)),
+                       dim3(256), 0, s, measured_heights, root_states, thigh_pos, commands, gp, tp, idx, foothold_obs,
+                       opt_world, pred, pred_to_robot, N);
+    return dtc::check_launch("foothold_plan_from_table");
 }
 
 extern "C" int dtc_foothold_rewards(const float* foot_positions, const float* opt_world, const uint8_t* contact,

@@ -79,6 +79,9 @@ _SIGS = {
     "dtc_foothold_rewards": (C.c_int, [c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, C.c_int, c_stream]),
     "dtc_get_heights": (C.c_int, [c_i16p, C.c_int, C.c_int, c_f32p, C.POINTER(DtcGridCfg), C.c_float, C.c_float,
                                   C.c_float, c_f32p, C.c_int, c_stream]),
+    "dtc_foothold_plan_from_table": (C.c_int, [c_i16p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, c_f32p, c_f32p,
+                                               c_f32p, C.POINTER(DtcGridCfg), c_f32p, c_i64p] + [c_f32p] * 4 +
+                                     [C.c_int, c_stream]),
     "dtc_compute_observations": (C.c_int, [c_f32p] * 11 + [C.c_int64] + [c_f32p] * 4 + [C.POINTER(DtcObsCfg)] +
                                  [c_f32p] * 3 + [C.c_int, c_stream]),
     "dtc_check_termination": (C.c_int, [c_f32p, C.c_int, c_i32p, C.c_int, c_i64p, C.c_int64, c_f32p, c_f32p, c_f32p,

@@ -3,8 +3,9 @@
 `plan(...)` returns exactly the attributes the reference block writes on `self`
 (pred_footholds, pred_footholds_to_robot, optimal_foothold_indice, foothold_obs,
 optimal_footholds_world and, on request, foothold_score / nominal_footholds_indice / slope /
-heights_world), computed by ONE fused HIP kernel (csrc/foothold.hip).  `patch_env(env)` shows
-the one-line integration into an env's `post_physics_step`.
+heights_world), computed by ONE fused HIP kernel (csrc/foothold.hip); `plan_from_table(...)` additionally samples the
+terrain height field (`_get_heights`) inside the same launch.  `patch_env(env)` shows the one-line integration into an
+env's `post_physics_step`.
 """
 from __future__ import annotations
 
@@ -97,6 +98,35 @@ def get_heights(height_samples: torch.Tensor, root_states: torch.Tensor, grid: G
                                     _ffi.stream())
     _ffi.check(rc, "dtc_get_heights")
     return out
+
+
+def plan_from_table(height_samples: torch.Tensor, root_states: torch.Tensor, thigh_pos: torch.Tensor,
+                    commands: torch.Tensor, grid: GridConfig | None = None, border_size: float = 20.0,
+                    horizontal_scale: float = 0.05, vertical_scale: float = 0.005) -> dict:
+    """`_get_heights` (legged_robot.py:1279-1317) + the foothold block (legged_robot_dtc.py:98-201) in ONE launch: the
+    planner samples the int16 terrain table itself and also returns `measured_heights` [N,P] for the observations.
+    Same results as `get_heights(...)` followed by `plan(...)`, bit for bit."""
+    grid = grid or GridConfig()
+    assert height_samples.dtype == torch.int16 and height_samples.dim() == 2
+    N, dev = root_states.shape[0], root_states.device
+    rs = root_states.contiguous()
+    th = thigh_pos.contiguous()
+    cmd = commands.contiguous()
+    if rs.shape != (N, 13) or th.shape != (N, 4, 3) or cmd.shape[0] != N or cmd.shape[1] < 3:
+        raise ValueError("bad input shapes")
+    cmd = cmd[:, :4].contiguous() if cmd.shape[1] >= 4 else torch.nn.functional.pad(cmd, (0, 4 - cmd.shape[1]))
+    mh = torch.empty(N, grid.num_points, dtype=torch.float32, device=dev)
+    idx = torch.empty(N, 1, 4, dtype=torch.int64, device=dev)
+    obs = torch.empty(N, 8, dtype=torch.float32, device=dev)
+    world, pred, p2r = (torch.empty(N, 4, 3, dtype=torch.float32, device=dev) for _ in range(3))
+    hs = height_samples.contiguous()
+    rc = _ffi.lib().dtc_foothold_plan_from_table(_ffi.cptr(hs), hs.shape[0], hs.shape[1], border_size, horizontal_scale,
+                                                 vertical_scale, _ffi.cptr(rs, torch.float32), _ffi.cptr(th, torch.float32),
+                                                 _ffi.cptr(cmd, torch.float32), grid.c_struct(), _ffi.ptr(mh), _ffi.ptr(idx),
+                                                 _ffi.ptr(obs), _ffi.ptr(world), _ffi.ptr(pred), _ffi.ptr(p2r), N, _ffi.stream())
+    _ffi.check(rc, "dtc_foothold_plan_from_table")
+    return dict(measured_heights=mh, optimal_foothold_indice=idx, foothold_obs=obs,
+                optimal_footholds_world=world, pred_footholds=pred, pred_footholds_to_robot=p2r)
 
 
 def rewards(foot_positions: torch.Tensor, optimal_footholds_world: torch.Tensor, contact_filt: torch.Tensor):
@@ -198,5 +228,18 @@ def patch_env(env, grid: GridConfig | None = None):
             setattr(env, k, v)
         return out
 
+    def measure_and_plan_footholds():
+        """`self.measured_heights = self._get_heights()` (legged_robot.py:388 / :1279-1317) and the foothold block in one
+        launch; for terrains with a height field (`env.height_samples`, `env.terrain.cfg`)."""
+        thigh = env.rigid_body_state.view(env.num_envs, env.num_bodies, 13)[:, env.thigh_indices, 0:3]
+        tc = env.terrain.cfg
+        out = plan_from_table(env.height_samples, env.root_states, thigh, env.commands, grid, tc.border_size,
+                              tc.horizontal_scale, tc.vertical_scale)
+        env.hip_positions = thigh
+        for k, v in out.items():
+            setattr(env, k, v)
+        return out
+
     env.plan_footholds = plan_footholds
+    env.measure_and_plan_footholds = measure_and_plan_footholds
     return env

@@ -8,7 +8,7 @@ if [ "${PROBES:-1}" = "1" ]; then
 /opt/rocm/bin/hipcc $F tools/probes/div_const_exact.hip -o /tmp/pb/div_const_exact 2>/dev/null && timeout 300 /tmp/pb/div_const_exact | tee $R/gpurun_out/r2/div_const_exact.txt
 fi
 cd $R
-timeout 1200 python -m pytest tests/test_hip_kernels.py -m gpu -x -q -k "scorer or heights or foothold" 2>&1 | tail -15 | tee gpurun_out/r2/planner_tests.log
+timeout 1200 python -m pytest tests/test_hip_kernels.py -m gpu -x -q -k "scorer or heights or foothold or plan or patch_env" 2>&1 | tail -15 | tee gpurun_out/r2/planner_tests.log
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_pl
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_pl -o p --output-format csv -- python $R/deep-tracking-control_amd/tools/planner_time.py 2>/dev/null | grep "us per call"

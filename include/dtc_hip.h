@@ -74,6 +74,17 @@ int dtc_get_heights(const int16_t* height_samples /*[rows,cols]*/, int rows, int
                     float horizontal_scale, float vertical_scale, float* measured_heights /*[N,P]*/,
                     int N, void* stream);
 
+/* Rows f1 + c fused: sample the terrain table (legged_robot.py:1279-1317), write measured_heights [N,P] (the observations
+ * consume it) and plan the footholds (legged_robot_dtc.py:98-201) from the freshly sampled rows in ONE launch -- no
+ * read-back of the [N,P] matrix.  Bit-identical to dtc_get_heights followed by dtc_foothold_plan (any grid other than
+ * the reference's 33 x 21 runs exactly those two). */
+int dtc_foothold_plan_from_table(const int16_t* height_samples /*[rows,cols]*/, int rows, int cols, float border_size,
+                                 float horizontal_scale, float vertical_scale, const float* root_states /*[N,13]*/,
+                                 const float* thigh_pos /*[N,4,3]*/, const float* commands /*[N,4]*/,
+                                 const DtcGridCfg* cfg, float* measured_heights /*out [N,P]*/, int64_t* idx /*[N,4]*/,
+                                 float* foothold_obs /*[N,8]*/, float* opt_world /*[N,4,3]*/, float* pred /*[N,4,3]*/,
+                                 float* pred_to_robot /*[N,4,3]*/, int N, void* stream);
+
 /* ---- env-step consumers of the planner output (row f3) ----------------------------------
  * LeggedRobotDTC.compute_observations, legged_gym/envs/base/legged_robot_dtc.py:255-288, and
  * LeggedRobotDTC.check_termination, legged_gym/envs/base/legged_robot_dtc.py:229-248. */
