@@ -679,7 +679,7 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     // dwordx4 stores of the output need 16-byte aligned rows (full tiles only; checked per block)
     static const bool wide_off = getenv("DTC_GEMM_WIDE") && atoi(getenv("DTC_GEMM_WIDE")) == 0;      // A/B switch
     const int wide = (!wide_off && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
-    if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
+    if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), occ_pad("FWD", 24576), s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
     else hipLaunchKernelGGL((linear_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
     return dtc::check_launch("linear_fwd");
 }
@@ -756,7 +756,7 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
         if (xd.s[i].ptr) bytes += 4.0 * M * xd.s[i].width * (xd.s[i].accumulate ? 2.0 : 1.0);   // dX written (+ read when accumulated)
     if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)K;                          // saved activations
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s, bytes);
-    if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
+    if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), occ_pad("DGRAD", 25088, 5), s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
     else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
     return dtc::check_launch("linear_dgrad");
 }

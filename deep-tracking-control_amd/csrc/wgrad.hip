@@ -453,7 +453,7 @@ extern "C" int dtc_wgrad_group(const DtcWgradJob* jobs, int count, int M, void* 
     {
         dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, G.tiles_total, count), P.flop, s, P.algo_bytes);
         const int grid = G.tiles_total * 8 * (int)dtc::ceil_div(G.splits, 8);
-        hipLaunchKernelGGL(wgrad_group_kernel, dim3(grid), dim3(256), 0, s, G);
+        hipLaunchKernelGGL(wgrad_group_kernel, dim3(grid), dim3(256), occ_pad("WGRAD", 25600), s, G);
     }
     {
         dtc::ProfScope prof(dtc::prof_shape_name("wgrad_reduce", G.splits, G.tiles_total, count), (double)P.bytes + P.bytes / (double)G.splits, s);
