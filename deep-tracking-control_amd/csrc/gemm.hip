@@ -86,8 +86,11 @@ __device__ unsigned long long* g_trace = nullptr;
 #define DTC_STAMP(i)
 #endif
 
-template <int BN, bool MSE = false>
-__global__ __launch_bounds__(256, 5) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
+// DEEP = true: the variant for launches that leave a CU with about one workgroup (rollout-sized batches): operand loads run TWO stages ahead of the MFMAs (two register sets, k-tail masks applied when a set is stored
+// to LDS, every stage takes the masked form) -- the single-stage pipeline relies on the other workgroups of the CU to
+// cover the load latency, and there are none.
+template <int BN, bool MSE = false, bool DEEP = false>
+__global__ __launch_bounds__(256, DEEP ? 3 : 5) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ Y,
                                                          long long ldy, int M, int N, int K, int act, int wide,
                                                          const MseEpi mse) {
@@ -189,6 +192,46 @@ __global__ __launch_bounds__(256, 5) void linear_fwd_kernel(const SegMatDev X, c
         buf ^= 1;
     };
     enter_segment();
+    if constexpr (DEEP) {
+        int total = 0;
+        for (int i = 0; i < X.nseg; ++i) total += (X.s[i].width + BK - 1) / BK;
+        int lseg = 0, lkt = 0, ln = (sd.width + BK - 1) / BK;          // load cursor: next stage to request
+        f32x4 qa[2][NA], qb[2];
+        int qtail[2];                                                    // last valid element (0..3) of a set's chunks
+        auto request = [&](f32x4 (&a)[NA], f32x4& b, int& tail) {
+            const u32 ka = (u32)(lkt * BK) * 4u, kw = (u32)(sd.start + lkt * BK) * 4u;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) a[i] = bload4(ares, aoff[i], ka);
+            b = bload4(wres, woff, kw);
+            tail = (sd.width - 1) - (lkt * BK + 4 * lch);
+            if (++lkt == ln && ++lseg < X.nseg) {
+                sd = X.s[lseg];
+                enter_segment();
+                lkt = 0;
+                ln = (sd.width + BK - 1) / BK;
+            }
+        };
+        auto commit = [&](int b, f32x4 (&a)[NA], f32x4& w, int tail) {   // registers -> LDS (waits for the loads here)
+#pragma unroll
+            for (int i = 0; i < NA; ++i) As[b][aslot[i]] = ktail(a[i], 0, tail);
+            if (BN >= 64 || bthread) Bs[b][bslot] = ktail(w, 0, tail);
+        };
+        request(qa[0], qb[0], qtail[0]);
+        if (total > 1) request(qa[1], qb[1], qtail[1]);
+        commit(0, qa[0], qb[0], qtail[0]);
+        __syncthreads();
+        for (int st = 0; st < total; st += 2) {
+            if (st + 2 < total) request(qa[0], qb[0], qtail[0]);
+            mfma_stage(0);
+            if (st + 1 < total) commit(1, qa[1], qb[1], qtail[1]);
+            __syncthreads();
+            if (st + 1 >= total) break;
+            if (st + 3 < total) request(qa[1], qb[1], qtail[1]);
+            mfma_stage(1);
+            if (st + 2 < total) commit(0, qa[0], qb[0], qtail[0]);
+            __syncthreads();
+        }
+    } else {
     load_stage(Masked{}, 0);
     store_stage(0);
     __syncthreads();
@@ -204,6 +247,7 @@ __global__ __launch_bounds__(256, 5) void linear_fwd_kernel(const SegMatDev X, c
         step(Masked{}, 0);
     }
     mfma_stage(buf);
+    }
     DTC_STAMP(2);
 
     const bool full = (m0 + BM <= M) && (n0 + BN <= N);
@@ -440,8 +484,8 @@ __global__ __launch_bounds__(256, 3) void gru_step_fwd_kernel(const float* __res
 // ROW: float4 loads along c, LDS image [n][col] (+4 pad), one ds_read_b32 per MFMA step from row 8q + 4h + t.
 // Columns of B past K read the next row of W (or 0 behind its last row): they only feed output columns that are never
 // stored, so the B loads carry no column masks at all.
-template <int BN>
-__global__ __launch_bounds__(256, 6) void linear_dgrad_kernel(const float* __restrict__ dZ, long long lddz,
+template <int BN, bool DEEP = false>
+__global__ __launch_bounds__(256, DEEP ? 3 : 6) void linear_dgrad_kernel(const float* __restrict__ dZ, long long lddz,
                                                            const float* __restrict__ W, const SegMatDev dX,
                                                            const float* __restrict__ Xs, long long ldxs, int M, int N,
                                                            int K, int act, int split_n, long long split_dst, int col_skip,
@@ -537,12 +581,47 @@ __global__ __launch_bounds__(256, 6) void linear_dgrad_kernel(const float* __res
         buf ^= 1;
     };
     const int KT = (N + BK - 1) / BK, KF = N / BK;
+    if constexpr (DEEP) {                                      // loads two stages ahead (see linear_fwd_kernel)
+        f32x4 qa[2][NA], qb[2];
+        int qtail[2];
+        int lkt = 0;
+        auto request = [&](f32x4 (&a)[NA], f32x4& b, int& tail) {
+            const int n_0 = lkt * BK;
+            const u32 sa = (u32)n_0 * 4u, sb = (u32)n_0 * (u32)K * 4u;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) a[i] = bload4(ares, aoff[i], sa);
+            b = bload4(bres, boff | oob_mask(n_0 + bk, N - 1), sb);
+            tail = (N - 1) - (n_0 + 4 * lch);
+            ++lkt;
+        };
+        auto commit = [&](int b, f32x4 (&a)[NA], f32x4& w, int tail) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) As[b][aslot[i]] = ktail(a[i], 0, tail);
+            if (BN >= 64 || bthread) *reinterpret_cast<f32x4*>(&Bs[b][bk][bc]) = w;
+        };
+        request(qa[0], qb[0], qtail[0]);
+        if (KT > 1) request(qa[1], qb[1], qtail[1]);
+        commit(0, qa[0], qb[0], qtail[0]);
+        __syncthreads();
+        for (int st = 0; st < KT; st += 2) {
+            if (st + 2 < KT) request(qa[0], qb[0], qtail[0]);
+            mfma_stage(0);
+            if (st + 1 < KT) commit(1, qa[1], qb[1], qtail[1]);
+            __syncthreads();
+            if (st + 1 >= KT) break;
+            if (st + 3 < KT) request(qa[1], qb[1], qtail[1]);
+            mfma_stage(1);
+            if (st + 2 < KT) commit(0, qa[0], qb[0], qtail[0]);
+            __syncthreads();
+        }
+    } else {
     if (KF >= 1) load_stage(Full{}, 0); else load_stage(Masked{}, 0);
     store_stage(0);
     __syncthreads();
     for (int kt = 1; kt < KF; ++kt) step(Full{}, kt);          // branch-free steady state (full stages)
     if (KT > KF && KT > 1) step(Masked{}, KT - 1);             // N tail
     mfma_stage(buf);
+    }
 
     // ---- epilogue: activation derivative (through the saved post-activation output), segmented destination
     const rsrc_t xres = make_rsrc_bytes(Xs, (long long)M * ldxs * 4);
@@ -636,6 +715,15 @@ int pick_bn_rows(int rows, int cols) {
     return dtc::ceil_div(rows, BM) * dtc::ceil_div(cols, 64) >= min_blocks ? 64 : 32;
 }
 
+// launches of at most this many workgroups (about one per CU: rollout-sized batches, M = 4096) take the two-stages-ahead
+// variants (DTC_GEMM_DEEP_BLOCKS; 0 = never).  Measured: 4096x512x752 61 -> 51 us, 4096x256x512 28 -> 24 us; the narrow layers
+// of the update (24576 rows, 384-768 workgroups) do not profit (9.06 vs 9.17 ms per step with the threshold at 704): their
+// time is the serial MFMA + epilogue chain of the one or two workgroups a CU gets, not exposed load latency.
+bool deep_variant(int grid) {
+    const char* e = getenv("DTC_GEMM_DEEP_BLOCKS");          // read per call: tests flip it between two launches
+    return grid <= (e ? atoi(e) : 300);
+}
+
 // dgrad wide-store eligibility: bit s = destination segment s can be read/written with float4 accesses (16-byte aligned
 // base + column origin, row stride a multiple of 4 floats, tile origin on a 4-column boundary); bit 4 = the same for
 // the saved-activation matrix
@@ -679,7 +767,10 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     // dwordx4 stores of the output need 16-byte aligned rows (full tiles only; checked per block)
     static const bool wide_off = getenv("DTC_GEMM_WIDE") && atoi(getenv("DTC_GEMM_WIDE")) == 0;      // A/B switch
     const int wide = (!wide_off && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
-    if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), occ_pad("FWD", 24576), s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
+    if (deep_variant(grid)) {
+        if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
+        else hipLaunchKernelGGL((linear_fwd_kernel<32, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
+    } else if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), occ_pad("FWD", 24576), s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
     else hipLaunchKernelGGL((linear_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
     return dtc::check_launch("linear_fwd");
 }
@@ -756,7 +847,10 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
         if (xd.s[i].ptr) bytes += 4.0 * M * xd.s[i].width * (xd.s[i].accumulate ? 2.0 : 1.0);   // dX written (+ read when accumulated)
     if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)K;                          // saved activations
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s, bytes);
-    if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), occ_pad("DGRAD", 25088, 5), s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
+    if (deep_variant(grid)) {
+        if (bn == 64) hipLaunchKernelGGL((linear_dgrad_kernel<64, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
+        else hipLaunchKernelGGL((linear_dgrad_kernel<32, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
+    } else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), occ_pad("DGRAD", 25088, 5), s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
     else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
     return dtc::check_launch("linear_dgrad");
 }

@@ -413,6 +413,31 @@ def test_linear_dgrad_segments_accumulate():
     assert float(dmulv2[:, 3:].abs().max()) == 0.0
     np.testing.assert_allclose(_np(dlt2), fulla[:, 72:].numpy(), rtol=2e-5, atol=2e-5)
 
+@pytest.mark.parametrize("M,N,K", [(24576, 128, 256), (24576, 64, 531), (24576, 35, 64), (24576, 1, 128), (4096, 512, 752),
+                                   (4096, 256, 512), (1000, 53, 128), (24576, 12, 128)])
+def test_deep_prefetch_variants_are_bit_identical(M, N, K, monkeypatch):
+    """Small launches (at most 300 workgroups by default) take the two-stages-ahead kernels (csrc/gemm.hip, DEEP): same operand images, same
+    k order, same accumulation -- forward and data gradient must equal the single-stage kernels bit for bit."""
+    from dtc_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    X = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    dZ = torch.randn(M, N, generator=g).to(DEV)
+    outs = []
+    for thr in ("0", "100000"):
+        monkeypatch.setenv("DTC_GEMM_DEEP_BLOCKS", thr)
+        Y = torch.empty(M, N, device=DEV)
+        ops.linear_fwd(X, W, b, Y, act="elu")
+        dX = torch.empty(M, K, device=DEV)
+        ops.linear_dgrad(dZ, W, dX, Xsaved=X, act="elu")
+        torch.cuda.synchronize()
+        outs.append((Y, dX))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.nn.functional.elu(X.double() @ W.double().t() + b.double())
+    assert float((outs[1][0].double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+
+
 
 @pytest.mark.parametrize("act", ["relu", "crelu", "elu", "selu", "lrelu", "tanh", "sigmoid", None])
 @pytest.mark.parametrize("M,N,K", [(384, 128, 265), (1000, 70, 100)])
