@@ -86,3 +86,23 @@ for s, e, n, q, g in step:
             acc[n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:40] + f" g{g}"] += hi - lo
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:30]:
     print(f"    {k:50s} {v / 1e6:7.3f} ms")
+
+# time inside those intervals in which nothing runs at all (dispatch gaps, cross-stream event waits)
+busy = []
+for s, e, n, q, g in step:
+    if g >= 700 and ("linear_" in n or "wgrad_group_kernel" in n):
+        continue
+    for gs, ge in gaps:
+        lo, hi = max(s, gs), min(e, ge)
+        if hi > lo:
+            busy.append((lo, hi))
+busy.sort()
+u, ce = 0, None
+for s, e in busy:
+    if ce is None or s > ce:
+        u += e - s
+        ce = e
+    elif e > ce:
+        u += e - ce
+        ce = e
+print(f"  of which some other kernel runs: {u / 1e6:.3f} ms; nothing runs: {(tot_gap - u) / 1e6:.3f} ms")

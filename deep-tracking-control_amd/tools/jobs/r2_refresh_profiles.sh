@@ -1,4 +1,4 @@
-# Round-2 profile set -> gpurun_out/r2p/ (copied into profiles/ by hand):
+# Round-2 profile set -> gpurun_out/r2p/ (converted into profiles/r02_* by tools/analysis/collect_profiles.py):
 #   bench line (default run), per-shape table, rocprofv3 kernel stats (serialised + overlapped), GRU / composite lines,
 #   N = 2 / N = 4 data-parallel rehearsals of bench.py over gloo on one device (collective-sequence check inside bench.py)
 O=gpurun_out/r2p
