@@ -715,6 +715,8 @@ int pick_bn_rows(int rows, int cols) {
     return dtc::ceil_div(rows, BM) * dtc::ceil_div(cols, 64) >= min_blocks ? 64 : 32;
 }
 
+int g_concurrency_hint = 0;          // dtc_set_concurrency_hint: another stream runs weight gradients next to this one
+
 // launches of at most this many workgroups (about one per CU: rollout-sized batches, M = 4096) take the two-stages-ahead
 // variants (DTC_GEMM_DEEP_BLOCKS; 0 = never).  Measured: 4096x512x752 61 -> 51 us, 4096x256x512 28 -> 24 us; the narrow layers
 // of the update (24576 rows, 384-768 workgroups) do not profit (9.06 vs 9.17 ms per step with the threshold at 704): their
@@ -774,6 +776,8 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     else hipLaunchKernelGGL((linear_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
     return dtc::check_launch("linear_fwd");
 }
+
+extern "C" void dtc_set_concurrency_hint(int side_stream_active) { g_concurrency_hint = side_stream_active ? 1 : 0; }
 
 extern "C" int dtc_linear_fwd_list(const DtcFwdLayer* layers, int count, int M, void* stream) {
     DTC_REQUIRE(layers != nullptr && count >= 1 && count <= 64, "layer list: count %d outside 1..64", count);
@@ -850,7 +854,7 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
     if (deep_variant(grid)) {
         if (bn == 64) hipLaunchKernelGGL((linear_dgrad_kernel<64, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
         else hipLaunchKernelGGL((linear_dgrad_kernel<32, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
-    } else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), occ_pad("DGRAD", 25088, 5), s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
+    } else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), occ_pad("DGRAD", 25088, g_concurrency_hint ? 5 : 0), s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
     else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
     return dtc::check_launch("linear_dgrad");
 }

@@ -123,10 +123,11 @@ __device__ __forceinline__ bool map_tile(int b, int row_tiles, int col_tiles, in
 }
 inline int grid_for(int row_tiles, int col_tiles) { return 8 * (int)dtc::ceil_div(row_tiles, 8) * col_tiles; }
 // extra dynamic LDS per workgroup so that only `occ` workgroups of a kernel fit on a CU (DTC_GEMM_OCC_<which>=occ overrides
-// the default; 0 = whatever registers and the static LDS allow).  Default: the data-gradient kernel is capped at 5 (its 80
-// registers would allow 6 and fill the register file): in the overlapped schedule the sixth slot is worth more to the
-// concurrent weight-gradient workgroups of the side stream (measured: 95.1 -> 94.1 ms per step; every other cap tried on
-// the forward / weight-gradient kernels was neutral or slower)
+// the default; 0 = whatever registers and the static LDS allow).  Default: while the caller runs weight gradients on a
+// second stream (dtc_set_concurrency_hint(1)) the data-gradient kernel is capped at 5 (its 80 registers would allow 6 and fill
+// the register file): the sixth slot is worth more to the concurrent weight-gradient workgroups (measured: 95.1 -> 94.1 ms
+// per step; alone on the device the cap costs the kernel ~3 %; every other cap tried on the forward / weight-gradient
+// kernels was neutral or slower)
 inline unsigned occ_pad(const char* which, unsigned static_lds, int default_occ = 0) {
     char name[64];
     snprintf(name, sizeof name, "DTC_GEMM_OCC_%s", which);

@@ -7,7 +7,7 @@
 // The torch version is ~10 passes over lv plus a sort-based median on ~4e5 values.  Here:
 //   stats (sum, sum^2 in fp64)  ->  3-level MSB radix select (11+11+10 bits) over the
 //   non-outliers with LDS histograms  ->  one apply pass that also writes z and the mask.
-// Every pass reads the 1.5 MB lv column block (L2 resident): 5 short launches + 1 memset.  (A single persistent launch
+// Every pass reads the 1.5 MB lv column block (L2 resident): 5 short launches (the first one also zeroes the scratch header).  (A single persistent launch
 // with device-scope counter barriers between the phases was built and measured in round 2: 56-92 us against 51 us --
 // with a few dozen workgroups the LDS histogram atomics on two or three hot bins serialise, with 256 workgroups the
 // barriers cost as much as the launch boundaries they replace; see DESIGN.md "measured and rejected".)
@@ -15,6 +15,7 @@
 // element; what it reads from other workgroups travels write-through (agent-scope relaxed stores / loads), no
 // cache-maintenance fence (an agent-scope release would write back the whole XCD L2).
 // mulv is the [B,35] output of the fused (latent_mu | latent_var) head: cols 0..18 mu, 19..34 lv.
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -28,7 +29,7 @@ constexpr int MAX_BLK = 256;
 struct Ws {
     double part[MAX_BLK * 2];
     float gpart[MAX_BLK];
-    unsigned hist1[NB1];        // hist1 .. ticket: zeroed by ONE memset before the forward kernel
+    unsigned hist1[NB1];        // hist1 .. ticket: contiguous scratch header, zeroed by the stats kernel
     unsigned hist2[NB2];
     unsigned hist3[NB3];
     unsigned spare;
@@ -59,6 +60,11 @@ __global__ __launch_bounds__(256) void lat_stats_kernel(const float* __restrict_
                                                         int* __restrict__ info) {
     __shared__ double sh[4];
     if (blockIdx.x == 0 && threadIdx.x < 4) info[threadIdx.x] = threadIdx.x == 1 ? 0x7f7f7f7f : 0;     // consumed 4 launches later
+    // scratch header (the three histograms of the later launches + the backward kernel's ticket): zeroed here instead of
+    // by a memset node in front of the chain
+    static_assert(offsetof(Ws, ticket) == offsetof(Ws, hist1) + sizeof(unsigned) * (NB1 + NB2 + NB3 + 1), "scratch header must be contiguous");
+    unsigned* head = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + offsetof(Ws, hist1));
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NB1 + NB2 + NB3 + 2; i += gridDim.x * blockDim.x) head[i] = 0u;
     double s = 0.0, q = 0.0;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
         const double x = (double)mulv[(e >> 4) * LD + MU + (e & 15)];
@@ -279,8 +285,6 @@ extern "C" int dtc_cenet_latent_fwd(float* mulv, const float* eps, float* z, uin
     const long long n = (long long)B * LAT;
     const int g = grid_for(n);
     dtc::ProfScope prof("cenet_latent_fwd", (double)n * 4.0 * 6, s);
-    // scratch header (histograms + the backward kernel's ticket): one memset; `info` is initialised by the stats kernel
-    (void)hipMemsetAsync(ws->hist1, 0, sizeof(unsigned) * (NB1 + NB2 + NB3 + 2), s);
     hipLaunchKernelGGL(lat_stats_kernel, dim3(g), dim3(256), 0, s, mulv, n, ws, info);
     hipLaunchKernelGGL(lat_hist_kernel<1>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
     hipLaunchKernelGGL(lat_hist_kernel<2>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);

@@ -129,6 +129,10 @@ _SIGS = {
     "dtc_gru_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dtc_gru_fwd": (C.c_int, [c_f32p] * 7 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_gru_bwd": (C.c_int, [c_f32p] * 9 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_set_concurrency_hint": (None, [C.c_int]),
+    "dtc_lstm_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "dtc_lstm_fwd": (C.c_int, [c_f32p] * 8 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_lstm_bwd": (C.c_int, [c_f32p] * 10 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_prof_enable": (None, [C.c_int]),
     "dtc_prof_reset": (None, []),
     "dtc_prof_report": (C.c_int, [C.POINTER(DtcProfRec), C.c_int]),

@@ -466,6 +466,7 @@ class PPO:
         one branch needs the other's result."""
         ac = self.actor_critic
         L = ac.L
+        _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap_wgrad)))     # weight gradients on the side stream
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
         dec_in = segmat([seg(fw.z, 0, 16), seg(fw.mulv, 0, 3), seg(fw.lt, 0, 512)])
         with tw.lane("aux"):
@@ -531,6 +532,7 @@ class PPO:
         ac = self.actor_critic
         L = ac.L
         act = AC_Args.activation
+        _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap_wgrad)))     # weight gradients on the side stream
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
         with tw.lane("aux"):
             ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)

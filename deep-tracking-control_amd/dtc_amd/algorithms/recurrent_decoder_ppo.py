@@ -91,6 +91,7 @@ class RecurrentDecoderPPO(PPO):
         # lanes: the critic head (raw-input features -> GRU -> MLP) is independent of the CE-net / terrain encoders and
         # of the actor head until the loss, and again until the optimiser step: it runs on `aux`, the small per-time-
         # step kernels of the two recurrences overlap
+        _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap_wgrad)))
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
         Xa = ac.actor_input(fw, flat["observations"], idx)
         Xc = ac.critic_input(flat["observations"], flat["base_vel"], flat["privileged_observations"], idx)

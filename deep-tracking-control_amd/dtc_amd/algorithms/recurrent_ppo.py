@@ -1,4 +1,4 @@
-"""PPO for the recurrent (GRU) actor-critic -- BASELINE.json config 3 ("ActorCriticRecurrent (GRU hidden
+"""PPO for the recurrent (GRU / LSTM) actor-critic -- BASELINE.json config 3 ("ActorCriticRecurrent (GRU hidden
 512) BPTT over 24 steps").
 
 The reference's `PPO` cannot drive `ActorCriticRecurrent` at this commit (it needs `.vae`, ppo.py:79, and its
@@ -72,11 +72,11 @@ class RecurrentPPO:
     def act(self, obs, critic_obs):
         self._require_gpu()
         ac, tr = self.actor_critic, self.transition
-        N, H = obs.shape[0], ac.rnn_hidden_size
+        N = obs.shape[0]
         for m in (ac.memory_a, ac.memory_c):
             if m.hidden_states is None:
-                m.hidden_states = torch.zeros(1, N, H, device=obs.device)
-        tr.hidden_states = tuple(h.clone() for h in ac.get_hidden_states())     # state BEFORE this step
+                m.hidden_states = m.init_hidden(N, obs.device)
+        tr.hidden_states = tuple(m.clone_hidden(h) for m, h in zip((ac.memory_a, ac.memory_c), ac.get_hidden_states()))   # BEFORE this step
         tr.actions = ac.act(obs).detach()
         tr.values = ac.evaluate(critic_obs).detach()
         tr.actions_log_prob = ac.get_actions_log_prob(tr.actions).detach()
@@ -99,7 +99,7 @@ class RecurrentPPO:
     def compute_returns(self, last_critic_obs):
         self._require_gpu()
         ac = self.actor_critic
-        keep = ac.memory_c.hidden_states.clone() if ac.memory_c.hidden_states is not None else None
+        keep = ac.memory_c.clone_hidden(ac.memory_c.hidden_states)
         last_values = ac.evaluate(last_critic_obs).detach()
         ac.memory_c.hidden_states = keep            # the bootstrap value must not advance the critic's state
         self.storage.compute_returns(last_values, self.gamma, self.lam)
@@ -170,6 +170,7 @@ class RecurrentPPO:
         store_idx = (torch.arange(T, device=dev).unsqueeze(1) * N + torch.arange(start, stop, device=dev)).reshape(-1).contiguous()
         stats = torch.zeros(STAT_COLS, device=dev) if stats is None else stats
         self.optimizer.set_lr(self.learning_rate)
+        _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap)))
         ln.begin(self.overlap)
         # forward: critic recurrence on the second lane
         with ln.lane("aux"):

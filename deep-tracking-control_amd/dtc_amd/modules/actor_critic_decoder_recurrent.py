@@ -36,6 +36,9 @@ class ActorCriticDecoderRecurrent(ActorCriticDecoder):
             print("ActorCriticDecoderRecurrent.__init__ got unexpected arguments, which will be ignored: "
                   + str([key for key in kwargs.keys()]))
         nn.Module.__init__(self)
+        if rnn_type.lower() != 'gru' or rnn_num_layers != 1:
+            raise NotImplementedError("the composite model of BASELINE.json configs[4] is built for a 1-layer GRU "
+                                      "(ActorCriticRecurrent / Memory take 'lstm' and deeper stacks)")
         if activation not in ("elu", "relu"):
             raise NotImplementedError("the HIP layers implement 'elu' and 'relu'")
         A = AC_Args

@@ -165,52 +165,121 @@ class ActorCritic(nn.Module):
 
 
 class Memory(nn.Module):
-    """GRU state holder (actor_critic_recurrent.py:92-116).  `self.rnn` keeps torch's parameter names."""
+    """Recurrent state holder (actor_critic_recurrent.py:92-116): torch.nn.GRU or torch.nn.LSTM (the reference's default),
+    any number of layers.  `self.rnn` keeps torch's parameter names; the recurrence runs in csrc/gru.hip / csrc/lstm.hip.
+    `hidden_states` follows torch: a [num_layers, N, H] tensor (GRU) or a tuple (h, c) of two such tensors (LSTM)."""
 
-    def __init__(self, input_size, type='gru', num_layers=1, hidden_size=256):
+    def __init__(self, input_size, type='lstm', num_layers=1, hidden_size=256):
         super().__init__()
-        if type.lower() != 'gru' or num_layers != 1:
-            raise NotImplementedError("the HIP recurrence implements a 1-layer GRU (BASELINE.json config 3)")
-        self.rnn = nn.GRU(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers)
+        kind = type.lower()
+        if kind not in ('gru', 'lstm') or num_layers < 1:
+            raise ValueError(f"Memory: type must be 'gru' or 'lstm' and num_layers >= 1 (got {type!r}, {num_layers})")
+        rnn_cls = nn.GRU if kind == 'gru' else nn.LSTM
+        self.rnn = rnn_cls(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers)
+        self.kind, self.num_layers, self.G = kind, num_layers, (3 if kind == 'gru' else 4)
         self.hidden_states = None
         self.input_size, self.hidden_size = input_size, hidden_size
         self.saved = None          # tensors of the last batch-mode forward (for BPTT)
 
     def bind(self, arena, prefix):
         v = lambda buf, n: arena.view(buf, f"{prefix}.rnn.{n}")
-        self.W_ih, self.W_hh = v(arena.flat, "weight_ih_l0"), v(arena.flat, "weight_hh_l0")
-        self.b_ih, self.b_hh = v(arena.flat, "bias_ih_l0"), v(arena.flat, "bias_hh_l0")
-        self.gW_ih, self.gW_hh = v(arena.grad, "weight_ih_l0"), v(arena.grad, "weight_hh_l0")
-        self.gb_ih, self.gb_hh = v(arena.grad, "bias_ih_l0"), v(arena.grad, "bias_hh_l0")
+        L = range(self.num_layers)
+        self.Wih, self.Whh = [v(arena.flat, f"weight_ih_l{l}") for l in L], [v(arena.flat, f"weight_hh_l{l}") for l in L]
+        self.bih, self.bhh = [v(arena.flat, f"bias_ih_l{l}") for l in L], [v(arena.flat, f"bias_hh_l{l}") for l in L]
+        self.gWih, self.gWhh = [v(arena.grad, f"weight_ih_l{l}") for l in L], [v(arena.grad, f"weight_hh_l{l}") for l in L]
+        self.gbih, self.gbhh = [v(arena.grad, f"bias_ih_l{l}") for l in L], [v(arena.grad, f"bias_hh_l{l}") for l in L]
+        # layer 0 under the names the composite model (1-layer GRU) uses
+        self.W_ih, self.W_hh, self.b_ih, self.b_hh = self.Wih[0], self.Whh[0], self.bih[0], self.bhh[0]
+        self.gW_ih, self.gW_hh, self.gb_ih, self.gb_hh = self.gWih[0], self.gWhh[0], self.gbih[0], self.gbhh[0]
 
-    def run(self, x, h0):
-        """x [T,R,I], h0 [R,H] -> dict(hs_all [T+1,R,H], gates, hn, gi, x)."""
-        T, R, I = x.shape
-        H, dev = self.hidden_size, x.device
-        x2 = x.contiguous().view(T * R, I)
-        gi = torch.empty(T, R, 3 * H, device=dev)
-        ops.linear_fwd(x2, self.W_ih, self.b_ih, gi.view(T * R, 3 * H), None)
-        hs_all = torch.empty(T + 1, R, H, device=dev)
-        gates, hn = torch.empty(T, R, 3 * H, device=dev), torch.empty(T, R, H, device=dev)
-        ws = ops.workspace(ops.gru_workspace_bytes(T, R, H), dev)
-        ops.gru_fwd(gi, h0.contiguous(), self.W_hh, self.b_hh, hs_all, gates, hn, ws)
-        return dict(hs_all=hs_all, gates=gates, hn=hn, x2=x2, ws=ws, T=T, R=R)
+    # ---- hidden-state helpers (GRU: tensor, LSTM: (h, c))
+    def init_hidden(self, N, device):
+        z = lambda: torch.zeros(self.num_layers, N, self.hidden_size, device=device)
+        return z() if self.kind == 'gru' else (z(), z())
+
+    @staticmethod
+    def clone_hidden(h):
+        if h is None:
+            return None
+        return tuple(t.clone() for t in h) if isinstance(h, (tuple, list)) else h.clone()
+
+    def _split(self, hidden):
+        """-> (h [L,R,H], c [L,R,H] or None)"""
+        if self.kind == 'lstm':
+            if not isinstance(hidden, (tuple, list)) or len(hidden) != 2:
+                raise ValueError("LSTM memory needs hidden states (h, c)")
+            h, c = hidden
+        else:
+            h, c = (hidden[0] if isinstance(hidden, (tuple, list)) else hidden), None
+        fix = lambda t: t if t.dim() == 3 else t.unsqueeze(0)
+        return fix(h), (fix(c) if c is not None else None)
+
+    def run(self, x, hidden):
+        """x [T,R,I], hidden as in `hidden_states` ([L,R,H] or (h, c)) -> saved dict; saved['out'] = top layer's [T,R,H]."""
+        T, R, _ = x.shape
+        H, G, dev = self.hidden_size, self.G, x.device
+        h0, c0 = self._split(hidden)
+        layers, cur = [], x.contiguous().view(T * R, -1)
+        for l in range(self.num_layers):
+            gi = torch.empty(T, R, G * H, device=dev)
+            ops.linear_fwd(cur, self.Wih[l], self.bih[l], gi.view(T * R, G * H), None)
+            hs_all = torch.empty(T + 1, R, H, device=dev)
+            gates = torch.empty(T, R, G * H, device=dev)
+            rec = dict(x2=cur, hs_all=hs_all, gates=gates)
+            if self.kind == 'gru':
+                rec["hn"] = torch.empty(T, R, H, device=dev)
+                rec["ws"] = ops.workspace(ops.gru_workspace_bytes(T, R, H), dev)
+                ops.gru_fwd(gi, h0[l].contiguous(), self.Whh[l], self.bhh[l], hs_all, gates, rec["hn"], rec["ws"])
+            else:
+                rec["cs_all"] = torch.empty(T + 1, R, H, device=dev)
+                rec["ws"] = ops.workspace(ops.lstm_workspace_bytes(T, R, H), dev)
+                ops.lstm_fwd(gi, h0[l].contiguous(), c0[l].contiguous(), self.Whh[l], self.bhh[l], hs_all, rec["cs_all"], gates,
+                             rec["ws"])
+            layers.append(rec)
+            cur = hs_all[1:].reshape(T * R, H)
+        top = layers[-1]
+        # layer-0 records under the flat names older callers use (1-layer GRU)
+        return dict(layers=layers, out=top["hs_all"][1:], hs_all=top["hs_all"], gates=top["gates"], hn=top.get("hn"),
+                    x2=layers[0]["x2"], ws=top["ws"], T=T, R=R)
+
+    def final_hidden(self, saved):
+        h = torch.stack([rec["hs_all"][-1] for rec in saved["layers"]])
+        if self.kind == 'gru':
+            return h
+        return h, torch.stack([rec["cs_all"][-1] for rec in saved["layers"]])
 
     def backward(self, saved, dhs, wgrad=None):
-        """BPTT: dhs [T,R,H] -> parameter gradients into the arena; returns dgi [T,R,3H] (gradient of the input
-        projection's output).  `wgrad(dZ, X, gW, gb)` optionally takes over the input-projection weight gradient
-        (the trainer runs it on its weight-gradient stream)."""
-        T, R, H = saved["T"], saved["R"], self.hidden_size
+        """BPTT: dhs [T,R,H] (gradient w.r.t. the top layer's outputs) -> parameter gradients into the arena; returns dgi
+        [T,R,G*H] of the BOTTOM layer (gradient of the input projection's output).  `wgrad(dZ, X, gW, gb)` optionally takes
+        over the input-projection weight gradients (the trainer runs them on its weight-gradient stream)."""
+        T, R, H, G = saved["T"], saved["R"], self.hidden_size, self.G
         dev = dhs.device
-        dgi = torch.empty(T, R, 3 * H, device=dev)
-        dh0 = torch.empty(R, H, device=dev)
-        ops.gru_bwd(dhs.contiguous(), saved["hs_all"], saved["gates"], saved["hn"], self.W_hh, dgi, self.gW_hh, self.gb_hh,
-                    dh0, saved["ws"])
-        if wgrad is not None:
-            wgrad(dgi.view(T * R, 3 * H), saved["x2"], self.gW_ih, self.gb_ih)
-        else:
-            wws = ops.workspace(ops.wgrad_workspace_bytes(T * R, 3 * H, self.input_size), dev)
-            ops.linear_wgrad(dgi.view(T * R, 3 * H), saved["x2"], self.gW_ih, self.gb_ih, wws)
+        d_out = dhs.contiguous()
+        keep = []
+        for l in range(self.num_layers - 1, -1, -1):
+            rec = saved["layers"][l]
+            dgi = torch.empty(T, R, G * H, device=dev)
+            dh0 = torch.empty(R, H, device=dev)
+            if self.kind == 'gru':
+                ops.gru_bwd(d_out, rec["hs_all"], rec["gates"], rec["hn"], self.Whh[l], dgi, self.gWhh[l], self.gbhh[l], dh0,
+                            rec["ws"])
+            else:
+                dc0 = torch.empty(R, H, device=dev)
+                ops.lstm_bwd(d_out, rec["hs_all"], rec["cs_all"], rec["gates"], self.Whh[l], dgi, self.gWhh[l], self.gbhh[l], dh0,
+                             dc0, rec["ws"])
+            I = self.Wih[l].shape[1]
+            if wgrad is not None:
+                wgrad(dgi.view(T * R, G * H), rec["x2"], self.gWih[l], self.gbih[l])
+            else:
+                wws = ops.workspace(ops.wgrad_workspace_bytes(T * R, G * H, I), dev)
+                ops.linear_wgrad(dgi.view(T * R, G * H), rec["x2"], self.gWih[l], self.gbih[l], wws)
+                keep.append(wws)
+            if l > 0:                              # gradient w.r.t. this layer's input = the outputs of the layer below
+                d_in = torch.empty(T * R, I, device=dev)
+                ops.linear_dgrad(dgi.view(T * R, G * H), self.Wih[l], d_in, None, None, M=T * R)
+                d_out = d_in.view(T, R, H)
+            keep.append(dgi)
+        saved["_bwd_keep"] = keep                  # read by side-stream weight gradients until the trainer's join
         return dgi
 
     def forward(self, input, masks=None, hidden_states=None):
@@ -218,17 +287,20 @@ class Memory(nn.Module):
         if batch_mode:
             if hidden_states is None:
                 raise ValueError("Hidden states not passed to memory module during policy update")
-            self.saved = self.run(input, hidden_states[0] if hidden_states.dim() == 3 else hidden_states)
-            return self.saved["hs_all"][1:]
+            self.saved = self.run(input, hidden_states)
+            return self.saved["out"]
         if self.hidden_states is None:
-            self.hidden_states = torch.zeros(1, input.shape[0], self.hidden_size, device=input.device)
-        out = self.run(input.unsqueeze(0), self.hidden_states[0])
-        self.hidden_states = out["hs_all"][1:2].clone()
-        return self.hidden_states
+            self.hidden_states = self.init_hidden(input.shape[0], input.device)
+        out = self.run(input.unsqueeze(0), self.hidden_states)
+        self.hidden_states = self.final_hidden(out)           # torch.stack: fresh tensors
+        return out["out"]
 
     def reset(self, dones=None):
-        if self.hidden_states is not None:
-            self.hidden_states[..., dones.bool() if dones.dtype != torch.bool else dones, :] = 0.0
+        if self.hidden_states is None:
+            return
+        d = dones.bool() if dones.dtype != torch.bool else dones
+        for t in (self.hidden_states if isinstance(self.hidden_states, (tuple, list)) else (self.hidden_states,)):
+            t[..., d, :] = 0.0
 
 
 class ActorCriticRecurrent(ActorCritic):

@@ -277,6 +277,24 @@ def gru_bwd(dhs, hs_all, gates, hn, W_hh, dgi, dW_hh, db_hh, dh0, ws):
                             stream()), "dtc_gru_bwd")
 
 
+def lstm_workspace_bytes(T, R, H) -> int:
+    return int(lib().dtc_lstm_workspace(T, R, H))
+
+
+def lstm_fwd(gi, h0, c0, W_hh, b_hh, hs_all, cs_all, gates, ws):
+    """gi [T,R,4H], h0 / c0 [R,H] -> hs_all / cs_all [T+1,R,H] (slot 0 = h0 / c0), gates [T,R,4H] (i, f, g, o)."""
+    T, R, H4 = gi.shape
+    check(lib().dtc_lstm_fwd(cptr(gi, f32), cptr(h0, f32), cptr(c0, f32), cptr(W_hh, f32), cptr(b_hh, f32), cptr(hs_all, f32),
+                             cptr(cs_all, f32), cptr(gates, f32), ptr(ws), T, R, H4 // 4, stream()), "dtc_lstm_fwd")
+
+
+def lstm_bwd(dhs, hs_all, cs_all, gates, W_hh, dgi, dW_hh, db_hh, dh0, dc0, ws):
+    T, R, H = dhs.shape
+    check(lib().dtc_lstm_bwd(cptr(dhs, f32), cptr(hs_all, f32), cptr(cs_all, f32), cptr(gates, f32), cptr(W_hh, f32),
+                             cptr(dgi, f32), cptr(dW_hh, f32), cptr(db_hh, f32), cptr(dh0, f32), cptr(dc0, f32), ptr(ws), T, R, H,
+                             stream()), "dtc_lstm_bwd")
+
+
 def scatter_rows(src, idx, dst):
     """dst[idx[r]] = src[r] for 2-D fp32 tensors (rows of src.shape[1] floats)."""
     check(lib().dtc_scatter_rows(cptr(src, f32), cptr(idx, torch.int64), cptr(dst, f32), src.shape[0], src.shape[1],

@@ -224,7 +224,9 @@ class RolloutStorage:
                 hid_a_batch = pick(self.saved_hidden_states_a)
                 hid_c_batch = pick(self.saved_hidden_states_c)
                 hid_a_batch = hid_a_batch[0] if len(hid_a_batch) == 1 else hid_a_batch
-                hid_c_batch = hid_c_batch[0] if len(hid_c_batch) == 1 else hid_c_batch
+                # (sic) rollout_storage.py:262 -- with more than one state tensor (LSTM: h and c) the reference hands the
+                # ACTOR's saved states to the critic as well; kept, so that an update matches the reference's
+                hid_c_batch = hid_c_batch[0] if len(hid_c_batch) == 1 else hid_a_batch
                 yield (obs_batch, critic_obs_batch, sl(self.actions), sl(self.values), sl(self.advantages),
                        sl(self.returns), sl(self.actions_log_prob), sl(self.mu), sl(self.sigma),
                        (hid_a_batch, hid_c_batch), masks_batch)

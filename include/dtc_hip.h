@@ -216,6 +216,11 @@ int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, const DtcSeg
 int dtc_linear_dgrad_split(const float* dZ, int64_t lddz, const float* W, float* dX, int64_t lddx, int64_t split_stride,
                            int M, int N, int K, int nsplit, void* stream);
 
+/* Host hint: non-zero while the caller launches weight gradients on a second stream next to the stream of the data
+ * gradients (the overlapped schedule of PPO.update).  The data-gradient kernel then leaves one of its six workgroup slots
+ * per CU to them.  Process-wide, not thread-safe against concurrent launches; results never depend on it. */
+void dtc_set_concurrency_hint(int side_stream_active);
+
 /* dW[N,K] = dZ^T X, db[N] = column sums of dZ.  workspace: >= dtc_linear_wgrad_workspace() bytes. */
 int64_t dtc_linear_wgrad_workspace(int M, int N, int K);
 int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* X, float* dW, float* db,
@@ -322,6 +327,21 @@ int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, const float
 int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* gates, const float* hn, const float* W_hh,
                 float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace, int T, int R, int H,
                 void* stream);
+
+/* ---- LSTM (torch.nn.LSTM, gate order i,f,g,o; the default `rnn_type` of actor_critic_recurrent.py:93-97) ----
+ * gi [T,R,4H] = x W_ih^T + b_ih is computed by dtc_linear_fwd over all T*R rows; this runs
+ *     a = gi_t + h_{t-1} W_hh^T + b_hh;  i,f,o = sig(a_i, a_f, a_o), g = tanh(a_g);  c_t = f c_{t-1} + i g;  h_t = o tanh(c_t)
+ * hs_all / cs_all are [T+1,R,H]: slot 0 receives h0 / c0, slot t+1 = h_t / c_t (hs_all[1:] is nn.LSTM's output);
+ * gates [T,R,4H] receives the activated (i, f, g, o).  workspace >= dtc_lstm_workspace() bytes. */
+int64_t dtc_lstm_workspace(int T, int R, int H);
+int dtc_lstm_fwd(const float* gi, const float* h0, const float* c0, const float* W_hh /*[4H,H]*/, const float* b_hh,
+                 float* hs_all, float* cs_all, float* gates, void* workspace, int T, int R, int H, void* stream);
+/* BPTT.  dhs [T,R,H] = gradient w.r.t. the outputs h_1..h_T (the final states carry no gradient).  Produces dgi [T,R,4H]
+ * (gradient w.r.t. the gate pre-activations: feed it to dtc_linear_wgrad with x for W_ih / b_ih and to dtc_linear_dgrad
+ * for the layer below), dW_hh [4H,H], db_hh [4H], dh0 and dc0 [R,H]. */
+int dtc_lstm_bwd(const float* dhs, const float* hs_all, const float* cs_all, const float* gates, const float* W_hh,
+                 float* dgi, float* dW_hh, float* db_hh, float* dh0, float* dc0, void* workspace, int T, int R, int H,
+                 void* stream);
 
 /* ---- per-kernel timing (HIP events on `stream`) used by bench.py's roofline object ---------- */
 void dtc_prof_enable(int on);

@@ -1,11 +1,12 @@
-"""torch-CPU restatement of the recurrent (GRU) actor-critic path (TEST INFRASTRUCTURE ONLY).
+"""torch-CPU restatement of the recurrent (GRU / LSTM) actor-critic path (TEST INFRASTRUCTURE ONLY).
 
 Restates rsl_rl/rsl_rl/modules/actor_critic.py:38-155, actor_critic_recurrent.py:40-116 (`ActorCriticRecurrent`,
 `Memory` around torch.nn.GRU), rsl_rl/rsl_rl/utils/utils.py:33-70 (split/pad/unpad) and the recurrent mini-batch
 of rollout_storage.py:217-267.  The reference's own `PPO` cannot train this model at this commit,
 so the training step is the upstream rsl_rl PPO step = ppo.py:288-335 without the VAE block (SURVEY.md §8a
 "Config 3"); that loss block is the one already pinned by tests/golden/ppo.npz.  The modules / padding are pinned
-by tests/golden/gru.npz (outputs of the imported reference classes).
+by tests/golden/gru.npz and tests/golden/lstm.npz (outputs of the imported reference classes; the LSTM fixture uses the
+reference's default `rnn_type='lstm'` with two layers).
 """
 from __future__ import annotations
 
@@ -24,19 +25,21 @@ def _mlp(in_dim, hidden, out_dim):
 
 
 class RefMemory(nn.Module):
-    def __init__(self, input_size, hidden_size):
+    def __init__(self, input_size, hidden_size, rnn_type='gru', num_layers=1):
         super().__init__()
-        self.rnn = nn.GRU(input_size=input_size, hidden_size=hidden_size, num_layers=1)
+        rnn_cls = nn.GRU if rnn_type.lower() == 'gru' else nn.LSTM          # actor_critic_recurrent.py:96-97
+        self.rnn = rnn_cls(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers)
 
 
 class RefActorCriticRecurrent(nn.Module):
-    def __init__(self, num_actor_obs=53, num_critic_obs=1389, num_actions=12, hidden=(512, 256, 128), rnn_hidden=512):
+    def __init__(self, num_actor_obs=53, num_critic_obs=1389, num_actions=12, hidden=(512, 256, 128), rnn_hidden=512,
+                 rnn_type='gru', num_layers=1):
         super().__init__()
         self.actor = _mlp(rnn_hidden, hidden, num_actions)
         self.critic = _mlp(rnn_hidden, hidden, 1)
         self.std = nn.Parameter(torch.ones(num_actions))
-        self.memory_a = RefMemory(num_actor_obs, rnn_hidden)
-        self.memory_c = RefMemory(num_critic_obs, rnn_hidden)
+        self.memory_a = RefMemory(num_actor_obs, rnn_hidden, rnn_type, num_layers)
+        self.memory_c = RefMemory(num_critic_obs, rnn_hidden, rnn_type, num_layers)
 
 
 def split_and_pad(tensor, dones):
@@ -58,7 +61,7 @@ def unpad(traj, masks):
 
 def recurrent_batches(st, hid_a, hid_c, num_mini_batches):
     """rollout_storage.py:217-267 for one epoch.  st: oracle RefStorage-like with [T,N,.] tensors;
-    hid_a/hid_c: saved hidden states [T, 1, N, H] (state BEFORE each step)."""
+    hid_a/hid_c: saved hidden states [T, L, N, H] (state BEFORE each step); a tuple (h, c) of two such for an LSTM."""
     obs_p, masks = split_and_pad(st.observations, st.dones)
     cobs_p, _ = split_and_pad(st.privileged_observations, st.dones)
     N = st.observations.shape[1]
@@ -72,9 +75,13 @@ def recurrent_batches(st, hid_a, hid_c, num_mini_batches):
         a, b = i * mb, (i + 1) * mb
         n_traj = int(lwd[:, a:b].sum())
         last = first + n_traj
-        pick = lambda h: h.permute(2, 0, 1, 3)[lwd.permute(1, 0)][first:last].transpose(1, 0).contiguous()
+        pick1 = lambda h: h.permute(2, 0, 1, 3)[lwd.permute(1, 0)][first:last].transpose(1, 0).contiguous()
+        pick = lambda h: tuple(pick1(x) for x in h) if isinstance(h, (tuple, list)) else pick1(h)     # LSTM: (h, c)
+        # rollout_storage.py:261-262: `hid_c_batch = hid_c_batch[0] if len(hid_c_batch)==1 else hid_a_batch` (sic) -- for an
+        # LSTM the critic receives the actor's saved states
+        ha, hc = pick(hid_a), pick(hid_c)
         yield dict(obs=obs_p[:, first:last], cobs=cobs_p[:, first:last], masks=masks[:, first:last],
-                   hid_a=pick(hid_a), hid_c=pick(hid_c), sl=slice(a, b))
+                   hid_a=ha, hid_c=(ha if isinstance(hid_c, (tuple, list)) else hc), sl=slice(a, b))
         first = last
 
 

@@ -1,7 +1,7 @@
 """Generate the committed golden fixtures by RUNNING THE REFERENCE (read-only import from
 /root/reference) on the deterministic synthetic inputs of dtc_amd.synthetic.
 
-    python tests/golden/make_golden.py [gae ppo scorer heights init gru composite observations]
+    python tests/golden/make_golden.py [gae ppo scorer heights init gru lstm composite observations]
 
 Runs only in the build container (the reference does not exist on the GPU box).  The fixtures
 hold outputs only -- inputs are regenerated from seeds on the test side -- so they stay small.
@@ -406,6 +406,51 @@ def gen_gru():
     save("gru", **out)
 
 
+# ------------------------------------------------------------------------------------ LSTM (the reference's default rnn_type), 2 layers
+def lstm_case(N=16, seed=6, H=256, L=2):
+    data = S.rollout(N, 24, seed=seed)
+    data["dones"][:, 0] = 0
+    g = torch.Generator().manual_seed(78)
+    mk = lambda: 0.1 * torch.randn(24, L, N, H, generator=g)
+    return data, (mk(), mk()), (mk(), mk())
+
+
+def gen_lstm():
+    torch.set_num_threads(GOLDEN_THREADS)
+    from rsl_rl.modules import ActorCriticRecurrent
+    from rsl_rl.storage import RolloutStorage
+    N = 16
+    with H.quiet():
+        torch.manual_seed(5)
+        ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+                                  activation='elu', rnn_type='lstm', rnn_hidden_size=256, rnn_num_layers=2)
+    fill_parameters_(ac, 23)
+    data, hid_a, hid_c = lstm_case(N)
+    st = RolloutStorage(N, 24, [53], [1389], [265], [12])
+    fill_ref_storage(st, data)
+    st.saved_hidden_states_a, st.saved_hidden_states_c = [h.clone() for h in hid_a], [h.clone() for h in hid_c]
+    out = dict(keys=np.array(list(ac.state_dict().keys())))
+    for i, b in enumerate(st.reccurent_mini_batch_generator(4, 1)):
+        (obs_b, cobs_b, act_b, val_b, adv_b, ret_b, lp_b, mu_b, sg_b, (ha, hc), masks) = b
+        with torch.no_grad():
+            ac.act(obs_b, masks=masks, hidden_states=ha)
+            mean = ac.action_mean.clone()
+            value = ac.evaluate(cobs_b, masks=masks, hidden_states=hc)
+        out[f"mb{i}_shape"] = np.array(list(obs_b.shape) + list(masks.shape) + list(ha[0].shape) + [len(ha)])
+        out[f"mb{i}_mean"] = mean.numpy()
+        out[f"mb{i}_value"] = value.numpy()
+    ac.memory_a.hidden_states = None
+    ac.memory_c.hidden_states = None
+    seq, vals = [], []
+    with torch.no_grad():
+        for t in range(3):
+            ac.act(data["observations"][t])
+            seq.append(ac.action_mean.clone().numpy())
+            vals.append(ac.evaluate(data["privileged_observations"][t]).clone().numpy())
+    out["rollout_means"], out["rollout_values"] = np.stack(seq), np.stack(vals)
+    save("lstm", **out)
+
+
 # ------------------------------------------------------------------------------------ f4: deployment path + checkpoint layout
 def gen_teacher():
     """`ActorCriticDecoder.act_teacher` (actor_critic_decoder.py:504-538, reached through `act_expert` /
@@ -545,7 +590,7 @@ def gen_composite():
     save("composite", **out)
 
 
-TASKS = dict(teacher=gen_teacher, observations=gen_observations, composite=gen_composite, gru=gen_gru, gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
+TASKS = dict(lstm=gen_lstm, teacher=gen_teacher, observations=gen_observations, composite=gen_composite, gru=gen_gru, gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
 
 if __name__ == "__main__":
     for t in (sys.argv[1:] or list(TASKS)):
