@@ -10,7 +10,7 @@
 //  * dtc_gaussian_act  ppo.py:141-148 (rollout side: sample, log-prob, mu, sigma)
 //
 // All reductions: per-block partials in fp64 + a single-block finalize (deterministic order).
-#include "common.hpp"
+#include "gemm_core.hpp"
 
 namespace {
 
@@ -127,86 +127,81 @@ __global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const double* __
 }
 
 // ---------------------------------------------------------------------------------- PPO losses
-// per-block partial layout: [0] surrogate sum, [1] value-loss sum, [2] kl sum, [3 .. 3+A) dstd sums
-__global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__ mean, const float* __restrict__ stdp,
-                                                       const float* __restrict__ value, const float* __restrict__ actions,
-                                                       const float* __restrict__ old_logp, const float* __restrict__ old_mu,
-                                                       const float* __restrict__ old_sigma, const float* __restrict__ adv,
-                                                       const float* __restrict__ returns, const float* __restrict__ old_values,
-                                                       const long long* __restrict__ idx, DtcPpoCfg cfg,
-                                                       float* __restrict__ dmean, float* __restrict__ dvalue,
-                                                       double* __restrict__ part, int B, int A) {
-    __shared__ double sh[4];
-    __shared__ float sstd[MAX_ACT];
-    if (threadIdx.x < A) sstd[threadIdx.x] = stdp[threadIdx.x];
-    __syncthreads();
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    const bool ok = b < B;
-    const float invB = 1.0f / (float)B;
-    double s_sur = 0.0, s_val = 0.0, s_kl = 0.0;
-    float dlogp_scale = 0.f;                 // dL/dlogp of this row
-    long long r = 0;
-    if (ok) {
-        r = idx ? idx[b] : (long long)b;
-        float logp = 0.f, kl = 0.f;
-        for (int j = 0; j < A; ++j) {
-            const float sg = sstd[j], mu = mean[(long long)b * A + j], a = actions[r * A + j];
-            const float d = a - mu;
-            logp += (-(d * d) / (2.0f * (sg * sg)) - logf(sg)) - 0.918938533204672742f;
-            const float so = old_sigma[r * A + j], mo = old_mu[r * A + j];
-            const float dm = mo - mu;
-            kl += (logf(sg / so + 1.e-5f) + (so * so + dm * dm) / (2.0f * (sg * sg))) - 0.5f;
-        }
-        s_kl = (double)kl;
-        const float ratio = expf(logp - old_logp[r]);
-        const float ad = adv[r];
-        const float lo = 1.0f - cfg.clip_param, hi = 1.0f + cfg.clip_param;
-        const float rc = fminf(fmaxf(ratio, lo), hi);
-        const float s1 = -ad * ratio, s2 = -ad * rc;
-        s_sur = (double)fmaxf(s1, s2);
-        const bool inrange = ratio >= lo && ratio <= hi;
-        float w = 0.f;                                            // weight of the d(-A*ratio) path
-        if (s1 > s2) w = 1.0f;
-        else if (s1 == s2) w = inrange ? 1.0f : 0.5f;            // tie: half to each branch of max()
-        dlogp_scale = w * (-ad) * ratio * invB;
-        const float v = value[b], ret = returns[r];
-        float dv;
-        if (cfg.use_clipped_value_loss) {
-            const float tv = old_values[r];
-            const float dlt = v - tv;
-            const float vc = tv + fminf(fmaxf(dlt, -cfg.clip_param), cfg.clip_param);
-            const float e1 = v - ret, e2 = vc - ret;
-            const float l1 = e1 * e1, l2 = e2 * e2;
-            s_val = (double)fmaxf(l1, l2);
-            const bool clip_pass = dlt >= -cfg.clip_param && dlt <= cfg.clip_param;
-            const float g1 = 2.0f * e1, g2 = clip_pass ? 2.0f * e2 : 0.f;
-            dv = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * (g1 + g2));
-        } else {
-            const float e1 = ret - v;
-            s_val = (double)(e1 * e1);
-            dv = -2.0f * e1;
-        }
-        dvalue[b] = cfg.value_loss_coef * dv * invB;
+// One row of ppo.py:288-327: Normal log-prob, KL to the rollout policy, clipped surrogate, (clipped) value loss.
+// In: mean[A] / value of this row, r = row of the rollout tensors.  Out: dmean[A], dvalue, dstd terms (ds[A]), sums.
+struct RowLoss {
+    double s_sur, s_val, s_kl;
+    float dvalue;
+};
+__device__ __forceinline__ RowLoss ppo_row_loss(const float* mean_row, float v, const float* sstd, const float* __restrict__ actions,
+                                                const float* __restrict__ old_logp, const float* __restrict__ old_mu,
+                                                const float* __restrict__ old_sigma, const float* __restrict__ adv,
+                                                const float* __restrict__ returns, const float* __restrict__ old_values,
+                                                long long r, const DtcPpoCfg& cfg, float invB, int A, float* dmean_row, float* ds_row) {
+    RowLoss o;
+    float logp = 0.f, kl = 0.f;
+    for (int j = 0; j < A; ++j) {
+        const float sg = sstd[j], mu = mean_row[j], a = actions[r * A + j];
+        const float d = a - mu;
+        logp += (-(d * d) / (2.0f * (sg * sg)) - logf(sg)) - 0.918938533204672742f;
+        const float so = old_sigma[r * A + j], mo = old_mu[r * A + j];
+        const float dm = mo - mu;
+        kl += (logf(sg / so + 1.e-5f) + (so * so + dm * dm) / (2.0f * (sg * sg))) - 0.5f;
     }
-    // all 3 + A block sums with ONE barrier: every wave reduces its values with shuffles, lane 0 parks them in LDS, then
-    // thread k adds the (at most 4) wave results of value k in wave order
+    o.s_kl = (double)kl;
+    const float ratio = expf(logp - old_logp[r]);
+    const float ad = adv[r];
+    const float lo = 1.0f - cfg.clip_param, hi = 1.0f + cfg.clip_param;
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float s1 = -ad * ratio, s2 = -ad * rc;
+    o.s_sur = (double)fmaxf(s1, s2);
+    const bool inrange = ratio >= lo && ratio <= hi;
+    float w = 0.f;                                            // weight of the d(-A*ratio) path
+    if (s1 > s2) w = 1.0f;
+    else if (s1 == s2) w = inrange ? 1.0f : 0.5f;            // tie: half to each branch of max()
+    const float dlogp_scale = w * (-ad) * ratio * invB;       // dL/dlogp of this row
+    const float ret = returns[r];
+    float dv;
+    if (cfg.use_clipped_value_loss) {
+        const float tv = old_values[r];
+        const float dlt = v - tv;
+        const float vc = tv + fminf(fmaxf(dlt, -cfg.clip_param), cfg.clip_param);
+        const float e1 = v - ret, e2 = vc - ret;
+        const float l1 = e1 * e1, l2 = e2 * e2;
+        o.s_val = (double)fmaxf(l1, l2);
+        const bool clip_pass = dlt >= -cfg.clip_param && dlt <= cfg.clip_param;
+        const float g1 = 2.0f * e1, g2 = clip_pass ? 2.0f * e2 : 0.f;
+        dv = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * (g1 + g2));
+    } else {
+        const float e1 = ret - v;
+        o.s_val = (double)(e1 * e1);
+        dv = -2.0f * e1;
+    }
+    o.dvalue = cfg.value_loss_coef * dv * invB;
+    for (int j = 0; j < A; ++j) {
+        const float sg = sstd[j], mu = mean_row[j], a = actions[r * A + j];
+        const float d = a - mu;
+        dmean_row[j] = dlogp_scale * (d / (sg * sg));
+        ds_row[j] = dlogp_scale * ((d * d) / (sg * sg * sg) - 1.0f / sg);
+    }
+    return o;
+}
+
+// all 3 + A block sums with ONE barrier: every wave reduces its values with shuffles, lane 0 parks them in LDS, then
+// thread k adds the (at most 4) wave results of value k in wave order.  per-block partial layout: [0] surrogate sum,
+// [1] value-loss sum, [2] kl sum, [3 .. 3+A) dstd sums
+__device__ __forceinline__ void ppo_block_partials(double s_sur, double s_val, double s_kl, const float* ds_row, bool ok, int A,
+                                                   double* __restrict__ part) {
     __shared__ double red[4][3 + MAX_ACT];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    double v0 = wave_sum_d(s_sur), v1 = wave_sum_d(s_val), v2 = wave_sum_d(s_kl);
+    const double v0 = wave_sum_d(s_sur), v1 = wave_sum_d(s_val), v2 = wave_sum_d(s_kl);
     if (lane == 0) {
         red[wv][0] = v0;
         red[wv][1] = v1;
         red[wv][2] = v2;
     }
     for (int j = 0; j < A; ++j) {
-        double ds = 0.0;
-        if (ok) {
-            const float sg = sstd[j], mu = mean[(long long)b * A + j], a = actions[r * A + j];
-            const float d = a - mu;
-            dmean[(long long)b * A + j] = dlogp_scale * (d / (sg * sg));
-            ds = (double)(dlogp_scale * ((d * d) / (sg * sg * sg) - 1.0f / sg));
-        }
-        ds = wave_sum_d(ds);
+        const double ds = wave_sum_d(ok ? (double)ds_row[j] : 0.0);
         if (lane == 0) red[wv][3 + j] = ds;
     }
     __syncthreads();
@@ -215,6 +210,130 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__
         for (int w = 0; w < nw; ++w) t += red[w][threadIdx.x];
         part[(long long)blockIdx.x * (3 + MAX_ACT) + threadIdx.x] = t;
     }
+}
+
+__global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__ mean, const float* __restrict__ stdp,
+                                                       const float* __restrict__ value, const float* __restrict__ actions,
+                                                       const float* __restrict__ old_logp, const float* __restrict__ old_mu,
+                                                       const float* __restrict__ old_sigma, const float* __restrict__ adv,
+                                                       const float* __restrict__ returns, const float* __restrict__ old_values,
+                                                       const long long* __restrict__ idx, DtcPpoCfg cfg,
+                                                       float* __restrict__ dmean, float* __restrict__ dvalue,
+                                                       double* __restrict__ part, int B, int A) {
+    __shared__ float sstd[MAX_ACT];
+    if (threadIdx.x < A) sstd[threadIdx.x] = stdp[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = b < B;
+    RowLoss o{0.0, 0.0, 0.0, 0.f};
+    float mrow[MAX_ACT], dm[MAX_ACT], ds[MAX_ACT];
+    if (ok) {
+        const long long r = idx ? idx[b] : (long long)b;
+        for (int j = 0; j < A; ++j) mrow[j] = mean[(long long)b * A + j];
+        o = ppo_row_loss(mrow, value[b], sstd, actions, old_logp, old_mu, old_sigma, adv, returns, old_values, r, cfg,
+                         1.0f / (float)B, A, dm, ds);
+        dvalue[b] = o.dvalue;
+        for (int j = 0; j < A; ++j) dmean[(long long)b * A + j] = dm[j];
+    }
+    ppo_block_partials(o.s_sur, o.s_val, o.s_kl, ds, ok, A, part);
+}
+
+// ---------------------------------------------------------------------------------- heads + PPO losses, fused
+// The last layers of the actor (H -> A) and the critic (H -> 1), the PPO losses, and the data gradients of those two
+// layers in ONE kernel (round 2): five latency-bound launches on the critical path of every policy step (two 12 us head
+// GEMMs, the loss, two head data gradients) become one.  256 threads = 64 rows x 4 threads; thread (row, p) owns the
+// 16-byte chunks c = p + 4 i of its row of both hidden activations (kept in registers from the forward dot products to
+// the backward products), the head weights sit in LDS (broadcast reads), the four partial dot products of a row are
+// combined by two quad butterflies, every thread of the row then holds mean / value and evaluates the row's loss.
+// dH = (d_out W) * act'(H) with the derivative through the saved post-activation value, as linear_dgrad_kernel does.
+template <int H>
+__global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
+    const float* __restrict__ Ha, long long ldha, const float* __restrict__ Hc, long long ldhc, const float* __restrict__ Wa,
+    const float* __restrict__ ba, const float* __restrict__ Wc, const float* __restrict__ bc, int act_prev,
+    const float* __restrict__ stdp, const float* __restrict__ actions, const float* __restrict__ old_logp,
+    const float* __restrict__ old_mu, const float* __restrict__ old_sigma, const float* __restrict__ adv,
+    const float* __restrict__ returns, const float* __restrict__ old_values, const long long* __restrict__ idx, DtcPpoCfg cfg,
+    float* __restrict__ mean, float* __restrict__ value, float* __restrict__ dmean, float* __restrict__ dvalue,
+    float* __restrict__ dHa, long long lddha, float* __restrict__ dHc, long long lddhc, double* __restrict__ part, int B, int A) {
+    constexpr int NC = H / 16;                       // chunks per thread
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float W[(MAX_ACT + 1) * H];      // rows 0..A-1: actor head, row A: critic head
+    __shared__ float sstd[MAX_ACT], sb[MAX_ACT + 1];
+    for (int e = threadIdx.x; e < (A + 1) * H; e += 256) W[e] = e < A * H ? Wa[e] : Wc[e - A * H];
+    if ((int)threadIdx.x < A) {
+        sstd[threadIdx.x] = stdp[threadIdx.x];
+        sb[threadIdx.x] = ba ? ba[threadIdx.x] : 0.f;
+    }
+    if (threadIdx.x == 0) sb[A] = bc ? bc[0] : 0.f;
+    __syncthreads();
+    const int row = blockIdx.x * 64 + (threadIdx.x >> 2), p = threadIdx.x & 3;
+    const bool rok = row < B;
+    const long long rr = rok ? row : 0;
+    f4 ha[NC], hc[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        ha[i] = *reinterpret_cast<const f4*>(Ha + rr * ldha + 4 * (p + 4 * i));
+        hc[i] = *reinterpret_cast<const f4*>(Hc + rr * ldhc + 4 * (p + 4 * i));
+    }
+    // ---- forward: mean = Ha Wa^T + ba, value = Hc Wc^T + bc
+    float mrow[MAX_ACT], v = 0.f;
+    for (int j = 0; j < A; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const f4 w = *reinterpret_cast<const f4*>(&W[j * H + 4 * (p + 4 * i)]);
+            acc += ha[i].x * w.x + ha[i].y * w.y + ha[i].z * w.z + ha[i].w * w.w;
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        mrow[j] = acc + sb[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const f4 w = *reinterpret_cast<const f4*>(&W[A * H + 4 * (p + 4 * i)]);
+        v += hc[i].x * w.x + hc[i].y * w.y + hc[i].z * w.z + hc[i].w * w.w;
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += sb[A];
+    // ---- the row's loss (every thread of the row evaluates it; thread p = 0 stores and contributes the sums)
+    RowLoss o{0.0, 0.0, 0.0, 0.f};
+    float dm[MAX_ACT], ds[MAX_ACT];
+    const bool ok = rok && p == 0;
+    if (rok) {
+        const long long r = idx ? idx[row] : (long long)row;
+        o = ppo_row_loss(mrow, v, sstd, actions, old_logp, old_mu, old_sigma, adv, returns, old_values, r, cfg, 1.0f / (float)B, A,
+                         dm, ds);
+    }
+    if (ok) {
+        value[row] = v;
+        dvalue[row] = o.dvalue;
+        for (int j = 0; j < A; ++j) {
+            mean[(long long)row * A + j] = mrow[j];
+            dmean[(long long)row * A + j] = dm[j];
+        }
+    }
+    // ---- backward through the two heads: dHa = (dmean Wa) * act'(Ha), dHc = (dvalue Wc) * act'(Hc)
+    if (rok) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            f4 ga = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < A; ++j) {
+                const f4 w = *reinterpret_cast<const f4*>(&W[j * H + 4 * (p + 4 * i)]);
+                ga += dm[j] * w;
+            }
+            const f4 wc = *reinterpret_cast<const f4*>(&W[A * H + 4 * (p + 4 * i)]);
+            f4 gc = o.dvalue * wc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ga[e] = act_bwd(ga[e], ha[i][e], act_prev);
+                gc[e] = act_bwd(gc[e], hc[i][e], act_prev);
+            }
+            *reinterpret_cast<f4*>(dHa + rr * lddha + 4 * (p + 4 * i)) = ga;
+            *reinterpret_cast<f4*>(dHc + rr * lddhc + 4 * (p + 4 * i)) = gc;
+        }
+    }
+    ppo_block_partials(ok ? o.s_sur : 0.0, ok ? o.s_val : 0.0, ok ? o.s_kl : 0.0, ds, ok, A, part);
 }
 
 // wave w owns the values k = w, w + 4, ...: lanes add the per-block partials in a fixed stride order, one shuffle
@@ -353,6 +472,37 @@ extern "C" int dtc_ppo_loss(const float* mean, const float* std, const float* va
     hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, B, num_actions, std, *cfg, dstd,
                        losses, lr);
     return dtc::check_launch("ppo_loss");
+}
+
+extern "C" int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc, int64_t ldhc, int H, const float* Wa,
+                                  const float* ba, const float* Wc, const float* bc, int act_prev, const float* std,
+                                  const float* actions, const float* old_logp, const float* old_mu, const float* old_sigma,
+                                  const float* advantages, const float* returns, const float* old_values, const int64_t* idx,
+                                  const DtcPpoCfg* cfg, float* mean, float* value, float* dmean, float* dvalue, float* dHa,
+                                  int64_t lddha, float* dHc, int64_t lddhc, float* dstd, float* losses, double* lr,
+                                  void* workspace, int B, int num_actions, void* stream) {
+    DTC_REQUIRE(B > 0 && num_actions > 0 && num_actions <= MAX_ACT, "bad shape B=%d A=%d", B, num_actions);
+    DTC_REQUIRE(H == 64 || H == 128 || H == 256, "hidden width %d unsupported by the fused heads (64, 128, 256)", H);
+    DTC_REQUIRE(Ha && Hc && Wa && Wc && std && actions && old_logp && old_mu && old_sigma && advantages && returns && old_values,
+                "null input");
+    DTC_REQUIRE(cfg && mean && value && dmean && dvalue && dHa && dHc && dstd && losses && workspace, "null output");
+    DTC_REQUIRE(ldha >= H && ldhc >= H && lddha >= H && lddhc >= H && ldha % 4 == 0 && ldhc % 4 == 0 && lddha % 4 == 0 &&
+                    lddhc % 4 == 0 && dtc::aligned16(Ha) && dtc::aligned16(Hc) && dtc::aligned16(dHa) && dtc::aligned16(dHc),
+                "hidden activations must be 16-byte aligned with row strides that are multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (int)dtc::ceil_div(B, 64);
+    DTC_REQUIRE(nblk <= MAX_BLK, "batch too large for the loss workspace");
+    double* part = (double*)workspace;
+    dtc::ProfScope prof("ppo_heads_loss", (double)B * (4.0 * H * 4 + num_actions * 32.0), s);
+#define DTC_HL_ARGS Ha, (long long)ldha, Hc, (long long)ldhc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, \
+                    advantages, returns, old_values, (const long long*)idx, *cfg, mean, value, dmean, dvalue, dHa, (long long)lddha, \
+                    dHc, (long long)lddhc, part, B, num_actions
+    if (H == 64) hipLaunchKernelGGL(ppo_heads_loss_kernel<64>, dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
+    else if (H == 128) hipLaunchKernelGGL(ppo_heads_loss_kernel<128>, dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
+    else hipLaunchKernelGGL(ppo_heads_loss_kernel<256>, dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
+#undef DTC_HL_ARGS
+    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, B, num_actions, std, *cfg, dstd, losses, lr);
+    return dtc::check_launch("ppo_heads_loss");
 }
 
 extern "C" int dtc_gaussian_act(const float* mean, const float* std, const float* noise, float* actions, float* logp,

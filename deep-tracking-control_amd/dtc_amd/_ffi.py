@@ -120,6 +120,9 @@ _SIGS = {
                                                                              c_stream]),
     "dtc_ppo_loss": (C.c_int, [c_f32p] * 10 + [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 4 +
                      [c_f64p, C.c_void_p, C.c_int, C.c_int, c_stream]),
+    "dtc_ppo_heads_loss": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int] + [c_f32p] * 4 + [C.c_int] + [c_f32p] * 8 +
+                           [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 5 + [C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f64p,
+                                                                      C.c_void_p, C.c_int, C.c_int, c_stream]),
     "dtc_lr_adapt": (C.c_int, [c_f32p, c_f64p, C.c_float, c_stream]),
     "dtc_gaussian_act": (C.c_int, [c_f32p] * 7 + [C.c_int, C.c_int, c_stream]),
     "dtc_adam_workspace": (C.c_int64, [C.c_int64]),

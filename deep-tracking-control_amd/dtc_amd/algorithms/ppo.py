@@ -258,6 +258,7 @@ class PPO:
         self._tws = {}
         # weight gradients on a side stream, concurrent with the data-gradient chain (DTC_OVERLAP_WGRAD=0: serial)
         self.overlap_wgrad = os.environ.get("DTC_OVERLAP_WGRAD", "1") != "0"
+        self.fuse_heads = os.environ.get("DTC_FUSE_HEADS", "1") != "0"       # dtc_ppo_heads_loss in the policy step
         # two compute lanes (needs the side stream: both lanes' weight gradients share one partials workspace)
         self.overlap_lanes = os.environ.get("DTC_OVERLAP_LANES", "1") != "0"
         # weight gradients queued per gradient bucket and run as one grouped launch (DTC_WGRAD_GROUP=0: per layer)
@@ -538,29 +539,38 @@ class PPO:
             ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
         ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
         tw.order("aux", "main")                                    # z, mu feed the actor
+        # output layers + losses + their data gradients in one launch when the last hidden width allows it (DTC_FUSE_HEADS)
+        fuse = self.fuse_heads and fw.a3.shape[1] == fw.v3.shape[1] and fw.a3.shape[1] in (64, 128, 256)
         with tw.lane("aux"):
-            ac.critic_forward_(fw, flat["observations"], flat["base_vel"], flat["privileged_observations"], idx)
-        ac.actor_forward_(fw, flat["observations"], idx)
+            ac.critic_forward_(fw, flat["observations"], flat["base_vel"], flat["privileged_observations"], idx, head=not fuse)
+        ac.actor_forward_(fw, flat["observations"], idx, head=not fuse)
         tw.order("aux", "main")
         world = self._world()
-        ops.ppo_loss(fw.mean, ac.std_view, fw.val, flat["actions"], flat["actions_log_prob"], flat["mu"],
-                     flat["sigma"], flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval,
-                     ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
+        g_c3, g_a3 = tw.g("c3", 128), tw.g("a3", 128)
+        if fuse:
+            ops.ppo_heads_loss(fw.a3, fw.v3, L["a3"].W, L["a3"].b, L["c3"].W, L["c3"].b, act, ac.std_view, flat["actions"],
+                               flat["actions_log_prob"], flat["mu"], flat["sigma"], flat["advantages"], flat["returns"],
+                               flat["values"], idx, cfg, fw.mean, fw.val, tw.dmean, tw.dval, g_a3, g_c3, ac.std_grad,
+                               stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
+        else:
+            ops.ppo_loss(fw.mean, ac.std_view, fw.val, flat["actions"], flat["actions_log_prob"], flat["mu"],
+                         flat["sigma"], flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval,
+                         ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
         if world > 1 and cfg.adaptive_schedule == 0 and self._adaptive():
             dp.allreduce_mean_(stats[S_KL:S_KL + 1])
             ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
         tw.order("main", "aux")
         # critic (aux)
-        g_c3, g_c2, g_c1 = tw.g("c3", 128), tw.g("c2", 256), tw.g("c1", 512)
+        g_c2, g_c1 = tw.g("c2", 256), tw.g("c1", 512)
         with tw.lane("aux"):
-            self._bwd(tw, L["c3"], tw.dval, fw.v3, g_c3, fw.v3, act)
+            self._bwd(tw, L["c3"], tw.dval, fw.v3, None if fuse else g_c3, fw.v3, act)      # fused: weight gradient only
             self._bwd(tw, L["c2"], g_c3, fw.v2, g_c2, fw.v2, act)
             self._bwd(tw, L["c1"], g_c2, fw.v1, g_c1, fw.v1, act)
             self._bwd(tw, L["c0"], g_c1, ac.critic_input(flat["observations"], flat["base_vel"],
                                                          flat["privileged_observations"], idx))
         # actor (main); layer-0 input gradient fans out to z, mu[:, :3], l_t (observations need none)
-        g_a3, g_a2, g_a1 = tw.g("a3", 128), tw.g("a2", 256), tw.g("a1", 512)
-        self._bwd(tw, L["a3"], tw.dmean, fw.a3, g_a3, fw.a3, act)
+        g_a2, g_a1 = tw.g("a2", 256), tw.g("a1", 512)
+        self._bwd(tw, L["a3"], tw.dmean, fw.a3, None if fuse else g_a3, fw.a3, act)
         self._bwd(tw, L["a2"], g_a3, fw.a2, g_a2, fw.a2, act)
         self._bwd(tw, L["a1"], g_a2, fw.a1, g_a1, fw.a1, act)
         tw.dmulv.zero_()

@@ -335,19 +335,22 @@ class ActorCriticDecoder(nn.Module):
         return segmat([seg(obs, 0, self.num_obs, gather=g), seg(base_vel, 0, 3, gather=g),
                        seg(priv, 693, 696, gather=g)], idx)
 
-    def actor_forward_(self, ws, obs, idx=None):
+    def actor_forward_(self, ws, obs, idx=None, head=True):
+        """`head=False`: stop before the output layer (the trainer's fused heads + loss kernel computes it)."""
         L, act = self.L, AC_Args.activation
         ops.linear_fwd(self.actor_input(ws, obs, idx), L["a0"].W, L["a0"].b, ws.a1, act, M=ws.B)
         ops.linear_fwd(ws.a1, L["a1"].W, L["a1"].b, ws.a2, act)
         ops.linear_fwd(ws.a2, L["a2"].W, L["a2"].b, ws.a3, act)
-        ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None)
+        if head:
+            ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None)
 
-    def critic_forward_(self, ws, obs, base_vel, priv, idx=None):
+    def critic_forward_(self, ws, obs, base_vel, priv, idx=None, head=True):
         L, act = self.L, AC_Args.activation
         ops.linear_fwd(self.critic_input(obs, base_vel, priv, idx), L["c0"].W, L["c0"].b, ws.v1, act, M=ws.B)
         ops.linear_fwd(ws.v1, L["c1"].W, L["c1"].b, ws.v2, act)
         ops.linear_fwd(ws.v2, L["c2"].W, L["c2"].b, ws.v3, act)
-        ops.linear_fwd(ws.v3, L["c3"].W, L["c3"].b, ws.val, None)
+        if head:
+            ops.linear_fwd(ws.v3, L["c3"].W, L["c3"].b, ws.val, None)
 
     # ------------------------------------------------------------------ reference API
     def reset(self, dones=None):

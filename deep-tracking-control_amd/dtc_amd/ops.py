@@ -232,6 +232,21 @@ def vae_loss_fused(recons, mulv, next_obs, base_vel, idx, d_recons, dmulv, heigh
                                    n_height_part, ptr(losses), ptr(ws), B, stream()), "dtc_vae_loss_fused")
 
 
+def ppo_heads_loss(Ha, Hc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, advantages, returns, old_values,
+                   idx, cfg, mean, value, dmean, dvalue, dHa, dHc, dstd, losses, lr, ws):
+    """Output layers of actor and critic + dtc_ppo_loss + their data gradients in one launch (see dtc_hip.h).
+    Ha / Hc [B,H] last hidden activations (post-activation, `act_prev`), dHa / dHc [B,H] receive their gradients."""
+    B, H = Ha.shape
+    A = Wa.shape[0]
+    check(lib().dtc_ppo_heads_loss(cptr(Ha, f32), Ha.stride(0), cptr(Hc, f32), Hc.stride(0), H, cptr(Wa, f32), cptr(ba, f32),
+                                   cptr(Wc, f32), cptr(bc, f32), ACT[act_prev], ptr(std), cptr(actions, f32), cptr(old_logp, f32),
+                                   cptr(old_mu, f32), cptr(old_sigma, f32), cptr(advantages, f32), cptr(returns, f32),
+                                   cptr(old_values, f32), cptr(idx, torch.int64) if idx is not None else None, cfg,
+                                   cptr(mean, f32), cptr(value, f32), cptr(dmean, f32), cptr(dvalue, f32), cptr(dHa, f32),
+                                   dHa.stride(0), cptr(dHc, f32), dHc.stride(0), ptr(dstd), ptr(losses), ptr(lr), ptr(ws), B, A,
+                                   stream()), "dtc_ppo_heads_loss")
+
+
 def ppo_loss(mean, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, old_values, idx, cfg,
              dmean, dvalue, dstd, losses, lr, ws):
     B, A = mean.shape

@@ -289,6 +289,19 @@ int dtc_ppo_loss(const float* mean, const float* std, const float* value, const 
                  const float* returns, const float* old_values, const int64_t* idx, const DtcPpoCfg* cfg,
                  float* dmean, float* dvalue, float* dstd, float* losses, double* lr, void* workspace,
                  int B, int num_actions, void* stream);
+/* The actor's and the critic's output layers (mean = Ha Wa^T + ba, value = Hc Wc^T + bc over the last hidden activations
+ * Ha, Hc [B,H], H in {64, 128, 256}), dtc_ppo_loss on them, and the data gradients of the two layers
+ * (dHa = (dmean Wa) * act'(Ha), dHc = (dvalue Wc) * act'(Hc), act' through the saved post-activation values as in
+ * dtc_linear_dgrad) in ONE launch + the finalize launch: replaces two dtc_linear_fwd, dtc_ppo_loss and two
+ * dtc_linear_dgrad calls on the critical path of every policy step (ppo.py:288-327 with actor_critic_decoder.py:
+ * 330-345).  Also writes mean [B,A], value [B], dmean, dvalue (the weight gradients of the two layers need them). */
+int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc, int64_t ldhc, int H, const float* Wa /*[A,H]*/,
+                       const float* ba, const float* Wc /*[1,H]*/, const float* bc, int act_prev, const float* std,
+                       const float* actions, const float* old_logp, const float* old_mu, const float* old_sigma,
+                       const float* advantages, const float* returns, const float* old_values, const int64_t* idx,
+                       const DtcPpoCfg* cfg, float* mean, float* value, float* dmean, float* dvalue, float* dHa,
+                       int64_t lddha, float* dHc, int64_t lddhc, float* dstd, float* losses, double* lr, void* workspace,
+                       int B, int num_actions, void* stream);
 /* The learning-rate rule of ppo.py:301-307 alone (data-parallel callers run dtc_ppo_loss with
  * adaptive_schedule = 0, all-reduce the KL mean, then call this so every rank takes the same branch). */
 int dtc_lr_adapt(const float* kl_mean, double* lr, float desired_kl, void* stream);

@@ -439,6 +439,43 @@ def test_overlapped_schedule_equals_serial_schedule_bitwise():
             assert torch.equal(v, other[2][k]), k
 
 
+def test_fused_heads_loss_equals_the_five_launches():
+    """dtc_ppo_heads_loss (output layers + PPO losses + their data gradients in one launch) against the unfused sequence
+    (two forward GEMMs, dtc_ppo_loss, two data-gradient GEMMs) on the same policy step at full mini-batch size: every
+    gradient and the four loss scalars agree to fp32 dot-product rounding (the heads' 128-term sums are accumulated in a
+    different order: VALU fma chains vs MFMA)."""
+    from dtc_amd.algorithms import PPO
+    from dtc_amd.algorithms import ppo as P
+    from dtc_amd.modules import ActorCriticDecoder
+    d = S.rollout(4096, 24, seed=4, device=DEV)
+    perm, e1, e2 = S.update_noise(4096, 24, 4, 5, seed=123)
+    got = []
+    for fuse in (True, False):
+        torch.manual_seed(3)
+        ac = ActorCriticDecoder(53, 1389, 12)
+        alg = PPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV)
+        alg.fuse_heads = fuse
+        alg.capture_grads = True
+        alg.init_storage(4096, 24, [53], [1389], [265], [12])
+        for k, v in d.items():
+            if k != "last_values":
+                getattr(alg.storage, k).copy_(v)
+        alg.storage.compute_returns(d["last_values"], 0.99, 0.95)
+        B = 24576
+        row, lr = alg.step_minibatch(perm[:B].to(DEV), e1[0].to(DEV), e2[0].to(DEV), which="ppo")
+        fw = ac._fwd_ws(B)
+        got.append((row.clone(), lr, alg.captured["main"].clone(), fw.mean.clone(), fw.val.clone()))
+    (r1, lr1, g1, m1, v1), (r0, lr0, g0, m0, v0) = got
+    assert lr1 == lr0
+    for col in (P.S_SURR, P.S_VALUE, P.S_ENTROPY, P.S_KL, P.S_GNORM):
+        assert abs(float(r1[col]) - float(r0[col])) <= 2e-6 * max(1.0, abs(float(r0[col]))), (col, float(r1[col]), float(r0[col]))
+    assert float((m1 - m0).abs().max()) <= 2e-6 * max(1.0, float(m0.abs().max()))
+    assert float((v1 - v0).abs().max()) <= 2e-6 * max(1.0, float(v0.abs().max()))
+    scale = float(g0.abs().max())
+    assert float((g1 - g0).abs().max()) <= 2e-5 * scale
+    assert float((g1 - g0).norm()) <= 1e-5 * float(g0.norm())
+
+
 def test_training_survives_model_to_calls():
     """`.to()` on the model must not orphan the optimiser's views of the parameter arena.  (a) a same-device
     `.to()` (what OnPolicyRunner.get_inference_policy(device=...) does) keeps the arena; (b) a real round trip
