@@ -265,11 +265,12 @@ def main():
         pl = [r for r in rep if r["name"].split("[")[0] == "foothold_plan"]
         if pl:                                  # the HBM-side kernel of the path: bytes = 3096 B/env
             pms, pby, pn = (sum(r[k] for r in pl) for k in ("ms_total", "work", "launches"))
-            planner = dict(bound="hbm", kernel="foothold_plan_kernel", achieved=pby / (pms * 1e-3) / 1e9, peak=8000.0,
+            planner = dict(bound="hbm", kernel="foothold_plan_fast_kernel", achieved=pby / (pms * 1e-3) / 1e9, peak=8000.0,
                            unit="GB/s", frac=pby / (pms * 1e-3) / 1e9 / 8000.0,
-                           traffic=306.3e6 * (pby / pn) / (3096.0 * 98304),
-                           traffic_source="rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_planner_pmc.md "
-                                          "(VALU-bound: SQ_ACTIVE_INST_VALU ~ 100 % of the kernel's cycles)",
+                           traffic=301.8e6 * (pby / pn) / (3096.0 * 98304),
+                           traffic_source="rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_planner_pmc.md "
+                                          "(instruction-bound: SQ_ACTIVE_INST_VALU = 86 % of the kernel's cycles; rocprofv3 "
+                                          "kernel durations over 110 launches: 110 us average, 102 us minimum)",
                            launches=pn, avg_launch_us=pms * 1e3 / pn, bytes_per_launch=pby / pn)
         classes = {r["name"]: dict(ms=round(r["ms_total"], 3), launches=r["launches"],
                                    rate=(r["work"] / (r["ms_total"] * 1e-3) / 1e12) if r["ms_total"] > 0 else 0.0)

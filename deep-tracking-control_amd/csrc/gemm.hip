@@ -86,11 +86,14 @@ __device__ unsigned long long* g_trace = nullptr;
 #define DTC_STAMP(i)
 #endif
 
+#ifndef DTC_FWD_WAVES
+#define DTC_FWD_WAVES 5      // workgroups per CU the register allocator aims at for the forward kernel (tuning aid)
+#endif
 // DEEP = true: the variant for launches that leave a CU with about one workgroup (rollout-sized batches): operand loads run TWO stages ahead of the MFMAs (two register sets, k-tail masks applied when a set is stored
 // to LDS, every stage takes the masked form) -- the single-stage pipeline relies on the other workgroups of the CU to
 // cover the load latency, and there are none.
 template <int BN, bool MSE = false, bool DEEP = false>
-__global__ __launch_bounds__(256, DEEP ? 3 : 5) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
+__global__ __launch_bounds__(256, DEEP ? 3 : DTC_FWD_WAVES) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ Y,
                                                          long long ldy, int M, int N, int K, int act, int wide,
                                                          const MseEpi mse) {
