@@ -87,18 +87,22 @@ __device__ unsigned long long* g_trace = nullptr;
 #endif
 
 #ifndef DTC_FWD_WAVES
-#define DTC_FWD_WAVES 5      // workgroups per CU the register allocator aims at for the forward kernel (tuning aid)
+#define DTC_FWD_WAVES 4      // workgroups per CU the register allocator aims at for the forward kernel (tuning aid)
 #endif
 // DEEP = true: the variant for launches that leave a CU with about one workgroup (rollout-sized batches): operand loads run TWO stages ahead of the MFMAs (two register sets, k-tail masks applied when a set is stored
 // to LDS, every stage takes the masked form) -- the single-stage pipeline relies on the other workgroups of the CU to
 // cover the load latency, and there are none.
 template <int BN, bool MSE = false, bool DEEP = false>
-__global__ __launch_bounds__(256, DEEP ? 3 : DTC_FWD_WAVES) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
+__global__ __launch_bounds__(256, DEEP ? 3 : (BN == 128 ? 2 : DTC_FWD_WAVES)) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ Y,
                                                          long long ldy, int M, int N, int K, int act, int wide,
                                                          const MseEpi mse) {
-    constexpr int TN = BN / 32;
+    // wave layout: BN <= 64: four waves stacked along the rows, each 32 x BN; BN = 128: 2 x 2 waves, each 64 x 64 (2 x 2 MFMA
+    // tiles: 8 ds_read_b128 feed 32 MFMAs per stage instead of 6 for 16, one barrier covers twice the MFMA work)
+    constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int NA = BM / 64;                      // loader passes over the 128 X rows
+    constexpr int NB = (BN + 63) / 64;               // loader passes over the W rows of the tile
     DTC_STAMP(0);
     __shared__ f32x4 As[2][BM * 4];
     __shared__ f32x4 Bs[2][BN * 4];
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : DTC_FWD_WAVES) void linear_fwd_kern
     }
     const int m0 = tr * BM, n0 = tc * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm_off = wave * 32;
+    const int wm_off = (wave / WN) * (32 * TM), wn_off = (wave % WN) * (32 * TN);
     const int half = lane >> 5, l31 = lane & 31;
 
     // loader geometry: thread owns chunk lch of rows lrow (+64) of X and of row lrow of W
@@ -124,9 +128,14 @@ __global__ __launch_bounds__(256, DEEP ? 3 : DTC_FWD_WAVES) void linear_fwd_kern
         grow[i] = (any_gather && m < M) ? (int)X.idx[m] : arow[i];
         aslot[i] = kslot(r, lch);
     }
-    const int wn = n0 + lrow;
-    const u32 woff = (bthread && wn < N) ? (u32)(wn * K + 4 * lch) * 4u : INVALID;
-    const int bslot = kslot(lrow, lch);
+    u32 woff[NB];
+    int bslot[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int wn = n0 + lrow + 64 * i;
+        woff[i] = (bthread && wn < N) ? (u32)(wn * K + 4 * lch) * 4u : INVALID;
+        bslot[i] = kslot(lrow + 64 * i, lch);
+    }
     const rsrc_t wres = make_rsrc_bytes(W, (long long)N * K * 4);
 
     // K loop: segment by segment.  The steady-state loop over the full stages of a segment is ONE basic block (loads
@@ -143,47 +152,55 @@ __global__ __launch_bounds__(256, DEEP ? 3 : DTC_FWD_WAVES) void linear_fwd_kern
             aoff[i] = r >= 0 ? ((u32)r * (u32)sd.ld + (u32)(sd.col0 + 4 * lch)) * 4u : INVALID;
         }
     };
-    f32x4 ra[NA], rb;
+    f32x4 ra[NA], rb[NB];
     auto load_stage = [&](auto masked, int kt) {     // stage kt of the current segment -> registers
         const u32 ka = (u32)(kt * BK) * 4u, kw = (u32)(sd.start + kt * BK) * 4u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = bload4(ares, aoff[i], ka);
-        rb = bload4(wres, woff, kw);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = bload4(wres, woff[i], kw);
         if (decltype(masked)::value) {
             const int k0 = kt * BK + 4 * lch;
 #pragma unroll
             for (int i = 0; i < NA; ++i) ra[i] = ktail(ra[i], k0, sd.width - 1);
-            rb = ktail(rb, k0, sd.width - 1);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = ktail(rb[i], k0, sd.width - 1);
         }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) As[buf][aslot[i]] = ra[i];
-        if (BN >= 64 || bthread) Bs[buf][bslot] = rb;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (BN >= 64 || bthread) Bs[buf][bslot[i]] = rb[i];
     };
 
-    f32x16 acc[TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int frow = wm_off + l31, fsw = (frow >> 2) & 3;
     auto mfma_stage = [&](int buf) {
-        f32x4 a[2], b[TN][2];
+        f32x4 a[TM][2], b[TN][2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            a[q] = As[buf][frow * 4 + ((2 * q + half) ^ fsw)];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j][q] = Bs[buf][kslot(32 * j + l31, 2 * q + half)];
+            for (int i = 0; i < TM; ++i) a[i][q] = As[buf][kslot(wm_off + 32 * i + l31, 2 * q + half)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j][q] = Bs[buf][kslot(wn_off + 32 * j + l31, 2 * q + half)];
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][t], b[j][q][t], acc[j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q][t], b[j][q][t], acc[i][j], 0, 0, 0);
     };
 
     int buf = 0;
@@ -199,13 +216,14 @@ __global__ __launch_bounds__(256, DEEP ? 3 : DTC_FWD_WAVES) void linear_fwd_kern
         int total = 0;
         for (int i = 0; i < X.nseg; ++i) total += (X.s[i].width + BK - 1) / BK;
         int lseg = 0, lkt = 0, ln = (sd.width + BK - 1) / BK;          // load cursor: next stage to request
-        f32x4 qa[2][NA], qb[2];
+        f32x4 qa[2][NA], qb[2][NB];
         int qtail[2];                                                    // last valid element (0..3) of a set's chunks
-        auto request = [&](f32x4 (&a)[NA], f32x4& b, int& tail) {
+        auto request = [&](f32x4 (&a)[NA], f32x4 (&b)[NB], int& tail) {
             const u32 ka = (u32)(lkt * BK) * 4u, kw = (u32)(sd.start + lkt * BK) * 4u;
 #pragma unroll
             for (int i = 0; i < NA; ++i) a[i] = bload4(ares, aoff[i], ka);
-            b = bload4(wres, woff, kw);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) b[i] = bload4(wres, woff[i], kw);
             tail = (sd.width - 1) - (lkt * BK + 4 * lch);
             if (++lkt == ln && ++lseg < X.nseg) {
                 sd = X.s[lseg];
@@ -214,10 +232,12 @@ __global__ __launch_bounds__(256, DEEP ? 3 : DTC_FWD_WAVES) void linear_fwd_kern
                 ln = (sd.width + BK - 1) / BK;
             }
         };
-        auto commit = [&](int b, f32x4 (&a)[NA], f32x4& w, int tail) {   // registers -> LDS (waits for the loads here)
+        auto commit = [&](int b, f32x4 (&a)[NA], f32x4 (&w)[NB], int tail) {   // registers -> LDS (waits for the loads here)
 #pragma unroll
             for (int i = 0; i < NA; ++i) As[b][aslot[i]] = ktail(a[i], 0, tail);
-            if (BN >= 64 || bthread) Bs[b][bslot] = ktail(w, 0, tail);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                if (BN >= 64 || bthread) Bs[b][bslot[i]] = ktail(w[i], 0, tail);
         };
         request(qa[0], qb[0], qtail[0]);
         if (total > 1) request(qa[1], qb[1], qtail[1]);
@@ -259,11 +279,13 @@ __global__ __launch_bounds__(256, DEEP ? 3 : DTC_FWD_WAVES) void linear_fwd_kern
         const rsrc_t tres = make_rsrc_bytes(mse.target, mse.target_bytes);
         double sq = 0.0;
 #pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + 32 * j + l31;
+            const int col = n0 + wn_off + 32 * j + l31;
             const bool cok = col < N;
             const float bv = (bias && cok) ? bias[col] : 0.f;
-            const int row0 = m0 + wm_off + 4 * half;
+            const int row0 = m0 + wm_off + 32 * i + 4 * half;
             float t[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {          // 16 gathered target loads in flight (rows past M read row 0, masked below)
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : DTC_FWD_WAVES) void linear_fwd_kern
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + (r & 3) + 8 * (r >> 2);
                 if (cok && row < M) {
-                    const float e = (acc[j][r] + bv) - t[r];
+                    const float e = (acc[i][j][r] + bv) - t[r];
                     Y[(long long)row * ldy + col] = e * mse.scale;
                     sq += (double)e * (double)e;
                 }
@@ -295,12 +317,14 @@ __global__ __launch_bounds__(256, DEEP ? 3 : DTC_FWD_WAVES) void linear_fwd_kern
         float* patch = reinterpret_cast<float*>(&As[0][0]) + wave * (32 * LDW);
         const int prow = lane >> 3, pc4 = lane & 7;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float bv = bias ? bias[n0 + 32 * j + l31] : 0.f;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] += bv;
-            patch_put(patch, acc[j], half, l31);
-            float* yp = &Y[(long long)(m0 + wm_off + prow) * ldy + n0 + 32 * j + 4 * pc4];
+        for (int j = 0; j < TN; ++j) {
+            const float bv = bias ? bias[n0 + wn_off + 32 * j + l31] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+            patch_put(patch, acc[i][j], half, l31);
+            float* yp = &Y[(long long)(m0 + wm_off + 32 * i + prow) * ldy + n0 + wn_off + 32 * j + 4 * pc4];
             // the activation is wave-uniform: one branch per tile, not a select around expm1f per element
             if (act == DTC_ACT_ELU) {
 #pragma unroll
@@ -335,17 +359,19 @@ __global__ __launch_bounds__(256, DEEP ? 3 : DTC_FWD_WAVES) void linear_fwd_kern
         return;
     }
 #pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + 32 * j + l31;
+        const int col = n0 + wn_off + 32 * j + l31;
         const bool cok = col < N;
         const float bv = (bias && cok) ? bias[col] : 0.f;
-        float* yp = Y + (long long)(m0 + wm_off + 4 * half) * ldy + col;
+        float* yp = Y + (long long)(m0 + wm_off + 32 * i + 4 * half) * ldy + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ro = (r & 3) + 8 * (r >> 2);
-            const float v = act_fwd(acc[j][r] + bv, act);
+            const float v = act_fwd(acc[i][j][r] + bv, act);
             if (full) yp[(long long)ro * ldy] = v;
-            else if (cok && m0 + wm_off + 4 * half + ro < M) yp[(long long)ro * ldy] = v;
+            else if (cok && m0 + wm_off + 32 * i + 4 * half + ro < M) yp[(long long)ro * ldy] = v;
         }
     }
 }
@@ -709,8 +735,16 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 6) void linear_dgrad_kernel(const f
 // workgroups -> prologue / epilogue of one block overlap the MFMA phase of its neighbours, 4 waves/SIMD);
 // when even those leave the chip short of workgroups (narrow layers, the ~1500-row GEMMs of one GRU time
 // step) 128x32 tiles double the count again
+// 128 x 128 tiles (2 x 2 waves of 64 x 64) for launches that still fill the chip with them: >= 700 tiles, i.e. three per CU
+// (DTC_GEMM_128_BLOCKS; lab: 133.6 vs 129-130 TFLOP/s on 24576x512x512, 99 vs 121 on 24576x256x512 where only 384 tiles remain)
+bool wide_tiles(int rows, int cols) {
+    const char* e = getenv("DTC_GEMM_128_BLOCKS");
+    const long long thr = e ? atoll(e) : 700;
+    return thr > 0 && cols >= 128 && dtc::ceil_div(rows, BM) * dtc::ceil_div(cols, 128) >= thr;
+}
+
 int pick_bn_rows(int rows, int cols) {
-    static const char* force = getenv("DTC_GEMM_BN");          // tuning aid: 32 | 64 (128x128 tiles were measured slower and are not built)
+    static const char* force = getenv("DTC_GEMM_BN");          // tuning aid: 32 | 64
     if (force && cols > 64) return atoi(force) == 32 ? 32 : 64;
     if (cols <= 32) return 32;
     static const char* thr_env = getenv("DTC_GEMM_MIN_BLOCKS");
@@ -766,13 +800,15 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     int rc = to_dev(X, xd, K, false, M);
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int bn = pick_bn_rows(M, N);
+    const int bn = wide_tiles(M, N) ? 128 : pick_bn_rows(M, N);
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, bn));
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     // dwordx4 stores of the output need 16-byte aligned rows (full tiles only; checked per block)
     static const bool wide_off = getenv("DTC_GEMM_WIDE") && atoi(getenv("DTC_GEMM_WIDE")) == 0;      // A/B switch
     const int wide = (!wide_off && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
-    if (deep_variant(grid)) {
+    if (bn == 128) {
+        hipLaunchKernelGGL((linear_fwd_kernel<128, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
+    } else if (deep_variant(grid)) {
         if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
         else hipLaunchKernelGGL((linear_fwd_kernel<32, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
     } else if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), occ_pad("FWD", 24576), s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});

@@ -255,7 +255,9 @@ __global__ __launch_bounds__(256, OCC) void fwd_v2(const float* __restrict__ X, 
     } else
     for (int kt = 1; kt < full_end; ++kt) {
         load(kt);
+        if (VAR == 4) __builtin_amdgcn_sched_barrier(0);
         mfma(buf);
+        if (VAR == 4) __builtin_amdgcn_sched_barrier(0);
         store(buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256, OCC) void fwd_v2(const float* __restrict__ X, 
     }
     mfma(buf);
     if (VAR == 1) t_loop = __builtin_amdgcn_s_memtime();
-    if (VAR == 3 && (N & 3) == 0 && m0 + BM <= M && n0 + BN <= N) {
+    if ((VAR == 3 || VAR == 4) && (N & 3) == 0 && m0 + BM <= M && n0 + BN <= N) {
         // wide-store epilogue: each wave transposes its 32x32 sub-tiles through a private LDS patch (lane = column ->
         // lane = 4 consecutive columns of one row) and writes dwordx4: 8 store instructions per wave instead of 32
         constexpr int LDW = 36;
@@ -318,6 +320,111 @@ __global__ __launch_bounds__(256, OCC) void fwd_v2(const float* __restrict__ X, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ v4
+// 128 x 128 workgroup tile, four waves as 2 x 2, each wave 64 x 64 (2 x 2 MFMA tiles, 64 accumulator registers): 8
+// ds_read_b128 feed 32 MFMAs per stage (v2: 6 for 16) and one barrier covers twice the MFMA work; 3 workgroups per CU.
+// K % 16 == 0, M % 128 == 0, N % 128 == 0 only (lab).
+template <int OCC, bool PIN = false>
+__global__ __launch_bounds__(256, OCC) void fwd_v4(const float* __restrict__ X, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, float* __restrict__ Y, int M, int N, int K) {
+    constexpr int BM = 128, BN = 128, BK = 16;
+    __shared__ f32x4 As[2][BM * 4];
+    __shared__ f32x4 Bs[2][BN * 4];
+    int tr, tc;
+    if (!map_tile(blockIdx.x, M / BM, N / BN, tr, tc)) return;
+    const int m0 = tr * BM, n0 = tc * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm_off = (wave >> 1) * 64, wn_off = (wave & 1) * 64;
+    const int lrow = tid >> 2, lch = tid & 3;
+    u32 aoff[2], woff[2];
+    int slot[2];
+    for (int i = 0; i < 2; ++i) {
+        const int r = lrow + 64 * i;
+        aoff[i] = (u32)((m0 + r) * K + 4 * lch) * 4u;
+        woff[i] = (u32)((n0 + r) * K + 4 * lch) * 4u;
+        slot[i] = r * 4 + (lch ^ ((r >> 2) & 3));
+    }
+    const rsrc_t ares = make_rsrc(X), wres = make_rsrc(W);
+    f32x4 ra[2], rb[2];
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int half = lane >> 5, l31 = lane & 31;
+    auto load = [&](int kt) {
+        const u32 ko = (u32)(kt * BK) * 4u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = bload4(ares, aoff[i], ko);
+            rb[i] = bload4(wres, woff[i], ko);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            As[buf][slot[i]] = ra[i];
+            Bs[buf][slot[i]] = rb[i];
+        }
+    };
+    auto mfma = [&](int buf) {
+        f32x4 a[2][2], b[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ar = wm_off + 32 * i + l31, br = wn_off + 32 * i + l31;
+                a[i][q] = As[buf][ar * 4 + ((2 * q + half) ^ ((ar >> 2) & 3))];
+                b[i][q] = Bs[buf][br * 4 + ((2 * q + half) ^ ((br >> 2) & 3))];
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q][t], b[j][q][t], acc[i][j], 0, 0, 0);
+    };
+    const int KT = K / BK;
+    int buf = 0;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int kt = 1; kt < KT; ++kt) {
+        load(kt);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);      // keep the loads of the next stage in front of this stage's MFMAs
+        mfma(buf);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
+        store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    mfma(buf);
+    // wide-store epilogue through a per-wave LDS patch (as v2 VAR 3)
+    constexpr int LDW = 36;
+    __syncthreads();
+    float* patch = reinterpret_cast<float*>(&As[0][0]) + wave * (32 * LDW);
+    const int rrow = lane >> 3, rc4 = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bv = bias[n0 + wn_off + 32 * j + l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r] + bv;
+                patch[((r & 3) + 8 * (r >> 2) + 4 * half) * LDW + l31] = v > 0.f ? v : 0.f;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = rrow + 8 * p;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&patch[row * LDW + 4 * rc4]);
+                *reinterpret_cast<f32x4*>(&Y[(long long)(m0 + wm_off + 32 * i + row) * N + n0 + wn_off + 32 * j + 4 * rc4]) = v;
+            }
+        }
+}
 
 // ------------------------------------------------------------------------------------------------ v3
 // 512-thread workgroups: waves w and w+4 share the 32 x 64 output sub-tile of rows 32w and split the stage's k range
@@ -698,6 +805,18 @@ int main(int argc, char** argv) {
                 report("v2 occ4 wide-st", timeit([&] { fwd_v2<64, 4, 3><<<grid_for(rt, (p.N + 63) / 64), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
                 hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
                 report("v2 occ6 wide-st", timeit([&] { fwd_v2<64, 6, 3><<<grid_for(rt, (p.N + 63) / 64), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
+                report("v2 occ4 pin wide", timeit([&] { fwd_v2<64, 4, 4><<<grid_for(rt, (p.N + 63) / 64), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
+                report("v2 occ5 pin wide", timeit([&] { fwd_v2<64, 5, 4><<<grid_for(rt, (p.N + 63) / 64), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                if (p.K % 16 == 0 && p.N % 128 == 0 && p.M % 128 == 0) {
+                    hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
+                    report("v4 128x128 occ3", timeit([&] { fwd_v4<3><<<grid_for(p.M / 128, p.N / 128), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                    hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
+                    report("v4 128x128 pin3", timeit([&] { fwd_v4<3, true><<<grid_for(p.M / 128, p.N / 128), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                    hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
+                    report("v4 128x128 pin2", timeit([&] { fwd_v4<2, true><<<grid_for(p.M / 128, p.N / 128), 256>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
+                }
                 if (p.K % 16 == 0) {
                     hipMemset(p.Y, 0, (size_t)p.M * p.N * 4);
                     report("v3 512thr occ2", timeit([&] { fwd_v3<2><<<grid_for(rt, (p.N + 63) / 64), 512>>>(p.X, p.W, p.b, p.Y, p.M, p.N, p.K); }, reps));
