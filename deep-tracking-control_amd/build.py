@@ -54,6 +54,39 @@ def _compile(src, force, save_temps):
     return obj, r.stderr
 
 
+def kernel_resources():
+    """Device-side resource use of every kernel: {kernel name: dict(scratch=bytes, vgprs=n, lds=bytes)}, read from the code
+    object metadata of a device-only assembly pass over csrc/*.hip (same flags as the product build).  Used by
+    tests/test_abi_and_host.py: NO kernel may use scratch (a kernel with any private segment pays at every wave launch -- the
+    forward GEMM lost 1.3 % of the whole step to five spilled registers of its prologue)."""
+    import re
+    import tempfile
+
+    def one(src):
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "k.s")
+            cmd = [HIPCC, *COMMON, *PER_FILE.get(src, []), "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc -S failed on {src}:\n{r.stderr[-1500:]}")
+            text = open(out).read()
+        res = {}
+        for blk in text.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            if not name:
+                continue
+            g = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", blk).group(1))
+            res[name.group(1)] = dict(scratch=g("private_segment_fixed_size"), vgprs=g("vgpr_count"), lds=g("group_segment_fixed_size"),
+                                      source=src)
+        return res
+
+    out = {}
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        for res in ex.map(one, sources()):
+            out.update(res)
+    return out
+
+
 def build_asan(verbose=True):
     """Host-side AddressSanitizer build of the same sources (device code unsanitised): libdtc_hip_asan.so.  Used by
     tests/test_abi_and_host.py to run the argument-validation / descriptor-marshalling layer of the C ABI under ASan

@@ -233,3 +233,19 @@ def test_host_validation_paths_under_address_sanitizer():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "asan-ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
     assert "AddressSanitizer" not in r.stderr
+
+
+def test_no_kernel_uses_scratch():
+    """Performance guard (no GPU needed: hipcc cross-compiles): every kernel of the library keeps its registers -- no private
+    segment.  A kernel with scratch pays at wave launch even when the spills sit outside its hot loop."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "dtc_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deep-tracking-control_amd", "build.py"))
+    build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(build)
+    res = build.kernel_resources()
+    assert len(res) >= 40, sorted(res)
+    bad = {k: v for k, v in res.items() if v["scratch"] != 0}
+    assert not bad, bad
+    assert all(v["lds"] <= 64 * 1024 for v in res.values())
