@@ -1,7 +1,7 @@
 """Headline benchmark: env-steps/sec of the PPO-update + foothold-score hot path on pre-recorded
 (synthetic) rollouts, 4096 envs x 24 steps per GPU (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one recorded rollout of 4096 envs x 24 env-steps:
@@ -89,6 +89,27 @@ def cpu_baseline():
                        f"{cores} threads (warm-up rates: " + ", ".join(f"{k} thr {1.0 / v:.0f}" for k, v in warm.items()) + ")")
 
 
+def self_launch(n: int) -> int:
+    """Re-execute this script as `n` ranks (one per GPU of this node) under torch.distributed.run and return its exit code.
+    The children inherit stdout / stderr, so rank 0's single JSON line is what the caller of `python bench.py --gpus N`
+    reads.  Rendezvous stays on 127.0.0.1 (the container host name may not resolve); the port is a free one unless
+    MASTER_PORT is set."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL's intra-node transport on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")                   # torchrun would pin it to 1 with a warning
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,11 +124,24 @@ def main():
                          "cannot pass flags selects configs[4]'s model with DTC_BENCH_WORKLOAD=composite)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` (the driver's command shape): become the launcher -- one rank per GPU under
+        # torch.distributed.run on this node, rendezvous on 127.0.0.1; rank 0's JSON line is this process's output
+        raise SystemExit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs a torch.distributed.run launch with WORLD_SIZE={a.gpus} (got {world})")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("DTC_BENCH_LAUNCH_CHECK") == "1":
+        # CPU rehearsal of the launch path only (tests/test_bench_launch.py): rendezvous, one all-reduce, rank 0's line
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "sum": float(t.item()), "steps": a.steps, "warmup": a.warmup}), flush=True)
+        dist.destroy_process_group()
+        return
     # test hooks (a 1-GPU box can rehearse the N > 1 control flow): DTC_BENCH_DEVICE pins every rank to one device,
     # DTC_BENCH_BACKEND=gloo replaces RCCL (two ranks cannot share a GPU under RCCL)
     if "DTC_BENCH_DEVICE" in os.environ:
@@ -181,9 +215,9 @@ def main():
         # communicator set-up and the first exchange of every bucket size happen here, never inside the timed region
         # (also with --warmup 0): one all-reduce of each gradient bucket + the scalar statistics, then a barrier
         arena = alg.actor_critic.ensure_arena()
-        for lo, hi in getattr(arena, "buckets", dict(all=(0, arena.grad.numel()))).values():
-            dist.all_reduce(arena.grad[lo:hi])
-        arena.grad.zero_()
+        for t in ([arena.exchange_view(k) for k in arena.buckets] if hasattr(arena, "buckets") else [arena.grad_full]):
+            dp.allreduce_mean_(t)                    # the real op (ReduceOp.AVG on RCCL) at the real bucket sizes
+        arena.grad_full.zero_()
         dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev))
     for _ in range(a.warmup):
         step()

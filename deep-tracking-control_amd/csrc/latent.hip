@@ -20,6 +20,21 @@
 
 #include "common.hpp"
 
+// The backward kernel's cross-workgroup hand-off (partial sums, the median element, the arrival ticket) uses RELAXED
+// agent-scope atomics + `s_waitcnt vmcnt(0)` instead of a release / acquire pair.  That is an architecture contract, not
+// the HIP memory model: on gfx9 (gfx90a / gfx942 / gfx950) an agent-scope atomic store or RMW is performed AT the L2 (sc1
+// write-through, never held in the per-CU vector cache), agent-scope atomic loads bypass the vector cache, and vmcnt counts
+// stores, so `store; s_waitcnt vmcnt(0); ticket RMW` orders the store before the ticket at the L2 every workgroup of one
+// XCD-spanning launch reads through.  A release fence would be correct everywhere but writes back the whole XCD L2
+// (dirty activations of unrelated kernels: measured 22 -> 14 us without it).  Any other target must use the fences:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "csrc/latent.hip: the relaxed write-through hand-off of lat_bwd_kernel is only valid on gfx9 (see the comment above)"
+#endif
+// Workspace contract (dtc_cenet_latent_fwd / _bwd): a backward call consumes what the forward call on the SAME workspace
+// left behind (mask, info, the zeroed ticket), so the two are ordered by data dependence; a forward call for the next
+// step must not be issued concurrently with a backward call still using the workspace (it would overwrite mask / info
+// as well as re-zero the ticket).
+
 namespace {
 
 constexpr int LAT = 16, MU = 19, LD = 35;

@@ -73,7 +73,14 @@ ProfScope::~ProfScope() {
 
 extern "C" {
 
-int dtc_version(void) { return 1; }
+int dtc_version(void) { return DTC_ABI_VERSION; }
+int dtc_abi_sizes(int64_t* out, int cap) {
+    const int64_t sz[] = {sizeof(DtcGridCfg), sizeof(DtcObsCfg), sizeof(DtcRowCopy), sizeof(DtcSeg), sizeof(DtcSegMat),
+                          sizeof(DtcFwdLayer), sizeof(DtcWgradJob), sizeof(DtcPpoCfg), sizeof(DtcProfRec)};
+    const int n = (int)(sizeof(sz) / sizeof(sz[0]));
+    for (int i = 0; i < n && i < cap && out; ++i) out[i] = sz[i];
+    return n;
+}
 const char* dtc_last_error(void) { return g_err; }
 
 void dtc_prof_enable(int on) {

@@ -71,8 +71,11 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
+ABI_VERSION = 3          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+
 _SIGS = {
     "dtc_version": (C.c_int, []),
+    "dtc_abi_sizes": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),
     "dtc_last_error": (C.c_char_p, []),
     "dtc_foothold_plan": (C.c_int, [c_f32p] * 4 + [C.POINTER(DtcGridCfg), c_i64p] + [c_f32p] * 5 +
                           [c_i64p, c_f32p, c_f32p, C.c_int, c_stream]),
@@ -159,7 +162,22 @@ def lib() -> C.CDLL:
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args
+        _check_abi(_lib)
     return _lib
+
+
+def _check_abi(l):
+    """The loaded library must be the revision this binding describes: same ABI version, same by-value struct layouts
+    (DTC_LIB may point at a separately built library, e.g. the ASan build: a stale one would misread every descriptor)."""
+    global _lib
+    mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec]
+    sizes = (C.c_int64 * 16)()
+    n = l.dtc_abi_sizes(sizes, 16)
+    theirs = list(sizes[:n])
+    if l.dtc_version() != ABI_VERSION or theirs != [C.sizeof(t) for t in mine]:
+        _lib = None
+        raise DtcError(f"{LIB_PATH}: ABI mismatch (library version {l.dtc_version()}, struct sizes {theirs}; binding version "
+                       f"{ABI_VERSION}, struct sizes {[C.sizeof(t) for t in mine]}): rebuild with deep-tracking-control_amd/build.py")
 
 
 def exported_symbols():

@@ -386,21 +386,45 @@ class PPO:
         return dp.world_size()
 
     def _allreduce_grads(self, opt):
-        dp.allreduce_mean_(opt.g)        # one flat bucket per optimiser step (no-op on a single rank)
+        """One flat all-reduce per optimiser step (no-op on a single rank): the fallback when the per-bucket exchange did
+        not run.  The main optimiser's range starts at offset 0, so its exchange carries the KL header too."""
+        if self._world() == 1:
+            return
+        arena, (lo, hi) = self.actor_critic.arena, opt.range
+        dp.allreduce_mean_(arena.grad_full[0:arena.HEADER + hi] if lo == 0 else opt.g)
 
     def _exchange_bucket(self, tw, name):
-        """Weight gradients of the bucket: flushed here.  Data parallel: average gradient bucket `name` of the arena over the ranks as soon as its last weight
-        gradient has been queued.  All weight gradients of this trainer run on the side stream, so the all-reduce is
-        issued THERE: it is ordered after them and overlaps the data-gradient chain still running on the compute lanes
-        (the decoders' / heads' bucket travels while the encoders run backward).  Returns True when it took place."""
+        """Weight gradients of the bucket: flushed here.  Data parallel: average gradient bucket `name` of the arena over
+        the ranks as soon as its last weight gradient has been queued.  All weight gradients of this trainer run on the
+        side stream, so the all-reduce is issued THERE: it is ordered after them (and, through the lane events below,
+        after everything the compute lanes have written so far: the GRU gradients of the recurrent trainers, the KL
+        header) and overlaps the data-gradient chain still running on the compute lanes -- the decoders' / heads' bucket
+        travels over xGMI while the encoders run backward.  Returns True when it took place."""
         self._flush_wgrads(tw)
         if self._world() == 1 or not (self.overlap_exchange and self.overlap_wgrad):
             return False
-        lo, hi = self.actor_critic.arena.buckets[name]
+        for lane in ((tw.main, tw.aux) if tw.two_lanes else (torch.cuda.current_stream(),)):
+            ev = tw.event()
+            ev.record(lane)
+            tw.side.wait_event(ev)
         with torch.cuda.stream(tw.side):
-            dp.allreduce_mean_(self.actor_critic.arena.grad[lo:hi])
+            dp.allreduce_mean_(self.actor_critic.arena.exchange_view(name))
         tw.side_busy = True
         return True
+
+    def _kl_to_header(self, stats):
+        """Data parallel, adaptive schedule: the local KL mean goes into slot 0 of the gradient header; it is averaged
+        with the first gradient bucket of the policy step (no collective of its own on the critical path)."""
+        if self._world() > 1 and self._adaptive():
+            self.actor_critic.arena.kl_slot.copy_(stats[S_KL:S_KL + 1])
+
+    def _lr_from_header(self, stats):
+        """After the exchange: the averaged KL drives the learning-rate rule (identical on every rank) and replaces the
+        local value in the statistics table."""
+        if self._world() > 1 and self._adaptive():
+            kl = self.actor_critic.arena.kl_slot
+            stats[S_KL:S_KL + 1].copy_(kl)
+            ops.lr_adapt(kl, self.optimizer.lr_dev, float(self.desired_kl))
 
     def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None):
         """Backward of one dense layer.  The weight gradient (dW = dZ^T X) is off the critical path -- only the
@@ -540,12 +564,12 @@ class PPO:
         ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
         tw.order("aux", "main")                                    # z, mu feed the actor
         # output layers + losses + their data gradients in one launch when the last hidden width allows it (DTC_FUSE_HEADS)
-        fuse = self.fuse_heads and fw.a3.shape[1] == fw.v3.shape[1] and fw.a3.shape[1] in (64, 128, 256)
+        # (its partial-sum workspace holds 4096 blocks of 64 rows: larger mini-batches take the unfused kernels)
+        fuse = self.fuse_heads and fw.a3.shape[1] == fw.v3.shape[1] and fw.a3.shape[1] in (64, 128, 256) and tw.B <= 4096 * 64
         with tw.lane("aux"):
             ac.critic_forward_(fw, flat["observations"], flat["base_vel"], flat["privileged_observations"], idx, head=not fuse)
         ac.actor_forward_(fw, flat["observations"], idx, head=not fuse)
         tw.order("aux", "main")
-        world = self._world()
         g_c3, g_a3 = tw.g("c3", 128), tw.g("a3", 128)
         if fuse:
             ops.ppo_heads_loss(fw.a3, fw.v3, L["a3"].W, L["a3"].b, L["c3"].W, L["c3"].b, act, ac.std_view, flat["actions"],
@@ -556,9 +580,7 @@ class PPO:
             ops.ppo_loss(fw.mean, ac.std_view, fw.val, flat["actions"], flat["actions_log_prob"], flat["mu"],
                          flat["sigma"], flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval,
                          ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
-        if world > 1 and cfg.adaptive_schedule == 0 and self._adaptive():
-            dp.allreduce_mean_(stats[S_KL:S_KL + 1])
-            ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
+        self._kl_to_header(stats)
         tw.order("main", "aux")
         # critic (aux)
         g_c2, g_c1 = tw.g("c2", 256), tw.g("c1", 512)
@@ -587,6 +609,7 @@ class PPO:
         self._join(tw)
         if not early:
             self._allreduce_grads(self.optimizer)
+        self._lr_from_header(stats)
         if self.capture_grads:
             self.captured["main"] = ac.arena.grad.clone()
         self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])

@@ -144,9 +144,7 @@ class RecurrentDecoderPPO(PPO):
         ops.ppo_loss(mean, ac.std_view, value, flat["actions"], flat["actions_log_prob"], flat["mu"], flat["sigma"],
                      flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval, ac.std_grad,
                      stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
-        if self._world() > 1 and cfg.adaptive_schedule == 0 and self._adaptive():
-            dp.allreduce_mean_(stats[S_KL:S_KL + 1])
-            ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
+        self._kl_to_header(stats)
         tw.order("main", "aux")
         with tw.lane("aux"):
             self._bwd(tw, hc["proj"], head_backward(hc, tw.dval), hc["X"])
@@ -155,11 +153,18 @@ class RecurrentDecoderPPO(PPO):
         tw.dmulv.zero_()
         dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
         self._bwd(tw, ha["proj"], dgi_a, ha["X"], dst, None, None)
+        # every gradient of the first bucket (both MLP heads, both GRUs, both input projections, std) has been written or
+        # queued: it travels (with the KL header) while the encoders run backward
+        early = self._exchange_bucket(tw, "main_only")
         ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
         self._terrain_encoder_backward(fw, tw, flat, idx)
         self._cenet_encoder_backward(fw, tw, flat, idx)
+        if early:
+            self._exchange_bucket(tw, "shared")
         self._join(tw)
-        self._allreduce_grads(self.optimizer)
+        if not early:
+            self._allreduce_grads(self.optimizer)
+        self._lr_from_header(stats)
         if self.capture_grads:
             self.captured["main"] = ac.arena.grad.clone()
         self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])

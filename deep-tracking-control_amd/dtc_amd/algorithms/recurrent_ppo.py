@@ -187,9 +187,9 @@ class RecurrentPPO:
         ops.ppo_loss(mean, ac.std_view, value, flat("actions"), flat("actions_log_prob"), flat("mu"), flat("sigma"),
                      flat("advantages"), flat("returns"), flat("values"), store_idx, self._loss_cfg(), dmean, dval,
                      ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, lws)
-        if dp.world_size() > 1 and self.desired_kl is not None and self.schedule == 'adaptive':
-            dp.allreduce_mean_(stats[S_KL:S_KL + 1])
-            ops.lr_adapt(stats[S_KL:S_KL + 1], self.optimizer.lr_dev, float(self.desired_kl))
+        dp_adaptive = dp.world_size() > 1 and self.desired_kl is not None and self.schedule == 'adaptive'
+        if dp_adaptive:                              # the KL mean travels in the header of the gradient exchange
+            arena.kl_slot.copy_(stats[S_KL:S_KL + 1])
         ln.order("main", "aux")
         # backward: MLPs -> scatter into the padded layout -> BPTT -> input-projection weight gradient
         H = ac.rnn_hidden_size
@@ -208,7 +208,11 @@ class RecurrentPPO:
             head_backward(ac.Cr, c_outs, c_saved, ac.memory_c, dval)
         head_backward(ac.A, a_outs, a_saved, ac.memory_a, dmean)
         ln.join()
-        dp.allreduce_mean_(self.optimizer.g)
+        if dp.world_size() > 1:
+            dp.allreduce_mean_(arena.grad_full)      # header (KL) + every gradient: one collective per optimiser step
+        if dp_adaptive:
+            stats[S_KL:S_KL + 1].copy_(arena.kl_slot)
+            ops.lr_adapt(arena.kl_slot, self.optimizer.lr_dev, float(self.desired_kl))
         if self.capture_grads:
             self.captured["main"] = ac.arena.grad.clone()
         self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])

@@ -3,8 +3,10 @@ through torch.distributed ("nccl" IS RCCL on ROCm; "gloo" in the CPU tests).  Th
 places where the hot path talks to other ranks:
 
   * `allreduce_mean_(flat_grad)`       two gradient buckets per optimiser step (7.42 MB VAE step / 7.76 MB policy step in total);
-  * `allreduce_sum_(stat)`             the two advantage-normalisation scalars (sum, sum of squared deviations);
-  * `allreduce_mean_(kl)`              so that every rank takes the same learning-rate branch (ppo.py:301-307).
+                                       the policy step's first bucket carries a 4-float header in front of the gradients
+                                       whose slot 0 is the KL statistic, so that every rank takes the same learning-rate
+                                       branch (ppo.py:301-307) without a collective of its own;
+  * `allreduce_sum_(stat)`             the two advantage-normalisation scalars (sum, sum of squared deviations).
 
 CE-net outlier statistics and the mini-batch permutation stay rank-local.  Everything else (planner,
 GAE scan, forward, backward, Adam) is embarrassingly parallel over envs; parameters stay bit-identical
@@ -87,11 +89,16 @@ def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
 
 
 def allreduce_mean_(t: torch.Tensor) -> torch.Tensor:
+    """In-place mean over the ranks.  RCCL averages inside the collective (ReduceOp.AVG: no second pass over the
+    bucket); gloo has no AVG, there the sum is scaled afterwards (CPU tests, one-GPU rehearsals)."""
     w = world_size()
     if w > 1:
         _record("all_reduce_mean", t)
-        dist.all_reduce(t)
-        t.mul_(1.0 / w)
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(t)
+            t.mul_(1.0 / w)
     return t
 
 

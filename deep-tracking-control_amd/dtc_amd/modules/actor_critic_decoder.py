@@ -95,6 +95,17 @@ class ParamArena:
     main optimiser range = [0, end(shared));  VAE optimiser range = [start(shared), end(vae-only)).
     The parameters of `unused` never receive a gradient in PPO.update."""
 
+    HEADER = 4
+
+    def exchange_view(self, name):
+        """The tensor the data-parallel exchange of gradient bucket `name` all-reduces (bucket 0 includes the header)."""
+        lo, hi = self.buckets[name]
+        return self.grad_full[0:self.HEADER + hi] if lo == 0 else self.grad[lo:hi]
+
+    @property
+    def kl_slot(self):
+        return self.grad_full[0:1]
+
     def __init__(self, model: "ActorCriticDecoder"):
         named = dict(model.named_parameters())
         order, groups = [], {}
@@ -113,7 +124,12 @@ class ParamArena:
         device = named["std"].device
         total = sum(named[k].numel() for k in order)
         self.flat = torch.empty(total, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        # gradient buffer with a 16-byte header in front: [kl, 0, 0, 0 | gradients ...].  The data-parallel exchange of the
+        # first bucket (`main_only`, offset 0) sends header + bucket as ONE all-reduce, so the KL mean every rank needs for
+        # the same learning-rate decision travels with the gradients (dtc_amd/distributed.py); `grad` itself starts
+        # behind the header and keeps its 16-byte alignment
+        self.grad_full = torch.zeros(self.HEADER + total, dtype=torch.float32, device=device)
+        self.grad = self.grad_full[self.HEADER:]
         self.offsets, off = {}, 0
         for k in order:
             p = named[k]

@@ -33,13 +33,20 @@ def _mlp(in_dim, hidden, out_dim, act):
 
 class FlatArena:
     """All parameters of a module in one flat fp32 buffer (+ a gradient twin); nn.Parameter.data are views."""
+    HEADER = 4
+
+    @property
+    def kl_slot(self):
+        return self.grad_full[0:1]
 
     def __init__(self, model: nn.Module):
         self._named = list(model.named_parameters())
         dev = self._named[0][1].device
         total = sum(p.numel() for _, p in self._named)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        # [kl, 0, 0, 0 | gradients]: the data-parallel exchange sends header + gradients as one all-reduce (see ParamArena)
+        self.grad_full = torch.zeros(self.HEADER + total, dtype=torch.float32, device=dev)
+        self.grad = self.grad_full[self.HEADER:]
         self.offsets, off = {}, 0
         for k, p in self._named:
             n = p.numel()
@@ -298,8 +305,13 @@ class Memory(nn.Module):
     def reset(self, dones=None):
         if self.hidden_states is None:
             return
+        states = self.hidden_states if isinstance(self.hidden_states, (tuple, list)) else (self.hidden_states,)
+        if dones is None:                 # actor_critic_recurrent.py:112-116 with dones=None: `t[..., None, :] = 0` clears every env
+            for t in states:
+                t.zero_()
+            return
         d = dones.bool() if dones.dtype != torch.bool else dones
-        for t in (self.hidden_states if isinstance(self.hidden_states, (tuple, list)) else (self.hidden_states,)):
+        for t in states:
             t[..., d, :] = 0.0
 
 

@@ -6,17 +6,21 @@ import time
 
 import torch
 
-from ..algorithms import PPO, RecurrentDecoderPPO
+from ..algorithms import PPO, RecurrentDecoderPPO, RecurrentPPO
 from ..env import HistoryWrapper
-from ..modules import ActorCriticDecoder, ActorCriticDecoderRecurrent  # resolved by name from train_cfg
+from ..modules import ActorCritic, ActorCriticDecoder, ActorCriticDecoderRecurrent, ActorCriticRecurrent  # resolved by name from train_cfg
 
 try:                                       # not installed in every image
     from torch.utils.tensorboard import SummaryWriter
 except Exception:                          # pragma: no cover
     SummaryWriter = None
 
-_POLICIES = {"ActorCriticDecoder": ActorCriticDecoder, "ActorCriticDecoderRecurrent": ActorCriticDecoderRecurrent}
-_ALGORITHMS = {"PPO": PPO, "RecurrentDecoderPPO": RecurrentDecoderPPO}
+# on_policy_runner.py:38-42, 60, 67 resolve the classes with eval(): the same names are reachable here.  `PPO` needs a
+# model with a `.vae` (ppo.py:79) exactly as in the reference; the recurrent actor-critic of BASELINE configs[2] trains
+# with `RecurrentPPO` (the upstream PPO step the fork dropped), the composite with `RecurrentDecoderPPO`.
+_POLICIES = {"ActorCritic": ActorCritic, "ActorCriticRecurrent": ActorCriticRecurrent, "ActorCriticDecoder": ActorCriticDecoder,
+             "ActorCriticDecoderRecurrent": ActorCriticDecoderRecurrent}
+_ALGORITHMS = {"PPO": PPO, "RecurrentPPO": RecurrentPPO, "RecurrentDecoderPPO": RecurrentDecoderPPO}
 
 
 class _EpisodeTracker:
@@ -65,8 +69,14 @@ class OnPolicyRunner:
         self.alg = alg_class(actor_critic, device=self.device, **self.alg_cfg)
         self.num_steps_per_env = self.cfg["num_steps_per_env"]
         self.save_interval = self.cfg["save_interval"]
-        self.alg.init_storage(self.env.num_envs, self.num_steps_per_env, [self.env.num_obs],
-                              [self.env.num_privileged_obs], [self.env.num_obs_history], [self.env.num_actions])
+        # upstream-style trainers (actor obs / critic obs only) take no observation history, base velocity or reward buffer
+        self._plain = isinstance(self.alg, RecurrentPPO)
+        if self._plain:
+            self.alg.init_storage(self.env.num_envs, self.num_steps_per_env, [self.env.num_obs], [num_critic_obs],
+                                  [self.env.num_actions])
+        else:
+            self.alg.init_storage(self.env.num_envs, self.num_steps_per_env, [self.env.num_obs],
+                                  [self.env.num_privileged_obs], [self.env.num_obs_history], [self.env.num_actions])
         self.log_dir = log_dir
         self.writer = None
         self.tot_timesteps = 0
@@ -85,7 +95,7 @@ class OnPolicyRunner:
         obs, priv, hist = self._observe(obs_dict)
         with torch.inference_mode():
             for _ in range(self.num_steps_per_env):
-                actions = self.alg.act(obs, priv, hist, obs_dict['base_vel'], rew_buf)
+                actions = self.alg.act(obs, priv) if self._plain else self.alg.act(obs, priv, hist, obs_dict['base_vel'], rew_buf)
                 obs_dict, rewards, dones, infos = self.env.step(actions)
                 obs, priv, hist = self._observe(obs_dict)
                 rewards, dones = rewards.to(self.device), dones.to(self.device)
@@ -94,7 +104,10 @@ class OnPolicyRunner:
                     tracker.step(rewards, dones)
                     if 'episode' in infos:
                         ep_infos.append(infos['episode'])
-            self.alg.compute_returns(obs, priv, obs_dict['base_vel'])
+            if self._plain:
+                self.alg.compute_returns(priv)
+            else:
+                self.alg.compute_returns(obs, priv, obs_dict['base_vel'])
         state["obs_dict"] = obs_dict
 
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
@@ -125,7 +138,7 @@ class OnPolicyRunner:
             self.save(os.path.join(self.log_dir, f'model_{last}.pt'))
 
     def log(self, it, last, losses, collection_time, learn_time, tracker, width=80, pad=35):
-        value_loss, surrogate_loss, _adaptation, _decoder, recons_loss, vel_loss, kld_loss = losses
+        value_loss, surrogate_loss, _adaptation, _decoder, recons_loss, vel_loss, kld_loss = tuple(losses) + (0.0,) * (7 - len(losses))
         steps = self.num_steps_per_env * self.env.num_envs
         self.tot_timesteps += steps
         self.tot_time += collection_time + learn_time

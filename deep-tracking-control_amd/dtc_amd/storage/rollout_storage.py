@@ -15,7 +15,7 @@ import torch
 
 from .. import distributed as dp
 from .. import _ffi, ops
-from ..utils import split_and_pad_trajectories
+from ..utils import split_and_pad_trajectories, trajectory_index_map
 
 
 class RolloutStorage:
@@ -90,11 +90,13 @@ class RolloutStorage:
                     f(tr.actions), dones.reshape(-1), f(tr.values), f(tr.actions_log_prob).reshape(-1), f(tr.action_mean),
                     f(tr.base_vel), f(tr.action_sigma))
             items = plan["items"]
-            if not plan["checked"]:                       # shapes are fixed for the life of the storage: validate once
-                for src, (base, step_bytes, width, numel) in zip(srcs, plan["dst"]):
-                    assert src.shape[0] == self.num_envs and src[0].numel() == numel and (src.dim() == 1 or src.stride(-1) == 1)
-                plan["checked"] = True
-            for i, (src, (base, step_bytes, width, numel)) in enumerate(zip(srcs, plan["dst"])):
+            for i, (src, (base, step_bytes, width, numel, dtype)) in enumerate(zip(srcs, plan["dst"])):
+                # per-call checks (a handful of integer compares): the kernel trusts these descriptors blindly
+                if src.shape[0] != self.num_envs or src.numel() != self.num_envs * numel or src.dtype != dtype or \
+                        (src.dim() > 1 and src.stride(-1) != 1) or not src.is_cuda:
+                    raise _ffi.DtcError(f"add_transitions: field {i} has shape {tuple(src.shape)} / strides {src.stride()} / "
+                                        f"{src.dtype} on {src.device}; expected [{self.num_envs}, {numel}] {dtype} rows with unit "
+                                        "inner stride on the storage's device")
                 it = items[i]
                 it.src, it.dst = src.data_ptr(), base + s * step_bytes
                 it.src_stride_bytes = src.stride(0) * src.element_size()
@@ -123,17 +125,136 @@ class RolloutStorage:
         self.step += 1
 
     def _store_plan(self):
+        dsts = (self.observations, self.next_observations, self.privileged_observations, self.observation_histories,
+                self.actions, self.dones, self.values, self.actions_log_prob, self.mu, self.base_vel, self.sigma)
         plan = getattr(self, "_plan", None)
-        if plan is None:
-            dsts = (self.observations, self.next_observations, self.privileged_observations, self.observation_histories,
-                    self.actions, self.dones, self.values, self.actions_log_prob, self.mu, self.base_vel, self.sigma)
+        ptrs = tuple(t.data_ptr() for t in dsts)
+        if plan is None or plan["ptrs"] != ptrs:          # first use, or a buffer was replaced (.to(), re-assignment)
             items = (_ffi.DtcRowCopy * len(dsts))()
             meta = []
             for i, t in enumerate(dsts):
                 row = t[0, 0].numel() * t.element_size()
                 items[i].width_bytes = row
-                meta.append((t.data_ptr(), t.stride(0) * t.element_size(), row, t[0, 0].numel()))
-            plan = self._plan = dict(items=items, dst=meta, checked=False)
+                meta.append((t.data_ptr(), t.stride(0) * t.element_size(), row, t[0, 0].numel(), t.dtype))
+            plan = self._plan = dict(items=items, dst=meta, ptrs=ptrs)
+        return plan
+
+    def _save_hidden_states(self, hidden_states):
+        """Record the recurrent states a rollout step started from (rollout_storage.py:118-132): `hidden_states` is the
+        (actor, critic) pair, each a [layers, N, H] tensor (GRU) or an (h, c) tuple of them (LSTM); storage is one
+        [T, layers, N, H] tensor per state tensor, allocated on first use."""
+        if hidden_states is None or hidden_states == (None, None):
+            return
+        nets = [h if isinstance(h, tuple) else (h,) for h in hidden_states[:2]]
+        if self.saved_hidden_states_a is None:
+            T = self.num_transitions_per_env
+            self.saved_hidden_states_a, self.saved_hidden_states_c = (
+                [torch.zeros(T, *h.shape, device=self.device) for h in net] for net in nets)
+        for saved, net in zip((self.saved_hidden_states_a, self.saved_hidden_states_c), nets):
+            for dst, h in zip(saved, net):
+                dst[self.step].copy_(h)
+
+    def clear(self):
+            self.__init__()
+
+    def __init__(self, num_envs, num_transitions_per_env, obs_shape, privileged_obs_shape, obs_history_shape,
+                 actions_shape, device='cpu'):
+        self.device = device
+        self.obs_shape = obs_shape
+        self.privileged_obs_shape = privileged_obs_shape
+        self.obs_history_shape = obs_history_shape
+        self.actions_shape = actions_shape
+        T, N = num_transitions_per_env, num_envs
+        z = lambda *s: torch.zeros(T, N, *s, device=self.device)
+        # Core
+        self.observations = z(*obs_shape)
+        self.next_observations = z(*obs_shape)
+        self.privileged_observations = z(*privileged_obs_shape)
+        self.observation_histories = z(*obs_history_shape)
+        self.rewards = z(1)
+        self.actions = z(*actions_shape)
+        self.dones = torch.zeros(T, N, 1, device=self.device, dtype=torch.uint8)
+        # For PPO
+        self.actions_log_prob = z(1)
+        self.values = z(1)
+        self.returns = z(1)
+        self.advantages = z(1)
+        self.mu = z(*actions_shape)
+        self.sigma = z(*actions_shape)
+        self.base_vel = z(3)
+        self.num_transitions_per_env = T
+        self.num_envs = N
+        # rnn
+        self.saved_hidden_states_a = None
+        self.saved_hidden_states_c = None
+        self.step = 0
+        self._stats = None
+
+    def add_transitions(self, transition: "RolloutStorage.Transition", time_outs=None, gamma=0.0):
+        """rollout_storage.py:99-116.  On a HIP device the 13 copies are ONE dtc_store_transition launch, which also
+        applies the time-out bootstrap of PPO.process_env_step (ppo.py:162-163) when `time_outs` is given."""
+        if self.step >= self.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        s, tr = self.step, transition
+        if self.observations.is_cuda:
+            f = lambda t: t if t.dtype == torch.float32 else t.float()
+            dones = tr.dones if tr.dones.dtype in (torch.uint8, torch.bool) else tr.dones.to(torch.uint8)
+            if dones.dtype == torch.bool:
+                dones = dones.view(torch.uint8)
+            # the 11 destination rows of step s: addresses from a plan marshalled once (base pointer + s * step bytes),
+            # only the source pointers are filled in per step -- the env step is host-bound, every us of FFI glue counts
+            plan = self._store_plan()
+            srcs = (f(tr.observations), f(tr.next_observations), f(tr.privileged_observations), f(tr.observation_histories),
+                    f(tr.actions), dones.reshape(-1), f(tr.values), f(tr.actions_log_prob).reshape(-1), f(tr.action_mean),
+                    f(tr.base_vel), f(tr.action_sigma))
+            items = plan["items"]
+            for i, (src, (base, step_bytes, width, numel, dtype)) in enumerate(zip(srcs, plan["dst"])):
+                # per-call checks (a handful of integer compares): the kernel trusts these descriptors blindly
+                if src.shape[0] != self.num_envs or src.numel() != self.num_envs * numel or src.dtype != dtype or \
+                        (src.dim() > 1 and src.stride(-1) != 1) or not src.is_cuda:
+                    raise _ffi.DtcError(f"add_transitions: field {i} has shape {tuple(src.shape)} / strides {src.stride()} / "
+                                        f"{src.dtype} on {src.device}; expected [{self.num_envs}, {numel}] {dtype} rows with unit "
+                                        "inner stride on the storage's device")
+                it = items[i]
+                it.src, it.dst = src.data_ptr(), base + s * step_bytes
+                it.src_stride_bytes = src.stride(0) * src.element_size()
+            to = None
+            if time_outs is not None:
+                to = time_outs.to(self.device)
+                to = to.view(torch.uint8) if to.dtype == torch.bool else to.to(torch.uint8)
+            ops.store_transition_items(items, len(srcs), f(tr.rewards).reshape(-1).contiguous(), f(tr.values).reshape(-1), to,
+                                       gamma, self.rewards[s], self.num_envs)
+        else:
+            if time_outs is not None:
+                tr.rewards = tr.rewards + gamma * torch.squeeze(tr.values * time_outs.unsqueeze(1).to(self.device), 1)
+            self.observations[s].copy_(tr.observations)
+            self.next_observations[s].copy_(tr.next_observations)
+            self.privileged_observations[s].copy_(tr.privileged_observations)
+            self.observation_histories[s].copy_(tr.observation_histories)
+            self.actions[s].copy_(tr.actions)
+            self.rewards[s].copy_(tr.rewards.view(-1, 1))
+            self.dones[s].copy_(tr.dones.view(-1, 1))
+            self.values[s].copy_(tr.values)
+            self.actions_log_prob[s].copy_(tr.actions_log_prob.view(-1, 1))
+            self.mu[s].copy_(tr.action_mean)
+            self.base_vel[s].copy_(tr.base_vel)
+            self.sigma[s].copy_(tr.action_sigma)
+        self._save_hidden_states(tr.hidden_states)
+        self.step += 1
+
+    def _store_plan(self):
+        dsts = (self.observations, self.next_observations, self.privileged_observations, self.observation_histories,
+                self.actions, self.dones, self.values, self.actions_log_prob, self.mu, self.base_vel, self.sigma)
+        plan = getattr(self, "_plan", None)
+        ptrs = tuple(t.data_ptr() for t in dsts)
+        if plan is None or plan["ptrs"] != ptrs:          # first use, or a buffer was replaced (.to(), re-assignment)
+            items = (_ffi.DtcRowCopy * len(dsts))()
+            meta = []
+            for i, t in enumerate(dsts):
+                row = t[0, 0].numel() * t.element_size()
+                items[i].width_bytes = row
+                meta.append((t.data_ptr(), t.stride(0) * t.element_size(), row, t[0, 0].numel(), t.dtype))
+            plan = self._plan = dict(items=items, dst=meta, ptrs=ptrs)
         return plan
 
     def _save_hidden_states(self, hidden_states):
@@ -167,14 +288,6 @@ class RolloutStorage:
         dp.allreduce_sum_(self._stats[1:2])
         ops.adv_normalize(self.advantages, self._stats, count)
 
-    def get_statistics(self):
-        done = self.dones
-        done[-1] = 1
-        flat_dones = done.permute(1, 0, 2).reshape(-1, 1)
-        done_indices = torch.cat((flat_dones.new_tensor([-1], dtype=torch.int64), flat_dones.nonzero(as_tuple=False)[:, 0]))
-        trajectory_lengths = (done_indices[1:] - done_indices[:-1])
-        return trajectory_lengths.float().mean(), self.rewards.mean()
-
     def flat(self, name):
         return getattr(self, name).flatten(0, 1)
 
@@ -196,38 +309,52 @@ class RolloutStorage:
                        g["actions_log_prob"], g["mu"], g["sigma"], g["base_vel"], g["next_observations"],
                        (None, None), None, g["rewards"])
 
-    # for RNNs only (rollout_storage.py:217-267)
+    # ---- recurrent mini-batches (rollout_storage.py:217-267) ------------------------------------------------------
+    # With more than one state tensor per network (LSTM: h and c) the reference hands the ACTOR's saved states to the critic
+    # as well (rollout_storage.py:262).  "reference" reproduces that (an update then matches the reference's, pinned by
+    # tests/golden/lstm.npz); "own" yields the critic's own states.  A GRU has one state tensor and is not affected.
+    lstm_critic_states = "reference"
+
+    def trajectory_layout(self, num_mini_batches):
+        """Index data of the recurrent mini-batches of the stored rollout, computed once per update on the device:
+        trajectories are numbered env-major (dtc_amd.utils.trajectory_index_map), so the trajectories of an env slice are
+        a contiguous range `bounds[i]:bounds[i+1]`; `start_row[j]` = time-major storage row (t * N + env) of trajectory j's
+        first step.  One host transfer (the num_mini_batches + 1 bounds) per call."""
+        T, N = self.num_transitions_per_env, self.num_envs
+        traj_id, _pos, lengths, n_traj = trajectory_index_map(self.dones)
+        first = torch.cumsum(lengths, 0) - lengths                      # env-major index n * T + t of every trajectory start
+        start_row = (first % T) * N + torch.div(first, T, rounding_mode="floor")
+        mb = N // num_mini_batches
+        slice_first = torch.arange(num_mini_batches, device=traj_id.device) * (mb * T)
+        bounds = traj_id[slice_first].tolist() + [n_traj]
+        return dict(bounds=bounds, start_row=start_row, lengths=lengths, n_traj=n_traj, mb=mb)
+
+    def _states_at(self, saved, start_row):
+        """[T, layers, N, H] saved states -> [layers, n_traj, H] at the trajectory starts (one row gather per state tensor)."""
+        out = []
+        for s in saved:
+            T, L, N, H = s.shape
+            out.append(s.transpose(1, 2).reshape(T * N, L, H).index_select(0, start_row).transpose(0, 1).contiguous())
+        return out
+
     def reccurent_mini_batch_generator(self, num_mini_batches, num_epochs=8):
-        padded_obs_trajectories, trajectory_masks = split_and_pad_trajectories(self.observations, self.dones)
-        if self.privileged_observations is not None:
-            padded_critic_obs_trajectories, _ = split_and_pad_trajectories(self.privileged_observations, self.dones)
+        """Yields the reference's 11-tuples: padded actor / critic observation trajectories of an env slice, the slice's
+        rows of the flat quantities, the hidden states at its trajectory starts and the padding masks."""
+        lay = self.trajectory_layout(num_mini_batches)
+        padded_obs, masks = split_and_pad_trajectories(self.observations, self.dones)
+        critic_src = self.privileged_observations if self.privileged_observations is not None else self.observations
+        padded_critic = padded_obs if critic_src is self.observations else split_and_pad_trajectories(critic_src, self.dones)[0]
+        hid_a_all = self._states_at(self.saved_hidden_states_a, lay["start_row"])
+        if len(hid_a_all) > 1 and self.lstm_critic_states == "reference":
+            hid_c_all = hid_a_all                                        # (sic) rollout_storage.py:262
         else:
-            padded_critic_obs_trajectories = padded_obs_trajectories
-        mini_batch_size = self.num_envs // num_mini_batches
-        for ep in range(num_epochs):
-            first_traj = 0
+            hid_c_all = self._states_at(self.saved_hidden_states_c, lay["start_row"])
+        per_env = (self.actions, self.values, self.advantages, self.returns, self.actions_log_prob, self.mu, self.sigma)
+        unwrap = lambda hs: hs[0] if len(hs) == 1 else hs
+        for _epoch in range(num_epochs):
             for i in range(num_mini_batches):
-                start, stop = i * mini_batch_size, (i + 1) * mini_batch_size
-                dones = self.dones.squeeze(-1)
-                last_was_done = torch.zeros_like(dones, dtype=torch.bool)
-                last_was_done[1:] = dones[:-1]
-                last_was_done[0] = True
-                trajectories_batch_size = int(torch.sum(last_was_done[:, start:stop]))
-                last_traj = first_traj + trajectories_batch_size
-                masks_batch = trajectory_masks[:, first_traj:last_traj]
-                obs_batch = padded_obs_trajectories[:, first_traj:last_traj]
-                critic_obs_batch = padded_critic_obs_trajectories[:, first_traj:last_traj]
-                sl = lambda t: t[:, start:stop]
-                lwd = last_was_done.permute(1, 0)
-                pick = lambda saved: [s.permute(2, 0, 1, 3)[lwd][first_traj:last_traj].transpose(1, 0).contiguous()
-                                      for s in saved]
-                hid_a_batch = pick(self.saved_hidden_states_a)
-                hid_c_batch = pick(self.saved_hidden_states_c)
-                hid_a_batch = hid_a_batch[0] if len(hid_a_batch) == 1 else hid_a_batch
-                # (sic) rollout_storage.py:262 -- with more than one state tensor (LSTM: h and c) the reference hands the
-                # ACTOR's saved states to the critic as well; kept, so that an update matches the reference's
-                hid_c_batch = hid_c_batch[0] if len(hid_c_batch) == 1 else hid_a_batch
-                yield (obs_batch, critic_obs_batch, sl(self.actions), sl(self.values), sl(self.advantages),
-                       sl(self.returns), sl(self.actions_log_prob), sl(self.mu), sl(self.sigma),
-                       (hid_a_batch, hid_c_batch), masks_batch)
-                first_traj = last_traj
+                a, b = lay["bounds"][i], lay["bounds"][i + 1]
+                envs = slice(i * lay["mb"], (i + 1) * lay["mb"])
+                hid_a = unwrap([h[:, a:b].contiguous() for h in hid_a_all])
+                hid_c = unwrap([h[:, a:b].contiguous() for h in hid_c_all])
+                yield (padded_obs[:, a:b], padded_critic[:, a:b], *(t[:, envs] for t in per_env), (hid_a, hid_c), masks[:, a:b])

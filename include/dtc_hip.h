@@ -38,7 +38,13 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-int dtc_version(void);                       /* ABI version, bumped on signature changes  */
+#define DTC_ABI_VERSION 3                    /* bumped whenever a signature or a by-value struct layout changes       */
+int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
+/* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
+   DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec: the binding compares them with its own layouts at load time (a library
+   built from another revision -- e.g. a stale DTC_LIB override -- must not receive descriptors it would misread).
+   Returns the number of entries (written up to `cap`). */
+int dtc_abi_sizes(int64_t* out, int cap);
 const char* dtc_last_error(void);            /* host string describing the last failure   */
 
 /* ---- foothold planner: legged_gym/envs/base/legged_robot_dtc.py:98-201 ----------------- */

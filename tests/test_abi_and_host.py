@@ -29,7 +29,13 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/dtc_hip.h but not exported"
     assert sorted(_ffi.exported_symbols()) == syms, "ctypes signature table out of sync with the header"
-    assert _ffi.lib().dtc_version() >= 1
+    header = open(os.path.join(ROOT, "include", "dtc_hip.h")).read()
+    C = ctypes
+    assert _ffi.lib().dtc_version() == _ffi.ABI_VERSION == int(re.search(r"#define DTC_ABI_VERSION (\d+)", header).group(1))
+    # the struct layouts of the binding are the library's (checked at load time; here: the check itself works)
+    sizes = (C.c_int64 * 16)()
+    n = _ffi.lib().dtc_abi_sizes(sizes, 16)
+    assert n == 9 and sizes[3] == C.sizeof(_ffi.DtcSeg) and sizes[6] == C.sizeof(_ffi.DtcWgradJob)
 
 
 def test_argument_validation_without_gpu():

@@ -220,3 +220,27 @@ def test_recurrent_overlapped_schedule_equals_serial_bitwise():
             out.append({k: v.clone() for k, v in ac.state_dict().items()})
         for k, v in out[0].items():
             assert torch.equal(v, out[1][k]), (kind, k)
+
+
+@pytest.mark.gpu
+def test_runner_drives_the_recurrent_actor_critic_by_name():
+    """BASELINE configs[2] from train_cfg, as the reference's runner resolves classes by name (on_policy_runner.py:38-42,
+    60, 67): `ActorCriticRecurrent` with the GRU of the config, trained by `RecurrentPPO` (the upstream PPO step; the
+    fork's own `PPO` fails on this model with the same AttributeError as the reference, ppo.py:79)."""
+    from dtc_amd.env import ReplayEnv
+    from dtc_amd.runners import OnPolicyRunner
+    pol = dict(actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], activation='elu', rnn_type='gru',
+               rnn_hidden_size=512, rnn_num_layers=1)
+    cfg = dict(runner=dict(policy_class_name="ActorCriticRecurrent", algorithm_class_name="RecurrentPPO",
+                           num_steps_per_env=24, save_interval=10), algorithm=dict(learning_rate=1e-3), policy=pol)
+    r = OnPolicyRunner(ReplayEnv(32, DEV), cfg, log_dir=None, device=DEV)
+    r.learn(2)
+    assert r.current_learning_iteration == 2
+    assert all(torch.isfinite(v).all() for v in r.alg.actor_critic.state_dict().values())
+    assert r.alg.storage.saved_hidden_states_a[0].shape == (24, 1, 32, 512)
+    assert r.get_inference_policy()(torch.zeros(32, 53, device=DEV)).shape == (32, 12)
+    with pytest.raises(AttributeError, match="vae"):
+        OnPolicyRunner(ReplayEnv(32, DEV), dict(cfg, runner=dict(cfg["runner"], algorithm_class_name="PPO")), device=DEV)
+    with pytest.raises(AttributeError, match="vae"):       # the MLP actor-critic resolves by name too; only PPO-with-VAE trains here
+        OnPolicyRunner(ReplayEnv(32, DEV), dict(cfg, policy=dict(), runner=dict(cfg["runner"], policy_class_name="ActorCritic",
+                                                                               algorithm_class_name="PPO")), device=DEV)

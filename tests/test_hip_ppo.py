@@ -3,8 +3,10 @@ step as SURVEY.md F4 prescribes: before every step the HIP model, both Adam stat
 rate are synchronised from the oracle, both run ONE mini-batch on identical indices / noise, and the
 per-step scalars, gradient norms, every parameter gradient and the updated weights are compared.
 Each mini-batch is two optimisation steps (VAE, PPO); both start from the oracle's exact state.
-Tolerance: 1e-5 * max(1, |x|) on scalars (BASELINE.json north_star), 2e-5 of the tensor's max on every
-parameter gradient; the optimiser kernel itself is checked against torch.optim.Adam on equal gradients.
+Tolerance: 1e-5 * max(1, |x|) on scalars (BASELINE.json north_star); every parameter gradient: max(99th percentile of the
+element errors, L2 error / 5) <= 2e-5 of the tensor's max (+ 3/B per ReLU knife edge); weights: 2e-6 abs on every element
+when the HIP optimiser steps on the ORACLE's gradient (the real arena, the batch's real sizes), a sanity bound on the
+weights from its own gradients (see _compare_weights).
 GPU only."""
 import numpy as np
 import pytest
@@ -97,6 +99,7 @@ def _compare_grads(k, which, grads_ref, ref, alg, n_expected, strict=False):
     # ... and at B = 24576 the 3.7e5 non-outliers are ~2e-6 apart around the median, so fp32 GEMM noise
     # (3e-7) can even swap WHICH element is the median: compare the element index, not just the value.
     same_median = int(fw.info[0]) == vae.last_outliers and int(fw.info[1]) == vae.last_median_index
+    BRANCH_LOG.append((B, which, bool(same_median)))          # full-size tests ASSERT that the compared branch ran (below)
     if B >= 4096:
         print(f"[step {k} {which}] B={B}: CE-net encoder gradients {'compared' if same_median else 'SKIPPED (median on another element)'}; "
               f"ReLU knife edges {n_mis}")
@@ -120,17 +123,46 @@ def _compare_grads(k, which, grads_ref, ref, alg, n_expected, strict=False):
     return n_mis
 
 
-def _compare_weights(k, before, ref, alg):
-    """Weights after clip+Adam.  The exactness of the optimiser kernel given equal gradients is covered
-    by test_clip_adam_kernel_vs_torch_adam and gradient equality by _compare_grads; here only a sanity
-    bound, because Adam's update lr*m/(sqrt(v)+1e-8) amplifies fp32 rounding noise of gradients that are
-    ~1e-8 after clipping into differences of up to 2*lr on those elements."""
-    sd_ref, sd = ref.actor_critic.state_dict(), alg.actor_critic.state_dict()
-    for name, w in sd_ref.items():
-        diff = (sd[name].cpu() - w).abs()
-        upd = (w - before[name]).norm().item()
+BRANCH_LOG = []          # (B, "vae" | "main", CE-net encoder gradients compared?) per _compare_grads call
+
+
+def _snapshot(ref):
+    import copy
+    return dict(model={n: w.clone() for n, w in ref.actor_critic.state_dict().items()},
+                opt=copy.deepcopy(ref.optimizer.state_dict()), vae_opt=copy.deepcopy(ref.vae_optimizer.state_dict()))
+
+
+def _compare_weights(k, which, pre, grads_ref, ref, alg):
+    """Weights after clip + Adam, in two parts.
+    (1) ENFORCED, 2e-6 abs on EVERY weight: the oracle's pre-clip gradient is written into the real gradient arena, the
+        HIP optimiser (dtc_clip_adam over the optimiser's arena range, at this batch's real sizes) steps from the
+        oracle's pre-step weights / Adam moments / learning rate, and the result must equal the oracle's post-step
+        weights -- the clip + Adam kernel pair on real data, independent of gradient noise.  Gradient equality itself is
+        _compare_grads' job.
+    (2) sanity only: the weights the HIP step produced from its OWN gradients.  Adam's update lr * m / (sqrt(v) + 1e-8)
+        turns fp32 rounding noise of gradients that are ~1e-8 after clipping into differences of up to 2 * lr on those
+        elements (the reference drifts the same way between 1 and 8 CPU threads), so this part only bounds
+        the damage: no weight off by more than 2.5 lr-steps, the error smaller than the update itself."""
+    sd_ref = ref.actor_critic.state_dict()
+    sd = {n: w.cpu().clone() for n, w in alg.actor_critic.state_dict().items()}
+    for name, w in sd_ref.items():                      # (2)
+        diff = (sd[name] - w).abs()
+        upd = (w - pre["model"][name]).norm().item()
         assert float(diff.max()) <= 2.5e-3, (k, name, float(diff.max()))
         assert diff.norm().item() <= 0.75 * upd + 1e-6, (k, name, diff.norm().item(), upd)
+    ac = alg.actor_critic                               # (1)
+    ac.load_state_dict(pre["model"])
+    alg.optimizer.load_state_dict(pre["opt"])
+    alg.vae_optimizer.load_state_dict(pre["vae_opt"])
+    arena = ac.arena
+    arena.grad.zero_()
+    for name, g in grads_ref.items():
+        arena.view(arena.grad, name).copy_(g.to(DEV))
+    opt = alg.vae_optimizer if which == "vae" else alg.optimizer
+    opt.set_lr(5e-4 if which == "vae" else ref.learning_rate)      # the oracle adapts the LR before its optimiser step
+    opt.step(alg.max_grad_norm)
+    worst = max((float((ac.state_dict()[name].cpu() - w).abs().max()), name) for name, w in sd_ref.items())
+    assert worst[0] <= 2e-6, (k, which, worst)
 
 
 def _teacher_forced_step(k, ref, alg, idx, e1, e2):
@@ -139,20 +171,20 @@ def _teacher_forced_step(k, ref, alg, idx, e1, e2):
     rec = StepRecord()
     ref.capture_grads = alg.capture_grads = True
     _sync_from_oracle(ref, alg)
-    before = {n: w.clone() for n, w in ref.actor_critic.state_dict().items()}
+    pre = _snapshot(ref)
     ref.vae_step(idx, e1, rec)
     row, _ = alg.step_minibatch(idx, e1, e2, which="vae")
     _compare_scalars(k, rec, row, ref, ("recons", "vel", "kld", "height", "vae_gnorm"))
     _compare_grads(k, "vae", rec.extra["vae_grads"], ref, alg, 26)
-    _compare_weights(k, before, ref, alg)
+    _compare_weights(k, "vae", pre, rec.extra["vae_grads"], ref, alg)
     _sync_from_oracle(ref, alg)
-    before = {n: w.clone() for n, w in ref.actor_critic.state_dict().items()}
+    pre = _snapshot(ref)
     ref.ppo_step(idx, e2, rec)
     row, lr = alg.step_minibatch(idx, e1, e2, which="ppo")
     _compare_scalars(k, rec, row, ref, ("surrogate", "value", "entropy", "kl_mean", "gnorm"))
     assert lr == ref.learning_rate, (k, lr, ref.learning_rate)
     _compare_grads(k, "main", rec.extra["grads"], ref, alg, 31)
-    _compare_weights(k, before, ref, alg)
+    _compare_weights(k, "main", pre, rec.extra["grads"], ref, alg)
 
 
 def test_initialisation_matches_reference_seed(golden):
@@ -322,8 +354,16 @@ def test_update_teacher_forced_4096(seed, noise_seed, steps):
     element, see _compare_grads)."""
     ref, alg = _pair(4096, seed=seed)
     perm, e1, e2 = S.update_noise(4096, 24, 4, 5, seed=noise_seed)
-    for k in range(steps):
-        _teacher_forced_step(k, ref, alg, perm[k * 24576:(k + 1) * 24576], e1[k], e2[k])
+    del BRANCH_LOG[:]
+    covered = lambda: all(any(same for B, w, same in BRANCH_LOG if B == 24576 and w == which) for which in ("vae", "main"))
+    k = 0
+    # the CE-net encoder / latent-head gradients (128 x 128 / grouped weight-gradient kernels at B = 24576) are only
+    # comparable when both sides put the median on the same element (~92 % of the calls): that branch must have RUN for
+    # both optimisers -- up to three extra steps are taken until it has, then the test FAILS instead of printing
+    while k < steps or (not covered() and k < steps + 3):
+        _teacher_forced_step(k, ref, alg, perm[(k % 4) * 24576:(k % 4 + 1) * 24576], e1[k], e2[k])
+        k += 1
+    assert covered(), BRANCH_LOG
 
 
 def test_update_free_running_matches_reference_golden(golden):

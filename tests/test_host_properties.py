@@ -53,3 +53,55 @@ def test_mini_batch_generator_visits_every_sample_once_per_epoch(N, T, nmb, epoc
         ep = torch.cat(seen[e * nmb:(e + 1) * nmb])
         assert ep.numel() == nmb * B and ep.unique().numel() == nmb * B
         assert torch.equal(ep, torch.cat(seen[:nmb]))            # one randperm per update, reused by all epochs (:165)
+
+
+@pytest.mark.parametrize("kind", ["gru", "lstm"])
+def test_recurrent_generator_on_index_maps_equals_the_reference_fixture_and_oracle(kind, golden):
+    """RolloutStorage.reccurent_mini_batch_generator (host logic on index maps, CPU tensors here) against (a) the shapes /
+    sums the reference's own generator produced (tests/golden/{gru,lstm}.npz) and (b) every tensor of the oracle's
+    restatement of rollout_storage.py:217-267, incl. the (sic) actor states handed to the LSTM critic; `"own"` yields the
+    critic's states instead."""
+    import importlib
+    import numpy as np
+    from dtc_amd.storage import RolloutStorage
+    from oracle import gru_ref as GR
+    mod = importlib.import_module("tests.test_gru_path" if kind == "gru" else "tests.test_lstm_path")
+    g = golden(kind)
+    if kind == "gru":
+        data, hid_a, hid_c = mod.gru_case()
+        sa, sc = [hid_a], [hid_c]
+    else:
+        data, hid_a, hid_c = mod.lstm_case()
+        sa, sc = list(hid_a), list(hid_c)
+    n = data["observations"].shape[1]
+    st = RolloutStorage(n, 24, [53], [1389], [1], [12], "cpu")
+    for k, v in data.items():
+        if k not in ("last_values", "observation_histories"):
+            getattr(st, k).copy_(v)
+    st.saved_hidden_states_a, st.saved_hidden_states_c = sa, sc
+    ref = mod.oracle_storage(data) if kind == "gru" else mod.oracle_storage(data)
+    want = list(GR.recurrent_batches(ref, hid_a, hid_c, 4))
+    got = list(st.reccurent_mini_batch_generator(4, 2))
+    assert len(got) == 8
+    for i, (b, w) in enumerate(zip(got[:4], want)):
+        obs, cobs, actions, values, adv, ret, logp, mu, sigma, (ha, hc), masks = b
+        if f"mb{i}_shape" in g.files:
+            shape = g[f"mb{i}_shape"]
+            assert list(obs.shape) == list(shape[:3]) and list(masks.shape) == list(shape[3:5])
+            if f"mb{i}_mask_sum" in g.files:
+                assert int(masks.sum()) == int(g[f"mb{i}_mask_sum"][0])
+                assert abs(obs.double().sum().item() - g[f"mb{i}_obs_sum"][0]) < 1e-6
+        assert torch.equal(obs, w["obs"]) and torch.equal(cobs, w["cobs"]) and torch.equal(masks, w["masks"])
+        assert torch.equal(actions, st.actions[:, w["sl"]]) and torch.equal(sigma, st.sigma[:, w["sl"]])
+        flat = lambda h: list(h) if isinstance(h, (tuple, list)) else [h]
+        for x, y in zip(flat(ha) + flat(hc), flat(w["hid_a"]) + flat(w["hid_c"])):
+            assert torch.equal(x, y)
+        for b2, b1 in zip(got[4 + i], b):                       # second epoch: the same batches
+            for x, y in zip(flat(b2) if not torch.is_tensor(b2) else [b2], flat(b1) if not torch.is_tensor(b1) else [b1]):
+                for u, v in zip(flat(x), flat(y)):
+                    assert torch.equal(u, v)
+    if kind == "lstm":
+        st.lstm_critic_states = "own"
+        b = next(iter(st.reccurent_mini_batch_generator(4, 1)))
+        own = next(iter(GR.recurrent_batches(ref, hid_c, hid_c, 4)))["hid_a"]
+        assert all(torch.equal(x, y) for x, y in zip(b[9][1], own)) and not torch.equal(b[9][1][0], b[9][0][0])
