@@ -96,7 +96,8 @@ template <int BN, bool MSE = false, bool DEEP = false>
 __global__ __launch_bounds__(256, DEEP ? 3 : (BN == 128 ? 2 : DTC_FWD_WAVES)) void linear_fwd_kernel(const SegMatDev X, const float* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ Y,
                                                          long long ldy, int M, int N, int K, int act, int wide,
-                                                         const MseEpi mse) {
+                                                         const MseEpi mse, unsigned short* __restrict__ rmask = nullptr,
+                                                         int ldm = 0) {
     // wave layout: BN <= 64: four waves stacked along the rows, each 32 x BN; BN = 128: 2 x 2 waves, each 64 x 64 (2 x 2 MFMA
     // tiles: 8 ds_read_b128 feed 32 MFMAs per stage instead of 6 for 16, one barrier covers twice the MFMA work)
     constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN;
@@ -323,6 +324,15 @@ __global__ __launch_bounds__(256, DEEP ? 3 : (BN == 128 ? 2 : DTC_FWD_WAVES)) vo
             const float bv = bias ? bias[n0 + wn_off + 32 * j + l31] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+            if (rmask) {
+                // sign record of the ReLU (dtc_linear_fwd_mask): one bit per output, packed in the accumulator layout --
+                // lane (column, half) holds 16 rows of its column -> one 16-bit word per (32-row block, half, column).  The
+                // data gradient reads 1 bit instead of the 4-byte activation (y > 0 <=> pre-activation > 0)
+                unsigned bits = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bits |= acc[i][j][r] > 0.f ? (1u << r) : 0u;
+                rmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * ldm + n0 + wn_off + 32 * j + l31] = (unsigned short)bits;
+            }
             patch_put(patch, acc[i][j], half, l31);
             float* yp = &Y[(long long)(m0 + wm_off + 32 * i + prow) * ldy + n0 + wn_off + 32 * j + 4 * pc4];
             // the activation is wave-uniform: one branch per tile, not a select around expm1f per element
@@ -518,7 +528,8 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 6) void linear_dgrad_kernel(const f
                                                            const float* __restrict__ W, const SegMatDev dX,
                                                            const float* __restrict__ Xs, long long ldxs, int M, int N,
                                                            int K, int act, int split_n, long long split_dst, int col_skip,
-                                                           int wide_segs) {
+                                                           int wide_segs, const unsigned short* __restrict__ rmask = nullptr,
+                                                           int ldm = 0) {
     constexpr int TN = BN / 32;
     constexpr int NA = BM / 64;
     constexpr int LDB = BN + 4;
@@ -653,6 +664,19 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 6) void linear_dgrad_kernel(const f
     }
 
     // ---- epilogue: activation derivative (through the saved post-activation output), segmented destination
+    if (rmask) {
+        // ReLU derivative from the forward kernel's sign record (dtc_linear_dgrad_mask): 2 bytes per lane and 32 x 32 tile
+        // instead of the 64 bytes of saved activations; full tiles only (checked by the host).  The result has the same bits
+        // as `y > 0 ? g : 0` on the saved output.
+        unsigned bits[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bits[j] = rmask[((long long)((m0 + wm_off) >> 5) * 2 + half) * ldm + c0 + 32 * j + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = (bits[j] >> r) & 1u ? acc[j][r] : 0.f;
+        act = DTC_ACT_NONE;
+    }
     const rsrc_t xres = make_rsrc_bytes(Xs, (long long)M * ldxs * 4);
     if (m0 + BM <= M && c0 + BN <= K) {
         // wide path per 32-column sub-tile that lies inside ONE destination segment with 16-byte aligned rows: transpose
@@ -790,8 +814,16 @@ extern "C" int dtc_debug_set_trace(unsigned long long* buf) {
 }
 #endif
 
-extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, int M, int N,
-                              int K, int act, void* stream) {
+// rows of 16-bit words per matrix of M rows: 2 per 32-row block, row tiles of 128 rows are always written whole
+static inline long long mask_rows(int M) { return dtc::ceil_div(M, BM) * (BM / 32) * 2; }
+
+extern "C" int64_t dtc_relu_mask_elems(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return mask_rows(M) * (int64_t)N;
+}
+
+static int linear_fwd_impl(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, int M, int N,
+                           int K, int act, uint16_t* rmask, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
     DTC_REQUIRE(W && Y, "null pointer");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
@@ -806,14 +838,32 @@ extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b
     // dwordx4 stores of the output need 16-byte aligned rows (full tiles only; checked per block)
     static const bool wide_off = getenv("DTC_GEMM_WIDE") && atoi(getenv("DTC_GEMM_WIDE")) == 0;      // A/B switch
     const int wide = (!wide_off && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
+    if (rmask) {
+        // the sign record is written by the wide epilogue of FULL tiles only: every tile of the launch must be one
+        DTC_REQUIRE(act == DTC_ACT_RELU, "a sign record needs the ReLU activation (got %d)", act);
+        DTC_REQUIRE(wide && M % BM == 0 && N % bn == 0, "sign record: M=%d must be a multiple of %d, N=%d of the %d-wide tile, Y 16-byte aligned rows", M, BM, N, bn);
+    }
+    unsigned short* rm = rmask;
+    const int ldm = N;
     if (bn == 128) {
-        hipLaunchKernelGGL((linear_fwd_kernel<128, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
+        hipLaunchKernelGGL((linear_fwd_kernel<128, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm);
     } else if (deep_variant(grid)) {
-        if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
-        else hipLaunchKernelGGL((linear_fwd_kernel<32, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
-    } else if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), occ_pad("FWD", 24576), s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
-    else hipLaunchKernelGGL((linear_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{});
+        if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm);
+        else hipLaunchKernelGGL((linear_fwd_kernel<32, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm);
+    } else if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), occ_pad("FWD", 24576), s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm);
+    else hipLaunchKernelGGL((linear_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm);
     return dtc::check_launch("linear_fwd");
+}
+
+extern "C" int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, int M, int N,
+                              int K, int act, void* stream) {
+    return linear_fwd_impl(X, W, b, Y, ldy, M, N, K, act, nullptr, stream);
+}
+
+extern "C" int dtc_linear_fwd_mask(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
+                                   int M, int N, int K, void* stream) {
+    DTC_REQUIRE(relu_mask != nullptr, "null sign record");
+    return linear_fwd_impl(X, W, b, Y, ldy, M, N, K, (int)DTC_ACT_RELU, relu_mask, stream);
 }
 
 extern "C" void dtc_set_concurrency_hint(int side_stream_active) { g_concurrency_hint = side_stream_active ? 1 : 0; }
@@ -866,8 +916,8 @@ extern "C" int dtc_gru_step_fwd(const float* hprev, const float* W_hh, const flo
     return dtc::check_launch("gru_step_fwd");
 }
 
-extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved,
-                                int64_t ldxs, int M, int N, int K, int act, void* stream) {
+static int linear_dgrad_impl(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved,
+                             int64_t ldxs, int M, int N, int K, int act, const uint16_t* rmask, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
     DTC_REQUIRE(dZ && W, "null pointer");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
@@ -888,14 +938,30 @@ extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, c
     double bytes = 4.0 * ((double)M * N + (double)N * K);                           // dZ, W
     for (int i = 0; i < xd.nseg; ++i)
         if (xd.s[i].ptr) bytes += 4.0 * M * xd.s[i].width * (xd.s[i].accumulate ? 2.0 : 1.0);   // dX written (+ read when accumulated)
-    if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)K;                          // saved activations
+    if (rmask) bytes += 0.125 * M * (double)K;                                       // one bit per output: the sign record
+    else if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)K;                     // saved activations
+    if (rmask) DTC_REQUIRE(M % BM == 0 && K % bn == 0 && col_skip == 0, "sign record: M=%d must be a multiple of %d and K=%d of the %d-wide tile", M, BM, K, bn);
+    const unsigned short* rm = rmask;
+    const int ldm = K;
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s, bytes);
     if (deep_variant(grid)) {
-        if (bn == 64) hipLaunchKernelGGL((linear_dgrad_kernel<64, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
-        else hipLaunchKernelGGL((linear_dgrad_kernel<32, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
-    } else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), occ_pad("DGRAD", 25088, g_concurrency_hint ? 5 : 0), s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
-    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide);
+        if (bn == 64) hipLaunchKernelGGL((linear_dgrad_kernel<64, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm);
+        else hipLaunchKernelGGL((linear_dgrad_kernel<32, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm);
+    } else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), occ_pad("DGRAD", 25088, g_concurrency_hint ? 5 : 0), s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm);
     return dtc::check_launch("linear_dgrad");
+}
+
+extern "C" int dtc_linear_dgrad(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved,
+                                int64_t ldxs, int M, int N, int K, int act, void* stream) {
+    return linear_dgrad_impl(dZ, lddz, W, dX, Xsaved, ldxs, M, N, K, act, nullptr, stream);
+}
+
+extern "C" int dtc_linear_dgrad_mask(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const uint16_t* relu_mask,
+                                     int M, int N, int K, void* stream) {
+    DTC_REQUIRE(relu_mask != nullptr, "null sign record");
+    DTC_REQUIRE(dX && dX->nseg == 1, "the ReLU derivative needs a single-segment destination");
+    return linear_dgrad_impl(dZ, lddz, W, dX, nullptr, 0, M, N, K, (int)DTC_ACT_NONE, relu_mask, stream);
 }
 
 extern "C" int dtc_linear_dgrad_split(const float* dZ, int64_t lddz, const float* W, float* dX, int64_t lddx,

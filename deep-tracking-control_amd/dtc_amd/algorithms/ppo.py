@@ -271,6 +271,9 @@ class PPO:
         self.overlap_exchange = os.environ.get("DTC_DP_OVERLAP", "1") != "0"
         # terrain-decoder output layer fused with the height loss (DTC_FUSE_HEIGHT_LOSS=0: separate layer + loss kernel)
         self.fuse_height_loss = os.environ.get("DTC_FUSE_HEIGHT_LOSS", "1") != "0"
+        # ReLU layers record their output signs in the forward epilogue; the data gradient reads 1 bit instead of the saved
+        # 4-byte activation (DTC_RELU_MASK=0: derivative through the saved activations; bit-identical results)
+        self.relu_masks = os.environ.get("DTC_RELU_MASK", "1") != "0"
         self._rollout_graphs = {}
         self.capture_grads, self.captured = False, {}      # tests: snapshot of the (pre-clip) gradient arena
         self.last_update_stats = None      # [steps, STAT_COLS] table of the last update (host tensor)
@@ -426,7 +429,7 @@ class PPO:
             stats[S_KL:S_KL + 1].copy_(kl)
             ops.lr_adapt(kl, self.optimizer.lr_dev, float(self.desired_kl))
 
-    def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None):
+    def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None, mask=None):
         """Backward of one dense layer.  The weight gradient (dW = dZ^T X) is off the critical path -- only the
         optimiser step (and the data-parallel exchange) needs it -- so it is QUEUED: `_flush_wgrads` runs all queued
         layers of a gradient bucket as one grouped launch on the side stream, where it overlaps with the data-gradient
@@ -444,7 +447,7 @@ class PPO:
         else:
             ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wgrad_ws(L.n_out, L.n_in), M=tw.B)
         if dX is not None:
-            ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B)
+            ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B, mask=mask)
 
     def _flush_wgrads(self, tw):
         """Launch the queued weight gradients (everything both compute lanes have issued so far is their input)."""
@@ -471,15 +474,16 @@ class PPO:
     def _terrain_encoder_backward(self, fw, tw, flat, idx):
         L = self.actor_critic.L
         g_te2, g_te1 = tw.g("te2", 512), tw.g("te1", 512)
-        self._bwd(tw, L["te2"], tw.dlt, fw.t2, g_te2, fw.t2, "relu")
-        self._bwd(tw, L["te1"], g_te2, fw.t1, g_te1, fw.t1, "relu")
+        rm = self.relu_masks
+        self._bwd(tw, L["te2"], tw.dlt, fw.t2, g_te2, fw.t2, "relu", fw.relu_mask("t2", 512, rm))
+        self._bwd(tw, L["te1"], g_te2, fw.t1, g_te1, fw.t1, "relu", fw.relu_mask("t1", 512, rm))
         self._bwd(tw, L["te0"], g_te1, segmat([seg(flat["privileged_observations"], 0, 693, gather=True)], idx))
 
     def _cenet_encoder_backward(self, fw, tw, flat, idx):
         L = self.actor_critic.L
         g_head, g_ce1 = tw.g("head", 64), tw.g("ce1", 128)
         self._bwd(tw, L["head"], tw.dmulv, fw.e, g_head, None, None)
-        self._bwd(tw, L["ce1"], g_head, fw.e1, g_ce1, fw.e1, "relu")
+        self._bwd(tw, L["ce1"], g_head, fw.e1, g_ce1, fw.e1, "relu", fw.relu_mask("e1", 128, self.relu_masks))
         self._bwd(tw, L["ce0"], g_ce1, segmat([seg(flat["observation_histories"], 0, flat["observation_histories"].shape[1],
                                                    gather=True)], idx))
 
@@ -494,16 +498,17 @@ class PPO:
         _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap_wgrad)))     # weight gradients on the side stream
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
         dec_in = segmat([seg(fw.z, 0, 16), seg(fw.mulv, 0, 3), seg(fw.lt, 0, 512)])
+        rm = self.relu_masks
         with tw.lane("aux"):
-            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
-        ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
+            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=rm)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=rm)
         tw.order("main", "aux")                                    # l_t feeds the CE-net decoder
         with tw.lane("aux"):
-            ops.linear_fwd(dec_in, L["cd0"].W, L["cd0"].b, tw.c1, "relu", M=tw.B)
-            ops.linear_fwd(tw.c1, L["cd1"].W, L["cd1"].b, tw.c2, "relu")
+            ops.linear_fwd(dec_in, L["cd0"].W, L["cd0"].b, tw.c1, "relu", M=tw.B, mask=fw.relu_mask("c1", 64, rm))
+            ops.linear_fwd(tw.c1, L["cd1"].W, L["cd1"].b, tw.c2, "relu", mask=fw.relu_mask("c2", 128, rm))
             ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None)
-        ops.linear_fwd(fw.lt, L["td0"].W, L["td0"].b, tw.d1, "relu")
-        ops.linear_fwd(tw.d1, L["td1"].W, L["td1"].b, tw.d2, "relu")
+        ops.linear_fwd(fw.lt, L["td0"].W, L["td0"].b, tw.d1, "relu", mask=fw.relu_mask("d1", 512, rm))
+        ops.linear_fwd(tw.d1, L["td1"].W, L["td1"].b, tw.d2, "relu", mask=fw.relu_mask("d2", 512, rm))
         # The loss kernel joins the two branches, but only the CE-net decoder's backward needs its output (dL/d recons,
         # the direct part of d mulv): the terrain decoder's dL/dY comes out of its own output layer.  The loss therefore
         # runs on `aux`; the main lane goes straight from the terrain decoder's forward into its backward.
@@ -528,13 +533,13 @@ class PPO:
         g_cd2, g_cd1 = tw.g("cd2", 128), tw.g("cd1", 64)
         dst = segmat([seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3, accumulate=True), seg(tw.dlt, 0, 512)])
         with tw.lane("aux"):
-            self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu")
-            self._bwd(tw, L["cd1"], g_cd2, tw.c1, g_cd1, tw.c1, "relu")
+            self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu", fw.relu_mask("c2", 128, rm))
+            self._bwd(tw, L["cd1"], g_cd2, tw.c1, g_cd1, tw.c1, "relu", fw.relu_mask("c1", 64, rm))
             self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None)
         # terrain decoder (main)
         g_td2, g_td1 = tw.g("td2", 512), tw.g("td1", 512)
-        self._bwd(tw, L["td2"], tw.g_hr, tw.d2, g_td2, tw.d2, "relu")
-        self._bwd(tw, L["td1"], g_td2, tw.d1, g_td1, tw.d1, "relu")
+        self._bwd(tw, L["td2"], tw.g_hr, tw.d2, g_td2, tw.d2, "relu", fw.relu_mask("d2", 512, rm))
+        self._bwd(tw, L["td1"], g_td2, tw.d1, g_td1, tw.d1, "relu", fw.relu_mask("d1", 512, rm))
         tw.order("aux", "main")                                    # d l_t of the CE-net decoder is written first
         self._bwd(tw, L["td0"], g_td1, fw.lt, segmat([seg(tw.dlt, 0, 512, accumulate=True)]), None, None)
         early = self._exchange_bucket(tw, "vae_only")              # decoder gradients are complete (queued on `side`)
@@ -560,8 +565,8 @@ class PPO:
         _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap_wgrad)))     # weight gradients on the side stream
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
         with tw.lane("aux"):
-            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
-        ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
+            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=self.relu_masks)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=self.relu_masks)
         tw.order("aux", "main")                                    # z, mu feed the actor
         # output layers + losses + their data gradients in one launch when the last hidden width allows it (DTC_FUSE_HEADS)
         # (its partial-sum workspace holds 4096 blocks of 64 rows: larger mini-batches take the unfused kernels)

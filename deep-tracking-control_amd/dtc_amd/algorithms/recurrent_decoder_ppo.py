@@ -136,8 +136,8 @@ class RecurrentDecoderPPO(PPO):
 
         with tw.lane("aux"):
             hc = head_forward("c", Xc, ac.memory_c, ac.proj_c, ac.Cr, bt["hid_c"])
-        ac.cenet_forward_(fw, flat["observation_histories"], eps, idx)
-        ac.terrain_encoder_(fw, flat["privileged_observations"], idx)
+        ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=self.relu_masks)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=self.relu_masks)
         ha = head_forward("a", Xa, ac.memory_a, ac.proj_a, ac.A, bt["hid_a"])
         tw.order("aux", "main")
         mean, value = ha["outs"][-1], hc["outs"][-1]

@@ -289,6 +289,17 @@ class ActorCriticDecoder(nn.Module):
             self.a1, self.a2, self.a3, self.mean = e(B, 512), e(B, 256), e(B, 128), e(B, num_actions)
             self.v1, self.v2, self.v3, self.val = e(B, 512), e(B, 256), e(B, 128), e(B, 1)
             self.lat_ws = torch.empty(int(_ffi.lib().dtc_cenet_workspace(B)) // 8 + 1, dtype=torch.float64, device=dev)
+            self._dev, self._masks = dev, {}
+
+        def relu_mask(self, name, width, enabled=True):
+            """Sign record of a ReLU layer's [B, width] output (training only): the data gradient reads one bit per
+            element instead of the saved activation.  None when the shape is not eligible or the feature is off."""
+            if not enabled or not ops.relu_mask_ok(self.B, width):
+                return None
+            m = self._masks.get(name)
+            if m is None:
+                m = self._masks[name] = ops.relu_mask(self.B, width, self._dev)
+            return m
 
     def _fwd_ws(self, B):
         ws = self._fw.get(B)
@@ -325,20 +336,21 @@ class ActorCriticDecoder(nn.Module):
         return ch
 
     # ------------------------------------------------------------------ kernel-level forward pieces
-    def cenet_forward_(self, ws, hist, eps, idx=None):
-        """vae.cenet_forward (actor_critic_decoder.py:286-302) into ws.mulv / ws.z."""
+    def cenet_forward_(self, ws, hist, eps, idx=None, masks=False):
+        """vae.cenet_forward (actor_critic_decoder.py:286-302) into ws.mulv / ws.z.  `masks`: training step -- the ReLU
+        layers also record their output signs (ws.relu_mask) for the backward pass."""
         L = self.L
         X = segmat([seg(hist, 0, hist.shape[1], gather=idx is not None)], idx)
-        ops.linear_fwd(X, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=ws.B)
+        ops.linear_fwd(X, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=ws.B, mask=ws.relu_mask("e1", 128, masks))
         ops.linear_fwd(ws.e1, L["ce1"].W, L["ce1"].b, ws.e, None)
         ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None)
         ops.cenet_latent_fwd(ws.mulv, eps, ws.z, ws.mask, ws.info, ws.lat_ws)
 
-    def terrain_encoder_(self, ws, priv, idx=None):
+    def terrain_encoder_(self, ws, priv, idx=None, masks=False):
         L = self.L
         X = segmat([seg(priv, 0, 693, gather=idx is not None)], idx)
-        ops.linear_fwd(X, L["te0"].W, L["te0"].b, ws.t1, "relu", M=ws.B)
-        ops.linear_fwd(ws.t1, L["te1"].W, L["te1"].b, ws.t2, "relu")
+        ops.linear_fwd(X, L["te0"].W, L["te0"].b, ws.t1, "relu", M=ws.B, mask=ws.relu_mask("t1", 512, masks))
+        ops.linear_fwd(ws.t1, L["te1"].W, L["te1"].b, ws.t2, "relu", mask=ws.relu_mask("t2", 512, masks))
         ops.linear_fwd(ws.t2, L["te2"].W, L["te2"].b, ws.lt, None)
 
     def actor_input(self, ws, obs, idx=None):

@@ -82,11 +82,26 @@ def as_segmat(x, idx=None):
     return segmat([seg(x, 0, x.shape[1])], idx)
 
 
-def linear_fwd(X, W, b, Y, act=None, M=None):
-    """Y = act(X W^T + b).  X: tensor or DtcSegMat; W [N,K]; Y [M,>=N] (row stride may exceed N)."""
+def relu_mask_ok(M, N):
+    """Shapes for which a ReLU layer can record its output signs (dtc_linear_fwd_mask / dtc_linear_dgrad_mask)."""
+    return M % 128 == 0 and (N % 128 == 0 or N == 64)
+
+
+def relu_mask(M, N, device):
+    return torch.empty(int(lib().dtc_relu_mask_elems(M, N)), dtype=torch.int16, device=device)
+
+
+def linear_fwd(X, W, b, Y, act=None, M=None, mask=None):
+    """Y = act(X W^T + b).  X: tensor or DtcSegMat; W [N,K]; Y [M,>=N] (row stride may exceed N).  `mask` (relu_mask
+    buffer, act must be "relu"): also record the output signs for linear_dgrad(..., mask=)."""
     Xs = as_segmat(X)
     N, K = W.shape
     M = Y.shape[0] if M is None else M
+    if mask is not None:
+        assert act in ("relu", "crelu")
+        check(lib().dtc_linear_fwd_mask(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
+                                        ptr(mask), M, N, K, stream()), "dtc_linear_fwd_mask")
+        return Y
     check(lib().dtc_linear_fwd(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0), M, N,
                                K, ACT[act], stream()), "dtc_linear_fwd")
     return Y
@@ -123,11 +138,17 @@ class FwdChain:
               "dtc_linear_fwd_list")
 
 
-def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None):
-    """dX = (dZ W) * act'(Xsaved); dX: tensor or DtcSegMat (destination)."""
+def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None):
+    """dX = (dZ W) * act'(Xsaved); dX: tensor or DtcSegMat (destination).  `mask`: the sign record of the ReLU layer that
+    produced Xsaved (then Xsaved itself is not read)."""
     dXs = as_segmat(dX)
     N, K = W.shape
     M = dZ.shape[0] if M is None else M
+    if mask is not None:
+        assert act in ("relu", "crelu")
+        check(lib().dtc_linear_dgrad_mask(ptr(dZ), dZ.stride(0), cptr(W, f32), dXs, ptr(mask), M, N, K, stream()),
+              "dtc_linear_dgrad_mask")
+        return
     check(lib().dtc_linear_dgrad(ptr(dZ), dZ.stride(0), cptr(W, f32), dXs, ptr(Xsaved),
                                  Xsaved.stride(0) if Xsaved is not None else 0, M, N, K, ACT[act], stream()),
           "dtc_linear_dgrad")

@@ -196,6 +196,18 @@ typedef struct DtcSegMat {
 /* Y[M,N] = act(X[M,K] W[N,K]^T + b).  X is segmented (host struct). */
 int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy,
                    int M, int N, int K, int act, void* stream);
+/* Same layer with the ReLU activation, additionally writing the SIGN RECORD of its output: one bit per element
+ * (y > 0), dtc_relu_mask_elems(M, N) 16-bit words -- word [(row / 32) * 2 + half][col] holds the 16 rows
+ * 4 * half + (r & 3) + 8 * (r >> 2), r = bit index, of its 32-row block (the accumulator layout of the kernels).
+ * dtc_linear_dgrad_mask reads it instead of the saved activation: 1/32 of the bytes, the same bits as
+ * `y > 0 ? g : 0` (torch's ReLU backward, rsl_rl/modules/actor_critic_decoder.py:98-131 encoder / decoder stacks under
+ * ppo.py:252, 333).  Requires M % 128 == 0 and N a multiple of the launch's tile width (N % 128 == 0, or N == 64). */
+int64_t dtc_relu_mask_elems(int M, int N);
+int dtc_linear_fwd_mask(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
+                        int M, int N, int K, void* stream);
+/* dX[M,K] = (dZ[M,N] W[N,K]) * (relu_mask bit), single-segment destination; M % 128 == 0, K as N above. */
+int dtc_linear_dgrad_mask(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const uint16_t* relu_mask,
+                          int M, int N, int K, void* stream);
 /* A chain of forward layers in ONE call (same kernels, same results as `count` dtc_linear_fwd calls issued in order on
  * `stream`): the rollout side of PPO.act / evaluate (ppo.py:137-155) is launch-bound -- ~16 small layers per env step at
  * M = num_envs rows -- and the host cost of marshalling each layer through the FFI is paid once per chain instead of

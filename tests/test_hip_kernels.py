@@ -413,6 +413,57 @@ def test_linear_dgrad_segments_accumulate():
     assert float(dmulv2[:, 3:].abs().max()) == 0.0
     np.testing.assert_allclose(_np(dlt2), fulla[:, 72:].numpy(), rtol=2e-5, atol=2e-5)
 
+@pytest.mark.parametrize("M,N,K,Kd", [(24576, 512, 693, 512), (24576, 512, 512, 693), (384, 128, 265, 64), (24576, 64, 531, 128),
+                                      (256, 64, 128, 35), (4096, 128, 64, 53), (1024, 512, 300, 512)])
+def test_relu_sign_record_fwd_and_dgrad_are_bit_identical(M, N, K, Kd):
+    """dtc_linear_fwd_mask writes the same Y as dtc_linear_fwd(relu) plus one bit per element; dtc_linear_dgrad_mask on
+    that record gives bit for bit the data gradient dtc_linear_dgrad computes from the saved activation -- for every tile
+    shape the launches pick (128-, 64- and 32-wide tiles, the two-stages-ahead variants of small grids).  Layer under
+    test: Y = relu(X W^T + b) [M, N]; the NEXT layer's data gradient dY = (dZ [M, Kd] Wn [Kd, N]) * (Y > 0)."""
+    from dtc_amd import ops
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    X = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    assert ops.relu_mask_ok(M, N)
+    Y0, Y1 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    mask = ops.relu_mask(M, N, DEV)
+    mask.fill_(0x5555)
+    ops.linear_fwd(X, W, b, Y0, "relu")
+    ops.linear_fwd(X, W, b, Y1, "relu", mask=mask)
+    assert torch.equal(Y0, Y1)
+    # the record itself: bit r of word [(row // 32) * 2 + half][col] <-> row 32 * blk + 4 * half + (r & 3) + 8 * (r >> 2)
+    pos = (Y0 > 0).cpu().view(M // 32, 4, 2, 4, N)                       # [blk, r >> 2, half, r & 3, col]
+    bits = pos.permute(0, 2, 1, 3, 4).reshape(M // 32, 2, 16, N).to(torch.int32)
+    want = (bits << torch.arange(16, dtype=torch.int32).view(1, 1, 16, 1)).sum(dim=2).reshape(-1, N)
+    got = mask.cpu().view(-1, N).to(torch.int32) & 0xFFFF
+    assert torch.equal(got, want)
+    dZ = torch.randn(M, Kd, generator=g).to(DEV)
+    Wn = (torch.randn(Kd, N, generator=g) / Kd ** 0.5).to(DEV)
+    d0 = torch.full((M, N), float("nan"), device=DEV)
+    d1 = torch.full((M, N), float("nan"), device=DEV)
+    ops.linear_dgrad(dZ, Wn, d0, Y0, "relu")
+    ops.linear_dgrad(dZ, Wn, d1, Y0, "relu", mask=mask)
+    assert torch.equal(d0, d1)
+    ref = (dZ.double() @ Wn.double()) * (Y0 > 0)
+    np.testing.assert_allclose(_np(d1), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    # accumulating destination
+    from dtc_amd import _ffi
+    base = torch.randn(M, N, generator=g).to(DEV)
+    a0, a1 = base.clone(), base.clone()
+    ops.linear_dgrad(dZ, Wn, _ffi.segmat([_ffi.seg(a0, 0, N, accumulate=True)]), Y0, "relu")
+    ops.linear_dgrad(dZ, Wn, _ffi.segmat([_ffi.seg(a1, 0, N, accumulate=True)]), Y0, "relu", mask=mask)
+    assert torch.equal(a0, a1)
+
+
+def test_relu_sign_record_rejects_ineligible_shapes():
+    from dtc_amd import _ffi, ops
+    X, W, Y = torch.randn(200, 64, device=DEV), torch.randn(96, 64, device=DEV), torch.empty(200, 96, device=DEV)
+    assert not ops.relu_mask_ok(200, 96)
+    with pytest.raises(_ffi.DtcError, match="sign record"):
+        ops.linear_fwd(X, W, None, Y, "relu", mask=torch.empty(4096, dtype=torch.int16, device=DEV))
+
+
 @pytest.mark.parametrize("M,N,K", [(24576, 128, 256), (24576, 64, 531), (24576, 35, 64), (24576, 1, 128), (4096, 512, 752),
                                    (4096, 256, 512), (1000, 53, 128), (24576, 12, 128)])
 def test_deep_prefetch_variants_are_bit_identical(M, N, K, monkeypatch):
