@@ -242,7 +242,27 @@ def main():
     # for the roofline object.  The timed region above overlaps the weight-gradient GEMMs with the
     # data-gradient chain on a second stream; a kernel that shares the chip has no duration of its own, so this
     # pass runs the same kernels serialised (overlap off) -- rocprofv3 cross-check: DTC_OVERLAP_WGRAD=0.
-    roof, classes, planner = None, None, None
+    roof, classes, planner, planner_4096 = None, None, None, None
+    if world == 1 and rank == 0:
+        # BASELINE configs[3]: ONE planner launch over 4096 envs x 4 legs (12.7 MB: launch / latency-bound, not HBM-bound):
+        # its own line, timed with events on the launch stream over 50 back-to-back launches
+        sc4 = {k: v[:NUM_ENVS].contiguous() for k, v in sc.items()}
+        for _ in range(5):
+            foothold.plan(sc4["measured_heights"], sc4["root_states"], sc4["thigh_pos"], sc4["commands"])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        e0.record()
+        for _ in range(reps):
+            foothold.plan(sc4["measured_heights"], sc4["root_states"], sc4["thigh_pos"], sc4["commands"])
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        planner_4096 = dict(bound="hbm", kernel="foothold_plan_fast_kernel", workload="BASELINE configs[3]: 4096 envs x 4 legs, one launch",
+                            bytes_per_launch=3096.0 * NUM_ENVS, avg_launch_us=us, achieved=3096.0 * NUM_ENVS / (us * 1e-6) / 1e9,
+                            peak=8000.0, unit="GB/s", frac=3096.0 * NUM_ENVS / (us * 1e-6) / 1e9 / 8000.0,
+                            env_steps_per_s=NUM_ENVS / (us * 1e-6),
+                            measured="HIP events around 50 back-to-back launches (includes the dispatch gap between launches)")
+
     # EVERY rank runs these two extra steps (they contain the data-parallel collectives); only rank 0 records events
     lib = _ffi.lib()
     overlap, overlap_rec = getattr(alg, "overlap_wgrad", False), getattr(alg, "overlap", False)
@@ -266,7 +286,7 @@ def main():
         lib.dtc_prof_reset()
         # the GEMM family = forward / data-gradient / weight-gradient kernels AND the split-reduce kernels the weight
         # gradients need (their time counts against the family's FLOP; they add no FLOP of their own)
-        fam = ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_reduce")
+        fam = ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_reduce", "gru_step_fwd")
         gemm = [r for r in rep if r["name"].split("[")[0] in fam]
         # (the composite's GRU steps call the same three kernels from inside dtc_gru_fwd / dtc_gru_bwd)
         ms = sum(r["ms_total"] for r in gemm)
@@ -296,6 +316,19 @@ def main():
                 roof["traffic_kernels"] = {k: dict(launches=v["launches"], MB=round(v["bytes"] / 1e6, 1)) for k, v in tr["kernels"].items()}
             except Exception as e:                 # no rocprofv3 on this box / counters unavailable: say so, keep the line
                 roof["traffic_error"] = str(e)[-300:]
+            # MFMA-pipe busy fraction of the same family over one serialised step: two more PMC passes (SQ / GRBM counters)
+            try:
+                import gemm_pmc as GP
+                pm = GP.collect(os.path.join(ROOT, "gpurun_out", "gemm_pmc"), a.workload)
+                roof["mfma_busy"] = pm["family_mfma_busy"]
+                roof["mfma_busy_source"] = ("rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ... over the serialised "
+                                            "last step of a child bench run: busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), "
+                                            "summed over the family's launches (profiled runs clock lower than the timed region)")
+                roof["mfma_busy_kernels"] = {k: dict(launches=v["launches"], mfma_busy=round(v["mfma_busy"], 3),
+                                                     executed_tflops=round(v["executed_tflops"], 1), clock_ghz=round(v["clock_ghz"], 2))
+                                             for k, v in pm["kernels"].items() if v["ms"] > 0.5}
+            except Exception as e:
+                roof["mfma_busy_error"] = str(e)[-300:]
         pl = [r for r in rep if r["name"].split("[")[0] == "foothold_plan"]
         if pl:                                  # the HBM-side kernel of the path: bytes = 3096 B/env
             pms, pby, pn = (sum(r[k] for r in pl) for k in ("ms_total", "work", "launches"))
@@ -336,6 +369,7 @@ def main():
                        "collectives_per_step": len(coll_log)},
             "roofline": roof,
             "roofline_planner": planner,
+            "roofline_planner_4096": planner_4096,
             "kernel_classes": classes,
             "last_update": [float(x) for x in out],
         }

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__
 // the backward products), the head weights sit in LDS (broadcast reads), the four partial dot products of a row are
 // combined by two quad butterflies, every thread of the row then holds mean / value and evaluates the row's loss.
 // dH = (d_out W) * act'(H) with the derivative through the saved post-activation value, as linear_dgrad_kernel does.
-template <int H>
+template <int H, int TPR = 4>
 __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     const float* __restrict__ Ha, long long ldha, const float* __restrict__ Hc, long long ldhc, const float* __restrict__ Wa,
     const float* __restrict__ ba, const float* __restrict__ Wc, const float* __restrict__ bc, int act_prev,
@@ -255,7 +255,9 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     const float* __restrict__ returns, const float* __restrict__ old_values, const long long* __restrict__ idx, DtcPpoCfg cfg,
     float* __restrict__ mean, float* __restrict__ value, float* __restrict__ dmean, float* __restrict__ dvalue,
     float* __restrict__ dHa, long long lddha, float* __restrict__ dHc, long long lddhc, double* __restrict__ part, int B, int A) {
-    constexpr int NC = H / 16;                       // chunks per thread
+    // TPR threads per row (4: 64 rows per workgroup; 8: 32 rows per workgroup = twice the workgroups, half the serial work
+    // per thread -- the kernel is a latency chain per row, not a bandwidth problem)
+    constexpr int NC = H / (4 * TPR);                // chunks per thread
     typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float W[(MAX_ACT + 1) * H];      // rows 0..A-1: actor head, row A: critic head
     __shared__ float sstd[MAX_ACT], sb[MAX_ACT + 1];
@@ -266,14 +268,14 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     }
     if (threadIdx.x == 0) sb[A] = bc ? bc[0] : 0.f;
     __syncthreads();
-    const int row = blockIdx.x * 64 + (threadIdx.x >> 2), p = threadIdx.x & 3;
+    const int row = blockIdx.x * (256 / TPR) + (int)(threadIdx.x / TPR), p = threadIdx.x % TPR;
     const bool rok = row < B;
     const long long rr = rok ? row : 0;
     f4 ha[NC], hc[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-        ha[i] = *reinterpret_cast<const f4*>(Ha + rr * ldha + 4 * (p + 4 * i));
-        hc[i] = *reinterpret_cast<const f4*>(Hc + rr * ldhc + 4 * (p + 4 * i));
+        ha[i] = *reinterpret_cast<const f4*>(Ha + rr * ldha + 4 * (p + TPR * i));
+        hc[i] = *reinterpret_cast<const f4*>(Hc + rr * ldhc + 4 * (p + TPR * i));
     }
     // ---- forward: mean = Ha Wa^T + ba, value = Hc Wc^T + bc
     float mrow[MAX_ACT], v = 0.f;
@@ -281,20 +283,22 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            const f4 w = *reinterpret_cast<const f4*>(&W[j * H + 4 * (p + 4 * i)]);
+            const f4 w = *reinterpret_cast<const f4*>(&W[j * H + 4 * (p + TPR * i)]);
             acc += ha[i].x * w.x + ha[i].y * w.y + ha[i].z * w.z + ha[i].w * w.w;
         }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
+        if (TPR == 8) acc += __shfl_xor(acc, 4, 64);
         mrow[j] = acc + sb[j];
     }
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-        const f4 w = *reinterpret_cast<const f4*>(&W[A * H + 4 * (p + 4 * i)]);
+        const f4 w = *reinterpret_cast<const f4*>(&W[A * H + 4 * (p + TPR * i)]);
         v += hc[i].x * w.x + hc[i].y * w.y + hc[i].z * w.z + hc[i].w * w.w;
     }
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
+    if (TPR == 8) v += __shfl_xor(v, 4, 64);
     v += sb[A];
     // ---- the row's loss (every thread of the row evaluates it; thread p = 0 stores and contributes the sums)
     RowLoss o{0.0, 0.0, 0.0, 0.f};
@@ -319,18 +323,18 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
         for (int i = 0; i < NC; ++i) {
             f4 ga = {0.f, 0.f, 0.f, 0.f};
             for (int j = 0; j < A; ++j) {
-                const f4 w = *reinterpret_cast<const f4*>(&W[j * H + 4 * (p + 4 * i)]);
+                const f4 w = *reinterpret_cast<const f4*>(&W[j * H + 4 * (p + TPR * i)]);
                 ga += dm[j] * w;
             }
-            const f4 wc = *reinterpret_cast<const f4*>(&W[A * H + 4 * (p + 4 * i)]);
+            const f4 wc = *reinterpret_cast<const f4*>(&W[A * H + 4 * (p + TPR * i)]);
             f4 gc = o.dvalue * wc;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 ga[e] = act_bwd(ga[e], ha[i][e], act_prev);
                 gc[e] = act_bwd(gc[e], hc[i][e], act_prev);
             }
-            *reinterpret_cast<f4*>(dHa + rr * lddha + 4 * (p + 4 * i)) = ga;
-            *reinterpret_cast<f4*>(dHc + rr * lddhc + 4 * (p + 4 * i)) = gc;
+            *reinterpret_cast<f4*>(dHa + rr * lddha + 4 * (p + TPR * i)) = ga;
+            *reinterpret_cast<f4*>(dHc + rr * lddhc + 4 * (p + TPR * i)) = gc;
         }
     }
     ppo_block_partials(ok ? o.s_sur : 0.0, ok ? o.s_val : 0.0, ok ? o.s_kl : 0.0, ds, ok, A, part);
@@ -490,14 +494,20 @@ extern "C" int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc
                     lddhc % 4 == 0 && dtc::aligned16(Ha) && dtc::aligned16(Hc) && dtc::aligned16(dHa) && dtc::aligned16(dHc),
                 "hidden activations must be 16-byte aligned with row strides that are multiples of 4");
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = (int)dtc::ceil_div(B, 64);
+    static const int tpr_env = getenv("DTC_HEADS_TPR") ? atoi(getenv("DTC_HEADS_TPR")) : 8;       // A/B switch: 4 | 8
+    const int tpr = (tpr_env == 4 || H < 32 * 2 || dtc::ceil_div(B, 32) > MAX_BLK) ? 4 : 8;
+    const int nblk = (int)dtc::ceil_div(B, 256 / tpr);
     DTC_REQUIRE(nblk <= MAX_BLK, "batch too large for the loss workspace");
     double* part = (double*)workspace;
     dtc::ProfScope prof("ppo_heads_loss", (double)B * (4.0 * H * 4 + num_actions * 32.0), s);
 #define DTC_HL_ARGS Ha, (long long)ldha, Hc, (long long)ldhc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, \
                     advantages, returns, old_values, (const long long*)idx, *cfg, mean, value, dmean, dvalue, dHa, (long long)lddha, \
                     dHc, (long long)lddhc, part, B, num_actions
-    if (H == 64) hipLaunchKernelGGL(ppo_heads_loss_kernel<64>, dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
+    if (tpr == 8) {
+        if (H == 64) hipLaunchKernelGGL((ppo_heads_loss_kernel<64, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
+        else if (H == 128) hipLaunchKernelGGL((ppo_heads_loss_kernel<128, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
+        else hipLaunchKernelGGL((ppo_heads_loss_kernel<256, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
+    } else if (H == 64) hipLaunchKernelGGL(ppo_heads_loss_kernel<64>, dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
     else if (H == 128) hipLaunchKernelGGL(ppo_heads_loss_kernel<128>, dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
     else hipLaunchKernelGGL(ppo_heads_loss_kernel<256>, dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
 #undef DTC_HL_ARGS

@@ -25,7 +25,27 @@ namespace {
 // float4 drags in from beyond N / beyond the segment only feed output rows / columns that are never stored (behind the
 // last row of a source the descriptor returns 0), so the loads carry row masks only.  The gathered row index of X is a
 // per-lane 8-byte load issued one stage ahead of the tile it addresses.
-template <int BN>
+// MFMA phase with INTERLEAVED column tiles (BN = 64: the wave's two 32 x 32 tiles own the even and the odd columns of its
+// 64-column strip).  The B operand of lane (column l, k half h) for k-step kp is then Bs[2 kp + h][2 l] and [2 l + 1]: ONE
+// ds_read_b64 feeds both tiles (32 lanes x 8 bytes = 256 contiguous bytes: conflict free) instead of two ds_read_b32 -- 16
+// instead of 24 LDS reads per 16 MFMAs, no transposition anywhere; which output column an accumulator register belongs to
+// is a matter of the epilogue's addressing only, every output element still sums its products in the same order.
+__device__ __forceinline__ void mfma_step_ilv(const float* __restrict__ As, const float* __restrict__ Bs,
+                                              f32x16 (&acc)[1][2], int lane, int wm_off) {
+    using C = Cfg<64>;
+    const int half = lane >> 5, l31 = lane & 31;
+    const float* ap = As + half * C::LDA + wm_off + l31;
+    const float* bp = Bs + half * C::LDB + 2 * l31;
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+        const float a = ap[2 * kp * C::LDA];
+        const float2 b = *reinterpret_cast<const float2*>(&bp[2 * kp * C::LDB]);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc[0][1], 0, 0, 0);
+    }
+}
+
+template <int BN, bool ILV = false>
 __device__ __forceinline__ void wgrad_block(const float* __restrict__ dZ, long long lddz, const SegMatDev& X,
                                             float* __restrict__ part, int M, int N, int K, int rows_per_split,
                                             int col_tiles, int split, int t, float (*As)[BK][Cfg<BN>::LDA],
@@ -92,9 +112,13 @@ __device__ __forceinline__ void wgrad_block(const float* __restrict__ dZ, long l
     const int KT = (m_end - m_begin + BK - 1) / BK;
     if (KT > 0) {                                   // uniform per block (an empty trailing split writes zeros)
         int buf = 0;
+        auto mfma = [&](int b) {
+            if constexpr (ILV) mfma_step_ilv(&As[b][0][0], &Bs[b][0][0], acc, lane, wm_off);
+            else mfma_step<BN>(&As[b][0][0], &Bs[b][0][0], acc, lane, wm_off, wn_off);
+        };
         auto step = [&](auto masked, int kt_next) {
             load_tile(masked, m_begin + kt_next * BK);
-            mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
+            mfma(buf);
             store_tile(buf ^ 1);
             __syncthreads();
             buf ^= 1;
@@ -104,7 +128,7 @@ __device__ __forceinline__ void wgrad_block(const float* __restrict__ dZ, long l
         __syncthreads();
         for (int kt = 1; kt + 1 < KT; ++kt) step(Full{}, kt);  // branch-free steady state (full tiles)
         if (KT > 1) step(Masked{}, KT - 1);                    // batch tail of the split
-        mfma_step<BN>(&As[buf][0][0], &Bs[buf][0][0], acc, lane, wm_off, wn_off);
+        mfma(buf);
     }
 
     const long long ldp = part_ld(K);
@@ -112,6 +136,26 @@ __device__ __forceinline__ void wgrad_block(const float* __restrict__ dZ, long l
     const int half = lane >> 5, l31 = lane & 31;
     const bool bias_block = seg == 0 && tc == 0;
     __syncthreads();                                // every wave is past its last operand read (LDS is reused below)
+    if constexpr (ILV) {
+        // interleaved tiles: lane (l, half) holds columns 2 l and 2 l + 1 of its 64-column strip for 16 rows
+        const int cl = lc0 + 2 * l31;
+        if (n0 + BM <= N && lc0 + BN <= sd.width && ((sd.start + lc0) & 1) == 0) {
+            float* q = P + (long long)(n0 + wm_off + 4 * half) * ldp + sd.start + cl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                *reinterpret_cast<float2*>(q + (long long)((r & 3) + 8 * (r >> 2)) * ldp) = make_float2(acc[0][0][r], acc[0][1][r]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (cl + j >= sd.width) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = n0 + wm_off + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < N) P[(long long)row * ldp + sd.start + cl + j] = acc[0][j][r];
+                }
+            }
+        }
+    } else
     if (n0 + BM <= N && lc0 + BN <= sd.width && ((sd.start + lc0) & 3) == 0) {
         // wide stores: each wave transposes its 32x32 tiles through a private LDS patch -> dwordx4 rows of the slab
         float* patch = &As[0][0][0] + wave * (32 * LDW);     // 4 x 4 KiB inside the A stage buffers
@@ -190,6 +234,7 @@ struct WGroupDev {
 
 // block b -> XCD b%8 -> batch slice (split) xcd + 8*(j / tiles_total), tile j % tiles_total of the job list: all tiles of
 // all layers that read the same batch slice run on one XCD back to back (dZ of layer l is X-adjacent data of layer l-1 ...)
+template <bool ILV>
 __global__ __launch_bounds__(256) void wgrad_group_kernel(const WGroupDev G) {
     using C = Cfg<64>;
     __shared__ float As[2][BK][C::LDA];
@@ -202,7 +247,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WGroupDev G) {
     while (j < G.count - 1 && t >= G.job[j].tile_end) ++j;
     if (j > 0) t -= G.job[j - 1].tile_end;
     const WJobDev& J = G.job[j];
-    wgrad_block<64>(J.dZ, J.lddz, J.X, J.part, G.M, J.N, J.K, G.rows_per_split, J.col_tiles, split, t, As, Bs);
+    wgrad_block<64, ILV>(J.dZ, J.lddz, J.X, J.part, G.M, J.N, J.K, G.rows_per_split, J.col_tiles, split, t, As, Bs);
 }
 
 // Sum of the split partials in a FIXED order (deterministic): block = 64 float4 columns x G split groups; group g
@@ -453,7 +498,11 @@ extern "C" int dtc_wgrad_group(const DtcWgradJob* jobs, int count, int M, void* 
     {
         dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, G.tiles_total, count), P.flop, s, P.algo_bytes);
         const int grid = G.tiles_total * 8 * (int)dtc::ceil_div(G.splits, 8);
-        hipLaunchKernelGGL(wgrad_group_kernel, dim3(grid), dim3(256), occ_pad("WGRAD", 25600), s, G);
+        // interleaved column tiles (one ds_read_b64 per operand pair): measured 31.95 vs 31.8 ms per step for the weight
+        // gradients (round 3, three interleaved runs) -- the LDS read count is not what bounds this kernel; off by default
+        static const bool ilv = getenv("DTC_WGRAD_ILV") && atoi(getenv("DTC_WGRAD_ILV")) == 1;
+        if (ilv) hipLaunchKernelGGL(wgrad_group_kernel<true>, dim3(grid), dim3(256), occ_pad("WGRAD", 25600), s, G);
+        else hipLaunchKernelGGL(wgrad_group_kernel<false>, dim3(grid), dim3(256), occ_pad("WGRAD", 25600), s, G);
     }
     {
         dtc::ProfScope prof(dtc::prof_shape_name("wgrad_reduce", G.splits, G.tiles_total, count), (double)P.bytes + P.bytes / (double)G.splits, s);

@@ -136,6 +136,8 @@ _SIGS = {
     "dtc_adam_workspace": (C.c_int64, [C.c_int64]),
     "dtc_clip_adam": (C.c_int, [c_f32p] * 4 + [C.c_int64, C.c_float, c_f64p, C.c_double, C.c_double, C.c_double,
                                                C.c_int64, c_f32p, C.c_void_p, c_stream]),
+    "dtc_randn": (C.c_int, [c_f32p, C.c_int64, C.c_uint64, C.c_uint64, c_stream]),
+    "dtc_randperm": (C.c_int, [c_i64p, C.c_int64, C.c_uint64, c_stream]),
     "dtc_gru_step_fwd": (C.c_int, [c_f32p] * 7 + [C.c_int, C.c_int, c_stream]),
     "dtc_gru_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dtc_gru_fwd": (C.c_int, [c_f32p] * 7 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),

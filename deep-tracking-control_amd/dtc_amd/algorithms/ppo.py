@@ -667,12 +667,11 @@ class PPO:
         nmb, epochs = self.num_mini_batches, self.num_learning_epochs
         B = (st.num_envs * st.num_transitions_per_env) // nmb
         steps = nmb * epochs
-        if perm is None:
-            perm = torch.randperm(nmb * B, device=dev)
-        if eps1 is None:
-            eps1 = torch.randn(steps, B, 16, device=dev)
-        if eps2 is None:
-            eps2 = torch.randn(steps, B, 16, device=dev)
+        if perm is None or eps1 is None or eps2 is None:
+            seed = ops.draw_seed()             # counter-based device draws (csrc/rng.hip): one launch each, no sort
+            perm = ops.randperm(nmb * B, dev, seed) if perm is None else perm
+            eps1 = ops.randn((steps, B, 16), dev, seed + 1) if eps1 is None else eps1
+            eps2 = ops.randn((steps, B, 16), dev, seed + 2) if eps2 is None else eps2
         perm = perm.to(dev).contiguous()
         flat = {k: st.flat(k) for k in self._FLAT_NAMES}
         fw, tw = ac._fwd_ws(B), self._train_ws(B)

@@ -194,8 +194,10 @@ class RecurrentDecoderPPO(PPO):
         nmb, epochs = self.num_mini_batches, self.num_learning_epochs
         B = (st.num_envs // nmb) * st.num_transitions_per_env
         steps = nmb * epochs
-        eps1 = torch.randn(steps, B, 16, device=dev) if eps1 is None else eps1
-        eps2 = torch.randn(steps, B, 16, device=dev) if eps2 is None else eps2
+        if eps1 is None or eps2 is None:
+            seed = ops.draw_seed()
+            eps1 = ops.randn((steps, B, 16), dev, seed + 1) if eps1 is None else eps1
+            eps2 = ops.randn((steps, B, 16), dev, seed + 2) if eps2 is None else eps2
         stats = torch.zeros(steps, STAT_COLS, dtype=torch.float32, device=dev)
         slices = list(self.recurrent_slices())
         k = 0

@@ -206,6 +206,24 @@ def wgrad_group(jobs, M, workspace, stream_ptr=None):
 
 
 # ---------------------------------------------------------------- CE-net latent / losses / optimiser
+# ---------------------------------------------------------------- device random draws of the update
+def draw_seed() -> int:
+    """A 62-bit seed from torch's CPU generator: reproducible under torch.manual_seed, no device synchronisation."""
+    return int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
+
+
+def randn(shape, device, seed: int, offset: int = 0) -> torch.Tensor:
+    out = torch.empty(shape, dtype=f32, device=device)
+    check(lib().dtc_randn(ptr(out), out.numel(), seed, offset, stream()), "dtc_randn")
+    return out
+
+
+def randperm(n: int, device, seed: int) -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    check(lib().dtc_randperm(ptr(out), n, seed, stream()), "dtc_randperm")
+    return out
+
+
 def workspace(nbytes: int, device) -> torch.Tensor:
     """8-byte aligned scratch of at least `nbytes` bytes."""
     return torch.empty(max(1, (int(nbytes) + 7) // 8), dtype=torch.float64, device=device)

@@ -34,7 +34,7 @@ def short(name):
 
 
 def run_pass(tag, out_dir, workload="decoder", timeout=900):
-    d = os.path.join(out_dir, "pmc_" + tag)
+    d = os.path.join(os.path.abspath(out_dir), "pmc_" + tag)       # rocprofv3 runs with cwd = /tmp
     shutil.rmtree(d, ignore_errors=True)
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp", DTC_OVERLAP_WGRAD="0", DTC_OVERLAP_LANES="0")
@@ -94,6 +94,7 @@ def parse_pass(d):
 
 
 def summarise(out_dir):
+    out_dir = os.path.abspath(out_dir)
     a, b = parse_pass(os.path.join(out_dir, "pmc_a")), parse_pass(os.path.join(out_dir, "pmc_b"))
     res = {}
     for k in sorted(a):

@@ -336,6 +336,14 @@ int dtc_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq
                   float* gnorm_out, void* workspace, void* stream);
 int64_t dtc_adam_workspace(int64_t n);
 
+/* ---- device random draws of PPO.update (counter-based: deterministic in (seed, offset / n), no host synchronisation) ----
+ * dtc_randn: n standard-normal floats (Philox4x32-10 + Box-Muller; element 4g..4g+3 from counter g + offset) -- the
+ * `torch.randn_like` of the CE-net reparameterisation (actor_critic_decoder.py:283).
+ * dtc_randperm: a pseudo-random permutation of [0, n) as int64 (keyed Feistel bijection of [0, 2^k) with cycle walking; no
+ * sort) -- the `torch.randperm` of the mini-batch generator (rollout_storage.py:165). */
+int dtc_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+int dtc_randperm(int64_t* out, int64_t n, uint64_t seed, void* stream);
+
 /* ---- GRU (torch.nn.GRU, 1 layer, gate order r,z,n; actor_critic_recurrent.py:92-116 `Memory`) ---- */
 /* One fused GRU time step (forward), the building block of dtc_gru_fwd: the recurrent GEMM
  * gh = hprev W_hh^T + b_hh and the gate math of torch.nn.GRU in its epilogue (gh never reaches HBM):
