@@ -1,0 +1,412 @@
+// Split-precision dense layers for gfx950: the fp32 products of the nn.Linear stacks (rsl_rl/rsl_rl/modules/
+// actor_critic_decoder.py:98-188, 323-349 under ppo.py:197-218, 265, 289, 252, 333) computed on the bf16 matrix pipe.
+//
+// Why: gfx950 has no TF32-like mode; v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TFLOP/s), 1/16 of
+// v_mfma_f32_32x32x16_bf16.  An fp32 number is the exact sum of three bf16 numbers (8 significant bits each, round to
+// nearest even on the successive remainders: a = a1 + a2 + a3 with |a - (a1 + a2 + a3)| <= 2^-24 |a|, the remainders
+// a - a1 and (a - a1) - a2 are exact fp32 subtractions).  A product a b is then
+//     a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1)        + O(2^-24 |a b|) dropped (a2 b3, a3 b2, a3 b3)
+// -- SIX bf16 MFMAs whose 16-bit x 16-bit products are exact in the fp32 accumulator; what is dropped is of the order of
+// the rounding error of ONE fp32 multiplication.  Six passes at 16x the rate = 2.67x the fp32 MFMA peak (419 TFLOP/s of
+// fp32-equivalent work).  Accuracy against fp64 is measured next to the single-pass fp32 kernels in
+// tests/test_hip_split.py (same error level; the sum is not bit-identical to the fmaf chain, nor is the reference's
+// own CPU GEMM between two thread counts).
+//
+// Data path (forward product Y = X W^T, both operands contiguous along the reduction index k):
+//   global (fp32, dwordx4 per 4 k, the segmented / gathered operand descriptors of gemm.hip) -> registers -> split into
+//   three packed-bf16 planes (v_cvt_pk_bf16_f32: 5.5 VALU per element, hidden under the MFMAs of the other waves) ->
+//   LDS planes [row][16 k] (32-byte rows, the two 16-byte halves of a row swapped on odd 8-row groups: conflict-free
+//   ds_write_b64 and ds_read_b128) -> one ds_read_b128 per plane and 32 x 32 tile = the 8 bf16 of a lane's MFMA fragment.
+//   Block tile 128 x 128 x 16, 2 x 2 waves of 64 x 64, 24 MFMAs per wave and stage, double-buffered LDS (48 KiB), 3
+//   workgroups per CU.
+// The data gradient uses the same kernel on the transposed weight (dtc_s3_transpose once per optimiser step): both
+// operands are then reduction-contiguous as well.
+#include "s3_core.hpp"
+
+namespace {
+
+// epilogue modes
+constexpr int EPI_FWD = 0, EPI_DGRAD = 1;
+
+struct DgradEpi {
+    SegMatDev dX;                 // segmented destination (accumulate flags, NULL segments)
+    const float* Xs;              // saved post-activation output of the previous layer (act != none), or NULL
+    long long ldxs;
+    const unsigned short* rmask;  // sign record of a ReLU layer (replaces Xs), or NULL
+    int ldm, col_skip, wide_segs;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void linear_s3_kernel(const SegMatDev X, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ Y,
+                                                           long long ldy, int M, int N, int K, int act, int wide,
+                                                           unsigned short* __restrict__ wmask, int ldwm, const DgradEpi dg) {
+    constexpr int BN = 128, WN = 2, TM = 2, TN = 2, NA = 2, NB = 2;
+    __shared__ __attribute__((aligned(16))) u32x2 As[2][3][BM * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Bs[2][3][BN * 4];
+    int tr, tc;
+    const int ncols = EPI == EPI_DGRAD ? N - dg.col_skip : N;          // output columns that are computed
+    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (ncols + BN - 1) / BN, tr, tc)) return;
+    const int m0 = tr * BM, n0 = (EPI == EPI_DGRAD ? dg.col_skip : 0) + tc * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm_off = (wave / WN) * (32 * TM), wn_off = (wave % WN) * (32 * TN);
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // loader geometry (as linear_fwd_kernel): thread owns k chunk lch of rows lrow (+64) of X and of W
+    const int lrow = tid >> 2, lch = tid & 3;
+    int arow[NA], grow[NA], aslot[NA];
+    const bool any_gather = X.gathers != 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int r = lrow + 64 * i, m = m0 + r;
+        arow[i] = m < M ? m : -1;
+        grow[i] = (any_gather && m < M) ? (int)X.idx[m] : arow[i];
+        aslot[i] = wslot(r, lch);
+    }
+    u32 woff[NB];
+    int bslot[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int wn = n0 + lrow + 64 * i;
+        woff[i] = wn < N ? (u32)(wn * K + 4 * lch) * 4u : INVALID;
+        bslot[i] = wslot(lrow + 64 * i, lch);
+    }
+    const rsrc_t wres = make_rsrc_bytes(W, (long long)N * K * 4);
+
+    SegDev sd = X.s[0];
+    rsrc_t ares;
+    u32 aoff[NA];
+    auto enter_segment = [&]() {
+        ares = make_rsrc_bytes(sd.ptr, (long long)sd.rows * sd.ld * 4);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = sd.gather ? grow[i] : arow[i];
+            aoff[i] = r >= 0 ? ((u32)r * (u32)sd.ld + (u32)(sd.col0 + 4 * lch)) * 4u : INVALID;
+        }
+    };
+    f32x4 ra[NA], rb[NB];
+    auto load_stage = [&](auto masked, int kt) {
+        const u32 ka = (u32)(kt * BK) * 4u, kw = (u32)(sd.start + kt * BK) * 4u;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = bload4(ares, aoff[i], ka);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = bload4(wres, woff[i], kw);
+        if (decltype(masked)::value) {              // k tail of a segment: elements past its last column are zeroed in the data
+            const int k0 = kt * BK + 4 * lch;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[i][e] = (k0 + e <= sd.width - 1) ? ra[i][e] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[i][e] = (k0 + e <= sd.width - 1) ? rb[i][e] : 0.f;
+        }
+    };
+    auto store_stage = [&](int buf) {               // split into the three bf16 planes on the way into LDS
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const Split3 s = split3(ra[i]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) As[buf][p][aslot[i]] = s.p[p];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const Split3 s = split3(rb[i]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) Bs[buf][p][bslot[i]] = s.p[p];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto mfma_stage = [&](int buf) {
+        // fragments: A planes of both row tiles stay live (24 registers), B planes are read per column tile (12 registers)
+        bf16x8 a[TM][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot(wm_off + 32 * i + l31, half)]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot(wn_off + 32 * j + l31, half)]);
+            // smallest terms first: (a3 b1, a2 b2, a1 b3), (a2 b1, a1 b2), a1 b1
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    int buf = 0;
+    auto step = [&](auto masked, int kt_next) {
+        load_stage(masked, kt_next);
+        mfma_stage(buf);
+        store_stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    };
+    enter_segment();
+    load_stage(Masked{}, 0);
+    store_stage(0);
+    __syncthreads();
+    for (int seg = 0;;) {
+        const int n = (sd.width + BK - 1) / BK;
+        const int nfull = sd.width / BK;
+        for (int kt = 1; kt < nfull; ++kt) step(Full{}, kt);
+        if (n > nfull && n > 1) step(Masked{}, n - 1);
+        if (++seg == X.nseg) break;
+        sd = X.s[seg];
+        enter_segment();
+        step(Masked{}, 0);
+    }
+    mfma_stage(buf);
+
+    const bool full = (m0 + BM <= M) && (n0 + BN <= N);
+    __syncthreads();                                    // every wave is past its last operand read: LDS becomes the patches
+    float* patch = reinterpret_cast<float*>(&As[0][0][0]) + wave * (32 * LDW);
+    const int prow = lane >> 3, pc4 = lane & 7;
+
+    if constexpr (EPI == EPI_FWD) {
+        if (wide && full) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float bv = bias ? bias[n0 + wn_off + 32 * j + l31] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+                if (wmask) {                            // sign record of a ReLU layer (see linear_fwd_kernel)
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bits |= acc[i][j][r] > 0.f ? (1u << r) : 0u;
+                    wmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * ldwm + n0 + wn_off + 32 * j + l31] = (unsigned short)bits;
+                }
+                patch_put(patch, acc[i][j], half, l31);
+                float* yp = &Y[(long long)(m0 + wm_off + 32 * i + prow) * ldy + n0 + wn_off + 32 * j + 4 * pc4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    f32x4 v = patch_get(patch, prow + 8 * p, pc4);
+                    if (act == DTC_ACT_ELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
+                    } else if (act == DTC_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    } else if (act != DTC_ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], act);
+                    }
+                    *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = v;
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn_off + 32 * j + l31;
+            const bool cok = col < N;
+            const float bv = (bias && cok) ? bias[col] : 0.f;
+            float* yp = Y + (long long)(m0 + wm_off + 32 * i + 4 * half) * ldy + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const float v = act_fwd(acc[i][j][r] + bv, act);
+                if (cok && m0 + wm_off + 32 * i + 4 * half + ro < M) yp[(long long)ro * ldy] = v;
+            }
+        }
+    } else {
+        // ---- data-gradient epilogue: activation derivative, segmented destination (csrc/gemm.hip: linear_dgrad_kernel)
+        const SegMatDev& dX = dg.dX;
+        if (dg.rmask && full) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const unsigned bits = dg.rmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * dg.ldm + n0 + wn_off + 32 * j + l31];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = (bits >> r) & 1u ? acc[i][j][r] : 0.f;
+            }
+            act = DTC_ACT_NONE;
+        }
+        const rsrc_t xres = make_rsrc_bytes(dg.Xs, (long long)M * dg.ldxs * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cj = n0 + wn_off + 32 * j;
+            const int row_t = m0 + wm_off + 32 * i;
+            const int sj = find_seg(dX, cj < N ? cj : 0);
+            const SegDev sdj = dX.s[sj];
+            const bool tile_wide = full && ((dg.wide_segs >> sj) & 1) && cj + 32 <= sdj.start + sdj.width && ((cj - sdj.start) & 3) == 0 &&
+                                   (act == DTC_ACT_NONE || ((dg.wide_segs >> 4) & 1));
+            if (tile_wide) {                            // wave-uniform
+                patch_put(patch, acc[i][j], half, l31);
+                if (sdj.ptr == nullptr) continue;
+                const int c4 = cj + 4 * pc4;
+                float* dst = sdj.ptr + sdj.col0 + (c4 - sdj.start) + (long long)(row_t + prow) * sdj.ld;
+                const float* ys = dg.Xs + (long long)(row_t + prow) * dg.ldxs + c4;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    f32x4 v = patch_get(patch, prow + 8 * p, pc4);
+                    if (act != DTC_ACT_NONE) {
+                        const f32x4 y = *reinterpret_cast<const f32x4*>(ys + (long long)(8 * p) * dg.ldxs);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_bwd(v[e], y[e], act);
+                    }
+                    f32x4* q = reinterpret_cast<f32x4*>(dst + (long long)(8 * p) * sdj.ld);
+                    if (sdj.accumulate) {
+                        const f32x4 o = *q;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = o[e] + v[e];
+                    }
+                    *q = v;
+                }
+                continue;
+            }
+            const int col = cj + l31;
+            const bool cok = col < N;
+            const SegDev sc = dX.s[find_seg(dX, cok ? col : 0)];
+            const bool live = cok && sc.ptr != nullptr;
+            float* dst = sc.ptr + sc.col0 + (col - sc.start);
+            const int row0 = row_t + 4 * half;
+            float y[16];
+            if (act != DTC_ACT_NONE) {
+                const u32 xoff = ((u32)row0 * (u32)dg.ldxs + (u32)col) * 4u | (cok ? 0u : INVALID);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[r] = bload(xres, xoff, (u32)(((r & 3) + 8 * (r >> 2)) * (int)dg.ldxs) * 4u);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r];
+                if (act != DTC_ACT_NONE) v = act_bwd(v, y[r], act);
+                if (live && row < M) {
+                    float* q = dst + (long long)row * sc.ld;
+                    *q = sc.accumulate ? (*q + v) : v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ W, float* __restrict__ WT, int N, int K) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int n = by + r, k = bx + tx;
+        t[r][tx] = (n < N && k < K) ? W[(long long)n * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = bx + r, n = by + tx;
+        if (k < K && n < N) WT[(long long)k * N + n] = t[tx][r];
+    }
+}
+
+}  // namespace
+
+namespace {
+
+int wide_mask_s3(const SegMatDev& xd, const float* Xsaved, long long ldxs, int col_skip) {
+    if (col_skip & 3) return 0;
+    int m = 0;
+    for (int i = 0; i < xd.nseg; ++i) {
+        const SegDev& sd = xd.s[i];
+        if (sd.ptr == nullptr || (dtc::aligned16(sd.ptr) && (sd.ld & 3) == 0 && ((sd.col0 - sd.start) & 3) == 0)) m |= 1 << i;
+    }
+    if (Xsaved == nullptr || (dtc::aligned16(Xsaved) && (ldxs & 3) == 0)) m |= 1 << 4;
+    return m;
+}
+
+}  // namespace
+
+// Y = act(X W^T + b) [+ the ReLU sign record when relu_mask != NULL] on the split-precision path
+extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
+                                 int M, int N, int K, int act, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
+    DTC_REQUIRE(W && Y, "null pointer");
+    DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
+    DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * ldy <= MAX_ELEMS * 4, "matrix too large");
+    SegMatDev xd;
+    int rc = to_dev(X, xd, K, false, M);
+    if (rc != DTC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128));
+    const int wide = (ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
+    if (relu_mask)
+        DTC_REQUIRE(act == DTC_ACT_RELU && wide && M % BM == 0 && N % 128 == 0, "sign record (split path): M=%d and N=%d must be multiples of 128", M, N);
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide,
+                       (unsigned short*)relu_mask, N, DgradEpi{});
+    return dtc::check_launch("linear_fwd_s3");
+}
+
+// dX = (dZ W) * act'(.) with WT = W^T [K, N] (dtc_transpose): same destination contract as dtc_linear_dgrad /
+// dtc_linear_dgrad_mask (relu_mask != NULL: the ReLU derivative from the sign record, Xsaved unused)
+extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* WT, const DtcSegMat* dX, const float* Xsaved,
+                                   int64_t ldxs, const uint16_t* relu_mask, int M, int N, int K, int act, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
+    DTC_REQUIRE(dZ && WT, "null pointer");
+    DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
+    DTC_REQUIRE(relu_mask || act == DTC_ACT_NONE || (Xsaved != nullptr && ldxs >= K), "activation derivative needs Xsaved");
+    DTC_REQUIRE((act == DTC_ACT_NONE && !relu_mask) || (dX && dX->nseg == 1), "activation derivative needs a single-segment destination");
+    DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * lddz <= MAX_ELEMS, "matrix too large");
+    DgradEpi dg;
+    int rc = to_dev(dX, dg.dX, K, true, 0);
+    if (rc != DTC_OK) return rc;
+    int col_skip = 0;
+    for (int i = 0; i < dg.dX.nseg && dg.dX.s[i].ptr == nullptr; ++i) col_skip += dg.dX.s[i].width;
+    DTC_REQUIRE(col_skip < K, "every destination segment is NULL");
+    col_skip &= ~31;                                 // whole 32-column sub-tiles only (the rest of a NULL segment is computed, not stored)
+    SegMatDev zin;                                    // the row operand of the product: dZ [M, N], one plain segment
+    zin.nseg = 1;
+    zin.gathers = 0;
+    zin.idx = nullptr;
+    for (int i = 0; i < 4; ++i) zin.s[i] = SegDev{nullptr, 0, 0, 0x7fffffff, 0, 0, 0, 0};
+    zin.s[0] = SegDev{const_cast<float*>(dZ), (long long)lddz, 0, 0, N, 0, 0, M};
+    dg.Xs = relu_mask ? nullptr : Xsaved;
+    dg.ldxs = ldxs;
+    dg.rmask = (const unsigned short*)relu_mask;
+    dg.ldm = K;
+    dg.col_skip = col_skip;
+    dg.wide_segs = wide_mask_s3(dg.dX, dg.Xs, ldxs, col_skip);
+    if (relu_mask) DTC_REQUIRE(M % BM == 0 && K % 128 == 0 && col_skip == 0, "sign record (split path): M=%d and K=%d must be multiples of 128", M, K);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K - col_skip, 128));
+    double bytes = 4.0 * ((double)M * N + (double)N * K);
+    for (int i = 0; i < dg.dX.nseg; ++i)
+        if (dg.dX.s[i].ptr) bytes += 4.0 * M * dg.dX.s[i].width * (dg.dX.s[i].accumulate ? 2.0 : 1.0);
+    if (relu_mask) bytes += 0.125 * M * (double)K;
+    else if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)K;
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s, bytes);
+    // roles inside the kernel: output columns = K of the layer, reduction = N of the layer
+    hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD>), dim3(grid), dim3(256), 0, s, zin, WT, (const float*)nullptr, (float*)nullptr, 0ll, M,
+                       K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg);
+    return dtc::check_launch("linear_dgrad_s3");
+}
+
+extern "C" int dtc_transpose(const float* W, float* WT, int N, int K, void* stream) {
+    DTC_REQUIRE(W && WT && N > 0 && K > 0, "bad arguments");
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dtc::ceil_div(K, 32), (unsigned)dtc::ceil_div(N, 32)), dim3(256), 0,
+                       (hipStream_t)stream, W, WT, N, K);
+    return dtc::check_launch("transpose");
+}

@@ -1,0 +1,343 @@
+// Split-precision weight gradients for gfx950: dW[N,K] = dZ[M,N]^T X[M,K], db[N] = column sums of dZ (the
+// `loss.backward()` share of nn.Linear in rsl_rl/rsl_rl/algorithms/ppo.py:252, 333) on the bf16 matrix pipe, every fp32
+// operand as three bf16 terms and six MFMA passes (csrc/gemm_s3.hip explains the arithmetic).
+//
+// Both operands have the REDUCTION index (the batch row m) as their row, while a lane's MFMA fragment needs 8 consecutive
+// m of ONE output row / column.  The transposition happens in registers, for free, on the way into LDS:
+//   * a loader thread owns a 4 (batch rows) x 4 (consecutive n resp. c) block: four dwordx4 loads along n / c (coalesced:
+//     32 threads cover 128 columns of a batch row), then for each of its four columns the four batch-row values are one
+//     k chunk of that column's plane row: split3 -> three ds_write_b64.  Threads 0..127 stage dZ, threads 128..255 stage X;
+//   * the plane rows are stored in PHYSICAL order p(n) = (n & 3) * 32 + (n >> 2): the 16 lanes of a ds_write_b64 group then
+//     write four consecutive physical rows (conflict free) although their logical columns are 4 apart.  MFMA tile t of the
+//     128-row plane therefore holds the logical rows n = 4 i + t -- which output element an accumulator register belongs
+//     to is only a matter of addressing: the partial slabs are written in physical order (coalesced float4 rows) and the
+//     reduce kernel maps them back while it sums the batch slices in a fixed order (deterministic, no atomics).
+// Tiles: 128 (n) x 128 (c, inside ONE segment of X), 2 x 2 waves of 64 x 64, stage = 16 batch rows, double-buffered LDS
+// (48 KiB); grouped launch over all layers of a gradient bucket and 8 k batch slices (slice s runs on XCD s % 8), as
+// csrc/wgrad.hip does for the single-pass kernels.
+#include "s3_core.hpp"
+
+namespace {
+
+constexpr int MAX_JOBS_S3 = 12;
+constexpr int TILE = 128;
+
+struct S3Job {
+    const float* dZ;
+    long long lddz;
+    SegMatDev X;
+    float* part;            // [splits][tiles][128][128] physical-order partial products
+    float* bpart;           // [splits][row_tiles][128] bias-gradient partials (logical order)
+    float* dW;
+    float* db;
+    int N, K, col_tiles, row_tiles;
+    int tile_end;           // running sum of tiles over the jobs
+};
+struct S3Group {
+    int count, M, rows_per_split, splits, tiles_total;
+    S3Job job[MAX_JOBS_S3];
+};
+
+__device__ __forceinline__ int phys(int x) { return (x & 3) * 32 + (x >> 2); }          // logical -> physical (0..127)
+__device__ __forceinline__ int logical(int p) { return 4 * (p & 31) + (p >> 5); }       // physical -> logical
+
+__global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G) {
+    __shared__ __attribute__((aligned(16))) u32x2 As[2][3][TILE * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Bs[2][3][TILE * 4];
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int split = xcd + 8 * (jb / G.tiles_total);
+    if (split >= G.splits) return;
+    int t = jb % G.tiles_total;
+    int j = 0;
+    while (j < G.count - 1 && t >= G.job[j].tile_end) ++j;
+    if (j > 0) t -= G.job[j - 1].tile_end;
+    const S3Job& J = G.job[j];
+    const int tr = t / J.col_tiles;
+    int tc = t - tr * J.col_tiles;
+    int seg = 0;
+    for (; seg < J.X.nseg - 1; ++seg) {
+        const int nt = (J.X.s[seg].width + TILE - 1) / TILE;
+        if (tc < nt) break;
+        tc -= nt;
+    }
+    const SegDev sd = J.X.s[seg];
+    const int N = J.N, M = G.M;
+    const int n0 = tr * TILE, lc0 = tc * TILE;
+    const int m_begin = split * G.rows_per_split;
+    const int m_end = min(M, m_begin + G.rows_per_split);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // ---- loaders: threads 0..127 stage dZ (A), 128..255 stage X (B); thread (g, lch): columns 4 g .. 4 g + 3, batch rows
+    // 4 lch .. 4 lch + 3 of the stage
+    const bool is_a = tid < 128;
+    const int lt = tid & 127, g = lt & 31, lch = lt >> 5;
+    const long long lddz = J.lddz;
+    const rsrc_t ares = make_rsrc_bytes(J.dZ, (long long)M * lddz * 4);
+    const rsrc_t bres = make_rsrc_bytes(sd.ptr, (long long)sd.rows * sd.ld * 4);
+    // column offset of this thread's float4 (INVALID behind the matrix / the segment: those lanes stage zeros)
+    const u32 acol = (n0 + 4 * g < N) ? (u32)(n0 + 4 * g) * 4u : INVALID;
+    const u32 bcol = (lc0 + 4 * g < sd.width) ? (u32)(sd.col0 + lc0 + 4 * g) * 4u : INVALID;
+    const u32 ldb = (u32)sd.ld * 4u, lda = (u32)lddz * 4u;
+    int slot[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) slot[e] = wslot(e * 32 + g, lch);           // physical row of column 4 g + e
+
+    f32x4 v[4];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    u32 rnext[4];
+    auto rows_of = [&](int mb) {                       // source rows of X for the stage starting at batch row mb
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = mb + 4 * lch + q;
+            const int mc = m < m_end ? m : m_end - 1;
+            rnext[q] = sd.gather ? (u32)J.X.idx[mc] : (u32)mc;
+        }
+    };
+    if (!is_a) rows_of(m_begin);
+    auto load_stage = [&](int mb) {
+        if (is_a) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = mb + 4 * lch + q;
+                v[q] = bload4(ares, (acol + (u32)m * lda) | oob_mask(m, m_end - 1), 0u);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = mb + 4 * lch + q;
+                v[q] = bload4(bres, (bcol + rnext[q] * ldb) | oob_mask(m, m_end - 1), 0u);
+            }
+            rows_of(mb + BK);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        u32x2(*dst)[TILE * 4] = is_a ? As[buf] : Bs[buf];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 col = {v[0][e], v[1][e], v[2][e], v[3][e]};          // four batch rows of column 4 g + e
+            const Split3 s = split3(col);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dst[p][slot[e]] = s.p[p];
+            bsum[e] += (col[0] + col[1]) + (col[2] + col[3]);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    auto mfma_stage = [&](int buf) {
+        bf16x8 a[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot((2 * wr + i) * 32 + l31, half)]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot((2 * wc + jj) * 32 + l31, half)]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mfma6(a[i], b, acc[i][jj]);
+        }
+    };
+
+    const int KT = (m_end - m_begin + BK - 1) / BK;
+    if (KT > 0) {
+        int buf = 0;
+        load_stage(m_begin);
+        store_stage(0);
+        __syncthreads();
+        for (int kt = 1; kt < KT; ++kt) {
+            load_stage(m_begin + kt * BK);
+            mfma_stage(buf);
+            store_stage(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        mfma_stage(buf);
+    }
+
+    // ---- epilogue: the accumulators in physical order -> slab tile [128][128] (float4 rows through the wave's LDS patch)
+    __syncthreads();
+    float* P = J.part + ((long long)split * (J.tile_end - (j > 0 ? G.job[j - 1].tile_end : 0)) + t) * (TILE * TILE);
+    float* patch = reinterpret_cast<float*>(&As[0][0][0]) + wave * (32 * LDW);
+    const int prow = lane >> 3, pc4 = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            patch_put(patch, acc[i][jj], half, l31);
+            float* q = P + (long long)((2 * wr + i) * 32 + prow) * TILE + (2 * wc + jj) * 32 + 4 * pc4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(q + (long long)(8 * p) * TILE) = patch_get(patch, prow + 8 * p, pc4);
+        }
+    // bias-gradient partial (first column tile of the layer only): thread (g, lch) summed columns 4 g + e over its batch rows
+    if (seg == 0 && tc == 0) {
+        float* red = reinterpret_cast<float*>(&Bs[0][0][0]);          // [4][128], disjoint from the patches in As
+        if (is_a) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[lch * TILE + 4 * g + e] = bsum[e];
+        }
+        __syncthreads();
+        if (tid < TILE) J.bpart[((long long)split * J.row_tiles + tr) * TILE + tid] = ((red[tid] + red[TILE + tid]) + red[2 * TILE + tid]) + red[3 * TILE + tid];
+    }
+}
+
+// Sum of the batch slices in a fixed order, physical -> logical mapping, dW / db written once.
+// block = (tile, 8 physical rows); thread = (physical row, float4 of physical columns)
+__global__ __launch_bounds__(256) void wgrad_s3_reduce_kernel(const S3Group G) {
+    int b = blockIdx.x;
+    const int blocks_tiles = G.tiles_total * 16;
+    if (b >= blocks_tiles) {                           // bias blocks: one per (job, row tile)
+        b -= blocks_tiles;
+        int j = 0, rt = b;
+        while (j < G.count - 1 && rt >= G.job[j].row_tiles) { rt -= G.job[j].row_tiles; ++j; }
+        const S3Job& J = G.job[j];
+        if (rt >= J.row_tiles || J.db == nullptr || threadIdx.x >= TILE) return;
+        const int n = rt * TILE + threadIdx.x;
+        if (n >= J.N) return;
+        float s = 0.f;
+        for (int sp = 0; sp < G.splits; ++sp) s += J.bpart[((long long)sp * J.row_tiles + rt) * TILE + threadIdx.x];
+        J.db[n] = s;
+        return;
+    }
+    int t = b >> 4;
+    const int rg = b & 15;
+    int j = 0;
+    while (j < G.count - 1 && t >= G.job[j].tile_end) ++j;
+    const int tiles_j = G.job[j].tile_end - (j > 0 ? G.job[j - 1].tile_end : 0);
+    if (j > 0) t -= G.job[j - 1].tile_end;
+    const S3Job& J = G.job[j];
+    const int tr = t / J.col_tiles;
+    int tc = t - tr * J.col_tiles;
+    int seg = 0;
+    for (; seg < J.X.nseg - 1; ++seg) {
+        const int nt = (J.X.s[seg].width + TILE - 1) / TILE;
+        if (tc < nt) break;
+        tc -= nt;
+    }
+    const SegDev& sd = J.X.s[seg];
+    const int pn = rg * 8 + (threadIdx.x >> 5), pc4 = threadIdx.x & 31;
+    const int n = tr * TILE + logical(pn);
+    if (n >= J.N) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(J.part + (long long)t * (TILE * TILE) + (long long)pn * TILE) + pc4;
+    const long long step = (long long)tiles_j * (TILE * TILE / 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int sp = 0;
+    for (; sp + 3 < G.splits; sp += 4) {
+        const f32x4 v0 = p[(long long)sp * step], v1 = p[(long long)(sp + 1) * step], v2 = p[(long long)(sp + 2) * step], v3 = p[(long long)(sp + 3) * step];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = (((acc[e] + v0[e]) + v1[e]) + v2[e]) + v3[e];
+    }
+    for (; sp < G.splits; ++sp) {
+        const f32x4 v0 = p[(long long)sp * step];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v0[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int lc = tc * TILE + logical(4 * pc4 + e);
+        if (lc < sd.width) J.dW[(long long)n * J.K + sd.start + lc] = acc[e];
+    }
+}
+
+int group_splits_s3(int M, int tiles_total) {
+    static const char* target_env = getenv("DTC_WGRAD_S3_BLOCKS");
+    const int target = target_env ? atoi(target_env) : 2048;
+    int s = target / (tiles_total > 0 ? tiles_total : 1) / 8 * 8;
+    if (s < 8) s = 8;
+    const int max_s = (int)dtc::ceil_div(dtc::ceil_div(M, BK * 8), 8) * 8;
+    if (s > max_s) s = max_s;
+    return s;
+}
+
+struct S3Plan {
+    S3Group dev;
+    long long bytes;
+    int red_blocks;
+    double flop, algo_bytes;
+};
+
+int plan_s3(const DtcWgradJob* jobs, int count, int M, void* workspace, S3Plan& P) {
+    DTC_REQUIRE(jobs != nullptr && count >= 1 && count <= MAX_JOBS_S3, "job count %d outside 1..%d", count, MAX_JOBS_S3);
+    DTC_REQUIRE(M > 0, "bad M=%d", M);
+    S3Group& G = P.dev;
+    G.count = count;
+    G.M = M;
+    int tiles = 0, row_tiles = 0;
+    for (int j = 0; j < count; ++j) {
+        const DtcWgradJob& h = jobs[j];
+        DTC_REQUIRE(h.N > 0 && h.K > 0 && h.lddz >= h.N, "job %d: bad shape N=%d K=%d lddz=%lld", j, h.N, h.K, (long long)h.lddz);
+        DTC_REQUIRE(h.dZ && h.dW, "job %d: null pointer", j);
+        DTC_REQUIRE((long long)M * h.lddz <= MAX_ELEMS, "job %d: matrix too large", j);
+        S3Job& d = G.job[j];
+        int rc = to_dev(&h.X, d.X, h.K, false, M);
+        if (rc != DTC_OK) return rc;
+        d.dZ = h.dZ;
+        d.lddz = h.lddz;
+        d.dW = h.dW;
+        d.db = h.db;
+        d.N = h.N;
+        d.K = h.K;
+        d.col_tiles = 0;
+        for (int i = 0; i < d.X.nseg; ++i) d.col_tiles += (int)dtc::ceil_div(d.X.s[i].width, TILE);
+        d.row_tiles = (int)dtc::ceil_div(h.N, TILE);
+        tiles += d.row_tiles * d.col_tiles;
+        row_tiles += d.row_tiles;
+        d.tile_end = tiles;
+    }
+    G.tiles_total = tiles;
+    G.splits = group_splits_s3(M, tiles);
+    G.rows_per_split = (int)dtc::ceil_div(dtc::ceil_div(M, G.splits), BK) * BK;
+    long long off = 0;
+    P.flop = P.algo_bytes = 0.0;
+    for (int j = 0; j < count; ++j) {
+        S3Job& d = G.job[j];
+        const long long tiles_j = d.tile_end - (j > 0 ? G.job[j - 1].tile_end : 0);
+        d.part = workspace ? (float*)((char*)workspace + off) : nullptr;
+        off += (long long)G.splits * tiles_j * TILE * TILE * (long long)sizeof(float);
+        d.bpart = workspace ? (float*)((char*)workspace + off) : nullptr;
+        off += (long long)G.splits * d.row_tiles * TILE * (long long)sizeof(float);
+        P.flop += 2.0 * M * (double)d.N * d.K;
+        P.algo_bytes += 4.0 * ((double)M * d.N + (double)M * d.K + (double)d.N * (d.K + 1));
+    }
+    P.bytes = off;
+    P.red_blocks = tiles * 16 + row_tiles;
+    return DTC_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t dtc_wgrad_group_s3_workspace(const DtcWgradJob* jobs, int count, int M) {
+    S3Plan P;
+    if (plan_s3(jobs, count, M, nullptr, P) != DTC_OK) return -1;
+    return P.bytes;
+}
+
+extern "C" int dtc_wgrad_group_s3(const DtcWgradJob* jobs, int count, int M, void* workspace, void* stream) {
+    DTC_REQUIRE(workspace != nullptr && dtc::aligned16(workspace), "wgrad group workspace must be a 16-byte aligned device buffer");
+    S3Plan P;
+    int rc = plan_s3(jobs, count, M, workspace, P);
+    if (rc != DTC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const S3Group& G = P.dev;
+    {
+        dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, G.tiles_total, count), P.flop, s, P.algo_bytes);
+        const int grid = G.tiles_total * 8 * (int)dtc::ceil_div(G.splits, 8);
+        hipLaunchKernelGGL(wgrad_s3_group_kernel, dim3(grid), dim3(256), 0, s, G);
+    }
+    {
+        dtc::ProfScope prof(dtc::prof_shape_name("wgrad_reduce", G.splits, G.tiles_total, count), (double)P.bytes + P.bytes / (double)G.splits, s);
+        hipLaunchKernelGGL(wgrad_s3_reduce_kernel, dim3(P.red_blocks), dim3(256), 0, s, G);
+    }
+    return dtc::check_launch("wgrad_group_s3");
+}

@@ -101,6 +101,11 @@ _SIGS = {
     "dtc_linear_fwd": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_stream]),
     "dtc_linear_fwd_list": (C.c_int, [C.POINTER(DtcFwdLayer), C.c_int, C.c_int, c_stream]),
+    "dtc_linear_fwd_s3": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, c_stream]),
+    "dtc_linear_dgrad_s3": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_transpose": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, c_stream]),
     "dtc_relu_mask_elems": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_linear_fwd_mask": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, c_stream]),
@@ -115,6 +120,8 @@ _SIGS = {
                                    C.c_int, C.c_int, c_stream]),
     "dtc_wgrad_group_workspace": (C.c_int64, [C.POINTER(DtcWgradJob), C.c_int, C.c_int]),
     "dtc_wgrad_group": (C.c_int, [C.POINTER(DtcWgradJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "dtc_wgrad_group_s3_workspace": (C.c_int64, [C.POINTER(DtcWgradJob), C.c_int, C.c_int]),
+    "dtc_wgrad_group_s3": (C.c_int, [C.POINTER(DtcWgradJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_cenet_workspace": (C.c_int64, [C.c_int]),
     "dtc_cenet_latent_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int, c_stream]),
     "dtc_cenet_latent_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int,

@@ -82,6 +82,18 @@ def as_segmat(x, idx=None):
     return segmat([seg(x, 0, x.shape[1])], idx)
 
 
+# split-precision GEMMs (csrc/gemm_s3.hip): DTC_GEMM_SPLIT=1 routes the wide layers (>= 128 output columns) of linear_fwd /
+# linear_dgrad through the bf16 x 3 kernels; `set_split()` switches at run time (tests, A/B runs)
+import os as _os
+SPLIT = _os.environ.get("DTC_GEMM_SPLIT", "0") == "1"
+SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "128"))
+
+
+def set_split(on: bool):
+    global SPLIT
+    SPLIT = bool(on)
+
+
 def relu_mask_ok(M, N):
     """Shapes for which a ReLU layer can record its output signs (dtc_linear_fwd_mask / dtc_linear_dgrad_mask)."""
     return M % 128 == 0 and (N % 128 == 0 or N == 64)
@@ -91,12 +103,16 @@ def relu_mask(M, N, device):
     return torch.empty(int(lib().dtc_relu_mask_elems(M, N)), dtype=torch.int16, device=device)
 
 
-def linear_fwd(X, W, b, Y, act=None, M=None, mask=None):
+def linear_fwd(X, W, b, Y, act=None, M=None, mask=None, split=None):
     """Y = act(X W^T + b).  X: tensor or DtcSegMat; W [N,K]; Y [M,>=N] (row stride may exceed N).  `mask` (relu_mask
     buffer, act must be "relu"): also record the output signs for linear_dgrad(..., mask=)."""
     Xs = as_segmat(X)
     N, K = W.shape
     M = Y.shape[0] if M is None else M
+    if (SPLIT if split is None else split) and N >= SPLIT_MIN_COLS and (mask is None or N % 128 == 0):
+        check(lib().dtc_linear_fwd_s3(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
+                                      ptr(mask) if mask is not None else None, M, N, K, ACT[act], stream()), "dtc_linear_fwd_s3")
+        return Y
     if mask is not None:
         assert act in ("relu", "crelu")
         check(lib().dtc_linear_fwd_mask(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
@@ -138,12 +154,27 @@ class FwdChain:
               "dtc_linear_fwd_list")
 
 
-def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None):
+_WT = {}          # (device, stream, numel) -> scratch for the transposed weight of a split-path data gradient
+
+
+def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None):
     """dX = (dZ W) * act'(Xsaved); dX: tensor or DtcSegMat (destination).  `mask`: the sign record of the ReLU layer that
     produced Xsaved (then Xsaved itself is not read)."""
     dXs = as_segmat(dX)
     N, K = W.shape
     M = dZ.shape[0] if M is None else M
+    if (SPLIT if split is None else split) and K >= SPLIT_MIN_COLS and (mask is None or K % 128 == 0):
+        # W^T for the reduction-contiguous operand form: transposed on the launch stream right before use (each layer's data
+        # gradient runs once per optimiser step, so this is once per step and layer); one scratch per stream and size
+        key = (W.device, stream(), W.numel())
+        WT = _WT.get(key)
+        if WT is None:
+            WT = _WT[key] = torch.empty(W.numel(), dtype=f32, device=W.device)
+        check(lib().dtc_transpose(cptr(W, f32), ptr(WT), N, K, stream()), "dtc_transpose")
+        check(lib().dtc_linear_dgrad_s3(ptr(dZ), dZ.stride(0), ptr(WT), dXs, ptr(Xsaved) if mask is None else None,
+                                        Xsaved.stride(0) if Xsaved is not None else 0, ptr(mask) if mask is not None else None,
+                                        M, N, K, ACT[act] if mask is None else ACT["relu"], stream()), "dtc_linear_dgrad_s3")
+        return
     if mask is not None:
         assert act in ("relu", "crelu")
         check(lib().dtc_linear_dgrad_mask(ptr(dZ), dZ.stride(0), cptr(W, f32), dXs, ptr(mask), M, N, K, stream()),
@@ -188,20 +219,23 @@ def _wgrad_jobs(jobs):
     return arr, keep
 
 
-def wgrad_group_workspace_bytes(jobs, M) -> int:
+def wgrad_group_workspace_bytes(jobs, M, split=None) -> int:
     arr, _ = _wgrad_jobs(jobs)
-    n = int(lib().dtc_wgrad_group_workspace(arr, len(jobs), M))
+    s3 = SPLIT if split is None else split
+    n = int((lib().dtc_wgrad_group_s3_workspace if s3 else lib().dtc_wgrad_group_workspace)(arr, len(jobs), M))
     if n < 0:
         raise _ffi.DtcError(f"dtc_wgrad_group_workspace failed: {lib().dtc_last_error().decode()}")
     return n
 
 
-def wgrad_group(jobs, M, workspace, stream_ptr=None):
+def wgrad_group(jobs, M, workspace, stream_ptr=None, split=None):
     """The weight gradients of several layers (one gradient bucket) in one partial launch + one reduce launch.
     jobs: list of (dZ [M,N], X tensor | DtcSegMat [M,K], dW [N,K], db [N] | None)."""
     arr, keep = _wgrad_jobs(jobs)
-    check(lib().dtc_wgrad_group(arr, len(jobs), M, ptr(workspace), stream() if stream_ptr is None else stream_ptr),
-          "dtc_wgrad_group")
+    s3 = SPLIT if split is None else split
+    check((lib().dtc_wgrad_group_s3 if s3 else lib().dtc_wgrad_group)(arr, len(jobs), M, ptr(workspace),
+                                                                       stream() if stream_ptr is None else stream_ptr),
+          "dtc_wgrad_group_s3" if s3 else "dtc_wgrad_group")
     return keep
 
 

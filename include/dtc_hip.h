@@ -208,6 +208,20 @@ int dtc_linear_fwd_mask(const DtcSegMat* X, const float* W, const float* b, floa
 /* dX[M,K] = (dZ[M,N] W[N,K]) * (relu_mask bit), single-segment destination; M % 128 == 0, K as N above. */
 int dtc_linear_dgrad_mask(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const uint16_t* relu_mask,
                           int M, int N, int K, void* stream);
+/* ---- split-precision path (csrc/gemm_s3.hip): the same products on the bf16 matrix pipe, every fp32 operand split into
+ * three bf16 terms (a = a1 + a2 + a3 exactly to 2^-24 |a|) and the six leading cross products accumulated in fp32 -- fp32-level
+ * accuracy (tests/test_hip_split.py measures it against fp64 next to the single-pass kernels) at up to 2.67x the fp32 MFMA
+ * rate; results are NOT bit-identical to the fmaf chain of dtc_linear_fwd.  Same argument meaning as dtc_linear_fwd /
+ * dtc_linear_fwd_mask (relu_mask may be NULL) and dtc_linear_dgrad / dtc_linear_dgrad_mask; the data gradient takes the
+ * TRANSPOSED weight WT [K, N] = W^T (dtc_transpose; once per optimiser step and layer). */
+int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
+                      int M, int N, int K, int act, void* stream);
+int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* WT, const DtcSegMat* dX, const float* Xsaved,
+                        int64_t ldxs, const uint16_t* relu_mask, int M, int N, int K, int act, void* stream);
+int dtc_transpose(const float* W /*[N,K]*/, float* WT /*[K,N]*/, int N, int K, void* stream);
+/* dtc_wgrad_group on the split-precision path (same jobs, same outputs; its own workspace size). */
+int64_t dtc_wgrad_group_s3_workspace(const struct DtcWgradJob* jobs, int count, int M);
+int dtc_wgrad_group_s3(const struct DtcWgradJob* jobs, int count, int M, void* workspace, void* stream);
 /* A chain of forward layers in ONE call (same kernels, same results as `count` dtc_linear_fwd calls issued in order on
  * `stream`): the rollout side of PPO.act / evaluate (ppo.py:137-155) is launch-bound -- ~16 small layers per env step at
  * M = num_envs rows -- and the host cost of marshalling each layer through the FFI is paid once per chain instead of

@@ -1,0 +1,196 @@
+"""Split-precision GEMMs (csrc/gemm_s3.hip: every fp32 operand as three bf16 terms, six bf16 MFMA passes, fp32 accumulate)
+against fp64, NEXT TO the single-pass fp32 MFMA kernels on the same inputs: the split path must be as accurate as the
+fp32 path (its error against fp64 within a small factor of the fp32 kernel's own), for every operand form the layers
+use -- segmented / gathered inputs, k tails, ragged N, bias + activation, the ReLU sign record, segmented / accumulating /
+partly-NULL gradient destinations, the ELU derivative through the saved output."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _err(y, ref):
+    return float((y.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def _act(v, act):
+    if act == "relu":
+        return torch.relu(v)
+    if act == "elu":
+        return torch.nn.functional.elu(v)
+    return v
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1024, 512, 512, "relu"), (384, 512, 693, "relu"), (300, 693, 512, None), (1000, 256, 512, "elu"),
+                                       (24576, 512, 512, "elu"), (130, 128, 265, "relu"), (4096, 140, 70, "elu")])
+def test_forward_split_is_as_accurate_as_the_fp32_kernel(M, N, K, act):
+    from dtc_amd import ops
+    g = torch.Generator().manual_seed(M + N + 3 * K)
+    X = torch.randn(M, K, generator=g)
+    X *= 10.0 ** torch.randint(-3, 3, (M, 1), generator=g).float()            # rows of very different magnitude
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = _act(X.double() @ W.double().T + b.double(), act)
+    Xd, Wd, bd = X.to(DEV), W.to(DEV), b.to(DEV)
+    y32 = torch.full((M, N), float("nan"), device=DEV)
+    ys3 = torch.full((M, N), float("nan"), device=DEV)
+    ops.linear_fwd(Xd, Wd, bd, y32, act, split=False)
+    ops.linear_fwd(Xd, Wd, bd, ys3, act, split=True)
+    e32, es3 = _err(y32, ref), _err(ys3, ref)
+    print(f"fwd {M}x{N}x{K}: fp32 MFMA err {e32:.2e}, split err {es3:.2e}")
+    assert es3 <= 2.0 * e32 + 2e-7, (e32, es3)
+    # element-wise: every output within fp32-GEMM distance of the fp32 kernel's
+    scale = (X.abs().double() @ W.abs().double().T + b.abs().double()).to(DEV)
+    assert float(((ys3 - y32).abs().double() / scale).max()) <= 1e-6
+
+
+def test_forward_split_segments_gather_and_sign_record():
+    from dtc_amd import _ffi, ops
+    g = torch.Generator().manual_seed(5)
+    B, R = 1536, 4000
+    obs, z, mulv, lt = (torch.randn(R, 53, generator=g), torch.randn(B, 16, generator=g), torch.randn(B, 35, generator=g),
+                        torch.randn(B, 512, generator=g))
+    idx = torch.randint(0, R, (B,), generator=g)
+    W = torch.randn(512, 584, generator=g) / 24.0
+    b = torch.randn(512, generator=g)
+    Xfull = torch.cat([obs[idx], z, mulv[:, :3], lt], dim=1)
+    ref = torch.relu(Xfull.double() @ W.double().T + b.double())
+    d = lambda t: t.to(DEV)
+    obs_d, z_d, mulv_d, lt_d, idx_d = d(obs), d(z), d(mulv), d(lt), d(idx)
+    X = _ffi.segmat([_ffi.seg(obs_d, 0, 53, gather=True), _ffi.seg(z_d, 0, 16), _ffi.seg(mulv_d, 0, 3), _ffi.seg(lt_d, 0, 512)], idx_d)
+    y32, ys3 = torch.empty(B, 512, device=DEV), torch.empty(B, 512, device=DEV)
+    m32, ms3 = ops.relu_mask(B, 512, DEV), ops.relu_mask(B, 512, DEV)
+    ops.linear_fwd(X, d(W), d(b), y32, "relu", M=B, mask=m32, split=False)
+    ops.linear_fwd(X, d(W), d(b), ys3, "relu", M=B, mask=ms3, split=True)
+    assert _err(ys3, ref) <= 2.0 * _err(y32, ref) + 2e-7
+    # the sign record describes the split path's OWN output exactly (knife edges may differ from the fp32 kernel's)
+    pos = (ys3 > 0).cpu().view(B // 32, 4, 2, 4, 512).permute(0, 2, 1, 3, 4).reshape(B // 32, 2, 16, 512).to(torch.int32)
+    want = (pos << torch.arange(16, dtype=torch.int32).view(1, 1, 16, 1)).sum(dim=2).reshape(-1, 512)
+    assert torch.equal(ms3.cpu().view(-1, 512).to(torch.int32) & 0xFFFF, want)
+    assert float(((ys3 > 0) != (y32 > 0)).float().mean()) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1024, 512, 512, "relu"), (384, 693, 512, "relu"), (512, 256, 512, "elu"), (300, 128, 256, "elu"),
+                                       (24576, 512, 512, "relu")])
+def test_data_gradient_split_is_as_accurate_as_the_fp32_kernel(M, N, K, act):
+    """dX [M, K] = (dZ [M, N] W [N, K]) * act'(Xs)."""
+    from dtc_amd import ops
+    g = torch.Generator().manual_seed(2 * M + N + K)
+    dZ = torch.randn(M, N, generator=g) * 10.0 ** torch.randint(-6, 0, (M, 1), generator=g).float()
+    W = torch.randn(N, K, generator=g) / N ** 0.5
+    Xs = _act(torch.randn(M, K, generator=g), act)
+    ref = dZ.double() @ W.double()
+    ref = ref * (Xs > 0) if act == "relu" else torch.where(Xs > 0, ref, ref * (Xs.double() + 1.0))
+    d32 = torch.full((M, K), float("nan"), device=DEV)
+    ds3 = torch.full((M, K), float("nan"), device=DEV)
+    ops.linear_dgrad(dZ.to(DEV), W.to(DEV), d32, Xs.to(DEV), act, split=False)
+    ops.linear_dgrad(dZ.to(DEV), W.to(DEV), ds3, Xs.to(DEV), act, split=True)
+    e32, es3 = _err(d32, ref), _err(ds3, ref)
+    print(f"dgrad {M}x{N}x{K}: fp32 MFMA err {e32:.2e}, split err {es3:.2e}")
+    assert es3 <= 2.0 * e32 + 2e-7, (e32, es3)
+    scale = (dZ.abs().double() @ W.abs().double()).to(DEV) + 1e-30
+    assert float(((ds3 - d32).abs().double() / scale).max()) <= 1e-6
+
+
+def test_data_gradient_split_destinations_and_sign_record():
+    from dtc_amd import _ffi, ops
+    g = torch.Generator().manual_seed(8)
+    B = 384
+    dZ = torch.randn(B, 512, generator=g)
+    Wa = torch.randn(512, 584, generator=g) / 22.0
+    full = dZ.double() @ Wa.double()
+    dz, dmulv, dlt0 = torch.zeros(B, 16, device=DEV), torch.zeros(B, 35, device=DEV), torch.randn(B, 512, generator=g)
+    dlt = dlt0.to(DEV)
+    dst = _ffi.segmat([_ffi.seg(None, 0, 53), _ffi.seg(dz, 0, 16), _ffi.seg(dmulv, 0, 3), _ffi.seg(dlt, 0, 512, accumulate=True)])
+    ops.linear_dgrad(dZ.to(DEV), Wa.to(DEV), dst, split=True)
+    np.testing.assert_allclose(dz.cpu().numpy(), full[:, 53:69].numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(dmulv.cpu().numpy()[:, :3], full[:, 69:72].numpy(), rtol=2e-5, atol=2e-5)
+    assert float(dmulv[:, 3:].abs().max()) == 0.0
+    np.testing.assert_allclose(dlt.cpu().numpy(), (dlt0.double() + full[:, 72:]).numpy(), rtol=2e-5, atol=2e-5)
+    # ReLU derivative from the sign record == from the saved activation (bitwise, both on the split path)
+    M, N, K = 1024, 512, 512
+    X = torch.randn(M, 300, generator=g).to(DEV)
+    W1 = (torch.randn(K, 300, generator=g) / 17.0).to(DEV)
+    Y = torch.empty(M, K, device=DEV)
+    mask = ops.relu_mask(M, K, DEV)
+    ops.linear_fwd(X, W1, None, Y, "relu", mask=mask, split=True)
+    dZ2 = torch.randn(M, N, generator=g).to(DEV)
+    W2 = (torch.randn(N, K, generator=g) / 22.0).to(DEV)
+    a, b = torch.empty(M, K, device=DEV), torch.empty(M, K, device=DEV)
+    ops.linear_dgrad(dZ2, W2, a, Y, "relu", split=True)
+    ops.linear_dgrad(dZ2, W2, b, Y, "relu", mask=mask, split=True)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M", [1536, 5000, 24576])
+def test_weight_gradients_split_are_as_accurate_as_the_fp32_kernels(M):
+    """dtc_wgrad_group_s3 on the layers of a bucket (wide, narrow, 1-row, segmented + gathered, ragged N / K, M not a
+    multiple of the stage) against fp64, next to dtc_wgrad_group; deterministic (second call bit-identical)."""
+    from dtc_amd import _ffi, ops
+    g = torch.Generator().manual_seed(100 + M)
+    R = M + 700
+    d = lambda t: t.to(DEV)
+    obs_all, priv, bv = torch.randn(R, 53, generator=g), torch.randn(R, 1389, generator=g), torch.randn(R, 3, generator=g)
+    idx = torch.randperm(R, generator=g)[:M]
+    obs_d, priv_d, bv_d, idx_d = d(obs_all), d(priv), d(bv), d(idx)
+    shapes = [(512, 752), (512, 512), (256, 512), (128, 265), (12, 128), (1, 128), (35, 64), (693, 512), (64, 531)]
+    jobs32, jobs3, refs = [], [], []
+    for li, (N, K) in enumerate(shapes):
+        dZ = torch.randn(M, N, generator=g) / M ** 0.5 * 10.0 ** torch.randint(-4, 1, (M, 1), generator=g).float()
+        if li == 0:
+            Xh = torch.cat([obs_all[idx], bv[idx], priv[idx, 693:]], dim=1)
+            mk = lambda: _ffi.segmat([_ffi.seg(obs_d, 0, 53, gather=True), _ffi.seg(bv_d, 0, 3, gather=True),
+                                      _ffi.seg(priv_d, 693, 696, gather=True)], idx_d)
+        elif li == 8:                               # CE-net decoder input: [z 16 | mu 3 | l_t 512], plain segments
+            zz, mm, ll = torch.randn(M, 16, generator=g), torch.randn(M, 35, generator=g), torch.randn(M, 512, generator=g)
+            Xh = torch.cat([zz, mm[:, :3], ll], dim=1)
+            zd, md, ld_ = d(zz), d(mm), d(ll)
+            mk = lambda zd=zd, md=md, ld_=ld_: _ffi.segmat([_ffi.seg(zd, 0, 16), _ffi.seg(md, 0, 3), _ffi.seg(ld_, 0, 512)])
+        else:
+            Xh = torch.randn(M, K, generator=g)
+            Xd = d(Xh)
+            mk = lambda Xd=Xd: Xd
+        dZd = d(dZ)
+        has_b = li != 3
+        jobs32.append((dZd, mk(), torch.full((N, K), float("nan"), device=DEV), torch.full((N,), float("nan"), device=DEV) if has_b else None))
+        jobs3.append((dZd, mk(), torch.full((N, K), float("nan"), device=DEV), torch.full((N,), float("nan"), device=DEV) if has_b else None))
+        refs.append((dZ.double().t() @ Xh.double(), dZ.double().sum(0), dZ.abs().double().t() @ Xh.abs().double()))
+    ws32 = ops.workspace(ops.wgrad_group_workspace_bytes(jobs32, M, split=False), DEV)
+    ws3 = ops.workspace(ops.wgrad_group_workspace_bytes(jobs3, M, split=True), DEV)
+    ops.wgrad_group(jobs32, M, ws32, split=False)
+    ops.wgrad_group(jobs3, M, ws3, split=True)
+    for li, ((_, _, w32, b32), (_, _, w3, b3), (rw, rb, sc)) in enumerate(zip(jobs32, jobs3, refs)):
+        assert torch.isfinite(w3).all(), li
+        e32, e3 = _err(w32, rw), _err(w3, rw)
+        print(f"wgrad M={M} {tuple(w3.shape)}: fp32 MFMA err {e32:.2e}, split err {e3:.2e}")
+        assert e3 <= 2.0 * e32 + 2e-7, (li, e32, e3)
+        assert float(((w3 - w32).abs().double().cpu() / (sc + 1e-30)).max()) <= 1e-6, li
+        if b3 is not None:
+            np.testing.assert_allclose(b3.cpu().numpy(), rb.numpy(), rtol=3e-5, atol=1e-6 * float(rb.abs().max()) + 1e-9)
+    first = [(j[2].clone(), None if j[3] is None else j[3].clone()) for j in jobs3]
+    ops.wgrad_group(jobs3, M, ws3, split=True)
+    for (dZ, X, dW, db), (w0, b0) in zip(jobs3, first):
+        assert torch.equal(dW, w0) and (db is None or torch.equal(db, b0))
+
+
+def test_split_timing_report():
+    """Not an assertion on speed: prints the per-launch time of both paths on the bench's 512-wide layer."""
+    from dtc_amd import ops
+    M, N, K = 24576, 512, 512
+    X, W, b = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV) / 22.0, torch.randn(N, device=DEV)
+    Y, dX = torch.empty(M, N, device=DEV), torch.empty(M, K, device=DEV)
+    for split in (False, True):
+        for name, fn in (("fwd", lambda: ops.linear_fwd(X, W, b, Y, "relu", split=split)),
+                         ("dgrad", lambda: ops.linear_dgrad(Y, W, dX, X, "relu", split=split))):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 50.0
+            print(f"{name} split={split}: {us:.1f} us = {2.0 * M * N * K / us / 1e6:.1f} TFLOP/s (fp32-equivalent)")
