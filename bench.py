@@ -29,6 +29,8 @@ import torch.distributed as dist  # noqa: E402
 NUM_ENVS, NUM_STEPS = 4096, 24
 FLOP_PER_ENV_STEP = 102.03e6          # 20.405 MFLOP per sample-visit x 5 epochs
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, no xf32 on gfx950
+PEAK_BF16_MFMA_TFLOPS = 2516.6        # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16), 16 x the fp32 MFMA rate
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0      # fp32-equivalent peak of the split path: six bf16 passes per product = 419.4
 
 
 def cpu_baseline():
@@ -161,7 +163,7 @@ def main():
         dtc_build.build(verbose=False)
     if world > 1:
         dist.barrier()
-    from dtc_amd import _ffi, foothold, synthetic as S
+    from dtc_amd import _ffi, foothold, ops, synthetic as S
     from dtc_amd.algorithms import PPO, RecurrentDecoderPPO, RecurrentPPO
     from dtc_amd.modules import ActorCriticDecoder, ActorCriticDecoderRecurrent, ActorCriticRecurrent
 
@@ -243,6 +245,29 @@ def main():
     # data-gradient chain on a second stream; a kernel that shares the chip has no duration of its own, so this
     # pass runs the same kernels serialised (overlap off) -- rocprofv3 cross-check: DTC_OVERLAP_WGRAD=0.
     roof, classes, planner, planner_4096 = None, None, None, None
+    accuracy = None
+    if rank == 0:
+        # accuracy of both GEMM paths against fp64 on the bench's 512-wide layer (outside the timed region; the fp64 product is
+        # the CHECKER, computed by torch): max |y - y64| / max |y64| for the forward, data-gradient and weight-gradient products
+        g = torch.Generator(device=dev).manual_seed(5)
+        Mx, Nx, Kx = 24576, 512, 512
+        Xa = torch.randn(Mx, Kx, device=dev, generator=g)
+        Wa = torch.randn(Nx, Kx, device=dev, generator=g) / Kx ** 0.5
+        dZa = torch.randn(Mx, Nx, device=dev, generator=g) / Mx ** 0.5
+        refs = dict(fwd=Xa.double() @ Wa.double().T, dgrad=dZa.double() @ Wa.double(), wgrad=dZa.double().T @ Xa.double())
+        accuracy = {}
+        for name, sp in (("fp32_mfma", False), ("split_bf16x3", True)):
+            Y, dX, dW, db = (torch.empty(Mx, Nx, device=dev), torch.empty(Mx, Kx, device=dev), torch.empty(Nx, Kx, device=dev),
+                             torch.empty(Nx, device=dev))
+            ops.linear_fwd(Xa, Wa, None, Y, None, split=sp)
+            ops.linear_dgrad(dZa, Wa, dX, split=sp)
+            jobs = [(dZa, Xa, dW, db)]
+            ws = ops.workspace(ops.wgrad_group_workspace_bytes(jobs, Mx, split=sp), dev)
+            ops.wgrad_group(jobs, Mx, ws, split=sp)
+            err = lambda y, r: float((y.double() - r).abs().max() / r.abs().max())
+            accuracy[name] = dict(fwd=err(Y, refs["fwd"]), dgrad=err(dX, refs["dgrad"]), wgrad=err(dW, refs["wgrad"]))
+        accuracy["measure"] = "max |y - y_fp64| / max |y_fp64| on a 24576 x 512 x 512 layer, random normal operands"
+        del Xa, Wa, dZa, refs
     if world == 1 and rank == 0:
         # BASELINE configs[3]: ONE planner launch over 4096 envs x 4 legs (12.7 MB: launch / latency-bound, not HBM-bound):
         # its own line, timed with events on the launch stream over 50 back-to-back launches
@@ -294,9 +319,18 @@ def main():
         n_launch = sum(r["launches"] for r in gemm)
         algo_bytes = sum(r["bytes"] for r in gemm)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roof = dict(bound="mfma", kernel="linear_{fwd,dgrad}_kernel, wgrad_group_kernel (+ its split-reduce kernel): fp32 "
-                                         "v_mfma_f32_32x32x2_f32 GEMM family",
-                    achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP32_MFMA_TFLOPS,
+        split = ops.SPLIT
+        peak = PEAK_SPLIT_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+        roof = dict(bound="mfma",
+                    kernel=("linear_s3_kernel, wgrad_s3_group_kernel (+ its reduce kernel): split-precision GEMM family -- every fp32 operand as "
+                            "three bf16 terms, six v_mfma_f32_32x32x16_bf16 passes per product, fp32 accumulate (csrc/gemm_s3.hip); the narrow "
+                            "layers (< 256 columns) stay on the single-pass v_mfma_f32_32x32x2_f32 kernels and are part of the family") if split else
+                           "linear_{fwd,dgrad}_kernel, wgrad_group_kernel (+ its split-reduce kernel): fp32 v_mfma_f32_32x32x2_f32 GEMM family",
+                    achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
+                    peak_definition=("dense bf16 MFMA peak 2516.6 TFLOP/s / 6 passes = 419.4 TFLOP/s of fp32-equivalent work "
+                                     "(MI355X_MICROARCH.md); achieved counts the ALGORITHMIC fp32 FLOP (2 M N K per product), not the bf16 passes")
+                    if split else "fp32 MFMA peak (MI355X_MICROARCH.md)",
+                    frac_of_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS,
                     traffic=None, traffic_algorithmic=algo_bytes / max(1, n_launch), launches=n_launch,
                     measured="HIP events per launch, kernels serialised on one stream; the split-reduce launches of the weight "
                              "gradients are part of the family (time, no FLOP)",
@@ -351,6 +385,11 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "gemm_arithmetic": ("f32 operands and results; wide layers on the bf16 matrix pipe as 3-term splits (a = a1 + a2 + a3 exactly to 2^-24), "
+                                "6 MFMA passes, fp32 accumulate -- fp32-level accuracy, measured below against fp64 next to the single-pass "
+                                "fp32 MFMA kernels; DTC_GEMM_SPLIT=0 selects the single-pass kernels everywhere") if ops.SPLIT else
+                               "f32 single-pass v_mfma_f32_32x32x2_f32 (DTC_GEMM_SPLIT=0)",
+            "gemm_accuracy": accuracy,
             "config": {"workload": ("BASELINE configs[1]: 4096 envs x 24 steps per GPU, ActorCriticDecoder (CE-net + "
                                     "terrain encoder latent 512 + MLP actor/critic): foothold planner over the 98304 "
                                     "recorded height maps + compute_returns + PPO.update (5 epochs x 4 mini-batches of 24576)")
@@ -363,7 +402,7 @@ def main():
                        "num_envs_per_gpu": NUM_ENVS, "num_steps_per_env": NUM_STEPS, "mini_batch": 24576,
                        "epochs": 5, "wgrad_overlap_stream": bool(getattr(alg, "overlap_wgrad", False)), "parallelism": f"dp{world}" if world > 1 else "single",
                        "mfma_frac_whole_step": None if (composite or gru) else
-                       (FLOP_PER_ENV_STEP * value / world) / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                       (FLOP_PER_ENV_STEP * value / world) / ((PEAK_SPLIT_TFLOPS if ops.SPLIT else PEAK_FP32_MFMA_TFLOPS) * 1e12),
                        "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
                        "allreduce_bytes_per_step_per_rank": dp.bytes_reduced(coll_log) if world > 1 else 0,
                        "collectives_per_step": len(coll_log)},

@@ -189,6 +189,42 @@ extern "C" int dtc_gather_rows(const void* src, const int64_t* idx, void* dst, i
     return dtc::check_launch("gather_rows");
 }
 
+namespace {
+// dst[row, 0:cols] = the segments of a DtcSegMat side by side (row-gathered where a segment asks for it): one thread per element
+__global__ __launch_bounds__(256) void pack_cols_kernel(const DtcSegMat X, float* __restrict__ dst, long long ld_dst, long long rows) {
+    const long long total = rows * X.cols;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / X.cols;
+        int c = (int)(e - r * X.cols), s = 0;
+        while (s < X.nseg - 1 && c >= X.seg[s].width) c -= X.seg[s++].width;
+        const DtcSeg& g = X.seg[s];
+        const long long src_row = g.gather ? X.idx[r] : r;
+        dst[r * ld_dst + (e - r * X.cols)] = g.ptr[src_row * g.ld + g.col0 + c];
+    }
+}
+}  // namespace
+
+// The narrow leading blocks of a layer input (e.g. the actor's [obs 53 | z 16 | mu 3], the critic's [obs 53 | base_vel 3]) packed
+// into ONE dense [rows, cols] matrix: the GEMM kernels pad every segment of an operand to whole 16-k stages / 128-column tiles,
+// so three narrow segments cost three stages / three tiles where the packed block costs one (actor_critic_decoder.py:431, 550
+// `torch.cat` of the same pieces -- here only of the narrow ones; wide blocks stay in place as segments).
+extern "C" int dtc_pack_cols(const DtcSegMat* X, float* dst, int64_t ld_dst, int64_t rows, void* stream) {
+    DTC_REQUIRE(X && dst && rows >= 0 && X->nseg >= 1 && X->nseg <= 4 && ld_dst >= X->cols, "bad arguments");
+    if (rows == 0) return DTC_OK;
+    int cols = 0;
+    for (int i = 0; i < X->nseg; ++i) {
+        DTC_REQUIRE(X->seg[i].ptr && X->seg[i].width > 0 && (!X->seg[i].gather || X->idx), "segment %d: null source / gather without idx", i);
+        cols += X->seg[i].width;
+    }
+    DTC_REQUIRE(cols == X->cols, "segments cover %d columns, descriptor says %d", cols, X->cols);
+    hipStream_t s = (hipStream_t)stream;
+    dtc::ProfScope prof("pack_cols", 8.0 * (double)rows * cols, s);
+    const long long total = rows * (long long)cols;
+    const unsigned grid = (unsigned)(dtc::ceil_div(total, 256) < 16384 ? dtc::ceil_div(total, 256) : 16384);
+    hipLaunchKernelGGL(pack_cols_kernel, dim3(grid), dim3(256), 0, s, *X, dst, (long long)ld_dst, (long long)rows);
+    return dtc::check_launch("pack_cols");
+}
+
 extern "C" int dtc_scatter_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int64_t row_floats,
                                 void* stream) {
     DTC_REQUIRE(rows >= 0 && row_floats > 0, "bad shape");

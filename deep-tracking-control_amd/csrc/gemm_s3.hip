@@ -26,7 +26,18 @@
 namespace {
 
 // epilogue modes
-constexpr int EPI_FWD = 0, EPI_DGRAD = 1;
+constexpr int EPI_FWD = 0, EPI_DGRAD = 1, EPI_MSE = 2;
+
+// loss epilogue (dtc_linear_fwd_mse_s3): the layer output feeds an MSE against a row-gathered target; the epilogue writes
+// dL/dY instead of Y and one double partial of sum(e^2) per workgroup
+struct MseEpiS3 {
+    const float* target;
+    const long long* tidx;
+    long long ldt, target_bytes;
+    int tcol0;
+    float scale;
+    double* part;
+};
 
 struct DgradEpi {
     SegMatDev dX;                 // segmented destination (accumulate flags, NULL segments)
@@ -37,42 +48,41 @@ struct DgradEpi {
 };
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void linear_s3_kernel(const SegMatDev X, const float* __restrict__ W,
+__global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, const float* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ Y,
                                                            long long ldy, int M, int N, int K, int act, int wide,
-                                                           unsigned short* __restrict__ wmask, int ldwm, const DgradEpi dg) {
+                                                           unsigned short* __restrict__ wmask, int ldwm, const DgradEpi dg,
+                                                           const MseEpiS3 mse) {
     constexpr int BN = 128, WN = 2, TM = 2, TN = 2, NA = 2, NB = 2;
     __shared__ __attribute__((aligned(16))) u32x2 As[2][3][BM * 4];
     __shared__ __attribute__((aligned(16))) u32x2 Bs[2][3][BN * 4];
     int tr, tc;
     const int ncols = EPI == EPI_DGRAD ? N - dg.col_skip : N;          // output columns that are computed
-    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (ncols + BN - 1) / BN, tr, tc)) return;
+    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (ncols + BN - 1) / BN, tr, tc)) {
+        if (EPI == EPI_MSE && threadIdx.x == 0) mse.part[blockIdx.x] = 0.0;      // padding block: its partial slot still gets summed
+        return;
+    }
     const int m0 = tr * BM, n0 = (EPI == EPI_DGRAD ? dg.col_skip : 0) + tc * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm_off = (wave / WN) * (32 * TM), wn_off = (wave % WN) * (32 * TN);
     const int half = lane >> 5, l31 = lane & 31;
 
-    // loader geometry (as linear_fwd_kernel): thread owns k chunk lch of rows lrow (+64) of X and of W
+    // loader geometry (as linear_fwd_kernel): thread owns k chunk lch (4 k) of rows lrow and lrow + 64 of X and of W.
+    // (Measured alternatives, round 3: the weight pre-split into bf16 planes by a small kernel + 8 k per thread with
+    // ds_write_b128 -- fewer conversion instructions, 3.1 instead of 5.8 VALU per MFMA -- ran SLOWER, 84 vs 76 us on
+    // 24576 x 512 x 512: the kernel is bound by the barrier-coupled wait / issue chain of a stage, not by its VALU count.)
     const int lrow = tid >> 2, lch = tid & 3;
-    int arow[NA], grow[NA], aslot[NA];
-    const bool any_gather = X.gathers != 0;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int r = lrow + 64 * i, m = m0 + r;
-        arow[i] = m < M ? m : -1;
-        grow[i] = (any_gather && m < M) ? (int)X.idx[m] : arow[i];
-        aslot[i] = wslot(r, lch);
-    }
+    const int aslot0 = wslot(lrow, lch);                       // rows lrow and lrow + 64 share the half-swap parity: + 64 * 4 slots
     u32 woff[NB];
-    int bslot[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int wn = n0 + lrow + 64 * i;
         woff[i] = wn < N ? (u32)(wn * K + 4 * lch) * 4u : INVALID;
-        bslot[i] = wslot(lrow + 64 * i, lch);
     }
     const rsrc_t wres = make_rsrc_bytes(W, (long long)N * K * 4);
 
+    // ONE loop over the stages of all segments; the (rare) hop into the next segment re-derives the row offsets (the gathered
+    // row index is re-read from idx: two loads per thread and segment instead of registers held across the whole K loop)
     SegDev sd = X.s[0];
     rsrc_t ares;
     u32 aoff[NA];
@@ -80,41 +90,54 @@ __global__ __launch_bounds__(256, 2) void linear_s3_kernel(const SegMatDev X, co
         ares = make_rsrc_bytes(sd.ptr, (long long)sd.rows * sd.ld * 4);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int r = sd.gather ? grow[i] : arow[i];
-            aoff[i] = r >= 0 ? ((u32)r * (u32)sd.ld + (u32)(sd.col0 + 4 * lch)) * 4u : INVALID;
+            const int m = m0 + lrow + 64 * i;
+            const bool ok = m < M;
+            const u32 r = ok ? (sd.gather ? (u32)X.idx[m] : (u32)m) : 0u;
+            aoff[i] = ok ? (r * (u32)sd.ld + (u32)(sd.col0 + 4 * lch)) * 4u : INVALID;
         }
     };
+    int seg = 0, kt = 0, nst = (sd.width + BK - 1) / BK;
+    // operand loads run ONE stage ahead of the MFMAs.  (Two stages ahead -- two register sets -- measured slower: 91 vs 73 us
+    // on 24576 x 512 x 512; the third workgroup per CU that the registers of the second set cost is worth more.)
     f32x4 ra[NA], rb[NB];
-    auto load_stage = [&](auto masked, int kt) {
+    int klast;                                      // last valid element (0..3, < 0: none) of the loaded k chunks; >= 3: no tail
+    auto load_stage = [&]() {                       // next stage of the cursor -> registers (no wait)
         const u32 ka = (u32)(kt * BK) * 4u, kw = (u32)(sd.start + kt * BK) * 4u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = bload4(ares, aoff[i], ka);
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = bload4(wres, woff[i], kw);
-        if (decltype(masked)::value) {              // k tail of a segment: elements past its last column are zeroed in the data
-            const int k0 = kt * BK + 4 * lch;
+        klast = sd.width - 1 - (kt * BK + 4 * lch);
+        if (++kt == nst && seg + 1 < X.nseg) {
+            ++seg;
+            sd = X.s[seg];
+            enter_segment();
+            kt = 0;
+            nst = (sd.width + BK - 1) / BK;
+        }
+    };
+    auto store_stage = [&](int buf) {               // registers -> (k-tail mask) -> three bf16 planes -> LDS
+        if (__builtin_amdgcn_readfirstlane(klast + 4 * lch) < BK - 1) {      // (the same value in every lane) last stage of a ragged segment
 #pragma unroll
             for (int i = 0; i < NA; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ra[i][e] = (k0 + e <= sd.width - 1) ? ra[i][e] : 0.f;
+                for (int e = 0; e < 4; ++e) ra[i][e] = e <= klast ? ra[i][e] : 0.f;
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rb[i][e] = (k0 + e <= sd.width - 1) ? rb[i][e] : 0.f;
+                for (int e = 0; e < 4; ++e) rb[i][e] = e <= klast ? rb[i][e] : 0.f;
         }
-    };
-    auto store_stage = [&](int buf) {               // split into the three bf16 planes on the way into LDS
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const Split3 s = split3(ra[i]);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) As[buf][p][aslot[i]] = s.p[p];
+            for (int p = 0; p < 3; ++p) As[buf][p][aslot0 + 256 * i] = s.p[p];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const Split3 s = split3(rb[i]);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) Bs[buf][p][bslot[i]] = s.p[p];
+            for (int p = 0; p < 3; ++p) Bs[buf][p][aslot0 + 256 * i] = s.p[p];
         }
     };
 
@@ -128,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void linear_s3_kernel(const SegMatDev X, co
 
     auto mfma_stage = [&](int buf) {
         // fragments: A planes of both row tiles stay live (24 registers), B planes are read per column tile (12 registers)
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};      // smallest terms first: (a3 b1, a2 b2, a1 b3), (a2 b1, a1 b2), a1 b1
         bf16x8 a[TM][3];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -140,40 +164,28 @@ __global__ __launch_bounds__(256, 2) void linear_s3_kernel(const SegMatDev X, co
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot(wn_off + 32 * j + l31, half)]);
-            // smallest terms first: (a3 b1, a2 b2, a1 b3), (a2 b1, a1 b2), a1 b1
+            // the two row tiles alternate: consecutive MFMAs never wait for each other's accumulator
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
-            }
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][j], 0, 0, 0);
         }
     };
 
+    int total = 0;
+    for (int i = 0; i < X.nseg; ++i) total += (X.s[i].width + BK - 1) / BK;
     int buf = 0;
-    auto step = [&](auto masked, int kt_next) {
-        load_stage(masked, kt_next);
+    enter_segment();
+    load_stage();
+    store_stage(0);
+    __syncthreads();
+    for (int st = 1; st < total; ++st) {            // stage st in flight while the MFMAs consume LDS[buf]
+        load_stage();
         mfma_stage(buf);
         store_stage(buf ^ 1);
         __syncthreads();
         buf ^= 1;
-    };
-    enter_segment();
-    load_stage(Masked{}, 0);
-    store_stage(0);
-    __syncthreads();
-    for (int seg = 0;;) {
-        const int n = (sd.width + BK - 1) / BK;
-        const int nfull = sd.width / BK;
-        for (int kt = 1; kt < nfull; ++kt) step(Full{}, kt);
-        if (n > nfull && n > 1) step(Masked{}, n - 1);
-        if (++seg == X.nseg) break;
-        sd = X.s[seg];
-        enter_segment();
-        step(Masked{}, 0);
     }
     mfma_stage(buf);
 
@@ -182,6 +194,43 @@ __global__ __launch_bounds__(256, 2) void linear_s3_kernel(const SegMatDev X, co
     float* patch = reinterpret_cast<float*>(&As[0][0][0]) + wave * (32 * LDW);
     const int prow = lane >> 3, pc4 = lane & 7;
 
+    if constexpr (EPI == EPI_MSE) {
+        // e = (acc + bias) - target[tidx[row], tcol0 + col];  dY = e * scale;  partial = sum e^2 (double)
+        const rsrc_t tres = make_rsrc_bytes(mse.target, mse.target_bytes);
+        double sq = 0.0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn_off + 32 * j + l31;
+            const bool cok = col < N;
+            const float bv = (bias && cok) ? bias[col] : 0.f;
+            const int row0 = m0 + wm_off + 32 * i + 4 * half;
+            float tg[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {          // 16 gathered target loads in flight (rows past M read row 0, masked below)
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                const long long src = mse.tidx[row < M ? row : 0];
+                tg[r] = bload(tres, (u32)((src * mse.ldt + mse.tcol0 + col) * 4) | (cok ? 0u : INVALID), 0u);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                if (cok && row < M) {
+                    const float e = (acc[i][j][r] + bv) - tg[r];
+                    Y[(long long)row * ldy + col] = e * mse.scale;
+                    sq += (double)e * (double)e;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        double* red = reinterpret_cast<double*>(&Bs[0][0][0]);
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) mse.part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+        return;
+    }
     if constexpr (EPI == EPI_FWD) {
         if (wide && full) {
 #pragma unroll
@@ -307,6 +356,7 @@ __global__ __launch_bounds__(256, 2) void linear_s3_kernel(const SegMatDev X, co
     }
 }
 
+// W [N, K] -> W^T [K, N] (the data gradient's reduction-contiguous operand; once per layer and optimiser step)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ W, float* __restrict__ WT, int N, int K) {
     __shared__ float t[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -339,10 +389,17 @@ int wide_mask_s3(const SegMatDev& xd, const float* Xsaved, long long ldxs, int c
 
 }  // namespace
 
+// scratch of one data-gradient call: the transposed weight
+extern "C" int64_t dtc_s3_planes_bytes(int N, int K) {
+    if (N <= 0 || K <= 0) return 0;
+    return 4ll * N * K + 64;
+}
+
 // Y = act(X W^T + b) [+ the ReLU sign record when relu_mask != NULL] on the split-precision path
 extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
-                                 int M, int N, int K, int act, void* stream) {
+                                 void* wplanes, int M, int N, int K, int act, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
+    (void)wplanes;
     DTC_REQUIRE(W && Y, "null pointer");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
     DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * ldy <= MAX_ELEMS * 4, "matrix too large");
@@ -355,17 +412,18 @@ extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float
     if (relu_mask)
         DTC_REQUIRE(act == DTC_ACT_RELU && wide && M % BM == 0 && N % 128 == 0, "sign record (split path): M=%d and N=%d must be multiples of 128", M, N);
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide,
-                       (unsigned short*)relu_mask, N, DgradEpi{});
+    hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
+                       M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{});
     return dtc::check_launch("linear_fwd_s3");
 }
 
-// dX = (dZ W) * act'(.) with WT = W^T [K, N] (dtc_transpose): same destination contract as dtc_linear_dgrad /
-// dtc_linear_dgrad_mask (relu_mask != NULL: the ReLU derivative from the sign record, Xsaved unused)
-extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* WT, const DtcSegMat* dX, const float* Xsaved,
-                                   int64_t ldxs, const uint16_t* relu_mask, int M, int N, int K, int act, void* stream) {
+// dX = (dZ W) * act'(.), W [N, K] as stored (the kernel's reduction-contiguous operand, the planes of W^T, is prepared here);
+// same destination contract as dtc_linear_dgrad / dtc_linear_dgrad_mask (relu_mask != NULL: the ReLU derivative from the sign
+// record, Xsaved unused)
+extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved,
+                                   int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int M, int N, int K, int act, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
-    DTC_REQUIRE(dZ && WT, "null pointer");
+    DTC_REQUIRE(dZ && W && wplanes && dtc::aligned16(wplanes), "null pointer / unaligned scratch");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
     DTC_REQUIRE(relu_mask || act == DTC_ACT_NONE || (Xsaved != nullptr && ldxs >= K), "activation derivative needs Xsaved");
     DTC_REQUIRE((act == DTC_ACT_NONE && !relu_mask) || (dX && dX->nseg == 1), "activation derivative needs a single-segment destination");
@@ -398,15 +456,38 @@ extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W
     if (relu_mask) bytes += 0.125 * M * (double)K;
     else if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)K;
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s, bytes);
+    float* WT = (float*)wplanes;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dtc::ceil_div(K, 32), (unsigned)dtc::ceil_div(N, 32)), dim3(256), 0, s, W, WT, N, K);
     // roles inside the kernel: output columns = K of the layer, reduction = N of the layer
-    hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD>), dim3(grid), dim3(256), 0, s, zin, WT, (const float*)nullptr, (float*)nullptr, 0ll, M,
-                       K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg);
+    hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD>), dim3(grid), dim3(256), 0, s, zin, (const float*)WT, (const float*)nullptr, (float*)nullptr,
+                       0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{});
     return dtc::check_launch("linear_dgrad_s3");
 }
 
-extern "C" int dtc_transpose(const float* W, float* WT, int N, int K, void* stream) {
-    DTC_REQUIRE(W && WT && N > 0 && K > 0, "bad arguments");
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dtc::ceil_div(K, 32), (unsigned)dtc::ceil_div(N, 32)), dim3(256), 0,
-                       (hipStream_t)stream, W, WT, N, K);
-    return dtc::check_launch("transpose");
+extern "C" int64_t dtc_linear_fwd_mse_s3_parts(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128));
+}
+
+// dtc_linear_fwd_mse on the split-precision path (sq_part: dtc_linear_fwd_mse_s3_parts(M, N) doubles)
+extern "C" int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
+                                     int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
+                                     double* sq_part, void* wplanes, int M, int N, int K, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N, "bad shape M=%d N=%d K=%d", M, N, K);
+    (void)wplanes;
+    DTC_REQUIRE(W && target && tidx && dY && sq_part, "null pointer");
+    DTC_REQUIRE(tcol0 >= 0 && tcol0 + N <= ldt && target_rows > 0, "target columns [%d, %d) outside its %lld-wide rows", tcol0,
+                tcol0 + N, (long long)ldt);
+    DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * lddy <= MAX_ELEMS && target_rows * ldt <= MAX_ELEMS, "matrix too large");
+    SegMatDev xd;
+    int rc = to_dev(X, xd, K, false, M);
+    if (rc != DTC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128));
+    const MseEpiS3 mse{target, (const long long*)tidx, (long long)ldt, target_rows * ldt * 4, tcol0, scale, sq_part};
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s,
+                        4.0 * ((double)M * K + (double)N * K + 2.0 * M * N));
+    hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
+                       M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse);
+    return dtc::check_launch("linear_fwd_mse_s3");
 }

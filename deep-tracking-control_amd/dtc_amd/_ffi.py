@@ -98,14 +98,18 @@ _SIGS = {
     "dtc_adv_normalize": (C.c_int, [c_f32p, c_f64p, C.c_int64, C.c_double, c_stream]),
     "dtc_gather_rows": (C.c_int, [C.c_void_p, c_i64p, C.c_void_p, C.c_int64, C.c_int64, c_stream]),
     "dtc_scatter_rows": (C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int64, C.c_int64, c_stream]),
+    "dtc_pack_cols": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_int64, c_stream]),
     "dtc_linear_fwd": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_stream]),
     "dtc_linear_fwd_list": (C.c_int, [C.POINTER(DtcFwdLayer), C.c_int, C.c_int, c_stream]),
-    "dtc_linear_fwd_s3": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                    C.c_int, c_stream]),
-    "dtc_linear_dgrad_s3": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_void_p, C.c_int,
-                                      C.c_int, C.c_int, C.c_int, c_stream]),
-    "dtc_transpose": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, c_stream]),
+    "dtc_s3_planes_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "dtc_linear_fwd_s3": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, c_stream]),
+    "dtc_linear_dgrad_s3": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_linear_fwd_mse_s3_parts": (C.c_int64, [C.c_int, C.c_int]),
+    "dtc_linear_fwd_mse_s3": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, c_i64p,
+                                        C.c_float, c_f32p, C.c_int64, c_f64p, C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_relu_mask_elems": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_linear_fwd_mask": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, c_stream]),

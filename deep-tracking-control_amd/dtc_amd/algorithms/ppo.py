@@ -274,6 +274,11 @@ class PPO:
         # ReLU layers record their output signs in the forward epilogue; the data gradient reads 1 bit instead of the saved
         # 4-byte activation (DTC_RELU_MASK=0: derivative through the saved activations; bit-identical results)
         self.relu_masks = os.environ.get("DTC_RELU_MASK", "1") != "0"
+        self.pack_inputs = os.environ.get("DTC_PACK_INPUTS", "1") != "0"
+        # tests: callable(fw, which) run between the forward and the backward pass of a step ("vae" | "ppo"); the parity tests
+        # use it to teacher-force the ReLU sign records (fw.relu_mask buffers) so that fp32 knife edges -- pre-activations that
+        # are 0 within rounding and land on different sides in two correct implementations -- do not enter the gradient comparison
+        self.after_forward_hook = None
         self._rollout_graphs = {}
         self.capture_grads, self.captured = False, {}      # tests: snapshot of the (pre-clip) gradient arena
         self.last_update_stats = None      # [steps, STAT_COLS] table of the last update (host tensor)
@@ -509,6 +514,8 @@ class PPO:
             ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None)
         ops.linear_fwd(fw.lt, L["td0"].W, L["td0"].b, tw.d1, "relu", mask=fw.relu_mask("d1", 512, rm))
         ops.linear_fwd(tw.d1, L["td1"].W, L["td1"].b, tw.d2, "relu", mask=fw.relu_mask("d2", 512, rm))
+        if self.after_forward_hook is not None:
+            self.after_forward_hook(fw, "vae")
         # The loss kernel joins the two branches, but only the CE-net decoder's backward needs its output (dL/d recons,
         # the direct part of d mulv): the terrain decoder's dL/dY comes out of its own output layer.  The loss therefore
         # runs on `aux`; the main lane goes straight from the terrain decoder's forward into its backward.
@@ -571,10 +578,21 @@ class PPO:
         # output layers + losses + their data gradients in one launch when the last hidden width allows it (DTC_FUSE_HEADS)
         # (its partial-sum workspace holds 4096 blocks of 64 rows: larger mini-batches take the unfused kernels)
         fuse = self.fuse_heads and fw.a3.shape[1] == fw.v3.shape[1] and fw.a3.shape[1] in (64, 128, 256) and tw.B <= 4096 * 64
+        # the narrow leading blocks of both layer-0 inputs packed into dense operands (DTC_PACK_INPUTS=0: four / three segments)
+        if self.pack_inputs:
+            with tw.lane("aux"):
+                Xc = ac.critic_input_packed(flat["observations"], flat["base_vel"], flat["privileged_observations"], idx,
+                                            tw.g("pack_c", ac.num_obs + 3), tw.B)
+            Xa = ac.actor_input_packed(fw, flat["observations"], idx, tw.g("pack_a", ac.num_obs + 19))
+        else:
+            Xc = ac.critic_input(flat["observations"], flat["base_vel"], flat["privileged_observations"], idx)
+            Xa = ac.actor_input(fw, flat["observations"], idx)
         with tw.lane("aux"):
-            ac.critic_forward_(fw, flat["observations"], flat["base_vel"], flat["privileged_observations"], idx, head=not fuse)
-        ac.actor_forward_(fw, flat["observations"], idx, head=not fuse)
+            ac.critic_forward_(fw, flat["observations"], flat["base_vel"], flat["privileged_observations"], idx, head=not fuse, X=Xc)
+        ac.actor_forward_(fw, flat["observations"], idx, head=not fuse, X=Xa)
         tw.order("aux", "main")
+        if self.after_forward_hook is not None:
+            self.after_forward_hook(fw, "ppo")
         g_c3, g_a3 = tw.g("c3", 128), tw.g("a3", 128)
         if fuse:
             ops.ppo_heads_loss(fw.a3, fw.v3, L["a3"].W, L["a3"].b, L["c3"].W, L["c3"].b, act, ac.std_view, flat["actions"],
@@ -593,8 +611,7 @@ class PPO:
             self._bwd(tw, L["c3"], tw.dval, fw.v3, None if fuse else g_c3, fw.v3, act)      # fused: weight gradient only
             self._bwd(tw, L["c2"], g_c3, fw.v2, g_c2, fw.v2, act)
             self._bwd(tw, L["c1"], g_c2, fw.v1, g_c1, fw.v1, act)
-            self._bwd(tw, L["c0"], g_c1, ac.critic_input(flat["observations"], flat["base_vel"],
-                                                         flat["privileged_observations"], idx))
+            self._bwd(tw, L["c0"], g_c1, Xc)
         # actor (main); layer-0 input gradient fans out to z, mu[:, :3], l_t (observations need none)
         g_a2, g_a1 = tw.g("a2", 256), tw.g("a1", 512)
         self._bwd(tw, L["a3"], tw.dmean, fw.a3, None if fuse else g_a3, fw.a3, act)
@@ -602,7 +619,7 @@ class PPO:
         self._bwd(tw, L["a1"], g_a2, fw.a1, g_a1, fw.a1, act)
         tw.dmulv.zero_()
         dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
-        self._bwd(tw, L["a0"], g_a1, ac.actor_input(fw, flat["observations"], idx), dst, None, None)
+        self._bwd(tw, L["a0"], g_a1, Xa, dst, None, None)
         early = self._exchange_bucket(tw, "main_only")             # actor + critic + std gradients are complete
         tw.order("main", "aux")                                    # dz, d mu[:, :3] (and d l_t) are written
         self._terrain_encoder_backward(fw, tw, flat, idx)          # needs d l_t only: starts right away on main

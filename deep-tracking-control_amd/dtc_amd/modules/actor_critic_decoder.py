@@ -363,18 +363,29 @@ class ActorCriticDecoder(nn.Module):
         return segmat([seg(obs, 0, self.num_obs, gather=g), seg(base_vel, 0, 3, gather=g),
                        seg(priv, 693, 696, gather=g)], idx)
 
-    def actor_forward_(self, ws, obs, idx=None, head=True):
+    def actor_input_packed(self, ws, obs, idx, buf):
+        """The same operand with its three narrow blocks [obs | z | mu[:, :3]] packed into `buf` [B, 72] (one launch): two
+        segments instead of four -- one 16-k stage / one column tile for the narrow part instead of three."""
+        ops.pack_cols(segmat([seg(obs, 0, self.num_obs, gather=idx is not None), seg(ws.z, 0, 16), seg(ws.mulv, 0, 3)], idx), buf, ws.B)
+        return segmat([seg(buf, 0, self.num_obs + 19), seg(ws.lt, 0, 512)])
+
+    def critic_input_packed(self, obs, base_vel, priv, idx, buf, B):
+        g = idx is not None
+        ops.pack_cols(segmat([seg(obs, 0, self.num_obs, gather=g), seg(base_vel, 0, 3, gather=g)], idx), buf, B)
+        return segmat([seg(buf, 0, self.num_obs + 3), seg(priv, 693, 696, gather=g)], idx)
+
+    def actor_forward_(self, ws, obs, idx=None, head=True, X=None):
         """`head=False`: stop before the output layer (the trainer's fused heads + loss kernel computes it)."""
         L, act = self.L, AC_Args.activation
-        ops.linear_fwd(self.actor_input(ws, obs, idx), L["a0"].W, L["a0"].b, ws.a1, act, M=ws.B)
+        ops.linear_fwd(self.actor_input(ws, obs, idx) if X is None else X, L["a0"].W, L["a0"].b, ws.a1, act, M=ws.B)
         ops.linear_fwd(ws.a1, L["a1"].W, L["a1"].b, ws.a2, act)
         ops.linear_fwd(ws.a2, L["a2"].W, L["a2"].b, ws.a3, act)
         if head:
             ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None)
 
-    def critic_forward_(self, ws, obs, base_vel, priv, idx=None, head=True):
+    def critic_forward_(self, ws, obs, base_vel, priv, idx=None, head=True, X=None):
         L, act = self.L, AC_Args.activation
-        ops.linear_fwd(self.critic_input(obs, base_vel, priv, idx), L["c0"].W, L["c0"].b, ws.v1, act, M=ws.B)
+        ops.linear_fwd(self.critic_input(obs, base_vel, priv, idx) if X is None else X, L["c0"].W, L["c0"].b, ws.v1, act, M=ws.B)
         ops.linear_fwd(ws.v1, L["c1"].W, L["c1"].b, ws.v2, act)
         ops.linear_fwd(ws.v2, L["c2"].W, L["c2"].b, ws.v3, act)
         if head:

@@ -82,16 +82,32 @@ def as_segmat(x, idx=None):
     return segmat([seg(x, 0, x.shape[1])], idx)
 
 
-# split-precision GEMMs (csrc/gemm_s3.hip): DTC_GEMM_SPLIT=1 routes the wide layers (>= 128 output columns) of linear_fwd /
-# linear_dgrad through the bf16 x 3 kernels; `set_split()` switches at run time (tests, A/B runs)
+# split-precision GEMMs (csrc/gemm_s3.hip, csrc/wgrad_s3.hip): the wide layers of linear_fwd / linear_dgrad / linear_fwd_mse and every
+# grouped weight gradient run on the bf16 matrix pipe with 3-term operand splits (fp32-level accuracy, tests/test_hip_split.py).
+# DTC_GEMM_SPLIT=0 selects the single-pass fp32 MFMA kernels everywhere; `set_split()` switches at run time (tests, A/B runs)
 import os as _os
-SPLIT = _os.environ.get("DTC_GEMM_SPLIT", "0") == "1"
-SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "128"))
+SPLIT = _os.environ.get("DTC_GEMM_SPLIT", "1") != "0"
+SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "256"))     # 128-column layers: 192 tiles of 128 x 128 do not fill the chip
+SPLIT_MIN_RED = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_RED", "384"))      # short reductions are prologue / epilogue bound either way
 
 
 def set_split(on: bool):
     global SPLIT
     SPLIT = bool(on)
+
+
+_PLANES = {}      # (device, stream, bytes) -> plane scratch of a split-path call (the pre-split weight)
+
+
+def _planes(W, rows, cols):
+    """Scratch for the three bf16 planes of a [rows, cols] weight operand, one buffer per launch stream and size: calls on one
+    stream are ordered, so the next call may overwrite it; the compute lanes of the trainer have their own."""
+    n = int(lib().dtc_s3_planes_bytes(rows, cols))
+    key = (W.device, stream(), n)
+    buf = _PLANES.get(key)
+    if buf is None:
+        buf = _PLANES[key] = torch.empty((n + 7) // 8, dtype=torch.float64, device=W.device)
+    return buf
 
 
 def relu_mask_ok(M, N):
@@ -103,15 +119,23 @@ def relu_mask(M, N, device):
     return torch.empty(int(lib().dtc_relu_mask_elems(M, N)), dtype=torch.int16, device=device)
 
 
+def pack_cols(X, dst, rows=None):
+    """dst[rows, :X.cols] = the segments of DtcSegMat X side by side (gathered where asked)."""
+    rows = dst.shape[0] if rows is None else rows
+    check(lib().dtc_pack_cols(X, ptr(dst), dst.stride(0), rows, stream()), "dtc_pack_cols")
+    return dst
+
+
 def linear_fwd(X, W, b, Y, act=None, M=None, mask=None, split=None):
     """Y = act(X W^T + b).  X: tensor or DtcSegMat; W [N,K]; Y [M,>=N] (row stride may exceed N).  `mask` (relu_mask
     buffer, act must be "relu"): also record the output signs for linear_dgrad(..., mask=)."""
     Xs = as_segmat(X)
     N, K = W.shape
     M = Y.shape[0] if M is None else M
-    if (SPLIT if split is None else split) and N >= SPLIT_MIN_COLS and (mask is None or N % 128 == 0):
+    if (SPLIT if split is None else split) and (split or (N >= SPLIT_MIN_COLS and K >= SPLIT_MIN_RED)) and (mask is None or N % 128 == 0):
         check(lib().dtc_linear_fwd_s3(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
-                                      ptr(mask) if mask is not None else None, M, N, K, ACT[act], stream()), "dtc_linear_fwd_s3")
+                                      ptr(mask) if mask is not None else None, ptr(_planes(W, N, K)), M, N, K, ACT[act], stream()),
+              "dtc_linear_fwd_s3")
         return Y
     if mask is not None:
         assert act in ("relu", "crelu")
@@ -154,26 +178,17 @@ class FwdChain:
               "dtc_linear_fwd_list")
 
 
-_WT = {}          # (device, stream, numel) -> scratch for the transposed weight of a split-path data gradient
-
-
 def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None):
     """dX = (dZ W) * act'(Xsaved); dX: tensor or DtcSegMat (destination).  `mask`: the sign record of the ReLU layer that
     produced Xsaved (then Xsaved itself is not read)."""
     dXs = as_segmat(dX)
     N, K = W.shape
     M = dZ.shape[0] if M is None else M
-    if (SPLIT if split is None else split) and K >= SPLIT_MIN_COLS and (mask is None or K % 128 == 0):
-        # W^T for the reduction-contiguous operand form: transposed on the launch stream right before use (each layer's data
-        # gradient runs once per optimiser step, so this is once per step and layer); one scratch per stream and size
-        key = (W.device, stream(), W.numel())
-        WT = _WT.get(key)
-        if WT is None:
-            WT = _WT[key] = torch.empty(W.numel(), dtype=f32, device=W.device)
-        check(lib().dtc_transpose(cptr(W, f32), ptr(WT), N, K, stream()), "dtc_transpose")
-        check(lib().dtc_linear_dgrad_s3(ptr(dZ), dZ.stride(0), ptr(WT), dXs, ptr(Xsaved) if mask is None else None,
+    if (SPLIT if split is None else split) and (split or (K >= SPLIT_MIN_COLS and N >= SPLIT_MIN_RED)) and (mask is None or K % 128 == 0):
+        check(lib().dtc_linear_dgrad_s3(ptr(dZ), dZ.stride(0), cptr(W, f32), dXs, ptr(Xsaved) if mask is None else None,
                                         Xsaved.stride(0) if Xsaved is not None else 0, ptr(mask) if mask is not None else None,
-                                        M, N, K, ACT[act] if mask is None else ACT["relu"], stream()), "dtc_linear_dgrad_s3")
+                                        ptr(_planes(W, K, N)), M, N, K, ACT[act] if mask is None else ACT["relu"], stream()),
+              "dtc_linear_dgrad_s3")
         return
     if mask is not None:
         assert act in ("relu", "crelu")
@@ -283,18 +298,22 @@ def vae_loss(recons, hrecon, mulv, next_obs, priv, base_vel, idx, d_recons, d_hr
                              cptr(d_hrecon, f32), cptr(dmulv, f32), ptr(losses), ptr(ws), B, stream()), "dtc_vae_loss")
 
 
-def linear_fwd_mse(X, W, b, target, tcol0, tidx, dY, sq_part, M=None):
+def linear_fwd_mse(X, W, b, target, tcol0, tidx, dY, sq_part, M=None, split=None):
     """Output layer fused with its MSE loss: dY = 2/(M*N) * ((X W^T + b) - target[tidx, tcol0:tcol0+N]); sum of squared
     errors per workgroup into `sq_part` (float64, >= mse_parts(M, N) slots)."""
     Xs = as_segmat(X)
     N, K = W.shape
     M = dY.shape[0] if M is None else M
-    n_part = int(lib().dtc_linear_fwd_mse_parts(M, N))
+    s3 = (SPLIT if split is None else split) and (split or N >= SPLIT_MIN_COLS)
+    n_part = int((lib().dtc_linear_fwd_mse_s3_parts if s3 else lib().dtc_linear_fwd_mse_parts)(M, N))
     if sq_part.numel() < n_part or sq_part.dtype != torch.float64:
         raise _ffi.DtcError(f"sq_part needs {n_part} float64 slots")
-    check(lib().dtc_linear_fwd_mse(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, cptr(target, f32),
-                                   target.stride(0), target.shape[0], tcol0, cptr(tidx, torch.int64), 2.0 / (M * N),
-                                   ptr(dY), dY.stride(0), ptr(sq_part), M, N, K, stream()), "dtc_linear_fwd_mse")
+    args = (Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, cptr(target, f32), target.stride(0), target.shape[0], tcol0,
+            cptr(tidx, torch.int64), 2.0 / (M * N), ptr(dY), dY.stride(0), ptr(sq_part))
+    if s3:
+        check(lib().dtc_linear_fwd_mse_s3(*args, ptr(_planes(W, N, K)), M, N, K, stream()), "dtc_linear_fwd_mse_s3")
+    else:
+        check(lib().dtc_linear_fwd_mse(*args, M, N, K, stream()), "dtc_linear_fwd_mse")
     return n_part
 
 

@@ -5,7 +5,8 @@
 
 Per kernel (template instance): launches, kernel time (rocprofv3 start -> end of the same pass), MFMA-pipe busy fraction
     mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
-the EXECUTED matrix rate (every v_mfma_f32_32x32x2_f32 = 64 busy cycles = 4096 FLOP, padding included) and the
+the EXECUTED matrix rate (every v_mfma_f32_32x32x2_f32 = 64 busy cycles = 4096 FLOP, padding included; the split-precision
+kernels: fp32-equivalent FLOP, i.e. bf16 FLOP / 6) and the
 instruction mix per MFMA.  `bench.py` imports `collect()` for `roofline.mfma_busy`.
 """
 import csv
@@ -23,7 +24,7 @@ PASSES = {
 }
 BY_GRID = os.environ.get("DTC_PMC_BY_GRID", "1") != "0"      # one row per (kernel, workgroup count) = per layer shape
 FAMILY = ("linear_fwd_kernel", "linear_dgrad_kernel", "linear_wgrad_kernel", "wgrad_group_kernel", "wgrad_reduce_kernel",
-          "wgrad_group_reduce_kernel", "gru_step_fwd_kernel", "chain_")
+          "wgrad_group_reduce_kernel", "gru_step_fwd_kernel", "linear_s3_kernel", "wgrad_s3_group_kernel", "wgrad_s3_reduce_kernel")
 
 
 def short(name):
@@ -100,10 +101,13 @@ def summarise(out_dir):
     for k in sorted(a):
         ca, cb = a[k], b.get(k, {})
         busy, gui = ca.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), ca.get("GRBM_GUI_ACTIVE", 0.0)
-        n_mfma = busy / 64.0
+        # single-pass kernels: v_mfma_f32_32x32x2_f32 = 64 busy cycles, 4096 FLOP; split kernels (_s3_): v_mfma_f32_32x32x16_bf16 =
+        # 32 busy cycles, 32768 bf16 FLOP = 32768 / 6 fp32-equivalent FLOP (six passes per product)
+        s3 = "_s3_" in k
+        n_mfma = busy / (32.0 if s3 else 64.0)
         sec = ca["_ns"] * 1e-9
         res[k] = dict(launches=ca["_n"], ms=ca["_ns"] * 1e-6, mfma_busy=busy / (1024.0 * gui / 8.0) if gui else 0.0,
-                      executed_tflops=n_mfma * 4096.0 / sec / 1e12 if sec > 0 else 0.0,
+                      executed_tflops=n_mfma * (32768.0 / 6.0 if s3 else 4096.0) / sec / 1e12 if sec > 0 else 0.0,
                       clock_ghz=gui / 8.0 / (ca["_ns"]) if ca["_ns"] else 0.0,
                       valu_per_mfma=cb.get("SQ_INSTS_VALU", 0.0) / n_mfma - 1.0 if n_mfma else 0.0,
                       salu_per_mfma=cb.get("SQ_INSTS_SALU", 0.0) / n_mfma if n_mfma else 0.0,

@@ -193,6 +193,10 @@ typedef struct DtcSegMat {
     DtcSeg seg[4];
 } DtcSegMat;
 
+/* dst[rows, X->cols] (row stride ld_dst) = the segments of X side by side, row-gathered where a segment asks for it: packs
+ * the narrow leading blocks of a layer input into one dense operand (see csrc/gae.hip: dtc_pack_cols). */
+int dtc_pack_cols(const DtcSegMat* X, float* dst, int64_t ld_dst, int64_t rows, void* stream);
+
 /* Y[M,N] = act(X[M,K] W[N,K]^T + b).  X is segmented (host struct). */
 int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy,
                    int M, int N, int K, int act, void* stream);
@@ -212,13 +216,20 @@ int dtc_linear_dgrad_mask(const float* dZ, int64_t lddz, const float* W, const D
  * three bf16 terms (a = a1 + a2 + a3 exactly to 2^-24 |a|) and the six leading cross products accumulated in fp32 -- fp32-level
  * accuracy (tests/test_hip_split.py measures it against fp64 next to the single-pass kernels) at up to 2.67x the fp32 MFMA
  * rate; results are NOT bit-identical to the fmaf chain of dtc_linear_fwd.  Same argument meaning as dtc_linear_fwd /
- * dtc_linear_fwd_mask (relu_mask may be NULL) and dtc_linear_dgrad / dtc_linear_dgrad_mask; the data gradient takes the
- * TRANSPOSED weight WT [K, N] = W^T (dtc_transpose; once per optimiser step and layer). */
+ * dtc_linear_fwd_mask (relu_mask may be NULL) and dtc_linear_dgrad / dtc_linear_dgrad_mask.  The weight operand is
+ * pre-split into its three bf16 planes by a small kernel inside the call (once per layer and optimiser step; the planes of
+ * W^T for the data gradient): the GEMM's loaders do no conversion work for it. */
+int64_t dtc_s3_planes_bytes(int N, int K);   /* scratch for the pre-split weight of ONE call (`wplanes`, 16-byte aligned, private
+                                               * to the call until it has completed on its stream)                              */
 int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
-                      int M, int N, int K, int act, void* stream);
-int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* WT, const DtcSegMat* dX, const float* Xsaved,
-                        int64_t ldxs, const uint16_t* relu_mask, int M, int N, int K, int act, void* stream);
-int dtc_transpose(const float* W /*[N,K]*/, float* WT /*[K,N]*/, int N, int K, void* stream);
+                      void* wplanes, int M, int N, int K, int act, void* stream);
+int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved,
+                        int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int M, int N, int K, int act, void* stream);
+/* dtc_linear_fwd_mse / dtc_linear_fwd_mse_parts on the split-precision path */
+int64_t dtc_linear_fwd_mse_s3_parts(int M, int N);
+int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
+                          int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
+                          double* sq_part, void* wplanes, int M, int N, int K, void* stream);
 /* dtc_wgrad_group on the split-precision path (same jobs, same outputs; its own workspace size). */
 int64_t dtc_wgrad_group_s3_workspace(const struct DtcWgradJob* jobs, int count, int M);
 int dtc_wgrad_group_s3(const struct DtcWgradJob* jobs, int count, int M, void* workspace, void* stream);

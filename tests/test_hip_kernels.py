@@ -607,3 +607,19 @@ def test_foothold_rewards_vs_oracle():
     t, m = foothold.rewards(foot.to(DEV), world.to(DEV), contact.to(DEV))
     np.testing.assert_allclose(_np(t), tr, rtol=2e-6, atol=2e-6)
     np.testing.assert_array_equal(_np(m), miss)
+
+
+def test_pack_cols_equals_cat_of_gathered_blocks():
+    from dtc_amd import _ffi, ops
+    g = torch.Generator().manual_seed(12)
+    R, B = 5000, 1537
+    obs, bv, z, mulv = torch.randn(R, 53, generator=g), torch.randn(R, 3, generator=g), torch.randn(B, 16, generator=g), torch.randn(B, 35, generator=g)
+    idx = torch.randint(0, R, (B,), generator=g)
+    d = lambda t: t.to(DEV)
+    obs_d, bv_d, z_d, mulv_d, idx_d = d(obs), d(bv), d(z), d(mulv), d(idx)
+    out = torch.full((B, 72), float("nan"), device=DEV)
+    ops.pack_cols(_ffi.segmat([_ffi.seg(obs_d, 0, 53, gather=True), _ffi.seg(z_d, 0, 16), _ffi.seg(mulv_d, 0, 3)], idx_d), out)
+    assert torch.equal(out.cpu(), torch.cat([obs[idx], z, mulv[:, :3]], dim=1))
+    out2 = torch.full((B, 60), float("nan"), device=DEV)            # row stride wider than the packed block
+    ops.pack_cols(_ffi.segmat([_ffi.seg(obs_d, 0, 53, gather=True), _ffi.seg(bv_d, 0, 3, gather=True)], idx_d), out2)
+    assert torch.equal(out2[:, :56].cpu(), torch.cat([obs[idx], bv[idx]], dim=1)) and torch.isnan(out2[:, 56:]).all()

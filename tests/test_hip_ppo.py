@@ -79,7 +79,44 @@ def _relu_mask_mismatches(ref, alg, which):
     return sum(int(((buf.cpu() > 0) != ref.relu_masks[name]).sum()) for name, buf in mine.items()), B
 
 
-def _compare_grads(k, which, grads_ref, ref, alg, n_expected, strict=False):
+_MASK_NAMES = {"cenet_encoder.1": "e1", "terrain_encoder.1": "t1", "terrain_encoder.3": "t2", "cenet_decoder.1": "c1",
+               "cenet_decoder.3": "c2", "terrain_decoder.1": "d1", "terrain_decoder.3": "d2"}
+
+
+def _pack_sign_record(pos):
+    """bool [B, W] -> the int16 sign-record words of dtc_linear_fwd_mask (include/dtc_hip.h)."""
+    B, W = pos.shape
+    bits = pos.view(B // 32, 4, 2, 4, W).permute(0, 2, 1, 3, 4).reshape(B // 32, 2, 16, W).to(torch.int32)
+    words = (bits << torch.arange(16, dtype=torch.int32).view(1, 1, 16, 1)).sum(dim=2).reshape(-1, W)
+    return torch.from_numpy(words.numpy().astype(np.uint16).view(np.int16))
+
+
+def _force_oracle_signs(ref, alg):
+    """Teacher-force the ReLU derivative pattern: between the HIP forward and backward pass the sign records are replaced by
+    the ORACLE's masks.  A pre-activation that is 0 within fp32 rounding lands on different sides in two correct forwards
+    (about one (sample, unit) pair per 4e5) and moves every upstream gradient by that sample's share; with the records
+    forced the gradient comparison measures the backward kernels, not the knife edges.  Returns the list of forced steps."""
+    forced = []
+
+    def hook(fw, which):
+        torch.cuda.synchronize()
+        n = 0
+        for ref_name, name in _MASK_NAMES.items():
+            buf = fw._masks.get(name)
+            if buf is None or ref_name not in ref.relu_masks or (which == "ppo" and name in ("c1", "c2", "d1", "d2")):
+                continue
+            words = _pack_sign_record(ref.relu_masks[ref_name])
+            assert words.numel() == buf.numel(), (name, words.shape, buf.shape)
+            buf.copy_(words.reshape(-1).to(buf.device))
+            n += 1
+        forced.append((which, n))
+        torch.cuda.synchronize()
+
+    alg.after_forward_hook = hook if alg.relu_masks else None
+    return forced
+
+
+def _compare_grads(k, which, grads_ref, ref, alg, n_expected, strict=False, forced=False):
     """Pre-clip gradient of every parameter (manual backward through the HIP kernels vs torch autograd):
     99 % of the elements of every tensor within `tol` of the tensor's max, whole tensor within tol in L2.
     tol = 2e-5 when every ReLU of the step is masked identically by both implementations.  A ReLU
@@ -106,7 +143,8 @@ def _compare_grads(k, which, grads_ref, ref, alg, n_expected, strict=False):
     if strict:
         assert n_mis == 0 and same_median, (n_mis, int(fw.info[0]), vae.last_outliers,
                                             float(fw.info[2:3].view(torch.float32)), vae.last_median)
-    tol = 2e-5 + 3.0 * n_mis / B
+    # records teacher-forced (every ReLU layer of this batch size has one): the flat bound; otherwise 3/B per knife edge
+    tol = 2e-5 if forced else 2e-5 + 3.0 * n_mis / B
     report = []
     for name, g_ref in grads_ref.items():
         if not same_median and name.startswith(("vae.cenet_encoder", "vae.latent_")):
@@ -170,12 +208,17 @@ def _teacher_forced_step(k, ref, alg, idx, e1, e2):
     from oracle.ppo_ref import StepRecord
     rec = StepRecord()
     ref.capture_grads = alg.capture_grads = True
+    from dtc_amd import ops
+    B = idx.numel()
+    forced_log = _force_oracle_signs(ref, alg)
+    can_force = alg.relu_masks and all(ops.relu_mask_ok(B, w) for w in (64, 128, 512))
     _sync_from_oracle(ref, alg)
     pre = _snapshot(ref)
     ref.vae_step(idx, e1, rec)
     row, _ = alg.step_minibatch(idx, e1, e2, which="vae")
+    assert not can_force or forced_log[-1] == ("vae", 7), forced_log
     _compare_scalars(k, rec, row, ref, ("recons", "vel", "kld", "height", "vae_gnorm"))
-    _compare_grads(k, "vae", rec.extra["vae_grads"], ref, alg, 26)
+    _compare_grads(k, "vae", rec.extra["vae_grads"], ref, alg, 26, forced=can_force)
     _compare_weights(k, "vae", pre, rec.extra["vae_grads"], ref, alg)
     _sync_from_oracle(ref, alg)
     pre = _snapshot(ref)
@@ -183,8 +226,10 @@ def _teacher_forced_step(k, ref, alg, idx, e1, e2):
     row, lr = alg.step_minibatch(idx, e1, e2, which="ppo")
     _compare_scalars(k, rec, row, ref, ("surrogate", "value", "entropy", "kl_mean", "gnorm"))
     assert lr == ref.learning_rate, (k, lr, ref.learning_rate)
-    _compare_grads(k, "main", rec.extra["grads"], ref, alg, 31)
+    assert not can_force or forced_log[-1] == ("ppo", 3), forced_log
+    _compare_grads(k, "main", rec.extra["grads"], ref, alg, 31, forced=can_force)
     _compare_weights(k, "main", pre, rec.extra["grads"], ref, alg)
+    alg.after_forward_hook = None
 
 
 def test_initialisation_matches_reference_seed(golden):

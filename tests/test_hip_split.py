@@ -175,6 +175,29 @@ def test_weight_gradients_split_are_as_accurate_as_the_fp32_kernels(M):
         assert torch.equal(dW, w0) and (db is None or torch.equal(db, b0))
 
 
+def test_fused_mse_output_layer_split_vs_fp32():
+    from dtc_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M, N, K, R = 1536, 693, 512, 3000
+    X = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) / 22.0).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    tgt = torch.randn(R, 1389, generator=g).to(DEV)
+    tidx = torch.randint(0, R, (M,), generator=g).to(DEV)
+    outs = []
+    for split in (False, True):
+        dY = torch.full((M, N), float("nan"), device=DEV)
+        part = torch.zeros(4096, dtype=torch.float64, device=DEV)
+        n = ops.linear_fwd_mse(X, W, b, tgt, 696, tidx, dY, part, split=split)
+        outs.append((dY, float(part[:n].sum())))
+    e = (X.double() @ W.double().T + b.double()) - tgt[tidx][:, 696:].double()
+    ref_dy, ref_sq = e * (2.0 / (M * N)), float((e * e).sum())
+    for dY, sq in outs:
+        assert abs(sq - ref_sq) <= 1e-6 * ref_sq
+        assert _err(dY, ref_dy.cpu()) <= 2e-6
+    assert _err(outs[1][0], ref_dy.cpu()) <= 2.0 * _err(outs[0][0], ref_dy.cpu()) + 2e-7
+
+
 def test_split_timing_report():
     """Not an assertion on speed: prints the per-launch time of both paths on the bench's 512-wide layer."""
     from dtc_amd import ops
@@ -194,3 +217,23 @@ def test_split_timing_report():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 50.0
             print(f"{name} split={split}: {us:.1f} us = {2.0 * M * N * K / us / 1e6:.1f} TFLOP/s (fp32-equivalent)")
+    # row alignment of the input: K = 693 columns out of rows of 693 (2772 bytes: not 16-byte aligned) vs 696 floats, plain and gathered
+    from dtc_amd import _ffi
+    K = 693
+    W = torch.randn(N, K, device=DEV) / 26.0
+    idx = torch.randperm(98304, device=DEV)[:M].contiguous()
+    for ld in (693, 696):
+        big = torch.randn(98304, ld, device=DEV)
+        for gather in (False, True):
+            Xs = _ffi.segmat([_ffi.seg(big, 0, K, gather=gather)], idx if gather else None)
+            for split in (False, True):
+                for _ in range(3):
+                    ops.linear_fwd(Xs, W, b, Y, "relu", M=M, split=split)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    ops.linear_fwd(Xs, W, b, Y, "relu", M=M, split=split)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 50.0
+                print(f"fwd 24576x512x693 row stride {ld} gather={gather} split={split}: {us:.1f} us = {2.0 * M * N * K / us / 1e6:.1f} TFLOP/s")
