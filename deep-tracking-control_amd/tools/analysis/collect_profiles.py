@@ -17,8 +17,9 @@ import re
 import shutil
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r2p"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r3p"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = int(tag[1:])
 dst = "profiles"
 
 
@@ -34,10 +35,13 @@ def short(name):
 
 d = last_json(f"{src}/{tag}_bench_n1.json")
 json.dump(d, open(f"{dst}/{tag}_bench_n1.json", "w"), indent=1)
-for w in ("gru", "composite"):
+for w in ("gru", "composite", "fp32mfma"):
     p = f"{src}/{tag}_bench_{w}.json"
     if os.path.exists(p):
         json.dump(last_json(p), open(f"{dst}/{tag}_bench_{w}_informative.json", "w"), indent=1)
+for name in (f"{tag}_gemm_pmc.md", f"{tag}_gemm_pmc_fp32mfma.md", f"{tag}_split_accuracy.log"):
+    if os.path.exists(f"{src}/{name}"):
+        shutil.copy(f"{src}/{name}", f"{dst}/{name}")
 
 # ---- per-shape table
 p = f"{src}/{tag}_bench_shapes.json"
@@ -48,7 +52,7 @@ if os.path.exists(p):
     gemm = sum(r[0] for r in rows if r[1].startswith("linear_"))
     red = sum(r[0] for r in rows if r[1].startswith("wgrad_reduce"))
     with open(f"{dst}/{tag}_gemm_shapes.md", "w") as f:
-        f.write("# Per-shape HIP-event table of one serialised bench step (round 2)\n\n")
+        f.write("# Per-shape HIP-event table of one serialised bench step (round %d)\n\n" % rnd)
         f.write("`DTC_PROF_SHAPES=1 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic`; names `linear_*[M x N x K]` "
                 "(N = output features, K = input features; `linear_wgrad[M x tiles x layers]` = one grouped weight-gradient launch, "
                 "`wgrad_reduce[splits x tiles x layers]` its split reduce).  Rate: TFLOP/s for the GEMM rows, TB/s for the others.  "
@@ -64,7 +68,7 @@ if os.path.exists(p):
 r = d["roofline"]
 if r.get("traffic_kernels"):
     with open(f"{dst}/{tag}_gemm_traffic_step.md", "w") as f:
-        f.write("# HBM-side traffic of the GEMM family over one serialised bench step (round 2)\n\n")
+        f.write("# HBM-side traffic of the GEMM family over one serialised bench step (round %d)\n\n" % rnd)
         f.write(r.get("traffic_source", "") + "\n\nCollected live by `bench.py` (two child runs under `rocprofv3 --kernel-trace --pmc <counter>`, "
                 "`tools/analysis/traffic.py`).\n\n| kernel | launches / step | traffic / step (MB) |\n|---|---|---|\n")
         for k, v in sorted(r["traffic_kernels"].items()):
@@ -72,10 +76,8 @@ if r.get("traffic_kernels"):
         f.write(f"\n* measured: **{r['traffic_step_bytes'] / 1e9:.1f} GB per step** = {r['traffic'] / 1e6:.1f} MB per launch ({r['traffic_launches']} launches)\n")
         f.write(f"* algorithmic (every operand read once, every output written once; in-library accounting): **{r['traffic_algorithmic_step_bytes'] / 1e9:.1f} GB per step** "
                 f"= {r['traffic_algorithmic'] / 1e6:.1f} MB per launch\n* ratio **{r['traffic_over_algorithmic']:.3f}**\n\n")
-        f.write("Where the excess comes from: the split partials of the weight gradients (24 batch slices x 7.4 / 7.8 MB of gradients per optimiser step: "
-                "~7.3 GB written by `wgrad_group_kernel` and ~7.3 GB read back by `wgrad_group_reduce_kernel` per step -- not counted as algorithmic), and "
-                "operand re-reads that miss the 4 MB per-XCD L2 (the X row panel of a 693-wide layer is re-read by its 8-11 column tiles).  The family moves "
-                "~1.5 TB/s: far from the HBM roof; the kernels are MFMA-bound.\n")
+        f.write("Where the excess comes from: the partial slabs of the weight gradients (written once by the grouped kernel, read once by its "
+                "reduce kernel -- not counted as algorithmic) and operand re-reads that miss the 4 MB per-XCD L2.\n")
 
 # ---- rocprofv3 kernel stats
 for mode in ("serial", "overlap"):
@@ -88,7 +90,7 @@ for mode in ("serial", "overlap"):
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for x in rows:
             w.writerow([short(x["Name"]), x["Calls"], x["TotalDurationNs"], x["AverageNs"], x["Percentage"], x["MinNs"], x["MaxNs"], x["StdDev"]])
-    fam = [x for x in rows if any(k in x["Name"] for k in ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_group", "wgrad_reduce", "gru_step_fwd"))]
+    fam = [x for x in rows if any(k in x["Name"] for k in ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_group", "wgrad_reduce", "gru_step_fwd", "linear_s3", "wgrad_s3"))]
     tot, calls = sum(float(x["TotalDurationNs"]) for x in fam), sum(int(x["Calls"]) for x in fam)
     print(f"{mode}: GEMM family {tot / 1e6:.1f} ms over {calls} launches -> {tot / calls / 1e3:.2f} us per launch")
 
