@@ -173,6 +173,53 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         }
     };
 
+#ifndef DTC_S3_NO_ILV
+    // Fused stage (round 3: 77.8 -> 74.9 us on 24576 x 512 x 512, 71.3 -> 69.7 ms per step; -DDTC_S3_NO_ILV restores the two phases): the MFMAs of LDS[buf] with the conversion + LDS store of the loaded registers (-> LDS[buf ^ 1])
+    // placed INTO the second half of the MFMA sequence (sched_barrier fences between the pieces; sched_group_barrier pipelines were
+    // ignored by this compiler): the conversion of a stage is ~110 VALU + 12 LDS stores, 24 MFMAs leave 24 x 28 idle issue cycles.
+    auto stage_ilv = [&](int buf) {
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        bf16x8 a[TM][3], b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot(wm_off + 32 * i + l31, half)]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot(wn_off + l31, half)]);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][0], 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot(wn_off + 32 + l31, half)]);
+        // branch-free k-tail masks (the block must stay one basic block for the scheduler)
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ra[i][e] = e <= klast ? ra[i][e] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rb[i][e] = e <= klast ? rb[i][e] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // hard ordering between the pieces: 3 MFMAs (96 cycles of pipe time) are issued, then one quarter of the conversion
+            // (~28 VALU + 3 LDS stores) issues while they execute
+            __builtin_amdgcn_sched_barrier(0);
+            const Split3 sp = split3(q < 2 ? ra[q] : rb[q - 2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) (q < 2 ? As : Bs)[buf ^ 1][p][aslot0 + 256 * (q & 1)] = sp.p[p];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const int m = 3 * q + t3, t = m >> 1, i = m & 1;
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][1], 0, 0, 0);
+            }
+        }
+    };
+#endif
+
     int total = 0;
     for (int i = 0; i < X.nseg; ++i) total += (X.s[i].width + BK - 1) / BK;
     int buf = 0;
@@ -182,8 +229,12 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     __syncthreads();
     for (int st = 1; st < total; ++st) {            // stage st in flight while the MFMAs consume LDS[buf]
         load_stage();
+#ifndef DTC_S3_NO_ILV
+        stage_ilv(buf);
+#else
         mfma_stage(buf);
         store_stage(buf ^ 1);
+#endif
         __syncthreads();
         buf ^= 1;
     }

@@ -74,6 +74,9 @@ ProfScope::~ProfScope() {
 extern "C" {
 
 int dtc_version(void) { return DTC_ABI_VERSION; }
+static int g_gemm_split = 0;
+void dtc_set_gemm_split(int on) { g_gemm_split = on ? 1 : 0; }
+int dtc_get_gemm_split(void) { return g_gemm_split; }
 int dtc_abi_sizes(int64_t* out, int cap) {
     const int64_t sz[] = {sizeof(DtcGridCfg), sizeof(DtcObsCfg), sizeof(DtcRowCopy), sizeof(DtcSeg), sizeof(DtcSegMat),
                           sizeof(DtcFwdLayer), sizeof(DtcWgradJob), sizeof(DtcPpoCfg), sizeof(DtcProfRec)};

@@ -9,10 +9,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ u32 cvt_pk_bf16(float lo, float hi) {          // (bf16(lo), bf16(hi)), round to nearest even
-    u32 r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (bf16(lo), bf16(hi)), round to nearest even: one v_cvt_pk_bf16_f32 (a builtin conversion, not inline asm: the instruction
+// scheduler can see and place it)
+__device__ __forceinline__ u32 cvt_pk_bf16(float lo, float hi) {
+    return __builtin_bit_cast(u32, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 __device__ __forceinline__ float bf_lo(u32 p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(u32 p) { return __uint_as_float(p & 0xffff0000u); }

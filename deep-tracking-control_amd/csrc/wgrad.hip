@@ -439,9 +439,35 @@ int plan_group(const DtcWgradJob* jobs, int count, int M, void* workspace, Group
 
 }  // namespace
 
+namespace {
+// one layer as a job of the split-precision grouped kernel (a single plain segment; callers with segmented X pass their own)
+DtcWgradJob one_job(const float* dZ, int64_t lddz, const DtcSegMat* X, float* dW, float* db, int N, int K) {
+    DtcWgradJob j;
+    j.dZ = dZ;
+    j.lddz = lddz;
+    j.X = *X;
+    j.dW = dW;
+    j.db = db;
+    j.N = N;
+    j.K = K;
+    return j;
+}
+// worst case of a one-layer split launch: every segment of X (<= 4) may add a partial 128-column tile
+int64_t s3_one_layer_bound(int M, int N, int K) {
+    const int64_t tiles = dtc::ceil_div(N, 128) * (dtc::ceil_div(K, 128) + 3);
+    int64_t splits = 2048 / (tiles > 0 ? tiles : 1) / 8 * 8;
+    if (splits < 8) splits = 8;
+    const int64_t max_s = dtc::ceil_div(dtc::ceil_div(M, 16 * 8), 8) * 8;
+    if (splits > max_s) splits = max_s;
+    return splits * (tiles * 128 * 128 + dtc::ceil_div(N, 128) * 128) * (int64_t)sizeof(float) + 64;
+}
+}  // namespace
+
 extern "C" int64_t dtc_linear_wgrad_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return (int64_t)wgrad_splits_bound(M, N, K) * N * part_ld(K) * (int64_t)sizeof(float);
+    const int64_t a = (int64_t)wgrad_splits_bound(M, N, K) * N * part_ld(K) * (int64_t)sizeof(float);
+    const int64_t b = dtc_get_gemm_split() ? s3_one_layer_bound(M, N, K) : 0;
+    return a > b ? a : b;
 }
 
 extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* X, float* dW, float* db, void* workspace,
@@ -450,6 +476,12 @@ extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* 
     DTC_REQUIRE(dZ && dW && workspace, "null pointer");
     DTC_REQUIRE(dtc::aligned16(workspace), "wgrad workspace must be 16-byte aligned");
     DTC_REQUIRE((long long)M * lddz <= MAX_ELEMS, "matrix too large");
+    if (dtc_get_gemm_split() && (long long)N * K >= 128 * 128 && M >= 1024) {
+        // split-precision path (dtc_set_gemm_split): this layer as a one-job grouped launch; the caller's workspace was sized by
+        // dtc_linear_wgrad_workspace for either path
+        const DtcWgradJob job = one_job(dZ, lddz, X, dW, db, N, K);
+        if (dtc_wgrad_group_s3_workspace(&job, 1, M) <= dtc_linear_wgrad_workspace(M, N, K)) return dtc_wgrad_group_s3(&job, 1, M, workspace, stream);
+    }
     SegMatDev xd;
     int rc = to_dev(X, xd, K, false, M);
     if (rc != DTC_OK) return rc;

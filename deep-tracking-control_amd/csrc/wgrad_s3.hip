@@ -153,6 +153,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
         }
     };
 
+    // fused stage: the MFMAs of LDS[buf] with the conversion + LDS store of the loaded block (-> LDS[buf ^ 1]) placed between the
+    // MFMAs of the second column tile, one column of the block per three MFMAs (see linear_s3_kernel)
+    auto stage_ilv = [&](int buf) {
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        bf16x8 a[2][3], b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot((2 * wr + i) * 32 + l31, half)]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot((2 * wc) * 32 + l31, half)]);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][0], 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot((2 * wc + 1) * 32 + l31, half)]);
+        u32x2(*dst)[TILE * 4] = is_a ? As[buf ^ 1] : Bs[buf ^ 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 col = {v[0][e], v[1][e], v[2][e], v[3][e]};
+            const Split3 sp = split3(col);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dst[p][slot[e]] = sp.p[p];
+            bsum[e] += (col[0] + col[1]) + (col[2] + col[3]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const int m = 3 * e + t3, t = m >> 1, i = m & 1;
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][1], 0, 0, 0);
+            }
+        }
+    };
+
     const int KT = (m_end - m_begin + BK - 1) / BK;
     if (KT > 0) {
         int buf = 0;
@@ -161,8 +197,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
         __syncthreads();
         for (int kt = 1; kt < KT; ++kt) {
             load_stage(m_begin + kt * BK);
+#ifndef DTC_S3_NO_ILV
+            stage_ilv(buf);
+#else
             mfma_stage(buf);
             store_stage(buf ^ 1);
+#endif
             __syncthreads();
             buf ^= 1;
         }

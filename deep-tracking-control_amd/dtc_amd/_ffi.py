@@ -102,6 +102,8 @@ _SIGS = {
     "dtc_linear_fwd": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_stream]),
     "dtc_linear_fwd_list": (C.c_int, [C.POINTER(DtcFwdLayer), C.c_int, C.c_int, c_stream]),
+    "dtc_set_gemm_split": (None, [C.c_int]),
+    "dtc_get_gemm_split": (C.c_int, []),
     "dtc_s3_planes_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_linear_fwd_s3": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, c_stream]),
@@ -181,6 +183,7 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _check_abi(_lib)
+        _lib.dtc_set_gemm_split(int(os.environ.get("DTC_GEMM_SPLIT", "1") != "0"))      # library-side twin of ops.SPLIT
     return _lib
 
 

@@ -94,6 +94,7 @@ SPLIT_MIN_RED = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_RED", "384"))      # sho
 def set_split(on: bool):
     global SPLIT
     SPLIT = bool(on)
+    lib().dtc_set_gemm_split(int(SPLIT))
 
 
 _PLANES = {}      # (device, stream, bytes) -> plane scratch of a split-path call (the pre-split weight)

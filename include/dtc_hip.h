@@ -219,6 +219,12 @@ int dtc_linear_dgrad_mask(const float* dZ, int64_t lddz, const float* W, const D
  * dtc_linear_fwd_mask (relu_mask may be NULL) and dtc_linear_dgrad / dtc_linear_dgrad_mask.  The weight operand is
  * pre-split into its three bf16 planes by a small kernel inside the call (once per layer and optimiser step; the planes of
  * W^T for the data gradient): the GEMM's loaders do no conversion work for it. */
+/* Library-side switch for the entry points that have no `_s3` twin of their own: with it on, dtc_linear_wgrad (and through it
+ * the W_hh / W_ih weight gradients inside dtc_gru_bwd / dtc_lstm_bwd) runs as a one-layer dtc_wgrad_group_s3, and
+ * dtc_linear_wgrad_workspace / dtc_gru_workspace / dtc_lstm_workspace return sizes that fit either path.  Off by default;
+ * dtc_amd/ops.py sets it from DTC_GEMM_SPLIT. */
+void dtc_set_gemm_split(int on);
+int dtc_get_gemm_split(void);
 int64_t dtc_s3_planes_bytes(int N, int K);   /* scratch for the pre-split weight of ONE call (`wplanes`, 16-byte aligned, private
                                                * to the call until it has completed on its stream)                              */
 int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
