@@ -87,8 +87,10 @@ def as_segmat(x, idx=None):
 # DTC_GEMM_SPLIT=0 selects the single-pass fp32 MFMA kernels everywhere; `set_split()` switches at run time (tests, A/B runs)
 import os as _os
 SPLIT = _os.environ.get("DTC_GEMM_SPLIT", "1") != "0"
-SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "256"))     # 128-column layers: 192 tiles of 128 x 128 do not fill the chip
-SPLIT_MIN_RED = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_RED", "384"))      # short reductions are prologue / epilogue bound either way
+# routing thresholds (output columns / reduction length); swept with bench.py in round 3: 256 / 384 -> 70.2 ms, 128 / 128 -> 69.5 ms per
+# step (the 128-column layers run longer per launch on 192 tiles of 128 x 128 -- 35 vs 28 us -- but on the second lane, under the wide GEMMs)
+SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "128"))
+SPLIT_MIN_RED = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_RED", "128"))
 
 
 def set_split(on: bool):
