@@ -295,7 +295,10 @@ __global__ __launch_bounds__(256) void wgrad_s3_reduce_kernel(const S3Group G) {
 
 int group_splits_s3(int M, int tiles_total) {
     static const char* target_env = getenv("DTC_WGRAD_S3_BLOCKS");
-    const int target = target_env ? atoi(target_env) : 2048;
+    // 768: eight batch slices for the 61..70-tile groups of the bench step.  Measured (tools/jobs/r3_sweep2.sh): 512..1536 within
+    // 0.5 % of each other in step time, 2048 (32 slices) no faster; the partial slabs are HBM traffic written and read once
+    // per slice, so the smallest count that still fills the chip wins (family traffic 1.30 -> 1.15 x the algorithmic bytes)
+    const int target = target_env ? atoi(target_env) : 768;
     int s = target / (tiles_total > 0 ? tiles_total : 1) / 8 * 8;
     if (s < 8) s = 8;
     const int max_s = (int)dtc::ceil_div(dtc::ceil_div(M, BK * 8), 8) * 8;

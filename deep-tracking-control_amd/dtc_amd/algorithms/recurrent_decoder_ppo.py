@@ -140,6 +140,8 @@ class RecurrentDecoderPPO(PPO):
         ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=self.relu_masks)
         ha = head_forward("a", Xa, ac.memory_a, ac.proj_a, ac.A, bt["hid_a"])
         tw.order("aux", "main")
+        if self.after_forward_hook is not None:
+            self.after_forward_hook(fw, "ppo")
         mean, value = ha["outs"][-1], hc["outs"][-1]
         ops.ppo_loss(mean, ac.std_view, value, flat["actions"], flat["actions_log_prob"], flat["mu"], flat["sigma"],
                      flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval, ac.std_grad,

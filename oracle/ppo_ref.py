@@ -70,7 +70,9 @@ class RefVae(nn.Module):
         with torch.no_grad():     # bookkeeping for the parity tests (which element IS the median)
             self.last_outliers, self.last_median = int(outliers.sum()), float(median)
             self.last_median_index = int(((lv == median) & ~outliers).flatten().nonzero()[0])
+            self.last_outlier_mask = outliers.detach().clone()
         lv[outliers] = median
+        self.last_logvar = lv.detach().clone()      # after the replacement (what the reparameterisation saw)
         z = eps * torch.exp(0.5 * lv) + mu[:, 3:]
         return mu, lv, z
 

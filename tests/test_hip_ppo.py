@@ -92,10 +92,17 @@ def _pack_sign_record(pos):
 
 
 def _force_oracle_signs(ref, alg):
-    """Teacher-force the ReLU derivative pattern: between the HIP forward and backward pass the sign records are replaced by
-    the ORACLE's masks.  A pre-activation that is 0 within fp32 rounding lands on different sides in two correct forwards
-    (about one (sample, unit) pair per 4e5) and moves every upstream gradient by that sample's share; with the records
-    forced the gradient comparison measures the backward kernels, not the knife edges.  Returns the list of forced steps."""
+    """Teacher-force the two data-dependent branches of the backward pass with the ORACLE's decisions, between the HIP forward
+    and backward pass of a step:
+    * the ReLU derivative pattern (sign records).  A pre-activation that is 0 within fp32 rounding lands on different sides
+      in two correct forwards (about one (sample, unit) pair per 4e5) and moves every upstream gradient by that sample's share;
+    * the CE-net outlier classification and the median element (actor_critic_decoder.py:293-299): every replaced entry sends
+      its gradient to the ONE median element, and at B = 24576 the non-outliers around the median are ~2e-6 apart, so GEMM
+      rounding noise decides which element that is (~8 % of the calls differ).  Entries classified differently also get the
+      oracle's log-variance, so the backward differentiates the function the oracle differentiated.
+    With both forced the gradient comparison measures the backward kernels, not the knife edges.  What the HIP forward
+    decided on its own is kept in alg.own_branch = (outliers, median index, entries classified differently) and reported.
+    Returns the list of forced steps."""
     forced = []
 
     def hook(fw, which):
@@ -109,9 +116,18 @@ def _force_oracle_signs(ref, alg):
             assert words.numel() == buf.numel(), (name, words.shape, buf.shape)
             buf.copy_(words.reshape(-1).to(buf.device))
             n += 1
+        vae = ref.actor_critic.vae
+        want = vae.last_outlier_mask.to(fw.mask.device)
+        differ = fw.mask.bool() != want
+        alg.own_branch = (int(fw.info[0]), int(fw.info[1]), int(differ.sum()))
+        if alg.own_branch[2]:
+            fw.mulv[:, 19:][differ] = vae.last_logvar.to(fw.mulv.device)[differ]
+        fw.mask.copy_(want.to(torch.uint8))
+        fw.info[:2] = torch.tensor([vae.last_outliers, vae.last_median_index], dtype=torch.int32, device=fw.info.device)
         forced.append((which, n))
         torch.cuda.synchronize()
 
+    alg.own_branch = None
     alg.after_forward_hook = hook if alg.relu_masks else None
     return forced
 
@@ -136,10 +152,13 @@ def _compare_grads(k, which, grads_ref, ref, alg, n_expected, strict=False, forc
     # ... and at B = 24576 the 3.7e5 non-outliers are ~2e-6 apart around the median, so fp32 GEMM noise
     # (3e-7) can even swap WHICH element is the median: compare the element index, not just the value.
     same_median = int(fw.info[0]) == vae.last_outliers and int(fw.info[1]) == vae.last_median_index
+    own = getattr(alg, "own_branch", None) if alg.after_forward_hook is not None else None
     BRANCH_LOG.append((B, which, bool(same_median)))          # full-size tests ASSERT that the compared branch ran (below)
     if B >= 4096:
-        print(f"[step {k} {which}] B={B}: CE-net encoder gradients {'compared' if same_median else 'SKIPPED (median on another element)'}; "
-              f"ReLU knife edges {n_mis}")
+        note = "" if own is None else (f" (teacher-forced; the HIP forward's own choice: {own[0]} outliers, median element {own[1]}, "
+                                       f"{own[2]} entries classified differently from the oracle's {vae.last_outliers} / {vae.last_median_index})")
+        print(f"[step {k} {which}] B={B}: CE-net encoder gradients {'compared' if same_median else 'SKIPPED (median on another element)'}"
+              f"{note}; ReLU knife edges {n_mis}")
     if strict:
         assert n_mis == 0 and same_median, (n_mis, int(fw.info[0]), vae.last_outliers,
                                             float(fw.info[2:3].view(torch.float32)), vae.last_median)
