@@ -21,6 +21,8 @@
 //   workgroups per CU.
 // The data gradient uses the same kernel on the transposed weight (dtc_s3_transpose once per optimiser step): both
 // operands are then reduction-contiguous as well.
+#include <type_traits>
+
 #include "s3_core.hpp"
 
 namespace {
@@ -47,15 +49,57 @@ struct DgradEpi {
     int ldm, col_skip, wide_segs;
 };
 
-template <int EPI>
+// Weight image (round 3): the W operand of a launch as the kernel's LDS planes, built ONCE per call by wimage_kernel instead of
+// once per row tile inside the K loop (192 times for M = 24576): for every 128-column tile and every 16-k stage of the segment
+// walk one 12 KiB chunk [plane 3][row 128][16 k bf16, halves swapped as rslot() says], k tails and rows past N zero-filled.
+// The K loop copies a chunk into LDS with three LDS-DMA instructions per wave (buffer_load_dwordx4 ... lds: no registers, no
+// conversion, no ds_write for the W side).
+constexpr int WIMG_PLANE = 128 * 32;            // bytes of one plane of one stage
+constexpr int WIMG_CHUNK = 3 * WIMG_PLANE;      // one stage of one 128-column tile
+struct WimgSegs {
+    int nseg, start[4], width[4];
+};
+typedef __attribute__((address_space(3))) void lds_void;
+
+// block = (column tile, stage), thread = (row of the tile, k half); trans: the operand is W^T (element (row, k) = W[k * ld + row])
+__global__ __launch_bounds__(256) void wimage_kernel(const float* __restrict__ W, u32x4* __restrict__ img, int rows, int row0, long long ld,
+                                                     int trans, const WimgSegs sg, int total) {
+    const int tc = blockIdx.x / total;
+    int kt = blockIdx.x - tc * total, seg = 0;
+    while (seg + 1 < sg.nseg && kt >= (sg.width[seg] + BK - 1) / BK) {
+        kt -= (sg.width[seg] + BK - 1) / BK;
+        ++seg;
+    }
+    const int r = threadIdx.x >> 1, h = threadIdx.x & 1;
+    const int row = row0 + tc * 128 + r, k0 = kt * BK + 8 * h;
+    f32x4 v[2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = k0 + e;
+        const long long col = sg.start[seg] + j;
+        const bool ok = row < rows && j < sg.width[seg];
+        v[e >> 2][e & 3] = ok ? (trans ? W[col * ld + row] : W[(long long)row * ld + col]) : 0.f;
+    }
+    const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
+    u32x4* dst = img + (long long)blockIdx.x * (WIMG_CHUNK / 16);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dst[p * 256 + rslot(r, h)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
+}
+
+template <int EPI, bool WIMG>
 __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, const float* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ Y,
                                                            long long ldy, int M, int N, int K, int act, int wide,
                                                            unsigned short* __restrict__ wmask, int ldwm, const DgradEpi dg,
-                                                           const MseEpiS3 mse) {
-    constexpr int BN = 128, WN = 2, TM = 2, TN = 2, NA = 2, NB = 2;
+                                                           const MseEpiS3 mse, const u32x4* __restrict__ wimg, long long wimg_bytes) {
+    constexpr int BN = 128, WN = 2, TM = 2, TN = 2, NA = 2, NB = WIMG ? 0 : 2;
     __shared__ __attribute__((aligned(16))) u32x2 As[2][3][BM * 4];
-    __shared__ __attribute__((aligned(16))) u32x2 Bs[2][3][BN * 4];
+    // two separate objects: the compiler then knows that an LDS-DMA into one stage buffer cannot alias the fragment reads of the
+    // other (with one array it waits for the DMA before the first ds_read of every stage); the K loop is unrolled by two so that
+    // the buffer index is a compile-time constant
+    __shared__ __attribute__((aligned(16))) u32x2 Bs0[3][BN * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Bs1[3][BN * 4];
+#define BS(b) ((b) ? Bs1 : Bs0)
     int tr, tc;
     const int ncols = EPI == EPI_DGRAD ? N - dg.col_skip : N;          // output columns that are computed
     if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (ncols + BN - 1) / BN, tr, tc)) {
@@ -73,13 +117,17 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     // 24576 x 512 x 512: the kernel is bound by the barrier-coupled wait / issue chain of a stage, not by its VALU count.)
     const int lrow = tid >> 2, lch = tid & 3;
     const int aslot0 = wslot(lrow, lch);                       // rows lrow and lrow + 64 share the half-swap parity: + 64 * 4 slots
-    u32 woff[NB];
+    u32 woff[NB ? NB : 1];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int wn = n0 + lrow + 64 * i;
         woff[i] = wn < N ? (u32)(wn * K + 4 * lch) * 4u : INVALID;
     }
-    const rsrc_t wres = make_rsrc_bytes(W, (long long)N * K * 4);
+    const rsrc_t wres = WIMG ? make_rsrc_bytes(wimg, wimg_bytes) : make_rsrc_bytes(W, (long long)N * K * 4);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int total = 0;
+    for (int i = 0; i < X.nseg; ++i) total += (X.s[i].width + BK - 1) / BK;
+    u32 wchunk = (u32)(tc * total) * (u32)WIMG_CHUNK;       // byte offset of the next stage's chunk of this column tile
 
     // ONE loop over the stages of all segments; the (rare) hop into the next segment re-derives the row offsets (the gathered
     // row index is re-read from idx: two loads per thread and segment instead of registers held across the whole K loop)
@@ -99,10 +147,17 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     int seg = 0, kt = 0, nst = (sd.width + BK - 1) / BK;
     // operand loads run ONE stage ahead of the MFMAs.  (Two stages ahead -- two register sets -- measured slower: 91 vs 73 us
     // on 24576 x 512 x 512; the third workgroup per CU that the registers of the second set cost is worth more.)
-    f32x4 ra[NA], rb[NB];
+    f32x4 ra[NA], rb[NB ? NB : 1];
     int klast;                                      // last valid element (0..3, < 0: none) of the loaded k chunks; >= 3: no tail
-    auto load_stage = [&]() {                       // next stage of the cursor -> registers (no wait)
+    auto load_stage = [&](auto nbc) {               // next stage of the cursor -> registers / (W image) LDS[nbuf] (no wait)
+        constexpr int nbuf = decltype(nbc)::value;
         const u32 ka = (u32)(kt * BK) * 4u, kw = (u32)(sd.start + kt * BK) * 4u;
+        if constexpr (WIMG) {                       // issued first: the compiler waits for ALL loads once an LDS-DMA is in flight
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)&BS(nbuf)[p][wave_u * 128], 16, tid * 16, wchunk + p * WIMG_PLANE, 0, 0);
+            wchunk += WIMG_CHUNK;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = bload4(ares, aoff[i], ka);
 #pragma unroll
@@ -116,7 +171,8 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
             nst = (sd.width + BK - 1) / BK;
         }
     };
-    auto store_stage = [&](int buf) {               // registers -> (k-tail mask) -> three bf16 planes -> LDS
+    auto store_stage = [&](auto bc) {               // registers -> (k-tail mask) -> three bf16 planes -> LDS
+        constexpr int buf = decltype(bc)::value;
         if (__builtin_amdgcn_readfirstlane(klast + 4 * lch) < BK - 1) {      // (the same value in every lane) last stage of a ragged segment
 #pragma unroll
             for (int i = 0; i < NA; ++i)
@@ -137,7 +193,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         for (int i = 0; i < NB; ++i) {
             const Split3 s = split3(rb[i]);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) Bs[buf][p][aslot0 + 256 * i] = s.p[p];
+            for (int p = 0; p < 3; ++p) BS(buf)[p][aslot0 + 256 * i] = s.p[p];
         }
     };
 
@@ -149,7 +205,8 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto mfma_stage = [&](int buf) {
+    auto mfma_stage = [&](auto bc) {
+        constexpr int buf = decltype(bc)::value;
         // fragments: A planes of both row tiles stay live (24 registers), B planes are read per column tile (12 registers)
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};      // smallest terms first: (a3 b1, a2 b2, a1 b3), (a2 b1, a1 b2), a1 b1
         bf16x8 a[TM][3];
@@ -163,7 +220,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
             bf16x8 b[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot(wn_off + 32 * j + l31, half)]);
+                b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&BS(buf)[p][0])[rslot(wn_off + 32 * j + l31, half)]);
             // the two row tiles alternate: consecutive MFMAs never wait for each other's accumulator
 #pragma unroll
             for (int t = 0; t < 6; ++t)
@@ -177,7 +234,8 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     // Fused stage (round 3: 77.8 -> 74.9 us on 24576 x 512 x 512, 71.3 -> 69.7 ms per step; -DDTC_S3_NO_ILV restores the two phases): the MFMAs of LDS[buf] with the conversion + LDS store of the loaded registers (-> LDS[buf ^ 1])
     // placed INTO the second half of the MFMA sequence (sched_barrier fences between the pieces; sched_group_barrier pipelines were
     // ignored by this compiler): the conversion of a stage is ~110 VALU + 12 LDS stores, 24 MFMAs leave 24 x 28 idle issue cycles.
-    auto stage_ilv = [&](int buf) {
+    auto stage_ilv = [&](auto bc) {
+        constexpr int buf = decltype(bc)::value;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
         bf16x8 a[TM][3], b[3];
 #pragma unroll
@@ -186,13 +244,13 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
             for (int i = 0; i < TM; ++i)
                 a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot(wm_off + 32 * i + l31, half)]);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot(wn_off + l31, half)]);
+        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&BS(buf)[p][0])[rslot(wn_off + l31, half)]);
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
             for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][0], 0, 0, 0);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot(wn_off + 32 + l31, half)]);
+        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&BS(buf)[p][0])[rslot(wn_off + 32 + l31, half)]);
         // branch-free k-tail masks (the block must stay one basic block for the scheduler)
 #pragma unroll
         for (int i = 0; i < NA; ++i)
@@ -202,43 +260,47 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) rb[i][e] = e <= klast ? rb[i][e] : 0.f;
+        constexpr int NQ = NA + NB, MQ = 12 / NQ;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            // hard ordering between the pieces: 3 MFMAs (96 cycles of pipe time) are issued, then one quarter of the conversion
+        for (int q = 0; q < NQ; ++q) {
+            // hard ordering between the pieces: 3 (W image: 6) MFMAs are issued, then the conversion of one float4 per thread
             // (~28 VALU + 3 LDS stores) issues while they execute
             __builtin_amdgcn_sched_barrier(0);
-            const Split3 sp = split3(q < 2 ? ra[q] : rb[q - 2]);
+            const Split3 sp = split3(q < NA ? ra[q] : rb[NB ? q - NA : 0]);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) (q < 2 ? As : Bs)[buf ^ 1][p][aslot0 + 256 * (q & 1)] = sp.p[p];
+            for (int p = 0; p < 3; ++p) (q < NA ? As[buf ^ 1] : BS(buf ^ 1))[p][aslot0 + 256 * (q & 1)] = sp.p[p];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) {
-                const int m = 3 * q + t3, t = m >> 1, i = m & 1;
+            for (int t3 = 0; t3 < MQ; ++t3) {
+                const int m = MQ * q + t3, t = m >> 1, i = m & 1;
                 acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][1], 0, 0, 0);
             }
         }
     };
 #endif
 
-    int total = 0;
-    for (int i = 0; i < X.nseg; ++i) total += (X.s[i].width + BK - 1) / BK;
-    int buf = 0;
     enter_segment();
-    load_stage();
-    store_stage(0);
+    load_stage(S0{});
+    store_stage(S0{});
     __syncthreads();
-    for (int st = 1; st < total; ++st) {            // stage st in flight while the MFMAs consume LDS[buf]
-        load_stage();
+    // stage st in flight while the MFMAs consume the other buffer; two stages per trip (constant buffer indices)
+    auto step = [&](auto bc) {
+        load_stage(std::integral_constant<int, decltype(bc)::value ^ 1>{});
 #ifndef DTC_S3_NO_ILV
-        stage_ilv(buf);
+        stage_ilv(bc);
 #else
-        mfma_stage(buf);
-        store_stage(buf ^ 1);
+        mfma_stage(bc);
+        store_stage(std::integral_constant<int, decltype(bc)::value ^ 1>{});
 #endif
         __syncthreads();
-        buf ^= 1;
+    };
+    // stages 0 .. total-1 are consumed two per trip; past the last stage the cursor loads nothing valid (klast < 0: the k-tail masks
+    // zero the X side, so the W side of a pad stage -- whatever finite planes the buffer holds -- contributes nothing): an even
+    // total ends with one unused load, an odd total with one all-zero stage
+    for (int trip = (total + 1) >> 1; trip > 0; --trip) {
+        step(S0{});
+        step(S1{});
     }
-    mfma_stage(buf);
 
     const bool full = (m0 + BM <= M) && (n0 + BN <= N);
     __syncthreads();                                    // every wave is past its last operand read: LDS becomes the patches
@@ -276,7 +338,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
-        double* red = reinterpret_cast<double*>(&Bs[0][0][0]);
+        double* red = reinterpret_cast<double*>(&Bs0[0][0]);
         if (lane == 0) red[wave] = sq;
         __syncthreads();
         if (tid == 0) mse.part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
@@ -438,19 +500,43 @@ int wide_mask_s3(const SegMatDev& xd, const float* Xsaved, long long ldxs, int c
     return m;
 }
 
+// W operand of one launch as the kernel's LDS planes (see wimage_kernel); DTC_S3_WIMG=0: the kernels split W inside their K loop
+// as they do X (round-3 A/B switch; the data gradient then reads a transposed fp32 copy)
+bool wimage_on() {
+    static const bool on = [] {
+        const char* e = getenv("DTC_S3_WIMG");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return on;
+}
+// launches wimage_kernel for the column tiles [0, col_tiles) of the operand whose first row is row0; returns the image bytes
+long long build_wimage(const float* W, void* img, int rows, int row0, long long ld, int trans, const SegMatDev& xd, int col_tiles, hipStream_t s) {
+    WimgSegs sg{};
+    sg.nseg = xd.nseg;
+    int total = 0;
+    for (int i = 0; i < xd.nseg; ++i) {
+        sg.start[i] = xd.s[i].start;
+        sg.width[i] = xd.s[i].width;
+        total += (xd.s[i].width + BK - 1) / BK;
+    }
+    hipLaunchKernelGGL(wimage_kernel, dim3((unsigned)(col_tiles * total)), dim3(256), 0, s, W, (u32x4*)img, rows, row0, ld, trans, sg, total);
+    return (long long)col_tiles * total * WIMG_CHUNK;
+}
+
 }  // namespace
 
-// scratch of one data-gradient call: the transposed weight
+// scratch of one split-path call: the weight image (at least the transposed fp32 weight of the DTC_S3_WIMG=0 data gradient)
 extern "C" int64_t dtc_s3_planes_bytes(int N, int K) {
     if (N <= 0 || K <= 0) return 0;
-    return 4ll * N * K + 64;
+    const long long img = (long long)WIMG_CHUNK * dtc::ceil_div(N, 128) * (dtc::ceil_div(K, BK) + 4);
+    const long long wt = 4ll * N * K;
+    return (img > wt ? img : wt) + 64;
 }
 
 // Y = act(X W^T + b) [+ the ReLU sign record when relu_mask != NULL] on the split-precision path
 extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
                                  void* wplanes, int M, int N, int K, int act, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
-    (void)wplanes;
     DTC_REQUIRE(W && Y, "null pointer");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
     DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * ldy <= MAX_ELEMS * 4, "matrix too large");
@@ -463,8 +549,15 @@ extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float
     if (relu_mask)
         DTC_REQUIRE(act == DTC_ACT_RELU && wide && M % BM == 0 && N % 128 == 0, "sign record (split path): M=%d and N=%d must be multiples of 128", M, N);
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
-                       M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{});
+    if (wimage_on()) {
+        DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
+        const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s);
+        hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
+                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)wplanes, ib);
+    } else {
+        hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
+                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)nullptr, 0ll);
+    }
     return dtc::check_launch("linear_fwd_s3");
 }
 
@@ -507,11 +600,19 @@ extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W
     if (relu_mask) bytes += 0.125 * M * (double)K;
     else if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)K;
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s, bytes);
-    float* WT = (float*)wplanes;
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dtc::ceil_div(K, 32), (unsigned)dtc::ceil_div(N, 32)), dim3(256), 0, s, W, WT, N, K);
     // roles inside the kernel: output columns = K of the layer, reduction = N of the layer
-    hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD>), dim3(grid), dim3(256), 0, s, zin, (const float*)WT, (const float*)nullptr, (float*)nullptr,
-                       0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{});
+    if (wimage_on()) {
+        const long long ib = build_wimage(W, wplanes, K, col_skip, K, 1, zin, (int)dtc::ceil_div(K - col_skip, 128), s);
+        hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, true>), dim3(grid), dim3(256), 0, s, zin, (const float*)nullptr, (const float*)nullptr,
+                           (float*)nullptr, 0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{},
+                           (const u32x4*)wplanes, ib);
+    } else {
+        float* WT = (float*)wplanes;
+        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dtc::ceil_div(K, 32), (unsigned)dtc::ceil_div(N, 32)), dim3(256), 0, s, W, WT, N, K);
+        hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, false>), dim3(grid), dim3(256), 0, s, zin, (const float*)WT, (const float*)nullptr,
+                           (float*)nullptr, 0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{},
+                           (const u32x4*)nullptr, 0ll);
+    }
     return dtc::check_launch("linear_dgrad_s3");
 }
 
@@ -525,7 +626,6 @@ extern "C" int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const f
                                      int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
                                      double* sq_part, void* wplanes, int M, int N, int K, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N, "bad shape M=%d N=%d K=%d", M, N, K);
-    (void)wplanes;
     DTC_REQUIRE(W && target && tidx && dY && sq_part, "null pointer");
     DTC_REQUIRE(tcol0 >= 0 && tcol0 + N <= ldt && target_rows > 0, "target columns [%d, %d) outside its %lld-wide rows", tcol0,
                 tcol0 + N, (long long)ldt);
@@ -538,7 +638,14 @@ extern "C" int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const f
     const MseEpiS3 mse{target, (const long long*)tidx, (long long)ldt, target_rows * ldt * 4, tcol0, scale, sq_part};
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s,
                         4.0 * ((double)M * K + (double)N * K + 2.0 * M * N));
-    hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
-                       M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse);
+    if (wimage_on()) {
+        DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
+        const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s);
+        hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE, true>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
+                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)wplanes, ib);
+    } else {
+        hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE, false>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
+                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)nullptr, 0ll);
+    }
     return dtc::check_launch("linear_fwd_mse_s3");
 }
