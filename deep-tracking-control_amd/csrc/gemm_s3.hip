@@ -61,27 +61,45 @@ struct WimgSegs {
 };
 typedef __attribute__((address_space(3))) void lds_void;
 
-// block = (column tile, stage), thread = (row of the tile, k half); trans: the operand is W^T (element (row, k) = W[k * ld + row])
-__global__ __launch_bounds__(256) void wimage_kernel(const float* __restrict__ W, u32x4* __restrict__ img, int rows, int row0, long long ld,
-                                                     int trans, const WimgSegs sg, int total) {
-    const int tc = blockIdx.x / total;
-    int kt = blockIdx.x - tc * total, seg = 0;
+// One image = one job; a launch builds up to WIMG_MAX_JOBS of them (all layers of a trainer phase: dtc_s3_wimage_group).
+// block = (job, column tile, stage), thread = (row of the tile, k half); trans: the operand is W^T (element (row, k) = W[k * ld + row])
+constexpr int WIMG_MAX_JOBS = 24;
+struct WimgJobDev {
+    const float* W;
+    u32x4* img;
+    long long ld;
+    int rows, row0, trans, total, block_end;      // block_end: running sum of (column tiles x stages) over the jobs
+    WimgSegs sg;
+};
+struct WimgGroup {
+    int count;
+    WimgJobDev job[WIMG_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void wimage_kernel(const WimgGroup G) {
+    int j = 0, b = blockIdx.x;
+    while (j < G.count - 1 && b >= G.job[j].block_end) ++j;
+    if (j > 0) b -= G.job[j - 1].block_end;
+    const WimgJobDev& J = G.job[j];
+    const float* __restrict__ W = J.W;
+    const WimgSegs& sg = J.sg;
+    const int tc = b / J.total;
+    int kt = b - tc * J.total, seg = 0;
     while (seg + 1 < sg.nseg && kt >= (sg.width[seg] + BK - 1) / BK) {
         kt -= (sg.width[seg] + BK - 1) / BK;
         ++seg;
     }
     const int r = threadIdx.x >> 1, h = threadIdx.x & 1;
-    const int row = row0 + tc * 128 + r, k0 = kt * BK + 8 * h;
+    const int row = J.row0 + tc * 128 + r, k0 = kt * BK + 8 * h;
     f32x4 v[2];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int j = k0 + e;
-        const long long col = sg.start[seg] + j;
-        const bool ok = row < rows && j < sg.width[seg];
-        v[e >> 2][e & 3] = ok ? (trans ? W[col * ld + row] : W[(long long)row * ld + col]) : 0.f;
+        const int jj = k0 + e;
+        const long long col = sg.start[seg] + jj;
+        const bool ok = row < J.rows && jj < sg.width[seg];
+        v[e >> 2][e & 3] = ok ? (J.trans ? W[col * J.ld + row] : W[(long long)row * J.ld + col]) : 0.f;
     }
     const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
-    u32x4* dst = img + (long long)blockIdx.x * (WIMG_CHUNK / 16);
+    u32x4* dst = J.img + (long long)b * (WIMG_CHUNK / 16);
 #pragma unroll
     for (int p = 0; p < 3; ++p) dst[p * 256 + rslot(r, h)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
 }
@@ -509,18 +527,44 @@ bool wimage_on() {
     }();
     return on;
 }
-// launches wimage_kernel for the column tiles [0, col_tiles) of the operand whose first row is row0; returns the image bytes
-long long build_wimage(const float* W, void* img, int rows, int row0, long long ld, int trans, const SegMatDev& xd, int col_tiles, hipStream_t s) {
-    WimgSegs sg{};
-    sg.nseg = xd.nseg;
-    int total = 0;
+// job of one image: the column tiles [0, col_tiles) of the operand whose first row is row0, the stages of xd's segment walk
+long long wimage_job(WimgJobDev& J, const float* W, void* img, int rows, int row0, long long ld, int trans, const SegMatDev& xd, int col_tiles) {
+    J.W = W;
+    J.img = (u32x4*)img;
+    J.ld = ld;
+    J.rows = rows;
+    J.row0 = row0;
+    J.trans = trans;
+    J.sg = WimgSegs{};
+    J.sg.nseg = xd.nseg;
+    J.total = 0;
     for (int i = 0; i < xd.nseg; ++i) {
-        sg.start[i] = xd.s[i].start;
-        sg.width[i] = xd.s[i].width;
-        total += (xd.s[i].width + BK - 1) / BK;
+        J.sg.start[i] = xd.s[i].start;
+        J.sg.width[i] = xd.s[i].width;
+        J.total += (xd.s[i].width + BK - 1) / BK;
     }
-    hipLaunchKernelGGL(wimage_kernel, dim3((unsigned)(col_tiles * total)), dim3(256), 0, s, W, (u32x4*)img, rows, row0, ld, trans, sg, total);
-    return (long long)col_tiles * total * WIMG_CHUNK;
+    J.block_end = col_tiles * J.total;
+    return (long long)col_tiles * J.total * WIMG_CHUNK;
+}
+// the image of ONE call, built on the call's stream right in front of the GEMM; returns the image bytes
+long long build_wimage(const float* W, void* img, int rows, int row0, long long ld, int trans, const SegMatDev& xd, int col_tiles, hipStream_t s,
+                       bool ready) {
+    WimgGroup G;
+    G.count = 1;
+    const long long bytes = wimage_job(G.job[0], W, img, rows, row0, ld, trans, xd, col_tiles);
+    if (!ready) hipLaunchKernelGGL(wimage_kernel, dim3((unsigned)G.job[0].block_end), dim3(256), 0, s, G);
+    return bytes;
+}
+// the data gradient's row operand (dZ [M, N], one plain segment) and the leading destination columns nothing is stored for
+void dgrad_operands(SegMatDev& zin, const SegMatDev& dX, const float* dZ, long long lddz, int M, int N, int K, int& col_skip) {
+    zin.nseg = 1;
+    zin.gathers = 0;
+    zin.idx = nullptr;
+    for (int i = 0; i < 4; ++i) zin.s[i] = SegDev{nullptr, 0, 0, 0x7fffffff, 0, 0, 0, 0};
+    zin.s[0] = SegDev{const_cast<float*>(dZ), lddz, 0, 0, N, 0, 0, M};
+    col_skip = 0;
+    for (int i = 0; i < dX.nseg && dX.s[i].ptr == nullptr; ++i) col_skip += dX.s[i].width;
+    if (col_skip < K) col_skip &= ~31;              // whole 32-column sub-tiles only (the rest of a NULL segment is computed, not stored)
 }
 
 }  // namespace
@@ -535,7 +579,7 @@ extern "C" int64_t dtc_s3_planes_bytes(int N, int K) {
 
 // Y = act(X W^T + b) [+ the ReLU sign record when relu_mask != NULL] on the split-precision path
 extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
-                                 void* wplanes, int M, int N, int K, int act, void* stream) {
+                                 void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
     DTC_REQUIRE(W && Y, "null pointer");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
@@ -551,7 +595,7 @@ extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     if (wimage_on()) {
         DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
-        const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s);
+        const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
                            M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)wplanes, ib);
     } else {
@@ -565,7 +609,8 @@ extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float
 // same destination contract as dtc_linear_dgrad / dtc_linear_dgrad_mask (relu_mask != NULL: the ReLU derivative from the sign
 // record, Xsaved unused)
 extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved,
-                                   int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int M, int N, int K, int act, void* stream) {
+                                   int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
+                                   void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
     DTC_REQUIRE(dZ && W && wplanes && dtc::aligned16(wplanes), "null pointer / unaligned scratch");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
@@ -575,16 +620,10 @@ extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W
     DgradEpi dg;
     int rc = to_dev(dX, dg.dX, K, true, 0);
     if (rc != DTC_OK) return rc;
-    int col_skip = 0;
-    for (int i = 0; i < dg.dX.nseg && dg.dX.s[i].ptr == nullptr; ++i) col_skip += dg.dX.s[i].width;
-    DTC_REQUIRE(col_skip < K, "every destination segment is NULL");
-    col_skip &= ~31;                                 // whole 32-column sub-tiles only (the rest of a NULL segment is computed, not stored)
+    int col_skip;
     SegMatDev zin;                                    // the row operand of the product: dZ [M, N], one plain segment
-    zin.nseg = 1;
-    zin.gathers = 0;
-    zin.idx = nullptr;
-    for (int i = 0; i < 4; ++i) zin.s[i] = SegDev{nullptr, 0, 0, 0x7fffffff, 0, 0, 0, 0};
-    zin.s[0] = SegDev{const_cast<float*>(dZ), (long long)lddz, 0, 0, N, 0, 0, M};
+    dgrad_operands(zin, dg.dX, dZ, (long long)lddz, M, N, K, col_skip);
+    DTC_REQUIRE(col_skip < K, "every destination segment is NULL");
     dg.Xs = relu_mask ? nullptr : Xsaved;
     dg.ldxs = ldxs;
     dg.rmask = (const unsigned short*)relu_mask;
@@ -602,7 +641,7 @@ extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s, bytes);
     // roles inside the kernel: output columns = K of the layer, reduction = N of the layer
     if (wimage_on()) {
-        const long long ib = build_wimage(W, wplanes, K, col_skip, K, 1, zin, (int)dtc::ceil_div(K - col_skip, 128), s);
+        const long long ib = build_wimage(W, wplanes, K, col_skip, K, 1, zin, (int)dtc::ceil_div(K - col_skip, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, true>), dim3(grid), dim3(256), 0, s, zin, (const float*)nullptr, (const float*)nullptr,
                            (float*)nullptr, 0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{},
                            (const u32x4*)wplanes, ib);
@@ -624,7 +663,7 @@ extern "C" int64_t dtc_linear_fwd_mse_s3_parts(int M, int N) {
 // dtc_linear_fwd_mse on the split-precision path (sq_part: dtc_linear_fwd_mse_s3_parts(M, N) doubles)
 extern "C" int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
                                      int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
-                                     double* sq_part, void* wplanes, int M, int N, int K, void* stream) {
+                                     double* sq_part, void* wplanes, int wimage_ready, int M, int N, int K, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N, "bad shape M=%d N=%d K=%d", M, N, K);
     DTC_REQUIRE(W && target && tidx && dY && sq_part, "null pointer");
     DTC_REQUIRE(tcol0 >= 0 && tcol0 + N <= ldt && target_rows > 0, "target columns [%d, %d) outside its %lld-wide rows", tcol0,
@@ -640,7 +679,7 @@ extern "C" int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const f
                         4.0 * ((double)M * K + (double)N * K + 2.0 * M * N));
     if (wimage_on()) {
         DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
-        const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s);
+        const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE, true>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
                            M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)wplanes, ib);
     } else {
@@ -648,4 +687,44 @@ extern "C" int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const f
                            M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)nullptr, 0ll);
     }
     return dtc::check_launch("linear_fwd_mse_s3");
+}
+
+// The weight images of `count` later calls in one launch per WIMG_MAX_JOBS jobs (a trainer builds the images of all layers of an
+// optimisation step at its start and passes wimage_ready = 1 to the calls): job i describes the call exactly as the call will --
+// trans == 0: dtc_linear_fwd_s3 / dtc_linear_fwd_mse_s3 with operand `seg` = X; trans == 1: dtc_linear_dgrad_s3 with `seg` = dX.
+extern "C" int dtc_s3_wimage_group(const DtcWimgJob* jobs, int count, void* stream) {
+    DTC_REQUIRE(jobs && count > 0, "no jobs");
+    DTC_REQUIRE(wimage_on(), "weight images are switched off (DTC_S3_WIMG=0)");
+    hipStream_t s = (hipStream_t)stream;
+    WimgGroup G;
+    G.count = 0;
+    auto flush = [&]() {
+        if (G.count == 0) return;
+        hipLaunchKernelGGL(wimage_kernel, dim3((unsigned)G.job[G.count - 1].block_end), dim3(256), 0, s, G);
+        G.count = 0;
+    };
+    for (int i = 0; i < count; ++i) {
+        const DtcWimgJob& h = jobs[i];
+        DTC_REQUIRE(h.W && h.img && dtc::aligned16(h.img) && h.seg && h.N > 0 && h.K > 0, "job %d: null pointer / bad shape", i);
+        DTC_REQUIRE((long long)h.N * h.K <= MAX_ELEMS, "job %d: matrix too large", i);
+        SegMatDev xd;
+        WimgJobDev& J = G.job[G.count];
+        if (h.trans) {
+            int rc = to_dev(h.seg, xd, h.K, true, 0);
+            if (rc != DTC_OK) return rc;
+            SegMatDev zin;
+            int col_skip;
+            dgrad_operands(zin, xd, nullptr, 0, 0, h.N, h.K, col_skip);
+            DTC_REQUIRE(col_skip < h.K, "job %d: every destination segment is NULL", i);
+            wimage_job(J, h.W, h.img, h.K, col_skip, h.K, 1, zin, (int)dtc::ceil_div(h.K - col_skip, 128));
+        } else {
+            int rc = to_dev(h.seg, xd, h.K, false, 0);
+            if (rc != DTC_OK) return rc;
+            wimage_job(J, h.W, h.img, h.N, 0, h.K, 0, xd, (int)dtc::ceil_div(h.N, 128));
+        }
+        if (G.count > 0) J.block_end += G.job[G.count - 1].block_end;
+        if (++G.count == WIMG_MAX_JOBS) flush();
+    }
+    flush();
+    return dtc::check_launch("s3_wimage_group");
 }

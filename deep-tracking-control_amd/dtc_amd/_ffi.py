@@ -45,6 +45,11 @@ class DtcFwdLayer(C.Structure):
                 ("N", C.c_int32), ("K", C.c_int32), ("act", C.c_int32)]
 
 
+class DtcWimgJob(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("img", C.c_void_p), ("seg", C.POINTER(DtcSegMat)), ("N", C.c_int32), ("K", C.c_int32),
+                ("trans", C.c_int32)]
+
+
 class DtcPpoCfg(C.Structure):
     _fields_ = [("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float),
                 ("desired_kl", C.c_float), ("use_clipped_value_loss", C.c_int32),
@@ -71,7 +76,7 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 3          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 4          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
@@ -105,13 +110,14 @@ _SIGS = {
     "dtc_set_gemm_split": (None, [C.c_int]),
     "dtc_get_gemm_split": (C.c_int, []),
     "dtc_s3_planes_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "dtc_s3_wimage_group": (C.c_int, [C.POINTER(DtcWimgJob), C.c_int, c_stream]),
     "dtc_linear_fwd_s3": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                    C.c_int, C.c_int, c_stream]),
+                                    C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_linear_dgrad_s3": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_void_p, C.c_void_p,
-                                      C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_linear_fwd_mse_s3_parts": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_linear_fwd_mse_s3": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, c_i64p,
-                                        C.c_float, c_f32p, C.c_int64, c_f64p, C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
+                                        C.c_float, c_f32p, C.c_int64, c_f64p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_relu_mask_elems": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_linear_fwd_mask": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, c_stream]),
@@ -191,7 +197,7 @@ def _check_abi(l):
     """The loaded library must be the revision this binding describes: same ABI version, same by-value struct layouts
     (DTC_LIB may point at a separately built library, e.g. the ASan build: a stale one would misread every descriptor)."""
     global _lib
-    mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec]
+    mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob]
     sizes = (C.c_int64 * 16)()
     n = l.dtc_abi_sizes(sizes, 16)
     theirs = list(sizes[:n])

@@ -263,6 +263,9 @@ class PPO:
         self.overlap_lanes = os.environ.get("DTC_OVERLAP_LANES", "1") != "0"
         # weight gradients queued per gradient bucket and run as one grouped launch (DTC_WGRAD_GROUP=0: per layer)
         self.group_wgrad = os.environ.get("DTC_WGRAD_GROUP", "1") != "0"
+        # weight images of the split-path layers: built by ONE launch at the start of each optimisation step (ops.WeightImages)
+        self.group_wimages = os.environ.get("DTC_WIMG_GROUP", "1") != "0" and os.environ.get("DTC_S3_WIMG", "1") != "0"
+        self._wimages = {}
         # rollout step (policy sample + value + log-prob) replayed from a HIP graph: OFF by default -- measured slower
         # than the eager launches on ROCm 7.2 (793 k vs 829 k env-steps/s end to end, tools/soak.py); DTC_ROLLOUT_GRAPH=1
         self.graph_rollout = os.environ.get("DTC_ROLLOUT_GRAPH", "0") == "1"
@@ -501,6 +504,25 @@ class PPO:
         ac = self.actor_critic
         L = ac.L
         _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap_wgrad)))     # weight gradients on the side stream
+        with self._images("vae"):                                  # weight images of the step's split-path layers: one launch
+            early = self._vae_forward_backward(fw, tw, flat, idx, eps, stats)
+        if not early:
+            self._allreduce_grads(self.vae_optimizer)
+        if self.capture_grads:
+            self.captured["vae"] = ac.arena.grad.clone()
+        self.vae_optimizer.step(self.max_grad_norm, stats[S_VAE_GNORM:S_VAE_GNORM + 1])
+
+    def _images(self, phase):
+        """ops.WeightImages block of an optimisation step (DTC_WIMG_GROUP=0: every call builds its own image)."""
+        if not self.group_wimages:
+            return contextlib.nullcontext()
+        if phase not in self._wimages:
+            self._wimages[phase] = ops.WeightImages()
+        return self._wimages[phase]
+
+    def _vae_forward_backward(self, fw, tw, flat, idx, eps, stats):
+        ac = self.actor_critic
+        L = ac.L
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
         dec_in = segmat([seg(fw.z, 0, 16), seg(fw.mulv, 0, 3), seg(fw.lt, 0, 512)])
         rm = self.relu_masks
@@ -557,11 +579,7 @@ class PPO:
         if early:
             self._exchange_bucket(tw, "shared")
         self._join(tw)
-        if not early:
-            self._allreduce_grads(self.vae_optimizer)
-        if self.capture_grads:
-            self.captured["vae"] = ac.arena.grad.clone()
-        self.vae_optimizer.step(self.max_grad_norm, stats[S_VAE_GNORM:S_VAE_GNORM + 1])
+        return early
 
     def _ppo_step(self, fw, tw, flat, idx, eps, stats, cfg):
         """ppo.py:265-335: policy / value forward with the freshly updated VAE, PPO losses, backward,
@@ -570,6 +588,19 @@ class PPO:
         L = ac.L
         act = AC_Args.activation
         _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap_wgrad)))     # weight gradients on the side stream
+        with self._images("ppo"):
+            early = self._ppo_forward_backward(fw, tw, flat, idx, eps, stats, cfg)
+        if not early:
+            self._allreduce_grads(self.optimizer)
+        self._lr_from_header(stats)
+        if self.capture_grads:
+            self.captured["main"] = ac.arena.grad.clone()
+        self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])
+
+    def _ppo_forward_backward(self, fw, tw, flat, idx, eps, stats, cfg):
+        ac = self.actor_critic
+        L = ac.L
+        act = AC_Args.activation
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
         with tw.lane("aux"):
             ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=self.relu_masks)
@@ -629,12 +660,7 @@ class PPO:
         if early:
             self._exchange_bucket(tw, "shared")
         self._join(tw)
-        if not early:
-            self._allreduce_grads(self.optimizer)
-        self._lr_from_header(stats)
-        if self.capture_grads:
-            self.captured["main"] = ac.arena.grad.clone()
-        self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])
+        return early
 
     def _adaptive(self):
         return self.desired_kl is not None and self.schedule == 'adaptive'

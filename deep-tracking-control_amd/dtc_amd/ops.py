@@ -5,6 +5,8 @@ failure.  These are the building blocks used by storage/, modules/ and algorithm
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 from . import _ffi
@@ -99,11 +101,11 @@ def set_split(on: bool):
     lib().dtc_set_gemm_split(int(SPLIT))
 
 
-_PLANES = {}      # (device, stream, bytes) -> plane scratch of a split-path call (the pre-split weight)
+_PLANES = {}      # (device, stream, bytes) -> weight-image scratch of a split-path call
 
 
 def _planes(W, rows, cols):
-    """Scratch for the three bf16 planes of a [rows, cols] weight operand, one buffer per launch stream and size: calls on one
+    """Scratch for the weight image of a [rows, cols] operand, one buffer per launch stream and size: calls on one
     stream are ordered, so the next call may overwrite it; the compute lanes of the trainer have their own."""
     n = int(lib().dtc_s3_planes_bytes(rows, cols))
     key = (W.device, stream(), n)
@@ -111,6 +113,71 @@ def _planes(W, rows, cols):
     if buf is None:
         buf = _PLANES[key] = torch.empty((n + 7) // 8, dtype=torch.float64, device=W.device)
     return buf
+
+
+class WeightImages:
+    """Weight images (include/dtc_hip.h: DtcWimgJob) of all split-path layers of ONE trainer phase, built by one grouped launch
+    at the start of the phase instead of one small launch in front of every GEMM (~29 per mini-batch of PPO.update).
+
+        imgs = ops.WeightImages()
+        with imgs:                     # start of an optimisation step, BEFORE the lanes fork: builds every image recorded so far
+            ... forward / backward of the step (ops.linear_fwd / linear_dgrad / linear_fwd_mse) ...
+        # the optimiser step follows outside
+
+    The set is learnt: a split-path call inside the block that has no image yet gets a persistent buffer, builds its image
+    itself this time (wimage_ready = 0) and is part of the grouped launch from the next block on.  Contract: the weights must
+    not change between entering the block and the last call that uses them (the optimiser steps after the block; a caller that
+    overwrites weights -- a test loading the oracle's -- does so between blocks), and the streams the calls run on must be
+    ordered after the stream current at entry (the trainers fork their lanes after it and join them before the next block)."""
+
+    def __init__(self):
+        self.entries = {}          # key -> [image tensor, DtcWimgJob fields, built-in-this-block flag]
+        self.jobs = None           # ctypes array of all entries (rebuilt when the set grows)
+        self.keep = []
+        self.active = False
+
+    def __enter__(self):
+        global _IMAGES
+        self.prev, _IMAGES = _IMAGES, self
+        self.active = True
+        if self.entries and SPLIT:
+            if self.jobs is None or len(self.jobs) != len(self.entries):
+                self.jobs = (_ffi.DtcWimgJob * len(self.entries))()
+                for a, e in zip(self.jobs, self.entries.values()):
+                    a.W, a.img, a.seg, a.N, a.K, a.trans = e[1]
+            check(lib().dtc_s3_wimage_group(self.jobs, len(self.jobs), stream()), "dtc_s3_wimage_group")
+            for e in self.entries.values():
+                e[2] = True
+        return self
+
+    def __exit__(self, *exc):
+        global _IMAGES
+        _IMAGES = self.prev
+        self.active = False
+        for e in self.entries.values():
+            e[2] = False
+        return False
+
+    def lookup(self, W, segs, N, K, trans):
+        """-> (image buffer, ready) for the call (W, operand segments, orientation)."""
+        key = (W.data_ptr(), N, K, trans, tuple((segs.seg[i].width, bool(segs.seg[i].ptr)) for i in range(segs.nseg)))
+        e = self.entries.get(key)
+        if e is None:
+            n = int(lib().dtc_s3_planes_bytes(K, N) if trans else lib().dtc_s3_planes_bytes(N, K))
+            img = torch.empty((n + 7) // 8, dtype=torch.float64, device=W.device)
+            own = _ffi.DtcSegMat.from_buffer_copy(segs)           # the job keeps its own copy of the descriptor
+            self.keep.append((W, own))
+            e = self.entries[key] = [img, (cptr(W, f32), ptr(img), C.pointer(own), N, K, trans), False]
+        return e[0], int(e[2])
+
+
+_IMAGES = None       # the WeightImages block the current calls run in, if any
+
+
+def _wimage(W, segs, N, K, trans):
+    if _IMAGES is not None:
+        return _IMAGES.lookup(W, segs, N, K, trans)
+    return (_planes(W, K, N) if trans else _planes(W, N, K)), 0
 
 
 def relu_mask_ok(M, N):
@@ -136,8 +203,9 @@ def linear_fwd(X, W, b, Y, act=None, M=None, mask=None, split=None):
     N, K = W.shape
     M = Y.shape[0] if M is None else M
     if (SPLIT if split is None else split) and (split or (N >= SPLIT_MIN_COLS and K >= SPLIT_MIN_RED)) and (mask is None or N % 128 == 0):
+        img, ready = _wimage(W, Xs, N, K, 0)
         check(lib().dtc_linear_fwd_s3(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
-                                      ptr(mask) if mask is not None else None, ptr(_planes(W, N, K)), M, N, K, ACT[act], stream()),
+                                      ptr(mask) if mask is not None else None, ptr(img), ready, M, N, K, ACT[act], stream()),
               "dtc_linear_fwd_s3")
         return Y
     if mask is not None:
@@ -188,9 +256,10 @@ def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None
     N, K = W.shape
     M = dZ.shape[0] if M is None else M
     if (SPLIT if split is None else split) and (split or (K >= SPLIT_MIN_COLS and N >= SPLIT_MIN_RED)) and (mask is None or K % 128 == 0):
+        img, ready = _wimage(W, dXs, N, K, 1)
         check(lib().dtc_linear_dgrad_s3(ptr(dZ), dZ.stride(0), cptr(W, f32), dXs, ptr(Xsaved) if mask is None else None,
                                         Xsaved.stride(0) if Xsaved is not None else 0, ptr(mask) if mask is not None else None,
-                                        ptr(_planes(W, K, N)), M, N, K, ACT[act] if mask is None else ACT["relu"], stream()),
+                                        ptr(img), ready, M, N, K, ACT[act] if mask is None else ACT["relu"], stream()),
               "dtc_linear_dgrad_s3")
         return
     if mask is not None:
@@ -314,7 +383,8 @@ def linear_fwd_mse(X, W, b, target, tcol0, tidx, dY, sq_part, M=None, split=None
     args = (Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, cptr(target, f32), target.stride(0), target.shape[0], tcol0,
             cptr(tidx, torch.int64), 2.0 / (M * N), ptr(dY), dY.stride(0), ptr(sq_part))
     if s3:
-        check(lib().dtc_linear_fwd_mse_s3(*args, ptr(_planes(W, N, K)), M, N, K, stream()), "dtc_linear_fwd_mse_s3")
+        img, ready = _wimage(W, Xs, N, K, 0)
+        check(lib().dtc_linear_fwd_mse_s3(*args, ptr(img), ready, M, N, K, stream()), "dtc_linear_fwd_mse_s3")
     else:
         check(lib().dtc_linear_fwd_mse(*args, M, N, K, stream()), "dtc_linear_fwd_mse")
     return n_part

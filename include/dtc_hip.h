@@ -38,7 +38,7 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-#define DTC_ABI_VERSION 3                    /* bumped whenever a signature or a by-value struct layout changes       */
+#define DTC_ABI_VERSION 4                    /* bumped whenever a signature or a by-value struct layout changes       */
 int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
 /* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
    DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec: the binding compares them with its own layouts at load time (a library
@@ -216,26 +216,36 @@ int dtc_linear_dgrad_mask(const float* dZ, int64_t lddz, const float* W, const D
  * three bf16 terms (a = a1 + a2 + a3 exactly to 2^-24 |a|) and the six leading cross products accumulated in fp32 -- fp32-level
  * accuracy (tests/test_hip_split.py measures it against fp64 next to the single-pass kernels) at up to 2.67x the fp32 MFMA
  * rate; results are NOT bit-identical to the fmaf chain of dtc_linear_fwd.  Same argument meaning as dtc_linear_fwd /
- * dtc_linear_fwd_mask (relu_mask may be NULL) and dtc_linear_dgrad / dtc_linear_dgrad_mask.  The weight operand is
- * pre-split into its three bf16 planes by a small kernel inside the call (once per layer and optimiser step; the planes of
- * W^T for the data gradient): the GEMM's loaders do no conversion work for it. */
+ * dtc_linear_fwd_mask (relu_mask may be NULL) and dtc_linear_dgrad / dtc_linear_dgrad_mask. */
 /* Library-side switch for the entry points that have no `_s3` twin of their own: with it on, dtc_linear_wgrad (and through it
  * the W_hh / W_ih weight gradients inside dtc_gru_bwd / dtc_lstm_bwd) runs as a one-layer dtc_wgrad_group_s3, and
  * dtc_linear_wgrad_workspace / dtc_gru_workspace / dtc_lstm_workspace return sizes that fit either path.  Off by default;
  * dtc_amd/ops.py sets it from DTC_GEMM_SPLIT. */
 void dtc_set_gemm_split(int on);
 int dtc_get_gemm_split(void);
-int64_t dtc_s3_planes_bytes(int N, int K);   /* scratch for the pre-split weight of ONE call (`wplanes`, 16-byte aligned, private
-                                               * to the call until it has completed on its stream)                              */
+/* Weight image: the W operand of a split-path call as the kernel's LDS planes -- for every 128-column tile and 16-k stage one
+ * 12 KiB chunk [plane 3][row 128][16 k bf16], copied into LDS by LDS-DMA (no conversion work for W inside the K loop).  Built by
+ * the call itself into `wplanes` (wimage_ready = 0; scratch of dtc_s3_planes_bytes(N, K) bytes -- for the data gradient
+ * (K, N) --, 16-byte aligned, private to the call until it has completed on its stream), or beforehand for many calls at once
+ * by dtc_s3_wimage_group (wimage_ready = 1: `wplanes` is the image of exactly this call: same W, shape and operand segments). */
+int64_t dtc_s3_planes_bytes(int N, int K);
+typedef struct DtcWimgJob {
+    const float* W;              /* [N, K] as stored                                                                        */
+    void* img;                   /* dtc_s3_planes_bytes(N, K) (trans: (K, N)) bytes                                         */
+    const DtcSegMat* seg;        /* trans == 0: the X operand of the forward call; trans == 1: the dX destination          */
+    int32_t N, K, trans;
+} DtcWimgJob;
+int dtc_s3_wimage_group(const DtcWimgJob* jobs, int count, void* stream);
 int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
-                      void* wplanes, int M, int N, int K, int act, void* stream);
+                      void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream);
 int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved,
-                        int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int M, int N, int K, int act, void* stream);
+                        int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
+                        void* stream);
 /* dtc_linear_fwd_mse / dtc_linear_fwd_mse_parts on the split-precision path */
 int64_t dtc_linear_fwd_mse_s3_parts(int M, int N);
 int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
                           int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
-                          double* sq_part, void* wplanes, int M, int N, int K, void* stream);
+                          double* sq_part, void* wplanes, int wimage_ready, int M, int N, int K, void* stream);
 /* dtc_wgrad_group on the split-precision path (same jobs, same outputs; its own workspace size). */
 int64_t dtc_wgrad_group_s3_workspace(const struct DtcWgradJob* jobs, int count, int M);
 int dtc_wgrad_group_s3(const struct DtcWgradJob* jobs, int count, int M, void* workspace, void* stream);

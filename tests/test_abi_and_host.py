@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     # the struct layouts of the binding are the library's (checked at load time; here: the check itself works)
     sizes = (C.c_int64 * 16)()
     n = _ffi.lib().dtc_abi_sizes(sizes, 16)
-    assert n == 9 and sizes[3] == C.sizeof(_ffi.DtcSeg) and sizes[6] == C.sizeof(_ffi.DtcWgradJob)
+    assert n == 10 and sizes[3] == C.sizeof(_ffi.DtcSeg) and sizes[6] == C.sizeof(_ffi.DtcWgradJob) and sizes[9] == C.sizeof(_ffi.DtcWimgJob)
 
 
 def test_argument_validation_without_gpu():

@@ -198,6 +198,63 @@ def test_fused_mse_output_layer_split_vs_fp32():
     assert _err(outs[1][0], ref_dy.cpu()) <= 2.0 * _err(outs[0][0], ref_dy.cpu()) + 2e-7
 
 
+def test_grouped_weight_images_equal_per_call_images_bitwise():
+    """ops.WeightImages: the images of a block's layers built by ONE launch at its start (second block on) give the same bits as the
+    per-call images -- segmented / gathered forward operand with k tails, partly-NULL segmented gradient destination (column
+    skip), fused MSE output layer, more jobs than one grouped launch holds -- and follow the weights when they change between blocks."""
+    from dtc_amd import _ffi, ops
+    g = torch.Generator().manual_seed(11)
+    B, R = 640, 2000
+    obs, z, lt = torch.randn(R, 53, generator=g).to(DEV), torch.randn(B, 19, generator=g).to(DEV), torch.randn(B, 512, generator=g).to(DEV)
+    idx = torch.randint(0, R, (B,), generator=g).to(DEV)
+    Wa = (torch.randn(512, 584, generator=g) / 24.0).to(DEV)
+    ba = torch.randn(512, generator=g).to(DEV)
+    Ws = [(torch.randn(256, 512, generator=g) / 22.0).to(DEV) for _ in range(26)]           # > one launch's 24 jobs together with the rest
+    Wo = (torch.randn(693, 256, generator=g) / 16.0).to(DEV)
+    bo = torch.randn(693, generator=g).to(DEV)
+    tgt = torch.randn(R, 1389, generator=g).to(DEV)
+    dZ = torch.randn(B, 512, generator=g).to(DEV)
+
+    def run():
+        Xs = _ffi.segmat([_ffi.seg(obs, 0, 53, gather=True), _ffi.seg(z, 0, 19), _ffi.seg(lt, 0, 512)], idx)
+        Y = torch.empty(B, 512, device=DEV)
+        ops.linear_fwd(Xs, Wa, ba, Y, "elu", M=B, split=True)
+        hs = []
+        for W in Ws:
+            h = torch.empty(B, 256, device=DEV)
+            ops.linear_fwd(Y, W, None, h, "relu", split=True)
+            hs.append(h)
+        dY = torch.empty(B, 693, device=DEV)
+        part = torch.zeros(4096, dtype=torch.float64, device=DEV)
+        n = ops.linear_fwd_mse(hs[0], Wo, bo, tgt, 696, idx, dY, part, split=True)
+        dz, dlt = torch.zeros(B, 19, device=DEV), torch.ones(B, 512, device=DEV)
+        dst = _ffi.segmat([_ffi.seg(None, 0, 53), _ffi.seg(dz, 0, 19), _ffi.seg(dlt, 0, 512, accumulate=True)])
+        ops.linear_dgrad(dZ, Wa, dst, split=True)
+        dh = torch.empty(B, 512, device=DEV)
+        ops.linear_dgrad(hs[1], Ws[1], dh, Y, "elu", split=True)
+        return [Y, dY, part[:n].clone(), dz, dlt, dh] + hs
+
+    ref = run()
+    imgs = ops.WeightImages()
+    for block in range(3):
+        with imgs:
+            out = run()
+        assert len(imgs.entries) == 1 + 26 + 1 + 2
+        for a, b in zip(ref, out):
+            assert torch.equal(a, b), block
+    Wa.mul_(1.5)                                   # the optimiser's step between two blocks
+    Ws[1].add_(0.01)
+    ref2 = run()
+    assert not torch.equal(ref2[0], ref[0])
+    with imgs:
+        out2 = run()
+    for a, b in zip(ref2, out2):
+        assert torch.equal(a, b)
+    out3 = run()                                   # outside a block: per-call images again
+    for a, b in zip(ref2, out3):
+        assert torch.equal(a, b)
+
+
 def test_split_timing_report():
     """Not an assertion on speed: prints the per-launch time of both paths on the bench's 512-wide layer."""
     from dtc_amd import ops
