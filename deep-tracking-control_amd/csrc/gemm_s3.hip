@@ -278,6 +278,55 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) rb[i][e] = e <= klast ? rb[i][e] : 0.f;
+#ifdef DTC_S3_FINE
+        if constexpr (WIMG) {
+            // (opt-in, measured round 3: 76.0 -> 74.0 us on 24576 x 512 x 512 alone, but 65.4 vs 64.9 ms per step in the overlapped
+            // schedule, so off.)  Only the X side is converted: its seven dependency levels (both float4 of the thread side by
+            // side, 4 to 8 VALU each) go one per MFMA gap -- an MFMA occupies the pipe for 32 cycles = 8 issue slots, so a level
+            // issues under the MFMA in front of it instead of 28 VALU in a row pausing this wave's MFMA stream
+            float r[8];
+            u32 pk[3][4], u[8];
+            auto mm = [&](int m) {
+                const int t = m >> 1, i = m & 1;
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = ra[e >> 2][e & 3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pk[0][q] = cvt_pk_bf16(r[2 * q], r[2 * q + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1);
+#pragma unroll
+            for (int lv = 0; lv < 2; ++lv) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u[2 * q] = pk[lv][q] << 16;
+                    u[2 * q + 1] = pk[lv][q] & 0xffff0000u;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mm(2 + 3 * lv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] -= __uint_as_float(u[e]);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(3 + 3 * lv);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk[lv + 1][q] = cvt_pk_bf16(r[2 * q], r[2 * q + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(4 + 3 * lv);
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) As[buf ^ 1][p][aslot0 + 256 * i] = u32x2{pk[p][2 * i], pk[p][2 * i + 1]};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 8; m < 12; ++m) mm(m);
+            return;
+        }
+#endif
         constexpr int NQ = NA + NB, MQ = 12 / NQ;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
