@@ -26,7 +26,7 @@ PER_FILE = {"foothold.hip": ["-ffp-contract=off"], "gae.hip": ["-ffp-contract=of
             "optim.hip": ["-ffp-contract=off"], "envstep.hip": ["-ffp-contract=off"],      # Adam mirrors torch's separately rounded ops
             # split kernels: no SLP packing of the remainder subtractions into v_pk_add_f32 -- a packed fp32 op next to MFMAs
             # costs more than the two scalar ones it replaces (MI355X_MICROARCH.md, issue-slot table); 69.8 -> 68.1 ms per step
-            "gemm_s3.hip": ["-fno-slp-vectorize"], "wgrad_s3.hip": ["-fno-slp-vectorize"]}
+            "gemm_s3.hip": ["-fno-slp-vectorize"], "wgrad_s3.hip": ["-fno-slp-vectorize"], "gru_s3.hip": ["-fno-slp-vectorize"]}
 if os.environ.get("DTC_BK"):                       # tuning aid: K step of the GEMM kernels
     PER_FILE["gemm.hip"] = [f"-DDTC_BK={int(os.environ['DTC_BK'])}"]
 

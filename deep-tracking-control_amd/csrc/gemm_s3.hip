@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef DTC_S3_NO_ILV
     auto mfma_stage = [&](auto bc) {
         constexpr int buf = decltype(bc)::value;
         // fragments: A planes of both row tiles stay live (24 registers), B planes are read per column tile (12 registers)
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][j], 0, 0, 0);
         }
     };
+#endif
 
 #ifndef DTC_S3_NO_ILV
     // Fused stage (round 3: 77.8 -> 74.9 us on 24576 x 512 x 512, 71.3 -> 69.7 ms per step; -DDTC_S3_NO_ILV restores the two phases): the MFMAs of LDS[buf] with the conversion + LDS store of the loaded registers (-> LDS[buf ^ 1])
@@ -666,7 +668,7 @@ extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W
     DTC_REQUIRE(relu_mask || act == DTC_ACT_NONE || (Xsaved != nullptr && ldxs >= K), "activation derivative needs Xsaved");
     DTC_REQUIRE((act == DTC_ACT_NONE && !relu_mask) || (dX && dX->nseg == 1), "activation derivative needs a single-segment destination");
     DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * lddz <= MAX_ELEMS, "matrix too large");
-    DgradEpi dg;
+    DgradEpi dg{};
     int rc = to_dev(dX, dg.dX, K, true, 0);
     if (rc != DTC_OK) return rc;
     int col_skip;
@@ -777,3 +779,4 @@ extern "C" int dtc_s3_wimage_group(const DtcWimgJob* jobs, int count, void* stre
     flush();
     return dtc::check_launch("s3_wimage_group");
 }
+

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void gru_gate_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restrict__ dhs_t, float* __restrict__ dh,
                                                            const float* __restrict__ part, const float* __restrict__ gates,
                                                            const float* __restrict__ hn, const float* __restrict__ hprev,
-                                                           float* __restrict__ dgi, float* __restrict__ dgh, int R, int H) {
+                                                           float* __restrict__ dgi, float* __restrict__ dgh, int R, int H, int nparts) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long long)R * H) return;
     const long long row = e / H;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restri
     float d = dhs_t[e] + dh[e];
     if (part) {
         const long long rh = (long long)R * H;
-        d = ((d + part[e]) + part[rh + e]) + part[2 * rh + e];
+        for (int c = 0; c < nparts; ++c) d += part[c * rh + e];              // fixed order
     }
     const float ghn = hn[e];
     const float dn = d * (1.0f - z);
@@ -86,9 +86,12 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restri
 }
 
 // dh0 <- dh0 + the three chunks of the last W_hh product
-__global__ __launch_bounds__(256) void gru_add_parts_kernel(float* __restrict__ dh, const float* __restrict__ part, long long rh) {
+__global__ __launch_bounds__(256) void gru_add_parts_kernel(float* __restrict__ dh, const float* __restrict__ part, long long rh, int nparts) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < rh) dh[e] = ((dh[e] + part[e]) + part[rh + e]) + part[2 * rh + e];
+    if (e >= rh) return;
+    float d = dh[e];
+    for (int c = 0; c < nparts; ++c) d += part[c * rh + e];
+    dh[e] = d;
 }
 
 DtcSegMat plain(const float* p, int64_t ld, int cols, int64_t rows) {
@@ -102,12 +105,34 @@ DtcSegMat plain(const float* p, int64_t ld, int cols, int64_t rows) {
 
 }  // namespace
 
-// workspace layout: [ gh: R*3H floats | dgh_all: T*R*3H floats | wgrad partials ]
+// workspace layout: [ gh / the chunks of the W_hh data gradient: MAX_PARTS * R * H floats | dgh_all: T*R*3H floats | wgrad partials |
+// the image of W_hh^T (split-precision path) ]
+constexpr int MAX_PARTS = 6;
+namespace {
+// chunks of the 3H-long reduction of dh += dgh W_hh that run side by side: 3 on the single-pass path; the split path runs 128 x 128
+// tiles (4 column tiles for H = 512), so it takes 6 to put ~290 workgroups on the chip (DTC_GRU_S3_PARTS = 1, 2, 3 or 6)
+int gru_parts(int H, bool s3) {
+    if (!s3) return 3;
+    static const int env = getenv("DTC_GRU_S3_PARTS") ? atoi(getenv("DTC_GRU_S3_PARTS")) : 6;
+    const int p = (env == 1 || env == 2 || env == 3 || env == 6) ? env : 6;
+    return (3 * H / p) % 16 == 0 ? p : 3;
+}
+bool gru_s3(int H) {
+    static const bool on = !(getenv("DTC_S3_WIMG") && atoi(getenv("DTC_S3_WIMG")) == 0) && !(getenv("DTC_GRU_S3") && atoi(getenv("DTC_GRU_S3")) == 0);
+    return dtc_get_gemm_split() && on && H % 128 == 0;
+}
+void* gru_image_slot(void* workspace, int T, int R, int H) {
+    float* dgh_all = (float*)workspace + (size_t)MAX_PARTS * R * H;
+    void* wg_ws = (void*)(((uintptr_t)(dgh_all + (size_t)T * R * 3 * H) + 15) & ~(uintptr_t)15);
+    return (char*)wg_ws + ((dtc_linear_wgrad_workspace(T * R, 3 * H, H) + 15) & ~(int64_t)15);
+}
+}  // namespace
 extern "C" int64_t dtc_gru_workspace(int T, int R, int H) {
     if (T <= 0 || R <= 0 || H <= 0) return 0;
-    const int64_t a = (int64_t)R * 3 * H * sizeof(float);
+    const int64_t a = (int64_t)R * MAX_PARTS * H * sizeof(float);
     const int64_t b = (int64_t)T * R * 3 * H * sizeof(float);
-    return a + b + 16 + dtc_linear_wgrad_workspace(T * R, 3 * H, H);     // +16: the partials start 16-byte aligned
+    const int64_t img = dtc_s3_planes_bytes(H, 3 * H) > dtc_gru_s3_image_bytes(H) ? dtc_s3_planes_bytes(H, 3 * H) : dtc_gru_s3_image_bytes(H);
+    return a + b + 16 + ((dtc_linear_wgrad_workspace(T * R, 3 * H, H) + 15) & ~(int64_t)15) + img;     // +16: 16-byte alignment
 }
 
 extern "C" int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, const float* b_hh, float* hs_all,
@@ -123,8 +148,22 @@ extern "C" int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, 
     }
     static const bool unfused = getenv("DTC_GRU_UNFUSED") != nullptr;      // two-kernel step (GEMM + gate kernel)
     const unsigned grid = (unsigned)dtc::ceil_div((int64_t)RH, 256);
+    // split-precision steps (csrc/gru_s3.hip) for the passes of the update (T time steps share ONE image of W_hh); the one-step
+    // calls of the rollout keep the single-pass kernel
+    const bool s3 = !unfused && T >= 4 && gru_s3(H);
+    void* img = s3 ? gru_image_slot(workspace, T, R, H) : nullptr;
+    if (s3) {
+        int rc = dtc_gru_s3_image(W_hh, img, H, 0, stream);
+        if (rc != DTC_OK) return rc;
+    }
     for (int t = 0; t < T; ++t) {
         const float* hprev = hs_all + (size_t)t * RH;
+        if (s3) {
+            int rc = dtc_gru_step_fwd_s3(hprev, img, b_hh, gi + (size_t)t * R * 3 * H, hs_all + (size_t)(t + 1) * RH,
+                                         gates + (size_t)t * R * 3 * H, hn + (size_t)t * RH, R, H, stream);
+            if (rc != DTC_OK) return rc;
+            continue;
+        }
         if (!unfused && H % 32 == 0) {
             int rc = dtc_gru_step_fwd(hprev, W_hh, b_hh, gi + (size_t)t * R * 3 * H, hs_all + (size_t)(t + 1) * RH,
                                       gates + (size_t)t * R * 3 * H, hn + (size_t)t * RH, R, H, stream);
@@ -148,26 +187,35 @@ extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* g
     DTC_REQUIRE(dhs && hs_all && gates && hn && W_hh && dgi && dW_hh && db_hh && dh0 && workspace, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     const size_t RH = (size_t)R * H, R3H = (size_t)R * 3 * H;
-    float* dgh_all = (float*)workspace + R3H;
+    float* dgh_all = (float*)workspace + (size_t)MAX_PARTS * RH;
     void* wg_ws = (void*)(((uintptr_t)(dgh_all + (size_t)T * R3H) + 15) & ~(uintptr_t)15);
+    void* wimage = gru_image_slot(workspace, T, R, H);
+    const bool s3 = gru_s3(H);
+    const int nparts = gru_parts(H, s3);
+    if (s3) {
+        int rc = dtc_gru_s3_image(W_hh, wimage, H, 1, stream);
+        if (rc != DTC_OK) return rc;
+    }
     if (hipMemsetAsync(dh0, 0, RH * sizeof(float), s) != hipSuccess) {
         dtc::set_error("gru_bwd: memset failed");
         return DTC_ERR_LAUNCH;
     }
     const unsigned grid = (unsigned)dtc::ceil_div((int64_t)RH, 256);
-    float* part = (float*)workspace;              // [3][R][H]: the region dtc_gru_fwd uses for gh
+    float* part = (float*)workspace;              // [nparts][R][H]: the region dtc_gru_fwd uses for gh
     for (int t = T - 1; t >= 0; --t) {
         float* dgh_t = dgh_all + (size_t)t * R3H;
         {
             dtc::ProfScope prof("gru_gate_bwd", (double)RH * 4.0 * 17, s);
             hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(grid), dim3(256), 0, s, dhs + (size_t)t * RH, dh0,
                                t == T - 1 ? (const float*)nullptr : (const float*)part, gates + (size_t)t * R3H,
-                               hn + (size_t)t * RH, hs_all + (size_t)t * RH, dgi + (size_t)t * R3H, dgh_t, R, H);
+                               hn + (size_t)t * RH, hs_all + (size_t)t * RH, dgi + (size_t)t * R3H, dgh_t, R, H, nparts);
         }
-        int rc = dtc_linear_dgrad_split(dgh_t, 3 * H, W_hh, part, H, (int64_t)RH, R, 3 * H, H, 3, stream);
+        // split path: ONE image of W_hh^T serves all T steps
+        int rc = s3 ? dtc_gru_dgrad_parts_s3(dgh_t, wimage, part, (int64_t)RH, R, H, nparts, stream)
+                    : dtc_linear_dgrad_split(dgh_t, 3 * H, W_hh, part, H, (int64_t)RH, R, 3 * H, H, nparts, stream);
         if (rc != DTC_OK) return rc;
     }
-    hipLaunchKernelGGL(gru_add_parts_kernel, dim3(grid), dim3(256), 0, s, dh0, part, (long long)RH);
+    hipLaunchKernelGGL(gru_add_parts_kernel, dim3(grid), dim3(256), 0, s, dh0, part, (long long)RH, nparts);
     const DtcSegMat Hprev = plain(hs_all, H, H, (int64_t)T * R);
     int rc = dtc_linear_wgrad(dgh_all, 3 * H, &Hprev, dW_hh, db_hh, wg_ws, T * R, 3 * H, H, stream);
     if (rc != DTC_OK) return rc;

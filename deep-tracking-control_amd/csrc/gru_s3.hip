@@ -1,0 +1,315 @@
+// GRU recurrence on the split-precision path (gfx950): the two per-time-step products of torch.nn.GRU's BPTT
+// (rsl_rl/rsl_rl/modules/actor_critic_recurrent.py:92-116 under ppo.py:265-335) with every fp32 operand as three bf16 terms and six
+// v_mfma_f32_32x32x16_bf16 passes per product (csrc/gemm_s3.hip explains the arithmetic and its accuracy):
+//   forward  : gh = h_{t-1} W_hh^T for the three gates of 32 hidden units + the gate math in the epilogue (the split twin of
+//              gru_step_fwd_kernel in gemm.hip) -- block tile 128 rows x (3 gates x 32 units), wave = 32 rows x 96 columns;
+//   backward : the chunks of dh_{t-1} += dgh_t W_hh (the split twin of dtc_linear_dgrad_split) -- block tile 128 x 128, 2 x 2 waves.
+// One time step has R ~ 1500 rows: 12 row tiles, 150-300 workgroups, ONE workgroup per CU and one wave per SIMD -- nothing hides a
+// load behind another wave, and the general kernels of gemm_s3.hip (loads one stage ahead, built for three workgroups per CU) spend
+// most of such a launch waiting (29 us for the backward chunks).  These kernels are built for that regime instead:
+//   * W_hh comes as an LDS image (gemm_s3.hip: wimage) built ONCE per forward / backward pass and copied by LDS-DMA one stage ahead:
+//     it serves all T time steps, and it stays in L2;
+//   * the row operand (h_{t-1} resp. dgh_t, L2-resident: the previous kernel wrote it) is loaded TWO stages ahead into two register
+//     sets, converted one stage ahead (between the MFMAs of the stage in flight) -- registers are free at one wave per SIMD;
+//   * the K loop is unrolled by two, so stage buffers and register sets have constant indices.
+#include <type_traits>
+
+#include "s3_core.hpp"
+
+namespace {
+
+constexpr int MODE_FWD = 0, MODE_BWD = 1;
+template <int MODE>
+struct Geo {
+    static constexpr int WN = MODE == MODE_FWD ? 1 : 2;          // waves along the columns
+    static constexpr int WM = 4 / WN;
+    static constexpr int TM = BM / (32 * WM);                    // 32 x 32 tiles per wave
+    static constexpr int TN = MODE == MODE_FWD ? 3 : 2;
+    static constexpr int BN = 32 * TN * WN;                      // 96 / 128 columns per tile
+    static constexpr int PLANE = 128 * 32;                       // bytes of one plane of one stage: 128 rows in both images (the forward
+                                                                 // tile's last 32 are zero padding: every wave then issues three LDS-DMA
+                                                                 // pieces per stage, no per-wave branches in the K loop)
+    static constexpr int CHUNK = 3 * PLANE;                      // 12 KiB
+};
+
+struct GruS3Args {
+    const float* A;             // [R, lda]: h_{t-1} (forward) / dgh_t (backward)
+    long long lda;
+    const u32x4* img;           // image of W_hh (forward: gate-interleaved unit tiles) / W_hh^T (backward)
+    long long img_bytes;
+    int R, H;
+    int stages;                 // stages of one block's reduction (H / 16 forward; chunk / 16 backward)
+    int stages_tile;            // stages of a whole column tile in the image (backward: 3 H / 16)
+    // forward epilogue
+    const float* bhh;
+    const float* gi;
+    float* hout;
+    float* gates;
+    float* hn;
+    // backward epilogue: chunk c -> part + c * part_stride, [R, H]
+    float* part;
+    long long part_stride;
+};
+
+// forward image: tile tc = units [32 tc, 32 tc + 32), row n of the tile = gate n / 32 of unit 32 tc + n % 32, reduction = hidden
+// index; backward image: tile tc = output columns [128 tc, +128) of dh, row = column, reduction = the 3H gate index (W_hh^T)
+template <int MODE>
+__global__ __launch_bounds__(256) void gru_wimage_kernel(const float* __restrict__ Whh, u32x4* __restrict__ img, int H, int stages_tile) {
+    using G = Geo<MODE>;
+    const int tc = blockIdx.x / stages_tile, st = blockIdx.x - tc * stages_tile;
+    const int r = threadIdx.x >> 1, h = threadIdx.x & 1;
+    f32x4 v[2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = st * BK + 8 * h + e;
+        float x;
+        if (MODE == MODE_FWD) x = r < G::BN ? Whh[((long long)(r >> 5) * H + tc * 32 + (r & 31)) * H + k] : 0.f;
+        else x = Whh[(long long)k * H + tc * 128 + r];
+        v[e >> 2][e & 3] = x;
+    }
+    const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
+    u32x4* dst = img + (long long)blockIdx.x * (G::CHUNK / 16);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dst[p * (G::PLANE / 16) + rslot(r, h)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
+}
+
+__device__ __forceinline__ float sigmoid_s3(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gru_s3_kernel(const GruS3Args a) {
+    using G = Geo<MODE>;
+    constexpr int TM = G::TM, TN = G::TN, NA = 2, NM = 6 * TM * TN;
+    constexpr int PLANE = G::PLANE, CHUNK = G::CHUNK;        // local copies: the generic lambdas below must not odr-use the members
+    __shared__ __attribute__((aligned(16))) u32x2 As[2][3][BM * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Bs0[3][128 * 4];        // two objects: see linear_s3_kernel
+    __shared__ __attribute__((aligned(16))) u32x2 Bs1[3][128 * 4];
+#define GBS(b) ((b) ? Bs1 : Bs0)
+    int tr, tc;
+    const int col_tiles = MODE == MODE_FWD ? a.H / 32 : a.H / 128;
+    if (!map_tile(blockIdx.x, (a.R + BM - 1) / BM, col_tiles, tr, tc)) return;
+    const int chunk = MODE == MODE_BWD ? blockIdx.y : 0;
+    const int m0 = tr * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm_off = (wave / G::WN) * (32 * TM), wn_off = (wave % G::WN) * (32 * TN);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int lrow = tid >> 2, lch = tid & 3;
+    const int aslot0 = wslot(lrow, lch);
+
+    const rsrc_t ares = make_rsrc_bytes(a.A, (long long)a.R * a.lda * 4);
+    const rsrc_t ires = make_rsrc_bytes(a.img, a.img_bytes);
+    u32 aoff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + lrow + 64 * i;
+        aoff[i] = m < a.R ? (u32)((long long)m * a.lda + (long long)chunk * a.stages * BK + 4 * lch) * 4u : INVALID;
+    }
+    u32 ichunk = (u32)(tc * a.stages_tile + chunk * a.stages) * (u32)CHUNK;      // next stage's chunk of the image
+    u32 ka = 0;                                                                      // next stage's byte offset along the row operand
+
+    f32x4 ra[2][NA];
+    auto dma = [&](auto nbc) {                      // the image chunk of the next stage -> LDS
+        constexpr int nb = decltype(nbc)::value;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ires, (lds_void_t*)&GBS(nb)[p][wave_u * 128], 16, tid * 16, (int)(ichunk + p * PLANE), 0, 0);
+        ichunk += CHUNK;
+    };
+    auto load_a = [&](auto setc) {                  // rows of the stage after next -> register set (no wait)
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[S][i] = bload4(ares, aoff[i], ka);
+        ka += BK * 4;
+    };
+    auto conv = [&](auto setc, auto nbc, int i) {   // one float4 of register set S -> three planes -> LDS[nb]
+        constexpr int S = decltype(setc)::value, nb = decltype(nbc)::value;
+        const Split3 sp = split3(ra[S][i]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) As[nb][p][aslot0 + 256 * i] = sp.p[p];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // one stage: MFMAs of LDS[b]; the conversion of register set b ^ 1 (the NEXT stage, loaded one step earlier) -> LDS[b ^ 1] is
+    // placed after one third and two thirds of them
+    auto step = [&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        using NB = std::integral_constant<int, b ^ 1>;
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        dma(NB{});
+        load_a(bc);                                  // set b is free: its stage went into LDS[b] one step ago
+        bf16x8 af[TM][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&As[b][p][0])[rslot(wm_off + 32 * i + l31, half)]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bf16x8 bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                bf[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&GBS(b)[p][0])[rslot(wn_off + 32 * j + l31, half)]);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = (j * 6 + t) * TM + i;
+                    if (m == NM / 3 || m == 2 * NM / 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        conv(NB{}, NB{}, m == NM / 3 ? 0 : 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[PB[t]], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    };
+
+    // prologue: stage 0 -> LDS[0] (image by DMA, rows through set 0), stage 1's rows -> set 1
+    dma(S0{});
+    load_a(S0{});
+    load_a(S1{});
+    conv(S0{}, S0{}, 0);
+    conv(S0{}, S0{}, 1);
+    __syncthreads();
+    // past the last stage the loads fetch rows / chunks nobody consumes (the buffer descriptors bound them)
+    for (int s = 0; s < a.stages; s += 2) {
+        step(S0{});
+        step(S1{});
+    }
+
+    if constexpr (MODE == MODE_FWD) {
+        // gate math of torch.nn.GRU (gru_step_fwd_kernel): r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z),
+        // n = tanh(gi_n + r * gh_n), h_t = (1 - z) * n + z * h_{t-1}; every lane holds the three pre-activations of its (row, unit) pairs
+        const int H = a.H, R = a.R;
+        const int j = tc * 32 + l31;
+        const float br = a.bhh[j], bz = a.bhh[H + j], bn = a.bhh[2 * H + j];
+        const rsrc_t gres = make_rsrc_bytes(a.gi, (long long)R * 3 * H * 4), hres = make_rsrc_bytes(a.A, (long long)R * a.lda * 4);
+        const int row0 = m0 + wm_off + 4 * half;
+        float gr[16], gz[16], gn[16], hp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            const u32 go = (u32)((row0 + ro) * 3 * H + j) * 4u;
+            gr[r] = bload(gres, go, 0u);
+            gz[r] = bload(gres, go, (u32)H * 4u);
+            gn[r] = bload(gres, go, (u32)H * 8u);
+            hp[r] = bload(hres, (u32)((long long)(row0 + ro) * a.lda + j) * 4u, 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            const float rg = sigmoid_s3(gr[r] + (acc[0][0][r] + br));
+            const float zg = sigmoid_s3(gz[r] + (acc[0][1][r] + bz));
+            const float ghn = acc[0][2][r] + bn;
+            const float ng = tanhf(gn[r] + rg * ghn);
+            if (row < R) {
+                const long long e = (long long)row * H + j;
+                float* gp = a.gates + (long long)row * 3 * H + j;
+                a.hout[e] = (1.0f - zg) * ng + zg * hp[r];
+                gp[0] = rg;
+                gp[H] = zg;
+                gp[2 * H] = ng;
+                a.hn[e] = ghn;
+            }
+        }
+    } else {
+        float* P = a.part + (long long)chunk * a.part_stride;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = tc * 128 + wn_off + 32 * j + l31;
+                const int row0 = m0 + wm_off + 32 * i + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2);
+                    if (row < a.R) P[(long long)row * a.H + col] = acc[i][j][r];
+                }
+            }
+    }
+#undef GBS
+}
+
+bool shapes_ok(int R, int H) { return R > 0 && H >= 128 && H % 128 == 0 && (long long)R * 3 * H <= MAX_ELEMS && 3ll * H * H <= MAX_ELEMS; }
+
+}  // namespace
+
+// bytes of either image of W_hh [3H, H]
+extern "C" int64_t dtc_gru_s3_image_bytes(int H) {
+    if (H <= 0) return 0;
+    const int64_t fwd = (int64_t)Geo<MODE_FWD>::CHUNK * (H / 32) * (H / BK), bwd = (int64_t)Geo<MODE_BWD>::CHUNK * dtc::ceil_div(H, 128) * (3 * H / BK);
+    return (fwd > bwd ? fwd : bwd) + 64;
+}
+
+// image of W_hh for dtc_gru_step_fwd_s3 (backward = 0) / dtc_gru_dgrad_parts_s3 (backward = 1): once per pass over the T time steps
+extern "C" int dtc_gru_s3_image(const float* W_hh, void* img, int H, int backward, void* stream) {
+    DTC_REQUIRE(W_hh && img && dtc::aligned16(img) && shapes_ok(1, H), "bad arguments (H = %d must be a multiple of 128)", H);
+    hipStream_t s = (hipStream_t)stream;
+    if (backward) {
+        const int st = 3 * H / BK;
+        hipLaunchKernelGGL(gru_wimage_kernel<MODE_BWD>, dim3((unsigned)((H / 128) * st)), dim3(256), 0, s, W_hh, (u32x4*)img, H, st);
+    } else {
+        const int st = H / BK;
+        hipLaunchKernelGGL(gru_wimage_kernel<MODE_FWD>, dim3((unsigned)((H / 32) * st)), dim3(256), 0, s, W_hh, (u32x4*)img, H, st);
+    }
+    return dtc::check_launch("gru_s3_image");
+}
+
+// dtc_gru_step_fwd on the split-precision path; `img` = dtc_gru_s3_image(W_hh, backward = 0)
+extern "C" int dtc_gru_step_fwd_s3(const float* hprev, const void* img, const float* b_hh, const float* gi_t, float* hout, float* gates_t,
+                                   float* hn_t, int R, int H, void* stream) {
+    DTC_REQUIRE(shapes_ok(R, H), "bad shape R=%d H=%d (H must be a multiple of 128)", R, H);
+    DTC_REQUIRE(hprev && img && b_hh && gi_t && hout && gates_t && hn_t, "null pointer");
+    GruS3Args a{};
+    a.A = hprev;
+    a.lda = H;
+    a.img = (const u32x4*)img;
+    a.img_bytes = (long long)Geo<MODE_FWD>::CHUNK * (H / 32) * (H / BK);
+    a.R = R;
+    a.H = H;
+    a.stages = a.stages_tile = H / BK;
+    a.bhh = b_hh;
+    a.gi = gi_t;
+    a.hout = hout;
+    a.gates = gates_t;
+    a.hn = hn_t;
+    hipStream_t s = (hipStream_t)stream;
+    dtc::ProfScope prof(dtc::prof_shape_name("gru_step_fwd", R, 3 * H, H), 2.0 * R * 3.0 * H * H, s);
+    hipLaunchKernelGGL(gru_s3_kernel<MODE_FWD>, dim3((unsigned)grid_for((int)dtc::ceil_div(R, BM), H / 32)), dim3(256), 0, s, a);
+    return dtc::check_launch("gru_step_fwd_s3");
+}
+
+// the `nparts` chunks of dgh_t [R, 3H] W_hh [3H, H] side by side: chunk c -> part + c * part_stride ([R, H]); the caller adds
+// them in a fixed order; `img` = dtc_gru_s3_image(W_hh, backward = 1); (3H / nparts) must be a multiple of 32
+extern "C" int dtc_gru_dgrad_parts_s3(const float* dgh_t, const void* img, float* part, int64_t part_stride, int R, int H, int nparts,
+                                      void* stream) {
+    DTC_REQUIRE(shapes_ok(R, H) && nparts >= 1 && (3 * H) % nparts == 0 && (3 * H / nparts) % (2 * BK) == 0, "bad shape R=%d H=%d nparts=%d", R, H, nparts);
+    DTC_REQUIRE(dgh_t && img && part && part_stride >= (int64_t)R * H, "null pointer / overlapping chunks");
+    GruS3Args a{};
+    a.A = dgh_t;
+    a.lda = 3 * H;
+    a.img = (const u32x4*)img;
+    a.img_bytes = (long long)Geo<MODE_BWD>::CHUNK * (H / 128) * (3 * H / BK);
+    a.R = R;
+    a.H = H;
+    a.stages = 3 * H / nparts / BK;
+    a.stages_tile = 3 * H / BK;
+    a.part = part;
+    a.part_stride = part_stride;
+    hipStream_t s = (hipStream_t)stream;
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", R, 3 * H, H), 2.0 * R * 3.0 * H * H, s,
+                        4.0 * ((double)R * 3 * H + 3.0 * H * H + (double)nparts * R * H));
+    const dim3 grid((unsigned)grid_for((int)dtc::ceil_div(R, BM), H / 128), (unsigned)nparts);
+    hipLaunchKernelGGL(gru_s3_kernel<MODE_BWD>, grid, dim3(256), 0, s, a);
+    return dtc::check_launch("gru_dgrad_parts_s3");
+}

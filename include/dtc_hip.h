@@ -246,6 +246,17 @@ int64_t dtc_linear_fwd_mse_s3_parts(int M, int N);
 int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
                           int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
                           double* sq_part, void* wplanes, int wimage_ready, int M, int N, int K, void* stream);
+/* GRU recurrence on the split-precision path (csrc/gru_s3.hip; H a multiple of 128): the per-time-step products with W_hh as an
+ * LDS image built once per pass (dtc_gru_s3_image: backward = 0 for the forward steps, 1 for the data-gradient chunks), row
+ * operands loaded two stages ahead -- kernels for the ~1500-row, one-workgroup-per-CU launches of one time step.  dtc_gru_fwd /
+ * dtc_gru_bwd use them for T >= 4 when dtc_get_gemm_split() is on (DTC_GRU_S3=0: single-pass kernels). */
+int64_t dtc_gru_s3_image_bytes(int H);
+int dtc_gru_s3_image(const float* W_hh, void* img, int H, int backward, void* stream);
+int dtc_gru_step_fwd_s3(const float* hprev, const void* img, const float* b_hh, const float* gi_t, float* hout, float* gates_t,
+                        float* hn_t, int R, int H, void* stream);
+/* chunk c of dgh_t [R, 3H] W_hh [3H, H] -> part + c * part_stride ([R, H]); (3H / nparts) a multiple of 32 */
+int dtc_gru_dgrad_parts_s3(const float* dgh_t, const void* img, float* part, int64_t part_stride, int R, int H, int nparts,
+                           void* stream);
 /* dtc_wgrad_group on the split-precision path (same jobs, same outputs; its own workspace size). */
 int64_t dtc_wgrad_group_s3_workspace(const struct DtcWgradJob* jobs, int count, int M);
 int dtc_wgrad_group_s3(const struct DtcWgradJob* jobs, int count, int M, void* workspace, void* stream);

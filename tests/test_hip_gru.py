@@ -53,3 +53,56 @@ def test_gru_forward_backward_vs_torch(T, R, I, H):
     close(db_ih, rnn.bias_ih_l0.grad, "db_ih")
     close(dh0, h0.grad[0], "dh0")
     close(dx.view(T, R, I), x.grad, "dx")
+
+
+@pytest.mark.parametrize("R", [13, 1473])
+def test_split_precision_step_kernels_vs_fp64(R):
+    """csrc/gru_s3.hip through its own entry points: the fused forward step and the data-gradient chunks on the bf16 x 3 path
+    against fp64, next to the single-pass fp32 kernels on the same inputs (same error level required)."""
+    from dtc_amd import _ffi, ops
+    lib = _ffi.lib()
+    H = 512
+    g = torch.Generator().manual_seed(R)
+    W = (torch.randn(3 * H, H, generator=g) / H ** 0.5).to(DEV)
+    b = torch.randn(3 * H, generator=g).to(DEV)
+    hp = torch.randn(R, H, generator=g).to(DEV)
+    gi = torch.randn(R, 3 * H, generator=g).to(DEV)
+    img = torch.empty(int(lib.dtc_gru_s3_image_bytes(H)) // 8 + 1, dtype=torch.float64, device=DEV)
+    outs = []
+    for s3 in (False, True):
+        h, gates, hn = (torch.full((R, H), float("nan"), device=DEV), torch.full((R, 3 * H), float("nan"), device=DEV),
+                        torch.full((R, H), float("nan"), device=DEV))
+        if s3:
+            _ffi.check(lib.dtc_gru_s3_image(_ffi.cptr(W, torch.float32), _ffi.ptr(img), H, 0, _ffi.stream()), "image")
+            _ffi.check(lib.dtc_gru_step_fwd_s3(_ffi.cptr(hp, torch.float32), _ffi.ptr(img), _ffi.cptr(b, torch.float32),
+                                               _ffi.cptr(gi, torch.float32), _ffi.ptr(h), _ffi.ptr(gates), _ffi.ptr(hn), R, H,
+                                               _ffi.stream()), "step")
+        else:
+            _ffi.check(lib.dtc_gru_step_fwd(_ffi.cptr(hp, torch.float32), _ffi.cptr(W, torch.float32), _ffi.cptr(b, torch.float32),
+                                            _ffi.cptr(gi, torch.float32), _ffi.ptr(h), _ffi.ptr(gates), _ffi.ptr(hn), R, H,
+                                            _ffi.stream()), "step")
+        outs.append((h, gates, hn))
+    gh = hp.double() @ W.double().T + b.double()
+    r, z = torch.sigmoid(gi[:, :H].double() + gh[:, :H]), torch.sigmoid(gi[:, H:2 * H].double() + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:].double() + r * gh[:, 2 * H:])
+    ref = ((1 - z) * n + z * hp.double(), torch.cat([r, z, n], 1), gh[:, 2 * H:])
+    for k in range(3):
+        e32 = float((outs[0][k].double() - ref[k]).abs().max())
+        es3 = float((outs[1][k].double() - ref[k]).abs().max())
+        print(f"gru step R={R} output {k}: fp32 MFMA err {e32:.2e}, split err {es3:.2e}")
+        assert es3 <= 2.0 * e32 + 1e-6, (k, e32, es3)
+    # data-gradient chunks: sum of the chunks == dgh W_hh
+    dgh = torch.randn(R, 3 * H, generator=g).to(DEV)
+    ref = dgh.double() @ W.double()
+    _ffi.check(lib.dtc_gru_s3_image(_ffi.cptr(W, torch.float32), _ffi.ptr(img), H, 1, _ffi.stream()), "image")
+    for nparts in (1, 3, 6):
+        part = torch.full((nparts, R, H), float("nan"), device=DEV)
+        _ffi.check(lib.dtc_gru_dgrad_parts_s3(_ffi.cptr(dgh, torch.float32), _ffi.ptr(img), _ffi.ptr(part), R * H, R, H, nparts,
+                                              _ffi.stream()), "parts")
+        p32 = torch.full((3, R, H), float("nan"), device=DEV)
+        _ffi.check(lib.dtc_linear_dgrad_split(_ffi.cptr(dgh, torch.float32), 3 * H, _ffi.cptr(W, torch.float32), _ffi.ptr(p32), H, R * H,
+                                              R, 3 * H, H, 3, _ffi.stream()), "split")
+        es3 = float((part.double().sum(0) - ref).abs().max() / ref.abs().max())
+        e32 = float((p32.double().sum(0) - ref).abs().max() / ref.abs().max())
+        print(f"gru dgrad chunks R={R} nparts={nparts}: fp32 MFMA err {e32:.2e}, split err {es3:.2e}")
+        assert es3 <= 2.0 * e32 + 2e-7, (nparts, e32, es3)
