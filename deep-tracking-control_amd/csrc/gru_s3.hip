@@ -81,6 +81,7 @@ template <int MODE>
 __global__ __launch_bounds__(256, 2) void gru_s3_kernel(const GruS3Args a) {
     using G = Geo<MODE>;
     constexpr int TM = G::TM, TN = G::TN, NA = 2, NM = 6 * TM * TN;
+    constexpr int GAP0 = 4;                                   // the conversion levels follow MFMAs GAP0 .. GAP0 + 7 of a stage
     constexpr int PLANE = G::PLANE, CHUNK = G::CHUNK;        // local copies: the generic lambdas below must not odr-use the members
     __shared__ __attribute__((aligned(16))) u32x2 As[2][3][BM * 4];
     __shared__ __attribute__((aligned(16))) u32x2 Bs0[3][128 * 4];        // two objects: see linear_s3_kernel
@@ -138,39 +139,71 @@ __global__ __launch_bounds__(256, 2) void gru_s3_kernel(const GruS3Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // one stage: MFMAs of LDS[b]; the conversion of register set b ^ 1 (the NEXT stage, loaded one step earlier) -> LDS[b ^ 1] is
-    // placed after one third and two thirds of them
+    // one stage: MFMAs of LDS[b]; the conversion of register set b ^ 1 (the NEXT stage, loaded one step earlier) -> LDS[b ^ 1] runs
+    // one dependency level per MFMA gap (both float4 of the thread side by side, 4 to 8 VALU per level: an MFMA holds the pipe for 32
+    // cycles = 8 issue slots, and with ONE wave per SIMD nothing else would fill them; a 28-instruction block between two MFMAs
+    // idles the pipe instead); all fragments are requested at the top of the stage (one exposed LDS latency, not one per column tile)
     auto step = [&](auto bc) {
         constexpr int b = decltype(bc)::value;
-        using NB = std::integral_constant<int, b ^ 1>;
+        constexpr int nb = b ^ 1;
+        using NB = std::integral_constant<int, nb>;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
         dma(NB{});
         load_a(bc);                                  // set b is free: its stage went into LDS[b] one step ago
-        bf16x8 af[TM][3];
+        bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 af[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&As[b][p][0])[rslot(wm_off + 32 * i + l31, half)]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            bf16x8 bf[3];
+        for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                bf[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&GBS(b)[p][0])[rslot(wn_off + 32 * j + l31, half)]);
+                bf[jj][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&GBS(b)[p][0])[rslot(wn_off + 32 * jj + l31, half)]);
+        float r[8];
+        u32 pk[3][4], u[8];
+        auto level = [&](int l) {                    // l is a constant after unrolling
+            if (l == 0) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+                for (int e = 0; e < 8; ++e) r[e] = ra[nb][e >> 2][e & 3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk[0][q] = cvt_pk_bf16(r[2 * q], r[2 * q + 1]);
+            } else if (l == 1 || l == 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u[2 * q] = pk[l / 3][q] << 16;
+                    u[2 * q + 1] = pk[l / 3][q] & 0xffff0000u;
+                }
+            } else if (l == 2 || l == 5) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] -= __uint_as_float(u[e]);
+            } else if (l == 3 || l == 6) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk[l / 3][q] = cvt_pk_bf16(r[2 * q], r[2 * q + 1]);
+            } else if (l == 7) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) As[nb][p][aslot0 + 256 * i] = u32x2{pk[p][2 * i], pk[p][2 * i + 1]};
+            }
+        };
+        // term t of all the wave's tiles in turn: consecutive MFMAs never share an accumulator (a filler between two MFMAs on the
+        // SAME accumulator costs ~40 cycles, MI355X_MICROARCH.md)
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const int m = (j * 6 + t) * TM + i;
-                    if (m == NM / 3 || m == 2 * NM / 3) {
+                    const int m = (t * TN + jj) * TM + i;
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[jj][PB[t]], acc[i][jj], 0, 0, 0);
+                    if (m >= GAP0 && m < GAP0 + 8) {
                         __builtin_amdgcn_sched_barrier(0);
-                        conv(NB{}, NB{}, m == NM / 3 ? 0 : 1);
+                        level(m - GAP0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[PB[t]], acc[i][j], 0, 0, 0);
                 }
-        }
         __syncthreads();
     };
 
