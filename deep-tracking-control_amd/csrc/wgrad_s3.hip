@@ -15,6 +15,8 @@
 // Tiles: 128 (n) x 128 (c, inside ONE segment of X), 2 x 2 waves of 64 x 64, stage = 16 batch rows, double-buffered LDS
 // (48 KiB); grouped launch over all layers of a gradient bucket and 8 k batch slices (slice s runs on XCD s % 8), as
 // csrc/wgrad.hip does for the single-pass kernels.
+#include <type_traits>
+
 #include "s3_core.hpp"
 
 namespace {
@@ -115,7 +117,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
             rows_of(mb + BK);
         }
     };
-    auto store_stage = [&](int buf) {
+    // BIAS (workgroup-uniform): the first column tile of a layer also sums dZ's columns (12 of the ~100 VALU of a stage that the
+    // other tiles, and the X side everywhere, do not need to issue)
+    auto store_stage = [&](int buf, auto bias) {
         u32x2(*dst)[TILE * 4] = is_a ? As[buf] : Bs[buf];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
             const Split3 s = split3(col);
 #pragma unroll
             for (int p = 0; p < 3; ++p) dst[p][slot[e]] = s.p[p];
-            bsum[e] += (col[0] + col[1]) + (col[2] + col[3]);
+            if constexpr (decltype(bias)::value) bsum[e] += (col[0] + col[1]) + (col[2] + col[3]);
         }
     };
 
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
 
     // fused stage: the MFMAs of LDS[buf] with the conversion + LDS store of the loaded block (-> LDS[buf ^ 1]) placed between the
     // MFMAs of the second column tile, one column of the block per three MFMAs (see linear_s3_kernel)
-    auto stage_ilv = [&](int buf) {
+    auto stage_ilv = [&](int buf, auto bias) {
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
         bf16x8 a[2][3], b[3];
 #pragma unroll
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
             const Split3 sp = split3(col);
 #pragma unroll
             for (int p = 0; p < 3; ++p) dst[p][slot[e]] = sp.p[p];
-            bsum[e] += (col[0] + col[1]) + (col[2] + col[3]);
+            if constexpr (decltype(bias)::value) bsum[e] += (col[0] + col[1]) + (col[2] + col[3]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t3 = 0; t3 < 3; ++t3) {
@@ -190,23 +194,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
     };
 
     const int KT = (m_end - m_begin + BK - 1) / BK;
-    if (KT > 0) {
+    auto k_loop = [&](auto bias) {
         int buf = 0;
         load_stage(m_begin);
-        store_stage(0);
+        store_stage(0, bias);
         __syncthreads();
         for (int kt = 1; kt < KT; ++kt) {
             load_stage(m_begin + kt * BK);
 #ifndef DTC_S3_NO_ILV
-            stage_ilv(buf);
+            stage_ilv(buf, bias);
 #else
             mfma_stage(buf);
-            store_stage(buf ^ 1);
+            store_stage(buf ^ 1, bias);
 #endif
             __syncthreads();
             buf ^= 1;
         }
         mfma_stage(buf);
+    };
+    const bool need_bias = seg == 0 && tc == 0;
+    if (KT > 0) {
+        if (need_bias) k_loop(std::true_type{});
+        else k_loop(std::false_type{});
     }
 
     // ---- epilogue: the accumulators in physical order -> slab tile [128][128] (float4 rows through the wave's LDS patch)
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
             for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(q + (long long)(8 * p) * TILE) = patch_get(patch, prow + 8 * p, pc4);
         }
     // bias-gradient partial (first column tile of the layer only): thread (g, lch) summed columns 4 g + e over its batch rows
-    if (seg == 0 && tc == 0) {
+    if (need_bias) {
         float* red = reinterpret_cast<float*>(&Bs[0][0][0]);          // [4][128], disjoint from the patches in As
         if (is_a) {
 #pragma unroll
