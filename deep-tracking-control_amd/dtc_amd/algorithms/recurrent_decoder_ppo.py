@@ -84,6 +84,16 @@ class RecurrentDecoderPPO(PPO):
         return t
 
     def _ppo_step_recurrent(self, fw, tw, flat, bt, eps, stats, cfg):
+        with self._images("ppo_recurrent"):                        # weight images of the step's split-path layers: one launch
+            early = self._ppo_recurrent_forward_backward(fw, tw, flat, bt, eps, stats, cfg)
+        if not early:
+            self._allreduce_grads(self.optimizer)
+        self._lr_from_header(stats)
+        if self.capture_grads:
+            self.captured["main"] = self.actor_critic.arena.grad.clone()
+        self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])
+
+    def _ppo_recurrent_forward_backward(self, fw, tw, flat, bt, eps, stats, cfg):
         ac = self.actor_critic
         H, M = ac.rnn_hidden_size, tw.B
         idx, unpad_idx, T, R = bt["idx"], bt["unpad_idx"], bt["T"], bt["R"]
@@ -164,12 +174,7 @@ class RecurrentDecoderPPO(PPO):
         if early:
             self._exchange_bucket(tw, "shared")
         self._join(tw)
-        if not early:
-            self._allreduce_grads(self.optimizer)
-        self._lr_from_header(stats)
-        if self.capture_grads:
-            self.captured["main"] = ac.arena.grad.clone()
-        self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])
+        return early
 
     def step_minibatch(self, bt, eps1, eps2, which="both", stats=None):
         """One recurrent mini-batch `bt` (an item of `recurrent_slices`): VAE step, policy step, or both."""
