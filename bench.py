@@ -311,20 +311,21 @@ def main():
         lib.dtc_prof_reset()
         # the GEMM family = forward / data-gradient / weight-gradient kernels AND the split-reduce kernels the weight
         # gradients need (their time counts against the family's FLOP; they add no FLOP of their own)
-        fam = ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_reduce", "gru_step_fwd")
+        fam = ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_reduce", "gru_step_fwd", "wimage")
         gemm = [r for r in rep if r["name"].split("[")[0] in fam]
         # (the composite's GRU steps call the same three kernels from inside dtc_gru_fwd / dtc_gru_bwd)
         ms = sum(r["ms_total"] for r in gemm)
-        fl = sum(r["work"] for r in gemm if not r["name"].startswith("wgrad_reduce"))
+        fl = sum(r["work"] for r in gemm if not r["name"].startswith(("wgrad_reduce", "wimage")))
         n_launch = sum(r["launches"] for r in gemm)
         algo_bytes = sum(r["bytes"] for r in gemm)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         split = ops.SPLIT
         peak = PEAK_SPLIT_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
         roof = dict(bound="mfma",
-                    kernel=("linear_s3_kernel, wgrad_s3_group_kernel (+ its reduce kernel): split-precision GEMM family -- every fp32 operand as "
-                            "three bf16 terms, six v_mfma_f32_32x32x16_bf16 passes per product, fp32 accumulate (csrc/gemm_s3.hip); the narrow "
-                            "layers (< 256 columns) stay on the single-pass v_mfma_f32_32x32x2_f32 kernels and are part of the family") if split else
+                    kernel=("linear_s3_kernel (+ the weight-image launches), wgrad_s3_group_kernel (+ its reduce kernel), gru_s3_kernel: "
+                            "split-precision GEMM family -- every fp32 operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 passes per "
+                            "product, fp32 accumulate (csrc/gemm_s3.hip, wgrad_s3.hip, gru_s3.hip); the narrow layers (< 128 columns) stay on "
+                            "the single-pass v_mfma_f32_32x32x2_f32 kernels and are part of the family") if split else
                            "linear_{fwd,dgrad}_kernel, wgrad_group_kernel (+ its split-reduce kernel): fp32 v_mfma_f32_32x32x2_f32 GEMM family",
                     achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
                     peak_definition=("dense bf16 MFMA peak 2516.6 TFLOP/s / 6 passes = 419.4 TFLOP/s of fp32-equivalent work "
@@ -333,7 +334,7 @@ def main():
                     frac_of_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS,
                     traffic=None, traffic_algorithmic=algo_bytes / max(1, n_launch), launches=n_launch,
                     measured="HIP events per launch, kernels serialised on one stream; the split-reduce launches of the weight "
-                             "gradients are part of the family (time, no FLOP)",
+                             "gradients and the weight-image launches are part of the family (time, no FLOP)",
                     avg_launch_us=ms * 1e3 / max(1, n_launch), flop_per_launch=fl / max(1, n_launch),
                     reduce_ms=sum(r["ms_total"] for r in gemm if r["name"].startswith("wgrad_reduce")))
         if world == 1 and not a.no_traffic:

@@ -747,6 +747,9 @@ extern "C" int dtc_s3_wimage_group(const DtcWimgJob* jobs, int count, void* stre
     DTC_REQUIRE(jobs && count > 0, "no jobs");
     DTC_REQUIRE(wimage_on(), "weight images are switched off (DTC_S3_WIMG=0)");
     hipStream_t s = (hipStream_t)stream;
+    double elems = 0.0;
+    for (int i = 0; i < count; ++i) elems += (double)jobs[i].N * jobs[i].K;
+    dtc::ProfScope prof("wimage", 0.0, s, 10.0 * elems);                 // 4 bytes read, 6 written per weight
     WimgGroup G;
     G.count = 0;
     auto flush = [&]() {

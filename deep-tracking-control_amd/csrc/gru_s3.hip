@@ -288,6 +288,7 @@ extern "C" int64_t dtc_gru_s3_image_bytes(int H) {
 extern "C" int dtc_gru_s3_image(const float* W_hh, void* img, int H, int backward, void* stream) {
     DTC_REQUIRE(W_hh && img && dtc::aligned16(img) && shapes_ok(1, H), "bad arguments (H = %d must be a multiple of 128)", H);
     hipStream_t s = (hipStream_t)stream;
+    dtc::ProfScope prof("wimage", 0.0, s, 30.0 * H * (double)H);
     if (backward) {
         const int st = 3 * H / BK;
         hipLaunchKernelGGL(gru_wimage_kernel<MODE_BWD>, dim3((unsigned)((H / 128) * st)), dim3(256), 0, s, W_hh, (u32x4*)img, H, st);
