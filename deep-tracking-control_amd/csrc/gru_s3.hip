@@ -84,9 +84,13 @@ __global__ __launch_bounds__(256, 2) void gru_s3_kernel(const GruS3Args a) {
     constexpr int GAP0 = 4;                                   // the conversion levels follow MFMAs GAP0 .. GAP0 + 7 of a stage
     constexpr int PLANE = G::PLANE, CHUNK = G::CHUNK;        // local copies: the generic lambdas below must not odr-use the members
     __shared__ __attribute__((aligned(16))) u32x2 As[2][3][BM * 4];
-    __shared__ __attribute__((aligned(16))) u32x2 Bs0[3][128 * 4];        // two objects: see linear_s3_kernel
+    // image ring: four stage buffers as SEPARATE objects (the compiler then knows that the LDS-DMA into one cannot alias the fragment
+    // reads of another, see linear_s3_kernel)
+    __shared__ __attribute__((aligned(16))) u32x2 Bs0[3][128 * 4];
     __shared__ __attribute__((aligned(16))) u32x2 Bs1[3][128 * 4];
-#define GBS(b) ((b) ? Bs1 : Bs0)
+    __shared__ __attribute__((aligned(16))) u32x2 Bs2[3][128 * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Bs3[3][128 * 4];
+#define GBS(b) ((b) == 0 ? Bs0 : (b) == 1 ? Bs1 : (b) == 2 ? Bs2 : Bs3)
     int tr, tc;
     const int col_tiles = MODE == MODE_FWD ? a.H / 32 : a.H / 128;
     if (!map_tile(blockIdx.x, (a.R + BM - 1) / BM, col_tiles, tr, tc)) return;
@@ -110,7 +114,12 @@ __global__ __launch_bounds__(256, 2) void gru_s3_kernel(const GruS3Args a) {
     u32 ichunk = (u32)(tc * a.stages_tile + chunk * a.stages) * (u32)CHUNK;      // next stage's chunk of the image
     u32 ka = 0;                                                                      // next stage's byte offset along the row operand
 
-    f32x4 ra[2][NA];
+    // Both operands run D - 1 = 3 stages ahead of the MFMAs: vmcnt counts in order, so a stage-ahead DMA that is waited for at every
+    // barrier would drag every older row load with it -- the image chunks and the row loads have to be equally deep.  The rows of
+    // a time step were written by the previous kernel (another XCD's L2 or HBM: ~1-2 us away), and with two stages in flight a
+    // 16-stage launch spent 1.2 us per stage waiting for them.
+    constexpr int D = 4;                            // register sets of the row operand = stage buffers of the image
+    f32x4 ra[D][NA];
     auto dma = [&](auto nbc) {                      // the image chunk of the next stage -> LDS
         constexpr int nb = decltype(nbc)::value;
 #pragma unroll
@@ -143,13 +152,15 @@ __global__ __launch_bounds__(256, 2) void gru_s3_kernel(const GruS3Args a) {
     // one dependency level per MFMA gap (both float4 of the thread side by side, 4 to 8 VALU per level: an MFMA holds the pipe for 32
     // cycles = 8 issue slots, and with ONE wave per SIMD nothing else would fill them; a 28-instruction block between two MFMAs
     // idles the pipe instead); all fragments are requested at the top of the stage (one exposed LDS latency, not one per column tile)
-    auto step = [&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        constexpr int nb = b ^ 1;
-        using NB = std::integral_constant<int, nb>;
+    auto step = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;       // stage index modulo D: LDS buffer k & 1; register set k is free (its stage went
+                                                     // into LDS one step ago), set (k + 1) % D holds the NEXT stage
+        constexpr int b = k & 1, nb = b ^ 1, cs = (k + 1) % D;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-        dma(NB{});
-        load_a(bc);                                  // set b is free: its stage went into LDS[b] one step ago
+        dma(std::integral_constant<int, (k + D - 1) % D>{});       // stage s + D - 1 -> the ring slot stage s - 1 was read from
+        __builtin_amdgcn_sched_barrier(0);                         // (issue order is part of the vmcnt arithmetic below)
+        load_a(kc);                                                // stage s + D -> set k
+        __builtin_amdgcn_sched_barrier(0);
         bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -160,13 +171,13 @@ __global__ __launch_bounds__(256, 2) void gru_s3_kernel(const GruS3Args a) {
         for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                bf[jj][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&GBS(b)[p][0])[rslot(wn_off + 32 * jj + l31, half)]);
+                bf[jj][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&GBS(k)[p][0])[rslot(wn_off + 32 * jj + l31, half)]);
         float r[8];
         u32 pk[3][4], u[8];
         auto level = [&](int l) {                    // l is a constant after unrolling
             if (l == 0) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) r[e] = ra[nb][e >> 2][e & 3];
+                for (int e = 0; e < 8; ++e) r[e] = ra[cs][e >> 2][e & 3];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pk[0][q] = cvt_pk_bf16(r[2 * q], r[2 * q + 1]);
             } else if (l == 1 || l == 4) {
@@ -204,21 +215,37 @@ __global__ __launch_bounds__(256, 2) void gru_s3_kernel(const GruS3Args a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-        __syncthreads();
+        // End of the stage: this wave's plane stores and ITS pieces of the NEXT stage's image chunk must have landed before anybody
+        // reads them.  __syncthreads() would wait for every DMA in flight (its release fence covers all LDS writes: vmcnt(2)), i.e.
+        // for the chunk issued a moment ago as well; the chunk of stage s + 1 was issued two steps back, and exactly 12 vector-memory
+        // operations of this wave follow it (2 + 3 + 2 + 3 + 2, the order pinned above), so vmcnt(12) is the wait that is needed
+        // (the first steps after the prologue have more behind it: the same immediate waits longer there, never shorter).
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x007C);          // vmcnt(12) expcnt(7) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
 
-    // prologue: stage 0 -> LDS[0] (image by DMA, rows through set 0), stage 1's rows -> set 1
+    // prologue: stage 0 -> LDS (image by DMA, rows through set 0); image chunks of stages 1, 2 and the rows of stages 1 .. 3 in flight
     dma(S0{});
     load_a(S0{});
+    dma(S1{});
+    dma(std::integral_constant<int, 2>{});
     load_a(S1{});
+    load_a(std::integral_constant<int, 2>{});
+    load_a(std::integral_constant<int, 3>{});
     conv(S0{}, S0{}, 0);
     conv(S0{}, S0{}, 1);
     __syncthreads();
     // past the last stage the loads fetch rows / chunks nobody consumes (the buffer descriptors bound them)
-    for (int s = 0; s < a.stages; s += 2) {
+    for (int s = 0; s < a.stages; s += D) {
         step(S0{});
         step(S1{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
     }
+    __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0): the run-ahead loads / image chunks land before this workgroup's LDS
+    asm volatile("" ::: "memory");                   // and registers are given back
 
     if constexpr (MODE == MODE_FWD) {
         // gate math of torch.nn.GRU (gru_step_fwd_kernel): r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z),
@@ -324,10 +351,10 @@ extern "C" int dtc_gru_step_fwd_s3(const float* hprev, const void* img, const fl
 }
 
 // the `nparts` chunks of dgh_t [R, 3H] W_hh [3H, H] side by side: chunk c -> part + c * part_stride ([R, H]); the caller adds
-// them in a fixed order; `img` = dtc_gru_s3_image(W_hh, backward = 1); (3H / nparts) must be a multiple of 32
+// them in a fixed order; `img` = dtc_gru_s3_image(W_hh, backward = 1); (3H / nparts) must be a multiple of 64
 extern "C" int dtc_gru_dgrad_parts_s3(const float* dgh_t, const void* img, float* part, int64_t part_stride, int R, int H, int nparts,
                                       void* stream) {
-    DTC_REQUIRE(shapes_ok(R, H) && nparts >= 1 && (3 * H) % nparts == 0 && (3 * H / nparts) % (2 * BK) == 0, "bad shape R=%d H=%d nparts=%d", R, H, nparts);
+    DTC_REQUIRE(shapes_ok(R, H) && nparts >= 1 && (3 * H) % nparts == 0 && (3 * H / nparts) % (4 * BK) == 0, "bad shape R=%d H=%d nparts=%d", R, H, nparts);
     DTC_REQUIRE(dgh_t && img && part && part_stride >= (int64_t)R * H, "null pointer / overlapping chunks");
     GruS3Args a{};
     a.A = dgh_t;

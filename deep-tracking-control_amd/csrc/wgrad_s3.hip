@@ -76,7 +76,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
     const bool is_a = tid < 128;
     // g is the fast index: a load instruction covers two whole 512-byte runs of two batch rows.  (With lch fast -- 4 rows x 256
     // bytes per instruction -- the ds_write_b64 of a 16-lane group cover four whole plane rows and SQ_LDS_BANK_CONFLICT drops from
-    // 95 % of the LDS cycles to 0, but the kernel runs SLOWER, 325 vs 266 us on the 61-tile bucket: the LDS is not what bounds it.)
+    // 95 % of the LDS cycles to 0, but the kernel runs SLOWER, 325 vs 266 us on the 61-tile bucket: the LDS is not what bounds it.
+    // Second attempt with the global pattern UNCHANGED -- lane = 2 g + (lch & 1), planes as [k half][row][16 bytes]: the 16 lanes of
+    // a write group then cover 128 contiguous bytes, conflict free, fragment reads stay one ds_read_b128 -- 64.96 vs 64.24 ms per
+    // step (3 interleaved runs each): no gain either.)
     const int lt = tid & 127, g = lt & 31, lch = lt >> 5;
     const long long lddz = J.lddz;
     const rsrc_t ares = make_rsrc_bytes(J.dZ, (long long)M * lddz * 4);

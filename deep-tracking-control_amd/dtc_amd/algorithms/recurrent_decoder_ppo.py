@@ -20,7 +20,7 @@ import torch
 from .. import _ffi, distributed as dp, ops
 from .._ffi import seg, segmat
 from ..modules.actor_critic_decoder_recurrent import ActorCriticDecoderRecurrent
-from ..utils import split_and_pad_trajectories
+from ..utils import split_and_pad_trajectories, true_indices
 from .ppo import PPO, S_GNORM, S_KL, S_RECONS, S_SURR, S_VALUE, S_VEL, S_KLD, STAT_COLS
 
 
@@ -68,10 +68,13 @@ class RecurrentDecoderPPO(PPO):
             last = first + int(counts[i])
             masks = masks_all[:, first:last]
             R = last - first
-            traj, pos = masks.transpose(1, 0).nonzero(as_tuple=True)
+            flat_rt = true_indices(masks.transpose(1, 0), mb * T)      # no nonzero() sync: the count is known
+            traj, pos = flat_rt // T, flat_rt % T
             unpad_idx = (pos * R + traj).view(mb, T).transpose(1, 0).reshape(-1).contiguous()
             idx = (torch.arange(T, device=dev).unsqueeze(1) * N + torch.arange(a, b, device=dev)).reshape(-1).contiguous()
-            pick = lambda h: h[:, :, a:b].permute(2, 0, 1, 3)[lwd[:, a:b].permute(1, 0)][:, 0].contiguous()   # [R, H]
+            starts = true_indices(lwd[:, a:b].permute(1, 0), R)      # (env, t) of every trajectory start, env-major; count known
+            s_env, s_t = a + starts // T, starts % T
+            pick = lambda h: h[s_t, 0, s_env].contiguous()           # [R, H]: layer 0's saved state at every trajectory start
             yield dict(a=a, b=b, idx=idx, unpad_idx=unpad_idx, T=T, R=R, hid_a=pick(hid_a), hid_c=pick(hid_c))
             first = last
 

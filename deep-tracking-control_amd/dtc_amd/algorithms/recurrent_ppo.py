@@ -20,6 +20,7 @@ from .. import _ffi, distributed as dp, ops
 from .._ffi import seg, segmat
 from ..modules.actor_critic_recurrent import ActorCriticRecurrent
 from ..storage import RolloutStorage
+from ..utils import true_indices
 import os
 
 from .ppo import FusedAdam, S_ENTROPY, S_GNORM, S_KL, S_SURR, S_VALUE, STAT_COLS, _Lanes
@@ -53,6 +54,7 @@ class RecurrentPPO:
         # runs on a second stream, every weight gradient on a third (DTC_OVERLAP_LANES=0 / DTC_OVERLAP_WGRAD=0: serial)
         self.overlap = os.environ.get("DTC_OVERLAP_LANES", "1") != "0" and os.environ.get("DTC_OVERLAP_WGRAD", "1") != "0"
         self._lanes = None
+        self._wimages = None
 
     def _require_gpu(self):
         if self.optimizer is None:
@@ -165,12 +167,33 @@ class RecurrentPPO:
             self._lanes.wg = None
         ln = self._lanes
         # un-padding as a row map: padded row (pos*R + traj) of each (t, env) in time-major order
-        traj, pos = masks.transpose(1, 0).nonzero(as_tuple=True)
+        flat_rt = true_indices(masks.transpose(1, 0), M)          # every (env, t) has exactly one padded slot: no nonzero() sync
+        traj, pos = flat_rt // T, flat_rt % T
         unpad_idx = (pos * R + traj).view(Nmb, T).transpose(1, 0).reshape(-1).contiguous()
         store_idx = (torch.arange(T, device=dev).unsqueeze(1) * N + torch.arange(start, stop, device=dev)).reshape(-1).contiguous()
         stats = torch.zeros(STAT_COLS, device=dev) if stats is None else stats
         self.optimizer.set_lr(self.learning_rate)
         _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap)))
+        if self._wimages is None:
+            self._wimages = ops.WeightImages()
+        with self._wimages:                          # weight images of the step's split-path layers: one launch
+            self._forward_backward(ln, batch, stats, unpad_idx, store_idx, M, T, R, dev)
+        arena = ac.arena
+        dp_adaptive = dp.world_size() > 1 and self.desired_kl is not None and self.schedule == 'adaptive'
+        if dp.world_size() > 1:
+            dp.allreduce_mean_(arena.grad_full)      # header (KL) + every gradient: one collective per optimiser step
+        if dp_adaptive:
+            stats[S_KL:S_KL + 1].copy_(arena.kl_slot)
+            ops.lr_adapt(arena.kl_slot, self.optimizer.lr_dev, float(self.desired_kl))
+        if self.capture_grads:
+            self.captured["main"] = ac.arena.grad.clone()
+        self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])
+        return stats
+
+    def _forward_backward(self, ln, batch, stats, unpad_idx, store_idx, M, T, R, dev):
+        ac, st = self.actor_critic, self.storage
+        arena = ac.arena
+        (obs_b, cobs_b, _a, _v, _adv, _r, _lp, _mu, _sg, (hid_a, hid_c), masks) = batch
         ln.begin(self.overlap)
         # forward: critic recurrence on the second lane
         with ln.lane("aux"):
@@ -208,15 +231,6 @@ class RecurrentPPO:
             head_backward(ac.Cr, c_outs, c_saved, ac.memory_c, dval)
         head_backward(ac.A, a_outs, a_saved, ac.memory_a, dmean)
         ln.join()
-        if dp.world_size() > 1:
-            dp.allreduce_mean_(arena.grad_full)      # header (KL) + every gradient: one collective per optimiser step
-        if dp_adaptive:
-            stats[S_KL:S_KL + 1].copy_(arena.kl_slot)
-            ops.lr_adapt(arena.kl_slot, self.optimizer.lr_dev, float(self.desired_kl))
-        if self.capture_grads:
-            self.captured["main"] = ac.arena.grad.clone()
-        self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])
-        return stats
 
     def update(self):
         self._require_gpu()

@@ -41,3 +41,11 @@ def split_and_pad_trajectories(tensor, dones):
 def unpad_trajectories(trajectories, masks):
     T = trajectories.shape[0]
     return trajectories.transpose(1, 0)[masks.transpose(1, 0)].view(-1, T, trajectories.shape[-1]).transpose(1, 0)
+
+
+def true_indices(mask, count):
+    """Flat indices of the True entries of `mask` in ascending order WITHOUT a host synchronisation: `count` = their number,
+    known to the caller (torch.nonzero / boolean indexing must read it back from the device first).  A stable sort of the negated
+    mask puts the True entries first, in their original order."""
+    flat = mask.reshape(-1)
+    return torch.argsort((~flat).to(torch.uint8), stable=True)[:count]
