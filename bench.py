@@ -33,7 +33,7 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6        # MI355X_MICROARCH.md: dense bf16 (v_mfma_
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0      # fp32-equivalent peak of the split path: six bf16 passes per product = 419.4
 
 
-def cpu_baseline():
+def cpu_baseline(full=False):
     """The oracle (torch-CPU restatement of the reference's PPO.update + numpy foothold planner) timed on the host cores
     as BASELINE.md §4 prescribes -- one warm-up, median of three runs -- on a BOUNDED sample of the workload: ONE of the
     update's five epochs (4 mini-batches of 24576 on the full 4096 x 24 rollout, + compute_returns) and 16384 of the
@@ -46,16 +46,19 @@ def cpu_baseline():
     from oracle import foothold as OF
     from oracle import ppo_ref as OP
     n_cpu = os.cpu_count() or 1
-    n_envs, n_maps, epochs = NUM_ENVS, 16384, 5
+    # full = True (`bench.py --cpu-baseline-full`, once per round into profiles/): the WHOLE workload -- all five epochs, all 98304
+    # maps -- one warm-up + one run, so that the scaling of the sampled figure stays checked
+    n_envs, n_maps, epochs = NUM_ENVS, (NUM_ENVS * NUM_STEPS if full else 16384), 5
+    run_epochs = epochs if full else 1
     d = S.rollout(n_envs, NUM_STEPS, seed=4)
-    perm, e1, e2 = S.update_noise(n_envs, NUM_STEPS, 4, 1, seed=123)
+    perm, e1, e2 = S.update_noise(n_envs, NUM_STEPS, 4, run_epochs, seed=123)
     inp = S.scorer_inputs(n_maps, seed=7)
     args = [inp[k].numpy() for k in ("measured_heights", "root_states", "thigh_pos", "commands")]
 
     def one_run():
         torch.manual_seed(3)
         ac = OP.RefActorCriticDecoder()
-        alg = OP.RefPPO(ac, num_learning_epochs=1, learning_rate=1e-3, entropy_coef=0.003)
+        alg = OP.RefPPO(ac, num_learning_epochs=run_epochs, learning_rate=1e-3, entropy_coef=0.003)
         alg.init_storage(n_envs, NUM_STEPS)
         for k, v in d.items():
             if k != "last_values":
@@ -70,7 +73,7 @@ def cpu_baseline():
         for lo in range(0, n_maps, 8192):             # bounded temporaries ([chunk, 693, 4] arrays)
             OF.plan(*[x[lo:lo + 8192] for x in args], S.MEASURED_POINTS_X, S.MEASURED_POINTS_Y)
         t_sc = time.perf_counter() - t0
-        per_env_step = (t_ret + epochs * t_epoch) / (n_envs * NUM_STEPS) + t_sc / n_maps
+        per_env_step = (t_ret + (epochs // run_epochs) * t_epoch) / (n_envs * NUM_STEPS) + t_sc / n_maps
         return per_env_step, t_ret + t_epoch + t_sc
 
     warm = {}
@@ -81,13 +84,14 @@ def cpu_baseline():
         warm[th] = one_run()[0]                       # doubles as the warm-up run
     cores = min(warm, key=warm.get)
     torch.set_num_threads(cores)
-    runs = [one_run() for _ in range(3)]
+    runs = [one_run() for _ in range(1 if full else 3)]
     per_env_step = statistics.median(r[0] for r in runs)
     return dict(value=1.0 / per_env_step, unit="env-steps/s", cores=cores, kind="port", host_cpus=n_cpu,
                 runs_env_steps_per_s=[round(1.0 / r[0], 1) for r in runs],
-                sample=f"oracle/ppo_ref.py: compute_returns + 1 of the 5 update epochs (4 mini-batches of 24576) on {n_envs} envs x "
+                sample=("WHOLE workload, nothing scaled: " if full else "") +
+                       f"oracle/ppo_ref.py: compute_returns + {run_epochs} of the 5 update epochs (4 mini-batches of 24576) on {n_envs} envs x "
                        f"{NUM_STEPS} steps, oracle/foothold.py on {n_maps} of {NUM_ENVS * NUM_STEPS} height maps; "
-                       f"{runs[0][1]:.1f} s of CPU work per run, warm-up + median of 3, torch {torch.__version__} CPU, "
+                       f"{runs[0][1]:.1f} s of CPU work per run, warm-up + median of {len(runs)}, torch {torch.__version__} CPU, "
                        f"{cores} threads (warm-up rates: " + ", ".join(f"{k} thr {1.0 / v:.0f}" for k, v in warm.items()) + ")")
 
 
@@ -124,7 +128,11 @@ def main():
                          "(GRU + CE-net + foothold obs, build-defined); gru = configs[2] (ActorCriticRecurrent, GRU 512, BPTT); "
                          "both on the same rollout shapes -- informative only.  Default from DTC_BENCH_WORKLOAD (a driver that "
                          "cannot pass flags selects configs[4]'s model with DTC_BENCH_WORKLOAD=composite)")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="time the CPU port on the WHOLE workload (no GPU work) and exit")
     a = ap.parse_args()
+    if a.cpu_baseline_full:
+        print(json.dumps(dict(cpu_baseline_full=cpu_baseline(full=True))), flush=True)
+        return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` (the driver's command shape): become the launcher -- one rank per GPU under

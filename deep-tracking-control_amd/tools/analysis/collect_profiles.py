@@ -39,7 +39,7 @@ for w in ("gru", "composite", "fp32mfma"):
     p = f"{src}/{tag}_bench_{w}.json"
     if os.path.exists(p):
         json.dump(last_json(p), open(f"{dst}/{tag}_bench_{w}_informative.json", "w"), indent=1)
-for name in (f"{tag}_gemm_pmc.md", f"{tag}_gemm_pmc_fp32mfma.md", f"{tag}_split_accuracy.log"):
+for name in (f"{tag}_gemm_pmc.md", f"{tag}_gemm_pmc_fp32mfma.md", f"{tag}_split_accuracy.log", f"{tag}_cpu_baseline_full.json"):
     if os.path.exists(f"{src}/{name}"):
         shutil.copy(f"{src}/{name}", f"{dst}/{name}")
 
@@ -77,7 +77,8 @@ if r.get("traffic_kernels"):
         f.write(f"* algorithmic (every operand read once, every output written once; in-library accounting): **{r['traffic_algorithmic_step_bytes'] / 1e9:.1f} GB per step** "
                 f"= {r['traffic_algorithmic'] / 1e6:.1f} MB per launch\n* ratio **{r['traffic_over_algorithmic']:.3f}**\n\n")
         f.write("Where the excess comes from: the partial slabs of the weight gradients (written once by the grouped kernel, read once by its "
-                "reduce kernel -- not counted as algorithmic) and operand re-reads that miss the 4 MB per-XCD L2.\n")
+                "reduce kernel -- not counted as algorithmic), the weight images (6 bytes per weight written per call and fetched once by "
+                "every XCD's L2 instead of 4) and operand re-reads that miss the 4 MB per-XCD L2.\n")
 
 # ---- rocprofv3 kernel stats
 for mode in ("serial", "overlap"):

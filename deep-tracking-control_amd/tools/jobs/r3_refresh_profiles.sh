@@ -20,6 +20,7 @@ timeout 600 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline
 done
 timeout 600 python -m pytest tests/test_hip_split.py -m gpu -q -s 2>&1 | grep -E "err |TFLOP|passed|failed" > $O/r03_split_accuracy.log
 python deep-tracking-control_amd/tools/soak.py 20 2>&1 | tail -1 > $O/r03_soak.log
+timeout 900 python bench.py --cpu-baseline-full 2>/dev/null | tail -1 > $O/r03_cpu_baseline_full.json
 rm -rf $O/pmc_split $O/pmc_fp32 $O/rp_serial/*/*trace* 2>/dev/null
 find $O -name "*.csv" -size +2M -delete
 ls $O
