@@ -181,8 +181,8 @@ extern "C" int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, 
 }
 
 extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* gates, const float* hn, const float* W_hh,
-                           float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace, int T, int R, int H,
-                           void* stream) {
+                           float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace, const int64_t* valid_rows, int n_valid,
+                           int T, int R, int H, void* stream) {
     DTC_REQUIRE(T > 0 && R > 0 && H > 0, "bad shape T=%d R=%d H=%d", T, R, H);
     DTC_REQUIRE(dhs && hs_all && gates && hn && W_hh && dgi && dW_hh && db_hh && dh0 && workspace, "null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -216,6 +216,10 @@ extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* g
         if (rc != DTC_OK) return rc;
     }
     hipLaunchKernelGGL(gru_add_parts_kernel, dim3(grid), dim3(256), 0, s, dh0, part, (long long)RH, nparts);
+    // the padding slots of the padded trajectory layout have dgh = 0: with the caller's list of valid slots the product skips them
+    if (valid_rows && n_valid >= 1024 && n_valid < T * R && dtc_get_gemm_split() && 3ll * H * H >= 128 * 128)
+        return dtc_linear_wgrad_rows(dgh_all, 3 * H, (int64_t)T * R, hs_all, H, (int64_t)T * R, valid_rows, dW_hh, db_hh, wg_ws, n_valid, 3 * H, H,
+                                     stream);
     const DtcSegMat Hprev = plain(hs_all, H, H, (int64_t)T * R);
     int rc = dtc_linear_wgrad(dgh_all, 3 * H, &Hprev, dW_hh, db_hh, wg_ws, T * R, 3 * H, H, stream);
     if (rc != DTC_OK) return rc;

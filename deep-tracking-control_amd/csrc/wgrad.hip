@@ -401,6 +401,7 @@ int plan_group(const DtcWgradJob* jobs, int count, int M, void* workspace, Group
         const DtcWgradJob& h = jobs[j];
         DTC_REQUIRE(h.N > 0 && h.K > 0 && h.lddz >= h.N, "job %d: bad shape N=%d K=%d lddz=%lld", j, h.N, h.K, (long long)h.lddz);
         DTC_REQUIRE(h.dZ && h.dW, "job %d: null pointer", j);
+        DTC_REQUIRE(h.dz_rows == 0, "job %d: a row map for dZ (dz_rows) is a feature of the split-precision path (dtc_wgrad_group_s3)", j);
         DTC_REQUIRE((long long)M * h.lddz <= MAX_ELEMS, "job %d: matrix too large", j);
         WJobDev& d = G.job[j];
         int rc = to_dev(&h.X, d.X, h.K, false, M);
@@ -450,6 +451,7 @@ DtcWgradJob one_job(const float* dZ, int64_t lddz, const DtcSegMat* X, float* dW
     j.db = db;
     j.N = N;
     j.K = K;
+    j.dz_rows = 0;
     return j;
 }
 // worst case of a one-layer split launch: every segment of X (<= 4) may add a partial 128-column tile
@@ -512,6 +514,23 @@ extern "C" int dtc_linear_wgrad(const float* dZ, int64_t lddz, const DtcSegMat* 
             hipLaunchKernelGGL(wgrad_reduce_kernel<16>, grid, dim3(64, 16), 0, s, part, dW, db, N, K, splits);
     }
     return dtc::check_launch("linear_wgrad");
+}
+
+// dW = dZ[idx]^T X[idx], db = column sums of dZ[idx]: both operands through ONE row map (see DtcWgradJob.dz_rows)
+extern "C" int dtc_linear_wgrad_rows(const float* dZ, int64_t lddz, int64_t dz_rows, const float* X, int64_t ldx, int64_t x_rows,
+                                     const int64_t* idx, float* dW, float* db, void* workspace, int M, int N, int K, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N && ldx >= K && dz_rows > 0 && x_rows > 0, "bad shape");
+    DTC_REQUIRE(dZ && X && idx && dW && workspace && dtc::aligned16(workspace), "null pointer / unaligned workspace");
+    DTC_REQUIRE(dtc_get_gemm_split(), "row-mapped weight gradients need the split-precision path (dtc_set_gemm_split)");
+    DtcSegMat xs;
+    xs.nseg = 1;
+    xs.cols = K;
+    xs.idx = const_cast<int64_t*>(idx);
+    xs.seg[0] = DtcSeg{const_cast<float*>(X), ldx, 0, K, 1, 0, x_rows};
+    DtcWgradJob job = one_job(dZ, lddz, &xs, dW, db, N, K);
+    job.dz_rows = dz_rows;
+    DTC_REQUIRE(dtc_wgrad_group_s3_workspace(&job, 1, M) <= dtc_linear_wgrad_workspace(M, N, K), "workspace too small");
+    return dtc_wgrad_group_s3(&job, 1, M, workspace, stream);
 }
 
 extern "C" int64_t dtc_wgrad_group_workspace(const DtcWgradJob* jobs, int count, int M) {

@@ -27,6 +27,7 @@ constexpr int TILE = 128;
 struct S3Job {
     const float* dZ;
     long long lddz;
+    long long dz_rows;      // > 0: dZ's rows are gathered through X.idx as well (see DtcWgradJob)
     SegMatDev X;
     float* part;            // [splits][tiles][128][128] physical-order partial products
     float* bpart;           // [splits][row_tiles][128] bias-gradient partials (logical order)
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
     // step (3 interleaved runs each): no gain either.)
     const int lt = tid & 127, g = lt & 31, lch = lt >> 5;
     const long long lddz = J.lddz;
-    const rsrc_t ares = make_rsrc_bytes(J.dZ, (long long)M * lddz * 4);
+    const bool gather_a = J.dz_rows > 0;
+    const rsrc_t ares = make_rsrc_bytes(J.dZ, (gather_a ? J.dz_rows : (long long)M) * lddz * 4);
     const rsrc_t bres = make_rsrc_bytes(sd.ptr, (long long)sd.rows * sd.ld * 4);
     // column offset of this thread's float4 (INVALID behind the matrix / the segment: those lanes stage zeros)
     const u32 acol = (n0 + 4 * g < N) ? (u32)(n0 + 4 * g) * 4u : INVALID;
@@ -100,16 +102,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
         for (int q = 0; q < 4; ++q) {
             const int m = mb + 4 * lch + q;
             const int mc = m < m_end ? m : m_end - 1;
-            rnext[q] = sd.gather ? (u32)J.X.idx[mc] : (u32)mc;
+            rnext[q] = (is_a ? gather_a : sd.gather != 0) ? (u32)J.X.idx[mc] : (u32)mc;
         }
     };
-    if (!is_a) rows_of(m_begin);
+    rows_of(m_begin);
     auto load_stage = [&](int mb) {
         if (is_a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int m = mb + 4 * lch + q;
-                v[q] = bload4(ares, (acol + (u32)m * lda) | oob_mask(m, m_end - 1), 0u);
+                v[q] = bload4(ares, (acol + rnext[q] * lda) | oob_mask(m, m_end - 1), 0u);
             }
         } else {
 #pragma unroll
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
                 const int m = mb + 4 * lch + q;
                 v[q] = bload4(bres, (bcol + rnext[q] * ldb) | oob_mask(m, m_end - 1), 0u);
             }
-            rows_of(mb + BK);
         }
+        rows_of(mb + BK);
     };
     // BIAS (workgroup-uniform): the first column tile of a layer also sums dZ's columns (12 of the ~100 VALU of a stage that the
     // other tiles, and the X side everywhere, do not need to issue)
@@ -336,12 +338,14 @@ int plan_s3(const DtcWgradJob* jobs, int count, int M, void* workspace, S3Plan& 
         const DtcWgradJob& h = jobs[j];
         DTC_REQUIRE(h.N > 0 && h.K > 0 && h.lddz >= h.N, "job %d: bad shape N=%d K=%d lddz=%lld", j, h.N, h.K, (long long)h.lddz);
         DTC_REQUIRE(h.dZ && h.dW, "job %d: null pointer", j);
-        DTC_REQUIRE((long long)M * h.lddz <= MAX_ELEMS, "job %d: matrix too large", j);
+        DTC_REQUIRE((h.dz_rows > 0 ? h.dz_rows : (long long)M) * h.lddz <= MAX_ELEMS, "job %d: matrix too large", j);
+        DTC_REQUIRE(h.dz_rows >= 0 && (h.dz_rows == 0 || h.X.idx != nullptr), "job %d: dz_rows needs the row map X.idx", j);
         S3Job& d = G.job[j];
         int rc = to_dev(&h.X, d.X, h.K, false, M);
         if (rc != DTC_OK) return rc;
         d.dZ = h.dZ;
         d.lddz = h.lddz;
+        d.dz_rows = h.dz_rows;
         d.dW = h.dW;
         d.db = h.db;
         d.N = h.N;

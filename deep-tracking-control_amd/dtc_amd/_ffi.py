@@ -37,7 +37,7 @@ class DtcSegMat(C.Structure):
 
 class DtcWgradJob(C.Structure):
     _fields_ = [("dZ", C.c_void_p), ("lddz", C.c_int64), ("X", DtcSegMat), ("dW", C.c_void_p), ("db", C.c_void_p),
-                ("N", C.c_int32), ("K", C.c_int32)]
+                ("N", C.c_int32), ("K", C.c_int32), ("dz_rows", C.c_int64)]
 
 
 class DtcFwdLayer(C.Structure):
@@ -76,7 +76,7 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 4          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 5          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
@@ -134,6 +134,8 @@ _SIGS = {
     "dtc_linear_wgrad_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dtc_linear_wgrad": (C.c_int, [c_f32p, C.c_int64, C.POINTER(DtcSegMat), c_f32p, c_f32p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, c_stream]),
+    "dtc_linear_wgrad_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, c_i64p, c_f32p, c_f32p, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_wgrad_group_workspace": (C.c_int64, [C.POINTER(DtcWgradJob), C.c_int, C.c_int]),
     "dtc_wgrad_group": (C.c_int, [C.POINTER(DtcWgradJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_wgrad_group_s3_workspace": (C.c_int64, [C.POINTER(DtcWgradJob), C.c_int, C.c_int]),
@@ -164,7 +166,7 @@ _SIGS = {
     "dtc_gru_step_fwd": (C.c_int, [c_f32p] * 7 + [C.c_int, C.c_int, c_stream]),
     "dtc_gru_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dtc_gru_fwd": (C.c_int, [c_f32p] * 7 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
-    "dtc_gru_bwd": (C.c_int, [c_f32p] * 9 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_gru_bwd": (C.c_int, [c_f32p] * 9 + [C.c_void_p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_set_concurrency_hint": (None, [C.c_int]),
     "dtc_lstm_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dtc_lstm_fwd": (C.c_int, [c_f32p] * 8 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),

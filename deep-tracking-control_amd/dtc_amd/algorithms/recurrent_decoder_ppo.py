@@ -144,7 +144,7 @@ class RecurrentDecoderPPO(PPO):
             dgi_p, dh0 = torch.empty(T, R, 3 * H, device=dev), torch.empty(R, H, device=dev)
             mem = hd["mem"]
             ops.gru_bwd(dhs.view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], mem.W_hh, dgi_p, mem.gW_hh, mem.gb_hh,
-                        dh0, hd["ws"])
+                        dh0, hd["ws"], rows=unpad_idx)          # the W_hh weight gradient skips the padding slots
             return ops.gather_rows(dgi_p.view(T * R, 3 * H), unpad_idx, out=tw.g("dgi_" + name, 3 * H))
 
         with tw.lane("aux"):

@@ -115,7 +115,7 @@ class RecurrentPPO:
         cfg.adaptive_schedule = int(self.desired_kl is not None and self.schedule == 'adaptive' and dp.world_size() == 1)
         return cfg
 
-    def _wgrad(self, ln, dZ, X, gW, gb, M):
+    def _wgrad(self, ln, dZ, X, gW, gb, M, rows=None):
         """Weight gradient on the side stream (off the critical path until the optimiser step)."""
         N, K = gW.shape
         need = ops.wgrad_workspace_bytes(M, N, K)
@@ -126,10 +126,10 @@ class RecurrentPPO:
             ev = ln.event()
             ev.record()
             ln.side.wait_event(ev)
-            ops.linear_wgrad(dZ, X, gW, gb, ln.wg, M=M, stream_ptr=ln.side.cuda_stream)
+            ops.linear_wgrad(dZ, X, gW, gb, ln.wg, M=M, stream_ptr=ln.side.cuda_stream, rows=rows)
             ln.side_busy = True
         else:
-            ops.linear_wgrad(dZ, X, gW, gb, ln.wg, M=M)
+            ops.linear_wgrad(dZ, X, gW, gb, ln.wg, M=M, rows=rows)
 
     def _mlp_backward(self, ln, layers, outs, dOut, X0, M, dev, keep):
         """Backward through an MLP given the saved layer outputs; returns the gradient w.r.t. its input rows.
@@ -224,7 +224,9 @@ class RecurrentPPO:
             d_in = self._mlp_backward(ln, layers, outs, dOut, X0, M, dev, keep)
             dhs = torch.zeros(T * R, H, device=dev)
             ops.scatter_rows(d_in, unpad_idx, dhs)
-            dgi = mem.backward(saved, dhs.view(T, R, H), wgrad=lambda dZ, X, gW, gb: self._wgrad(ln, dZ, X, gW, gb, T * R))
+            # unpad_idx doubles as the list of valid (t, r) slots: the recurrent weight gradients skip the padding
+            dgi = mem.backward(saved, dhs.view(T, R, H), rows=unpad_idx,
+                               wgrad=lambda dZ, X, gW, gb: self._wgrad(ln, dZ, X, gW, gb, T * R, rows=unpad_idx))
             keep.extend((d_in, dhs, dgi, X0, outs, saved))
 
         with ln.lane("aux"):

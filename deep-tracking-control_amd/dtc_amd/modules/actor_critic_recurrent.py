@@ -255,10 +255,11 @@ class Memory(nn.Module):
             return h
         return h, torch.stack([rec["cs_all"][-1] for rec in saved["layers"]])
 
-    def backward(self, saved, dhs, wgrad=None):
+    def backward(self, saved, dhs, wgrad=None, rows=None):
         """BPTT: dhs [T,R,H] (gradient w.r.t. the top layer's outputs) -> parameter gradients into the arena; returns dgi
         [T,R,G*H] of the BOTTOM layer (gradient of the input projection's output).  `wgrad(dZ, X, gW, gb)` optionally takes
-        over the input-projection weight gradients (the trainer runs them on its weight-gradient stream)."""
+        over the input-projection weight gradients (the trainer runs them on its weight-gradient stream).  `rows`: the valid
+        (t, r) slots of the padded batch (t * R + r, int64 device index; GRU only): weight gradients skip the padding slots."""
         T, R, H, G = saved["T"], saved["R"], self.hidden_size, self.G
         dev = dhs.device
         d_out = dhs.contiguous()
@@ -269,7 +270,7 @@ class Memory(nn.Module):
             dh0 = torch.empty(R, H, device=dev)
             if self.kind == 'gru':
                 ops.gru_bwd(d_out, rec["hs_all"], rec["gates"], rec["hn"], self.Whh[l], dgi, self.gWhh[l], self.gbhh[l], dh0,
-                            rec["ws"])
+                            rec["ws"], rows=rows)
             else:
                 dc0 = torch.empty(R, H, device=dev)
                 ops.lstm_bwd(d_out, rec["hs_all"], rec["cs_all"], rec["gates"], self.Whh[l], dgi, self.gWhh[l], self.gbhh[l], dh0,
@@ -279,7 +280,7 @@ class Memory(nn.Module):
                 wgrad(dgi.view(T * R, G * H), rec["x2"], self.gWih[l], self.gbih[l])
             else:
                 wws = ops.workspace(ops.wgrad_workspace_bytes(T * R, G * H, I), dev)
-                ops.linear_wgrad(dgi.view(T * R, G * H), rec["x2"], self.gWih[l], self.gbih[l], wws)
+                ops.linear_wgrad(dgi.view(T * R, G * H), rec["x2"], self.gWih[l], self.gbih[l], wws, rows=rows)
                 keep.append(wws)
             if l > 0:                              # gradient w.r.t. this layer's input = the outputs of the layer below
                 d_in = torch.empty(T * R, I, device=dev)

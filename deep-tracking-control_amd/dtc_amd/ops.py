@@ -93,6 +93,8 @@ SPLIT = _os.environ.get("DTC_GEMM_SPLIT", "1") != "0"
 # step (the 128-column layers run longer per launch on 192 tiles of 128 x 128 -- 35 vs 28 us -- but on the second lane, under the wide GEMMs)
 SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "128"))
 SPLIT_MIN_RED = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_RED", "128"))
+# recurrent trainers: weight gradients over the valid slots of the padded trajectory layout only (0: over all T x R rows)
+WGRAD_ROWS = _os.environ.get("DTC_WGRAD_ROWS", "1") != "0"
 
 
 def set_split(on: bool):
@@ -276,15 +278,23 @@ def wgrad_workspace_bytes(M, N, K) -> int:
     return int(lib().dtc_linear_wgrad_workspace(M, N, K))
 
 
-def linear_wgrad(dZ, X, dW, db, workspace, M=None, stream_ptr=None):
+def linear_wgrad(dZ, X, dW, db, workspace, M=None, stream_ptr=None, rows=None):
     """dW = dZ^T X, db = colsum(dZ).  X: tensor or DtcSegMat.  `stream_ptr`: raw HIP stream to launch on
-    (default: torch's current stream)."""
-    Xs = as_segmat(X)
+    (default: torch's current stream).  `rows` (int64 device index, X a plain tensor): only these rows of BOTH operands enter the
+    product -- every other row of dZ must be zero (the padding rows of a padded trajectory layout), so the result is the same sum
+    without the work spent on zeros; taken on the split-precision path, ignored otherwise."""
     N, K = dW.shape
     M = dZ.shape[0] if M is None else M
     need = wgrad_workspace_bytes(M, N, K)
     if workspace.numel() * workspace.element_size() < need:
         raise _ffi.DtcError(f"wgrad workspace too small: {workspace.numel() * workspace.element_size()} < {need}")
+    if (rows is not None and WGRAD_ROWS and SPLIT and isinstance(X, torch.Tensor) and N * K >= 128 * 128 and rows.numel() >= 1024
+            and rows.numel() < M):
+        check(lib().dtc_linear_wgrad_rows(ptr(dZ), dZ.stride(0), M, cptr(X, f32), X.stride(0), X.shape[0], cptr(rows, torch.int64),
+                                          cptr(dW, f32), cptr(db, f32) if db is not None else None, ptr(workspace), rows.numel(),
+                                          N, K, stream() if stream_ptr is None else stream_ptr), "dtc_linear_wgrad_rows")
+        return
+    Xs = as_segmat(X)
     check(lib().dtc_linear_wgrad(ptr(dZ), dZ.stride(0), Xs, cptr(dW, f32), cptr(db, f32) if db is not None else None,
                                  ptr(workspace), M, N, K, stream() if stream_ptr is None else stream_ptr),
           "dtc_linear_wgrad")
@@ -450,10 +460,14 @@ def gru_fwd(gi, h0, W_hh, b_hh, hs_all, gates, hn, ws):
                             cptr(gates, f32), cptr(hn, f32), ptr(ws), T, R, H3 // 3, stream()), "dtc_gru_fwd")
 
 
-def gru_bwd(dhs, hs_all, gates, hn, W_hh, dgi, dW_hh, db_hh, dh0, ws):
+def gru_bwd(dhs, hs_all, gates, hn, W_hh, dgi, dW_hh, db_hh, dh0, ws, rows=None):
+    """`rows`: the valid (t, r) slots t * R + r of a padded trajectory batch (int64 device index): the W_hh weight gradient skips
+    the padding slots (their gradients are zero)."""
     T, R, H = dhs.shape
+    use = rows is not None and WGRAD_ROWS
     check(lib().dtc_gru_bwd(cptr(dhs, f32), cptr(hs_all, f32), cptr(gates, f32), cptr(hn, f32), cptr(W_hh, f32),
-                            cptr(dgi, f32), cptr(dW_hh, f32), cptr(db_hh, f32), cptr(dh0, f32), ptr(ws), T, R, H,
+                            cptr(dgi, f32), cptr(dW_hh, f32), cptr(db_hh, f32), cptr(dh0, f32), ptr(ws),
+                            cptr(rows, torch.int64) if use else None, rows.numel() if use else 0, T, R, H,
                             stream()), "dtc_gru_bwd")
 
 

@@ -38,7 +38,7 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-#define DTC_ABI_VERSION 4                    /* bumped whenever a signature or a by-value struct layout changes       */
+#define DTC_ABI_VERSION 5                    /* bumped whenever a signature or a by-value struct layout changes       */
 int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
 /* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
    DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec: the binding compares them with its own layouts at load time (a library
@@ -308,8 +308,15 @@ typedef struct DtcWgradJob {
     float* dW;           /* [N, K]                                                               */
     float* db;           /* [N] or NULL                                                          */
     int32_t N, K;
+    int64_t dz_rows;     /* 0: row m of the product is dZ[m].  > 0 (split path only): dZ has dz_rows rows and row m of the
+                          * product is dZ[X.idx[m]] -- the SAME row map as X's gathered segments (the recurrent trainers' valid
+                          * rows of the padded trajectory layout: the padding rows carry zero gradient and are skipped)      */
 } DtcWgradJob;
 int64_t dtc_wgrad_group_workspace(const DtcWgradJob* jobs, int count, int M);
+/* dtc_linear_wgrad over the rows idx[0 .. M) of BOTH operands (dZ [dz_rows, N] and the single-segment X [x_rows, K] share the row
+ * map; split-precision path only: returns DTC_ERR_ARG when it is switched off -- the caller then runs the padded product). */
+int dtc_linear_wgrad_rows(const float* dZ, int64_t lddz, int64_t dz_rows, const float* X, int64_t ldx, int64_t x_rows,
+                          const int64_t* idx, float* dW, float* db, void* workspace, int M, int N, int K, void* stream);
 int dtc_wgrad_group(const DtcWgradJob* jobs, int count, int M, void* workspace, void* stream);
 
 /* ---- CE-net latent: actor_critic_decoder.py:274-302 ---------------------------------------- */
@@ -414,10 +421,12 @@ int64_t dtc_gru_workspace(int T, int R, int H);
 int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, const float* b_hh, float* hs_all,
                 float* gates, float* hn, void* workspace, int T, int R, int H, void* stream);
 /* BPTT.  dhs [T,R,H] = gradient w.r.t. the outputs h_1..h_T.  Produces dgi [T,R,3H] (gradient w.r.t. gi:
- * feed it to dtc_linear_wgrad with x for W_ih / b_ih), dW_hh [3H,H], db_hh [3H] and dh0 [R,H]. */
+ * feed it to dtc_linear_wgrad with x for W_ih / b_ih), dW_hh [3H,H], db_hh [3H] and dh0 [R,H].
+ * valid_rows (optional, n_valid entries of t * R + r): the (t, r) slots that belong to a trajectory -- the padding slots of the
+ * padded layout carry zero gradient, and on the split-precision path the W_hh weight gradient then skips them. */
 int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* gates, const float* hn, const float* W_hh,
-                float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace, int T, int R, int H,
-                void* stream);
+                float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace, const int64_t* valid_rows, int n_valid,
+                int T, int R, int H, void* stream);
 
 /* ---- LSTM (torch.nn.LSTM, gate order i,f,g,o; the default `rnn_type` of actor_critic_recurrent.py:93-97) ----
  * gi [T,R,4H] = x W_ih^T + b_ih is computed by dtc_linear_fwd over all T*R rows; this runs

@@ -254,4 +254,6 @@ def test_no_kernel_uses_scratch():
     assert len(res) >= 40, sorted(res)
     bad = {k: v for k, v in res.items() if v["scratch"] != 0}
     assert not bad, bad
-    assert all(v["lds"] <= 64 * 1024 for v in res.values())
+    # LDS: every kernel leaves room for at least two workgroups per CU; the GRU time-step kernels (ring of four image buffers,
+    # launches of one workgroup per CU) are the only ones above 64 KiB
+    assert all(v["lds"] <= (80 if "gru_s3_kernel" in k else 64) * 1024 for k, v in res.items()), {k: v["lds"] for k, v in res.items() if v["lds"] > 64 * 1024}

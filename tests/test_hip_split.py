@@ -255,6 +255,34 @@ def test_grouped_weight_images_equal_per_call_images_bitwise():
         assert torch.equal(a, b)
 
 
+def test_weight_gradient_over_a_row_map_skips_zero_rows():
+    """ops.linear_wgrad(rows=...): only the listed rows of both operands enter the product (the recurrent trainers' valid slots of a
+    padded trajectory batch; every other row of dZ is zero).  Same result as the product over all rows -- against fp64 and next to
+    it --, also when the rows the map leaves out hold garbage in X."""
+    from dtc_amd import ops
+    g = torch.Generator().manual_seed(21)
+    Mp, N, K = 6000, 1536, 512
+    valid = torch.randperm(Mp, generator=g)[:4100].sort().values
+    dZ = torch.zeros(Mp, N)
+    dZ[valid] = torch.randn(valid.numel(), N, generator=g)
+    X = torch.randn(Mp, K, generator=g)
+    ref_w, ref_b = dZ.double().T @ X.double(), dZ.double().sum(0)
+    Xg = X.clone()
+    pad = torch.ones(Mp, dtype=torch.bool)
+    pad[valid] = False
+    Xg[pad] = float("nan")                                  # rows outside the map are never read
+    d = lambda t: t.to(DEV)
+    outs = []
+    for rows, Xin in ((None, X), (valid, Xg)):
+        dW, db = torch.full((N, K), float("nan"), device=DEV), torch.full((N,), float("nan"), device=DEV)
+        ws = ops.workspace(ops.wgrad_workspace_bytes(Mp, N, K), DEV)
+        ops.linear_wgrad(d(dZ), d(Xin), dW, db, ws, rows=d(rows) if rows is not None else None)
+        outs.append((dW, db))
+    for dW, db in outs:
+        assert _err(dW, ref_w) <= 2e-6 and _err(db, ref_b) <= 2e-6
+    assert _err(outs[1][0], ref_w) <= 2.0 * _err(outs[0][0], ref_w) + 2e-7
+
+
 def test_split_timing_report():
     """Not an assertion on speed: prints the per-launch time of both paths on the bench's 512-wide layer."""
     from dtc_amd import ops
