@@ -95,6 +95,7 @@ SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "128"))
 SPLIT_MIN_RED = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_RED", "128"))
 # recurrent trainers: weight gradients over the valid slots of the padded trajectory layout only (0: over all T x R rows)
 WGRAD_ROWS = _os.environ.get("DTC_WGRAD_ROWS", "1") != "0"
+WIMG = _os.environ.get("DTC_S3_WIMG", "1") != "0"          # the library's weight-image switch (csrc/gemm_s3.hip reads the same variable)
 
 
 def set_split(on: bool):
@@ -142,7 +143,7 @@ class WeightImages:
         global _IMAGES
         self.prev, _IMAGES = _IMAGES, self
         self.active = True
-        if self.entries and SPLIT:
+        if self.entries and SPLIT and WIMG:
             if self.jobs is None or len(self.jobs) != len(self.entries):
                 self.jobs = (_ffi.DtcWimgJob * len(self.entries))()
                 for a, e in zip(self.jobs, self.entries.values()):
