@@ -12,15 +12,16 @@
 // tests/test_hip_split.py (same error level; the sum is not bit-identical to the fmaf chain, nor is the reference's
 // own CPU GEMM between two thread counts).
 //
-// Data path (forward product Y = X W^T, both operands contiguous along the reduction index k):
-//   global (fp32, dwordx4 per 4 k, the segmented / gathered operand descriptors of gemm.hip) -> registers -> split into
-//   three packed-bf16 planes (v_cvt_pk_bf16_f32: 5.5 VALU per element, hidden under the MFMAs of the other waves) ->
-//   LDS planes [row][16 k] (32-byte rows, the two 16-byte halves of a row swapped on odd 8-row groups: conflict-free
-//   ds_write_b64 and ds_read_b128) -> one ds_read_b128 per plane and 32 x 32 tile = the 8 bf16 of a lane's MFMA fragment.
+// Data path (forward product Y = X W^T):
+//   X: global (fp32, dwordx4 per 4 k, the segmented / gathered operand descriptors of gemm.hip) -> registers -> split into three
+//   packed-bf16 planes (v_cvt_pk_bf16_f32: 5.5 VALU per element, placed between the MFMAs of the stage in flight) -> LDS planes
+//   [row][16 k] (32-byte rows, the two 16-byte halves of a row swapped on odd 8-row groups: conflict-free ds_write_b64 and
+//   ds_read_b128) -> one ds_read_b128 per plane and 32 x 32 tile = the 8 bf16 of a lane's MFMA fragment;
+//   W: a WEIGHT IMAGE -- the same planes, built once per call (or once per optimisation step for all layers:
+//   dtc_s3_wimage_group) by wimage_kernel, one 12 KiB chunk per 128-column tile and 16-k stage -- copied into LDS by LDS-DMA.
 //   Block tile 128 x 128 x 16, 2 x 2 waves of 64 x 64, 24 MFMAs per wave and stage, double-buffered LDS (48 KiB), 3
 //   workgroups per CU.
-// The data gradient uses the same kernel on the transposed weight (dtc_s3_transpose once per optimiser step): both
-// operands are then reduction-contiguous as well.
+// The data gradient uses the same kernel with the image of W^T (the builder reads W transposed).
 #include <type_traits>
 
 #include "s3_core.hpp"
