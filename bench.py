@@ -421,6 +421,24 @@ def main():
             "kernel_classes": classes,
             "last_update": [float(x) for x in out],
         }
+        if world == 1 and ops.SPLIT:
+            # the SAME workload on the single-pass fp32 MFMA kernels, timed in this process after everything above (same box, same
+            # data): for a reader who wants the headline without the split arithmetic
+            ops.set_split(False)
+            try:
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                k = max(3, min(a.steps, 5))
+                for _ in range(k):
+                    step()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / k
+                line["single_pass_fp32_mfma"] = dict(ms_per_step=dt * 1e3, value=NUM_ENVS * NUM_STEPS / dt, unit="env-steps/s", steps=k,
+                                                     note="DTC_GEMM_SPLIT=0 path (v_mfma_f32_32x32x2_f32 everywhere), same process and data")
+            finally:
+                ops.set_split(True)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
