@@ -221,15 +221,32 @@ class Memory(nn.Module):
         fix = lambda t: t if t.dim() == 3 else t.unsqueeze(0)
         return fix(h), (fix(c) if c is not None else None)
 
-    def run(self, x, hidden):
-        """x [T,R,I], hidden as in `hidden_states` ([L,R,H] or (h, c)) -> saved dict; saved['out'] = top layer's [T,R,H]."""
+    def _padded_gi(self, rows_total, width, dev):
+        """Persistent, zero-initialised [T * R, G * H] buffer for the compacted input projection (grown on demand): the slots a
+        mini-batch does not write keep finite values of earlier mini-batches."""
+        buf = getattr(self, "_gi_pad", None)
+        if buf is None or buf.numel() < rows_total * width or buf.device != dev:
+            buf = self._gi_pad = torch.zeros(rows_total * width, device=dev)
+        return buf[:rows_total * width].view(rows_total, width)
+
+    def run(self, x, hidden, rows=None):
+        """x [T,R,I], hidden as in `hidden_states` ([L,R,H] or (h, c)) -> saved dict; saved['out'] = top layer's [T,R,H].
+        `rows`: see forward()."""
         T, R, _ = x.shape
         H, G, dev = self.hidden_size, self.G, x.device
         h0, c0 = self._split(hidden)
         layers, cur = [], x.contiguous().view(T * R, -1)
+        compact = rows is not None and ops.WGRAD_ROWS and self.kind == 'gru' and 1024 <= rows.numel() < T * R
         for l in range(self.num_layers):
-            gi = torch.empty(T, R, G * H, device=dev)
-            ops.linear_fwd(cur, self.Wih[l], self.bih[l], gi.view(T * R, G * H), None)
+            if compact and l == 0:
+                # ~30 % of a padded recurrent mini-batch is padding: project the valid rows (gathered) and scatter them into place
+                gi_c = torch.empty(rows.numel(), G * H, device=dev)
+                ops.linear_fwd(segmat([seg(cur, 0, cur.shape[1], gather=True)], rows), self.Wih[l], self.bih[l], gi_c, None, M=rows.numel())
+                gi = self._padded_gi(T * R, G * H, dev).view(T, R, G * H)
+                ops.scatter_rows(gi_c, rows, gi.view(T * R, G * H))
+            else:
+                gi = torch.empty(T, R, G * H, device=dev)
+                ops.linear_fwd(cur, self.Wih[l], self.bih[l], gi.view(T * R, G * H), None)
             hs_all = torch.empty(T + 1, R, H, device=dev)
             gates = torch.empty(T, R, G * H, device=dev)
             rec = dict(x2=cur, hs_all=hs_all, gates=gates)
@@ -290,12 +307,14 @@ class Memory(nn.Module):
         saved["_bwd_keep"] = keep                  # read by side-stream weight gradients until the trainer's join
         return dgi
 
-    def forward(self, input, masks=None, hidden_states=None):
+    def forward(self, input, masks=None, hidden_states=None, rows=None):
+        """`rows` (batch mode, optional): the valid (t, r) slots t * R + r of the padded batch -- the input projection is then
+        computed for those rows only (the padding slots keep finite stale values nobody reads)."""
         batch_mode = masks is not None
         if batch_mode:
             if hidden_states is None:
                 raise ValueError("Hidden states not passed to memory module during policy update")
-            self.saved = self.run(input, hidden_states)
+            self.saved = self.run(input, hidden_states, rows=rows)
             return self.saved["out"]
         if self.hidden_states is None:
             self.hidden_states = self.init_hidden(input.shape[0], input.device)
@@ -342,7 +361,7 @@ class ActorCriticRecurrent(ActorCritic):
     def _through(self, memory, layers, observations, masks, hidden_states, unpad_idx):
         """memory -> (un-pad as a row gather) -> MLP.  Returns the MLP layer outputs."""
         self.ensure_arena()
-        out = memory(observations.float(), masks, hidden_states)          # [T,R,H] or [1,N,H]
+        out = memory(observations.float(), masks, hidden_states, rows=unpad_idx if masks is not None else None)   # [T,R,H] or [1,N,H]
         T, R, H = out.shape
         flat = out.reshape(T * R, H)
         if masks is None:
