@@ -421,9 +421,10 @@ def main():
             "kernel_classes": classes,
             "last_update": [float(x) for x in out],
         }
-        if world == 1 and ops.SPLIT:
+        if world == 1 and ops.SPLIT and not a.no_traffic:
             # the SAME workload on the single-pass fp32 MFMA kernels, timed in this process after everything above (same box, same
-            # data): for a reader who wants the headline without the split arithmetic
+            # data): for a reader who wants the headline without the split arithmetic.  (Not in the --no-traffic child runs of the
+            # counter passes: their parsers take the LAST step of the process, which must stay the serialised split-path step.)
             ops.set_split(False)
             try:
                 for _ in range(2):
