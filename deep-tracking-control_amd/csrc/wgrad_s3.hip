@@ -44,6 +44,11 @@ struct S3Group {
 __device__ __forceinline__ int phys(int x) { return (x & 3) * 32 + (x >> 2); }          // logical -> physical (0..127)
 __device__ __forceinline__ int logical(int p) { return 4 * (p & 31) + (p >> 5); }       // physical -> logical
 
+// GATHER_A: some job of the group maps dZ's rows through X.idx (DtcWgradJob.dz_rows); the plain kernel keeps the row arithmetic of
+// the dZ loader out of its K loop (with it in, for jobs that do not need it, the loop issued 2.8 instead of 0.55 scalar and 5.9
+// instead of 4.8 vector instructions per MFMA, 180 instead of 168 registers -- two instead of three workgroups per CU -- and the
+// bench step's grouped launches ran 318 instead of 270 us).  The row-map variant keeps 180 registers (budget 3 would spill one)
+template <bool GATHER_A>
 __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G) {
     __shared__ __attribute__((aligned(16))) u32x2 As[2][3][TILE * 4];
     __shared__ __attribute__((aligned(16))) u32x2 Bs[2][3][TILE * 4];
@@ -83,16 +88,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
     // step (3 interleaved runs each): no gain either.)
     const int lt = tid & 127, g = lt & 31, lch = lt >> 5;
     const long long lddz = J.lddz;
-    const bool gather_a = J.dz_rows > 0;
+    const bool gather_a = GATHER_A && J.dz_rows > 0;
     const rsrc_t ares = make_rsrc_bytes(J.dZ, (gather_a ? J.dz_rows : (long long)M) * lddz * 4);
     const rsrc_t bres = make_rsrc_bytes(sd.ptr, (long long)sd.rows * sd.ld * 4);
     // column offset of this thread's float4 (INVALID behind the matrix / the segment: those lanes stage zeros)
     const u32 acol = (n0 + 4 * g < N) ? (u32)(n0 + 4 * g) * 4u : INVALID;
     const u32 bcol = (lc0 + 4 * g < sd.width) ? (u32)(sd.col0 + lc0 + 4 * g) * 4u : INVALID;
     const u32 ldb = (u32)sd.ld * 4u, lda = (u32)lddz * 4u;
-    int slot[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) slot[e] = wslot(e * 32 + g, lch);           // physical row of column 4 g + e
+    // physical row of column 4 g + e = 32 e + g: rows 32 apart share the half-swap parity, so the four slots are slot0 + 128 e
+    // (immediate offsets of one address register)
+    const int slot0 = wslot(g, lch);
 
     f32x4 v[4];
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -105,13 +110,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
             rnext[q] = (is_a ? gather_a : sd.gather != 0) ? (u32)J.X.idx[mc] : (u32)mc;
         }
     };
-    rows_of(m_begin);
+    if (GATHER_A || !is_a) rows_of(m_begin);
     auto load_stage = [&](int mb) {
         if (is_a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int m = mb + 4 * lch + q;
-                v[q] = bload4(ares, (acol + rnext[q] * lda) | oob_mask(m, m_end - 1), 0u);
+                v[q] = bload4(ares, (acol + (GATHER_A ? rnext[q] : (u32)m) * lda) | oob_mask(m, m_end - 1), 0u);
             }
         } else {
 #pragma unroll
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
                 v[q] = bload4(bres, (bcol + rnext[q] * ldb) | oob_mask(m, m_end - 1), 0u);
             }
         }
-        rows_of(mb + BK);
+        if (GATHER_A || !is_a) rows_of(mb + BK);
     };
     // BIAS (workgroup-uniform): the first column tile of a layer also sums dZ's columns (12 of the ~100 VALU of a stage that the
     // other tiles, and the X side everywhere, do not need to issue)
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
             const f32x4 col = {v[0][e], v[1][e], v[2][e], v[3][e]};          // four batch rows of column 4 g + e
             const Split3 s = split3(col);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) dst[p][slot[e]] = s.p[p];
+            for (int p = 0; p < 3; ++p) dst[p][slot0 + 128 * e] = s.p[p];
             if constexpr (decltype(bias)::value) bsum[e] += (col[0] + col[1]) + (col[2] + col[3]);
         }
     };
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
             const f32x4 col = {v[0][e], v[1][e], v[2][e], v[3][e]};
             const Split3 sp = split3(col);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) dst[p][slot[e]] = sp.p[p];
+            for (int p = 0; p < 3; ++p) dst[p][slot0 + 128 * e] = sp.p[p];
             if constexpr (decltype(bias)::value) bsum[e] += (col[0] + col[1]) + (col[2] + col[3]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -395,7 +400,10 @@ extern "C" int dtc_wgrad_group_s3(const DtcWgradJob* jobs, int count, int M, voi
     {
         dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, G.tiles_total, count), P.flop, s, P.algo_bytes);
         const int grid = G.tiles_total * 8 * (int)dtc::ceil_div(G.splits, 8);
-        hipLaunchKernelGGL(wgrad_s3_group_kernel, dim3(grid), dim3(256), 0, s, G);
+        bool any_rows = false;
+        for (int j = 0; j < G.count; ++j) any_rows = any_rows || G.job[j].dz_rows > 0;
+        if (any_rows) hipLaunchKernelGGL(wgrad_s3_group_kernel<true>, dim3(grid), dim3(256), 0, s, G);
+        else hipLaunchKernelGGL(wgrad_s3_group_kernel<false>, dim3(grid), dim3(256), 0, s, G);
     }
     {
         dtc::ProfScope prof(dtc::prof_shape_name("wgrad_reduce", G.splits, G.tiles_total, count), (double)P.bytes + P.bytes / (double)G.splits, s);
