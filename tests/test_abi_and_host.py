@@ -254,6 +254,10 @@ def test_no_kernel_uses_scratch():
     assert len(res) >= 40, sorted(res)
     bad = {k: v for k, v in res.items() if v["scratch"] != 0}
     assert not bad, bad
+    # register budgets the schedule depends on: three workgroups per CU (<= 168 registers) for the split forward / data-gradient
+    # kernels and the plain grouped weight-gradient kernel (a row-map change once pushed the latter to 180: 4 ms per step)
+    three = {k: v["vgprs"] for k, v in res.items() if "linear_s3_kernel" in k or "wgrad_s3_group_kernelILb0" in k}
+    assert len(three) >= 7 and all(n <= 168 for n in three.values()), three
     # LDS: every kernel leaves room for at least two workgroups per CU; the GRU time-step kernels (ring of four image buffers,
     # launches of one workgroup per CU) are the only ones above 64 KiB
     assert all(v["lds"] <= (80 if "gru_s3_kernel" in k else 64) * 1024 for k, v in res.items()), {k: v["lds"] for k, v in res.items() if v["lds"] > 64 * 1024}
