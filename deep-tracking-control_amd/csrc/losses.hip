@@ -377,10 +377,12 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(const double* __
     }
 }
 
-__global__ void lr_adapt_kernel(const float* __restrict__ kl_mean, double* __restrict__ lr, float desired_kl) {
+__global__ void lr_adapt_kernel(float* __restrict__ kl_mean, double* __restrict__ lr, float desired_kl) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const float klm = *kl_mean;
+        *kl_mean = __builtin_nanf("");                  // consumed: the next step has to deposit its own value
         double cur = *lr;
+        if (klm != klm) cur = (double)klm;              // nothing was deposited (or the KL itself is NaN): fail loudly
         if (klm > desired_kl * 2.0f) cur = fmax(1e-5, cur / 1.5);
         else if (klm < desired_kl / 2.0f && klm > 0.0f) cur = fmin(1e-2, cur * 1.5);
         *lr = cur;
@@ -527,7 +529,7 @@ extern "C" int dtc_gaussian_act(const float* mean, const float* std, const float
     return dtc::check_launch("gaussian_act");
 }
 
-extern "C" int dtc_lr_adapt(const float* kl_mean, double* lr, float desired_kl, void* stream) {
+extern "C" int dtc_lr_adapt(float* kl_mean, double* lr, float desired_kl, void* stream) {
     DTC_REQUIRE(kl_mean && lr, "null pointer");
     hipLaunchKernelGGL(lr_adapt_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_mean, lr, desired_kl);
     return dtc::check_launch("lr_adapt");

@@ -76,7 +76,7 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 5          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 6          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),

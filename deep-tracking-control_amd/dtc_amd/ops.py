@@ -95,6 +95,8 @@ SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "128"))
 SPLIT_MIN_RED = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_RED", "128"))
 # recurrent trainers: weight gradients over the valid slots of the padded trajectory layout only (0: over all T x R rows)
 WGRAD_ROWS = _os.environ.get("DTC_WGRAD_ROWS", "1") != "0"
+WIMG_CHECK = _os.environ.get("DTC_WIMG_CHECK", "0") == "1"  # debug: re-derive every cached weight image at its use and compare
+_NOT_NULL = 16                                             # stand-in address of a non-NULL operand block in a cached descriptor
 WIMG = _os.environ.get("DTC_S3_WIMG", "1") != "0"          # the library's weight-image switch (csrc/gemm_s3.hip reads the same variable)
 
 
@@ -168,10 +170,30 @@ class WeightImages:
         if e is None:
             n = int(lib().dtc_s3_planes_bytes(K, N) if trans else lib().dtc_s3_planes_bytes(N, K))
             img = torch.empty((n + 7) // 8, dtype=torch.float64, device=W.device)
-            own = _ffi.DtcSegMat.from_buffer_copy(segs)           # the job keeps its own copy of the descriptor
+            own = _ffi.DtcSegMat.from_buffer_copy(segs)           # the job keeps its own copy of the descriptor: the image
+            own.idx = None                                        # builder reads the segment walk (widths, which destination
+            for i in range(own.nseg):                             # blocks are NULL), never the operand: no address of the
+                if own.seg[i].ptr:                                # first call's tensors survives in the copy
+                    own.seg[i].ptr = _NOT_NULL
+                own.seg[i].gather = 0
             self.keep.append((W, own))
             e = self.entries[key] = [img, (cptr(W, f32), ptr(img), C.pointer(own), N, K, trans), False]
+        elif e[2] and WIMG_CHECK:
+            self._verify(e, key)
         return e[0], int(e[2])
+
+    def _verify(self, e, key):
+        """DTC_WIMG_CHECK=1 (debug): the image built at block entry must still be the image of the weights this call sees --
+        a caller that changed W inside the block (the contract above) is caught here instead of computing on stale planes."""
+        fresh = torch.empty_like(e[0])
+        job = (_ffi.DtcWimgJob * 1)()
+        job[0].W, _img, job[0].seg, job[0].N, job[0].K, job[0].trans = e[1]
+        job[0].img = ptr(fresh)
+        check(lib().dtc_s3_wimage_group(job, 1, stream()), "dtc_s3_wimage_group")
+        n = int(lib().dtc_s3_planes_bytes(key[2], key[1]) if key[3] else lib().dtc_s3_planes_bytes(key[1], key[2]))
+        if not torch.equal(fresh.view(torch.uint8)[:n], e[0].view(torch.uint8)[:n]):
+            raise _ffi.DtcError(f"WeightImages: weights of layer N={key[1]} K={key[2]} trans={key[3]} changed inside the block "
+                                "(stale weight image)")
 
 
 _IMAGES = None       # the WeightImages block the current calls run in, if any

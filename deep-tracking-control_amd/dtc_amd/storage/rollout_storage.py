@@ -155,122 +155,6 @@ class RolloutStorage:
                 dst[self.step].copy_(h)
 
     def clear(self):
-            self.__init__()
-
-    def __init__(self, num_envs, num_transitions_per_env, obs_shape, privileged_obs_shape, obs_history_shape,
-                 actions_shape, device='cpu'):
-        self.device = device
-        self.obs_shape = obs_shape
-        self.privileged_obs_shape = privileged_obs_shape
-        self.obs_history_shape = obs_history_shape
-        self.actions_shape = actions_shape
-        T, N = num_transitions_per_env, num_envs
-        z = lambda *s: torch.zeros(T, N, *s, device=self.device)
-        # Core
-        self.observations = z(*obs_shape)
-        self.next_observations = z(*obs_shape)
-        self.privileged_observations = z(*privileged_obs_shape)
-        self.observation_histories = z(*obs_history_shape)
-        self.rewards = z(1)
-        self.actions = z(*actions_shape)
-        self.dones = torch.zeros(T, N, 1, device=self.device, dtype=torch.uint8)
-        # For PPO
-        self.actions_log_prob = z(1)
-        self.values = z(1)
-        self.returns = z(1)
-        self.advantages = z(1)
-        self.mu = z(*actions_shape)
-        self.sigma = z(*actions_shape)
-        self.base_vel = z(3)
-        self.num_transitions_per_env = T
-        self.num_envs = N
-        # rnn
-        self.saved_hidden_states_a = None
-        self.saved_hidden_states_c = None
-        self.step = 0
-        self._stats = None
-
-    def add_transitions(self, transition: "RolloutStorage.Transition", time_outs=None, gamma=0.0):
-        """rollout_storage.py:99-116.  On a HIP device the 13 copies are ONE dtc_store_transition launch, which also
-        applies the time-out bootstrap of PPO.process_env_step (ppo.py:162-163) when `time_outs` is given."""
-        if self.step >= self.num_transitions_per_env:
-            raise AssertionError("Rollout buffer overflow")
-        s, tr = self.step, transition
-        if self.observations.is_cuda:
-            f = lambda t: t if t.dtype == torch.float32 else t.float()
-            dones = tr.dones if tr.dones.dtype in (torch.uint8, torch.bool) else tr.dones.to(torch.uint8)
-            if dones.dtype == torch.bool:
-                dones = dones.view(torch.uint8)
-            # the 11 destination rows of step s: addresses from a plan marshalled once (base pointer + s * step bytes),
-            # only the source pointers are filled in per step -- the env step is host-bound, every us of FFI glue counts
-            plan = self._store_plan()
-            srcs = (f(tr.observations), f(tr.next_observations), f(tr.privileged_observations), f(tr.observation_histories),
-                    f(tr.actions), dones.reshape(-1), f(tr.values), f(tr.actions_log_prob).reshape(-1), f(tr.action_mean),
-                    f(tr.base_vel), f(tr.action_sigma))
-            items = plan["items"]
-            for i, (src, (base, step_bytes, width, numel, dtype)) in enumerate(zip(srcs, plan["dst"])):
-                # per-call checks (a handful of integer compares): the kernel trusts these descriptors blindly
-                if src.shape[0] != self.num_envs or src.numel() != self.num_envs * numel or src.dtype != dtype or \
-                        (src.dim() > 1 and src.stride(-1) != 1) or not src.is_cuda:
-                    raise _ffi.DtcError(f"add_transitions: field {i} has shape {tuple(src.shape)} / strides {src.stride()} / "
-                                        f"{src.dtype} on {src.device}; expected [{self.num_envs}, {numel}] {dtype} rows with unit "
-                                        "inner stride on the storage's device")
-                it = items[i]
-                it.src, it.dst = src.data_ptr(), base + s * step_bytes
-                it.src_stride_bytes = src.stride(0) * src.element_size()
-            to = None
-            if time_outs is not None:
-                to = time_outs.to(self.device)
-                to = to.view(torch.uint8) if to.dtype == torch.bool else to.to(torch.uint8)
-            ops.store_transition_items(items, len(srcs), f(tr.rewards).reshape(-1).contiguous(), f(tr.values).reshape(-1), to,
-                                       gamma, self.rewards[s], self.num_envs)
-        else:
-            if time_outs is not None:
-                tr.rewards = tr.rewards + gamma * torch.squeeze(tr.values * time_outs.unsqueeze(1).to(self.device), 1)
-            self.observations[s].copy_(tr.observations)
-            self.next_observations[s].copy_(tr.next_observations)
-            self.privileged_observations[s].copy_(tr.privileged_observations)
-            self.observation_histories[s].copy_(tr.observation_histories)
-            self.actions[s].copy_(tr.actions)
-            self.rewards[s].copy_(tr.rewards.view(-1, 1))
-            self.dones[s].copy_(tr.dones.view(-1, 1))
-            self.values[s].copy_(tr.values)
-            self.actions_log_prob[s].copy_(tr.actions_log_prob.view(-1, 1))
-            self.mu[s].copy_(tr.action_mean)
-            self.base_vel[s].copy_(tr.base_vel)
-            self.sigma[s].copy_(tr.action_sigma)
-        self._save_hidden_states(tr.hidden_states)
-        self.step += 1
-
-    def _store_plan(self):
-        dsts = (self.observations, self.next_observations, self.privileged_observations, self.observation_histories,
-                self.actions, self.dones, self.values, self.actions_log_prob, self.mu, self.base_vel, self.sigma)
-        plan = getattr(self, "_plan", None)
-        ptrs = tuple(t.data_ptr() for t in dsts)
-        if plan is None or plan["ptrs"] != ptrs:          # first use, or a buffer was replaced (.to(), re-assignment)
-            items = (_ffi.DtcRowCopy * len(dsts))()
-            meta = []
-            for i, t in enumerate(dsts):
-                row = t[0, 0].numel() * t.element_size()
-                items[i].width_bytes = row
-                meta.append((t.data_ptr(), t.stride(0) * t.element_size(), row, t[0, 0].numel(), t.dtype))
-            plan = self._plan = dict(items=items, dst=meta, ptrs=ptrs)
-        return plan
-
-    def _save_hidden_states(self, hidden_states):
-        if hidden_states is None or hidden_states == (None, None):
-            return
-        hid_a = hidden_states[0] if isinstance(hidden_states[0], tuple) else (hidden_states[0],)
-        hid_c = hidden_states[1] if isinstance(hidden_states[1], tuple) else (hidden_states[1],)
-        if self.saved_hidden_states_a is None:
-            T = self.observations.shape[0]
-            self.saved_hidden_states_a = [torch.zeros(T, *hid_a[i].shape, device=self.device) for i in range(len(hid_a))]
-            self.saved_hidden_states_c = [torch.zeros(T, *hid_c[i].shape, device=self.device) for i in range(len(hid_c))]
-        for i in range(len(hid_a)):
-            self.saved_hidden_states_a[i][self.step].copy_(hid_a[i])
-            self.saved_hidden_states_c[i][self.step].copy_(hid_c[i])
-
-    def clear(self):
         self.step = 0
 
     def compute_returns(self, last_values, gamma, lam):
@@ -287,6 +171,14 @@ class RolloutStorage:
         ops.adv_sqdev(self.advantages, self._stats, count)
         dp.allreduce_sum_(self._stats[1:2])
         ops.adv_normalize(self.advantages, self._stats, count)
+
+    def get_statistics(self):
+        """(mean trajectory length, mean reward) of the stored rollout (rollout_storage.py:154-160).  The reference marks the
+        last stored step as done IN the storage while it counts (`done = self.dones; done[-1] = 1`, an alias, not a copy);
+        that side effect is replicated: a later compute_returns / recurrent generator sees the same dones as the reference's."""
+        self.dones[-1] = 1
+        _traj, _pos, lengths, _n = trajectory_index_map(self.dones)
+        return lengths.float().mean(), self.rewards.mean()
 
     def flat(self, name):
         return getattr(self, name).flatten(0, 1)

@@ -38,7 +38,7 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-#define DTC_ABI_VERSION 5                    /* bumped whenever a signature or a by-value struct layout changes       */
+#define DTC_ABI_VERSION 6                    /* bumped whenever a signature or a by-value struct layout changes       */
 int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
 /* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
    DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec: the binding compares them with its own layouts at load time (a library
@@ -380,8 +380,10 @@ int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc, int64_t l
                        int64_t lddha, float* dHc, int64_t lddhc, float* dstd, float* losses, double* lr, void* workspace,
                        int B, int num_actions, void* stream);
 /* The learning-rate rule of ppo.py:301-307 alone (data-parallel callers run dtc_ppo_loss with
- * adaptive_schedule = 0, all-reduce the KL mean, then call this so every rank takes the same branch). */
-int dtc_lr_adapt(const float* kl_mean, double* lr, float desired_kl, void* stream);
+ * adaptive_schedule = 0, all-reduce the KL mean, then call this so every rank takes the same branch).
+ * The slot is CONSUMED: it is overwritten with NaN, and a NaN found in it (a caller that exchanged the gradient header
+ * without depositing this step's KL first) poisons *lr with NaN instead of silently re-using a stale value. */
+int dtc_lr_adapt(float* kl_mean, double* lr, float desired_kl, void* stream);
 /* log-prob / sampling side of PPO.act (ppo.py:137-150): actions = mean + std*noise,
  * logp = sum_j log N(a; mean, std). */
 int dtc_gaussian_act(const float* mean, const float* std, const float* noise, float* actions,
