@@ -10,12 +10,18 @@ One "step" = one pass of the hot path over one recorded rollout of 4096 envs x 2
   + PPO.update: 5 epochs x 4 mini-batches of 24576          (ppo.py:174-357)
 Inputs are resident in HBM before the timed region.  Multi-GPU = data parallel, weak scaling
 (4096 envs per rank, RCCL all-reduce of the two flat gradient buckets + three scalars per step).
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  N > 1: the headline stays configs[1] PER RANK at every N (the configuration BASELINE.json's
+metric is quoted on: the driver's 1 -> 8 efficiency is then a like-for-like ratio), and the same line carries
+`configs4_composite`: configs[4]'s model (GRU + CE-net + foothold obs) on 4096 x N envs, timed in the same job.
+Failure is loud: a run that cannot complete (missing GPU, a rank that died, a hung collective, the launcher's SIGTERM) ends
+with ONE JSON line carrying `"error"` and a non-zero exit code within the deadline -- never a silent hang.
 """
 import argparse
 import json
 import os
+import signal
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -95,6 +101,78 @@ def cpu_baseline(full=False):
                        f"{cores} threads (warm-up rates: " + ", ".join(f"{k} thr {1.0 / v:.0f}" for k, v in warm.items()) + ")")
 
 
+METRIC = "env-steps/sec, PPO.update on pre-recorded rollouts, 4096 envs, 1/2/4/8 GPU"
+_LINE_LOCK = threading.Lock()
+_LINE_DONE = [False]
+
+
+def emit_line(obj) -> bool:
+    """Rank 0's single JSON line (first caller wins; the watchdog thread and the main thread may race for it)."""
+    with _LINE_LOCK:
+        if _LINE_DONE[0]:
+            return False
+        _LINE_DONE[0] = True
+        sys.stdout.write(json.dumps(obj) + "\n")
+        sys.stdout.flush()
+        return True
+
+
+def error_line(msg, n_gpus, phase=None, **extra):
+    return dict({"metric": METRIC, "value": None, "unit": "env-steps/s", "n_gpus": n_gpus, "error": str(msg)[-1500:], "phase": phase,
+                 "higher_is_better": True}, **extra)
+
+
+class Watchdog(threading.Thread):
+    """Turns every way an N > 1 run can stall into ONE JSON error line + a non-zero exit, from a thread that does not depend on
+    the main thread returning from a blocked C call (an RCCL collective whose peer died, a communicator init, a device sync):
+      * a deadline per phase (`enter(phase, seconds)`), DTC_BENCH_DEADLINE_S caps the whole run;
+      * SIGTERM / SIGINT (torchrun terminates the surviving ranks when one rank fails): the C-level handler writes to a
+        wake-up pipe, this thread reads it -- Python-level handlers only run once the main thread is back in the interpreter.
+    Rank 0 prints the line; every rank writes a diagnostic to stderr; the process ends with os._exit."""
+
+    def __init__(self, rank, world):
+        super().__init__(daemon=True)
+        self.rank, self.world = rank, world
+        self.phase, self.deadline = "start", time.monotonic() + float(os.environ.get("DTC_BENCH_DEADLINE_S", "1500"))
+        self.hard = self.deadline
+        self.r, self.w = os.pipe()
+        os.set_blocking(self.w, False)
+        self.done = False
+
+    def arm(self):
+        signal.set_wakeup_fd(self.w, warn_on_full_buffer=False)
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            signal.signal(sig, lambda *_: None)              # keep the default action from killing us before the line is out
+        self.start()
+        return self
+
+    def enter(self, phase, seconds):
+        self.phase, self.deadline = phase, min(self.hard, time.monotonic() + seconds)
+
+    def finish(self):
+        self.done = True
+
+    def fail(self, msg, code=3):
+        sys.stderr.write(f"[bench rank {self.rank}] {msg} (phase: {self.phase})\n")
+        sys.stderr.flush()
+        if self.rank == 0:
+            emit_line(error_line(msg, self.world, self.phase))
+        os._exit(code)
+
+    def run(self):
+        import select
+        while not self.done:
+            ready, _, _ = select.select([self.r], [], [], 0.5)
+            if self.done:
+                return
+            if ready:
+                sig = os.read(self.r, 16)
+                self.fail(f"terminated by signal {sig[0] if sig else '?'} -- under torch.distributed.run this means ANOTHER rank "
+                          "failed (its message is on stderr) and the launcher is tearing the job down", 4)
+            if time.monotonic() > self.deadline:
+                self.fail(f"no progress: phase '{self.phase}' exceeded its deadline -- a rank is missing or a collective hangs", 5)
+
+
 def self_launch(n: int) -> int:
     """Re-execute this script as `n` ranks (one per GPU of this node) under torch.distributed.run and return its exit code.
     The children inherit stdout / stderr, so rank 0's single JSON line is what the caller of `python bench.py --gpus N`
@@ -102,6 +180,12 @@ def self_launch(n: int) -> int:
     MASTER_PORT is set."""
     import socket
     import subprocess
+    launch_check = os.environ.get("DTC_BENCH_LAUNCH_CHECK") == "1"
+    if not launch_check:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:                                         # fail fast, before any rank blocks in a rendezvous
+            emit_line(error_line(f"--gpus {n} but this node exposes {have} GPU(s) (torch.cuda.device_count())", n, "preflight"))
+            return 2
     port = os.environ.get("MASTER_PORT")
     if port is None:
         with socket.socket() as s:
@@ -113,7 +197,20 @@ def self_launch(n: int) -> int:
     env.pop("MASTER_PORT", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # rank 0's stdout is relayed line by line; if the job ends without its JSON line (a rank crashed before rank 0 could
+    # report), the launcher prints the error line itself
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    seen = False
+    for ln in proc.stdout:
+        if ln.startswith("{"):
+            seen = True
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if not seen:
+        emit_line(error_line(f"the {n}-rank job ended with exit code {rc} and without a result line (see stderr)", n, "launcher"))
+        return rc or 1
+    return rc
 
 
 def main():
@@ -131,7 +228,7 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the CPU port on the WHOLE workload (no GPU work) and exit")
     a = ap.parse_args()
     if a.cpu_baseline_full:
-        print(json.dumps(dict(cpu_baseline_full=cpu_baseline(full=True))), flush=True)
+        emit_line(dict(cpu_baseline_full=cpu_baseline(full=True)))
         return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -143,29 +240,63 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    wd = Watchdog(rank, world).arm() if world > 1 else None
+    try:
+        run(a, rank, local_rank, world, wd)
+    except SystemExit:
+        raise
+    except BaseException as e:                       # any failure: ONE error line from rank 0, non-zero exit, no hang in teardown
+        import traceback
+        traceback.print_exc()
+        msg = f"rank {rank}: {type(e).__name__}: {e}"
+        if wd is not None:
+            wd.fail(msg, 1)
+        emit_line(error_line(msg, world, "run"))
+        raise SystemExit(1)
+    if wd is not None:
+        wd.finish()
+
+
+def run(a, rank, local_rank, world, wd):
+    from datetime import timedelta
+    phase = (lambda name, seconds: wd.enter(name, seconds)) if wd is not None else (lambda name, seconds: None)
+    coll_timeout = timedelta(seconds=int(os.environ.get("DTC_BENCH_COLL_TIMEOUT_S", "300")))
+    if os.environ.get("DTC_BENCH_FAIL_RANK") == str(rank):       # test hook: this rank dies before the rendezvous
+        raise RuntimeError("DTC_BENCH_FAIL_RANK: simulated rank failure")
     if os.environ.get("DTC_BENCH_LAUNCH_CHECK") == "1":
         # CPU rehearsal of the launch path only (tests/test_bench_launch.py): rendezvous, one all-reduce, rank 0's line
-        dist.init_process_group("gloo")
+        phase("rendezvous (gloo rehearsal)", 120)
+        dist.init_process_group("gloo", timeout=coll_timeout)
         t = torch.ones(1)
         dist.all_reduce(t)
+        if os.environ.get("DTC_BENCH_HANG_RANK") == str(rank):   # test hook: this rank stops taking part
+            time.sleep(3600)
+        if os.environ.get("DTC_BENCH_HANG_RANK") is not None:
+            phase("collective with a silent peer (rehearsal)", float(os.environ.get("DTC_BENCH_REHEARSAL_DEADLINE_S", "10")))
+            dist.all_reduce(t)
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "sum": float(t.item()), "steps": a.steps, "warmup": a.warmup}), flush=True)
+            emit_line({"launch_check": True, "n_gpus": world, "sum": float(t.item()), "steps": a.steps, "warmup": a.warmup})
         dist.destroy_process_group()
         return
     # test hooks (a 1-GPU box can rehearse the N > 1 control flow): DTC_BENCH_DEVICE pins every rank to one device,
     # DTC_BENCH_BACKEND=gloo replaces RCCL (two ranks cannot share a GPU under RCCL)
     if "DTC_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["DTC_BENCH_DEVICE"])
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if local_rank >= have:
+        raise RuntimeError(f"rank {rank} needs GPU {local_rank} but this node exposes {have} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DTC_BENCH_BACKEND", "nccl")
+        phase("rendezvous + communicator init", 240)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(dev))
+            dist.init_process_group("nccl", device_id=torch.device(dev), timeout=coll_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=coll_timeout)
 
+    phase("library build + imports", 600)
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:            # in-tree library: (re)build when missing / stale (no-op otherwise)
         import build as dtc_build
         dtc_build.build(verbose=False)
@@ -175,44 +306,52 @@ def main():
     from dtc_amd.algorithms import PPO, RecurrentDecoderPPO, RecurrentPPO
     from dtc_amd.modules import ActorCriticDecoder, ActorCriticDecoderRecurrent, ActorCriticRecurrent
 
-    torch.manual_seed(3)                      # identical initial weights on every rank
-    composite, gru = a.workload == "composite", a.workload == "gru"
-    if gru:
-        ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
-                                  activation='elu', rnn_type='gru', rnn_hidden_size=512, rnn_num_layers=1)
-        alg = RecurrentPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
-        alg.init_storage(NUM_ENVS, NUM_STEPS, [53], [1389], [12])
-    else:
-        ac = (ActorCriticDecoderRecurrent if composite else ActorCriticDecoder)(53, 1389, 12)
-        alg = (RecurrentDecoderPPO if composite else PPO)(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
-        alg.init_storage(NUM_ENVS, NUM_STEPS, [53], [1389], [265], [12])
+    from dtc_amd import distributed as dp
+    from dtc_amd import tracing
+
+    phase("workload set-up (weights, recorded rollout, planner inputs)", 600)
     data = S.rollout(NUM_ENVS, NUM_STEPS, seed=4 + rank, device=dev)
-    for k, v in data.items():
-        if k != "last_values" and not (gru and k == "observation_histories"):
-            getattr(alg.storage, k).copy_(v)
-    if composite or gru:                             # recorded GRU states at every (step, env): the storage's saved_hidden_states
-        g = torch.Generator(device=dev).manual_seed(77 + rank)
-        hid = [0.1 * torch.randn(NUM_STEPS, 1, NUM_ENVS, 512, generator=g, device=dev) for _ in range(2)]
     # recorded planner inputs of the same rollout: one height map per (step, env)
     sc = S.scorer_inputs(NUM_ENVS * NUM_STEPS, seed=7 + rank, device=dev)
     last = {k: data[k][-1] for k in ("observations", "privileged_observations", "base_vel")}
-    torch.manual_seed(123 + rank)
+    hid = []
 
-    from dtc_amd import tracing
+    def make_workload(kind):
+        """(trainer, step closure) of one workload on this rank's recorded rollout: decoder = configs[1], gru = configs[2],
+        composite = configs[4]'s model."""
+        torch.manual_seed(3)                      # identical initial weights on every rank
+        composite, gru = kind == "composite", kind == "gru"
+        if gru:
+            ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+                                      activation='elu', rnn_type='gru', rnn_hidden_size=512, rnn_num_layers=1)
+            alg = RecurrentPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
+            alg.init_storage(NUM_ENVS, NUM_STEPS, [53], [1389], [12])
+        else:
+            ac = (ActorCriticDecoderRecurrent if composite else ActorCriticDecoder)(53, 1389, 12)
+            alg = (RecurrentDecoderPPO if composite else PPO)(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev)
+            alg.init_storage(NUM_ENVS, NUM_STEPS, [53], [1389], [265], [12])
+        for k, v in data.items():
+            if k != "last_values" and not (gru and k == "observation_histories"):
+                getattr(alg.storage, k).copy_(v)
+        if (composite or gru) and not hid:               # recorded GRU states at every (step, env): the storage's saved_hidden_states
+            g = torch.Generator(device=dev).manual_seed(77 + rank)
+            hid.extend(0.1 * torch.randn(NUM_STEPS, 1, NUM_ENVS, 512, generator=g, device=dev) for _ in range(2))
+        torch.manual_seed(123 + rank)
 
-    def step():
-        with tracing.span("foothold_plan"):
-            foothold.plan(sc["measured_heights"], sc["root_states"], sc["thigh_pos"], sc["commands"])
-        with tracing.span("compute_returns"):
-            if gru:
-                alg.compute_returns(last["privileged_observations"])
-            else:
-                alg.compute_returns(last["observations"], last["privileged_observations"], last["base_vel"])
-        alg.storage.step = NUM_STEPS
-        if composite or gru:
-            alg.storage.saved_hidden_states_a, alg.storage.saved_hidden_states_c = [hid[0]], [hid[1]]
-        with tracing.span("update"):
-            return alg.update()
+        def step():
+            with tracing.span("foothold_plan"):
+                foothold.plan(sc["measured_heights"], sc["root_states"], sc["thigh_pos"], sc["commands"])
+            with tracing.span("compute_returns"):
+                if gru:
+                    alg.compute_returns(last["privileged_observations"])
+                else:
+                    alg.compute_returns(last["observations"], last["privileged_observations"], last["base_vel"])
+            alg.storage.step = NUM_STEPS
+            if composite or gru:
+                alg.storage.saved_hidden_states_a, alg.storage.saved_hidden_states_c = [hid[0]], [hid[1]]
+            with tracing.span("update"):
+                return alg.update()
+        return alg, step
 
     def fence():
         torch.cuda.synchronize()
@@ -220,33 +359,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from dtc_amd import distributed as dp
-    if world > 1:
-        # communicator set-up and the first exchange of every bucket size happen here, never inside the timed region
-        # (also with --warmup 0): one all-reduce of each gradient bucket + the scalar statistics, then a barrier
+    def prime_collectives(alg):
+        """Communicator set-up and the first exchange of every bucket size happen here, never inside a timed region (also
+        with --warmup 0): one all-reduce of each gradient bucket + the scalar statistics."""
+        if world == 1:
+            return
         arena = alg.actor_critic.ensure_arena()
         for t in ([arena.exchange_view(k) for k in arena.buckets] if hasattr(arena, "buckets") else [arena.grad_full]):
             dp.allreduce_mean_(t)                    # the real op (ReduceOp.AVG on RCCL) at the real bucket sizes
         arena.grad_full.zero_()
         dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev))
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    mine = time.perf_counter() - t0                  # this rank's own time (before the closing barrier)
-    fence()
-    elapsed = time.perf_counter() - t0
-    rank_ms = [mine / a.steps * 1e3]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tl = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(tl, torch.tensor([mine / a.steps * 1e3], dtype=torch.float64, device=dev))
-        rank_ms = [float(x.item()) for x in tl]
+        torch.cuda.synchronize()
+
+    def timed(step, steps, warmup):
+        """`warmup` untimed steps, then EXACTLY `steps` steps between two (barrier + device synchronise) fences; the job's time
+        is the MAX over ranks.  -> (seconds, per-rank ms per step before the closing barrier, last update's return)."""
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0                  # this rank's own time (before the closing barrier)
+        fence()
+        elapsed = time.perf_counter() - t0
+        rank_ms = [mine / steps * 1e3]
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            tl = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(tl, torch.tensor([mine / steps * 1e3], dtype=torch.float64, device=dev))
+            rank_ms = [float(x.item()) for x in tl]
+        return elapsed, rank_ms, out
+
+    composite, gru = a.workload == "composite", a.workload == "gru"
+    alg, step = make_workload(a.workload)
+    phase("first exchange of every gradient bucket", 240)
+    prime_collectives(alg)
+    phase(f"warm-up + timed region ({a.warmup} + {a.steps} steps)", 120 + 3.0 * (a.warmup + a.steps))
+    elapsed, rank_ms, out = timed(step, a.steps, a.warmup)
+    phase("accuracy check, per-kernel pass", 900)
 
     # per-kernel HIP-event timing of one more step (same process, each kernel on the stream it is launched on)
     # for the roofline object.  The timed region above overlaps the weight-gradient GEMMs with the
@@ -386,11 +540,33 @@ def main():
                                    rate=(r["work"] / (r["ms_total"] * 1e-3) / 1e12) if r["ms_total"] > 0 else 0.0)
                    for r in rep}
 
+    # N > 1, headline workload: configs[4]'s model (GRU + CE-net + foothold obs) on the same ranks in the same job -- 4096 envs
+    # per rank, i.e. 32768 envs at N = 8 -- so that the first multi-GPU run measures BOTH the like-for-like weak-scaling
+    # headline and the configuration BASELINE.json names for 8 GPUs.  Every rank takes part (its update exchanges buckets).
+    configs4 = None
+    if world > 1 and a.workload == "decoder" and os.environ.get("DTC_BENCH_CONFIGS4", "1") != "0":
+        phase("configs[4] composite: set-up + first exchanges", 600)
+        del alg, step
+        torch.cuda.empty_cache()
+        alg4, step4 = make_workload("composite")
+        prime_collectives(alg4)
+        k4 = max(1, min(a.steps, 3))
+        phase(f"configs[4] composite: warm-up + timed region (1 + {k4} steps)", 180 + 6.0 * k4)
+        el4, rank_ms4, out4 = timed(step4, k4, 1)
+        configs4 = dict(workload=f"BASELINE configs[4]: {NUM_ENVS * world} envs data-parallel over {world} GPUs ({NUM_ENVS} per rank) x "
+                                 f"{NUM_STEPS} steps, GRU + CE-net + foothold-obs composite (build-defined, DESIGN.md): planner + "
+                                 "compute_returns + RecurrentDecoderPPO.update (5 epochs x 4 recurrent mini-batches, BPTT), gradient "
+                                 "buckets all-reduced over RCCL",
+                        value=NUM_ENVS * NUM_STEPS * world * k4 / el4, unit="env-steps/s", ms_per_step=el4 / k4 * 1e3, steps=k4, warmup=1,
+                        n_gpus=world, num_envs_total=NUM_ENVS * world,
+                        rank_ms_per_step={"min": min(rank_ms4), "max": max(rank_ms4)}, last_update=[float(x) for x in out4])
+        alg = alg4
+    phase("result line", 120)
     if rank == 0:
         env_steps = NUM_ENVS * NUM_STEPS * world * a.steps
         value = env_steps / elapsed
         line = {
-            "metric": "env-steps/sec, PPO.update on pre-recorded rollouts, 4096 envs, 1/2/4/8 GPU",
+            "metric": METRIC,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -409,12 +585,15 @@ def main():
                         "steps per GPU: planner over 98304 maps + compute_returns + RecurrentDecoderPPO.update (5 epochs x "
                         "4 recurrent mini-batches of 1024 envs x 24 steps, BPTT)"),
                        "num_envs_per_gpu": NUM_ENVS, "num_steps_per_env": NUM_STEPS, "mini_batch": 24576,
-                       "epochs": 5, "wgrad_overlap_stream": bool(getattr(alg, "overlap_wgrad", False)), "parallelism": f"dp{world}" if world > 1 else "single",
+                       "epochs": 5, "wgrad_overlap_stream": bool(overlap),
+                       "headline_at_every_n": "configs[1] per rank (weak scaling: the N = 1 workload on every GPU); configs[4]'s model on "
+                                              "4096 x N envs is measured in the same job at N > 1: configs4_composite", "parallelism": f"dp{world}" if world > 1 else "single",
                        "mfma_frac_whole_step": None if (composite or gru) else
                        (FLOP_PER_ENV_STEP * value / world) / ((PEAK_SPLIT_TFLOPS if ops.SPLIT else PEAK_FP32_MFMA_TFLOPS) * 1e12),
                        "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
                        "allreduce_bytes_per_step_per_rank": dp.bytes_reduced(coll_log) if world > 1 else 0,
                        "collectives_per_step": len(coll_log)},
+            "configs4_composite": configs4,
             "roofline": roof,
             "roofline_planner": planner,
             "roofline_planner_4096": planner_4096,
@@ -442,8 +621,12 @@ def main():
                 ops.set_split(True)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     if world > 1:
+        phase("teardown", 60)
+        dist.barrier()
+        if wd is not None:
+            wd.finish()                              # the line is out: a slow communicator teardown is not a failure
         dist.destroy_process_group()
 
 

@@ -12,6 +12,8 @@ ran a full rollout without a reset -- the only case in which its own `unpad` wor
 """
 import torch
 
+from .export import export_policy_as_jit  # noqa: F401  (legged_gym/utils/helpers.py:150)
+
 
 def trajectory_index_map(dones):
     """dones [T,N,1] or [T,N] -> (traj_id [N*T], pos [N*T], lengths [n_traj]) in env-major order."""
