@@ -181,7 +181,7 @@ def self_launch(n: int) -> int:
     import socket
     import subprocess
     launch_check = os.environ.get("DTC_BENCH_LAUNCH_CHECK") == "1"
-    if not launch_check:
+    if not launch_check and "DTC_BENCH_DEVICE" not in os.environ:     # (DTC_BENCH_DEVICE: all ranks share one GPU, rehearsal)
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < n:                                         # fail fast, before any rank blocks in a rendezvous
             emit_line(error_line(f"--gpus {n} but this node exposes {have} GPU(s) (torch.cuda.device_count())", n, "preflight"))
@@ -204,8 +204,10 @@ def self_launch(n: int) -> int:
     for ln in proc.stdout:
         if ln.startswith("{"):
             seen = True
-        sys.stdout.write(ln)
-        sys.stdout.flush()
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        else:                                                # library chatter on the ranks' stdout (gloo's connection notes) is not the result
+            sys.stderr.write(ln)
     rc = proc.wait()
     if not seen:
         emit_line(error_line(f"the {n}-rank job ended with exit code {rc} and without a result line (see stderr)", n, "launcher"))

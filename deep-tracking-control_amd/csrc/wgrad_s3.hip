@@ -38,6 +38,7 @@ struct S3Job {
 };
 struct S3Group {
     int count, M, rows_per_split, splits, tiles_total;
+    int per_xcd;            // > 0: balanced map -- the (slice, tile) items in slice-major order, cut into 8 equal runs, one per XCD
     S3Job job[MAX_JOBS_S3];
 };
 
@@ -53,9 +54,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
     __shared__ __attribute__((aligned(16))) u32x2 As[2][3][TILE * 4];
     __shared__ __attribute__((aligned(16))) u32x2 Bs[2][3][TILE * 4];
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int split = xcd + 8 * (jb / G.tiles_total);
-    if (split >= G.splits) return;
-    int t = jb % G.tiles_total;
+    int split, t;
+    if (G.per_xcd > 0) {                               // any slice count: every XCD gets the same number of workgroups
+        const int q = xcd * G.per_xcd + jb;
+        if (q >= G.splits * G.tiles_total) return;
+        split = q / G.tiles_total;
+        t = q - split * G.tiles_total;
+    } else {
+        split = xcd + 8 * (jb / G.tiles_total);
+        if (split >= G.splits) return;
+        t = jb % G.tiles_total;
+    }
     int j = 0;
     while (j < G.count - 1 && t >= G.job[j].tile_end) ++j;
     if (j > 0) t -= G.job[j - 1].tile_end;
@@ -312,13 +321,24 @@ __global__ __launch_bounds__(256) void wgrad_s3_reduce_kernel(const S3Group G) {
     }
 }
 
+// DTC_WGRAD_S3_FILL=1: as many batch slices as fill the chip's 768 workgroup slots ONCE (61 tiles: 12 slices = 732 workgroups
+// instead of 8 = 488 on 768 slots), with the balanced (slice, tile) -> XCD map
+bool fill_slots() {
+    static const bool on = [] {
+        const char* e = getenv("DTC_WGRAD_S3_FILL");
+        return e ? atoi(e) != 0 : false;
+    }();
+    return on;
+}
+
 int group_splits_s3(int M, int tiles_total) {
     static const char* target_env = getenv("DTC_WGRAD_S3_BLOCKS");
     // 768: eight batch slices for the 61..70-tile groups of the bench step.  Measured (tools/jobs/r3_sweep2.sh): 512..1536 within
     // 0.5 % of each other in step time, 2048 (32 slices) no faster; the partial slabs are HBM traffic written and read once
     // per slice, so the smallest count that still fills the chip wins (family traffic 1.30 -> 1.15 x the algorithmic bytes)
     const int target = target_env ? atoi(target_env) : 768;
-    int s = target / (tiles_total > 0 ? tiles_total : 1) / 8 * 8;
+    int s = target / (tiles_total > 0 ? tiles_total : 1);
+    if (!fill_slots()) s = s / 8 * 8;                 // the slice -> XCD map needs whole groups of eight
     if (s < 8) s = 8;
     const int max_s = (int)dtc::ceil_div(dtc::ceil_div(M, BK * 8), 8) * 8;
     if (s > max_s) s = max_s;
@@ -365,6 +385,7 @@ int plan_s3(const DtcWgradJob* jobs, int count, int M, void* workspace, S3Plan& 
     G.tiles_total = tiles;
     G.splits = group_splits_s3(M, tiles);
     G.rows_per_split = (int)dtc::ceil_div(dtc::ceil_div(M, G.splits), BK) * BK;
+    G.per_xcd = (G.splits % 8) ? (int)dtc::ceil_div((long long)G.splits * tiles, 8) : 0;
     long long off = 0;
     P.flop = P.algo_bytes = 0.0;
     for (int j = 0; j < count; ++j) {
@@ -399,7 +420,7 @@ extern "C" int dtc_wgrad_group_s3(const DtcWgradJob* jobs, int count, int M, voi
     const S3Group& G = P.dev;
     {
         dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, G.tiles_total, count), P.flop, s, P.algo_bytes);
-        const int grid = G.tiles_total * 8 * (int)dtc::ceil_div(G.splits, 8);
+        const int grid = G.per_xcd > 0 ? 8 * G.per_xcd : G.tiles_total * 8 * (int)dtc::ceil_div(G.splits, 8);
         bool any_rows = false;
         for (int j = 0; j < G.count; ++j) any_rows = any_rows || G.job[j].dz_rows > 0;
         if (any_rows) hipLaunchKernelGGL(wgrad_s3_group_kernel<true>, dim3(grid), dim3(256), 0, s, G);

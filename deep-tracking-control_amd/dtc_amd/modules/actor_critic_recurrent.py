@@ -370,6 +370,7 @@ class ActorCriticRecurrent(ActorCritic):
         return self.mlp_forward(layers, X, unpad_idx.numel(), flat.device), flat
 
     def act(self, observations, masks=None, hidden_states=None, unpad_idx=None, noise=None):
+        self.ensure_arena()                       # self.A / self.Cr exist from here on (first call on a fresh model)
         outs, _ = self._through(self.memory_a, self.A, observations, masks, hidden_states, unpad_idx)
         self._actor_outs = outs
         mean = outs[-1]
@@ -382,10 +383,12 @@ class ActorCriticRecurrent(ActorCritic):
         return actions
 
     def act_inference(self, observations):
+        self.ensure_arena()
         outs, _ = self._through(self.memory_a, self.A, observations, None, None, None)
         return outs[-1]
 
     def evaluate(self, critic_observations, masks=None, hidden_states=None, unpad_idx=None):
+        self.ensure_arena()
         outs, _ = self._through(self.memory_c, self.Cr, critic_observations, masks, hidden_states, unpad_idx)
         self._critic_outs = outs
         return outs[-1]
