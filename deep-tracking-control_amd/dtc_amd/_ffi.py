@@ -50,6 +50,10 @@ class DtcWimgJob(C.Structure):
                 ("trans", C.c_int32)]
 
 
+class DtcWgradImgJob(C.Structure):
+    _fields_ = [("dZimg", C.c_void_p), ("Ximg", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32)]
+
+
 class DtcPpoCfg(C.Structure):
     _fields_ = [("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float),
                 ("desired_kl", C.c_float), ("use_clipped_value_loss", C.c_int32),
@@ -76,7 +80,7 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 6          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 7          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
@@ -119,6 +123,16 @@ _SIGS = {
     "dtc_gru_s3_image": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, c_stream]),
     "dtc_gru_step_fwd_s3": (C.c_int, [c_f32p, C.c_void_p] + [c_f32p] * 5 + [C.c_int, C.c_int, c_stream]),
     "dtc_gru_dgrad_parts_s3": (C.c_int, [c_f32p, C.c_void_p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_s3_aimage_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "dtc_s3_aimage": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "dtc_linear_fwd_i3": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_linear_fwd_mse_i3": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, c_i64p, C.c_float, c_f32p,
+                                        C.c_int64, C.c_void_p, c_f64p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_linear_dgrad_i3": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_void_p, c_f32p, C.c_int64, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_wgrad_group_i3_workspace": (C.c_int64, [C.POINTER(DtcWgradImgJob), C.c_int, C.c_int]),
+    "dtc_wgrad_group_i3": (C.c_int, [C.POINTER(DtcWgradImgJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_linear_fwd_mse_s3_parts": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_linear_fwd_mse_s3": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, c_i64p,
                                         C.c_float, c_f32p, C.c_int64, c_f64p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
@@ -203,7 +217,7 @@ def _check_abi(l):
     """The loaded library must be the revision this binding describes: same ABI version, same by-value struct layouts
     (DTC_LIB may point at a separately built library, e.g. the ASan build: a stale one would misread every descriptor)."""
     global _lib
-    mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob]
+    mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcWgradImgJob]
     sizes = (C.c_int64 * 16)()
     n = l.dtc_abi_sizes(sizes, 16)
     theirs = list(sizes[:n])
