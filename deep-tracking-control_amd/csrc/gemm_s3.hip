@@ -105,12 +105,95 @@ __global__ __launch_bounds__(256) void wimage_kernel(const WimgGroup G) {
     for (int p = 0; p < 3; ++p) dst[p * 256 + rslot(r, h)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
 }
 
+// ---- activation-image results (round 4; the format and its consumers: see "ACTIVATION IMAGES" below) ----------------------------
+struct ImgOut {
+    u32x4* img;         // NULL: no image of the result
+    int stages;         // ceil(result columns / 16)
+};
+struct DgradEpiI3 {
+    float* dst;                   // fp32 destination [M, N] (may be NULL)
+    long long ldd;
+    int accumulate;               // result = dst + product (dst is only READ when an image is written: the sum goes to the image)
+    const float* Xs;              // saved post-activation output (act != none and no sign record)
+    long long ldxs;
+    const unsigned short* rmask;
+    int ldm;
+};
+
+// fp32 [M, K] (row stride lda) -> image; block = (row tile, stage), thread = (row, k half)
+__global__ __launch_bounds__(256) void aimage_kernel(const float* __restrict__ A, long long lda, int M, int K, u32x4* __restrict__ img, int stages) {
+    const int tr = blockIdx.x / stages, s = blockIdx.x - tr * stages;
+    const int r = threadIdx.x >> 1, h = threadIdx.x & 1;
+    const int row = tr * 128 + r, k0 = s * BK + 8 * h;
+    f32x4 v[2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = (row < M && k0 + e < K) ? A[(long long)row * lda + k0 + e] : 0.f;
+    const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
+    u32x4* dst = img + (long long)blockIdx.x * (WIMG_CHUNK / 16);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dst[p * 256 + rslot(r, h)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
+}
+
+// The wave's 32 x 32 tile sits in its LDS patch; lane -> rows (lane >> 2) + 16 q, the 8 columns 8 (lane & 3) .. + 7.  `fin(v, row, col)`
+// turns the 8 raw values of a row into final ones (activation derivative, accumulation, fp32 store); what it returns is split into
+// the image.  trow: the tile's first row inside its 128-row tile; col_t: its first result column.
+template <class F>
+__device__ __forceinline__ void patch_rows8(const float* patch, int lane, int tr, int trow, int col_t, int M, int N, const ImgOut& yo, F fin) {
+    const int r16 = lane >> 2, c8 = lane & 3;
+    const int col = col_t + 8 * c8;
+    u32x4* chunk = yo.img ? yo.img + ((long long)tr * yo.stages + (col >> 4)) * (WIMG_CHUNK / 16) : nullptr;
+    const bool in_img = yo.img && (col >> 4) < yo.stages && tr * 128 < M;      // (a 12-wave workgroup's row tiles behind the matrix have no chunk)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rl = r16 + 16 * q, row = tr * 128 + trow + rl;
+        f32x4 v[2] = {patch_get(patch, rl, 2 * c8), patch_get(patch, rl, 2 * c8 + 1)};
+        fin(v, row, col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = (row < M && col + e < N) ? v[e >> 2][e & 3] : 0.f;
+        if (in_img) {
+            const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) chunk[p * 256 + rslot(trow + rl, (col >> 3) & 1)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
+        }
+    }
+}
+// 8 consecutive floats of a row to / from global memory: two 16-byte accesses when the row allows it (aligned base, ld % 4 == 0,
+// all 8 inside the matrix), element-wise otherwise
+__device__ __forceinline__ void store8(float* base, long long ld, int row, int col, int M, int N, bool wide, const f32x4 (&v)[2]) {
+    if (row >= M) return;
+    float* p = base + (long long)row * ld + col;
+    if (wide && col + 8 <= N) {
+        *reinterpret_cast<f32x4*>(p) = v[0];
+        *reinterpret_cast<f32x4*>(p + 4) = v[1];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (col + e < N) p[e] = v[e >> 2][e & 3];
+    }
+}
+__device__ __forceinline__ void load8(const float* base, long long ld, int row, int col, int M, int N, bool wide, f32x4 (&v)[2]) {
+    v[0] = v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row >= M) return;
+    const float* p = base + (long long)row * ld + col;
+    if (wide && col + 8 <= N) {
+        v[0] = *reinterpret_cast<const f32x4*>(p);
+        v[1] = *reinterpret_cast<const f32x4*>(p + 4);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (col + e < N) v[e >> 2][e & 3] = p[e];
+    }
+}
+
 template <int EPI, bool WIMG>
 __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, const float* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ Y,
                                                            long long ldy, int M, int N, int K, int act, int wide,
                                                            unsigned short* __restrict__ wmask, int ldwm, const DgradEpi dg,
-                                                           const MseEpiS3 mse, const u32x4* __restrict__ wimg, long long wimg_bytes) {
+                                                           const MseEpiS3 mse, const u32x4* __restrict__ wimg, long long wimg_bytes,
+                                                           const ImgOut yo, int yo_seg) {
+    // yo.img != NULL (round 4): the result ALSO (EPI_FWD: Y may then be NULL) leaves as an activation image -- of the whole result
+    // (EPI_FWD) or of destination block yo_seg (EPI_DGRAD) -- for the image-operand kernels that consume it
     constexpr int BN = 128, WN = 2, TM = 2, TN = 2, NA = 2, NB = WIMG ? 0 : 2;
     __shared__ __attribute__((aligned(16))) u32x2 As[2][3][BM * 4];
     // two separate objects: the compiler then knows that an LDS-DMA into one stage buffer cannot alias the fragment reads of the
@@ -415,6 +498,38 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         return;
     }
     if constexpr (EPI == EPI_FWD) {
+        if (yo.img) {                                   // the epilogue of linear_i3_kernel: final values -> patch -> fp32 rows and / or image pieces
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn_off + 32 * j + l31;
+                const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+                if (wmask && full) {
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bits |= acc[i][j][r] > 0.f ? (1u << r) : 0u;
+                    wmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * ldwm + col] = (unsigned short)bits;
+                }
+                if (act == DTC_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : 0.f;
+                } else if (act == DTC_ACT_ELU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : expm1f(acc[i][j][r]);
+                } else if (act != DTC_ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], act);
+                }
+                patch_put(patch, acc[i][j], half, l31);
+                patch_rows8(patch, lane, tr, wm_off + 32 * i, n0 + wn_off + 32 * j, M, N, yo, [&](f32x4 (&v)[2], int row, int c) {
+                    if (Y) store8(Y, ldy, row, c, M, N, wide != 0, v);
+                });
+            }
+            return;
+        }
         if (wide && full) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -467,6 +582,73 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     } else {
         // ---- data-gradient epilogue: activation derivative, segmented destination (csrc/gemm.hip: linear_dgrad_kernel)
         const SegMatDev& dX = dg.dX;
+        if (yo.img) {
+            // every tile through the patch; lane -> 8 consecutive result columns of a row.  A group that lies inside ONE destination
+            // block takes 16-byte accesses (derivative through the saved output, accumulation, fp32 store) and, in block yo_seg, the
+            // image pieces; a group that straddles a block border (never in the image's block: its borders are multiples of 8) goes
+            // element by element.
+            const int r16 = lane >> 2, c8 = lane & 3;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (dg.rmask && full) {
+                    const unsigned bits = dg.rmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * dg.ldm + n0 + wn_off + 32 * j + l31];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = (bits >> r) & 1u ? acc[i][j][r] : 0.f;
+                }
+                patch_put(patch, acc[i][j], half, l31);
+                const int col = n0 + wn_off + 32 * j + 8 * c8;
+                if (col >= N) continue;
+                const int sj = find_seg(dX, col);
+                const SegDev sdj = dX.s[sj];
+                const bool whole = col + 8 <= sdj.start + sdj.width;
+                const bool w16 = whole && ((dg.wide_segs >> sj) & 1) && ((col - sdj.start + sdj.col0) & 3) == 0;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int rl = r16 + 16 * q, row = m0 + wm_off + 32 * i + rl;
+                    f32x4 v[2] = {patch_get(patch, rl, 2 * c8), patch_get(patch, rl, 2 * c8 + 1)};
+                    if (!dg.rmask && act != DTC_ACT_NONE) {         // (single destination block: host-checked)
+                        f32x4 y[2];
+                        load8(dg.Xs, dg.ldxs, row, col, M, N, ((dg.wide_segs >> 4) & 1) != 0, y);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = act_bwd(v[e >> 2][e & 3], y[e >> 2][e & 3], act);
+                    }
+                    if (whole) {
+                        const int lc = col - sdj.start;             // column inside the block
+                        float* base = sdj.ptr ? sdj.ptr + sdj.col0 - 0 : nullptr;
+                        if (sdj.ptr && sdj.accumulate) {
+                            f32x4 o[2];
+                            load8(base, sdj.ld, row, lc, M, sdj.width, w16, o);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = o[e >> 2][e & 3] + v[e >> 2][e & 3];
+                        }
+                        const bool to_img = sj == yo_seg;
+                        if (sdj.ptr && !(sdj.accumulate && to_img)) store8(base, sdj.ld, row, lc, M, sdj.width, w16, v);
+                        if (to_img && (lc >> 4) < yo.stages) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = (row < M) ? v[e >> 2][e & 3] : 0.f;
+                            const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
+                            u32x4* chunk = yo.img + ((long long)tr * yo.stages + (lc >> 4)) * (WIMG_CHUNK / 16);
+#pragma unroll
+                            for (int p = 0; p < 3; ++p)
+                                chunk[p * 256 + rslot(wm_off + 32 * i + rl, (lc >> 3) & 1)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
+                        }
+                    } else if (row < M) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int c = col + e;
+                            if (c >= N) break;
+                            const SegDev sc = dX.s[find_seg(dX, c)];
+                            if (sc.ptr == nullptr) continue;
+                            float* qd = sc.ptr + sc.col0 + (c - sc.start) + (long long)row * sc.ld;
+                            *qd = sc.accumulate ? (*qd + v[e >> 2][e & 3]) : v[e >> 2][e & 3];
+                        }
+                    }
+                }
+            }
+            return;
+        }
         if (dg.rmask && full) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -632,8 +814,17 @@ extern "C" int64_t dtc_s3_planes_bytes(int N, int K) {
 // Y = act(X W^T + b) [+ the ReLU sign record when relu_mask != NULL] on the split-precision path
 extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
                                  void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream) {
-    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
-    DTC_REQUIRE(W && Y, "null pointer");
+    DTC_REQUIRE(Y, "null pointer");
+    return dtc_linear_fwd_s3i(X, W, b, Y, ldy, nullptr, relu_mask, wplanes, wimage_ready, M, N, K, act, stream);
+}
+
+// dtc_linear_fwd_s3 whose result also (Y != NULL) or only (Y == NULL) leaves as the activation image Yimg = image(M, N)
+extern "C" int dtc_linear_fwd_s3i(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
+                                  void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && (Y == nullptr || ldy >= N), "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
+    DTC_REQUIRE(W && (Y || Yimg) && dtc::aligned16(Yimg), "null / unaligned pointer");
+    DTC_REQUIRE(Yimg == nullptr || dtc_s3_aimage_bytes(M, N) < (1ll << 31), "image beyond 2 GiB");
+    const ImgOut yo{(u32x4*)Yimg, (int)dtc::ceil_div(N, BK)};
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
     DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * ldy <= MAX_ELEMS * 4, "matrix too large");
     SegMatDev xd;
@@ -641,18 +832,18 @@ extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128));
-    const int wide = (ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
+    const int wide = (Y && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
     if (relu_mask)
-        DTC_REQUIRE(act == DTC_ACT_RELU && wide && M % BM == 0 && N % 128 == 0, "sign record (split path): M=%d and N=%d must be multiples of 128", M, N);
+        DTC_REQUIRE(act == DTC_ACT_RELU && (wide || Yimg) && M % BM == 0 && N % 128 == 0, "sign record (split path): M=%d and N=%d must be multiples of 128", M, N);
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     if (wimage_on()) {
         DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
         const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
-                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)wplanes, ib);
+                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)wplanes, ib, yo, 0);
     } else {
         hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
-                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)nullptr, 0ll);
+                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)nullptr, 0ll, yo, 0);
     }
     return dtc::check_launch("linear_fwd_s3");
 }
@@ -663,6 +854,14 @@ extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float
 extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved,
                                    int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
                                    void* stream) {
+    return dtc_linear_dgrad_s3i(dZ, lddz, W, dX, nullptr, 0, Xsaved, ldxs, relu_mask, wplanes, wimage_ready, M, N, K, act, stream);
+}
+
+// dtc_linear_dgrad_s3 whose destination block `img_seg` (its first column and width multiples of 8 / 16) ALSO leaves as the activation
+// image dXimg = image(M, width of the block); a block that accumulates is then only read (the sum exists as the image)
+extern "C" int dtc_linear_dgrad_s3i(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, void* dXimg, int img_seg,
+                                    const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N,
+                                    int K, int act, void* stream) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
     DTC_REQUIRE(dZ && W && wplanes && dtc::aligned16(wplanes), "null pointer / unaligned scratch");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
@@ -683,6 +882,14 @@ extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W
     dg.col_skip = col_skip;
     dg.wide_segs = wide_mask_s3(dg.dX, dg.Xs, ldxs, col_skip);
     if (relu_mask) DTC_REQUIRE(M % BM == 0 && K % 128 == 0 && col_skip == 0, "sign record (split path): M=%d and K=%d must be multiples of 128", M, K);
+    ImgOut yo{nullptr, 0};
+    if (dXimg) {
+        DTC_REQUIRE(dtc::aligned16(dXimg) && img_seg >= 0 && img_seg < dg.dX.nseg, "image block %d outside the destination's %d blocks", img_seg, dg.dX.nseg);
+        const SegDev& sg = dg.dX.s[img_seg];
+        DTC_REQUIRE(sg.start % 8 == 0 && sg.width % 16 == 0 && sg.start >= col_skip, "image block: first column %d / width %d must be multiples of 8 / 16", sg.start, sg.width);
+        DTC_REQUIRE(dtc_s3_aimage_bytes(M, sg.width) < (1ll << 31), "image beyond 2 GiB");
+        yo = ImgOut{(u32x4*)dXimg, sg.width / BK};
+    }
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K - col_skip, 128));
     double bytes = 4.0 * ((double)M * N + (double)N * K);
@@ -696,13 +903,13 @@ extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W
         const long long ib = build_wimage(W, wplanes, K, col_skip, K, 1, zin, (int)dtc::ceil_div(K - col_skip, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, true>), dim3(grid), dim3(256), 0, s, zin, (const float*)nullptr, (const float*)nullptr,
                            (float*)nullptr, 0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{},
-                           (const u32x4*)wplanes, ib);
+                           (const u32x4*)wplanes, ib, yo, img_seg);
     } else {
         float* WT = (float*)wplanes;
         hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dtc::ceil_div(K, 32), (unsigned)dtc::ceil_div(N, 32)), dim3(256), 0, s, W, WT, N, K);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, false>), dim3(grid), dim3(256), 0, s, zin, (const float*)WT, (const float*)nullptr,
                            (float*)nullptr, 0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{},
-                           (const u32x4*)nullptr, 0ll);
+                           (const u32x4*)nullptr, 0ll, yo, img_seg);
     }
     return dtc::check_launch("linear_dgrad_s3");
 }
@@ -733,10 +940,10 @@ extern "C" int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const f
         DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
         const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE, true>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
-                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)wplanes, ib);
+                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)wplanes, ib, ImgOut{nullptr, 0}, 0);
     } else {
         hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE, false>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
-                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)nullptr, 0ll);
+                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)nullptr, 0ll, ImgOut{nullptr, 0}, 0);
     }
     return dtc::check_launch("linear_fwd_mse_s3");
 }
@@ -795,85 +1002,6 @@ extern "C" int dtc_s3_wimage_group(const DtcWimgJob* jobs, int count, void* stre
 // operand registers.  Rows >= M and columns >= K of an image are zero (the producers write whole chunks).
 //   image(M, K): ceil(M / 128) x ceil(K / 16) chunks; chunk (r, s) at ((r * stages + s) * 12 KiB).
 namespace {
-
-struct ImgOut {
-    u32x4* img;         // NULL: no image of the result
-    int stages;         // ceil(result columns / 16)
-};
-struct DgradEpiI3 {
-    float* dst;                   // fp32 destination [M, N] (may be NULL)
-    long long ldd;
-    int accumulate;               // result = dst + product (dst is only READ when an image is written: the sum goes to the image)
-    const float* Xs;              // saved post-activation output (act != none and no sign record)
-    long long ldxs;
-    const unsigned short* rmask;
-    int ldm;
-};
-
-// fp32 [M, K] (row stride lda) -> image; block = (row tile, stage), thread = (row, k half)
-__global__ __launch_bounds__(256) void aimage_kernel(const float* __restrict__ A, long long lda, int M, int K, u32x4* __restrict__ img, int stages) {
-    const int tr = blockIdx.x / stages, s = blockIdx.x - tr * stages;
-    const int r = threadIdx.x >> 1, h = threadIdx.x & 1;
-    const int row = tr * 128 + r, k0 = s * BK + 8 * h;
-    f32x4 v[2];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = (row < M && k0 + e < K) ? A[(long long)row * lda + k0 + e] : 0.f;
-    const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
-    u32x4* dst = img + (long long)blockIdx.x * (WIMG_CHUNK / 16);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) dst[p * 256 + rslot(r, h)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
-}
-
-// The wave's 32 x 32 tile sits in its LDS patch; lane -> rows (lane >> 2) + 16 q, the 8 columns 8 (lane & 3) .. + 7.  `fin(v, row, col)`
-// turns the 8 raw values of a row into final ones (activation derivative, accumulation, fp32 store); what it returns is split into
-// the image.  trow: the tile's first row inside its 128-row tile; col_t: its first result column.
-template <class F>
-__device__ __forceinline__ void patch_rows8(const float* patch, int lane, int tr, int trow, int col_t, int M, int N, const ImgOut& yo, F fin) {
-    const int r16 = lane >> 2, c8 = lane & 3;
-    const int col = col_t + 8 * c8;
-    u32x4* chunk = yo.img ? yo.img + ((long long)tr * yo.stages + (col >> 4)) * (WIMG_CHUNK / 16) : nullptr;
-    const bool in_img = yo.img && (col >> 4) < yo.stages && tr * 128 < M;      // (a 12-wave workgroup's row tiles behind the matrix have no chunk)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int rl = r16 + 16 * q, row = tr * 128 + trow + rl;
-        f32x4 v[2] = {patch_get(patch, rl, 2 * c8), patch_get(patch, rl, 2 * c8 + 1)};
-        fin(v, row, col);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = (row < M && col + e < N) ? v[e >> 2][e & 3] : 0.f;
-        if (in_img) {
-            const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) chunk[p * 256 + rslot(trow + rl, (col >> 3) & 1)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
-        }
-    }
-}
-// 8 consecutive floats of a row to / from global memory: two 16-byte accesses when the row allows it (aligned base, ld % 4 == 0,
-// all 8 inside the matrix), element-wise otherwise
-__device__ __forceinline__ void store8(float* base, long long ld, int row, int col, int M, int N, bool wide, const f32x4 (&v)[2]) {
-    if (row >= M) return;
-    float* p = base + (long long)row * ld + col;
-    if (wide && col + 8 <= N) {
-        *reinterpret_cast<f32x4*>(p) = v[0];
-        *reinterpret_cast<f32x4*>(p + 4) = v[1];
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (col + e < N) p[e] = v[e >> 2][e & 3];
-    }
-}
-__device__ __forceinline__ void load8(const float* base, long long ld, int row, int col, int M, int N, bool wide, f32x4 (&v)[2]) {
-    v[0] = v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row >= M) return;
-    const float* p = base + (long long)row * ld + col;
-    if (wide && col + 8 <= N) {
-        v[0] = *reinterpret_cast<const f32x4*>(p);
-        v[1] = *reinterpret_cast<const f32x4*>(p + 4);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (col + e < N) v[e >> 2][e & 3] = p[e];
-    }
-}
 
 // Both operands as images.  EPI_FWD: Y = act(X W^T + b) as fp32 (Y != NULL) and / or as an image (yo.img), sign record optional.
 // EPI_MSE: the loss epilogue of dtc_linear_fwd_mse.  EPI_DGRAD: dX = (dZ W) * act'(.), single destination (dg).

@@ -221,12 +221,20 @@ def pack_cols(X, dst, rows=None):
     return dst
 
 
-def linear_fwd(X, W, b, Y, act=None, M=None, mask=None, split=None):
+def linear_fwd(X, W, b, Y, act=None, M=None, mask=None, split=None, Yimg=None):
     """Y = act(X W^T + b).  X: tensor or DtcSegMat; W [N,K]; Y [M,>=N] (row stride may exceed N).  `mask` (relu_mask
-    buffer, act must be "relu"): also record the output signs for linear_dgrad(..., mask=)."""
+    buffer, act must be "relu"): also record the output signs for linear_dgrad(..., mask=).  `Yimg` (AImage [M, N], split path only):
+    the result also (Y given) or only (Y None) leaves as the activation image the image-operand kernels read."""
     Xs = as_segmat(X)
     N, K = W.shape
-    M = Y.shape[0] if M is None else M
+    M = (Y.shape[0] if Y is not None else Yimg.M) if M is None else M
+    if Yimg is not None:
+        assert (Yimg.M, Yimg.K) == (M, N)
+        img, ready = _wimage(W, Xs, N, K, 0)
+        check(lib().dtc_linear_fwd_s3i(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y) if Y is not None else None,
+                                       Y.stride(0) if Y is not None else 0, Yimg.ptr(), ptr(mask) if mask is not None else None, ptr(img), ready,
+                                       M, N, K, ACT[act], stream()), "dtc_linear_fwd_s3i")
+        return Y
     if (SPLIT if split is None else split) and (split or (N >= SPLIT_MIN_COLS and K >= SPLIT_MIN_RED)) and (mask is None or N % 128 == 0):
         img, ready = _wimage(W, Xs, N, K, 0)
         check(lib().dtc_linear_fwd_s3(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
@@ -274,12 +282,20 @@ class FwdChain:
               "dtc_linear_fwd_list")
 
 
-def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None):
+def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None, dXimg=None, img_seg=0):
     """dX = (dZ W) * act'(Xsaved); dX: tensor or DtcSegMat (destination).  `mask`: the sign record of the ReLU layer that
-    produced Xsaved (then Xsaved itself is not read)."""
+    produced Xsaved (then Xsaved itself is not read).  `dXimg` (AImage, split path only): destination block `img_seg` also leaves as
+    an activation image (an accumulating block is then only read: the sum exists as the image)."""
     dXs = as_segmat(dX)
     N, K = W.shape
     M = dZ.shape[0] if M is None else M
+    if dXimg is not None:
+        assert dXimg.M == M and dXimg.K == dXs.seg[img_seg].width
+        img, ready = _wimage(W, dXs, N, K, 1)
+        check(lib().dtc_linear_dgrad_s3i(ptr(dZ), dZ.stride(0), cptr(W, f32), dXs, dXimg.ptr(), img_seg, ptr(Xsaved) if mask is None else None,
+                                         Xsaved.stride(0) if Xsaved is not None else 0, ptr(mask) if mask is not None else None,
+                                         ptr(img), ready, M, N, K, ACT[act] if mask is None else ACT["relu"], stream()), "dtc_linear_dgrad_s3i")
+        return
     if (SPLIT if split is None else split) and (split or (K >= SPLIT_MIN_COLS and N >= SPLIT_MIN_RED)) and (mask is None or K % 128 == 0):
         img, ready = _wimage(W, dXs, N, K, 1)
         check(lib().dtc_linear_dgrad_s3(ptr(dZ), dZ.stride(0), cptr(W, f32), dXs, ptr(Xsaved) if mask is None else None,

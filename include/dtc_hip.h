@@ -252,6 +252,14 @@ int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W, const Dtc
  * dtc_s3_aimage_bytes(M, K) bytes (< 2 GiB). */
 int64_t dtc_s3_aimage_bytes(int M, int K);
 int dtc_s3_aimage(const float* A, int64_t lda, int M, int K, void* img, void* stream);
+/* dtc_linear_fwd_s3 / dtc_linear_dgrad_s3 (fp32 row operand, converted in the K loop: gathered / segmented inputs) whose result also
+ * leaves as an image.  Forward: Y may be NULL (image only).  Data gradient: destination block `img_seg` of dX (first column / width
+ * multiples of 8 / 16) as dXimg = image(M, width); a block that accumulates is then only read. */
+int dtc_linear_fwd_s3i(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
+                       void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream);
+int dtc_linear_dgrad_s3i(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, void* dXimg, int img_seg, const float* Xsaved,
+                         int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
+                         void* stream);
 /* dtc_linear_fwd_s3 with X = image(M, K); results: Y fp32 (may be NULL) and / or Yimg = image(M, N) (may be NULL), one at least */
 int dtc_linear_fwd_i3(const void* Ximg, const float* W, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
                       void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream);

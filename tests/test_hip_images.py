@@ -186,3 +186,60 @@ def test_weight_gradients_from_images(M, layers):
         eb3, ebi = _err(s3[3], rb.cpu()), _err(i3[3], rb.cpu())
         print(f"wgrad {M}x{N}x{K}: dW split {eW3:.2e} image {eWi:.2e};  db split {eb3:.2e} image {ebi:.2e}")
         assert eWi <= 2.0 * eW3 + 2e-7 and ebi <= 2.0 * eb3 + 3e-7
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1024, 512, 693, "relu"), (384, 512, 584, "elu"), (300, 256, 140, None)])
+def test_converting_forward_kernel_writes_images_too(M, N, K, act):
+    """linear_s3_kernel (fp32 / gathered / segmented X, converted in its K loop) with an image result: the hand-over from the fp32 inputs
+    of a stack (terrain heights, packed observations) into the image chain."""
+    from dtc_amd import _ffi, ops
+    g = torch.Generator().manual_seed(M + K)
+    R = 3 * M
+    src, W, b = torch.randn(R, K, generator=g).to(DEV), (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV), torch.randn(N, generator=g).to(DEV)
+    idx = torch.randint(0, R, (M,), generator=g).to(DEV)
+    X = _ffi.segmat([_ffi.seg(src, 0, K, gather=True)], idx)
+    y0 = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(X, W, b, y0, act, M=M, split=True)
+    y1, img, img2 = torch.full((M, N), float("nan"), device=DEV), ops.AImage(M, N, DEV), ops.AImage(M, N, DEV)
+    mask = ops.relu_mask(M, N, DEV) if (act == "relu" and M % 128 == 0 and N % 128 == 0) else None
+    ops.linear_fwd(X, W, b, y1, act, M=M, Yimg=img, mask=mask)
+    ops.linear_fwd(X, W, b, None, act, M=M, Yimg=img2, mask=mask)
+    assert torch.equal(y0, y1) and torch.equal(img.buf.view(torch.int64), img2.buf.view(torch.int64))
+    _same_as_fp32(img, y1)
+
+
+def test_converting_data_gradient_writes_the_image_of_one_destination_block():
+    """The actor's first layer (ppo.py:333 backward through actor_body[0]): destination [None 53 | dz 16 | dmu 3 (accumulating) | dlt 512],
+    with dlt leaving as an image for the terrain encoder's image-operand backward."""
+    from dtc_amd import _ffi, ops
+    g = torch.Generator().manual_seed(8)
+    B = 384
+    dZ = torch.randn(B, 512, generator=g).to(DEV)
+    Wa = (torch.randn(512, 584, generator=g) / 22.0).to(DEV)
+    full = (dZ.double() @ Wa.double()).cpu()
+    mk = lambda: (torch.zeros(B, 16, device=DEV), torch.full((B, 35), 0.5, device=DEV), torch.empty(B, 512, device=DEV))
+    dz0, dmu0, dlt0 = mk()
+    ops.linear_dgrad(dZ, Wa, _ffi.segmat([_ffi.seg(None, 0, 53), _ffi.seg(dz0, 0, 16), _ffi.seg(dmu0, 0, 3, accumulate=True), _ffi.seg(dlt0, 0, 512)]), split=True)
+    dz1, dmu1, dlt1 = mk()
+    img = ops.AImage(B, 512, DEV)
+    ops.linear_dgrad(dZ, Wa, _ffi.segmat([_ffi.seg(None, 0, 53), _ffi.seg(dz1, 0, 16), _ffi.seg(dmu1, 0, 3, accumulate=True), _ffi.seg(dlt1, 0, 512)]),
+                     dXimg=img, img_seg=3)
+    assert torch.equal(dz0, dz1) and torch.equal(dmu0, dmu1) and torch.equal(dlt0, dlt1)
+    np.testing.assert_allclose(dlt1.cpu().numpy(), full[:, 72:].numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(dmu1.cpu().numpy()[:, :3], 0.5 + full[:, 69:72].numpy(), rtol=2e-5, atol=2e-5)
+    _same_as_fp32(img, dlt1)
+    # accumulating image block: fp32 only read, the sum in the image; single block with the ELU derivative
+    old = torch.randn(B, 512, generator=g).to(DEV)
+    dst, img2 = old.clone(), ops.AImage(B, 512, DEV)
+    Wt = (torch.randn(512, 512, generator=g) / 22.0).to(DEV)
+    ops.linear_dgrad(dZ, Wt, _ffi.segmat([_ffi.seg(dst, 0, 512, accumulate=True)]), dXimg=img2, img_seg=0)
+    assert torch.equal(dst, old)
+    want = old.clone()
+    ops.linear_dgrad(dZ, Wt, _ffi.segmat([_ffi.seg(want, 0, 512, accumulate=True)]), split=True)
+    _same_as_fp32(img2, want)
+    Xs = torch.nn.functional.elu(torch.randn(B, 512, generator=g)).to(DEV)
+    d0, d1, img3 = torch.empty(B, 512, device=DEV), torch.empty(B, 512, device=DEV), ops.AImage(B, 512, DEV)
+    ops.linear_dgrad(dZ, Wt, d0, Xs, "elu", split=True)
+    ops.linear_dgrad(dZ, Wt, d1, Xs, "elu", dXimg=img3)
+    assert torch.equal(d0, d1)
+    _same_as_fp32(img3, d1)
