@@ -1277,9 +1277,11 @@ int i3_row_tiles(int M, int cols) {
         const char* e = getenv("DTC_I3_RT");
         return e ? atoi(e) : 0;
     }();
-    if (forced == 1 || forced == 3) return forced;
-    const long long wgs = dtc::ceil_div(M, 384) * dtc::ceil_div(cols, 128);
-    return wgs >= 224 ? 3 : 1;
+    // measured (tools/img_probe.py, DTC_I3_RT=1 / 3): 24576 x 512 x 512 64.4 vs 66.7 us for 3 (256 workgroups: one per CU), but 24576 x 693
+    // x 512 147.6 vs 122.0 (384 workgroups: a round and a half) and 256-wide layers 49 vs 41 (half the CUs): the default is 1
+    (void)M;
+    (void)cols;
+    return forced == 3 ? 3 : 1;
 }
 template <int EPI, typename... Args>
 void launch_i3(int M, int cols, hipStream_t s, Args... args) {

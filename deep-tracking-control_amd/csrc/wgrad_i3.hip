@@ -253,11 +253,20 @@ struct I3Plan {
     double flop, algo_bytes;
 };
 
+int split_cap() {
+    static const int cap = [] {
+        const char* e = getenv("DTC_WGRAD_SPLIT_CAP");
+        return e ? atoi(e) : 24;
+    }();
+    return cap;
+}
+
 int i3_splits(int M, int tiles_total) {
     static const char* target_env = getenv("DTC_WGRAD_I3_BLOCKS");
     const int target = target_env ? atoi(target_env) : 768;     // one residency round of 3 workgroups per CU (as wgrad_s3_group_kernel)
     int s = target / (tiles_total > 0 ? tiles_total : 1) / 8 * 8;
     if (s < 8) s = 8;
+    if (s > split_cap()) s = split_cap();               // small groups: bounded slab traffic (64 KiB per tile and slice, written and re-read)
     const int max_s = (int)dtc::ceil_div(dtc::ceil_div(M, BK * 8), 8) * 8;
     if (s > max_s) s = max_s;
     return s;

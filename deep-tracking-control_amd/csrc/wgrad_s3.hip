@@ -331,6 +331,14 @@ bool fill_slots() {
     return on;
 }
 
+int split_cap() {
+    static const int cap = [] {
+        const char* e = getenv("DTC_WGRAD_SPLIT_CAP");
+        return e ? atoi(e) : 24;
+    }();
+    return cap;
+}
+
 int group_splits_s3(int M, int tiles_total) {
     static const char* target_env = getenv("DTC_WGRAD_S3_BLOCKS");
     // 768: eight batch slices for the 61..70-tile groups of the bench step.  Measured (tools/jobs/r3_sweep2.sh): 512..1536 within
@@ -340,6 +348,7 @@ int group_splits_s3(int M, int tiles_total) {
     int s = target / (tiles_total > 0 ? tiles_total : 1);
     if (!fill_slots()) s = s / 8 * 8;                 // the slice -> XCD map needs whole groups of eight
     if (s < 8) s = 8;
+    if (s > split_cap()) s = split_cap();               // small groups: bounded slab traffic (64 KiB per tile and slice, written and re-read)
     const int max_s = (int)dtc::ceil_div(dtc::ceil_div(M, BK * 8), 8) * 8;
     if (s > max_s) s = max_s;
     return s;

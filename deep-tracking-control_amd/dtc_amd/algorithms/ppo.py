@@ -196,8 +196,28 @@ class _TrainWorkspace(_Lanes):
         self.wg = ops.workspace(max(lib.dtc_linear_wgrad_workspace(B, n, k) for n, k in shapes), dev)
         self.loss_ws = ops.workspace(lib.dtc_loss_workspace(B), dev)
         self.hpart = torch.zeros(int(lib.dtc_linear_fwd_mse_parts(B, 693)), dtype=torch.float64, device=dev)
-        self.gws = None
+        self.gws = self.gws_img = None
         self.pending, self.held = [], []      # queued weight-gradient jobs; operands of flushed jobs (alive until the join)
+        self.pending_img = []                 # queued weight-gradient jobs whose operands are activation images
+        self._imgs, self.live_img = {}, set()
+
+    def img(self, name, width=None):
+        """Activation image (ops.AImage) of the [B, width] activation / gradient `name`, allocated on first use."""
+        im = self._imgs.get(name)
+        if im is None:
+            im = self._imgs[name] = ops.AImage(self.B, width, self._dev)
+        return im
+
+    def value(self, name):
+        """fp32 view for tests: decoded from the image when the last step kept `name` as an image only."""
+        return self._imgs[name].to_tensor() if name in self.live_img else getattr(self, name)
+
+    def group_ws_img(self, jobs):
+        need = ops.wgrad_group_img_workspace_bytes(jobs, self.B)
+        if self.gws_img is None or self.gws_img.numel() * self.gws_img.element_size() < need:
+            torch.cuda.synchronize()
+            self.gws_img = ops.workspace(need, self._dev)
+        return self.gws_img
 
     MAX_GROUP = 12           # jobs per grouped weight-gradient launch (MAX_JOBS of csrc/wgrad.hip)
 
@@ -278,6 +298,8 @@ class PPO:
         # 4-byte activation (DTC_RELU_MASK=0: derivative through the saved activations; bit-identical results)
         self.relu_masks = os.environ.get("DTC_RELU_MASK", "1") != "0"
         self.pack_inputs = os.environ.get("DTC_PACK_INPUTS", "1") != "0"
+        # hidden activations / gradients of the wide stacks as activation images (ops.AImage; DTC_IMAGES=0: fp32 everywhere)
+        self.use_images = ops.IMAGES
         # tests: callable(fw, which) run between the forward and the backward pass of a step ("vae" | "ppo"); the parity tests
         # use it to teacher-force the ReLU sign records (fw.relu_mask buffers) so that fp32 knife edges -- pre-activations that
         # are 0 within rounding and land on different sides in two correct implementations -- do not enter the gradient comparison
@@ -437,7 +459,21 @@ class PPO:
             stats[S_KL:S_KL + 1].copy_(kl)
             ops.lr_adapt(kl, self.optimizer.lr_dev, float(self.desired_kl))
 
-    def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None, mask=None):
+    def _image_mode(self, fw):
+        """This step keeps the wide hidden activations / gradients as images (see ActorCriticDecoder.images_ok)."""
+        return (self.use_images and self.relu_masks and self.group_wgrad and self.fuse_height_loss and self.actor_critic.images_ok(fw)
+                and fw.relu_mask("t1", 512) is not None)
+
+    def _bwd_img(self, tw, L, dZimg, Ximg, dX=None, dXimg=None, accumulate=False, Xsaved=None, act_prev=None, mask=None):
+        """_bwd for a layer whose output gradient dZ and input X are activation images: the weight gradient is queued for the
+        bucket's image-operand grouped launch, the data gradient (fp32 `dX` and / or image `dXimg`) runs on the image-operand kernel."""
+        tw.pending_img.append((dZimg, Ximg, L.gW, L.gb))
+        if len(tw.pending_img) == tw.MAX_GROUP:
+            self._flush_wgrads(tw)
+        if dX is not None or dXimg is not None:
+            ops.linear_dgrad_img(dZimg, L.W, dX, dXimg, accumulate=accumulate, Xsaved=Xsaved, act=act_prev, mask=mask)
+
+    def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None, mask=None, dXimg=None, img_seg=0):
         """Backward of one dense layer.  The weight gradient (dW = dZ^T X) is off the critical path -- only the
         optimiser step (and the data-parallel exchange) needs it -- so it is QUEUED: `_flush_wgrads` runs all queued
         layers of a gradient bucket as one grouped launch on the side stream, where it overlaps with the data-gradient
@@ -455,24 +491,30 @@ class PPO:
         else:
             ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wgrad_ws(L.n_out, L.n_in), M=tw.B)
         if dX is not None:
-            ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B, mask=mask)
+            ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B, mask=mask, dXimg=dXimg, img_seg=img_seg)
 
     def _flush_wgrads(self, tw):
-        """Launch the queued weight gradients (everything both compute lanes have issued so far is their input)."""
-        if not tw.pending:
+        """Launch the queued weight gradients (everything both compute lanes have issued so far is their input): one grouped
+        launch for the layers with fp32 operands, one for the layers whose operands are activation images."""
+        if not tw.pending and not tw.pending_img:
             return
         jobs, tw.pending = tw.pending, []
-        ws = tw.group_ws(jobs)
+        jobs_img, tw.pending_img = tw.pending_img, []
+        ws = tw.group_ws(jobs) if jobs else None
+        ws_img = tw.group_ws_img(jobs_img) if jobs_img else None
+        sp = None
         if self.overlap_wgrad:
             lanes = (tw.main, tw.aux) if tw.two_lanes else (torch.cuda.current_stream(),)
             for lane in lanes:
                 ev = tw.event()
                 ev.record(lane)
                 tw.side.wait_event(ev)
-            tw.held.append(ops.wgrad_group(jobs, tw.B, ws, stream_ptr=tw.side.cuda_stream))
+            sp = tw.side.cuda_stream
             tw.side_busy = True
-        else:
-            tw.held.append(ops.wgrad_group(jobs, tw.B, ws))
+        if jobs_img:
+            tw.held.append(ops.wgrad_group_img(jobs_img, tw.B, ws_img, stream_ptr=sp))
+        if jobs:
+            tw.held.append(ops.wgrad_group(jobs, tw.B, ws, stream_ptr=sp))
 
     def _join(self, tw):
         self._flush_wgrads(tw)
@@ -483,6 +525,15 @@ class PPO:
         L = self.actor_critic.L
         g_te2, g_te1 = tw.g("te2", 512), tw.g("te1", 512)
         rm = self.relu_masks
+        if "dlt" in tw.live_img and {"t1", "t2"} <= fw.live_img:
+            # image chain: d l_t arrived as an image (the decoders' / the actor's data gradient wrote it), t1 / t2 are images; the
+            # first layer's input are the gathered fp32 heights, so its output gradient leaves as fp32
+            g_te2i = tw.img("g_te2", L["te2"].n_in)
+            self._bwd_img(tw, L["te2"], tw.img("dlt"), fw.img("t2"), dXimg=g_te2i, mask=fw.relu_mask("t2", 512, rm))
+            self._bwd_img(tw, L["te1"], g_te2i, fw.img("t1"), dX=g_te1, mask=fw.relu_mask("t1", 512, rm))
+            self._bwd(tw, L["te0"], g_te1, segmat([seg(flat["privileged_observations"], 0, 693, gather=True)], idx))
+            tw.live_img |= {"g_te2"}
+            return
         self._bwd(tw, L["te2"], tw.dlt, fw.t2, g_te2, fw.t2, "relu", fw.relu_mask("t2", 512, rm))
         self._bwd(tw, L["te1"], g_te2, fw.t1, g_te1, fw.t1, "relu", fw.relu_mask("t1", 512, rm))
         self._bwd(tw, L["te0"], g_te1, segmat([seg(flat["privileged_observations"], 0, 693, gather=True)], idx))
@@ -526,16 +577,24 @@ class PPO:
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
         dec_in = segmat([seg(fw.z, 0, 16), seg(fw.mulv, 0, 3), seg(fw.lt, 0, 512)])
         rm = self.relu_masks
+        im = self._image_mode(fw)
+        tw.live_img.clear()
         with tw.lane("aux"):
             ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=rm)
-        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=rm)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=rm, images=im, lt_img=im)
         tw.order("main", "aux")                                    # l_t feeds the CE-net decoder
         with tw.lane("aux"):
             ops.linear_fwd(dec_in, L["cd0"].W, L["cd0"].b, tw.c1, "relu", M=tw.B, mask=fw.relu_mask("c1", 64, rm))
             ops.linear_fwd(tw.c1, L["cd1"].W, L["cd1"].b, tw.c2, "relu", mask=fw.relu_mask("c2", 128, rm))
             ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None)
-        ops.linear_fwd(fw.lt, L["td0"].W, L["td0"].b, tw.d1, "relu", mask=fw.relu_mask("d1", 512, rm))
-        ops.linear_fwd(tw.d1, L["td1"].W, L["td1"].b, tw.d2, "relu", mask=fw.relu_mask("d2", 512, rm))
+        if im:                                                     # terrain decoder on images: d1 / d2 never exist as fp32
+            d1i, d2i = tw.img("d1", L["td0"].n_out), tw.img("d2", L["td1"].n_out)
+            ops.linear_fwd_img(fw.img("lt"), L["td0"].W, L["td0"].b, None, d1i, "relu", mask=fw.relu_mask("d1", 512, rm))
+            ops.linear_fwd_img(d1i, L["td1"].W, L["td1"].b, None, d2i, "relu", mask=fw.relu_mask("d2", 512, rm))
+            tw.live_img |= {"d1", "d2"}
+        else:
+            ops.linear_fwd(fw.lt, L["td0"].W, L["td0"].b, tw.d1, "relu", mask=fw.relu_mask("d1", 512, rm))
+            ops.linear_fwd(tw.d1, L["td1"].W, L["td1"].b, tw.d2, "relu", mask=fw.relu_mask("d2", 512, rm))
         if self.after_forward_hook is not None:
             self.after_forward_hook(fw, "vae")
         # The loss kernel joins the two branches, but only the CE-net decoder's backward needs its output (dL/d recons,
@@ -544,7 +603,12 @@ class PPO:
         if self.fuse_height_loss:
             # output layer of the terrain decoder + its MSE against priv[..., 696:] in one kernel: dL/d height_recon comes
             # out of the GEMM epilogue, height_recon itself never reaches HBM
-            n_hp = ops.linear_fwd_mse(tw.d2, L["td2"].W, L["td2"].b, flat["privileged_observations"], 696, idx, tw.g_hr, tw.hpart)
+            if im:                                                 # dL/d height_recon leaves as an image only (its two consumers read images)
+                n_hp = ops.linear_fwd_mse_img(tw.img("d2"), L["td2"].W, L["td2"].b, flat["privileged_observations"], 696, idx, None,
+                                              tw.img("g_hr", L["td2"].n_out), tw.hpart)
+                tw.live_img |= {"g_hr"}
+            else:
+                n_hp = ops.linear_fwd_mse(tw.d2, L["td2"].W, L["td2"].b, flat["privileged_observations"], 696, idx, tw.g_hr, tw.hpart)
             tw.order("main", "aux")
             with tw.lane("aux"):
                 ops.vae_loss_fused(tw.rec, fw.mulv, flat["next_observations"], flat["base_vel"], idx, tw.g_rec, tw.dmulv,
@@ -567,10 +631,19 @@ class PPO:
             self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None)
         # terrain decoder (main)
         g_td2, g_td1 = tw.g("td2", 512), tw.g("td1", 512)
-        self._bwd(tw, L["td2"], tw.g_hr, tw.d2, g_td2, tw.d2, "relu", fw.relu_mask("d2", 512, rm))
-        self._bwd(tw, L["td1"], g_td2, tw.d1, g_td1, tw.d1, "relu", fw.relu_mask("d1", 512, rm))
-        tw.order("aux", "main")                                    # d l_t of the CE-net decoder is written first
-        self._bwd(tw, L["td0"], g_td1, fw.lt, segmat([seg(tw.dlt, 0, 512, accumulate=True)]), None, None)
+        if im:
+            g_td2i, g_td1i = tw.img("g_td2", L["td2"].n_in), tw.img("g_td1", L["td1"].n_in)
+            self._bwd_img(tw, L["td2"], tw.img("g_hr"), tw.img("d2"), dXimg=g_td2i, mask=fw.relu_mask("d2", 512, rm))
+            self._bwd_img(tw, L["td1"], g_td2i, tw.img("d1"), dXimg=g_td1i, mask=fw.relu_mask("d1", 512, rm))
+            tw.order("aux", "main")                                # d l_t of the CE-net decoder is written first
+            # ... read (fp32), added to, and the sum leaves as the image the terrain encoder's backward reads
+            self._bwd_img(tw, L["td0"], g_td1i, fw.img("lt"), dX=tw.dlt, dXimg=tw.img("dlt", L["td0"].n_in), accumulate=True)
+            tw.live_img |= {"g_td2", "g_td1", "dlt"}
+        else:
+            self._bwd(tw, L["td2"], tw.g_hr, tw.d2, g_td2, tw.d2, "relu", fw.relu_mask("d2", 512, rm))
+            self._bwd(tw, L["td1"], g_td2, tw.d1, g_td1, tw.d1, "relu", fw.relu_mask("d1", 512, rm))
+            tw.order("aux", "main")                                # d l_t of the CE-net decoder is written first
+            self._bwd(tw, L["td0"], g_td1, fw.lt, segmat([seg(tw.dlt, 0, 512, accumulate=True)]), None, None)
         early = self._exchange_bucket(tw, "vae_only")              # decoder gradients are complete (queued on `side`)
         self._terrain_encoder_backward(fw, tw, flat, idx)
         with tw.lane("aux"):
@@ -602,9 +675,11 @@ class PPO:
         L = ac.L
         act = AC_Args.activation
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
+        im = self._image_mode(fw)
+        tw.live_img.clear()
         with tw.lane("aux"):
             ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=self.relu_masks)
-        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=self.relu_masks)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=self.relu_masks, images=im)
         tw.order("aux", "main")                                    # z, mu feed the actor
         # output layers + losses + their data gradients in one launch when the last hidden width allows it (DTC_FUSE_HEADS)
         # (its partial-sum workspace holds 4096 blocks of 64 rows: larger mini-batches take the unfused kernels)
@@ -619,8 +694,8 @@ class PPO:
             Xc = ac.critic_input(flat["observations"], flat["base_vel"], flat["privileged_observations"], idx)
             Xa = ac.actor_input(fw, flat["observations"], idx)
         with tw.lane("aux"):
-            ac.critic_forward_(fw, flat["observations"], flat["base_vel"], flat["privileged_observations"], idx, head=not fuse, X=Xc)
-        ac.actor_forward_(fw, flat["observations"], idx, head=not fuse, X=Xa)
+            ac.critic_forward_(fw, flat["observations"], flat["base_vel"], flat["privileged_observations"], idx, head=not fuse, X=Xc, images=im)
+        ac.actor_forward_(fw, flat["observations"], idx, head=not fuse, X=Xa, images=im)
         tw.order("aux", "main")
         if self.after_forward_hook is not None:
             self.after_forward_hook(fw, "ppo")
@@ -638,19 +713,35 @@ class PPO:
         tw.order("main", "aux")
         # critic (aux)
         g_c2, g_c1 = tw.g("c2", 256), tw.g("c1", 512)
+        # image chain (im): the gradient of the 256-wide hidden layer leaves the converting kernel as fp32 + image; the layer below reads
+        # both of its operands (that gradient, its own input) as images
         with tw.lane("aux"):
             self._bwd(tw, L["c3"], tw.dval, fw.v3, None if fuse else g_c3, fw.v3, act)      # fused: weight gradient only
-            self._bwd(tw, L["c2"], g_c3, fw.v2, g_c2, fw.v2, act)
-            self._bwd(tw, L["c1"], g_c2, fw.v1, g_c1, fw.v1, act)
+            if im:
+                g_c2i = tw.img("g_c2", L["c2"].n_in)
+                self._bwd(tw, L["c2"], g_c3, fw.v2, g_c2, fw.v2, act, dXimg=g_c2i)
+                self._bwd_img(tw, L["c1"], g_c2i, fw.img("v1"), dX=g_c1, Xsaved=fw.v1, act_prev=act)
+            else:
+                self._bwd(tw, L["c2"], g_c3, fw.v2, g_c2, fw.v2, act)
+                self._bwd(tw, L["c1"], g_c2, fw.v1, g_c1, fw.v1, act)
             self._bwd(tw, L["c0"], g_c1, Xc)
         # actor (main); layer-0 input gradient fans out to z, mu[:, :3], l_t (observations need none)
         g_a2, g_a1 = tw.g("a2", 256), tw.g("a1", 512)
         self._bwd(tw, L["a3"], tw.dmean, fw.a3, None if fuse else g_a3, fw.a3, act)
-        self._bwd(tw, L["a2"], g_a3, fw.a2, g_a2, fw.a2, act)
-        self._bwd(tw, L["a1"], g_a2, fw.a1, g_a1, fw.a1, act)
+        if im:
+            g_a2i = tw.img("g_a2", L["a2"].n_in)
+            self._bwd(tw, L["a2"], g_a3, fw.a2, g_a2, fw.a2, act, dXimg=g_a2i)
+            self._bwd_img(tw, L["a1"], g_a2i, fw.img("a1"), dX=g_a1, Xsaved=fw.a1, act_prev=act)
+        else:
+            self._bwd(tw, L["a2"], g_a3, fw.a2, g_a2, fw.a2, act)
+            self._bwd(tw, L["a1"], g_a2, fw.a1, g_a1, fw.a1, act)
         tw.dmulv.zero_()
         dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
-        self._bwd(tw, L["a0"], g_a1, Xa, dst, None, None)
+        if im:                                                     # d l_t also as the image the terrain encoder's backward reads
+            self._bwd(tw, L["a0"], g_a1, Xa, dst, None, None, dXimg=tw.img("dlt", 512), img_seg=3)
+            tw.live_img |= {"dlt"}
+        else:
+            self._bwd(tw, L["a0"], g_a1, Xa, dst, None, None)
         early = self._exchange_bucket(tw, "main_only")             # actor + critic + std gradients are complete
         tw.order("main", "aux")                                    # dz, d mu[:, :3] (and d l_t) are written
         self._terrain_encoder_backward(fw, tw, flat, idx)          # needs d l_t only: starts right away on main

@@ -290,6 +290,19 @@ class ActorCriticDecoder(nn.Module):
             self.v1, self.v2, self.v3, self.val = e(B, 512), e(B, 256), e(B, 128), e(B, 1)
             self.lat_ws = torch.empty(int(_ffi.lib().dtc_cenet_workspace(B)) // 8 + 1, dtype=torch.float64, device=dev)
             self._dev, self._masks = dev, {}
+            self._imgs, self.live_img = {}, set()
+
+        def img(self, name, width=None):
+            """Activation image (ops.AImage) of the [B, width] activation `name`, allocated on first use."""
+            im = self._imgs.get(name)
+            if im is None:
+                im = self._imgs[name] = ops.AImage(self.B, width, self._dev)
+            return im
+
+        def value(self, name):
+            """The activation `name` as fp32 (tests / debugging): decoded from its image when the last forward pass kept it as an
+            image only (`live_img`), else the fp32 buffer."""
+            return self._imgs[name].to_tensor() if name in self.live_img else getattr(self, name)
 
         def relu_mask(self, name, width, enabled=True):
             """Sign record of a ReLU layer's [B, width] output (training only): the data gradient reads one bit per
@@ -346,9 +359,25 @@ class ActorCriticDecoder(nn.Module):
         ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None)
         ops.cenet_latent_fwd(ws.mulv, eps, ws.z, ws.mask, ws.info, ws.lat_ws)
 
-    def terrain_encoder_(self, ws, priv, idx=None, masks=False):
+    def images_ok(self, ws):
+        """Activation images (ops.AImage: the hidden activations of the wide stacks live in HBM as the bf16 x 3 planes the split
+        kernels read by LDS-DMA, written once by the producing epilogue) need the split path with weight images and the ReLU sign
+        records (whole 128-row tiles): training steps of mini-batches that are multiples of 128 rows."""
+        return ops.SPLIT and ops.WIMG and ws.B % 128 == 0
+
+    def terrain_encoder_(self, ws, priv, idx=None, masks=False, images=False, lt_img=False):
+        """`images` (training step, see images_ok): t1 / t2 leave as images only (ws.live_img), l_t as fp32 (+ image: lt_img)."""
         L = self.L
         X = segmat([seg(priv, 0, 693, gather=idx is not None)], idx)
+        if images and masks:
+            w1, w2 = L["te0"].n_out, L["te1"].n_out
+            t1i, t2i = ws.img("t1", w1), ws.img("t2", w2)
+            ops.linear_fwd(X, L["te0"].W, L["te0"].b, None, "relu", M=ws.B, mask=ws.relu_mask("t1", w1, masks), Yimg=t1i)
+            ops.linear_fwd_img(t1i, L["te1"].W, L["te1"].b, None, t2i, "relu", mask=ws.relu_mask("t2", w2, masks))
+            ops.linear_fwd_img(t2i, L["te2"].W, L["te2"].b, ws.lt, ws.img("lt", L["te2"].n_out) if lt_img else None, None)
+            ws.live_img |= {"t1", "t2"}
+            return
+        ws.live_img -= {"t1", "t2"}
         ops.linear_fwd(X, L["te0"].W, L["te0"].b, ws.t1, "relu", M=ws.B, mask=ws.relu_mask("t1", 512, masks))
         ops.linear_fwd(ws.t1, L["te1"].W, L["te1"].b, ws.t2, "relu", mask=ws.relu_mask("t2", 512, masks))
         ops.linear_fwd(ws.t2, L["te2"].W, L["te2"].b, ws.lt, None)
@@ -374,20 +403,32 @@ class ActorCriticDecoder(nn.Module):
         ops.pack_cols(segmat([seg(obs, 0, self.num_obs, gather=g), seg(base_vel, 0, 3, gather=g)], idx), buf, B)
         return segmat([seg(buf, 0, self.num_obs + 3), seg(priv, 693, 696, gather=g)], idx)
 
-    def actor_forward_(self, ws, obs, idx=None, head=True, X=None):
-        """`head=False`: stop before the output layer (the trainer's fused heads + loss kernel computes it)."""
+    def _body_forward_(self, ws, X, names, outs, images):
+        """First three layers of an actor / critic body.  `images`: the two hidden activations also leave as images (fp32 stays: the
+        ELU derivative of the backward pass reads it), the layers after the first read their input by LDS-DMA."""
         L, act = self.L, AC_Args.activation
-        ops.linear_fwd(self.actor_input(ws, obs, idx) if X is None else X, L["a0"].W, L["a0"].b, ws.a1, act, M=ws.B)
-        ops.linear_fwd(ws.a1, L["a1"].W, L["a1"].b, ws.a2, act)
-        ops.linear_fwd(ws.a2, L["a2"].W, L["a2"].b, ws.a3, act)
+        l0, l1, l2 = (L[n] for n in names)
+        o0, o1, o2 = (getattr(ws, n) for n in outs)
+        if images:
+            i0, i1 = ws.img(outs[0], l0.n_out), ws.img(outs[1], l1.n_out)
+            ops.linear_fwd(X, l0.W, l0.b, o0, act, M=ws.B, Yimg=i0)
+            ops.linear_fwd_img(i0, l1.W, l1.b, o1, i1, act)
+            ops.linear_fwd_img(i1, l2.W, l2.b, o2, None, act)
+            return
+        ops.linear_fwd(X, l0.W, l0.b, o0, act, M=ws.B)
+        ops.linear_fwd(o0, l1.W, l1.b, o1, act)
+        ops.linear_fwd(o1, l2.W, l2.b, o2, act)
+
+    def actor_forward_(self, ws, obs, idx=None, head=True, X=None, images=False):
+        """`head=False`: stop before the output layer (the trainer's fused heads + loss kernel computes it)."""
+        L = self.L
+        self._body_forward_(ws, self.actor_input(ws, obs, idx) if X is None else X, ("a0", "a1", "a2"), ("a1", "a2", "a3"), images)
         if head:
             ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None)
 
-    def critic_forward_(self, ws, obs, base_vel, priv, idx=None, head=True, X=None):
-        L, act = self.L, AC_Args.activation
-        ops.linear_fwd(self.critic_input(obs, base_vel, priv, idx) if X is None else X, L["c0"].W, L["c0"].b, ws.v1, act, M=ws.B)
-        ops.linear_fwd(ws.v1, L["c1"].W, L["c1"].b, ws.v2, act)
-        ops.linear_fwd(ws.v2, L["c2"].W, L["c2"].b, ws.v3, act)
+    def critic_forward_(self, ws, obs, base_vel, priv, idx=None, head=True, X=None, images=False):
+        L = self.L
+        self._body_forward_(ws, self.critic_input(obs, base_vel, priv, idx) if X is None else X, ("c0", "c1", "c2"), ("v1", "v2", "v3"), images)
         if head:
             ops.linear_fwd(ws.v3, L["c3"].W, L["c3"].b, ws.val, None)
 

@@ -95,6 +95,12 @@ SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "128"))
 SPLIT_MIN_RED = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_RED", "128"))
 # recurrent trainers: weight gradients over the valid slots of the padded trajectory layout only (0: over all T x R rows)
 WGRAD_ROWS = _os.environ.get("DTC_WGRAD_ROWS", "1") != "0"
+# activation images (AImage): the hidden activations of the wide stacks as bf16 x 3 planes in HBM, written by the producing epilogue,
+# read by LDS-DMA.  OFF by default (DTC_IMAGES=1 / trainer.use_images = True switches the trainers' image chain on): measured in round 4,
+# the image-operand kernels are 3-7 % faster per launch in isolation (no conversion in any K loop), but the whole step is 7 % SLOWER
+# (71.1 vs 66.4 ms, three interleaved runs: DESIGN.md 4.2c) -- two grouped weight-gradient launches per bucket instead of one, fp32 + image
+# double writes at the hand-over points, and a GEMM family that is limited by the clock the chip sustains, not by its issue slots
+IMAGES = _os.environ.get("DTC_IMAGES", "0") == "1"
 WIMG_CHECK = _os.environ.get("DTC_WIMG_CHECK", "0") == "1"  # debug: re-derive every cached weight image at its use and compare
 _NOT_NULL = 16                                             # stand-in address of a non-NULL operand block in a cached descriptor
 WIMG = _os.environ.get("DTC_S3_WIMG", "1") != "0"          # the library's weight-image switch (csrc/gemm_s3.hip reads the same variable)

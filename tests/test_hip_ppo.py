@@ -76,10 +76,11 @@ def _relu_mask_mismatches(ref, alg, which):
     knife edges: a pre-activation that is 0 within rounding)."""
     B = next(iter(ref.relu_masks.values())).shape[0]
     fw, tw = alg.actor_critic._fwd_ws(B), alg._train_ws(B)
-    mine = {"cenet_encoder.1": fw.e1, "terrain_encoder.1": fw.t1, "terrain_encoder.3": fw.t2}
+    # (value(): the wide hidden activations may exist as activation images only -- decoded here)
+    mine = {"cenet_encoder.1": fw.e1, "terrain_encoder.1": fw.value("t1"), "terrain_encoder.3": fw.value("t2")}
     if which == "vae":
-        mine.update({"cenet_decoder.1": tw.c1, "cenet_decoder.3": tw.c2, "terrain_decoder.1": tw.d1,
-                     "terrain_decoder.3": tw.d2})
+        mine.update({"cenet_decoder.1": tw.c1, "cenet_decoder.3": tw.c2, "terrain_decoder.1": tw.value("d1"),
+                     "terrain_decoder.3": tw.value("d2")})
     return sum(int(((buf.cpu() > 0) != ref.relu_masks[name]).sum()) for name, buf in mine.items()), B
 
 
@@ -468,9 +469,9 @@ def _unforced_half(ref, alg, which, idx, eps_ref, e1, e2, rec, budget):
     alg.step_minibatch(idx, e1, e2, which=which)
     B = idx.numel()
     fw, tw = alg.actor_critic._fwd_ws(B), alg._train_ws(B)
-    mine = {"cenet_encoder.1": fw.e1, "terrain_encoder.1": fw.t1, "terrain_encoder.3": fw.t2}
+    mine = {"cenet_encoder.1": fw.e1, "terrain_encoder.1": fw.value("t1"), "terrain_encoder.3": fw.value("t2")}
     if which == "vae":
-        mine.update({"cenet_decoder.1": tw.c1, "cenet_decoder.3": tw.c2, "terrain_decoder.1": tw.d1, "terrain_decoder.3": tw.d2})
+        mine.update({"cenet_decoder.1": tw.c1, "cenet_decoder.3": tw.c2, "terrain_decoder.1": tw.value("d1"), "terrain_decoder.3": tw.value("d2")})
     per_layer = {name: int(((buf.cpu() > 0) != ref.relu_masks[name]).sum()) for name, buf in mine.items()}
     decisions = sum(buf.numel() for buf in mine.values())
     n_relu = sum(per_layer.values())
@@ -555,6 +556,21 @@ def test_update_free_running_4096_matches_reference_golden(golden):
     print("free-running 4096: worst error / envelope per step:", [max(w for w in worst if w[1] == k)[:3] for k in range(4)])
     assert max(worst)[0] <= 1.0, sorted(worst, reverse=True)[:6]
     assert lrs == [float(x) for x in g["u4096_lr"][:4]], (lrs, g["u4096_lr"][:4])
+
+
+@pytest.mark.parametrize("n_envs,steps", [(64, 3), (4096, 1)])
+def test_update_teacher_forced_with_activation_images(n_envs, steps):
+    """The trainers' image chain (trainer.use_images / DTC_IMAGES=1, off by default: DESIGN.md 4.2c): hidden activations and gradients of
+    the wide stacks as activation images, image-operand forward / data-gradient / weight-gradient kernels -- same teacher-forced bounds
+    as the default schedule."""
+    ref, alg = _pair(n_envs)
+    alg.use_images = True
+    perm, e1, e2 = S.update_noise(n_envs, 24, 4, 5, seed=123)
+    mb = n_envs * 24 // 4
+    for k in range(steps):
+        _teacher_forced_step(k, ref, alg, perm[(k % 4) * mb:(k % 4 + 1) * mb], e1[k], e2[k])
+    fw, tw = alg.actor_critic._fwd_ws(mb), alg._train_ws(mb)
+    assert {"t1", "t2"} <= fw.live_img and "dlt" in tw.live_img, (fw.live_img, tw.live_img)       # the image chain really ran
 
 
 def test_update_free_running_matches_reference_golden(golden):
