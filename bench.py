@@ -501,6 +501,18 @@ def run(a, rank, local_rank, world, wd):
                              "gradients and the weight-image launches are part of the family (time, no FLOP)",
                     avg_launch_us=ms * 1e3 / max(1, n_launch), flop_per_launch=fl / max(1, n_launch),
                     reduce_ms=sum(r["ms_total"] for r in gemm if r["name"].startswith("wgrad_reduce")))
+        if world == 1 and ops.SPLIT:
+            # the rate the matrix pipe SUSTAINS for this family's MFMA stream (registers only, nothing else in the loop): the chip clocks
+            # to its power budget, so the all-zero run shows the instruction-stream ceiling and the random-operand run the ceiling on
+            # real data -- both far from the data sheet's dense-bf16 peak the `peak` / `frac` fields are priced against
+            try:
+                z, r = ops.mfma_sustained(dev, False), ops.mfma_sustained(dev, True)
+                roof["sustained_mfma"] = dict(zero_operands=z, random_operands=r, unit="TFLOP/s of fp32-equivalent work (bf16 FLOP / 6)",
+                                              measured="dtc_probe_mfma_stream: 768 workgroups x 4 waves, 24 v_mfma_f32_32x32x16_bf16 per stage on "
+                                                       "register operands, 12 launches of ~2-3 ms after 3 warm-up launches, HIP events")
+                roof["frac_of_sustained_random"] = achieved / r if r > 0 else None
+            except Exception as e:
+                roof["sustained_mfma_error"] = str(e)[-200:]
         if world == 1 and not a.no_traffic:
             # HBM-side traffic of the same family over one serialised step: two rocprofv3 PMC passes over a child bench run
             try:

@@ -127,6 +127,7 @@ _SIGS = {
                                      C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_linear_dgrad_s3i": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), C.c_void_p, C.c_int, c_f32p, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_probe_mfma_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, c_stream]),
     "dtc_s3_aimage_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_s3_aimage": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_linear_fwd_i3": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

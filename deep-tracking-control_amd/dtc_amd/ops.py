@@ -493,6 +493,24 @@ def wgrad_group_img(jobs, M, workspace, stream_ptr=None):
     return jobs
 
 
+def mfma_sustained(device, random_operands: bool, launches=12, iters=2000, blocks=768):
+    """TFLOP/s of fp32-equivalent work (bf16 FLOP / 6) the bare MFMA stream of the split kernels sustains on this chip for all-zero or
+    random-normal bf16 operand bits (dtc_probe_mfma_stream): the chip clocks to its power budget, so the two differ."""
+    ops_bits = (torch.randn(32768, device=device) if random_operands else torch.zeros(32768, device=device)).bfloat16()
+    sink = torch.zeros(4, device=device)
+    run = lambda: check(lib().dtc_probe_mfma_stream(ptr(ops_bits), blocks, iters, ptr(sink), stream()), "dtc_probe_mfma_stream")
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    flop = float(launches) * blocks * 4 * iters * 24 * 32768
+    return flop / (e0.elapsed_time(e1) * 1e-3) / 6.0 / 1e12
+
+
 # ---------------------------------------------------------------- CE-net latent / losses / optimiser
 # ---------------------------------------------------------------- device random draws of the update
 def draw_seed() -> int:

@@ -497,6 +497,11 @@ typedef struct DtcProfRec { char name[48]; double ms_total; double work; int64_t
 int dtc_prof_report(DtcProfRec* out, int cap);
 void dtc_prof_reset(void);
 
+/* Measurement aid: one launch of the split kernels' bare MFMA stream (24 v_mfma_f32_32x32x16_bf16 per wave and stage, three waves per
+ * SIMD, register operands taken from the 64 KiB at `operands`) -- blocks * 4 * iters * 24 * 32768 bf16 FLOP.  bench.py times it on
+ * zero and on random operand bits: the rate the chip SUSTAINS (it clocks to its power budget) next to the data-sheet peak. */
+int dtc_probe_mfma_stream(const void* operands, int blocks, int iters, float* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
