@@ -39,7 +39,8 @@ def main():
             for row in csv.DictReader(fh):
                 if sub not in row["Kernel_Name"]:
                     continue
-                key = (row["Kernel_Name"].split("(")[0][-48:], row.get("Grid_Size"))
+                name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+                key = (name.split("(")[0][:60], row.get("Grid_Size"))
                 e = per.setdefault((key, row["Dispatch_Id"]), {})
                 e[row["Counter_Name"]] = e.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
         for (key, _), c in per.items():
