@@ -445,12 +445,24 @@ def run(a, rank, local_rank, world, wd):
             foothold.plan(sc4["measured_heights"], sc4["root_states"], sc4["thigh_pos"], sc4["commands"])
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / reps
+        call_us = e0.elapsed_time(e1) * 1e3 / reps
+        # the kernel itself: HIP events of the in-library profiler around each launch on its stream (the back-to-back figure above is
+        # the launch path of a call -- ctypes marshalling + dispatch -- at this size: one env per wave instead of four changes neither)
+        _ffi.lib().dtc_prof_reset()
+        _ffi.lib().dtc_prof_enable(1)
+        for _ in range(reps):
+            foothold.plan(sc4["measured_heights"], sc4["root_states"], sc4["thigh_pos"], sc4["commands"])
+        torch.cuda.synchronize()
+        _ffi.lib().dtc_prof_enable(0)
+        pl4 = [r for r in _ffi.prof_report() if r["name"].split("[")[0] == "foothold_plan"]
+        _ffi.lib().dtc_prof_reset()
+        us = sum(r["ms_total"] for r in pl4) * 1e3 / max(1, sum(r["launches"] for r in pl4)) if pl4 else call_us
         planner_4096 = dict(bound="hbm", kernel="foothold_plan_fast_kernel", workload="BASELINE configs[3]: 4096 envs x 4 legs, one launch",
                             bytes_per_launch=3096.0 * NUM_ENVS, avg_launch_us=us, achieved=3096.0 * NUM_ENVS / (us * 1e-6) / 1e9,
                             peak=8000.0, unit="GB/s", frac=3096.0 * NUM_ENVS / (us * 1e-6) / 1e9 / 8000.0,
-                            env_steps_per_s=NUM_ENVS / (us * 1e-6),
-                            measured="HIP events around 50 back-to-back launches (includes the dispatch gap between launches)")
+                            env_steps_per_s=NUM_ENVS / (call_us * 1e-6), call_us=call_us,
+                            measured="avg_launch_us: HIP events around each of 50 launches on the launch stream (incl. ~3 us of event overhead); "
+                                     "call_us / env_steps_per_s: 50 back-to-back calls through the Python / ctypes boundary (launch-path bound)")
 
     # EVERY rank runs these two extra steps (they contain the data-parallel collectives); only rank 0 records events
     lib = _ffi.lib()

@@ -95,7 +95,7 @@ for mode in ("serial", "overlap"):
     tot, calls = sum(float(x["TotalDurationNs"]) for x in fam), sum(int(x["Calls"]) for x in fam)
     print(f"{mode}: GEMM family {tot / 1e6:.1f} ms over {calls} launches -> {tot / calls / 1e3:.2f} us per launch")
 
-for name in (f"{tag}_dp_rehearsal.log", f"{tag}_soak.log"):
+for name in (f"{tag}_dp_rehearsal.log", f"{tag}_soak.log", f"{tag}_images_ab.log", f"{tag}_image_kernels.log", f"{tag}_i3_pmc.txt", f"{tag}_wgrad_pmc.txt"):
     if os.path.exists(f"{src}/{name}"):
         shutil.copy(f"{src}/{name}", f"{dst}/{name}")
 print("bench:", d["value"], d["ms_per_step"], "roofline", r["achieved"], r["frac"], "traffic ratio", r.get("traffic_over_algorithmic"))
