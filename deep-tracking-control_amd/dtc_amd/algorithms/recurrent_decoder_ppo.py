@@ -209,6 +209,9 @@ class RecurrentDecoderPPO(PPO):
             eps1 = ops.randn((steps, B, 16), dev, seed + 1) if eps1 is None else eps1
             eps2 = ops.randn((steps, B, 16), dev, seed + 2) if eps2 is None else eps2
         stats = torch.zeros(steps, STAT_COLS, dtype=torch.float32, device=dev)
+        for key, buf in self._train_ws(B)._g.items():         # padded input projections: the padding slots start every update from zero
+            if isinstance(key, tuple) and key[0] == "pad" and key[1].startswith("gi_"):
+                buf.zero_()
         slices = list(self.recurrent_slices())
         k = 0
         for _ in range(epochs):

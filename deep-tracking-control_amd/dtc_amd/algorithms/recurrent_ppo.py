@@ -242,6 +242,8 @@ class RecurrentPPO:
         dev = self.actor_critic.std.device
         stats = torch.zeros(nmb * epochs, STAT_COLS, device=dev)
         k = 0
+        for mem in (self.actor_critic.memory_a, self.actor_critic.memory_c):
+            mem.new_update()
         for batch in st.reccurent_mini_batch_generator(nmb, epochs):
             i = k % nmb
             self.step_minibatch(batch, i * mb, (i + 1) * mb, stats[k])

@@ -221,9 +221,17 @@ class Memory(nn.Module):
         fix = lambda t: t if t.dim() == 3 else t.unsqueeze(0)
         return fix(h), (fix(c) if c is not None else None)
 
+    def new_update(self):
+        """Called by the trainers at the start of an update: the padding slots of the compacted input projection start from zero, so
+        an update's result never depends on what earlier updates left there (within an update they hold finite values of its own
+        earlier mini-batches, which nothing reads: the outputs of padding steps are masked out and their gradients are zero)."""
+        buf = getattr(self, "_gi_pad", None)
+        if buf is not None:
+            buf.zero_()
+
     def _padded_gi(self, rows_total, width, dev):
         """Persistent, zero-initialised [T * R, G * H] buffer for the compacted input projection (grown on demand): the slots a
-        mini-batch does not write keep finite values of earlier mini-batches."""
+        mini-batch does not write keep finite values of earlier mini-batches of the same update (new_update)."""
         buf = getattr(self, "_gi_pad", None)
         if buf is None or buf.numel() < rows_total * width or buf.device != dev:
             buf = self._gi_pad = torch.zeros(rows_total * width, device=dev)

@@ -134,8 +134,9 @@ def test_recurrent_minibatch_step_vs_oracle(kw):
 def test_recurrent_minibatch_step_full_size():
     """BASELINE configs[2] at its real size: 4096 envs x 24 steps, one recurrent mini-batch of 1024 envs
     (~1500 padded trajectories) teacher-forced against the CPU oracle.  At this size the HIP path runs what the 16-env
-    cases never reach: 128x64 tiles on every layer, the three-chunk split data gradient of the GRU backward, the fused
-    GRU step at R ~ 1500 rows, the grouped weight gradients with 24 batch slices."""
+    cases never reach: the split-precision kernels on every wide layer (128 x 128 tiles), the GRU time steps on csrc/gru_s3.hip
+    (fused forward step at R ~ 1500 rows, the six-chunk recurrent data gradient), the input projection and the W_ih / W_hh weight
+    gradients over the valid rows of the padded batch only, grouped weight gradients with 8-24 batch slices."""
     from dtc_amd.algorithms import ppo as P
     n = 4096
     ref, alg, st, hid_a, hid_c = _hip_pair(n=n)
