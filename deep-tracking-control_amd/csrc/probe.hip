@@ -8,6 +8,9 @@
 
 namespace {
 
+// ORDER: the sequence of the six plane pairs of a product.  0 = the kernels' order (smallest terms first); 1 = B-stationary (b1 x3, b2 x2,
+// b3); 2 = A-stationary -- does keeping one operand's bits on the pipe's inputs for consecutive instructions change what it sustains?
+template <int ORDER>
 __global__ __launch_bounds__(256, 3) void mfma_stream_kernel(const u32x4* __restrict__ operands, int iters, float* __restrict__ sink) {
     const int tid = threadIdx.x;
     bf16x8 a[2][3], b[2][3];
@@ -25,7 +28,8 @@ __global__ __launch_bounds__(256, 3) void mfma_stream_kernel(const u32x4* __rest
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    constexpr int PA[6] = {2, ORDER == 0 ? 1 : ORDER == 1 ? 1 : 1, ORDER == 0 ? 0 : ORDER == 1 ? 0 : 1, ORDER == 0 ? 1 : ORDER == 1 ? 1 : 0, 0, 0};
+    constexpr int PB[6] = {0, ORDER == 0 ? 1 : ORDER == 1 ? 0 : 0, ORDER == 0 ? 2 : ORDER == 1 ? 0 : 1, ORDER == 0 ? 0 : ORDER == 1 ? 1 : 0, 1, ORDER == 2 ? 2 : ORDER == 1 ? 2 : 0};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -51,6 +55,9 @@ __global__ __launch_bounds__(256, 3) void mfma_stream_kernel(const u32x4* __rest
 // whose bits are the MFMA inputs (zeros, or random bf16 patterns).
 extern "C" int dtc_probe_mfma_stream(const void* operands, int blocks, int iters, float* sink, void* stream) {
     DTC_REQUIRE(operands && sink && blocks > 0 && iters > 0 && dtc::aligned16(operands), "null / unaligned pointer or bad size");
-    hipLaunchKernelGGL(mfma_stream_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)operands, iters, sink);
+    static const int order = getenv("DTC_PROBE_ORDER") ? atoi(getenv("DTC_PROBE_ORDER")) : 0;
+    if (order == 1) hipLaunchKernelGGL(mfma_stream_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)operands, iters, sink);
+    else if (order == 2) hipLaunchKernelGGL(mfma_stream_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)operands, iters, sink);
+    else hipLaunchKernelGGL(mfma_stream_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)operands, iters, sink);
     return dtc::check_launch("probe_mfma_stream");
 }

@@ -29,11 +29,18 @@ def main():
         if r.returncode != 0:
             print(f"pass {tag} failed: {r.stderr.decode()[-300:]}")
             continue
-        path = None
+        path = trace = None
         for base, _, files in os.walk(d):
             for f in files:
                 if f.endswith("counter_collection.csv"):
                     path = os.path.join(base, f)
+                if f.endswith("kernel_trace.csv"):
+                    trace = os.path.join(base, f)
+        dur = {}
+        if trace:
+            with open(trace, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    dur[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
         per = {}
         with open(path, newline="") as fh:
             for row in csv.DictReader(fh):
@@ -43,6 +50,8 @@ def main():
                 key = (name.split("(")[0][:60], row.get("Grid_Size"))
                 e = per.setdefault((key, row["Dispatch_Id"]), {})
                 e[row["Counter_Name"]] = e.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                if tag == "a" and row["Dispatch_Id"] in dur:
+                    e["_duration_ns"] = dur[row["Dispatch_Id"]]
         for (key, _), c in per.items():
             a = agg.setdefault(key, {"_n": {}})
             for k, v in c.items():
@@ -57,6 +66,8 @@ def main():
         g = avg.get("GRBM_GUI_ACTIVE")
         if g:
             simd_cycles = 1024.0 * g / 8.0
+            if avg.get("_duration_ns"):
+                print(f"   -> kernel duration {avg['_duration_ns'] / 1e3:.1f} us (counter pass a), clock = GRBM_GUI_ACTIVE / 8 XCDs / duration = {g / 8.0 / avg['_duration_ns']:.2f} GHz")
             print(f"   -> MFMA busy {avg.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / simd_cycles:.3f};  per wave-cycle: parked {avg.get('SQ_WAIT_ANY', 0) / max(1, avg.get('SQ_WAVE_CYCLES', 1)):.3f}, "
                   f"issue-stalled {avg.get('SQ_WAIT_INST_ANY', 0) / max(1, avg.get('SQ_WAVE_CYCLES', 1)):.3f}, issuing {avg.get('SQ_ACTIVE_INST_ANY', 0) / max(1, avg.get('SQ_WAVE_CYCLES', 1)):.3f}")
         if avg.get("SQ_LDS_IDX_ACTIVE"):

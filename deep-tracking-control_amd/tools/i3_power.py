@@ -39,8 +39,14 @@ Xr, Wr = torch.randn(M, K, device=DEV, generator=g), torch.randn(N, K, device=DE
 Xz, Wz = torch.zeros(M, K, device=DEV), torch.zeros(N, K, device=DEV)
 Xb = Xr.bfloat16().float()          # values with 8 significant bits: planes 2 and 3 are zero
 Wb = Wr.bfloat16().float()
-run("random X, random W", Xr, Wr)
-run("zero X, zero W", Xz, Wz)
-run("random X, zero W", Xr, Wz)
-run("bf16-exact X and W", Xb, Wb)
-run("random X, random W (again)", Xr, Wr)
+only = sys.argv[1] if len(sys.argv) > 1 else None      # "random" / "zero": one case only (counter passes: tools/analysis/pmc_any.py)
+if only == "random":
+    run("random X, random W", Xr, Wr)
+elif only == "zero":
+    run("zero X, zero W", Xz, Wz)
+else:
+    run("random X, random W", Xr, Wr)
+    run("zero X, zero W", Xz, Wz)
+    run("random X, zero W", Xr, Wz)
+    run("bf16-exact X and W", Xb, Wb)
+    run("random X, random W (again)", Xr, Wr)
