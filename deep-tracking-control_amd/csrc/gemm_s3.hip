@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                     }
                     if (whole) {
                         const int lc = col - sdj.start;             // column inside the block
-                        float* base = sdj.ptr ? sdj.ptr + sdj.col0 - 0 : nullptr;
+                        float* base = sdj.ptr ? sdj.ptr + sdj.col0 : nullptr;
                         if (sdj.ptr && sdj.accumulate) {
                             f32x4 o[2];
                             load8(base, sdj.ld, row, lc, M, sdj.width, w16, o);
@@ -1313,7 +1313,6 @@ extern "C" int dtc_linear_fwd_i3(const void* Ximg, const float* W, const float* 
     DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * (ldy > N ? ldy : N) <= MAX_ELEMS * 4 && dtc_s3_aimage_bytes(M, K) < (1ll << 31) &&
                 dtc_s3_aimage_bytes(M, N) < (1ll << 31), "matrix too large");
     hipStream_t s = (hipStream_t)stream;
-    const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128));
     const int wide = (Y && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
     if (relu_mask) DTC_REQUIRE(act == DTC_ACT_RELU && M % BM == 0 && N % 128 == 0, "sign record (split path): M=%d and N=%d must be multiples of 128", M, N);
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s,
@@ -1369,7 +1368,6 @@ extern "C" int dtc_linear_dgrad_i3(const void* dZimg, const float* W, float* dX,
     DgradEpiI3 dg{dX, (long long)lddx, accumulate, relu_mask ? nullptr : Xsaved, (long long)ldxs, (const unsigned short*)relu_mask, K};
     const int wide = ((dX && lddx % 4 == 0 && dtc::aligned16(dX)) ? 1 : 0) | ((dg.Xs && ldxs % 4 == 0 && dtc::aligned16(dg.Xs)) ? 2 : 0);
     hipStream_t s = (hipStream_t)stream;
-    const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K, 128));
     double bytes = 6.0 * M * (double)N + 6.0 * N * (double)K + (dXimg ? 6.0 : 0.0) * M * K + (dX ? 4.0 : 0.0) * M * K;
     if (relu_mask) bytes += 0.125 * M * (double)K;
     else if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)K;
