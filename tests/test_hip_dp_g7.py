@@ -241,9 +241,11 @@ def _spawn(target, world, args, timeout=900):
     return dict(out)
 
 
-@pytest.mark.parametrize("kind", ["decoder", "composite"])
-def test_exchanged_hip_gradients_equal_the_oracles_shard_average(kind):
-    out = _spawn(_g7_worker, 2, (kind, 64))
+@pytest.mark.parametrize("kind,n", [("decoder", 64), ("composite", 64), ("decoder", 1024)])
+def test_exchanged_hip_gradients_equal_the_oracles_shard_average(kind, n):
+    """n = 64 envs per rank: mini-batches of 384 rows; n = 1024: 6144 rows -- the 128 x 128 split-precision tiles, 8-slice grouped weight
+    gradients and sign records of the full-size schedule under the exchange."""
+    out = _spawn(_g7_worker, 2, (kind, n))
     print(kind, {r: out[r]["report"] for r in out})
     assert torch.equal(out[0]["flat"], out[1]["flat"]) and out[0]["lr"] == out[1]["lr"]
 
