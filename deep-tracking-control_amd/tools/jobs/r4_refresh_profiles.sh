@@ -43,7 +43,8 @@ done ) > $O/r04_images_ab.log 2>&1
   echo "== zero vs random operands (tools/i3_power.py)"; python $T/i3_power.py 2>/dev/null
   echo "== LDS-DMA bandwidth into LDS, GEMM access pattern without MFMAs (tools/probes/dma_bw.hip)"; $T/_bin/dma_bw 2>/dev/null
   echo "== ds_read_b64_tr_b16 / LDS-DMA out-of-range semantics (tools/probes/tr16_dma.hip)"; $T/_bin/tr16_dma 2>/dev/null | head -8
-  echo "== K-loop ablation of linear_i3_kernel (tools/jobs/r4_ablate.sh; probes run on static operand bits: see the zero-operand run)"; bash $T/jobs/r4_ablate.sh 2>/dev/null ) > $O/r04_image_kernels.log 2>&1
+  ) > $O/r04_image_kernels.log 2>&1
+bash $T/jobs/r4_ablate_all.sh > /dev/null 2>&1          # -> $O/r04_i3_ablation.txt (variant libraries: tools/build_variant.sh, see the script)
 cd /tmp
 python $R/$T/analysis/pmc_any.py $R/$O/pmc_i3 linear_i3_kernel -- python $R/$T/i3_ablate.py product > $R/$O/r04_i3_pmc.txt 2>&1
 python $R/$T/analysis/pmc_any.py $R/$O/pmc_w wgrad_ -- python $R/$T/img_probe.py wgrad > $R/$O/r04_wgrad_pmc.txt 2>&1
