@@ -379,11 +379,18 @@ def run(a, rank, local_rank, world, wd):
         for _ in range(warmup):
             step()
         fence()
+        if ops.AMAX_STATS is not None:
+            ops.AMAX_STATS.clear()
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0                  # this rank's own time (before the closing barrier)
+        if ops.AMAX_STATS:                               # DTC_AMAX_STATS=1 (debug): operands of the fp16 path that no kernel published an amax for
+            for k, v in sorted(ops.AMAX_STATS.items(), key=lambda kv: -kv[1]):
+                sys.stderr.write(f"amax fallback {k}: {v / steps:.1f} per step\n")
+            sys.stderr.write(f"amax fallbacks per step: {sum(ops.AMAX_STATS.values()) / steps:.1f}\n")
+            ops.AMAX_STATS.clear()
         fence()
         elapsed = time.perf_counter() - t0
         rank_ms = [mine / steps * 1e3]

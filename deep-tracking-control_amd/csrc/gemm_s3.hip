@@ -71,11 +71,48 @@ struct WimgJobDev {
     long long ld;
     int rows, row0, trans, total, block_end;      // block_end: running sum of (column tiles x stages) over the jobs
     WimgSegs sg;
+    long long welems;                             // fp16 images: elements of the whole weight matrix and the WPART partial maxima of
+    u32* wa;                                      // their |w| (right behind the image's last chunk)
 };
 struct WimgGroup {
     int count;
     WimgJobDev job[WIMG_MAX_JOBS];
 };
+// fp16 images, first step: the largest |w| of every job's matrix as WPART partial maxima (block = (job, part); no atomics, nothing to
+// zero); the image builder and the GEMM kernels take the maximum of them
+constexpr int WPART = 32;
+__device__ __forceinline__ u32 wpart_max(const u32* wa) {
+    u32 m = 0u;
+#pragma unroll
+    for (int i = 0; i < WPART; ++i) {
+        const u32 v = __hip_atomic_load(wa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m = v > m ? v : m;
+    }
+    return m;
+}
+__global__ __launch_bounds__(256) void wamax_kernel(const WimgGroup G) {
+    const WimgJobDev& J = G.job[blockIdx.x / WPART];
+    const int e = blockIdx.x % WPART;
+    u32 m = 0u;
+    for (long long i = (long long)e * 256 + threadIdx.x; i < J.welems; i += WPART * 256) {
+        const u32 b = abs_bits(J.W[i]);
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const u32 o = (u32)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+    }
+    __shared__ u32 red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) m = red[w] > m ? red[w] : m;
+        J.wa[e] = m;
+    }
+}
+
+template <bool H2>
 __global__ __launch_bounds__(256) void wimage_kernel(const WimgGroup G) {
     int j = 0, b = blockIdx.x;
     while (j < G.count - 1 && b >= G.job[j].block_end) ++j;
@@ -99,10 +136,15 @@ __global__ __launch_bounds__(256) void wimage_kernel(const WimgGroup G) {
         const bool ok = row < J.rows && jj < sg.width[seg];
         v[e >> 2][e & 3] = ok ? (J.trans ? W[col * J.ld + row] : W[(long long)row * J.ld + col]) : 0.f;
     }
-    const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
-    u32x4* dst = J.img + (long long)b * (WIMG_CHUNK / 16);
+    int ew = 0;
+    if constexpr (H2) {
+        ew = h2_exp(wpart_max(J.wa));
+    }
+    using P = Prec<H2>;
+    const P s0 = P::split(v[0], ew), s1 = P::split(v[1], ew);
+    u32x4* dst = J.img + (long long)b * (P::NP * WIMG_PLANE / 16);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) dst[p * 256 + rslot(r, h)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
+    for (int p = 0; p < P::NP; ++p) dst[p * 256 + rslot(r, h)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
 }
 
 // ---- activation-image results (round 4; the format and its consumers: see "ACTIVATION IMAGES" below) ----------------------------
@@ -185,22 +227,36 @@ __device__ __forceinline__ void load8(const float* base, long long ld, int row, 
     }
 }
 
-template <int EPI, bool WIMG>
+#ifdef DTC_H2_DEBUG
+__device__ u32 g_dbg[8];
+#endif
+// amax slots of a two-term fp16 launch (s3_core.hpp): operand segments in, weight image partials in, results out
+struct H2Arg {
+    const u32* xa[4];             // one slot per segment of the row operand (X resp. dZ)
+    const u32* wa;                // the weight image's WPART partial maxima (behind its last chunk)
+    u32* ya[4];                   // EPI_FWD / EPI_MSE: [0] = slot of the result; EPI_DGRAD: one per destination block (NULL: not published)
+};
+
+// H2 (round 4): operands as TWO fp16 terms and three MFMA passes (s3_core.hpp) instead of three bf16 terms and six passes
+template <int EPI, bool WIMG, bool H2 = false>
 __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, const float* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ Y,
                                                            long long ldy, int M, int N, int K, int act, int wide,
                                                            unsigned short* __restrict__ wmask, int ldwm, const DgradEpi dg,
                                                            const MseEpiS3 mse, const u32x4* __restrict__ wimg, long long wimg_bytes,
-                                                           const ImgOut yo, int yo_seg) {
+                                                           const ImgOut yo, int yo_seg, const H2Arg h2) {
     // yo.img != NULL (round 4): the result ALSO (EPI_FWD: Y may then be NULL) leaves as an activation image -- of the whole result
     // (EPI_FWD) or of destination block yo_seg (EPI_DGRAD) -- for the image-operand kernels that consume it
+    static_assert(!H2 || WIMG, "the fp16 path reads its weights as an image");
+    using P = Prec<H2>;
+    constexpr int NP = P::NP, NT = P::NT, WCH = NP * WIMG_PLANE;
     constexpr int BN = 128, WN = 2, TM = 2, TN = 2, NA = 2, NB = WIMG ? 0 : 2;
-    __shared__ __attribute__((aligned(16))) u32x2 As[2][3][BM * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 As[2][NP][BM * 4];
     // two separate objects: the compiler then knows that an LDS-DMA into one stage buffer cannot alias the fragment reads of the
     // other (with one array it waits for the DMA before the first ds_read of every stage); the K loop is unrolled by two so that
     // the buffer index is a compile-time constant
-    __shared__ __attribute__((aligned(16))) u32x2 Bs0[3][BN * 4];
-    __shared__ __attribute__((aligned(16))) u32x2 Bs1[3][BN * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Bs0[NP][BN * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Bs1[NP][BN * 4];
 #define BS(b) ((b) ? Bs1 : Bs0)
     int tr, tc;
     const int ncols = EPI == EPI_DGRAD ? N - dg.col_skip : N;          // output columns that are computed
@@ -229,7 +285,28 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int total = 0;
     for (int i = 0; i < X.nseg; ++i) total += (X.s[i].width + BK - 1) / BK;
-    u32 wchunk = (u32)(tc * total) * (u32)WIMG_CHUNK;       // byte offset of the next stage's chunk of this column tile
+    u32 wchunk = (u32)(tc * total) * (u32)WCH;              // byte offset of the next stage's chunk of this column tile
+    // fp16 path: the scale exponents of the two operands (uniform: scalar loads)
+    int ex = 0, ew = 0;
+    if constexpr (H2) {
+        u32 mx = 0u;
+        for (int i = 0; i < X.nseg; ++i) {
+            const u32 v = amax_read(h2.xa[i]);
+            mx = v > mx ? v : mx;
+        }
+        ex = __builtin_amdgcn_readfirstlane(h2_exp(mx));
+        ew = __builtin_amdgcn_readfirstlane(h2_exp(wpart_max(h2.wa)));
+#ifdef DTC_H2_DEBUG
+        if (threadIdx.x == 0) {
+            atomicMax(&g_dbg[0], (u32)(ex + 1000));
+            atomicMin(&g_dbg[1], (u32)(ex + 1000));
+            atomicMax(&g_dbg[2], (u32)(ew + 1000));
+            atomicMin(&g_dbg[3], (u32)(ew + 1000));
+            atomicMax(&g_dbg[4], mx);
+            atomicMin(&g_dbg[5], mx);
+        }
+#endif
+    }
 
     // ONE loop over the stages of all segments; the (rare) hop into the next segment re-derives the row offsets (the gathered
     // row index is re-read from idx: two loads per thread and segment instead of registers held across the whole K loop)
@@ -256,9 +333,9 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         const u32 ka = (u32)(kt * BK) * 4u, kw = (u32)(sd.start + kt * BK) * 4u;
         if constexpr (WIMG) {                       // issued first: the compiler waits for ALL loads once an LDS-DMA is in flight
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)&BS(nbuf)[p][wave_u * 128], 16, tid * 16, wchunk + p * WIMG_PLANE, 0, 0);
-            wchunk += WIMG_CHUNK;
+            wchunk += WCH;
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = bload4(ares, aoff[i], ka);
@@ -287,15 +364,15 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const Split3 s = split3(ra[i]);
+            const P s = P::split(ra[i], ex);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) As[buf][p][aslot0 + 256 * i] = s.p[p];
+            for (int p = 0; p < NP; ++p) As[buf][p][aslot0 + 256 * i] = s.p[p];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const Split3 s = split3(rb[i]);
+            const P s = P::split(rb[i], 0);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) BS(buf)[p][aslot0 + 256 * i] = s.p[p];
+            for (int p = 0; p < NP; ++p) BS(buf)[p][aslot0 + 256 * i] = s.p[p];
         }
     };
 
@@ -311,25 +388,25 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     auto mfma_stage = [&](auto bc) {
         constexpr int buf = decltype(bc)::value;
         // fragments: A planes of both row tiles stay live (24 registers), B planes are read per column tile (12 registers)
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};      // smallest terms first: (a3 b1, a2 b2, a1 b3), (a2 b1, a1 b2), a1 b1
-        bf16x8 a[TM][3];
+        // smallest terms first: (a3 b1, a2 b2, a1 b3), (a2 b1, a1 b2), a1 b1 (Prec::pa / pb)
+        u32x4 a[TM][NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot(wm_off + 32 * i + l31, half)]);
+                a[i][p] = reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot(wm_off + 32 * i + l31, half)];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            bf16x8 b[3];
+            u32x4 b[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&BS(buf)[p][0])[rslot(wn_off + 32 * j + l31, half)]);
+            for (int p = 0; p < NP; ++p)
+                b[p] = reinterpret_cast<const u32x4*>(&BS(buf)[p][0])[rslot(wn_off + 32 * j + l31, half)];
             // the two row tiles alternate: consecutive MFMAs never wait for each other's accumulator
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][j], 0, 0, 0);
+                    acc[i][j] = P::mfma(a[i][P::pa(t)], b[P::pb(t)], acc[i][j]);
         }
     };
 #endif
@@ -340,21 +417,20 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     // ignored by this compiler): the conversion of a stage is ~110 VALU + 12 LDS stores, 24 MFMAs leave 24 x 28 idle issue cycles.
     auto stage_ilv = [&](auto bc) {
         constexpr int buf = decltype(bc)::value;
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-        bf16x8 a[TM][3], b[3];
+        u32x4 a[TM][NP], b[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot(wm_off + 32 * i + l31, half)]);
+                a[i][p] = reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot(wm_off + 32 * i + l31, half)];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&BS(buf)[p][0])[rslot(wn_off + l31, half)]);
+        for (int p = 0; p < NP; ++p) b[p] = reinterpret_cast<const u32x4*>(&BS(buf)[p][0])[rslot(wn_off + l31, half)];
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][0], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i][0] = P::mfma(a[i][P::pa(t)], b[P::pb(t)], acc[i][0]);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&BS(buf)[p][0])[rslot(wn_off + 32 + l31, half)]);
+        for (int p = 0; p < NP; ++p) b[p] = reinterpret_cast<const u32x4*>(&BS(buf)[p][0])[rslot(wn_off + 32 + l31, half)];
         // branch-free k-tail masks (the block must stay one basic block for the scheduler)
 #pragma unroll
         for (int i = 0; i < NA; ++i)
@@ -365,7 +441,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
 #pragma unroll
             for (int e = 0; e < 4; ++e) rb[i][e] = e <= klast ? rb[i][e] : 0.f;
 #ifdef DTC_S3_FINE
-        if constexpr (WIMG) {
+        if constexpr (WIMG && !H2) {
             // (opt-in, measured round 3: 76.0 -> 74.0 us on 24576 x 512 x 512 alone, but 65.4 vs 64.9 ms per step in the overlapped
             // schedule, so off.)  Only the X side is converted: its seven dependency levels (both float4 of the thread side by
             // side, 4 to 8 VALU each) go one per MFMA gap -- an MFMA occupies the pipe for 32 cycles = 8 issue slots, so a level
@@ -374,7 +450,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
             u32 pk[3][4], u[8];
             auto mm = [&](int m) {
                 const int t = m >> 1, i = m & 1;
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][1], 0, 0, 0);
+                acc[i][1] = P::mfma(a[i][P::pa(t)], b[P::pb(t)], acc[i][1]);
                 __builtin_amdgcn_sched_barrier(0);
             };
             __builtin_amdgcn_sched_barrier(0);
@@ -413,20 +489,20 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
             return;
         }
 #endif
-        constexpr int NQ = NA + NB, MQ = 12 / NQ;
+        constexpr int NQ = NA + NB, MQ = 2 * NT / NQ;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            // hard ordering between the pieces: 3 (W image: 6) MFMAs are issued, then the conversion of one float4 per thread
-            // (~28 VALU + 3 LDS stores) issues while they execute
+            // hard ordering between the pieces: 3 (W image: 6; fp16 terms: 3) MFMAs are issued, then the conversion of one float4 per
+            // thread (~28 VALU + 3 LDS stores; fp16 terms: ~16 + 2) issues while they execute
             __builtin_amdgcn_sched_barrier(0);
-            const Split3 sp = split3(q < NA ? ra[q] : rb[NB ? q - NA : 0]);
+            const P sp = P::split(q < NA ? ra[q] : rb[NB ? q - NA : 0], q < NA ? ex : 0);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) (q < NA ? As[buf ^ 1] : BS(buf ^ 1))[p][aslot0 + 256 * (q & 1)] = sp.p[p];
+            for (int p = 0; p < NP; ++p) (q < NA ? As[buf ^ 1] : BS(buf ^ 1))[p][aslot0 + 256 * (q & 1)] = sp.p[p];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t3 = 0; t3 < MQ; ++t3) {
                 const int m = MQ * q + t3, t = m >> 1, i = m & 1;
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][1], 0, 0, 0);
+                acc[i][1] = P::mfma(a[i][P::pa(t)], b[P::pb(t)], acc[i][1]);
             }
         }
     };
@@ -456,6 +532,21 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     }
 
     const bool full = (m0 + BM <= M) && (n0 + BN <= N);
+    if constexpr (H2) {                                 // the sums carry 2^(ex + ew): scaled back exactly
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], -(ex + ew));
+    }
+    u32 am = 0u;                                        // fp16 path: this lane's largest |stored value| (bit pattern)
+    auto seen = [&](float v) {
+        if constexpr (H2) {
+            const u32 b = abs_bits(v);
+            am = b > am ? b : am;
+        }
+    };
     __syncthreads();                                    // every wave is past its last operand read: LDS becomes the patches
     float* patch = reinterpret_cast<float*>(&As[0][0][0]) + wave * (32 * LDW);
     const int prow = lane >> 3, pc4 = lane & 7;
@@ -485,6 +576,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                 if (cok && row < M) {
                     const float e = (acc[i][j][r] + bv) - tg[r];
                     Y[(long long)row * ldy + col] = e * mse.scale;
+                    seen(e * mse.scale);
                     sq += (double)e * (double)e;
                 }
             }
@@ -495,10 +587,11 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         if (lane == 0) red[wave] = sq;
         __syncthreads();
         if (tid == 0) mse.part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+        if constexpr (H2) amax_publish(h2.ya[0], am);
         return;
     }
     if constexpr (EPI == EPI_FWD) {
-        if (yo.img) {                                   // the epilogue of linear_i3_kernel: final values -> patch -> fp32 rows and / or image pieces
+        if (!H2 && yo.img) {                                   // the epilogue of linear_i3_kernel: final values -> patch -> fp32 rows and / or image pieces
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -560,8 +653,11 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                         for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], act);
                     }
                     *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) seen(v[e]);
                 }
             }
+            if constexpr (H2) amax_publish(h2.ya[0], am);
             return;
         }
 #pragma unroll
@@ -576,13 +672,17 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
             for (int r = 0; r < 16; ++r) {
                 const int ro = (r & 3) + 8 * (r >> 2);
                 const float v = act_fwd(acc[i][j][r] + bv, act);
-                if (cok && m0 + wm_off + 32 * i + 4 * half + ro < M) yp[(long long)ro * ldy] = v;
+                if (cok && m0 + wm_off + 32 * i + 4 * half + ro < M) {
+                    yp[(long long)ro * ldy] = v;
+                    seen(v);
+                }
             }
         }
+        if constexpr (H2) amax_publish(h2.ya[0], am);
     } else {
         // ---- data-gradient epilogue: activation derivative, segmented destination (csrc/gemm.hip: linear_dgrad_kernel)
         const SegMatDev& dX = dg.dX;
-        if (yo.img) {
+        if (!H2 && yo.img) {
             // every tile through the patch; lane -> 8 consecutive result columns of a row.  A group that lies inside ONE destination
             // block takes 16-byte accesses (derivative through the saved output, accumulation, fp32 store) and, in block yo_seg, the
             // image pieces; a group that straddles a block border (never in the image's block: its borders are multiples of 8) goes
@@ -671,6 +771,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
             const SegDev sdj = dX.s[sj];
             const bool tile_wide = full && ((dg.wide_segs >> sj) & 1) && cj + 32 <= sdj.start + sdj.width && ((cj - sdj.start) & 3) == 0 &&
                                    (act == DTC_ACT_NONE || ((dg.wide_segs >> 4) & 1));
+            am = 0u;                                    // (fp16 path) published per tile: its destination block has its own slot
             if (tile_wide) {                            // wave-uniform
                 patch_put(patch, acc[i][j], half, l31);
                 if (sdj.ptr == nullptr) continue;
@@ -692,7 +793,10 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                         for (int e = 0; e < 4; ++e) v[e] = o[e] + v[e];
                     }
                     *q = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) seen(v[e]);
                 }
+                if constexpr (H2) amax_publish(h2.ya[sj], am);
                 continue;
             }
             const int col = cj + l31;
@@ -714,8 +818,15 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                 if (act != DTC_ACT_NONE) v = act_bwd(v, y[r], act);
                 if (live && row < M) {
                     float* q = dst + (long long)row * sc.ld;
-                    *q = sc.accumulate ? (*q + v) : v;
+                    v = sc.accumulate ? (*q + v) : v;
+                    *q = v;
+                    seen(v);
                 }
+            }
+            if constexpr (H2) {                         // lanes of this tile may write different destination blocks: one update per lane
+                u32* slot = live ? h2.ya[find_seg(dX, col)] : nullptr;
+                if (slot) slot += (lane & (AMAX_SUB - 1)) * AMAX_STRIDE;
+                if (slot && am > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, am);
             }
         }
     }
@@ -762,7 +873,8 @@ bool wimage_on() {
     return on;
 }
 // job of one image: the column tiles [0, col_tiles) of the operand whose first row is row0, the stages of xd's segment walk
-long long wimage_job(WimgJobDev& J, const float* W, void* img, int rows, int row0, long long ld, int trans, const SegMatDev& xd, int col_tiles) {
+long long wimage_job(WimgJobDev& J, const float* W, void* img, int rows, int row0, long long ld, int trans, const SegMatDev& xd, int col_tiles,
+                     bool h2 = false, long long welems = 0) {
     J.W = W;
     J.img = (u32x4*)img;
     J.ld = ld;
@@ -778,15 +890,25 @@ long long wimage_job(WimgJobDev& J, const float* W, void* img, int rows, int row
         J.total += (xd.s[i].width + BK - 1) / BK;
     }
     J.block_end = col_tiles * J.total;
-    return (long long)col_tiles * J.total * WIMG_CHUNK;
+    const long long bytes = (long long)col_tiles * J.total * (h2 ? 2 * WIMG_PLANE : WIMG_CHUNK);
+    J.welems = welems;
+    J.wa = h2 ? reinterpret_cast<u32*>(reinterpret_cast<char*>(img) + bytes) : nullptr;      // inside dtc_s3_planes_bytes' slack
+    return bytes;
 }
 // the image of ONE call, built on the call's stream right in front of the GEMM; returns the image bytes
 long long build_wimage(const float* W, void* img, int rows, int row0, long long ld, int trans, const SegMatDev& xd, int col_tiles, hipStream_t s,
-                       bool ready) {
+                       bool ready, bool h2 = false, long long welems = 0) {
     WimgGroup G;
     G.count = 1;
-    const long long bytes = wimage_job(G.job[0], W, img, rows, row0, ld, trans, xd, col_tiles);
-    if (!ready) hipLaunchKernelGGL(wimage_kernel, dim3((unsigned)G.job[0].block_end), dim3(256), 0, s, G);
+    const long long bytes = wimage_job(G.job[0], W, img, rows, row0, ld, trans, xd, col_tiles, h2, welems);
+    if (!ready) {
+        if (h2) {
+            hipLaunchKernelGGL(wamax_kernel, dim3(WPART), dim3(256), 0, s, G);
+            hipLaunchKernelGGL(wimage_kernel<true>, dim3((unsigned)G.job[0].block_end), dim3(256), 0, s, G);
+        } else {
+            hipLaunchKernelGGL(wimage_kernel<false>, dim3((unsigned)G.job[0].block_end), dim3(256), 0, s, G);
+        }
+    }
     return bytes;
 }
 // the data gradient's row operand (dZ [M, N], one plain segment) and the leading destination columns nothing is stored for
@@ -819,8 +941,27 @@ extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float
 }
 
 // dtc_linear_fwd_s3 whose result also (Y != NULL) or only (Y == NULL) leaves as the activation image Yimg = image(M, N)
-extern "C" int dtc_linear_fwd_s3i(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
-                                  void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream) {
+namespace {
+// The row operand's amax slots of an fp16 launch.  A segment that brings none gets the amax of exactly its block (rows < M, its
+// columns) computed here, into the call's own scratch: `scratch` = four records behind the weight image's partial maxima
+int h2_operand(const DtcSegMat* X, const SegMatDev& xd, int M, H2Arg& a, void* scratch, hipStream_t s) {
+    a = H2Arg{};
+    AmaxGroup G;
+    G.count = 0;
+    for (int i = 0; i < X->nseg; ++i) {
+        if (X->seg[i].amax != nullptr) {
+            a.xa[i] = X->seg[i].amax;
+        } else {
+            u32* slot = reinterpret_cast<u32*>(scratch) + i * (AMAX_RECORD_BYTES / 4);
+            a.xa[i] = slot;
+            amax_item(G, xd.s[i].ptr, xd.s[i].gather ? xd.idx : nullptr, xd.s[i].ld, xd.s[i].col0, xd.s[i].width, M, slot);
+        }
+    }
+    DTC_REQUIRE(amax_group_run(G, scratch, 4 * AMAX_RECORD_BYTES, s), "hipMemsetAsync failed");
+    return DTC_OK;
+}
+int fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
+           void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream, bool h2, uint32_t* y_amax) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && (Y == nullptr || ldy >= N), "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
     DTC_REQUIRE(W && (Y || Yimg) && dtc::aligned16(Yimg), "null / unaligned pointer");
     DTC_REQUIRE(Yimg == nullptr || dtc_s3_aimage_bytes(M, N) < (1ll << 31), "image beyond 2 GiB");
@@ -836,16 +977,41 @@ extern "C" int dtc_linear_fwd_s3i(const DtcSegMat* X, const float* W, const floa
     if (relu_mask)
         DTC_REQUIRE(act == DTC_ACT_RELU && (wide || Yimg) && M % BM == 0 && N % 128 == 0, "sign record (split path): M=%d and N=%d must be multiples of 128", M, N);
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    if (wimage_on()) {
+    if (h2) {
+        DTC_REQUIRE(wimage_on() && Yimg == nullptr, "fp16 path: needs weight images (DTC_S3_WIMG) and writes no activation image");
+        DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
+        H2Arg a;
+        const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0, true, (long long)N * K);
+        rc = h2_operand(X, xd, M, a, reinterpret_cast<char*>(wplanes) + ib + 4 * WPART, s);
+        if (rc != DTC_OK) return rc;
+        a.ya[0] = y_amax;
+        a.wa = reinterpret_cast<const u32*>(reinterpret_cast<const char*>(wplanes) + ib);
+        hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD, true, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
+                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)wplanes, ib, yo, 0, a);
+    } else if (wimage_on()) {
         DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
         const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
-                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)wplanes, ib, yo, 0);
+                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)wplanes, ib, yo, 0, H2Arg{});
     } else {
         hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
-                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)nullptr, 0ll, yo, 0);
+                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)nullptr, 0ll, yo, 0, H2Arg{});
     }
     return dtc::check_launch("linear_fwd_s3");
+}
+}  // namespace
+
+extern "C" int dtc_linear_fwd_s3i(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
+                                  void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream) {
+    return fwd_s3(X, W, b, Y, ldy, Yimg, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, false, nullptr);
+}
+
+// The same layer on the two-term fp16 path (s3_core.hpp): a segment of X brings the amax slot of its source tensor (DtcSeg.amax) or
+// none (NULL: computed here, one memset + one small launch in front of the GEMM), y_amax (may be NULL) receives max(*y_amax, largest |Y| written) -- zero it before the first kernel that writes Y
+extern "C" int dtc_linear_fwd_h2(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
+                                 void* wplanes, int wimage_ready, uint32_t* y_amax, int M, int N, int K, int act, void* stream) {
+    DTC_REQUIRE(Y, "null pointer");
+    return fwd_s3(X, W, b, Y, ldy, nullptr, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, true, y_amax);
 }
 
 // dX = (dZ W) * act'(.), W [N, K] as stored (the kernel's reduction-contiguous operand, the planes of W^T, is prepared here);
@@ -859,9 +1025,10 @@ extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W
 
 // dtc_linear_dgrad_s3 whose destination block `img_seg` (its first column and width multiples of 8 / 16) ALSO leaves as the activation
 // image dXimg = image(M, width of the block); a block that accumulates is then only read (the sum exists as the image)
-extern "C" int dtc_linear_dgrad_s3i(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, void* dXimg, int img_seg,
-                                    const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N,
-                                    int K, int act, void* stream) {
+namespace {
+int dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, void* dXimg, int img_seg,
+             const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N,
+             int K, int act, void* stream, bool h2, const uint32_t* dz_amax) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
     DTC_REQUIRE(dZ && W && wplanes && dtc::aligned16(wplanes), "null pointer / unaligned scratch");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
@@ -899,19 +1066,64 @@ extern "C" int dtc_linear_dgrad_s3i(const float* dZ, int64_t lddz, const float* 
     else if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)K;
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s, bytes);
     // roles inside the kernel: output columns = K of the layer, reduction = N of the layer
-    if (wimage_on()) {
+    if (h2) {
+        DTC_REQUIRE(wimage_on() && dXimg == nullptr, "fp16 path: needs weight images and writes no activation image");
+        H2Arg a{};
+        for (int i = 0; i < dX->nseg; ++i) a.ya[i] = dX->seg[i].amax;
+        const long long ib = build_wimage(W, wplanes, K, col_skip, K, 1, zin, (int)dtc::ceil_div(K - col_skip, 128), s, wimage_ready != 0, true, (long long)N * K);
+        a.xa[0] = dz_amax;
+        if (dz_amax == nullptr) {                     // dZ came without a slot: its amax into the call's scratch behind the image
+            u32* slot = reinterpret_cast<u32*>(reinterpret_cast<char*>(wplanes) + ib + 4 * WPART);
+            AmaxGroup G;
+            G.count = 0;
+            amax_item(G, dZ, nullptr, (long long)lddz, 0, N, M, slot);
+            DTC_REQUIRE(amax_group_run(G, slot, AMAX_RECORD_BYTES, s), "hipMemsetAsync failed");
+            a.xa[0] = slot;
+#ifdef DTC_H2_DEBUG
+            if (getenv("DTC_H2_DUMP") && N == 512 && K == 128) {
+                (void)hipStreamSynchronize(s);
+                u32 h[AMAX_RECORD_BYTES / 4];
+                (void)hipMemcpy(h, slot, sizeof h, hipMemcpyDeviceToHost);
+                u32 m = 0;
+                for (int i = 0; i < AMAX_SUB; ++i) m = h[i * AMAX_STRIDE] > m ? h[i * AMAX_STRIDE] : m;
+                fprintf(stderr, "H2DUMP dgrad M=%d record max %08x  words:", M, m);
+                for (int i = 0; i < AMAX_SUB; ++i) fprintf(stderr, " %08x", h[i * AMAX_STRIDE]);
+                fprintf(stderr, "  blocks %d slot %p wplanes %p ib %lld\n", G.it[0].block_end, (void*)slot, wplanes, ib);
+            }
+#endif
+        }
+        a.wa = reinterpret_cast<const u32*>(reinterpret_cast<const char*>(wplanes) + ib);
+        hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, true, true>), dim3(grid), dim3(256), 0, s, zin, (const float*)nullptr, (const float*)nullptr,
+                           (float*)nullptr, 0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{},
+                           (const u32x4*)wplanes, ib, yo, img_seg, a);
+    } else if (wimage_on()) {
         const long long ib = build_wimage(W, wplanes, K, col_skip, K, 1, zin, (int)dtc::ceil_div(K - col_skip, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, true>), dim3(grid), dim3(256), 0, s, zin, (const float*)nullptr, (const float*)nullptr,
                            (float*)nullptr, 0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{},
-                           (const u32x4*)wplanes, ib, yo, img_seg);
+                           (const u32x4*)wplanes, ib, yo, img_seg, H2Arg{});
     } else {
         float* WT = (float*)wplanes;
         hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dtc::ceil_div(K, 32), (unsigned)dtc::ceil_div(N, 32)), dim3(256), 0, s, W, WT, N, K);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, false>), dim3(grid), dim3(256), 0, s, zin, (const float*)WT, (const float*)nullptr,
                            (float*)nullptr, 0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{},
-                           (const u32x4*)nullptr, 0ll, yo, img_seg);
+                           (const u32x4*)nullptr, 0ll, yo, img_seg, H2Arg{});
     }
     return dtc::check_launch("linear_dgrad_s3");
+}
+}  // namespace
+
+extern "C" int dtc_linear_dgrad_s3i(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, void* dXimg, int img_seg,
+                                    const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N,
+                                    int K, int act, void* stream) {
+    return dgrad_s3(dZ, lddz, W, dX, dXimg, img_seg, Xsaved, ldxs, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, false, nullptr);
+}
+
+// The data gradient on the two-term fp16 path: dz_amax = amax slot of dZ; every destination block with a slot (dX->seg[i].amax, may be
+// NULL) receives max(slot, largest |value| written to it) -- for an accumulating block the value written is the sum
+extern "C" int dtc_linear_dgrad_h2(const float* dZ, int64_t lddz, const uint32_t* dz_amax, const float* W, const DtcSegMat* dX, const float* Xsaved,
+                                   int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
+                                   void* stream) {
+    return dgrad_s3(dZ, lddz, W, dX, nullptr, 0, Xsaved, ldxs, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, true, dz_amax);
 }
 
 extern "C" int64_t dtc_linear_fwd_mse_s3_parts(int M, int N) {
@@ -920,9 +1132,10 @@ extern "C" int64_t dtc_linear_fwd_mse_s3_parts(int M, int N) {
 }
 
 // dtc_linear_fwd_mse on the split-precision path (sq_part: dtc_linear_fwd_mse_s3_parts(M, N) doubles)
-extern "C" int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
-                                     int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
-                                     double* sq_part, void* wplanes, int wimage_ready, int M, int N, int K, void* stream) {
+namespace {
+int fwd_mse_s3(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
+               int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
+               double* sq_part, void* wplanes, int wimage_ready, int M, int N, int K, void* stream, bool h2, uint32_t* dy_amax) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N, "bad shape M=%d N=%d K=%d", M, N, K);
     DTC_REQUIRE(W && target && tidx && dY && sq_part, "null pointer");
     DTC_REQUIRE(tcol0 >= 0 && tcol0 + N <= ldt && target_rows > 0, "target columns [%d, %d) outside its %lld-wide rows", tcol0,
@@ -936,33 +1149,63 @@ extern "C" int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const f
     const MseEpiS3 mse{target, (const long long*)tidx, (long long)ldt, target_rows * ldt * 4, tcol0, scale, sq_part};
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s,
                         4.0 * ((double)M * K + (double)N * K + 2.0 * M * N));
-    if (wimage_on()) {
+    if (h2) {
+        DTC_REQUIRE(wimage_on() && wplanes && dtc::aligned16(wplanes), "fp16 path: needs weight images; null / unaligned weight-image scratch");
+        H2Arg a;
+        const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0, true, (long long)N * K);
+        rc = h2_operand(X, xd, M, a, reinterpret_cast<char*>(wplanes) + ib + 4 * WPART, s);
+        if (rc != DTC_OK) return rc;
+        a.ya[0] = dy_amax;
+        a.wa = reinterpret_cast<const u32*>(reinterpret_cast<const char*>(wplanes) + ib);
+        hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE, true, true>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
+                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)wplanes, ib, ImgOut{nullptr, 0}, 0, a);
+    } else if (wimage_on()) {
         DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
         const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE, true>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
-                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)wplanes, ib, ImgOut{nullptr, 0}, 0);
+                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)wplanes, ib, ImgOut{nullptr, 0}, 0, H2Arg{});
     } else {
         hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE, false>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
-                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)nullptr, 0ll, ImgOut{nullptr, 0}, 0);
+                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)nullptr, 0ll, ImgOut{nullptr, 0}, 0, H2Arg{});
     }
     return dtc::check_launch("linear_fwd_mse_s3");
+}
+}  // namespace
+
+extern "C" int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
+                                     int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
+                                     double* sq_part, void* wplanes, int wimage_ready, int M, int N, int K, void* stream) {
+    return fwd_mse_s3(X, W, b, target, ldt, target_rows, tcol0, tidx, scale, dY, lddy, sq_part, wplanes, wimage_ready, M, N, K, stream, false, nullptr);
+}
+
+// dtc_linear_fwd_mse_s3 on the two-term fp16 path; dy_amax (may be NULL): amax slot of the gradient dY it writes
+extern "C" int dtc_linear_fwd_mse_h2(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
+                                     int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
+                                     double* sq_part, void* wplanes, int wimage_ready, uint32_t* dy_amax, int M, int N, int K, void* stream) {
+    return fwd_mse_s3(X, W, b, target, ldt, target_rows, tcol0, tidx, scale, dY, lddy, sq_part, wplanes, wimage_ready, M, N, K, stream, true, dy_amax);
 }
 
 // The weight images of `count` later calls in one launch per WIMG_MAX_JOBS jobs (a trainer builds the images of all layers of an
 // optimisation step at its start and passes wimage_ready = 1 to the calls): job i describes the call exactly as the call will --
 // trans == 0: dtc_linear_fwd_s3 / dtc_linear_fwd_mse_s3 with operand `seg` = X; trans == 1: dtc_linear_dgrad_s3 with `seg` = dX.
-extern "C" int dtc_s3_wimage_group(const DtcWimgJob* jobs, int count, void* stream) {
+namespace {
+int wimage_group(const DtcWimgJob* jobs, int count, void* stream, bool h2) {
     DTC_REQUIRE(jobs && count > 0, "no jobs");
     DTC_REQUIRE(wimage_on(), "weight images are switched off (DTC_S3_WIMG=0)");
     hipStream_t s = (hipStream_t)stream;
     double elems = 0.0;
     for (int i = 0; i < count; ++i) elems += (double)jobs[i].N * jobs[i].K;
-    dtc::ProfScope prof("wimage", 0.0, s, 10.0 * elems);                 // 4 bytes read, 6 written per weight
+    dtc::ProfScope prof("wimage", 0.0, s, (h2 ? 12.0 : 10.0) * elems);   // 4 bytes read, 6 written per weight (fp16 terms: read twice, 4 written)
     WimgGroup G;
     G.count = 0;
     auto flush = [&]() {
         if (G.count == 0) return;
-        hipLaunchKernelGGL(wimage_kernel, dim3((unsigned)G.job[G.count - 1].block_end), dim3(256), 0, s, G);
+        if (h2) {
+            hipLaunchKernelGGL(wamax_kernel, dim3((unsigned)(WPART * G.count)), dim3(256), 0, s, G);
+            hipLaunchKernelGGL(wimage_kernel<true>, dim3((unsigned)G.job[G.count - 1].block_end), dim3(256), 0, s, G);
+        } else {
+            hipLaunchKernelGGL(wimage_kernel<false>, dim3((unsigned)G.job[G.count - 1].block_end), dim3(256), 0, s, G);
+        }
         G.count = 0;
     };
     for (int i = 0; i < count; ++i) {
@@ -978,11 +1221,11 @@ extern "C" int dtc_s3_wimage_group(const DtcWimgJob* jobs, int count, void* stre
             int col_skip;
             dgrad_operands(zin, xd, nullptr, 0, 0, h.N, h.K, col_skip);
             DTC_REQUIRE(col_skip < h.K, "job %d: every destination segment is NULL", i);
-            wimage_job(J, h.W, h.img, h.K, col_skip, h.K, 1, zin, (int)dtc::ceil_div(h.K - col_skip, 128));
+            wimage_job(J, h.W, h.img, h.K, col_skip, h.K, 1, zin, (int)dtc::ceil_div(h.K - col_skip, 128), h2, (long long)h.N * h.K);
         } else {
             int rc = to_dev(h.seg, xd, h.K, false, 0);
             if (rc != DTC_OK) return rc;
-            wimage_job(J, h.W, h.img, h.N, 0, h.K, 0, xd, (int)dtc::ceil_div(h.N, 128));
+            wimage_job(J, h.W, h.img, h.N, 0, h.K, 0, xd, (int)dtc::ceil_div(h.N, 128), h2, (long long)h.N * h.K);
         }
         if (G.count > 0) J.block_end += G.job[G.count - 1].block_end;
         if (++G.count == WIMG_MAX_JOBS) flush();
@@ -990,7 +1233,44 @@ extern "C" int dtc_s3_wimage_group(const DtcWimgJob* jobs, int count, void* stre
     flush();
     return dtc::check_launch("s3_wimage_group");
 }
+}  // namespace
 
+extern "C" int dtc_s3_wimage_group(const DtcWimgJob* jobs, int count, void* stream) { return wimage_group(jobs, count, stream, false); }
+// the images of the two-term fp16 calls (dtc_linear_fwd_h2 / _mse_h2 / dtc_linear_dgrad_h2): same jobs, same buffers (dtc_s3_planes_bytes)
+extern "C" int dtc_h2_wimage_group(const DtcWimgJob* jobs, int count, void* stream) { return wimage_group(jobs, count, stream, true); }
+
+// ---- amax of an operand that no kernel published one for (rollout storage, a tensor written by a torch op): slot = bit pattern of the
+// largest |x| over the rows < M (gathered through X.idx where a segment asks for it) and the columns of every segment
+namespace {
+__global__ __launch_bounds__(256) void amax_kernel(const SegMatDev X, int M, u32* __restrict__ slot) {
+    u32 m = 0u;
+    for (int row = blockIdx.x; row < M; row += gridDim.x) {
+        for (int i = 0; i < X.nseg; ++i) {
+            const SegDev& sd = X.s[i];
+            const float* src = sd.ptr + (sd.gather ? X.idx[row] : (long long)row) * sd.ld + sd.col0;
+            for (int c = threadIdx.x; c < sd.width; c += 256) {
+                const u32 b = abs_bits(src[c]);
+                m = b > m ? b : m;
+            }
+        }
+    }
+    amax_publish(slot, m);
+}
+}  // namespace
+
+extern "C" int64_t dtc_amax_record_bytes(void) { return AMAX_RECORD_BYTES; }
+
+extern "C" int dtc_amax(const DtcSegMat* X, int M, uint32_t* slot, void* stream) {
+    DTC_REQUIRE(X && slot && M > 0, "null pointer / bad shape");
+    SegMatDev xd;
+    int rc = to_dev(X, xd, X->cols, false, M);
+    if (rc != DTC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    DTC_REQUIRE(hipMemsetAsync(slot, 0, AMAX_RECORD_BYTES, s) == hipSuccess, "hipMemsetAsync failed");
+    const int grid = M < 2048 ? M : 2048;
+    hipLaunchKernelGGL(amax_kernel, dim3(grid), dim3(256), 0, s, xd, M, (u32*)slot);
+    return dtc::check_launch("amax");
+}
 
 // =====================================================================================================================
 // Round 4: ACTIVATION IMAGES.  The X side of linear_s3_kernel is converted fp32 -> bf16 x 3 inside the K loop of every one of
@@ -1380,3 +1660,14 @@ extern "C" int dtc_linear_dgrad_i3(const void* dZimg, const float* W, float* dX,
                        MseEpiS3{});
     return dtc::check_launch("linear_dgrad_i3");
 }
+
+#ifdef DTC_H2_DEBUG
+// debug build only: (max, min) over the workgroups of the launches since the last call of ex + 1000, ew + 1000 and the X amax bits
+extern "C" int dtc_h2_debug(uint32_t* out6) {
+    u32 h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof h) != hipSuccess) return 1;
+    for (int i = 0; i < 6; ++i) out6[i] = h[i];
+    const u32 init[8] = {0u, 0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u, 0u};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), init, sizeof init) != hipSuccess;
+}
+#endif

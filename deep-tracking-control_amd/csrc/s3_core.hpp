@@ -36,6 +36,151 @@ __device__ __forceinline__ Split3 split3(f32x4 v) {
     return s;
 }
 
+// ---- two-term fp16 split (round 4, "h2") --------------------------------------------------------------------------------------
+// An fp32 operand x of a tensor whose largest magnitude is amax is scaled by a power of two (exact) so that amax lands in
+// [2^14, 2^15), then written as hi + lo with hi = fp16(x 2^e), lo = fp16(x 2^e - hi) (the remainder is an exact fp32 subtraction; both
+// conversions round to nearest even).  hi carries 11 significant bits, lo the next 11: |x 2^e - (hi + lo)| <= max(2^-22 |x 2^e|, 2^-25)
+// -- the second bound is fp16's subnormal spacing, reached by elements more than 2^18 below amax (their error is 2^-40 amax).
+// A product needs THREE fp16 MFMAs (lo hi', hi lo', hi hi': 11-bit x 11-bit products are exact in the fp32 accumulator; the dropped
+// lo lo' is 2^-22 of the product) instead of six bf16 ones, and two planes instead of three in LDS; the accumulator is scaled back by
+// 2^-(e + e') (v_ldexp_f32, exact) before the epilogue.  amax travels as the BIT PATTERN of |x| in a u32 slot (unsigned order = float
+// order for non-negative floats; a NaN pattern is larger than every number, so a poisoned operand poisons the scale and the result).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 cvt_pk_f16(float lo, float hi) {         // one v_cvt_pk_f16_f32
+    return __builtin_bit_cast(u32, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+__device__ __forceinline__ float f16_lo(u32 p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float f16_hi(u32 p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
+// scale exponent of an operand whose amax slot holds `bits`: 14 - floor(log2 amax) for a normal amax; zero / subnormal amax: 141 (the
+// scaled values stay below 2^15); inf / NaN: -114 (the values are inf / NaN whatever the scale)
+__device__ __forceinline__ int h2_exp(u32 bits) { return 141 - (int)((bits >> 23) & 0xffu); }
+__device__ __forceinline__ u32 abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+struct Split2 {
+    u32x2 p[2];
+};
+__device__ __forceinline__ Split2 split2(f32x4 v, int e) {
+    const float x0 = __builtin_ldexpf(v[0], e), x1 = __builtin_ldexpf(v[1], e), x2 = __builtin_ldexpf(v[2], e), x3 = __builtin_ldexpf(v[3], e);
+    // (scalar halves on purpose: with the pair taken back out of the u32x2 through a vector bit_cast, hipcc 7.2 subtracted the FIRST
+    // pair's values from the second pair as well)
+    const u32 h0 = cvt_pk_f16(x0, x1), h1 = cvt_pk_f16(x2, x3);
+    Split2 s;
+    s.p[0] = u32x2{h0, h1};
+    s.p[1] = u32x2{cvt_pk_f16(x0 - f16_lo(h0), x1 - f16_hi(h0)), cvt_pk_f16(x2 - f16_lo(h1), x3 - f16_hi(h1))};
+    return s;
+}
+// the two representations behind one interface: planes per operand, MFMA passes per 16-k block (smallest terms first), the split
+template <bool H2>
+struct Prec {
+    static constexpr int NP = H2 ? 2 : 3, NT = H2 ? 3 : 6;
+    u32x2 p[NP];
+    static __device__ __forceinline__ int pa(int t) { return H2 ? (t == 0 ? 1 : 0) : (t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0); }
+    static __device__ __forceinline__ int pb(int t) { return H2 ? (t == 1 ? 1 : 0) : (t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0); }
+    static __device__ __forceinline__ Prec split(f32x4 v, int e) {
+        Prec r;
+        if constexpr (H2) {
+            const Split2 s = split2(v, e);
+            r.p[0] = s.p[0];
+            r.p[1] = s.p[1];
+        } else {
+            const Split3 s = split3(v);
+            r.p[0] = s.p[0];
+            r.p[1] = s.p[1];
+            r.p[2] = s.p[2];
+        }
+        return r;
+    }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        if constexpr (H2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+// An amax slot is a RECORD of AMAX_SUB words, one per 128-byte line: a kernel's ~3000 waves reach their epilogue together, and that
+// many atomic maxima on ONE address cost ~20 us (measured: 65 instead of 46 us for the 24576 x 512 x 512 forward layer); spread over
+// 16 lines (wave -> line by workgroup and wave index) they cost nothing measurable.  Readers take the maximum of the 16 words.
+constexpr int AMAX_SUB = 16, AMAX_STRIDE = 32, AMAX_RECORD_BYTES = AMAX_SUB * AMAX_STRIDE * 4;
+__device__ __forceinline__ u32 amax_read(const u32* rec) {
+    u32 m = 0u;
+#pragma unroll
+    for (int i = 0; i < AMAX_SUB; ++i) {
+        const u32 v = __hip_atomic_load(rec + i * AMAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m = v > m ? v : m;
+    }
+    return m;
+}
+// wave-wide maximum of the lanes' |value| bit patterns -> the tensor's amax record (skipped when the line already holds as much)
+__device__ __forceinline__ void amax_publish(u32* rec, u32 m) {
+    if (rec == nullptr) return;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const u32 o = (u32)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+    }
+    u32* slot = rec + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (AMAX_SUB - 1)) * AMAX_STRIDE;
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
+}
+
+// amax of operands that come without a slot (include/dtc_hip.h: a NULL DtcSeg.amax / dz_amax): ONE memset + ONE launch for all such
+// operands of a call, into slots of the call's own scratch.  Item = a column block of a matrix, rows < M (through idx where gathered);
+// block = 8192 elements of one item.
+struct AmaxItem {
+    const float* ptr;
+    const long long* idx;       // row map (NULL: plain rows)
+    long long ld;
+    int col0, width, rows;
+    int tw_shift;               // threads across a row = 1 << tw_shift (the power of two >= width, at most 256)
+    int rows_per_block, block_end;      // block_end: running sum of blocks over the items
+    u32* slot;
+};
+constexpr int AMAX_MAX_ITEMS = 60, AMAX_BLOCK_ELEMS = 8192;
+struct AmaxGroup {
+    int count;
+    AmaxItem it[AMAX_MAX_ITEMS];
+};
+// block = rows_per_block whole rows of one item (~8192 elements); thread = (row of the pass, column): consecutive lanes read consecutive
+// floats of a row, no division anywhere
+__global__ __launch_bounds__(256) void amax_group_kernel(const AmaxGroup G) {
+    int i = 0, b = blockIdx.x;
+    while (i < G.count - 1 && b >= G.it[i].block_end) ++i;
+    if (i > 0) b -= G.it[i - 1].block_end;
+    const AmaxItem& I = G.it[i];
+    const int tw = 1 << I.tw_shift, c0 = threadIdx.x & (tw - 1), rstep = 256 >> I.tw_shift;
+    const int r_end = min(I.rows, (b + 1) * I.rows_per_block);
+    u32 m = 0u;
+    for (int row = b * I.rows_per_block + (threadIdx.x >> I.tw_shift); row < r_end; row += rstep) {
+        const float* src = I.ptr + (I.idx ? I.idx[row] : (long long)row) * I.ld + I.col0;
+        for (int c = c0; c < I.width; c += tw) {
+            const u32 v = abs_bits(src[c]);
+            m = v > m ? v : m;
+        }
+    }
+    amax_publish(I.slot, m);
+}
+// host side: add an item, run the group (slots: the items' records, `bytes` bytes of device scratch, zeroed here)
+inline void amax_item(AmaxGroup& G, const float* ptr, const long long* idx, long long ld, int col0, int width, int rows, u32* slot) {
+    AmaxItem& I = G.it[G.count];
+    I = AmaxItem{ptr, idx, ld, col0, width, rows, 0, 0, 0, slot};
+    while ((1 << I.tw_shift) < width && I.tw_shift < 8) ++I.tw_shift;
+    I.rows_per_block = AMAX_BLOCK_ELEMS / width > 0 ? AMAX_BLOCK_ELEMS / width : 1;
+    const int step = 256 >> I.tw_shift;
+    I.rows_per_block = (I.rows_per_block + step - 1) / step * step;
+    I.block_end = (G.count > 0 ? G.it[G.count - 1].block_end : 0) + (rows + I.rows_per_block - 1) / I.rows_per_block;
+    ++G.count;
+}
+__global__ __launch_bounds__(256) void amax_zero_kernel(u32* p, int words) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < words) p[i] = 0u;
+}
+inline bool amax_group_run(const AmaxGroup& G, void* slots, size_t bytes, hipStream_t s) {
+    if (G.count == 0) return true;
+    const int words = (int)(bytes / 4);
+    hipLaunchKernelGGL(amax_zero_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (u32*)slots, words);
+    hipLaunchKernelGGL(amax_group_kernel, dim3((unsigned)G.it[G.count - 1].block_end), dim3(256), 0, s, G);
+    static const bool sync = getenv("DTC_AMAX_SYNC") != nullptr;       // debug
+    if (sync) (void)hipStreamSynchronize(s);
+    return true;
+}
+
 // LDS plane: 128 (or BN) rows x 16 k bf16 = 32 bytes per row = four 8-byte slots.  Row r keeps its k half hh (8 bf16 = 16
 // bytes) at half position hh ^ ((r >> 3) & 1): the 16 lanes of a ds_read_b128 group (rows i, half h) then touch 16
 // different 16-byte slots of the 256-byte bank row, and the 16 lanes of a ds_write_b64 group write 4 whole rows.

@@ -35,6 +35,8 @@ struct S3Job {
     float* db;
     int N, K, col_tiles, row_tiles;
     int tile_end;           // running sum of tiles over the jobs
+    const u32* za;          // two-term fp16 launches: amax slots of dZ and of X's segments (s3_core.hpp)
+    const u32* xa[4];
 };
 struct S3Group {
     int count, M, rows_per_split, splits, tiles_total;
@@ -49,9 +51,12 @@ __device__ __forceinline__ int logical(int p) { return 4 * (p & 31) + (p >> 5); 
 // the dZ loader out of its K loop (with it in, for jobs that do not need it, the loop issued 2.8 instead of 0.55 scalar and 5.9
 // instead of 4.8 vector instructions per MFMA, 180 instead of 168 registers -- two instead of three workgroups per CU -- and the
 // bench step's grouped launches ran 318 instead of 270 us).  The row-map variant keeps 180 registers (budget 3 would spill one)
-template <bool GATHER_A>
+// H2 (round 4): operands as two fp16 terms, three MFMA passes per 16 batch rows (s3_core.hpp) instead of three bf16 terms and six
+template <bool GATHER_A, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G) {
-    __shared__ __attribute__((aligned(16))) u32x2 As[2][3][TILE * 4];
+    using P = Prec<H2>;
+    constexpr int NP = P::NP, NT = P::NT;
+    __shared__ __attribute__((aligned(16))) u32x2 As[2][3][TILE * 4];          // (three planes either way: the epilogue's patches need the 48 KiB)
     __shared__ __attribute__((aligned(16))) u32x2 Bs[2][3][TILE * 4];
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     int split, t;
@@ -107,6 +112,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
     // physical row of column 4 g + e = 32 e + g: rows 32 apart share the half-swap parity, so the four slots are slot0 + 128 e
     // (immediate offsets of one address register)
     const int slot0 = wslot(g, lch);
+    int ez = 0, exx = 0;                               // fp16 path: scale exponents of dZ and of this tile's segment of X
+    if constexpr (H2) {
+        ez = __builtin_amdgcn_readfirstlane(h2_exp(amax_read(J.za)));
+        exx = __builtin_amdgcn_readfirstlane(h2_exp(amax_read(J.xa[seg])));
+    }
+    const int e_mine = is_a ? ez : exx;
 
     f32x4 v[4];
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -143,9 +154,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const f32x4 col = {v[0][e], v[1][e], v[2][e], v[3][e]};          // four batch rows of column 4 g + e
-            const Split3 s = split3(col);
+            const P s = P::split(col, e_mine);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) dst[p][slot0 + 128 * e] = s.p[p];
+            for (int p = 0; p < NP; ++p) dst[p][slot0 + 128 * e] = s.p[p];
             if constexpr (decltype(bias)::value) bsum[e] += (col[0] + col[1]) + (col[2] + col[3]);
         }
     };
@@ -159,55 +170,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
     auto mfma_stage = [&](int buf) {
-        bf16x8 a[2][3];
+        u32x4 a[2][NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot((2 * wr + i) * 32 + l31, half)]);
+                a[i][p] = reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot((2 * wr + i) * 32 + l31, half)];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            bf16x8 b[3];
+            u32x4 b[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot((2 * wc + jj) * 32 + l31, half)]);
+            for (int p = 0; p < NP; ++p)
+                b[p] = reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot((2 * wc + jj) * 32 + l31, half)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) mfma6(a[i], b, acc[i][jj]);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[i][jj] = P::mfma(a[i][P::pa(t)], b[P::pb(t)], acc[i][jj]);
         }
     };
 
     // fused stage: the MFMAs of LDS[buf] with the conversion + LDS store of the loaded block (-> LDS[buf ^ 1]) placed between the
     // MFMAs of the second column tile, one column of the block per three MFMAs (see linear_s3_kernel)
     auto stage_ilv = [&](int buf, auto bias) {
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-        bf16x8 a[2][3], b[3];
+        u32x4 a[2][NP], b[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot((2 * wr + i) * 32 + l31, half)]);
+                a[i][p] = reinterpret_cast<const u32x4*>(&As[buf][p][0])[rslot((2 * wr + i) * 32 + l31, half)];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot((2 * wc) * 32 + l31, half)]);
+        for (int p = 0; p < NP; ++p) b[p] = reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot((2 * wc) * 32 + l31, half)];
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][0], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) acc[i][0] = P::mfma(a[i][P::pa(t)], b[P::pb(t)], acc[i][0]);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot((2 * wc + 1) * 32 + l31, half)]);
+        for (int p = 0; p < NP; ++p) b[p] = reinterpret_cast<const u32x4*>(&Bs[buf][p][0])[rslot((2 * wc + 1) * 32 + l31, half)];
         u32x2(*dst)[TILE * 4] = is_a ? As[buf ^ 1] : Bs[buf ^ 1];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             __builtin_amdgcn_sched_barrier(0);
             const f32x4 col = {v[0][e], v[1][e], v[2][e], v[3][e]};
-            const Split3 sp = split3(col);
+            const P sp = P::split(col, e_mine);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) dst[p][slot0 + 128 * e] = sp.p[p];
+            for (int p = 0; p < NP; ++p) dst[p][slot0 + 128 * e] = sp.p[p];
             if constexpr (decltype(bias)::value) bsum[e] += (col[0] + col[1]) + (col[2] + col[3]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) {
-                const int m = 3 * e + t3, t = m >> 1, i = m & 1;
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[PB[t]], acc[i][1], 0, 0, 0);
+            for (int m = (2 * NT * e) / 4; m < (2 * NT * (e + 1)) / 4; ++m) {      // 3 (fp16 terms: 2, 1, 2, 1) MFMAs behind every column
+                const int t = m >> 1, i = m & 1;
+                acc[i][1] = P::mfma(a[i][P::pa(t)], b[P::pb(t)], acc[i][1]);
             }
         }
     };
@@ -238,8 +250,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
     }
 
     // ---- epilogue: the accumulators in physical order -> slab tile [128][128] (float4 rows through the wave's LDS patch)
+    if constexpr (H2) {                                // the sums carry 2^(ez + exx): scaled back exactly
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = __builtin_ldexpf(acc[i][jj][r], -(ez + exx));
+    }
     __syncthreads();
-    float* P = J.part + ((long long)split * (J.tile_end - (j > 0 ? G.job[j - 1].tile_end : 0)) + t) * (TILE * TILE);
+    float* slab = J.part + ((long long)split * (J.tile_end - (j > 0 ? G.job[j - 1].tile_end : 0)) + t) * (TILE * TILE);
     float* patch = reinterpret_cast<float*>(&As[0][0][0]) + wave * (32 * LDW);
     const int prow = lane >> 3, pc4 = lane & 7;
 #pragma unroll
@@ -247,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             patch_put(patch, acc[i][jj], half, l31);
-            float* q = P + (long long)((2 * wr + i) * 32 + prow) * TILE + (2 * wc + jj) * 32 + 4 * pc4;
+            float* q = slab + (long long)((2 * wr + i) * 32 + prow) * TILE + (2 * wc + jj) * 32 + 4 * pc4;
 #pragma unroll
             for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(q + (long long)(8 * p) * TILE) = patch_get(patch, prow + 8 * p, pc4);
         }
@@ -354,8 +374,10 @@ int group_splits_s3(int M, int tiles_total) {
     return s;
 }
 
+constexpr int SLOT_BYTES = MAX_JOBS_S3 * 5 * AMAX_RECORD_BYTES;      // 12 jobs x (dZ + 4 segments of X) records
 struct S3Plan {
     S3Group dev;
+    u32* slots;
     long long bytes;
     int red_blocks;
     double flop, algo_bytes;
@@ -382,6 +404,8 @@ int plan_s3(const DtcWgradJob* jobs, int count, int M, void* workspace, S3Plan& 
         d.dz_rows = h.dz_rows;
         d.dW = h.dW;
         d.db = h.db;
+        d.za = h.dz_amax;
+        for (int i = 0; i < 4; ++i) d.xa[i] = i < h.X.nseg ? h.X.seg[i].amax : nullptr;
         d.N = h.N;
         d.K = h.K;
         d.col_tiles = 0;
@@ -407,6 +431,8 @@ int plan_s3(const DtcWgradJob* jobs, int count, int M, void* workspace, S3Plan& 
         P.flop += 2.0 * M * (double)d.N * d.K;
         P.algo_bytes += 4.0 * ((double)M * d.N + (double)M * d.K + (double)d.N * (d.K + 1));
     }
+    P.slots = workspace ? (u32*)((char*)workspace + off) : nullptr;      // fp16 launches: amax slots of operands that came without one
+    off += SLOT_BYTES;
     P.bytes = off;
     P.red_blocks = tiles * 16 + row_tiles;
     return DTC_OK;
@@ -420,24 +446,59 @@ extern "C" int64_t dtc_wgrad_group_s3_workspace(const DtcWgradJob* jobs, int cou
     return P.bytes;
 }
 
-extern "C" int dtc_wgrad_group_s3(const DtcWgradJob* jobs, int count, int M, void* workspace, void* stream) {
+namespace {
+int wgrad_group_s3(const DtcWgradJob* jobs, int count, int M, void* workspace, void* stream, bool h2) {
     DTC_REQUIRE(workspace != nullptr && dtc::aligned16(workspace), "wgrad group workspace must be a 16-byte aligned device buffer");
     S3Plan P;
     int rc = plan_s3(jobs, count, M, workspace, P);
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (h2) {
+        // operands that came without an amax slot: one memset + one launch for all of them, slots in the workspace's tail
+        AmaxGroup A;
+        A.count = 0;
+        S3Group& Gm = P.dev;
+        for (int j = 0; j < Gm.count; ++j) {
+            S3Job& d = Gm.job[j];
+            if (d.za == nullptr) {
+                u32* slot = P.slots + (5 * j) * (AMAX_RECORD_BYTES / 4);
+                amax_item(A, d.dZ, d.dz_rows > 0 ? d.X.idx : nullptr, d.lddz, 0, d.N, M, slot);
+                d.za = slot;
+            }
+            for (int i = 0; i < d.X.nseg; ++i)
+                if (d.xa[i] == nullptr) {
+                    u32* slot = P.slots + (5 * j + 1 + i) * (AMAX_RECORD_BYTES / 4);
+                    const SegDev& sd = d.X.s[i];
+                    amax_item(A, sd.ptr, sd.gather ? d.X.idx : nullptr, sd.ld, sd.col0, sd.width, M, slot);
+                    d.xa[i] = slot;
+                }
+        }
+        DTC_REQUIRE(amax_group_run(A, P.slots, SLOT_BYTES, s), "hipMemsetAsync failed");
+    }
     const S3Group& G = P.dev;
     {
         dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, G.tiles_total, count), P.flop, s, P.algo_bytes);
         const int grid = G.per_xcd > 0 ? 8 * G.per_xcd : G.tiles_total * 8 * (int)dtc::ceil_div(G.splits, 8);
         bool any_rows = false;
         for (int j = 0; j < G.count; ++j) any_rows = any_rows || G.job[j].dz_rows > 0;
-        if (any_rows) hipLaunchKernelGGL(wgrad_s3_group_kernel<true>, dim3(grid), dim3(256), 0, s, G);
-        else hipLaunchKernelGGL(wgrad_s3_group_kernel<false>, dim3(grid), dim3(256), 0, s, G);
+        if (h2) {
+            if (any_rows) hipLaunchKernelGGL((wgrad_s3_group_kernel<true, true>), dim3(grid), dim3(256), 0, s, G);
+            else hipLaunchKernelGGL((wgrad_s3_group_kernel<false, true>), dim3(grid), dim3(256), 0, s, G);
+        } else if (any_rows) hipLaunchKernelGGL((wgrad_s3_group_kernel<true>), dim3(grid), dim3(256), 0, s, G);
+        else hipLaunchKernelGGL((wgrad_s3_group_kernel<false>), dim3(grid), dim3(256), 0, s, G);
     }
     {
         dtc::ProfScope prof(dtc::prof_shape_name("wgrad_reduce", G.splits, G.tiles_total, count), (double)P.bytes + P.bytes / (double)G.splits, s);
         hipLaunchKernelGGL(wgrad_s3_reduce_kernel, dim3(P.red_blocks), dim3(256), 0, s, G);
     }
     return dtc::check_launch("wgrad_group_s3");
+}
+}  // namespace
+
+extern "C" int dtc_wgrad_group_s3(const DtcWgradJob* jobs, int count, int M, void* workspace, void* stream) {
+    return wgrad_group_s3(jobs, count, M, workspace, stream, false);
+}
+// the same launches on the two-term fp16 path (include/dtc_hip.h: every job brings dz_amax and X.seg[i].amax)
+extern "C" int dtc_wgrad_group_h2(const DtcWgradJob* jobs, int count, int M, void* workspace, void* stream) {
+    return wgrad_group_s3(jobs, count, M, workspace, stream, true);
 }

@@ -28,7 +28,7 @@ class DtcGridCfg(C.Structure):
 
 class DtcSeg(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int64), ("col0", C.c_int32), ("width", C.c_int32),
-                ("gather", C.c_int32), ("accumulate", C.c_int32), ("rows", C.c_int64)]
+                ("gather", C.c_int32), ("accumulate", C.c_int32), ("rows", C.c_int64), ("amax", C.c_void_p)]
 
 
 class DtcSegMat(C.Structure):
@@ -37,7 +37,7 @@ class DtcSegMat(C.Structure):
 
 class DtcWgradJob(C.Structure):
     _fields_ = [("dZ", C.c_void_p), ("lddz", C.c_int64), ("X", DtcSegMat), ("dW", C.c_void_p), ("db", C.c_void_p),
-                ("N", C.c_int32), ("K", C.c_int32), ("dz_rows", C.c_int64)]
+                ("N", C.c_int32), ("K", C.c_int32), ("dz_rows", C.c_int64), ("dz_amax", C.c_void_p)]
 
 
 class DtcFwdLayer(C.Structure):
@@ -80,7 +80,7 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 7          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 8          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
@@ -138,6 +138,16 @@ _SIGS = {
                                       C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_wgrad_group_i3_workspace": (C.c_int64, [C.POINTER(DtcWgradImgJob), C.c_int, C.c_int]),
     "dtc_wgrad_group_i3": (C.c_int, [C.POINTER(DtcWgradImgJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "dtc_amax_record_bytes": (C.c_int64, []),
+    "dtc_amax": (C.c_int, [C.POINTER(DtcSegMat), C.c_int, C.c_void_p, c_stream]),
+    "dtc_h2_wimage_group": (C.c_int, [C.POINTER(DtcWimgJob), C.c_int, c_stream]),
+    "dtc_linear_fwd_h2": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_linear_dgrad_h2": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, c_f32p, C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_linear_fwd_mse_h2": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, c_i64p,
+                                        C.c_float, c_f32p, C.c_int64, c_f64p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_wgrad_group_h2": (C.c_int, [C.POINTER(DtcWgradJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_linear_fwd_mse_s3_parts": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_linear_fwd_mse_s3": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, c_i64p,
                                         C.c_float, c_f32p, C.c_int64, c_f64p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
@@ -267,7 +277,8 @@ def stream() -> int:
 
 def seg(t: torch.Tensor | None, col0: int, width: int, gather: bool = False, accumulate: bool = False,
         ld: int | None = None) -> DtcSeg:
-    """Column block [col0, col0+width) of a 2-D row-major tensor `t` (row stride = t.stride(0))."""
+    """Column block [col0, col0+width) of a 2-D row-major tensor `t` (row stride = t.stride(0)).  The block remembers `t` (`_keep`):
+    the two-term fp16 path looks the tensor's amax slot up through it (dtc_amd/ops.py: Amax)."""
     s = DtcSeg()
     if t is None:
         s.ptr, s.ld = None, 0

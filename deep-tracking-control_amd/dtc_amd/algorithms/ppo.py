@@ -767,6 +767,7 @@ class PPO:
         idx = idx.to(dev).contiguous()
         B = idx.numel()
         flat = {k: st.flat(k) for k in self._FLAT_NAMES}
+        self._amax_static(flat)
         fw, tw = ac._fwd_ws(B), self._train_ws(B)
         self.optimizer.set_lr(self.learning_rate)
         stats = torch.zeros(STAT_COLS, dtype=torch.float32, device=dev) if stats is None else stats.to(dev)
@@ -774,6 +775,7 @@ class PPO:
             self._vae_step(fw, tw, flat, idx, eps1.to(dev).contiguous(), stats)
         if which in ("ppo", "both"):
             self._ppo_step(fw, tw, flat, idx, eps2.to(dev).contiguous(), stats, self._loss_cfg())
+        ops.amax_static_clear()
         self.learning_rate = float(self.optimizer.lr_dev.item())
         for g in self.optimizer.param_groups:
             g['lr'] = self.learning_rate
@@ -781,6 +783,17 @@ class PPO:
 
     _FLAT_NAMES = ("observations", "next_observations", "privileged_observations", "observation_histories", "actions",
                    "values", "advantages", "returns", "actions_log_prob", "mu", "sigma", "base_vel")
+
+    _AMAX_STATIC = ("observations", "next_observations", "privileged_observations", "observation_histories", "base_vel")
+
+    def _amax_static(self, flat):
+        """Two-term fp16 GEMM path (ops.H2): the rollout tensors that enter GEMMs as gathered operands bring the amax of the whole
+        stored tensor -- they do not change during the update, so it is computed once here, before the compute lanes fork."""
+        if ops.SPLIT and ops.H2:
+            ops.amax_static_clear()
+            for k in self._AMAX_STATIC:
+                if k in flat and flat[k].dtype == torch.float32 and flat[k].dim() == 2:
+                    ops.amax_static(flat[k])
 
     def _loss_cfg(self):
         cfg = _ffi.DtcPpoCfg()
@@ -808,6 +821,7 @@ class PPO:
             eps2 = ops.randn((steps, B, 16), dev, seed + 2) if eps2 is None else eps2
         perm = perm.to(dev).contiguous()
         flat = {k: st.flat(k) for k in self._FLAT_NAMES}
+        self._amax_static(flat)
         fw, tw = ac._fwd_ws(B), self._train_ws(B)
         cfg = self._loss_cfg()
         self.optimizer.set_lr(self.learning_rate)
@@ -824,6 +838,7 @@ class PPO:
                 if lr_hist is not None:
                     lr_hist[k:k + 1].copy_(self.optimizer.lr_dev)
                 k += 1
+        ops.amax_static_clear()                        # the storage is about to be refilled: its amax slots are void
         # the single device -> host synchronisation of the update
         host = stats.cpu()
         self.learning_rate = float(self.optimizer.lr_dev.item())

@@ -187,6 +187,7 @@ class RecurrentDecoderPPO(PPO):
         dev = ac.std.device
         B = bt["idx"].numel()
         flat = {k: st.flat(k) for k in self._FLAT_NAMES}
+        self._amax_static(flat)
         fw, tw = ac._fwd_ws(B), self._train_ws(B)
         self.optimizer.set_lr(self.learning_rate)
         stats = torch.zeros(STAT_COLS, dtype=torch.float32, device=dev) if stats is None else stats
@@ -194,6 +195,7 @@ class RecurrentDecoderPPO(PPO):
             self._vae_step(fw, tw, flat, bt["idx"], eps1.to(dev).contiguous(), stats)
         if which in ("ppo", "both"):
             self._ppo_step_recurrent(fw, tw, flat, bt, eps2.to(dev).contiguous(), stats, self._loss_cfg())
+        ops.amax_static_clear()
         return stats
 
     def update(self, eps1=None, eps2=None, return_stats=False):

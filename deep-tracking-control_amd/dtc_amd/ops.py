@@ -88,7 +88,13 @@ def as_segmat(x, idx=None):
 # grouped weight gradient run on the bf16 matrix pipe with 3-term operand splits (fp32-level accuracy, tests/test_hip_split.py).
 # DTC_GEMM_SPLIT=0 selects the single-pass fp32 MFMA kernels everywhere; `set_split()` switches at run time (tests, A/B runs)
 import os as _os
-SPLIT = _os.environ.get("DTC_GEMM_SPLIT", "1") != "0"
+SPLIT = _os.environ.get("DTC_GEMM_SPLIT", "2") != "0"
+# representation of the split operands: two fp16 terms and three MFMA passes per product (DTC_GEMM_SPLIT=2, the default since round 4:
+# include/dtc_hip.h "two-term fp16 path"; operands bring the amax of their tensor, class Amax below) or three bf16 terms and six passes
+# (DTC_GEMM_SPLIT=1: no amax needed, twice the matrix-pipe work).  The recurrent kernels and the activation-image chain are bf16 x 3 only.
+H2 = _os.environ.get("DTC_GEMM_SPLIT", "2") == "2"
+AMAX_CHECK = _os.environ.get("DTC_AMAX_CHECK", "0") == "1"   # debug: re-derive every published amax at its use (synchronises)
+AMAX_STATS = {} if _os.environ.get("DTC_AMAX_STATS", "0") == "1" else None   # debug: (kind, shape) -> count of dtc_amax fallbacks
 # routing thresholds (output columns / reduction length); swept with bench.py in round 3: 256 / 384 -> 70.2 ms, 128 / 128 -> 69.5 ms per
 # step (the 128-column layers run longer per launch on 192 tiles of 128 x 128 -- 35 vs 28 us -- but on the second lane, under the wide GEMMs)
 SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "128"))
@@ -106,10 +112,151 @@ _NOT_NULL = 16                                             # stand-in address of
 WIMG = _os.environ.get("DTC_S3_WIMG", "1") != "0"          # the library's weight-image switch (csrc/gemm_s3.hip reads the same variable)
 
 
-def set_split(on: bool):
-    global SPLIT
+def set_split(on: bool, h2: bool | None = None):
+    """Switch the split path on / off at run time; `h2` (when given) selects the operand representation (True: two fp16 terms)."""
+    global SPLIT, H2
     SPLIT = bool(on)
+    if h2 is not None:
+        H2 = bool(h2)
     lib().dtc_set_gemm_split(int(SPLIT))
+
+
+# ---------------------------------------------------------------- amax slots of the two-term fp16 path
+class Amax:
+    """Where the fp16 path's operands get the amax of their tensor from (include/dtc_hip.h: DtcSeg.amax).
+
+    * published: a split-path kernel that writes a WHOLE tensor (all its columns) adds the largest |value| it writes to the tensor's
+      slot (atomic max in its epilogue); consumers of the tensor -- on any stream that is ordered after the producer, as every reader of
+      the data is -- read the slot.  Slots are zeroed by `reset()` at the start of a trainer phase (WeightImages.__enter__), so a
+      buffer that is rewritten phase after phase does not carry an old maximum along.
+    * static: tensors that do not change during an update (the rollout storage), computed once by `static()` before the lanes fork.
+    * everything else (outputs of the narrow single-pass kernels, of the loss / latent kernels, of torch ops) comes without a slot: the
+      library computes the amax of such an operand itself, right in front of the consumer (one memset + one launch per call for
+      all its slot-less operands, include/dtc_hip.h).
+    A tensor is identified by its base address, width and row stride; a published or static slot covers every column block of it."""
+
+    SLOTS = 512
+
+    def __init__(self, device):
+        self.device = device
+        self.rec = int(lib().dtc_amax_record_bytes())       # a slot is a record of 16 words on 16 cache lines (csrc/s3_core.hpp)
+        self.arena = torch.zeros(self.SLOTS * self.rec // 4, dtype=torch.int32, device=device)      # published slots (reset every phase)
+        self.fixed = torch.zeros(64 * self.rec // 4, dtype=torch.int32, device=device)              # static slots
+        self.index = {}            # key -> slot index in the arena
+        self.fresh = {}            # keys whose slot is valid in this phase -> the tensor (held until the phase ends: a published
+                                   # tensor's memory must not return to the caching allocator and come back as ANOTHER tensor with the
+                                   # same key while its slot is live -- the recurrent trainers allocate their activations per step)
+        self.static_index = {}     # base address -> index in `fixed`
+        self.keep = {}
+
+    def reset(self):
+        self.arena.zero_()
+        self.fresh.clear()
+        self.index.clear()
+
+    def _slot(self, key):
+        i = self.index.get(key)
+        if i is None:
+            i = self.index[key] = len(self.index)
+            if i >= self.SLOTS:
+                raise _ffi.DtcError("Amax: out of slots")
+        return self.arena.data_ptr() + self.rec * i
+
+    @staticmethod
+    def _key(t):
+        return (t.data_ptr(), t.shape[1], t.stride(0))      # (a narrower view that starts at the same address is another tensor)
+
+    def static(self, t):
+        """(Re)compute the amax of a tensor that stays unchanged until the next call (on the current stream)."""
+        i = self.static_index.setdefault(t.data_ptr(), len(self.static_index))
+        self.keep[t.data_ptr()] = t
+        if i >= 64:
+            raise _ffi.DtcError("Amax: out of static slots")
+        p = self.fixed.data_ptr() + self.rec * i
+        check(lib().dtc_amax(as_segmat(t.view(-1, t.shape[-1])), t.numel() // t.shape[-1], p, stream()), "dtc_amax")
+        return p
+
+    def out(self, t, col0, width):
+        """Slot a producer of columns [col0, col0 + width) of `t` publishes into (None: not the whole tensor -- nothing published)."""
+        if t is None or col0 != 0 or width != t.shape[1]:
+            return None
+        key = self._key(t)
+        self.fresh[key] = t
+        return self._slot(key)
+
+    def of(self, t, kind=""):
+        """Slot a consumer of (any column block of) `t` reads; None: the tensor has none (the library computes its amax)."""
+        i = self.static_index.get(t.data_ptr())
+        if i is not None:
+            return self.fixed.data_ptr() + self.rec * i
+        key = self._key(t)
+        if key in self.fresh:
+            if AMAX_CHECK:
+                self._verify(t, self._slot(key))
+            return self._slot(key)
+        if AMAX_STATS is not None:
+            k = ("no slot", kind, tuple(t.shape))
+            AMAX_STATS[k] = AMAX_STATS.get(k, 0) + 1
+        return None
+
+    def _verify(self, t, p):
+        torch.cuda.synchronize()
+        w = (p - self.arena.data_ptr()) // 4
+        have = max(int(v) & 0xffffffff for v in self.arena[w:w + self.rec // 4].tolist())
+        true = t.detach().abs().max().view(torch.int32).item() if t.numel() else 0
+        if have < true or (true > 0 and have > true + (12 << 23)):
+            raise _ffi.DtcError(f"Amax: slot of a {tuple(t.shape)} tensor holds {have:#x}, the tensor's amax is {true:#x}")
+
+
+_AMAX = {}         # device -> Amax: the registry the calls inside a WeightImages block (= one trainer phase) use
+
+
+def amax_registry(device) -> Amax:
+    a = _AMAX.get(device)
+    if a is None:
+        a = _AMAX[device] = Amax(device)
+    return a
+
+
+def amax_static(t):
+    """Trainers: the amax of a tensor that stays unchanged until `amax_static_clear()` (the rollout storage during an update), computed
+    once on the current stream -- call it before the compute lanes fork."""
+    return amax_registry(t.device).static(t)
+
+
+def amax_static_clear():
+    for a in _AMAX.values():
+        a.static_index.clear()
+        a.keep.clear()
+
+
+def _amax_in(t, kind=""):
+    """amax slot of operand tensor `t` (None: no kernel published one and it is not static -- the library computes it)."""
+    if _IMAGES is not None and _IMAGES.active:
+        return amax_registry(t.device).of(t, kind)
+    return None
+
+
+def _amax_out(t, col0, width):
+    if _IMAGES is not None and _IMAGES.active and t is not None:
+        return amax_registry(t.device).out(t, col0, width)
+    return None
+
+
+def _h2_operand(Xs, kind="fwd"):
+    """Fill the amax slots of a row operand's segments (its source tensors ride along in the descriptor's keep-alive list)."""
+    srcs = Xs._keep[1]
+    for i in range(Xs.nseg):
+        Xs.seg[i].amax = _amax_in(srcs[i], kind)
+    return Xs
+
+
+def _h2_destination(dXs):
+    srcs = dXs._keep[1]
+    for i in range(dXs.nseg):
+        s = dXs.seg[i]
+        s.amax = _amax_out(srcs[i], s.col0, s.width) if s.ptr else None
+    return dXs
 
 
 _PLANES = {}      # (device, stream, bytes) -> weight-image scratch of a split-path call
@@ -151,12 +298,19 @@ class WeightImages:
         global _IMAGES
         self.prev, _IMAGES = _IMAGES, self
         self.active = True
+        for a in _AMAX.values():   # two-term fp16 path: a new phase -- the published amax slots start from zero
+            a.reset()
         if self.entries and SPLIT and WIMG:
-            if self.jobs is None or len(self.jobs) != len(self.entries):
-                self.jobs = (_ffi.DtcWimgJob * len(self.entries))()
-                for a, e in zip(self.jobs, self.entries.values()):
-                    a.W, a.img, a.seg, a.N, a.K, a.trans = e[1]
-            check(lib().dtc_s3_wimage_group(self.jobs, len(self.jobs), stream()), "dtc_s3_wimage_group")
+            if self.jobs is None or sum(len(j) for j in self.jobs.values()) != len(self.entries):
+                self.jobs = {}
+                for rep in (False, True):                      # bf16 x 3 images and two-term fp16 images: one grouped launch each
+                    es = [e for e in self.entries.values() if e[3] == rep]
+                    if es:
+                        arr = self.jobs[rep] = (_ffi.DtcWimgJob * len(es))()
+                        for a, e in zip(arr, es):
+                            a.W, a.img, a.seg, a.N, a.K, a.trans = e[1]
+            for rep, arr in self.jobs.items():
+                check((lib().dtc_h2_wimage_group if rep else lib().dtc_s3_wimage_group)(arr, len(arr), stream()), "dtc_s3_wimage_group")
             for e in self.entries.values():
                 e[2] = True
         return self
@@ -169,21 +323,22 @@ class WeightImages:
             e[2] = False
         return False
 
-    def lookup(self, W, segs, N, K, trans):
-        """-> (image buffer, ready) for the call (W, operand segments, orientation)."""
-        key = (W.data_ptr(), N, K, trans, tuple((segs.seg[i].width, bool(segs.seg[i].ptr)) for i in range(segs.nseg)))
+    def lookup(self, W, segs, N, K, trans, h2=False):
+        """-> (image buffer, ready) for the call (W, operand segments, orientation, representation)."""
+        key = (W.data_ptr(), N, K, trans, tuple((segs.seg[i].width, bool(segs.seg[i].ptr)) for i in range(segs.nseg)), h2)
         e = self.entries.get(key)
         if e is None:
             n = int(lib().dtc_s3_planes_bytes(K, N) if trans else lib().dtc_s3_planes_bytes(N, K))
-            img = torch.empty((n + 7) // 8, dtype=torch.float64, device=W.device)
+            img = torch.zeros((n + 7) // 8, dtype=torch.float64, device=W.device)
             own = _ffi.DtcSegMat.from_buffer_copy(segs)           # the job keeps its own copy of the descriptor: the image
             own.idx = None                                        # builder reads the segment walk (widths, which destination
             for i in range(own.nseg):                             # blocks are NULL), never the operand: no address of the
                 if own.seg[i].ptr:                                # first call's tensors survives in the copy
                     own.seg[i].ptr = _NOT_NULL
                 own.seg[i].gather = 0
+                own.seg[i].amax = None
             self.keep.append((W, own))
-            e = self.entries[key] = [img, (cptr(W, f32), ptr(img), C.pointer(own), N, K, trans), False]
+            e = self.entries[key] = [img, (cptr(W, f32), ptr(img), C.pointer(own), N, K, trans), False, h2]
         elif e[2] and WIMG_CHECK:
             self._verify(e, key)
         return e[0], int(e[2])
@@ -191,11 +346,11 @@ class WeightImages:
     def _verify(self, e, key):
         """DTC_WIMG_CHECK=1 (debug): the image built at block entry must still be the image of the weights this call sees --
         a caller that changed W inside the block (the contract above) is caught here instead of computing on stale planes."""
-        fresh = torch.empty_like(e[0])
+        fresh = torch.zeros_like(e[0])
         job = (_ffi.DtcWimgJob * 1)()
         job[0].W, _img, job[0].seg, job[0].N, job[0].K, job[0].trans = e[1]
         job[0].img = ptr(fresh)
-        check(lib().dtc_s3_wimage_group(job, 1, stream()), "dtc_s3_wimage_group")
+        check((lib().dtc_h2_wimage_group if key[5] else lib().dtc_s3_wimage_group)(job, 1, stream()), "dtc_s3_wimage_group")
         n = int(lib().dtc_s3_planes_bytes(key[2], key[1]) if key[3] else lib().dtc_s3_planes_bytes(key[1], key[2]))
         if not torch.equal(fresh.view(torch.uint8)[:n], e[0].view(torch.uint8)[:n]):
             raise _ffi.DtcError(f"WeightImages: weights of layer N={key[1]} K={key[2]} trans={key[3]} changed inside the block "
@@ -205,9 +360,9 @@ class WeightImages:
 _IMAGES = None       # the WeightImages block the current calls run in, if any
 
 
-def _wimage(W, segs, N, K, trans):
+def _wimage(W, segs, N, K, trans, h2=False):
     if _IMAGES is not None:
-        return _IMAGES.lookup(W, segs, N, K, trans)
+        return _IMAGES.lookup(W, segs, N, K, trans, h2)
     return (_planes(W, K, N) if trans else _planes(W, N, K)), 0
 
 
@@ -242,7 +397,12 @@ def linear_fwd(X, W, b, Y, act=None, M=None, mask=None, split=None, Yimg=None):
                                        M, N, K, ACT[act], stream()), "dtc_linear_fwd_s3i")
         return Y
     if (SPLIT if split is None else split) and (split or (N >= SPLIT_MIN_COLS and K >= SPLIT_MIN_RED)) and (mask is None or N % 128 == 0):
-        img, ready = _wimage(W, Xs, N, K, 0)
+        img, ready = _wimage(W, Xs, N, K, 0, H2)
+        if H2:
+            check(lib().dtc_linear_fwd_h2(_h2_operand(Xs), cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
+                                          ptr(mask) if mask is not None else None, ptr(img), ready, _amax_out(Y, 0, N), M, N, K, ACT[act],
+                                          stream()), "dtc_linear_fwd_h2")
+            return Y
         check(lib().dtc_linear_fwd_s3(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
                                       ptr(mask) if mask is not None else None, ptr(img), ready, M, N, K, ACT[act], stream()),
               "dtc_linear_fwd_s3")
@@ -303,7 +463,13 @@ def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None
                                          ptr(img), ready, M, N, K, ACT[act] if mask is None else ACT["relu"], stream()), "dtc_linear_dgrad_s3i")
         return
     if (SPLIT if split is None else split) and (split or (K >= SPLIT_MIN_COLS and N >= SPLIT_MIN_RED)) and (mask is None or K % 128 == 0):
-        img, ready = _wimage(W, dXs, N, K, 1)
+        img, ready = _wimage(W, dXs, N, K, 1, H2)
+        if H2:
+            check(lib().dtc_linear_dgrad_h2(ptr(dZ), dZ.stride(0), _amax_in(dZ, "dgrad"), cptr(W, f32), _h2_destination(dXs),
+                                            ptr(Xsaved) if mask is None else None, Xsaved.stride(0) if Xsaved is not None else 0,
+                                            ptr(mask) if mask is not None else None, ptr(img), ready, M, N, K,
+                                            ACT[act] if mask is None else ACT["relu"], stream()), "dtc_linear_dgrad_h2")
+            return
         check(lib().dtc_linear_dgrad_s3(ptr(dZ), dZ.stride(0), cptr(W, f32), dXs, ptr(Xsaved) if mask is None else None,
                                         Xsaved.stride(0) if Xsaved is not None else 0, ptr(mask) if mask is not None else None,
                                         ptr(img), ready, M, N, K, ACT[act] if mask is None else ACT["relu"], stream()),
@@ -463,8 +629,16 @@ def wgrad_group(jobs, M, workspace, stream_ptr=None, split=None):
     jobs: list of (dZ [M,N], X tensor | DtcSegMat [M,K], dW [N,K], db [N] | None)."""
     arr, keep = _wgrad_jobs(jobs)
     s3 = SPLIT if split is None else split
-    check((lib().dtc_wgrad_group_s3 if s3 else lib().dtc_wgrad_group)(arr, len(jobs), M, ptr(workspace),
-                                                                       stream() if stream_ptr is None else stream_ptr),
+    sp = stream() if stream_ptr is None else stream_ptr
+    if s3 and H2:
+        for a, (dZ, Xs, _dW, _db) in zip(arr, keep):
+            a.dz_amax = _amax_in(dZ, "wgrad dZ")
+            srcs = Xs._keep[1]
+            for i in range(Xs.nseg):
+                a.X.seg[i].amax = _amax_in(srcs[i], "wgrad X")
+        check(lib().dtc_wgrad_group_h2(arr, len(jobs), M, ptr(workspace), sp), "dtc_wgrad_group_h2")
+        return keep
+    check((lib().dtc_wgrad_group_s3 if s3 else lib().dtc_wgrad_group)(arr, len(jobs), M, ptr(workspace), sp),
           "dtc_wgrad_group_s3" if s3 else "dtc_wgrad_group")
     return keep
 
@@ -568,7 +742,11 @@ def linear_fwd_mse(X, W, b, target, tcol0, tidx, dY, sq_part, M=None, split=None
     args = (Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, cptr(target, f32), target.stride(0), target.shape[0], tcol0,
             cptr(tidx, torch.int64), 2.0 / (M * N), ptr(dY), dY.stride(0), ptr(sq_part))
     if s3:
-        img, ready = _wimage(W, Xs, N, K, 0)
+        img, ready = _wimage(W, Xs, N, K, 0, H2)
+        if H2:
+            _h2_operand(Xs)
+            check(lib().dtc_linear_fwd_mse_h2(*args, ptr(img), ready, _amax_out(dY, 0, N), M, N, K, stream()), "dtc_linear_fwd_mse_h2")
+            return n_part
         check(lib().dtc_linear_fwd_mse_s3(*args, ptr(img), ready, M, N, K, stream()), "dtc_linear_fwd_mse_s3")
     else:
         check(lib().dtc_linear_fwd_mse(*args, M, N, K, stream()), "dtc_linear_fwd_mse")

@@ -38,7 +38,7 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-#define DTC_ABI_VERSION 7                    /* bumped whenever a signature or a by-value struct layout changes       */
+#define DTC_ABI_VERSION 8                    /* bumped whenever a signature or a by-value struct layout changes       */
 int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
 /* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
    DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcWgradImgJob: the binding compares them with its own layouts at load time (a library
@@ -184,6 +184,10 @@ typedef struct DtcSeg {
     int64_t rows;        /* inputs: number of rows of the source matrix (rows*ld floats behind ptr are readable: the
                           * loaders read 16 bytes at a time and bound their buffer descriptor with it -- reads past
                           * the last row return 0); outputs: unused                                              */
+    uint32_t* amax;      /* two-term fp16 path (dtc_*_h2) only, device pointer.  Inputs: slot that holds the bit pattern of the
+                          * largest |x| of the source tensor (or of any superset of the block: an upper bound costs precision only
+                          * when it is more than ~2^10 too large), written by dtc_amax or by the kernel that produced the tensor.
+                          * Outputs: slot that receives max(slot, largest |value| this call writes to the block), or NULL    */
 } DtcSeg;
 
 typedef struct DtcSegMat {
@@ -284,6 +288,31 @@ typedef struct DtcWgradImgJob {
 } DtcWgradImgJob;
 int64_t dtc_wgrad_group_i3_workspace(const DtcWgradImgJob* jobs, int count, int M);
 int dtc_wgrad_group_i3(const DtcWgradImgJob* jobs, int count, int M, void* workspace, void* stream);
+/* ---- two-term fp16 path (round 4, csrc/s3_core.hpp): the same products with every fp32 operand x scaled by a power of two chosen from
+ * its tensor's amax (largest |x|: scaled into [2^14, 2^15)) and written as hi + lo, hi = fp16(x 2^e), lo = fp16(x 2^e - hi): 22 significant
+ * bits (elements more than 2^18 below amax: absolute error 2^-40 amax), THREE fp16 MFMA passes per product (lo hi', hi lo', hi hi'; exact
+ * in the fp32 accumulator) instead of six bf16 ones, the sums scaled back exactly.  Error level of the fp32 MFMA chain
+ * (tests/test_hip_split.py); half the matrix-pipe work and energy of the bf16 x 3 path.  An operand brings its amax in a device
+ * SLOT -- a record of dtc_amax_record_bytes() bytes (16 words on 16 cache lines: the waves of a producer spread their atomic maxima over
+ * them, readers take the largest; each word the BIT PATTERN of a float; unsigned order = float order, NaN above everything) --:
+ * DtcSeg.amax for segmented operands, dz_amax for dZ; NULL = the operand has none and the call computes it (one memset + one launch in
+ * front of the GEMM for all such operands of the call).  A producer adds its result to a slot: ZERO it before the first kernel that writes the tensor (a stale
+ * larger value is harmless up to ~2^10; a smaller one overflows fp16 and the result turns NaN -- never silently wrong).  Weight
+ * images: same jobs and buffers as the bf16 ones, built by dtc_h2_wimage_group or by the call (wimage_ready = 0); the weight's own
+ * amax lives inside the image buffer. */
+int64_t dtc_amax_record_bytes(void);                                        /* size of one slot (see below)                   */
+int dtc_amax(const DtcSegMat* X, int M, uint32_t* slot, void* stream);      /* slot = amax over rows < M of all segments of X */
+int dtc_h2_wimage_group(const DtcWimgJob* jobs, int count, void* stream);
+int dtc_linear_fwd_h2(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
+                      void* wplanes, int wimage_ready, uint32_t* y_amax, int M, int N, int K, int act, void* stream);
+int dtc_linear_dgrad_h2(const float* dZ, int64_t lddz, const uint32_t* dz_amax, const float* W, const DtcSegMat* dX, const float* Xsaved,
+                        int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
+                        void* stream);
+int dtc_linear_fwd_mse_h2(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
+                          int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
+                          double* sq_part, void* wplanes, int wimage_ready, uint32_t* dy_amax, int M, int N, int K, void* stream);
+/* dtc_wgrad_group_s3 on the fp16 path: every job brings dz_amax and X.seg[i].amax (same workspace size) */
+int dtc_wgrad_group_h2(const struct DtcWgradJob* jobs, int count, int M, void* workspace, void* stream);
 int64_t dtc_linear_fwd_mse_s3_parts(int M, int N);
 int dtc_linear_fwd_mse_s3(const DtcSegMat* X, const float* W, const float* b, const float* target, int64_t ldt,
                           int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy,
@@ -353,6 +382,7 @@ typedef struct DtcWgradJob {
     int64_t dz_rows;     /* 0: row m of the product is dZ[m].  > 0 (split path only): dZ has dz_rows rows and row m of the
                           * product is dZ[X.idx[m]] -- the SAME row map as X's gathered segments (the recurrent trainers' valid
                           * rows of the padded trajectory layout: the padding rows carry zero gradient and are skipped)      */
+    const uint32_t* dz_amax;   /* dtc_wgrad_group_h2 only: amax slot of dZ (see DtcSeg.amax)                                   */
 } DtcWgradJob;
 int64_t dtc_wgrad_group_workspace(const DtcWgradJob* jobs, int count, int M);
 /* dtc_linear_wgrad over the rows idx[0 .. M) of BOTH operands (dZ [dz_rows, N] and the single-segment X [x_rows, K] share the row

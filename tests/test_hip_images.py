@@ -9,6 +9,17 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _bf16x3_split_kernels():
+    """The activation-image chain is bf16 x 3: the converting kernels these tests put next to it run in the same representation
+    (the default since round 4 is the two-term fp16 one, whose sums differ in the last bits)."""
+    from dtc_amd import ops
+    was = ops.H2
+    ops.set_split(ops.SPLIT, h2=False)
+    yield
+    ops.set_split(ops.SPLIT, h2=was)
+
+
 def _err(y, ref):
     return float((y.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-30))
 

@@ -328,7 +328,10 @@ def test_linear_fwd_detects_transposed_output():
     W = torch.arange(K * K, dtype=torch.float32).view(K, K) / 100.0        # W[n,k] asymmetric
     Y = torch.zeros(K, K, device=DEV)
     ops.linear_fwd(X.to(DEV), W.to(DEV), None, Y, None)
-    np.testing.assert_array_equal(_np(Y), W.t().numpy())
+    if ops.SPLIT and ops.H2:        # two fp16 terms carry 22 of the 24 significant bits of W (three bf16 terms: all of them)
+        np.testing.assert_allclose(_np(Y), W.t().numpy(), rtol=2.0 ** -21, atol=0)
+    else:
+        np.testing.assert_array_equal(_np(Y), W.t().numpy())
 
 
 def test_linear_fwd_segments_and_gather():
