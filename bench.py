@@ -36,7 +36,12 @@ NUM_ENVS, NUM_STEPS = 4096, 24
 FLOP_PER_ENV_STEP = 102.03e6          # 20.405 MFLOP per sample-visit x 5 epochs
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, no xf32 on gfx950
 PEAK_BF16_MFMA_TFLOPS = 2516.6        # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16), 16 x the fp32 MFMA rate
-PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0      # fp32-equivalent peak of the split path: six bf16 passes per product = 419.4
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0      # fp32-equivalent peak of the bf16 x 3 split path: six bf16 passes per product = 419.4
+PEAK_H2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0         # ... of the two-term fp16 path (the fp16 MFMA rate = the bf16 one): three passes = 838.9
+
+
+def split_peak(ops):
+    return PEAK_H2_TFLOPS if ops.H2 else PEAK_SPLIT_TFLOPS
 
 
 def cpu_baseline(full=False):
@@ -427,7 +432,9 @@ def run(a, rank, local_rank, world, wd):
         dZa = torch.randn(Mx, Nx, device=dev, generator=g) / Mx ** 0.5
         refs = dict(fwd=Xa.double() @ Wa.double().T, dgrad=dZa.double() @ Wa.double(), wgrad=dZa.double().T @ Xa.double())
         accuracy = {}
-        for name, sp in (("fp32_mfma", False), ("split_bf16x3", True)):
+        h2_was = ops.H2
+        for name, sp, h2 in (("fp32_mfma", False, h2_was), ("split_bf16x3", True, False), ("split_f16x2", True, True)):
+            ops.set_split(ops.SPLIT, h2=h2)
             Y, dX, dW, db = (torch.empty(Mx, Nx, device=dev), torch.empty(Mx, Kx, device=dev), torch.empty(Nx, Kx, device=dev),
                              torch.empty(Nx, device=dev))
             ops.linear_fwd(Xa, Wa, None, Y, None, split=sp)
@@ -437,6 +444,7 @@ def run(a, rank, local_rank, world, wd):
             ops.wgrad_group(jobs, Mx, ws, split=sp)
             err = lambda y, r: float((y.double() - r).abs().max() / r.abs().max())
             accuracy[name] = dict(fwd=err(Y, refs["fwd"]), dgrad=err(dX, refs["dgrad"]), wgrad=err(dW, refs["wgrad"]))
+        ops.set_split(ops.SPLIT, h2=h2_was)
         accuracy["measure"] = "max |y - y_fp64| / max |y_fp64| on a 24576 x 512 x 512 layer, random normal operands"
         del Xa, Wa, dZa, refs
     if world == 1 and rank == 0:
@@ -503,17 +511,27 @@ def run(a, rank, local_rank, world, wd):
         algo_bytes = sum(r["bytes"] for r in gemm)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         split = ops.SPLIT
-        peak = PEAK_SPLIT_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+        peak = split_peak(ops) if split else PEAK_FP32_MFMA_TFLOPS
         roof = dict(bound="mfma",
-                    kernel=("linear_s3_kernel (+ the weight-image launches), wgrad_s3_group_kernel (+ its reduce kernel), gru_s3_kernel: "
-                            "split-precision GEMM family -- every fp32 operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 passes per "
-                            "product, fp32 accumulate (csrc/gemm_s3.hip, wgrad_s3.hip, gru_s3.hip); the narrow layers (< 128 columns) stay on "
-                            "the single-pass v_mfma_f32_32x32x2_f32 kernels and are part of the family") if split else
+                    kernel=(("linear_s3_kernel<.., H2> (+ the weight-image launches), wgrad_s3_group_kernel<.., H2> (+ its reduce kernel): "
+                             "split-precision GEMM family -- every fp32 operand scaled by a power of two from its tensor's amax and written as "
+                             "two fp16 terms, three v_mfma_f32_32x32x16_f16 passes per product, fp32 accumulate (csrc/s3_core.hpp, gemm_s3.hip, "
+                             "wgrad_s3.hip); the recurrent kernels (gru_s3_kernel) keep three bf16 terms / six passes; the narrow layers "
+                             "(< 128 columns) stay on the single-pass v_mfma_f32_32x32x2_f32 kernels and are part of the family") if ops.H2 else
+                            ("linear_s3_kernel (+ the weight-image launches), wgrad_s3_group_kernel (+ its reduce kernel), gru_s3_kernel: "
+                             "split-precision GEMM family -- every fp32 operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 passes per "
+                             "product, fp32 accumulate (csrc/gemm_s3.hip, wgrad_s3.hip, gru_s3.hip); the narrow layers (< 128 columns) stay on "
+                             "the single-pass v_mfma_f32_32x32x2_f32 kernels and are part of the family")) if split else
                            "linear_{fwd,dgrad}_kernel, wgrad_group_kernel (+ its split-reduce kernel): fp32 v_mfma_f32_32x32x2_f32 GEMM family",
                     achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
-                    peak_definition=("dense bf16 MFMA peak 2516.6 TFLOP/s / 6 passes = 419.4 TFLOP/s of fp32-equivalent work "
-                                     "(MI355X_MICROARCH.md); achieved counts the ALGORITHMIC fp32 FLOP (2 M N K per product), not the bf16 passes")
+                    peak_definition=(("dense fp16 / bf16 MFMA peak 2516.6 TFLOP/s / 3 passes = 838.9 TFLOP/s of fp32-equivalent work "
+                                      "(MI355X_MICROARCH.md); achieved counts the ALGORITHMIC fp32 FLOP (2 M N K per product), not the fp16 "
+                                      "passes.  (Rounds 2-4 priced the family against 419.4 = the six-pass bf16 x 3 roof: DTC_GEMM_SPLIT=1.)")
+                                     if ops.H2 else
+                                     ("dense bf16 MFMA peak 2516.6 TFLOP/s / 6 passes = 419.4 TFLOP/s of fp32-equivalent work "
+                                      "(MI355X_MICROARCH.md); achieved counts the ALGORITHMIC fp32 FLOP (2 M N K per product), not the bf16 passes"))
                     if split else "fp32 MFMA peak (MI355X_MICROARCH.md)",
+                    frac_of_bf16x3_roof=achieved / PEAK_SPLIT_TFLOPS,
                     frac_of_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS,
                     traffic=None, traffic_algorithmic=algo_bytes / max(1, n_launch), launches=n_launch,
                     measured="HIP events per launch, kernels serialised on one stream; the split-reduce launches of the weight "
@@ -526,8 +544,11 @@ def run(a, rank, local_rank, world, wd):
             # real data -- both far from the data sheet's dense-bf16 peak the `peak` / `frac` fields are priced against
             try:
                 z, r = ops.mfma_sustained(dev, False), ops.mfma_sustained(dev, True)
-                roof["sustained_mfma"] = dict(zero_operands=z, random_operands=r, unit="TFLOP/s of fp32-equivalent work (bf16 FLOP / 6)",
-                                              measured="dtc_probe_mfma_stream: 768 workgroups x 4 waves, 24 v_mfma_f32_32x32x16_bf16 per stage on "
+                roof["sustained_mfma"] = dict(zero_operands=z, random_operands=r,
+                                              unit="TFLOP/s of fp32-equivalent work (fp16 FLOP / 3)" if ops.H2 else "TFLOP/s of fp32-equivalent work (bf16 FLOP / 6)",
+                                              measured=("dtc_probe_mfma_stream_h2: 768 workgroups x 4 waves, 12 v_mfma_f32_32x32x16_f16 per stage on "
+                                                        if ops.H2 else
+                                                        "dtc_probe_mfma_stream: 768 workgroups x 4 waves, 24 v_mfma_f32_32x32x16_bf16 per stage on ") +
                                                        "register operands, 12 launches of ~2-3 ms after 3 warm-up launches, HIP events")
                 roof["frac_of_sustained_random"] = achieved / r if r > 0 else None
             except Exception as e:
@@ -603,9 +624,14 @@ def run(a, rank, local_rank, world, wd):
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "gemm_arithmetic": ("f32 operands and results; wide layers on the bf16 matrix pipe as 3-term splits (a = a1 + a2 + a3 exactly to 2^-24), "
-                                "6 MFMA passes, fp32 accumulate -- fp32-level accuracy, measured below against fp64 next to the single-pass "
-                                "fp32 MFMA kernels; DTC_GEMM_SPLIT=0 selects the single-pass kernels everywhere") if ops.SPLIT else
+            "gemm_arithmetic": (("f32 operands and results; wide layers on the fp16 matrix pipe as 2-term splits (x 2^e = hi + lo, e from the "
+                                 "tensor's amax: 22 significant bits, the sums scaled back exactly), 3 MFMA passes, fp32 accumulate -- the error "
+                                 "level of the fp32 MFMA chain, measured below against fp64 next to the single-pass fp32 MFMA kernels and the "
+                                 "bf16 x 3 / six-pass kernels (DTC_GEMM_SPLIT=1); DTC_GEMM_SPLIT=0 selects the single-pass kernels everywhere")
+                                if ops.H2 else
+                                ("f32 operands and results; wide layers on the bf16 matrix pipe as 3-term splits (a = a1 + a2 + a3 exactly to 2^-24), "
+                                 "6 MFMA passes, fp32 accumulate -- fp32-level accuracy, measured below against fp64 next to the single-pass "
+                                 "fp32 MFMA kernels; DTC_GEMM_SPLIT=0 selects the single-pass kernels everywhere")) if ops.SPLIT else
                                "f32 single-pass v_mfma_f32_32x32x2_f32 (DTC_GEMM_SPLIT=0)",
             "gemm_accuracy": accuracy,
             "config": {"workload": ("BASELINE configs[1]: 4096 envs x 24 steps per GPU, ActorCriticDecoder (CE-net + "
@@ -622,7 +648,7 @@ def run(a, rank, local_rank, world, wd):
                        "headline_at_every_n": "configs[1] per rank (weak scaling: the N = 1 workload on every GPU); configs[4]'s model on "
                                               "4096 x N envs is measured in the same job at N > 1: configs4_composite", "parallelism": f"dp{world}" if world > 1 else "single",
                        "mfma_frac_whole_step": None if (composite or gru) else
-                       (FLOP_PER_ENV_STEP * value / world) / ((PEAK_SPLIT_TFLOPS if ops.SPLIT else PEAK_FP32_MFMA_TFLOPS) * 1e12),
+                       (FLOP_PER_ENV_STEP * value / world) / ((split_peak(ops) if ops.SPLIT else PEAK_FP32_MFMA_TFLOPS) * 1e12),
                        "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
                        "allreduce_bytes_per_step_per_rank": dp.bytes_reduced(coll_log) if world > 1 else 0,
                        "collectives_per_step": len(coll_log)},

@@ -9,6 +9,7 @@
 //  * dtc_gather_rows    rollout_storage.py:195-209  (`tensor.flatten(0,1)[batch_idx]`)
 //
 // Compiled with -ffp-contract=off: the scan reproduces oracle/gae.py bit for bit.
+#include "amax.hpp"
 #include "common.hpp"
 
 namespace {
@@ -203,16 +204,21 @@ extern "C" int dtc_gather_rows(const void* src, const int64_t* idx, void* dst, i
 
 namespace {
 // dst[row, 0:cols] = the segments of a DtcSegMat side by side (row-gathered where a segment asks for it): one thread per element
-__global__ __launch_bounds__(256) void pack_cols_kernel(const DtcSegMat X, float* __restrict__ dst, long long ld_dst, long long rows) {
+__global__ __launch_bounds__(256) void pack_cols_kernel(const DtcSegMat X, float* __restrict__ dst, long long ld_dst, long long rows,
+                                                        amax_u32* __restrict__ dst_amax) {
     const long long total = rows * X.cols;
+    amax_u32 m = 0u;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const long long r = e / X.cols;
         int c = (int)(e - r * X.cols), s = 0;
         while (s < X.nseg - 1 && c >= X.seg[s].width) c -= X.seg[s++].width;
         const DtcSeg& g = X.seg[s];
         const long long src_row = g.gather ? X.idx[r] : r;
-        dst[r * ld_dst + (e - r * X.cols)] = g.ptr[src_row * g.ld + g.col0 + c];
+        const float v = g.ptr[src_row * g.ld + g.col0 + c];
+        dst[r * ld_dst + (e - r * X.cols)] = v;
+        m = abs_bits(v) > m ? abs_bits(v) : m;
     }
+    amax_publish(dst_amax, m);
 }
 }  // namespace
 
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256) void pack_cols_kernel(const DtcSegMat X, float
 // into ONE dense [rows, cols] matrix: the GEMM kernels pad every segment of an operand to whole 16-k stages / 128-column tiles,
 // so three narrow segments cost three stages / three tiles where the packed block costs one (actor_critic_decoder.py:431, 550
 // `torch.cat` of the same pieces -- here only of the narrow ones; wide blocks stay in place as segments).
-extern "C" int dtc_pack_cols(const DtcSegMat* X, float* dst, int64_t ld_dst, int64_t rows, void* stream) {
+extern "C" int dtc_pack_cols(const DtcSegMat* X, float* dst, int64_t ld_dst, int64_t rows, uint32_t* dst_amax, void* stream) {
     DTC_REQUIRE(X && dst && rows >= 0 && X->nseg >= 1 && X->nseg <= 4 && ld_dst >= X->cols, "bad arguments");
     if (rows == 0) return DTC_OK;
     int cols = 0;
@@ -233,7 +239,7 @@ extern "C" int dtc_pack_cols(const DtcSegMat* X, float* dst, int64_t ld_dst, int
     dtc::ProfScope prof("pack_cols", 8.0 * (double)rows * cols, s);
     const long long total = rows * (long long)cols;
     const unsigned grid = (unsigned)(dtc::ceil_div(total, 256) < 16384 ? dtc::ceil_div(total, 256) : 16384);
-    hipLaunchKernelGGL(pack_cols_kernel, dim3(grid), dim3(256), 0, s, *X, dst, (long long)ld_dst, (long long)rows);
+    hipLaunchKernelGGL(pack_cols_kernel, dim3(grid), dim3(256), 0, s, *X, dst, (long long)ld_dst, (long long)rows, (amax_u32*)dst_amax);
     return dtc::check_launch("pack_cols");
 }
 

@@ -10,6 +10,7 @@
 //  * dtc_gaussian_act  ppo.py:141-148 (rollout side: sample, log-prob, mu, sigma)
 //
 // All reductions: per-block partials in fp64 + a single-block finalize (deterministic order).
+#include "amax.hpp"
 #include "gemm_core.hpp"
 
 namespace {
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     const float* __restrict__ old_mu, const float* __restrict__ old_sigma, const float* __restrict__ adv,
     const float* __restrict__ returns, const float* __restrict__ old_values, const long long* __restrict__ idx, DtcPpoCfg cfg,
     float* __restrict__ mean, float* __restrict__ value, float* __restrict__ dmean, float* __restrict__ dvalue,
-    float* __restrict__ dHa, long long lddha, float* __restrict__ dHc, long long lddhc, double* __restrict__ part, int B, int A) {
+    float* __restrict__ dHa, long long lddha, float* __restrict__ dHc, long long lddhc, double* __restrict__ part, int B, int A,
+    amax_u32* __restrict__ dha_amax, amax_u32* __restrict__ dhc_amax) {
     // TPR threads per row (4: 64 rows per workgroup; 8: 32 rows per workgroup = twice the workgroups, half the serial work
     // per thread -- the kernel is a latency chain per row, not a bandwidth problem)
     constexpr int NC = H / (4 * TPR);                // chunks per thread
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
         }
     }
     // ---- backward through the two heads: dHa = (dmean Wa) * act'(Ha), dHc = (dvalue Wc) * act'(Hc)
+    amax_u32 ma = 0u, mc = 0u;             // largest |dHa| / |dHc| this thread writes (amax records of the two-term fp16 GEMM path)
     if (rok) {
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
@@ -332,11 +335,15 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
             for (int e = 0; e < 4; ++e) {
                 ga[e] = act_bwd(ga[e], ha[i][e], act_prev);
                 gc[e] = act_bwd(gc[e], hc[i][e], act_prev);
+                ma = abs_bits(ga[e]) > ma ? abs_bits(ga[e]) : ma;
+                mc = abs_bits(gc[e]) > mc ? abs_bits(gc[e]) : mc;
             }
             *reinterpret_cast<f4*>(dHa + rr * lddha + 4 * (p + TPR * i)) = ga;
             *reinterpret_cast<f4*>(dHc + rr * lddhc + 4 * (p + TPR * i)) = gc;
         }
     }
+    amax_publish(dha_amax, ma);
+    amax_publish(dhc_amax, mc);
     ppo_block_partials(ok ? o.s_sur : 0.0, ok ? o.s_val : 0.0, ok ? o.s_kl : 0.0, ds, ok, A, part);
 }
 
@@ -486,7 +493,7 @@ extern "C" int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc
                                   const float* advantages, const float* returns, const float* old_values, const int64_t* idx,
                                   const DtcPpoCfg* cfg, float* mean, float* value, float* dmean, float* dvalue, float* dHa,
                                   int64_t lddha, float* dHc, int64_t lddhc, float* dstd, float* losses, double* lr,
-                                  void* workspace, int B, int num_actions, void* stream) {
+                                  void* workspace, int B, int num_actions, uint32_t* dha_amax, uint32_t* dhc_amax, void* stream) {
     DTC_REQUIRE(B > 0 && num_actions > 0 && num_actions <= MAX_ACT, "bad shape B=%d A=%d", B, num_actions);
     DTC_REQUIRE(H == 64 || H == 128 || H == 256, "hidden width %d unsupported by the fused heads (64, 128, 256)", H);
     DTC_REQUIRE(Ha && Hc && Wa && Wc && std && actions && old_logp && old_mu && old_sigma && advantages && returns && old_values,
@@ -506,7 +513,7 @@ extern "C" int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc
     dtc::ProfScope prof("ppo_heads_loss", (double)B * (4.0 * H * 4 + num_actions * 32.0), s);
 #define DTC_HL_ARGS Ha, (long long)ldha, Hc, (long long)ldhc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, \
                     advantages, returns, old_values, (const long long*)idx, *cfg, mean, value, dmean, dvalue, dHa, (long long)lddha, \
-                    dHc, (long long)lddhc, part, B, num_actions
+                    dHc, (long long)lddhc, part, B, num_actions, (amax_u32*)dha_amax, (amax_u32*)dhc_amax
     if (tpr == 8) {
         if (H == 64) hipLaunchKernelGGL((ppo_heads_loss_kernel<64, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
         else if (H == 128) hipLaunchKernelGGL((ppo_heads_loss_kernel<128, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);

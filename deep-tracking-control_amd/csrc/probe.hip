@@ -48,7 +48,50 @@ __global__ __launch_bounds__(256, 3) void mfma_stream_kernel(const u32x4* __rest
     if (s == 123.456f) sink[0] = s;                       // keeps the loop alive, never true for the operands used
 }
 
+// the two-term fp16 kernels' stream: 12 v_mfma_f32_32x32x16_f16 per wave and stage (3 passes x 2 x 2 tiles) on four accumulators
+__global__ __launch_bounds__(256, 3) void mfma_stream_h2_kernel(const u32x4* __restrict__ operands, int iters, float* __restrict__ sink) {
+    const int tid = threadIdx.x;
+    u32x4 a[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            a[i][p] = operands[((i * 2 + p) * 256 + tid) & 4095];
+            b[i][p] = operands[((4 + i * 2 + p) * 256 + tid) & 4095];
+        }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = Prec<true>::mfma(a[i][Prec<true>::pa(t)], b[j][Prec<true>::pb(t)], acc[i][j]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 123.456f) sink[0] = s;
+}
+
 }  // namespace
+
+// the fp16 stream: blocks * 4 * iters * 12 * 32768 fp16 FLOP = that / 3 of fp32-equivalent work
+extern "C" int dtc_probe_mfma_stream_h2(const void* operands, int blocks, int iters, float* sink, void* stream) {
+    DTC_REQUIRE(operands && sink && blocks > 0 && iters > 0 && dtc::aligned16(operands), "null / unaligned pointer or bad size");
+    hipLaunchKernelGGL(mfma_stream_h2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)operands, iters, sink);
+    return dtc::check_launch("probe_mfma_stream_h2");
+}
 
 // One launch of the bare MFMA stream: `blocks` workgroups of 4 waves, each `iters` stages of 24 MFMAs (6 passes x 2 x 2 tiles of
 // 32 x 32 x 16): blocks * 4 * iters * 24 * 32768 bf16 FLOP = that / 6 of fp32-equivalent work.  operands: 64 KiB of device memory

@@ -1,6 +1,7 @@
 // Shared device pieces of the split-precision (bf16 x 3) kernels: csrc/gemm_s3.hip (forward / data gradient) and
 // csrc/wgrad_s3.hip (weight gradients).  See the header comment of gemm_s3.hip.
 #pragma once
+#include "amax.hpp"
 #include "gemm_core.hpp"
 
 namespace {
@@ -55,7 +56,6 @@ __device__ __forceinline__ float f16_hi(u32 p) { return (float)__builtin_bit_cas
 // scale exponent of an operand whose amax slot holds `bits`: 14 - floor(log2 amax) for a normal amax; zero / subnormal amax: 141 (the
 // scaled values stay below 2^15); inf / NaN: -114 (the values are inf / NaN whatever the scale)
 __device__ __forceinline__ int h2_exp(u32 bits) { return 141 - (int)((bits >> 23) & 0xffu); }
-__device__ __forceinline__ u32 abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 struct Split2 {
     u32x2 p[2];
 };
@@ -95,31 +95,6 @@ struct Prec {
         else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
-// An amax slot is a RECORD of AMAX_SUB words, one per 128-byte line: a kernel's ~3000 waves reach their epilogue together, and that
-// many atomic maxima on ONE address cost ~20 us (measured: 65 instead of 46 us for the 24576 x 512 x 512 forward layer); spread over
-// 16 lines (wave -> line by workgroup and wave index) they cost nothing measurable.  Readers take the maximum of the 16 words.
-constexpr int AMAX_SUB = 16, AMAX_STRIDE = 32, AMAX_RECORD_BYTES = AMAX_SUB * AMAX_STRIDE * 4;
-__device__ __forceinline__ u32 amax_read(const u32* rec) {
-    u32 m = 0u;
-#pragma unroll
-    for (int i = 0; i < AMAX_SUB; ++i) {
-        const u32 v = __hip_atomic_load(rec + i * AMAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        m = v > m ? v : m;
-    }
-    return m;
-}
-// wave-wide maximum of the lanes' |value| bit patterns -> the tensor's amax record (skipped when the line already holds as much)
-__device__ __forceinline__ void amax_publish(u32* rec, u32 m) {
-    if (rec == nullptr) return;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const u32 o = (u32)__shfl_xor((int)m, off, 64);
-        m = o > m ? o : m;
-    }
-    u32* slot = rec + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (AMAX_SUB - 1)) * AMAX_STRIDE;
-    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
-}
-
 // amax of operands that come without a slot (include/dtc_hip.h: a NULL DtcSeg.amax / dz_amax): ONE memset + ONE launch for all such
 // operands of a call, into slots of the call's own scratch.  Item = a column block of a matrix, rows < M (through idx where gathered);
 // block = 8192 elements of one item.

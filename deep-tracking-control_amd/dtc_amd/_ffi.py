@@ -107,7 +107,7 @@ _SIGS = {
     "dtc_adv_normalize": (C.c_int, [c_f32p, c_f64p, C.c_int64, C.c_double, c_stream]),
     "dtc_gather_rows": (C.c_int, [C.c_void_p, c_i64p, C.c_void_p, C.c_int64, C.c_int64, c_stream]),
     "dtc_scatter_rows": (C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int64, C.c_int64, c_stream]),
-    "dtc_pack_cols": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_int64, c_stream]),
+    "dtc_pack_cols": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_int64, C.c_void_p, c_stream]),
     "dtc_linear_fwd": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_stream]),
     "dtc_linear_fwd_list": (C.c_int, [C.POINTER(DtcFwdLayer), C.c_int, C.c_int, c_stream]),
@@ -128,6 +128,7 @@ _SIGS = {
     "dtc_linear_dgrad_s3i": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), C.c_void_p, C.c_int, c_f32p, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_probe_mfma_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, c_stream]),
+    "dtc_probe_mfma_stream_h2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, c_stream]),
     "dtc_s3_aimage_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_s3_aimage": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_linear_fwd_i3": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -184,7 +185,7 @@ _SIGS = {
                      [c_f64p, C.c_void_p, C.c_int, C.c_int, c_stream]),
     "dtc_ppo_heads_loss": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int] + [c_f32p] * 4 + [C.c_int] + [c_f32p] * 8 +
                            [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 5 + [C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f64p,
-                                                                      C.c_void_p, C.c_int, C.c_int, c_stream]),
+                                                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_stream]),
     "dtc_lr_adapt": (C.c_int, [c_f32p, c_f64p, C.c_float, c_stream]),
     "dtc_gaussian_act": (C.c_int, [c_f32p] * 7 + [C.c_int, C.c_int, c_stream]),
     "dtc_adam_workspace": (C.c_int64, [C.c_int64]),

@@ -378,7 +378,8 @@ def relu_mask(M, N, device):
 def pack_cols(X, dst, rows=None):
     """dst[rows, :X.cols] = the segments of DtcSegMat X side by side (gathered where asked)."""
     rows = dst.shape[0] if rows is None else rows
-    check(lib().dtc_pack_cols(X, ptr(dst), dst.stride(0), rows, stream()), "dtc_pack_cols")
+    check(lib().dtc_pack_cols(X, ptr(dst), dst.stride(0), rows, _amax_out(dst, 0, X.cols) if (SPLIT and H2 and rows == dst.shape[0]) else None,
+                              stream()), "dtc_pack_cols")
     return dst
 
 
@@ -667,12 +668,16 @@ def wgrad_group_img(jobs, M, workspace, stream_ptr=None):
     return jobs
 
 
-def mfma_sustained(device, random_operands: bool, launches=12, iters=2000, blocks=768):
-    """TFLOP/s of fp32-equivalent work (bf16 FLOP / 6) the bare MFMA stream of the split kernels sustains on this chip for all-zero or
-    random-normal bf16 operand bits (dtc_probe_mfma_stream): the chip clocks to its power budget, so the two differ."""
-    ops_bits = (torch.randn(32768, device=device) if random_operands else torch.zeros(32768, device=device)).bfloat16()
+def mfma_sustained(device, random_operands: bool, launches=12, iters=2000, blocks=768, h2=None):
+    """TFLOP/s of fp32-equivalent work the bare MFMA stream of the split kernels sustains on this chip for all-zero or random operand
+    bits: the chip clocks to its power budget, so the two differ.  h2 (default: the active representation): the two-term fp16 stream
+    (12 fp16 MFMAs per stage, fp16 FLOP / 3; dtc_probe_mfma_stream_h2) instead of the bf16 x 3 one (24 per stage, bf16 FLOP / 6)."""
+    h2 = H2 if h2 is None else h2
+    src = torch.randn(32768, device=device) if random_operands else torch.zeros(32768, device=device)
+    ops_bits = src.half() if h2 else src.bfloat16()
     sink = torch.zeros(4, device=device)
-    run = lambda: check(lib().dtc_probe_mfma_stream(ptr(ops_bits), blocks, iters, ptr(sink), stream()), "dtc_probe_mfma_stream")
+    fn = lib().dtc_probe_mfma_stream_h2 if h2 else lib().dtc_probe_mfma_stream
+    run = lambda: check(fn(ptr(ops_bits), blocks, iters, ptr(sink), stream()), "dtc_probe_mfma_stream")
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -681,8 +686,9 @@ def mfma_sustained(device, random_operands: bool, launches=12, iters=2000, block
         run()
     e1.record()
     torch.cuda.synchronize()
-    flop = float(launches) * blocks * 4 * iters * 24 * 32768
-    return flop / (e0.elapsed_time(e1) * 1e-3) / 6.0 / 1e12
+    per_stage, passes = (12, 3.0) if h2 else (24, 6.0)
+    flop = float(launches) * blocks * 4 * iters * per_stage * 32768
+    return flop / (e0.elapsed_time(e1) * 1e-3) / passes / 1e12
 
 
 # ---------------------------------------------------------------- CE-net latent / losses / optimiser
@@ -772,6 +778,7 @@ def ppo_heads_loss(Ha, Hc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old
                                    cptr(old_values, f32), cptr(idx, torch.int64) if idx is not None else None, cfg,
                                    cptr(mean, f32), cptr(value, f32), cptr(dmean, f32), cptr(dvalue, f32), cptr(dHa, f32),
                                    dHa.stride(0), cptr(dHc, f32), dHc.stride(0), ptr(dstd), ptr(losses), ptr(lr), ptr(ws), B, A,
+                                   _amax_out(dHa, 0, H) if (SPLIT and H2) else None, _amax_out(dHc, 0, H) if (SPLIT and H2) else None,
                                    stream()), "dtc_ppo_heads_loss")
 
 

@@ -199,7 +199,8 @@ typedef struct DtcSegMat {
 
 /* dst[rows, X->cols] (row stride ld_dst) = the segments of X side by side, row-gathered where a segment asks for it: packs
  * the narrow leading blocks of a layer input into one dense operand (see csrc/gae.hip: dtc_pack_cols). */
-int dtc_pack_cols(const DtcSegMat* X, float* dst, int64_t ld_dst, int64_t rows, void* stream);
+int dtc_pack_cols(const DtcSegMat* X, float* dst, int64_t ld_dst, int64_t rows, uint32_t* dst_amax /* amax slot of dst (two-term fp16 GEMM
+                  path, see DtcSeg.amax) or NULL */, void* stream);
 
 /* Y[M,N] = act(X[M,K] W[N,K]^T + b).  X is segmented (host struct). */
 int dtc_linear_fwd(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy,
@@ -450,7 +451,8 @@ int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc, int64_t l
                        const float* advantages, const float* returns, const float* old_values, const int64_t* idx,
                        const DtcPpoCfg* cfg, float* mean, float* value, float* dmean, float* dvalue, float* dHa,
                        int64_t lddha, float* dHc, int64_t lddhc, float* dstd, float* losses, double* lr, void* workspace,
-                       int B, int num_actions, void* stream);
+                       int B, int num_actions, uint32_t* dha_amax, uint32_t* dhc_amax /* amax slots of dHa / dHc (two-term fp16 GEMM
+                       path, see DtcSeg.amax) or NULL */, void* stream);
 /* The learning-rate rule of ppo.py:301-307 alone (data-parallel callers run dtc_ppo_loss with
  * adaptive_schedule = 0, all-reduce the KL mean, then call this so every rank takes the same branch).
  * The slot is CONSUMED: it is overwritten with NaN, and a NaN found in it (a caller that exchanged the gradient header
@@ -531,6 +533,7 @@ void dtc_prof_reset(void);
  * SIMD, register operands taken from the 64 KiB at `operands`) -- blocks * 4 * iters * 24 * 32768 bf16 FLOP.  bench.py times it on
  * zero and on random operand bits: the rate the chip SUSTAINS (it clocks to its power budget) next to the data-sheet peak. */
 int dtc_probe_mfma_stream(const void* operands, int blocks, int iters, float* sink, void* stream);
+int dtc_probe_mfma_stream_h2(const void* operands, int blocks, int iters, float* sink, void* stream);   /* 12 fp16 MFMAs per stage (two-term path) */
 
 #ifdef __cplusplus
 }
