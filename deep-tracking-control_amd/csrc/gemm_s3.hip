@@ -288,14 +288,17 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     u32 wchunk = (u32)(tc * total) * (u32)WCH;              // byte offset of the next stage's chunk of this column tile
     // fp16 path: the scale exponents of the two operands (uniform: scalar loads)
     int ex = 0, ew = 0;
+    bool poison = false;                                    // an inf / NaN amax: the whole result turns NaN (never a silently wrong scale)
     if constexpr (H2) {
         u32 mx = 0u;
         for (int i = 0; i < X.nseg; ++i) {
             const u32 v = amax_read(h2.xa[i]);
             mx = v > mx ? v : mx;
         }
+        const u32 mw = wpart_max(h2.wa);
         ex = __builtin_amdgcn_readfirstlane(h2_exp(mx));
-        ew = __builtin_amdgcn_readfirstlane(h2_exp(wpart_max(h2.wa)));
+        ew = __builtin_amdgcn_readfirstlane(h2_exp(mw));
+        poison = __builtin_amdgcn_readfirstlane((mx >= 0x7f800000u || mw >= 0x7f800000u) ? 1 : 0) != 0;
 #ifdef DTC_H2_DEBUG
         if (threadIdx.x == 0) {
             atomicMax(&g_dbg[0], (u32)(ex + 1000));
@@ -326,22 +329,36 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     int seg = 0, kt = 0, nst = (sd.width + BK - 1) / BK;
     // operand loads run ONE stage ahead of the MFMAs.  (Two stages ahead -- two register sets -- measured slower: 91 vs 73 us
     // on 24576 x 512 x 512; the third workgroup per CU that the registers of the second set cost is worth more.)
-    f32x4 ra[NA], rb[NB ? NB : 1];
-    int klast;                                      // last valid element (0..3, < 0: none) of the loaded k chunks; >= 3: no tail
-    auto load_stage = [&](auto nbc) {               // next stage of the cursor -> registers / (W image) LDS[nbuf] (no wait)
+    // AH2 (fp16 path, round 4; -DDTC_H2_AHEAD2=1, OFF by default): the X loads run TWO stages ahead (two register sets, set = parity
+    // of the stage; the weight image's LDS-DMA stays one stage ahead, an explicit s_waitcnt before the barrier completes it while the X
+    // loads of the stage after next stay in flight).  The idea: with three MFMA passes a stage's matrix phase is ~160 ns per wave, short
+    // against a global load issued one stage earlier (3450 cycles per stage on 24576 x 512 x 512, 384 of them MFMA).  Measured: no gain --
+    // 50.1 vs 49.6 us for that layer back to back, 60.6 vs 60.8 ms per step -- for 8 more registers (132: three instead of four
+    // workgroups per CU): back to back the kernel runs at ~1240 W and 1.93 GHz, i.e. it is the power budget again, not the load latency.
+#ifndef DTC_H2_AHEAD2
+#define DTC_H2_AHEAD2 0
+#endif
+    constexpr bool AH2 = H2 && WIMG && (DTC_H2_AHEAD2 != 0);
+    f32x4 ras[AH2 ? 2 : 1][NA], rb[NB ? NB : 1];
+    int kls[AH2 ? 2 : 1];                           // last valid element (0..3, < 0: none) of the loaded k chunks; >= 3: no tail
+    auto load_w = [&](auto nbc) {                   // (W image) next stage's chunk -> LDS[nbuf] (no wait)
         constexpr int nbuf = decltype(nbc)::value;
-        const u32 ka = (u32)(kt * BK) * 4u, kw = (u32)(sd.start + kt * BK) * 4u;
         if constexpr (WIMG) {                       // issued first: the compiler waits for ALL loads once an LDS-DMA is in flight
 #pragma unroll
             for (int p = 0; p < NP; ++p)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)&BS(nbuf)[p][wave_u * 128], 16, tid * 16, wchunk + p * WIMG_PLANE, 0, 0);
             wchunk += WCH;
+            if constexpr (AH2) __builtin_amdgcn_sched_barrier(0);     // the X loads below must stay BEHIND the LDS-DMA (vmcnt arithmetic of step())
         }
+    };
+    auto load_x = [&](auto setc) {                  // next stage of the X cursor -> register set (no wait)
+        constexpr int set = decltype(setc)::value;
+        const u32 ka = (u32)(kt * BK) * 4u, kw = (u32)(sd.start + kt * BK) * 4u;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = bload4(ares, aoff[i], ka);
+        for (int i = 0; i < NA; ++i) ras[set][i] = bload4(ares, aoff[i], ka);
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = bload4(wres, woff[i], kw);
-        klast = sd.width - 1 - (kt * BK + 4 * lch);
+        kls[set] = sd.width - 1 - (kt * BK + 4 * lch);
         if (++kt == nst && seg + 1 < X.nseg) {
             ++seg;
             sd = X.s[seg];
@@ -350,8 +367,11 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
             nst = (sd.width + BK - 1) / BK;
         }
     };
+
     auto store_stage = [&](auto bc) {               // registers -> (k-tail mask) -> three bf16 planes -> LDS
         constexpr int buf = decltype(bc)::value;
+        f32x4(&ra)[NA] = ras[AH2 ? buf : 0];
+        const int klast = kls[AH2 ? buf : 0];
         if (__builtin_amdgcn_readfirstlane(klast + 4 * lch) < BK - 1) {      // (the same value in every lane) last stage of a ragged segment
 #pragma unroll
             for (int i = 0; i < NA; ++i)
@@ -417,6 +437,8 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     // ignored by this compiler): the conversion of a stage is ~110 VALU + 12 LDS stores, 24 MFMAs leave 24 x 28 idle issue cycles.
     auto stage_ilv = [&](auto bc) {
         constexpr int buf = decltype(bc)::value;
+        f32x4(&ra)[NA] = ras[AH2 ? (buf ^ 1) : 0];
+        const int klast = kls[AH2 ? (buf ^ 1) : 0];
         u32x4 a[TM][NP], b[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p)
@@ -509,18 +531,25 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
 #endif
 
     enter_segment();
-    load_stage(S0{});
+    load_w(S0{});
+    load_x(S0{});
     store_stage(S0{});
+    if constexpr (AH2) load_x(S1{});                // stage 1 on its way while stage 0's planes settle
     __syncthreads();
     // stage st in flight while the MFMAs consume the other buffer; two stages per trip (constant buffer indices)
     auto step = [&](auto bc) {
-        load_stage(std::integral_constant<int, decltype(bc)::value ^ 1>{});
+        constexpr int buf = decltype(bc)::value;
+        load_w(std::integral_constant<int, buf ^ 1>{});
+        load_x(std::integral_constant<int, AH2 ? buf : 0>{});        // AH2: stage + 2 into the set stage `buf` was converted from
 #ifndef DTC_S3_NO_ILV
         stage_ilv(bc);
 #else
         mfma_stage(bc);
-        store_stage(std::integral_constant<int, decltype(bc)::value ^ 1>{});
+        store_stage(std::integral_constant<int, buf ^ 1>{});
 #endif
+        // AH2: nothing in the stage waited for the weight chunk's LDS-DMA (the X loads the conversion waited for were issued BEFORE it):
+        // vmcnt(NA) = only the NA X loads issued after it may still be in flight (expcnt / lgkmcnt untouched: 7 / 15)
+        if constexpr (AH2) __builtin_amdgcn_s_waitcnt(0x0F70 | NA);
         __syncthreads();
     };
     // stages 0 .. total-1 are consumed two per trip; past the last stage the cursor loads nothing valid (klast < 0: the k-tail masks
@@ -538,7 +567,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], -(ex + ew));
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = poison ? __builtin_nanf("") : __builtin_ldexpf(acc[i][j][r], -(ex + ew));
     }
     u32 am = 0u;                                        // fp16 path: this lane's largest |stored value| (bit pattern)
     auto seen = [&](float v) {

@@ -113,9 +113,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
     // (immediate offsets of one address register)
     const int slot0 = wslot(g, lch);
     int ez = 0, exx = 0;                               // fp16 path: scale exponents of dZ and of this tile's segment of X
+    bool poison = false;                               // an inf / NaN amax: the tile's result turns NaN
     if constexpr (H2) {
-        ez = __builtin_amdgcn_readfirstlane(h2_exp(amax_read(J.za)));
-        exx = __builtin_amdgcn_readfirstlane(h2_exp(amax_read(J.xa[seg])));
+        const u32 mz = amax_read(J.za), mx = amax_read(J.xa[seg]);
+        ez = __builtin_amdgcn_readfirstlane(h2_exp(mz));
+        exx = __builtin_amdgcn_readfirstlane(h2_exp(mx));
+        poison = __builtin_amdgcn_readfirstlane((mz >= 0x7f800000u || mx >= 0x7f800000u) ? 1 : 0) != 0;
     }
     const int e_mine = is_a ? ez : exx;
 
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jj][r] = __builtin_ldexpf(acc[i][jj][r], -(ez + exx));
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = poison ? __builtin_nanf("") : __builtin_ldexpf(acc[i][jj][r], -(ez + exx));
     }
     __syncthreads();
     float* slab = J.part + ((long long)split * (J.tile_end - (j > 0 ? G.job[j - 1].tile_end : 0)) + t) * (TILE * TILE);
