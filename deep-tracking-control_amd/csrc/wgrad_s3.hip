@@ -367,7 +367,9 @@ int group_splits_s3(int M, int tiles_total) {
     // 768: eight batch slices for the 61..70-tile groups of the bench step.  Measured (tools/jobs/r3_sweep2.sh): 512..1536 within
     // 0.5 % of each other in step time, 2048 (32 slices) no faster; the partial slabs are HBM traffic written and read once
     // per slice, so the smallest count that still fills the chip wins (family traffic 1.30 -> 1.15 x the algorithmic bytes)
-    const int target = target_env ? atoi(target_env) : 768;
+    // (round 4, two-term fp16 kernels -- half the matrix work per workgroup: 1536 = 24 slices for the 61..64-tile groups, 16 for the
+    // 70-tile one: 57.4 vs 60.2 ms per step; 2048 / 3072 with a higher cap: 59.7 / 61.0 vs 59.1 on another box)
+    const int target = target_env ? atoi(target_env) : 1536;
     int s = target / (tiles_total > 0 ? tiles_total : 1);
     if (!fill_slots()) s = s / 8 * 8;                 // the slice -> XCD map needs whole groups of eight
     if (s < 8) s = 8;

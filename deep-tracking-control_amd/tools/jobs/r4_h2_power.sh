@@ -1,5 +1,5 @@
 # socket power / shader clock while the bench step runs on the two-term fp16 path and on the bf16 x 3 path; serialised per-kernel sums
-O=gpurun_out/r4h2
+O=${O:-gpurun_out/r4h2}
 mkdir -p $O
 : > $O/h2_power.txt
 sample() {
