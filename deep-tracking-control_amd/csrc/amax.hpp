@@ -33,4 +33,24 @@ __device__ __forceinline__ void amax_publish(amax_u32* rec, amax_u32 m) {
     if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
 }
 
+// the same for a whole 256-thread workgroup: ONE atomic per workgroup (every thread of the workgroup must call it; `lds4`: four words of
+// LDS nobody else uses across the call).  A GEMM launch publishes ~800 values instead of ~3000 -- the waves of a launch reach their
+// epilogues together and nearly all of them see a slot that is still zero, so the filter above does not thin them out.
+__device__ __forceinline__ void amax_publish_block(amax_u32* rec, amax_u32 m, amax_u32* lds4) {
+    if (rec == nullptr) return;                           // (uniform)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const amax_u32 o = (amax_u32)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) m = lds4[w] > m ? lds4[w] : m;
+        amax_u32* slot = rec + (blockIdx.x & (AMAX_SUB - 1)) * AMAX_STRIDE;
+        if (m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
+    }
+}
+
 }  // namespace

@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void pack_cols_kernel(const DtcSegMat X, float
         dst[r * ld_dst + (e - r * X.cols)] = v;
         m = abs_bits(v) > m ? abs_bits(v) : m;
     }
-    amax_publish(dst_amax, m);
+    __shared__ amax_u32 red[4];
+    amax_publish_block(dst_amax, m, red);
 }
 }  // namespace
 

@@ -94,9 +94,18 @@ __global__ __launch_bounds__(256) void wamax_kernel(const WimgGroup G) {
     const WimgJobDev& J = G.job[blockIdx.x / WPART];
     const int e = blockIdx.x % WPART;
     u32 m = 0u;
-    for (long long i = (long long)e * 256 + threadIdx.x; i < J.welems; i += WPART * 256) {
-        const u32 b = abs_bits(J.W[i]);
-        m = b > m ? b : m;
+    if ((reinterpret_cast<unsigned long long>(J.W) & 15ull) == 0 && (J.welems & 3) == 0) {       // (uniform) 16-byte loads
+        const f32x4* W4 = reinterpret_cast<const f32x4*>(J.W);
+        for (long long i = (long long)e * 256 + threadIdx.x; i < (J.welems >> 2); i += WPART * 256) {
+            const f32x4 v = W4[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m = abs_bits(v[q]) > m ? abs_bits(v[q]) : m;
+        }
+    } else {
+        for (long long i = (long long)e * 256 + threadIdx.x; i < J.welems; i += WPART * 256) {
+            const u32 b = abs_bits(J.W[i]);
+            m = b > m ? b : m;
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -570,6 +579,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = poison ? __builtin_nanf("") : __builtin_ldexpf(acc[i][j][r], -(ex + ew));
     }
     u32 am = 0u;                                        // fp16 path: this lane's largest |stored value| (bit pattern)
+    u32* am_lds = reinterpret_cast<u32*>(&Bs1[0][0]);   // four words for the workgroup-wide maximum (no epilogue touches this stage buffer)
     auto seen = [&](float v) {
         if constexpr (H2) {
             const u32 b = abs_bits(v);
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         if (lane == 0) red[wave] = sq;
         __syncthreads();
         if (tid == 0) mse.part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
-        if constexpr (H2) amax_publish(h2.ya[0], am);
+        if constexpr (H2) amax_publish_block(h2.ya[0], am, am_lds);
         return;
     }
     if constexpr (EPI == EPI_FWD) {
@@ -686,7 +696,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                     for (int e = 0; e < 4; ++e) seen(v[e]);
                 }
             }
-            if constexpr (H2) amax_publish(h2.ya[0], am);
+            if constexpr (H2) amax_publish_block(h2.ya[0], am, am_lds);
             return;
         }
 #pragma unroll
@@ -707,7 +717,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                 }
             }
         }
-        if constexpr (H2) amax_publish(h2.ya[0], am);
+        if constexpr (H2) amax_publish_block(h2.ya[0], am, am_lds);
     } else {
         // ---- data-gradient epilogue: activation derivative, segmented destination (csrc/gemm.hip: linear_dgrad_kernel)
         const SegMatDev& dX = dg.dX;
@@ -800,7 +810,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
             const SegDev sdj = dX.s[sj];
             const bool tile_wide = full && ((dg.wide_segs >> sj) & 1) && cj + 32 <= sdj.start + sdj.width && ((cj - sdj.start) & 3) == 0 &&
                                    (act == DTC_ACT_NONE || ((dg.wide_segs >> 4) & 1));
-            am = 0u;                                    // (fp16 path) published per tile: its destination block has its own slot
+            if (dX.nseg > 1) am = 0u;                   // (fp16 path) several destination blocks: published per tile, each block has its own slot
             if (tile_wide) {                            // wave-uniform
                 patch_put(patch, acc[i][j], half, l31);
                 if (sdj.ptr == nullptr) continue;
@@ -825,7 +835,9 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
 #pragma unroll
                     for (int e = 0; e < 4; ++e) seen(v[e]);
                 }
-                if constexpr (H2) amax_publish(h2.ya[sj], am);
+                if constexpr (H2) {
+                    if (dX.nseg > 1) amax_publish(h2.ya[sj], am);
+                }
                 continue;
             }
             const int col = cj + l31;
@@ -853,10 +865,15 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                 }
             }
             if constexpr (H2) {                         // lanes of this tile may write different destination blocks: one update per lane
-                u32* slot = live ? h2.ya[find_seg(dX, col)] : nullptr;
-                if (slot) slot += (lane & (AMAX_SUB - 1)) * AMAX_STRIDE;
-                if (slot && am > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, am);
+                if (dX.nseg > 1) {
+                    u32* slot = live ? h2.ya[find_seg(dX, col)] : nullptr;
+                    if (slot) slot += (lane & (AMAX_SUB - 1)) * AMAX_STRIDE;
+                    if (slot && am > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, am);
+                }
             }
+        }
+        if constexpr (H2) {                             // one destination block: the workgroup's maximum, one atomic
+            if (dX.nseg == 1) amax_publish_block(h2.ya[0], am, am_lds);
         }
     }
 }

@@ -342,8 +342,9 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
             *reinterpret_cast<f4*>(dHc + rr * lddhc + 4 * (p + TPR * i)) = gc;
         }
     }
-    amax_publish(dha_amax, ma);
-    amax_publish(dhc_amax, mc);
+    __shared__ amax_u32 red_a[4], red_c[4];
+    amax_publish_block(dha_amax, ma, red_a);
+    amax_publish_block(dhc_amax, mc, red_c);
     ppo_block_partials(ok ? o.s_sur : 0.0, ok ? o.s_val : 0.0, ok ? o.s_kl : 0.0, ds, ok, A, part);
 }
 

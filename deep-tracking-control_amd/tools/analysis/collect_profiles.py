@@ -35,7 +35,7 @@ def short(name):
 
 d = last_json(f"{src}/{tag}_bench_n1.json")
 json.dump(d, open(f"{dst}/{tag}_bench_n1.json", "w"), indent=1)
-for w in ("gru", "composite", "fp32mfma"):
+for w in ("gru", "composite", "fp32mfma", "bf16x3"):
     p = f"{src}/{tag}_bench_{w}.json"
     if os.path.exists(p):
         json.dump(last_json(p), open(f"{dst}/{tag}_bench_{w}_informative.json", "w"), indent=1)
@@ -95,7 +95,8 @@ for mode in ("serial", "overlap"):
     tot, calls = sum(float(x["TotalDurationNs"]) for x in fam), sum(int(x["Calls"]) for x in fam)
     print(f"{mode}: GEMM family {tot / 1e6:.1f} ms over {calls} launches -> {tot / calls / 1e3:.2f} us per launch")
 
-for name in (f"{tag}_dp_rehearsal.log", f"{tag}_soak.log", f"{tag}_images_ab.log", f"{tag}_image_kernels.log", f"{tag}_i3_pmc.txt", f"{tag}_wgrad_pmc.txt"):
+for name in (f"{tag}_dp_rehearsal.log", f"{tag}_soak.log", f"{tag}_images_ab.log", f"{tag}_image_kernels.log", f"{tag}_i3_pmc.txt", f"{tag}_wgrad_pmc.txt",
+             f"{tag}_h2_power.txt", f"{tag}_energy.txt"):
     if os.path.exists(f"{src}/{name}"):
         shutil.copy(f"{src}/{name}", f"{dst}/{name}")
 print("bench:", d["value"], d["ms_per_step"], "roofline", r["achieved"], r["frac"], "traffic ratio", r.get("traffic_over_algorithmic"))

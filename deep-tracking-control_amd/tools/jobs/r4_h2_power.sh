@@ -9,11 +9,11 @@ sample() {
   done
 }
 for mode in 2 1; do
-  DTC_GEMM_SPLIT=$mode python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-traffic > $O/power_bench_$mode.json 2>/dev/null &
-  P=$!; sleep 9; sample "bench step, DTC_GEMM_SPLIT=$mode" $P
+  DTC_GEMM_SPLIT=$mode python bench.py --steps 300 --warmup 5 --no-cpu-baseline --no-traffic > $O/power_bench_$mode.json 2>/dev/null &
+  P=$!; sleep 8; sample "bench step, DTC_GEMM_SPLIT=$mode" $P
   python -c "import json; d=json.loads(open('$O/power_bench_$mode.json').read().strip().splitlines()[-1]); print('DTC_GEMM_SPLIT=$mode', d['value'], d['ms_per_step'])" >> $O/h2_power.txt
 done
-grep -v amdgpu $O/h2_power.txt | awk 'NR%3==1 || /DTC_GEMM_SPLIT=[12] [0-9]/' | tail -24
+grep -v amdgpu $O/h2_power.txt | sed "s/GPU\[0\]\t\t: //g; s/=* Power Consumption =*//" | tail -40
 for mode in 2 1; do
   DTC_GEMM_SPLIT=$mode DTC_PROF_SHAPES=1 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-traffic 2>/dev/null | python -c "
 import sys, json
