@@ -12,14 +12,21 @@ __device__ __forceinline__ amax_u32 abs_bits(float v) { return __float_as_uint(v
 // many atomic maxima on ONE address cost ~20 us (measured: 65 instead of 46 us for the 24576 x 512 x 512 forward layer); spread over
 // 16 lines (wave -> line by workgroup and wave index) they cost nothing measurable.  Readers take the maximum of the 16 words.
 constexpr int AMAX_SUB = 16, AMAX_STRIDE = 32, AMAX_RECORD_BYTES = AMAX_SUB * AMAX_STRIDE * 4;
-__device__ __forceinline__ amax_u32 amax_read(const amax_u32* rec) {
-    amax_u32 m = 0u;
+// wave-wide maximum of one value per lane (every lane of the wave must take part)
+__device__ __forceinline__ amax_u32 wave_max_u32(amax_u32 m) {
 #pragma unroll
-    for (int i = 0; i < AMAX_SUB; ++i) {
-        const amax_u32 v = __hip_atomic_load(rec + i * AMAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        m = v > m ? v : m;
+    for (int off = 32; off >= 1; off >>= 1) {
+        const amax_u32 o = (amax_u32)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
     }
     return m;
+}
+// the record's value: lane i < 16 loads word i, the wave reduces (one load instruction per wave instead of 16; every lane of the wave
+// must call it).  Device-scope loads: the words were written by atomics of other kernels
+__device__ __forceinline__ amax_u32 amax_read(const amax_u32* rec) {
+    const int lane = threadIdx.x & 63;
+    const amax_u32 v = lane < AMAX_SUB ? __hip_atomic_load(rec + lane * AMAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    return wave_max_u32(v);
 }
 // wave-wide maximum of the lanes' |value| bit patterns -> the tensor's amax record (skipped when the line already holds as much)
 __device__ __forceinline__ void amax_publish(amax_u32* rec, amax_u32 m) {

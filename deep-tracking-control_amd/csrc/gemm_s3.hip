@@ -81,14 +81,9 @@ struct WimgGroup {
 // fp16 images, first step: the largest |w| of every job's matrix as WPART partial maxima (block = (job, part); no atomics, nothing to
 // zero); the image builder and the GEMM kernels take the maximum of them
 constexpr int WPART = 32;
-__device__ __forceinline__ u32 wpart_max(const u32* wa) {
-    u32 m = 0u;
-#pragma unroll
-    for (int i = 0; i < WPART; ++i) {
-        const u32 v = __hip_atomic_load(wa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        m = v > m ? v : m;
-    }
-    return m;
+__device__ __forceinline__ u32 wpart_max(const u32* wa) {          // lane i < WPART loads partial i (every lane of the wave must call it)
+    const int lane = threadIdx.x & 63;
+    return wave_max_u32(lane < WPART ? __hip_atomic_load(wa + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
 }
 __global__ __launch_bounds__(256) void wamax_kernel(const WimgGroup G) {
     const WimgJobDev& J = G.job[blockIdx.x / WPART];

@@ -110,6 +110,7 @@ IMAGES = _os.environ.get("DTC_IMAGES", "0") == "1"
 WIMG_CHECK = _os.environ.get("DTC_WIMG_CHECK", "0") == "1"  # debug: re-derive every cached weight image at its use and compare
 _NOT_NULL = 16                                             # stand-in address of a non-NULL operand block in a cached descriptor
 WIMG = _os.environ.get("DTC_S3_WIMG", "1") != "0"          # the library's weight-image switch (csrc/gemm_s3.hip reads the same variable)
+H2 = H2 and WIMG                                           # the fp16 kernels read their weights as images only
 
 
 def set_split(on: bool, h2: bool | None = None):
@@ -133,7 +134,9 @@ class Amax:
     * everything else (outputs of the narrow single-pass kernels, of the loss / latent kernels, of torch ops) comes without a slot: the
       library computes the amax of such an operand itself, right in front of the consumer (one memset + one launch per call for
       all its slot-less operands, include/dtc_hip.h).
-    A tensor is identified by its base address, width and row stride; a published or static slot covers every column block of it."""
+    A tensor is identified by its base address, width and row stride; a published or static slot covers every column block of it.
+    One registry per device, one phase at a time: entering a WeightImages block zeroes the records of the previous one (a consumer that
+    still needed them would scale by 2^141, overflow fp16 and return NaN -- loud, as every misuse of a record is)."""
 
     SLOTS = 512
 
