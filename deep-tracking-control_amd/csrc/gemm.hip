@@ -32,6 +32,7 @@
 // Workgroup -> tile mapping is XCD-aware (block b runs on XCD b%8): all column tiles of one row panel
 // (fwd/dgrad) resp. all output tiles of one batch slice (wgrad) run on the same XCD, so the panel is
 // fetched from HBM into ONE L2 and shared there.
+#include "amax.hpp"
 #include "gemm_core.hpp"
 
 namespace {
@@ -97,7 +98,10 @@ __global__ __launch_bounds__(256, DEEP ? 3 : (BN == 128 ? 2 : DTC_FWD_WAVES)) vo
                                                          const float* __restrict__ bias, float* __restrict__ Y,
                                                          long long ldy, int M, int N, int K, int act, int wide,
                                                          const MseEpi mse, unsigned short* __restrict__ rmask = nullptr,
-                                                         int ldm = 0) {
+                                                         int ldm = 0, amax_u32* __restrict__ yamax = nullptr) {
+    // yamax (round 4): amax record of Y for the two-term fp16 GEMM path that may consume it (amax.hpp); NULL: nothing published
+    amax_u32 am = 0u;
+    auto seen = [&](float v) { am = abs_bits(v) > am ? abs_bits(v) : am; };
     // wave layout: BN <= 64: four waves stacked along the rows, each 32 x BN; BN = 128: 2 x 2 waves, each 64 x 64 (2 x 2 MFMA
     // tiles: 8 ds_read_b128 feed 32 MFMAs per stage instead of 6 for 16, one barrier covers twice the MFMA work)
     constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN;
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : (BN == 128 ? 2 : DTC_FWD_WAVES)) vo
                 if (cok && row < M) {
                     const float e = (acc[i][j][r] + bv) - t[r];
                     Y[(long long)row * ldy + col] = e * mse.scale;
+                    seen(e * mse.scale);
                     sq += (double)e * (double)e;
                 }
             }
@@ -310,6 +315,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : (BN == 128 ? 2 : DTC_FWD_WAVES)) vo
         if (lane == 0) red[wave] = sq;
         __syncthreads();
         if (tid == 0) mse.part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+        amax_publish(yamax, am);
         return;
     }
     if (wide && full) {
@@ -343,6 +349,8 @@ __global__ __launch_bounds__(256, DEEP ? 3 : (BN == 128 ? 2 : DTC_FWD_WAVES)) vo
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
                     *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) seen(v[e]);
                 }
             } else if (act == DTC_ACT_RELU) {
 #pragma unroll
@@ -351,10 +359,17 @@ __global__ __launch_bounds__(256, DEEP ? 3 : (BN == 128 ? 2 : DTC_FWD_WAVES)) vo
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) seen(v[e]);
                 }
             } else if (act == DTC_ACT_NONE) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = patch_get(patch, prow + 8 * p, pc4);
+                for (int p = 0; p < 4; ++p) {
+                    const f32x4 v = patch_get(patch, prow + 8 * p, pc4);
+                    *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) seen(v[e]);
+                }
             } else {                                // selu / lrelu / tanh / sigmoid: not on this model's path, generic form
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -362,10 +377,13 @@ __global__ __launch_bounds__(256, DEEP ? 3 : (BN == 128 ? 2 : DTC_FWD_WAVES)) vo
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], act);
                     *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) seen(v[e]);
                 }
             }
         }
         DTC_STAMP(3);
+        amax_publish(yamax, am);
         return;
     }
 #pragma unroll
@@ -380,10 +398,13 @@ __global__ __launch_bounds__(256, DEEP ? 3 : (BN == 128 ? 2 : DTC_FWD_WAVES)) vo
         for (int r = 0; r < 16; ++r) {
             const int ro = (r & 3) + 8 * (r >> 2);
             const float v = act_fwd(acc[i][j][r] + bv, act);
-            if (full) yp[(long long)ro * ldy] = v;
-            else if (cok && m0 + wm_off + 32 * i + 4 * half + ro < M) yp[(long long)ro * ldy] = v;
+            if (full || (cok && m0 + wm_off + 32 * i + 4 * half + ro < M)) {
+                yp[(long long)ro * ldy] = v;
+                seen(v);
+            }
         }
     }
+    amax_publish(yamax, am);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -529,7 +550,9 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 6) void linear_dgrad_kernel(const f
                                                            const float* __restrict__ Xs, long long ldxs, int M, int N,
                                                            int K, int act, int split_n, long long split_dst, int col_skip,
                                                            int wide_segs, const unsigned short* __restrict__ rmask = nullptr,
-                                                           int ldm = 0) {
+                                                           int ldm = 0, amax_u32* __restrict__ xamax = nullptr) {
+    // xamax (round 4): amax record of a SINGLE whole-tensor destination (two-term fp16 GEMM path, amax.hpp); NULL: nothing published
+    amax_u32 am = 0u;
     constexpr int TN = BN / 32;
     constexpr int NA = BM / 64;
     constexpr int LDB = BN + 4;
@@ -719,8 +742,11 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 6) void linear_dgrad_kernel(const f
                         for (int e = 0; e < 4; ++e) v[e] = o[e] + v[e];
                     }
                     *q = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) am = abs_bits(v[e]) > am ? abs_bits(v[e]) : am;
                 }
             }
+            amax_publish(xamax, am);
             return;
         }
     }
@@ -749,10 +775,13 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 6) void linear_dgrad_kernel(const f
             if (act != DTC_ACT_NONE) v = act_bwd(v, y[r], act);
             if (live && row < M) {
                 float* q = dst + (long long)row * sd.ld;
-                *q = sd.accumulate ? (*q + v) : v;
+                v = sd.accumulate ? (*q + v) : v;
+                *q = v;
+                am = abs_bits(v) > am ? abs_bits(v) : am;
             }
         }
     }
+    amax_publish(xamax, am);
 }
 
 // fwd / dgrad: 128x64 tiles measured faster than 128x128 at every layer width of this model (twice the
@@ -823,7 +852,7 @@ extern "C" int64_t dtc_relu_mask_elems(int M, int N) {
 }
 
 static int linear_fwd_impl(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, int M, int N,
-                           int K, int act, uint16_t* rmask, void* stream) {
+                           int K, int act, uint16_t* rmask, void* stream, uint32_t* y_amax = nullptr) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
     DTC_REQUIRE(W && Y, "null pointer");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
@@ -846,12 +875,12 @@ static int linear_fwd_impl(const DtcSegMat* X, const float* W, const float* b, f
     unsigned short* rm = rmask;
     const int ldm = N;
     if (bn == 128) {
-        hipLaunchKernelGGL((linear_fwd_kernel<128, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm);
+        hipLaunchKernelGGL((linear_fwd_kernel<128, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm, (amax_u32*)y_amax);
     } else if (deep_variant(grid)) {
-        if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm);
-        else hipLaunchKernelGGL((linear_fwd_kernel<32, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm);
-    } else if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), occ_pad("FWD", 24576), s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm);
-    else hipLaunchKernelGGL((linear_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm);
+        if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm, (amax_u32*)y_amax);
+        else hipLaunchKernelGGL((linear_fwd_kernel<32, false, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm, (amax_u32*)y_amax);
+    } else if (bn == 64) hipLaunchKernelGGL((linear_fwd_kernel<64, false>), dim3(grid), dim3(256), occ_pad("FWD", 24576), s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm, (amax_u32*)y_amax);
+    else hipLaunchKernelGGL((linear_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy, M, N, K, act, wide, MseEpi{}, rm, ldm, (amax_u32*)y_amax);
     return dtc::check_launch("linear_fwd");
 }
 
@@ -864,6 +893,13 @@ extern "C" int dtc_linear_fwd_mask(const DtcSegMat* X, const float* W, const flo
                                    int M, int N, int K, void* stream) {
     DTC_REQUIRE(relu_mask != nullptr, "null sign record");
     return linear_fwd_impl(X, W, b, Y, ldy, M, N, K, (int)DTC_ACT_RELU, relu_mask, stream);
+}
+
+// dtc_linear_fwd / dtc_linear_fwd_mask (relu_mask may be NULL) that also adds the largest |Y| it writes to the amax record y_amax
+// (two-term fp16 GEMM path, include/dtc_hip.h: DtcSeg.amax) -- for narrow layers whose result a split-path kernel consumes
+extern "C" int dtc_linear_fwd_amax(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
+                                   uint32_t* y_amax, int M, int N, int K, int act, void* stream) {
+    return linear_fwd_impl(X, W, b, Y, ldy, M, N, K, relu_mask ? (int)DTC_ACT_RELU : act, relu_mask, stream, y_amax);
 }
 
 extern "C" void dtc_set_concurrency_hint(int side_stream_active) { g_concurrency_hint = side_stream_active ? 1 : 0; }
@@ -943,12 +979,13 @@ static int linear_dgrad_impl(const float* dZ, int64_t lddz, const float* W, cons
     if (rmask) DTC_REQUIRE(M % BM == 0 && K % bn == 0 && col_skip == 0, "sign record: M=%d must be a multiple of %d and K=%d of the %d-wide tile", M, BM, K, bn);
     const unsigned short* rm = rmask;
     const int ldm = K;
+    amax_u32* xam = (dX->nseg == 1) ? (amax_u32*)dX->seg[0].amax : nullptr;       // (DtcSeg.amax of a single destination: published)
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s, bytes);
     if (deep_variant(grid)) {
-        if (bn == 64) hipLaunchKernelGGL((linear_dgrad_kernel<64, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm);
-        else hipLaunchKernelGGL((linear_dgrad_kernel<32, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm);
-    } else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), occ_pad("DGRAD", 25088, g_concurrency_hint ? 5 : 0), s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm);
-    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm);
+        if (bn == 64) hipLaunchKernelGGL((linear_dgrad_kernel<64, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm, xam);
+        else hipLaunchKernelGGL((linear_dgrad_kernel<32, true>), dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm, xam);
+    } else if (bn == 64) hipLaunchKernelGGL(linear_dgrad_kernel<64>, dim3(grid), dim3(256), occ_pad("DGRAD", 25088, g_concurrency_hint ? 5 : 0), s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm, xam);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(256), 0, s, dZ, (long long)lddz, W, xd, Xsaved, (long long)ldxs, M, N, K, act, 0, 0ll, col_skip, wide, rm, ldm, xam);
     return dtc::check_launch("linear_dgrad");
 }
 

@@ -155,6 +155,8 @@ _SIGS = {
     "dtc_relu_mask_elems": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_linear_fwd_mask": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, c_stream]),
+    "dtc_linear_fwd_amax": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, c_stream]),
     "dtc_linear_dgrad_mask": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         c_stream]),
     "dtc_linear_dgrad": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), c_f32p, C.c_int64, C.c_int,

@@ -411,6 +411,12 @@ def linear_fwd(X, W, b, Y, act=None, M=None, mask=None, split=None, Yimg=None):
                                       ptr(mask) if mask is not None else None, ptr(img), ready, M, N, K, ACT[act], stream()),
               "dtc_linear_fwd_s3")
         return Y
+    slot = _amax_out(Y, 0, N) if (SPLIT and H2) else None
+    if slot is not None:          # a narrow layer inside a trainer phase of the fp16 path: its result's amax rides along for the consumers
+        assert mask is None or act in ("relu", "crelu")
+        check(lib().dtc_linear_fwd_amax(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
+                                        ptr(mask) if mask is not None else None, slot, M, N, K, ACT[act], stream()), "dtc_linear_fwd_amax")
+        return Y
     if mask is not None:
         assert act in ("relu", "crelu")
         check(lib().dtc_linear_fwd_mask(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
@@ -479,6 +485,12 @@ def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None
                                         ptr(img), ready, M, N, K, ACT[act] if mask is None else ACT["relu"], stream()),
               "dtc_linear_dgrad_s3")
         return
+    if SPLIT and H2:                  # a single whole-tensor destination publishes its amax from the narrow kernels as well (several
+        if dXs.nseg == 1:             # blocks: they publish nothing, so no record may be handed out for them)
+            _h2_destination(dXs)
+        else:
+            for i in range(dXs.nseg):
+                dXs.seg[i].amax = None
     if mask is not None:
         assert act in ("relu", "crelu")
         check(lib().dtc_linear_dgrad_mask(ptr(dZ), dZ.stride(0), cptr(W, f32), dXs, ptr(mask), M, N, K, stream()),

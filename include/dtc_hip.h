@@ -217,6 +217,11 @@ int dtc_linear_fwd_mask(const DtcSegMat* X, const float* W, const float* b, floa
 /* dX[M,K] = (dZ[M,N] W[N,K]) * (relu_mask bit), single-segment destination; M % 128 == 0, K as N above. */
 int dtc_linear_dgrad_mask(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const uint16_t* relu_mask,
                           int M, int N, int K, void* stream);
+/* dtc_linear_fwd / dtc_linear_fwd_mask (relu_mask may be NULL) that also adds the largest |Y| it writes to the amax record y_amax of
+ * the two-term fp16 GEMM path (DtcSeg.amax below) -- for the narrow layers whose result a split-path kernel consumes.  dtc_linear_dgrad /
+ * dtc_linear_dgrad_mask do the same for a SINGLE destination block that brings a record in dX->seg[0].amax. */
+int dtc_linear_fwd_amax(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
+                        uint32_t* y_amax, int M, int N, int K, int act, void* stream);
 /* ---- split-precision path (csrc/gemm_s3.hip): the same products on the bf16 matrix pipe, every fp32 operand split into
  * three bf16 terms (a = a1 + a2 + a3 exactly to 2^-24 |a|) and the six leading cross products accumulated in fp32 -- fp32-level
  * accuracy (tests/test_hip_split.py measures it against fp64 next to the single-pass kernels) at up to 2.67x the fp32 MFMA

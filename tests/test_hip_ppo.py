@@ -563,6 +563,9 @@ def test_update_teacher_forced_with_activation_images(n_envs, steps):
     """The trainers' image chain (trainer.use_images / DTC_IMAGES=1, off by default: DESIGN.md 4.2c): hidden activations and gradients of
     the wide stacks as activation images, image-operand forward / data-gradient / weight-gradient kernels -- same teacher-forced bounds
     as the default schedule."""
+    from dtc_amd import ops
+    if not ops.SPLIT:
+        pytest.skip("the activation-image chain is part of the split-precision path (DTC_GEMM_SPLIT=0 selected the single-pass kernels)")
     ref, alg = _pair(n_envs)
     alg.use_images = True
     perm, e1, e2 = S.update_noise(n_envs, 24, 4, 5, seed=123)
