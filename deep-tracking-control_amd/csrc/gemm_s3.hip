@@ -22,6 +22,11 @@
 //   Block tile 128 x 128 x 16, 2 x 2 waves of 64 x 64, 24 MFMAs per wave and stage, double-buffered LDS (48 KiB), 3
 //   workgroups per CU.
 // The data gradient uses the same kernel with the image of W^T (the builder reads W transposed).
+//
+// Round 4: the kernels are templated on the REPRESENTATION (s3_core.hpp: Prec<H2>).  H2 = two fp16 terms of the operand scaled by a power
+// of two from its tensor's amax, three v_mfma_f32_32x32x16_f16 passes, 8 KiB image chunks, 32 KiB of LDS, the sums scaled back with
+// v_ldexp_f32 before the (unchanged) epilogue, which also publishes the result's amax for the next consumer (amax.hpp).  It is the
+// default (DTC_GEMM_SPLIT=2); the text above describes DTC_GEMM_SPLIT=1.
 #include <type_traits>
 
 #include "s3_core.hpp"
