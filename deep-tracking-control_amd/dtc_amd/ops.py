@@ -118,7 +118,7 @@ def set_split(on: bool, h2: bool | None = None):
     global SPLIT, H2
     SPLIT = bool(on)
     if h2 is not None:
-        H2 = bool(h2)
+        H2 = bool(h2) and WIMG            # (the fp16 kernels read their weights as images only: DTC_S3_WIMG=0 keeps the bf16 x 3 kernels)
     lib().dtc_set_gemm_split(int(SPLIT))
 
 
