@@ -86,6 +86,9 @@ struct WimgGroup {
 // fp16 images, first step: the largest |w| of every job's matrix as WPART partial maxima (block = (job, part); no atomics, nothing to
 // zero); the image builder and the GEMM kernels take the maximum of them
 constexpr int WPART = 32;
+// behind an fp16 image's last chunk: the WPART partial maxima, then up to four amax records of operands the call computes itself
+// (inside the slack dtc_s3_planes_bytes leaves: its chunks are sized for three planes and four spare stages; checked per call)
+constexpr long long H2_TAIL_BYTES = 4 * WPART + 4 * AMAX_RECORD_BYTES;
 __device__ __forceinline__ u32 wpart_max(const u32* wa) {          // lane i < WPART loads partial i (every lane of the wave must call it)
     const int lane = threadIdx.x & 63;
     return wave_max_u32(lane < WPART ? __hip_atomic_load(wa + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
@@ -236,9 +239,6 @@ __device__ __forceinline__ void load8(const float* base, long long ld, int row, 
     }
 }
 
-#ifdef DTC_H2_DEBUG
-__device__ u32 g_dbg[8];
-#endif
 // amax slots of a two-term fp16 launch (s3_core.hpp): operand segments in, weight image partials in, results out
 struct H2Arg {
     const u32* xa[4];             // one slot per segment of the row operand (X resp. dZ)
@@ -308,16 +308,6 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         ex = __builtin_amdgcn_readfirstlane(h2_exp(mx));
         ew = __builtin_amdgcn_readfirstlane(h2_exp(mw));
         poison = __builtin_amdgcn_readfirstlane((mx >= 0x7f800000u || mw >= 0x7f800000u) ? 1 : 0) != 0;
-#ifdef DTC_H2_DEBUG
-        if (threadIdx.x == 0) {
-            atomicMax(&g_dbg[0], (u32)(ex + 1000));
-            atomicMin(&g_dbg[1], (u32)(ex + 1000));
-            atomicMax(&g_dbg[2], (u32)(ew + 1000));
-            atomicMin(&g_dbg[3], (u32)(ew + 1000));
-            atomicMax(&g_dbg[4], mx);
-            atomicMin(&g_dbg[5], mx);
-        }
-#endif
     }
 
     // ONE loop over the stages of all segments; the (rare) hop into the next segment re-derives the row offsets (the gathered
@@ -1028,6 +1018,7 @@ int fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t
         DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
         H2Arg a;
         const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0, true, (long long)N * K);
+        DTC_REQUIRE(ib + H2_TAIL_BYTES <= dtc_s3_planes_bytes(N, K), "weight-image buffer too small for the fp16 path's tail");
         rc = h2_operand(X, xd, M, a, reinterpret_cast<char*>(wplanes) + ib + 4 * WPART, s);
         if (rc != DTC_OK) return rc;
         a.ya[0] = y_amax;
@@ -1117,6 +1108,7 @@ int dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX,
         H2Arg a{};
         for (int i = 0; i < dX->nseg; ++i) a.ya[i] = dX->seg[i].amax;
         const long long ib = build_wimage(W, wplanes, K, col_skip, K, 1, zin, (int)dtc::ceil_div(K - col_skip, 128), s, wimage_ready != 0, true, (long long)N * K);
+        DTC_REQUIRE(ib + H2_TAIL_BYTES <= dtc_s3_planes_bytes(K, N), "weight-image buffer too small for the fp16 path's tail");
         a.xa[0] = dz_amax;
         if (dz_amax == nullptr) {                     // dZ came without a slot: its amax into the call's scratch behind the image
             u32* slot = reinterpret_cast<u32*>(reinterpret_cast<char*>(wplanes) + ib + 4 * WPART);
@@ -1125,18 +1117,6 @@ int dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX,
             amax_item(G, dZ, nullptr, (long long)lddz, 0, N, M, slot);
             DTC_REQUIRE(amax_group_run(G, slot, AMAX_RECORD_BYTES, s), "hipMemsetAsync failed");
             a.xa[0] = slot;
-#ifdef DTC_H2_DEBUG
-            if (getenv("DTC_H2_DUMP") && N == 512 && K == 128) {
-                (void)hipStreamSynchronize(s);
-                u32 h[AMAX_RECORD_BYTES / 4];
-                (void)hipMemcpy(h, slot, sizeof h, hipMemcpyDeviceToHost);
-                u32 m = 0;
-                for (int i = 0; i < AMAX_SUB; ++i) m = h[i * AMAX_STRIDE] > m ? h[i * AMAX_STRIDE] : m;
-                fprintf(stderr, "H2DUMP dgrad M=%d record max %08x  words:", M, m);
-                for (int i = 0; i < AMAX_SUB; ++i) fprintf(stderr, " %08x", h[i * AMAX_STRIDE]);
-                fprintf(stderr, "  blocks %d slot %p wplanes %p ib %lld\n", G.it[0].block_end, (void*)slot, wplanes, ib);
-            }
-#endif
         }
         a.wa = reinterpret_cast<const u32*>(reinterpret_cast<const char*>(wplanes) + ib);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, true, true>), dim3(grid), dim3(256), 0, s, zin, (const float*)nullptr, (const float*)nullptr,
@@ -1199,6 +1179,7 @@ int fwd_mse_s3(const DtcSegMat* X, const float* W, const float* b, const float* 
         DTC_REQUIRE(wimage_on() && wplanes && dtc::aligned16(wplanes), "fp16 path: needs weight images; null / unaligned weight-image scratch");
         H2Arg a;
         const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0, true, (long long)N * K);
+        DTC_REQUIRE(ib + H2_TAIL_BYTES <= dtc_s3_planes_bytes(N, K), "weight-image buffer too small for the fp16 path's tail");
         rc = h2_operand(X, xd, M, a, reinterpret_cast<char*>(wplanes) + ib + 4 * WPART, s);
         if (rc != DTC_OK) return rc;
         a.ya[0] = dy_amax;
@@ -1707,13 +1688,3 @@ extern "C" int dtc_linear_dgrad_i3(const void* dZimg, const float* W, float* dX,
     return dtc::check_launch("linear_dgrad_i3");
 }
 
-#ifdef DTC_H2_DEBUG
-// debug build only: (max, min) over the workgroups of the launches since the last call of ex + 1000, ew + 1000 and the X amax bits
-extern "C" int dtc_h2_debug(uint32_t* out6) {
-    u32 h[8];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof h) != hipSuccess) return 1;
-    for (int i = 0; i < 6; ++i) out6[i] = h[i];
-    const u32 init[8] = {0u, 0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u, 0u};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), init, sizeof init) != hipSuccess;
-}
-#endif

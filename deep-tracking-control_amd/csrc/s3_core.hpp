@@ -151,8 +151,6 @@ inline bool amax_group_run(const AmaxGroup& G, void* slots, size_t bytes, hipStr
     const int words = (int)(bytes / 4);
     hipLaunchKernelGGL(amax_zero_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (u32*)slots, words);
     hipLaunchKernelGGL(amax_group_kernel, dim3((unsigned)G.it[G.count - 1].block_end), dim3(256), 0, s, G);
-    static const bool sync = getenv("DTC_AMAX_SYNC") != nullptr;       // debug
-    if (sync) (void)hipStreamSynchronize(s);
     return true;
 }
 

@@ -246,16 +246,24 @@ def _amax_out(t, col0, width):
     return None
 
 
+def _sources(Xs):
+    """The tensors behind a descriptor's segments (`_ffi.segmat` keeps them alive next to the raw pointers); a descriptor built any other
+    way has none: its operands simply bring no amax record (the library computes it)."""
+    keep = getattr(Xs, "_keep", None)
+    srcs = list(keep[1]) if keep else []
+    return srcs + [None] * (4 - len(srcs))
+
+
 def _h2_operand(Xs, kind="fwd"):
     """Fill the amax slots of a row operand's segments (its source tensors ride along in the descriptor's keep-alive list)."""
-    srcs = Xs._keep[1]
+    srcs = _sources(Xs)
     for i in range(Xs.nseg):
-        Xs.seg[i].amax = _amax_in(srcs[i], kind)
+        Xs.seg[i].amax = _amax_in(srcs[i], kind) if srcs[i] is not None else None
     return Xs
 
 
 def _h2_destination(dXs):
-    srcs = dXs._keep[1]
+    srcs = _sources(dXs)
     for i in range(dXs.nseg):
         s = dXs.seg[i]
         s.amax = _amax_out(srcs[i], s.col0, s.width) if s.ptr else None
@@ -649,9 +657,9 @@ def wgrad_group(jobs, M, workspace, stream_ptr=None, split=None):
     if s3 and H2:
         for a, (dZ, Xs, _dW, _db) in zip(arr, keep):
             a.dz_amax = _amax_in(dZ, "wgrad dZ")
-            srcs = Xs._keep[1]
+            srcs = _sources(Xs)
             for i in range(Xs.nseg):
-                a.X.seg[i].amax = _amax_in(srcs[i], "wgrad X")
+                a.X.seg[i].amax = _amax_in(srcs[i], "wgrad X") if srcs[i] is not None else None
         check(lib().dtc_wgrad_group_h2(arr, len(jobs), M, ptr(workspace), sp), "dtc_wgrad_group_h2")
         return keep
     check((lib().dtc_wgrad_group_s3 if s3 else lib().dtc_wgrad_group)(arr, len(jobs), M, ptr(workspace), sp),
