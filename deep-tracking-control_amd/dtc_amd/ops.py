@@ -309,8 +309,9 @@ class WeightImages:
         global _IMAGES
         self.prev, _IMAGES = _IMAGES, self
         self.active = True
-        for a in _AMAX.values():   # two-term fp16 path: a new phase -- the published amax slots start from zero
-            a.reset()
+        if SPLIT and H2:           # two-term fp16 path: a new phase -- the published amax slots start from zero
+            for a in _AMAX.values():
+                a.reset()
         if self.entries and SPLIT and WIMG:
             if self.jobs is None or sum(len(j) for j in self.jobs.values()) != len(self.entries):
                 self.jobs = {}
