@@ -328,16 +328,17 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     int seg = 0, kt = 0, nst = (sd.width + BK - 1) / BK;
     // operand loads run ONE stage ahead of the MFMAs.  (Two stages ahead -- two register sets -- measured slower: 91 vs 73 us
     // on 24576 x 512 x 512; the third workgroup per CU that the registers of the second set cost is worth more.)
-    // AH2 (fp16 path, round 4; -DDTC_H2_AHEAD2=1, OFF by default): the X loads run TWO stages ahead (two register sets, set = parity
-    // of the stage; the weight image's LDS-DMA stays one stage ahead, an explicit s_waitcnt before the barrier completes it while the X
-    // loads of the stage after next stay in flight).  The idea: with three MFMA passes a stage's matrix phase is ~160 ns per wave, short
-    // against a global load issued one stage earlier (3450 cycles per stage on 24576 x 512 x 512, 384 of them MFMA).  Measured: no gain --
-    // 50.1 vs 49.6 us for that layer back to back, 60.6 vs 60.8 ms per step -- for 8 more registers (132: three instead of four
-    // workgroups per CU): back to back the kernel runs at ~1240 W and 1.93 GHz, i.e. it is the power budget again, not the load latency.
+    // AH2 (fp16 path, round 4): the X loads run TWO stages ahead (two register sets, set = parity of the stage; the weight image's LDS-DMA
+    // stays one stage ahead, an explicit s_waitcnt before the barrier completes it while the X loads of the stage after next stay in
+    // flight).  With three MFMA passes a stage's matrix phase is ~160 ns per wave, short against a global load issued one stage earlier.
+    // Measured at the end of the round (the first A/B, taken while every wave still paid an atomic in its epilogue, had shown nothing):
+    // the launches that leave a CU one workgroup or less gain most -- 24576 x 128 x 256: 30.0 -> 27.5 us, 256 x 512: 44.4 -> 39.6, the
+    // 693-wide MSE layer 107 -> 98; 512 x 512 and the data gradients unchanged -- and the step 55.4 -> 54.4 ms (three interleaved pairs;
+    // forward kernels only, -DDTC_H2_AHEAD2=2: 55.0).  8 more registers (132-141: three workgroups per CU).  -DDTC_H2_AHEAD2=0: one stage.
 #ifndef DTC_H2_AHEAD2
-#define DTC_H2_AHEAD2 0
+#define DTC_H2_AHEAD2 1
 #endif
-    constexpr bool AH2 = H2 && WIMG && (DTC_H2_AHEAD2 != 0);
+    constexpr bool AH2 = H2 && WIMG && (DTC_H2_AHEAD2 == 1 || (DTC_H2_AHEAD2 == 2 && EPI != EPI_DGRAD));
     f32x4 ras[AH2 ? 2 : 1][NA], rb[NB ? NB : 1];
     int kls[AH2 ? 2 : 1];                           // last valid element (0..3, < 0: none) of the loaded k chunks; >= 3: no tail
     auto load_w = [&](auto nbc) {                   // (W image) next stage's chunk -> LDS[nbuf] (no wait)

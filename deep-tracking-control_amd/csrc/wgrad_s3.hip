@@ -53,7 +53,10 @@ __device__ __forceinline__ int logical(int p) { return 4 * (p & 31) + (p >> 5); 
 // bench step's grouped launches ran 318 instead of 270 us).  The row-map variant keeps 180 registers (budget 3 would spill one)
 // H2 (round 4): operands as two fp16 terms, three MFMA passes per 16 batch rows (s3_core.hpp) instead of three bf16 terms and six
 template <bool GATHER_A, bool H2 = false>
-__global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G) {
+#ifndef DTC_WGRAD_H2_WG
+#define DTC_WGRAD_H2_WG 2
+#endif
+__global__ __launch_bounds__(256, H2 ? DTC_WGRAD_H2_WG : 2) void wgrad_s3_group_kernel(const S3Group G) {
     using P = Prec<H2>;
     constexpr int NP = P::NP, NT = P::NT;
     __shared__ __attribute__((aligned(16))) u32x2 As[2][3][TILE * 4];          // (three planes either way: the epilogue's patches need the 48 KiB)
@@ -122,7 +125,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
     }
     const int e_mine = is_a ? ez : exx;
 
-    f32x4 v[4];
+    // AHW (fp16 kernels, round 4; -DDTC_H2_WGRAD_AHEAD2=1, OFF): the operand loads TWO stages ahead of the MFMAs (two register sets, set =
+    // parity of the stage), as linear_s3_kernel<.., H2> has them.  Here both operands travel through registers: 180 instead of 152
+    // registers = two instead of three workgroups per CU, 59.4 vs 54.5 ms per step; squeezed into three (-DDTC_WGRAD_H2_WG=3): 58.8 vs 57.3.
+#ifndef DTC_H2_WGRAD_AHEAD2
+#define DTC_H2_WGRAD_AHEAD2 0
+#endif
+    constexpr bool AHW = H2 && !GATHER_A && (DTC_H2_WGRAD_AHEAD2 != 0);
+    f32x4 vs[AHW ? 2 : 1][4];
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     u32 rnext[4];
     auto rows_of = [&](int mb) {                       // source rows of X for the stage starting at batch row mb
@@ -134,7 +144,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
         }
     };
     if (GATHER_A || !is_a) rows_of(m_begin);
-    auto load_stage = [&](int mb) {
+    auto load_stage = [&](int mb, auto setc) {
+        f32x4(&v)[4] = vs[AHW ? decltype(setc)::value : 0];
         if (is_a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -152,7 +163,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
     };
     // BIAS (workgroup-uniform): the first column tile of a layer also sums dZ's columns (12 of the ~100 VALU of a stage that the
     // other tiles, and the X side everywhere, do not need to issue)
-    auto store_stage = [&](int buf, auto bias) {
+    auto store_stage = [&](int buf, auto bias, auto setc) {
+        f32x4(&v)[4] = vs[AHW ? decltype(setc)::value : 0];
         u32x2(*dst)[TILE * 4] = is_a ? As[buf] : Bs[buf];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -194,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
 
     // fused stage: the MFMAs of LDS[buf] with the conversion + LDS store of the loaded block (-> LDS[buf ^ 1]) placed between the
     // MFMAs of the second column tile, one column of the block per three MFMAs (see linear_s3_kernel)
-    auto stage_ilv = [&](int buf, auto bias) {
+    auto stage_ilv = [&](int buf, auto bias, auto setc) {        // setc: the register set that is converted (-> LDS[buf ^ 1])
+        f32x4(&v)[4] = vs[AHW ? decltype(setc)::value : 0];
         u32x4 a[2][NP], b[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p)
@@ -229,17 +242,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_group_kernel(const S3Group G)
 
     const int KT = (m_end - m_begin + BK - 1) / BK;
     auto k_loop = [&](auto bias) {
+        if constexpr (AHW) {
+            // stage kt lives in register set kt & 1 and goes to LDS[kt & 1]; half step HS<P>(kt), P = kt & 1: the loads of stage kt + 1
+            // are issued (into the set stage kt - 1 was converted from), LDS[P ^ 1] (stage kt - 1) feeds the MFMAs, set P (stage kt,
+            // loaded one half step earlier) is converted into LDS[P].  Loads past the slice read masked rows: zeros, never stored.
+            load_stage(m_begin, S0{});
+            store_stage(0, bias, S0{});
+            load_stage(m_begin + BK, S1{});
+            __syncthreads();
+            int kt = 1;
+            for (; kt + 1 < KT; kt += 2) {                   // kt is odd here
+                load_stage(m_begin + (kt + 1) * BK, S0{});
+                stage_ilv(0, bias, S1{});
+                __syncthreads();
+                load_stage(m_begin + (kt + 2) * BK, S1{});
+                stage_ilv(1, bias, S0{});
+                __syncthreads();
+            }
+            if (kt < KT) {
+                load_stage(m_begin + (kt + 1) * BK, S0{});
+                stage_ilv(0, bias, S1{});
+                __syncthreads();
+            }
+            mfma_stage((KT - 1) & 1);
+            return;
+        }
         int buf = 0;
-        load_stage(m_begin);
-        store_stage(0, bias);
+        load_stage(m_begin, S0{});
+        store_stage(0, bias, S0{});
         __syncthreads();
         for (int kt = 1; kt < KT; ++kt) {
-            load_stage(m_begin + kt * BK);
+            load_stage(m_begin + kt * BK, S0{});
 #ifndef DTC_S3_NO_ILV
-            stage_ilv(buf, bias);
+            stage_ilv(buf, bias, S0{});
 #else
             mfma_stage(buf);
-            store_stage(buf ^ 1, bias);
+            store_stage(buf ^ 1, bias, S0{});
 #endif
             __syncthreads();
             buf ^= 1;
