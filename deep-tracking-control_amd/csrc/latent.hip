@@ -15,6 +15,7 @@
 // element; what it reads from other workgroups travels write-through (agent-scope relaxed stores / loads), no
 // cache-maintenance fence (an agent-scope release would write back the whole XCD L2).
 // mulv is the [B,35] output of the fused (latent_mu | latent_var) head: cols 0..18 mu, 19..34 lv.
+#include "amax.hpp"
 #include <stddef.h>
 #include <stdlib.h>
 
@@ -184,7 +185,10 @@ __global__ __launch_bounds__(256) void lat_hist_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(256) void lat_apply_kernel(float* __restrict__ mulv, const float* __restrict__ eps,
                                                         float* __restrict__ z, uint8_t* __restrict__ mask,
-                                                        int* __restrict__ info, long long n, int nblk_stats, Ws* ws) {
+                                                        int* __restrict__ info, long long n, int nblk_stats, Ws* ws,
+                                                        amax_u32* __restrict__ z_amax) {
+    __shared__ amax_u32 red_z[4];
+    amax_u32 mz = 0u;                                  // largest |z| this thread writes (amax record, two-term fp16 GEMM path)
     __shared__ double shd[4];
     __shared__ unsigned long long shs[258];
     __shared__ int cnt[4];
@@ -211,8 +215,11 @@ __global__ __launch_bounds__(256) void lat_apply_kernel(float* __restrict__ mulv
             atomicMin(&info[1], (int)e);
         }
         mask[e] = out ? 1 : 0;
-        z[e] = eps[e] * expf(0.5f * x) + mulv[b * LD + 3 + j];
+        const float zv = eps[e] * expf(0.5f * x) + mulv[b * LD + 3 + j];
+        z[e] = zv;
+        mz = abs_bits(zv) > mz ? abs_bits(zv) : mz;
     }
+    amax_publish_block(z_amax, mz, red_z);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) nout += __shfl_xor(nout, off, 64);
     if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = nout;
@@ -227,15 +234,22 @@ __global__ __launch_bounds__(256) void lat_apply_kernel(float* __restrict__ mulv
 __global__ __launch_bounds__(256) void lat_bwd_kernel(float* __restrict__ dmulv, const float* __restrict__ dz,
                                                       const float* __restrict__ eps, const float* __restrict__ mulv,
                                                       const uint8_t* __restrict__ mask, const int* __restrict__ info,
-                                                      long long n, Ws* ws) {
+                                                      long long n, Ws* ws, amax_u32* __restrict__ dmulv_amax) {
+    // dmulv_amax: amax record of the WHOLE [B, 35] gradient after this call (the columns this kernel rewrites, the three leading ones it
+    // leaves alone -- read for the record only --, and the median element's late update)
     __shared__ float shf[4];
+    __shared__ amax_u32 red_m[4];
+    amax_u32 md = 0u;
     float acc = 0.f;
     const int em = info[1];                           // flat index of the median element (written by the forward call)
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
         const long long b = e >> 4;
         const int j = (int)(e & 15);
         const float g = dz[e];
-        dmulv[b * LD + 3 + j] += g;                                   // z = ... + mu[:, 3:]
+        const float gmu = dmulv[b * LD + 3 + j] + g;                  // z = ... + mu[:, 3:]
+        dmulv[b * LD + 3 + j] = gmu;
+        md = abs_bits(gmu) > md ? abs_bits(gmu) : md;
+        if (dmulv_amax != nullptr && j < 3) md = abs_bits(dmulv[b * LD + j]) > md ? abs_bits(dmulv[b * LD + j]) : md;
         const float lv = mulv[b * LD + MU + j];
         float glv = dmulv[b * LD + MU + j] + g * eps[e] * (0.5f * expf(0.5f * lv));
         if (mask[e]) {
@@ -245,7 +259,9 @@ __global__ __launch_bounds__(256) void lat_bwd_kernel(float* __restrict__ dmulv,
         // the median element is read again by the LAST workgroup of this launch: write it through (sc1), all others plain
         if (e == (long long)em) __hip_atomic_store(&dmulv[b * LD + MU + j], glv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else dmulv[b * LD + MU + j] = glv;
+        md = abs_bits(glv) > md ? abs_bits(glv) : md;
     }
+    amax_publish_block(dmulv_amax, md, red_m);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if ((threadIdx.x & 63) == 0) shf[threadIdx.x >> 6] = acc;
@@ -273,6 +289,7 @@ __global__ __launch_bounds__(256) void lat_bwd_kernel(float* __restrict__ dmulv,
                 float* p = &dmulv[(long long)(em >> 4) * LD + MU + (em & 15)];
                 const float cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *p = cur + tot;
+                if (dmulv_amax != nullptr) atomicMax(dmulv_amax, abs_bits(cur + tot));
             }
             __hip_atomic_store(&ws->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
         }
@@ -292,7 +309,7 @@ extern "C" int64_t dtc_cenet_workspace(int B) {
 }
 
 extern "C" int dtc_cenet_latent_fwd(float* mulv, const float* eps, float* z, uint8_t* mask, int32_t* info,
-                                    void* workspace, int B, void* stream) {
+                                    void* workspace, int B, uint32_t* z_amax, void* stream) {
     DTC_REQUIRE(B > 0 && (long long)B * LAT >= 2, "bad batch %d", B);
     DTC_REQUIRE(mulv && eps && z && mask && info && workspace, "null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -304,12 +321,13 @@ extern "C" int dtc_cenet_latent_fwd(float* mulv, const float* eps, float* z, uin
     hipLaunchKernelGGL(lat_hist_kernel<1>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
     hipLaunchKernelGGL(lat_hist_kernel<2>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
     hipLaunchKernelGGL(lat_hist_kernel<3>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
-    hipLaunchKernelGGL(lat_apply_kernel, dim3(g), dim3(256), 0, s, mulv, eps, z, mask, info, n, g, ws);
+    hipLaunchKernelGGL(lat_apply_kernel, dim3(g), dim3(256), 0, s, mulv, eps, z, mask, info, n, g, ws, (amax_u32*)z_amax);
     return dtc::check_launch("cenet_latent_fwd");
 }
 
 extern "C" int dtc_cenet_latent_bwd(float* dmulv, const float* dz, const float* eps, const float* mulv,
-                                    const uint8_t* mask, const int32_t* info, void* workspace, int B, void* stream) {
+                                    const uint8_t* mask, const int32_t* info, void* workspace, int B, uint32_t* dmulv_amax,
+                                    void* stream) {
     DTC_REQUIRE(B > 0, "bad batch %d", B);
     DTC_REQUIRE(dmulv && dz && eps && mulv && mask && info && workspace, "null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -317,6 +335,6 @@ extern "C" int dtc_cenet_latent_bwd(float* dmulv, const float* dz, const float* 
     const long long n = (long long)B * LAT;
     const int g = grid_for(n);
     dtc::ProfScope prof("cenet_latent_bwd", (double)n * 4.0 * 6, s);
-    hipLaunchKernelGGL(lat_bwd_kernel, dim3(g), dim3(256), 0, s, dmulv, dz, eps, mulv, mask, info, n, ws);
+    hipLaunchKernelGGL(lat_bwd_kernel, dim3(g), dim3(256), 0, s, dmulv, dz, eps, mulv, mask, info, n, ws, (amax_u32*)dmulv_amax);
     return dtc::check_launch("cenet_latent_bwd");
 }

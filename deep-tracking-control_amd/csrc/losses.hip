@@ -41,8 +41,11 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
                                                        const float* __restrict__ priv, const float* __restrict__ base_vel,
                                                        const long long* __restrict__ idx, float* __restrict__ d_recons,
                                                        float* __restrict__ d_hrecon, float* __restrict__ dmulv,
-                                                       double* __restrict__ part, int B, int nb_h, int nb_r) {
+                                                       double* __restrict__ part, int B, int nb_h, int nb_r,
+                                                       amax_u32* __restrict__ drec_amax) {
     __shared__ double sh[4];
+    __shared__ amax_u32 red_m[4];
+    amax_u32 mrec = 0u;                                // largest |d_recons| this thread writes (amax record, two-term fp16 GEMM path)
     const int blk = blockIdx.x;
     double acc0 = 0.0, acc1 = 0.0;
     int slot0 = 3, slot1 = -1;
@@ -69,6 +72,7 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
                 const float diff = recons[(long long)b * OBS + lane] - next_obs[idx[b] * OBS + lane];
                 acc0 += (double)diff * (double)diff;
                 d_recons[(long long)b * OBS + lane] = diff * scale;
+                mrec = abs_bits(diff * scale) > mrec ? abs_bits(diff * scale) : mrec;
             }
         }
         slot0 = 0;
@@ -99,6 +103,7 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
             acc1 = (double)(-0.5f * row);
         }
     }
+    amax_publish_block(drec_amax, mrec, red_m);
     acc0 = block_sum_d(acc0, sh);
     if (slot1 >= 0) acc1 = block_sum_d(acc1, sh);
     if (threadIdx.x == 0) {
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     const float* __restrict__ returns, const float* __restrict__ old_values, const long long* __restrict__ idx, DtcPpoCfg cfg,
     float* __restrict__ mean, float* __restrict__ value, float* __restrict__ dmean, float* __restrict__ dvalue,
     float* __restrict__ dHa, long long lddha, float* __restrict__ dHc, long long lddhc, double* __restrict__ part, int B, int A,
-    amax_u32* __restrict__ dha_amax, amax_u32* __restrict__ dhc_amax) {
+    amax_u32* __restrict__ dha_amax, amax_u32* __restrict__ dhc_amax, amax_u32* __restrict__ dmean_amax, amax_u32* __restrict__ dval_amax) {
     // TPR threads per row (4: 64 rows per workgroup; 8: 32 rows per workgroup = twice the workgroups, half the serial work
     // per thread -- the kernel is a latency chain per row, not a bandwidth problem)
     constexpr int NC = H / (4 * TPR);                // chunks per thread
@@ -311,12 +316,15 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
         o = ppo_row_loss(mrow, v, sstd, actions, old_logp, old_mu, old_sigma, adv, returns, old_values, r, cfg, 1.0f / (float)B, A,
                          dm, ds);
     }
+    amax_u32 mdm = 0u, mdv = 0u;           // largest |dmean| / |dvalue| this thread writes
     if (ok) {
         value[row] = v;
         dvalue[row] = o.dvalue;
+        mdv = abs_bits(o.dvalue);
         for (int j = 0; j < A; ++j) {
             mean[(long long)row * A + j] = mrow[j];
             dmean[(long long)row * A + j] = dm[j];
+            mdm = abs_bits(dm[j]) > mdm ? abs_bits(dm[j]) : mdm;
         }
     }
     // ---- backward through the two heads: dHa = (dmean Wa) * act'(Ha), dHc = (dvalue Wc) * act'(Hc)
@@ -342,9 +350,11 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
             *reinterpret_cast<f4*>(dHc + rr * lddhc + 4 * (p + TPR * i)) = gc;
         }
     }
-    __shared__ amax_u32 red_a[4], red_c[4];
+    __shared__ amax_u32 red_a[4], red_c[4], red_m[4], red_v[4];
     amax_publish_block(dha_amax, ma, red_a);
     amax_publish_block(dhc_amax, mc, red_c);
+    amax_publish_block(dmean_amax, mdm, red_m);
+    amax_publish_block(dval_amax, mdv, red_v);
     ppo_block_partials(ok ? o.s_sur : 0.0, ok ? o.s_val : 0.0, ok ? o.s_kl : 0.0, ds, ok, A, part);
 }
 
@@ -426,7 +436,7 @@ extern "C" int64_t dtc_loss_workspace(int B) {
 
 extern "C" int dtc_vae_loss(const float* recons, const float* hrecon, const float* mulv, const float* next_obs,
                             const float* priv, const float* base_vel, const int64_t* idx, float* d_recons,
-                            float* d_hrecon, float* dmulv, float* losses, void* workspace, int B, void* stream) {
+                            float* d_hrecon, float* dmulv, float* losses, void* workspace, int B, uint32_t* drec_amax, void* stream) {
     DTC_REQUIRE(B > 0, "bad batch %d", B);
     DTC_REQUIRE(recons && hrecon && mulv && next_obs && priv && base_vel && idx, "null input");
     DTC_REQUIRE(d_recons && d_hrecon && dmulv && losses && workspace, "null output");
@@ -441,14 +451,14 @@ extern "C" int dtc_vae_loss(const float* recons, const float* hrecon, const floa
     double* part = (double*)workspace;
     dtc::ProfScope prof("vae_loss", (double)B * (HGT * 12.0 + OBS * 12.0 + LD * 8.0), s);
     hipLaunchKernelGGL(vae_loss_kernel, dim3(nblk), dim3(256), 0, s, recons, hrecon, mulv, next_obs, priv, base_vel,
-                       (const long long*)idx, d_recons, d_hrecon, dmulv, part, B, nb_h, nb_r);
+                       (const long long*)idx, d_recons, d_hrecon, dmulv, part, B, nb_h, nb_r, (amax_u32*)drec_amax);
     hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, B, losses, (const double*)nullptr, 0);
     return dtc::check_launch("vae_loss");
 }
 
 extern "C" int dtc_vae_loss_fused(const float* recons, const float* mulv, const float* next_obs, const float* base_vel,
                                   const int64_t* idx, float* d_recons, float* dmulv, const double* height_sq_part,
-                                  int n_height_part, float* losses, void* workspace, int B, void* stream) {
+                                  int n_height_part, float* losses, void* workspace, int B, uint32_t* drec_amax, void* stream) {
     DTC_REQUIRE(B > 0 && n_height_part >= 0, "bad batch %d", B);
     DTC_REQUIRE(recons && mulv && next_obs && base_vel && idx, "null input");
     DTC_REQUIRE(d_recons && dmulv && losses && workspace && (height_sq_part || n_height_part == 0), "null output");
@@ -461,7 +471,8 @@ extern "C" int dtc_vae_loss_fused(const float* recons, const float* mulv, const 
     double* part = (double*)workspace;
     dtc::ProfScope prof("vae_loss", (double)B * (OBS * 12.0 + LD * 8.0), s);
     hipLaunchKernelGGL(vae_loss_kernel, dim3(nblk), dim3(256), 0, s, recons, (const float*)nullptr, mulv, next_obs,
-                       (const float*)nullptr, base_vel, (const long long*)idx, d_recons, (float*)nullptr, dmulv, part, B, 0, nb_r);
+                       (const float*)nullptr, base_vel, (const long long*)idx, d_recons, (float*)nullptr, dmulv, part, B, 0, nb_r,
+                       (amax_u32*)drec_amax);
     hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, B, losses, height_sq_part, n_height_part);
     return dtc::check_launch("vae_loss_fused");
 }
@@ -494,7 +505,8 @@ extern "C" int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc
                                   const float* advantages, const float* returns, const float* old_values, const int64_t* idx,
                                   const DtcPpoCfg* cfg, float* mean, float* value, float* dmean, float* dvalue, float* dHa,
                                   int64_t lddha, float* dHc, int64_t lddhc, float* dstd, float* losses, double* lr,
-                                  void* workspace, int B, int num_actions, uint32_t* dha_amax, uint32_t* dhc_amax, void* stream) {
+                                  void* workspace, int B, int num_actions, uint32_t* dha_amax, uint32_t* dhc_amax, uint32_t* dmean_amax,
+                                  uint32_t* dval_amax, void* stream) {
     DTC_REQUIRE(B > 0 && num_actions > 0 && num_actions <= MAX_ACT, "bad shape B=%d A=%d", B, num_actions);
     DTC_REQUIRE(H == 64 || H == 128 || H == 256, "hidden width %d unsupported by the fused heads (64, 128, 256)", H);
     DTC_REQUIRE(Ha && Hc && Wa && Wc && std && actions && old_logp && old_mu && old_sigma && advantages && returns && old_values,
@@ -514,7 +526,8 @@ extern "C" int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc
     dtc::ProfScope prof("ppo_heads_loss", (double)B * (4.0 * H * 4 + num_actions * 32.0), s);
 #define DTC_HL_ARGS Ha, (long long)ldha, Hc, (long long)ldhc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, \
                     advantages, returns, old_values, (const long long*)idx, *cfg, mean, value, dmean, dvalue, dHa, (long long)lddha, \
-                    dHc, (long long)lddhc, part, B, num_actions, (amax_u32*)dha_amax, (amax_u32*)dhc_amax
+                    dHc, (long long)lddhc, part, B, num_actions, (amax_u32*)dha_amax, (amax_u32*)dhc_amax, (amax_u32*)dmean_amax, \
+                    (amax_u32*)dval_amax
     if (tpr == 8) {
         if (H == 64) hipLaunchKernelGGL((ppo_heads_loss_kernel<64, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
         else if (H == 128) hipLaunchKernelGGL((ppo_heads_loss_kernel<128, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);

@@ -80,7 +80,7 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 8          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 9          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
@@ -173,21 +173,22 @@ _SIGS = {
     "dtc_wgrad_group_s3_workspace": (C.c_int64, [C.POINTER(DtcWgradJob), C.c_int, C.c_int]),
     "dtc_wgrad_group_s3": (C.c_int, [C.POINTER(DtcWgradJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_cenet_workspace": (C.c_int64, [C.c_int]),
-    "dtc_cenet_latent_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int, c_stream]),
-    "dtc_cenet_latent_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int,
+    "dtc_cenet_latent_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int, C.c_void_p, c_stream]),
+    "dtc_cenet_latent_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int, C.c_void_p,
                                        c_stream]),
     "dtc_loss_workspace": (C.c_int64, [C.c_int]),
-    "dtc_vae_loss": (C.c_int, [c_f32p] * 6 + [c_i64p] + [c_f32p] * 4 + [C.c_void_p, C.c_int, c_stream]),
+    "dtc_vae_loss": (C.c_int, [c_f32p] * 6 + [c_i64p] + [c_f32p] * 4 + [C.c_void_p, C.c_int, C.c_void_p, c_stream]),
     "dtc_linear_fwd_mse_parts": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_linear_fwd_mse": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, c_i64p,
                                      C.c_float, c_f32p, C.c_int64, c_f64p, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_vae_loss_fused": (C.c_int, [c_f32p] * 4 + [c_i64p] + [c_f32p] * 2 + [c_f64p, C.c_int, c_f32p, C.c_void_p, C.c_int,
-                                                                             c_stream]),
+                                                                             C.c_void_p, c_stream]),
     "dtc_ppo_loss": (C.c_int, [c_f32p] * 10 + [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 4 +
                      [c_f64p, C.c_void_p, C.c_int, C.c_int, c_stream]),
     "dtc_ppo_heads_loss": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int] + [c_f32p] * 4 + [C.c_int] + [c_f32p] * 8 +
                            [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 5 + [C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f64p,
-                                                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_stream]),
+                                                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                                      C.c_void_p, c_stream]),
     "dtc_lr_adapt": (C.c_int, [c_f32p, c_f64p, C.c_float, c_stream]),
     "dtc_gaussian_act": (C.c_int, [c_f32p] * 7 + [C.c_int, C.c_int, c_stream]),
     "dtc_adam_workspace": (C.c_int64, [C.c_int64]),

@@ -94,6 +94,7 @@ SPLIT = _os.environ.get("DTC_GEMM_SPLIT", "2") != "0"
 # (DTC_GEMM_SPLIT=1: no amax needed, twice the matrix-pipe work).  The recurrent kernels and the activation-image chain are bf16 x 3 only.
 H2 = _os.environ.get("DTC_GEMM_SPLIT", "2") == "2"
 AMAX_CHECK = _os.environ.get("DTC_AMAX_CHECK", "0") == "1"   # debug: re-derive every published amax at its use (synchronises)
+_NOPUB_SMALL = _os.environ.get("DTC_AMAX_NOPUB_SMALL", "0") == "1"    # A/B aid: the latent / loss kernels publish no amax (their consumers compute it)
 AMAX_STATS = {} if _os.environ.get("DTC_AMAX_STATS", "0") == "1" else None   # debug: (kind, shape) -> count of dtc_amax fallbacks
 # routing thresholds (output columns / reduction length); swept with bench.py in round 3: 256 / 384 -> 70.2 ms, 128 / 128 -> 69.5 ms per
 # step (the 128-column layers run longer per launch on 192 tiles of 128 x 128 -- 35 vs 28 us -- but on the second lane, under the wide GEMMs)
@@ -260,6 +261,13 @@ def _h2_operand(Xs, kind="fwd"):
     for i in range(Xs.nseg):
         Xs.seg[i].amax = _amax_in(srcs[i], kind) if srcs[i] is not None else None
     return Xs
+
+
+def _pub(t):
+    """Record a kernel that writes ALL of the 2-D tensor `t` publishes its amax into (None outside the fp16 path / a trainer phase)."""
+    if not (SPLIT and H2) or t is None or t.dim() != 2 or _NOPUB_SMALL:
+        return None
+    return _amax_out(t, 0, t.shape[1])
 
 
 def _h2_destination(dXs):
@@ -742,13 +750,13 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 def cenet_latent_fwd(mulv, eps, z, mask, info, ws):
     B = mulv.shape[0]
     check(lib().dtc_cenet_latent_fwd(cptr(mulv, f32), cptr(eps, f32), cptr(z, f32), cptr(mask, torch.uint8),
-                                     cptr(info, torch.int32), ptr(ws), B, stream()), "dtc_cenet_latent_fwd")
+                                     cptr(info, torch.int32), ptr(ws), B, _pub(z), stream()), "dtc_cenet_latent_fwd")
 
 
 def cenet_latent_bwd(dmulv, dz, eps, mulv, mask, info, ws):
     B = mulv.shape[0]
     check(lib().dtc_cenet_latent_bwd(cptr(dmulv, f32), cptr(dz, f32), cptr(eps, f32), cptr(mulv, f32),
-                                     cptr(mask, torch.uint8), cptr(info, torch.int32), ptr(ws), B, stream()),
+                                     cptr(mask, torch.uint8), cptr(info, torch.int32), ptr(ws), B, _pub(dmulv), stream()),
           "dtc_cenet_latent_bwd")
 
 
@@ -756,7 +764,7 @@ def vae_loss(recons, hrecon, mulv, next_obs, priv, base_vel, idx, d_recons, d_hr
     B = recons.shape[0]
     check(lib().dtc_vae_loss(cptr(recons, f32), cptr(hrecon, f32), cptr(mulv, f32), cptr(next_obs, f32),
                              cptr(priv, f32), cptr(base_vel, f32), cptr(idx, torch.int64), cptr(d_recons, f32),
-                             cptr(d_hrecon, f32), cptr(dmulv, f32), ptr(losses), ptr(ws), B, stream()), "dtc_vae_loss")
+                             cptr(d_hrecon, f32), cptr(dmulv, f32), ptr(losses), ptr(ws), B, _pub(d_recons), stream()), "dtc_vae_loss")
 
 
 def linear_fwd_mse(X, W, b, target, tcol0, tidx, dY, sq_part, M=None, split=None):
@@ -787,7 +795,7 @@ def vae_loss_fused(recons, mulv, next_obs, base_vel, idx, d_recons, dmulv, heigh
     B = recons.shape[0]
     check(lib().dtc_vae_loss_fused(cptr(recons, f32), cptr(mulv, f32), cptr(next_obs, f32), cptr(base_vel, f32),
                                    cptr(idx, torch.int64), cptr(d_recons, f32), cptr(dmulv, f32), ptr(height_sq_part),
-                                   n_height_part, ptr(losses), ptr(ws), B, stream()), "dtc_vae_loss_fused")
+                                   n_height_part, ptr(losses), ptr(ws), B, _pub(d_recons), stream()), "dtc_vae_loss_fused")
 
 
 def ppo_heads_loss(Ha, Hc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, advantages, returns, old_values,
@@ -802,8 +810,7 @@ def ppo_heads_loss(Ha, Hc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old
                                    cptr(old_values, f32), cptr(idx, torch.int64) if idx is not None else None, cfg,
                                    cptr(mean, f32), cptr(value, f32), cptr(dmean, f32), cptr(dvalue, f32), cptr(dHa, f32),
                                    dHa.stride(0), cptr(dHc, f32), dHc.stride(0), ptr(dstd), ptr(losses), ptr(lr), ptr(ws), B, A,
-                                   _amax_out(dHa, 0, H) if (SPLIT and H2) else None, _amax_out(dHc, 0, H) if (SPLIT and H2) else None,
-                                   stream()), "dtc_ppo_heads_loss")
+                                   _pub(dHa), _pub(dHc), _pub(dmean), _pub(dvalue), stream()), "dtc_ppo_heads_loss")
 
 
 def ppo_loss(mean, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, old_values, idx, cfg,

@@ -38,7 +38,7 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-#define DTC_ABI_VERSION 8                    /* bumped whenever a signature or a by-value struct layout changes       */
+#define DTC_ABI_VERSION 9                    /* bumped whenever a signature or a by-value struct layout changes       */
 int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
 /* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
    DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcWgradImgJob: the binding compares them with its own layouts at load time (a library
@@ -404,11 +404,13 @@ int dtc_wgrad_group(const DtcWgradJob* jobs, int count, int M, void* workspace, 
  * median bits, 0}.  workspace >= dtc_cenet_workspace() bytes. */
 int64_t dtc_cenet_workspace(int B);
 int dtc_cenet_latent_fwd(float* mulv, const float* eps, float* z, uint8_t* mask, int32_t* info,
-                         void* workspace, int B, void* stream);
+                         void* workspace, int B, uint32_t* z_amax /* amax record of z (two-term fp16 GEMM path, DtcSeg.amax) or NULL */,
+                         void* stream);
 /* backward of the above: dmulv [B,35] holds the direct gradients w.r.t. (mu, lv_fixed) on entry
  * and the gradients w.r.t. the raw head outputs on exit. */
 int dtc_cenet_latent_bwd(float* dmulv, const float* dz, const float* eps, const float* mulv,
-                         const uint8_t* mask, const int32_t* info, void* workspace, int B, void* stream);
+                         const uint8_t* mask, const int32_t* info, void* workspace, int B,
+                         uint32_t* dmulv_amax /* amax record of the whole [B,35] gradient on exit, or NULL */, void* stream);
 
 /* ---- losses (fused forward + gradient) ------------------------------------------------------ */
 /* VAE losses of ppo.py:205-247.  Gathered operands are read as src[idx[b]].  Outputs:
@@ -416,7 +418,8 @@ int dtc_cenet_latent_bwd(float* dmulv, const float* dz, const float* eps, const 
  * losses[0..3] = {recons, vel, kld, height} (float, device). */
 int dtc_vae_loss(const float* recons, const float* hrecon, const float* mulv, const float* next_obs,
                  const float* priv, const float* base_vel, const int64_t* idx, float* d_recons,
-                 float* d_hrecon, float* dmulv, float* losses, void* workspace, int B, void* stream);
+                 float* d_hrecon, float* dmulv, float* losses, void* workspace, int B,
+                 uint32_t* drec_amax /* amax record of d_recons or NULL */, void* stream);
 
 /* The terrain-decoder output layer fused with its loss (ppo.py:216-218: height_recon = terrain_decoder(l_t),
  * height_loss = mse(height_recon, priv[..., 696:])): e = (X W^T + b) - target[tidx[m], tcol0 + n]; writes
@@ -429,7 +432,7 @@ int dtc_linear_fwd_mse(const DtcSegMat* X, const float* W, const float* b, const
                        int64_t lddy, double* sq_part, int M, int N, int K, void* stream);
 int dtc_vae_loss_fused(const float* recons, const float* mulv, const float* next_obs, const float* base_vel,
                        const int64_t* idx, float* d_recons, float* dmulv, const double* height_sq_part, int n_height_part,
-                       float* losses, void* workspace, int B, void* stream);
+                       float* losses, void* workspace, int B, uint32_t* drec_amax /* as dtc_vae_loss */, void* stream);
 int64_t dtc_loss_workspace(int B);
 
 typedef struct DtcPpoCfg {
@@ -456,8 +459,9 @@ int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc, int64_t l
                        const float* advantages, const float* returns, const float* old_values, const int64_t* idx,
                        const DtcPpoCfg* cfg, float* mean, float* value, float* dmean, float* dvalue, float* dHa,
                        int64_t lddha, float* dHc, int64_t lddhc, float* dstd, float* losses, double* lr, void* workspace,
-                       int B, int num_actions, uint32_t* dha_amax, uint32_t* dhc_amax /* amax slots of dHa / dHc (two-term fp16 GEMM
-                       path, see DtcSeg.amax) or NULL */, void* stream);
+                       int B, int num_actions, uint32_t* dha_amax, uint32_t* dhc_amax, uint32_t* dmean_amax,
+                       uint32_t* dval_amax /* amax records of dHa / dHc / dmean / dvalue (two-term fp16 GEMM path, see DtcSeg.amax), each
+                       may be NULL */, void* stream);
 /* The learning-rate rule of ppo.py:301-307 alone (data-parallel callers run dtc_ppo_loss with
  * adaptive_schedule = 0, all-reduce the KL mean, then call this so every rank takes the same branch).
  * The slot is CONSUMED: it is overwritten with NaN, and a NaN found in it (a caller that exchanged the gradient header
