@@ -213,7 +213,7 @@ def _bad_descriptor_calls():
         jobs[j].dZ, jobs[j].lddz, jobs[j].X, jobs[j].dW, jobs[j].N, jobs[j].K = p.value, 8, m, p.value, 8, 8
     assert lib.dtc_wgrad_group_workspace(jobs, 2, 4) > 0         # a valid plan: sizes only, no device access
     expect_err(lib.dtc_wgrad_group(jobs, 2, 4, None, None), "workspace")
-    expect_err(lib.dtc_cenet_latent_fwd(None, None, None, None, None, None, 8, None), "null")
+    expect_err(lib.dtc_cenet_latent_fwd(None, None, None, None, None, None, 8, None, None), "null")
     expect_err(lib.dtc_clip_adam(None, None, None, None, 8, 1.0, None, 0.9, 0.999, 1e-8, 1, None, None, None), "null")
     rec = (_ffi.DtcProfRec * 4)()
     assert lib.dtc_prof_report(rec, 4) == 0
