@@ -148,9 +148,6 @@ __global__ __launch_bounds__(256) void amax_zero_kernel(u32* p, int words) {
 }
 inline bool amax_group_run(const AmaxGroup& G, void* slots, size_t bytes, hipStream_t s) {
     if (G.count == 0) return true;
-#ifdef DTC_AMAX_TIMING_HACK
-    return true;                                       // timing experiment only: what the in-call launches cost (results are garbage)
-#endif
     const int words = (int)(bytes / 4);
     hipLaunchKernelGGL(amax_zero_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (u32*)slots, words);
     hipLaunchKernelGGL(amax_group_kernel, dim3((unsigned)G.it[G.count - 1].block_end), dim3(256), 0, s, G);
