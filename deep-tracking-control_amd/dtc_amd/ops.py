@@ -127,14 +127,15 @@ def set_split(on: bool, h2: bool | None = None):
 class Amax:
     """Where the fp16 path's operands get the amax of their tensor from (include/dtc_hip.h: DtcSeg.amax).
 
-    * published: a split-path kernel that writes a WHOLE tensor (all its columns) adds the largest |value| it writes to the tensor's
-      slot (atomic max in its epilogue); consumers of the tensor -- on any stream that is ordered after the producer, as every reader of
-      the data is -- read the slot.  Slots are zeroed by `reset()` at the start of a trainer phase (WeightImages.__enter__), so a
-      buffer that is rewritten phase after phase does not carry an old maximum along.
+    * published: a kernel that writes a WHOLE tensor (all its columns) -- the split-path and the narrow GEMM kernels, dtc_pack_cols, the
+      latent, VAE-loss and PPO-heads kernels -- adds the largest |value| it writes to the tensor's slot (one atomic max per workgroup in
+      its epilogue); consumers of the tensor -- on any stream that is ordered after the producer, as every reader of the data is -- read
+      the slot.  Slots are zeroed by `reset()` at the start of a trainer phase (WeightImages.__enter__), so a buffer that is rewritten
+      phase after phase does not carry an old maximum along.
     * static: tensors that do not change during an update (the rollout storage), computed once by `static()` before the lanes fork.
-    * everything else (outputs of the narrow single-pass kernels, of the loss / latent kernels, of torch ops) comes without a slot: the
-      library computes the amax of such an operand itself, right in front of the consumer (one memset + one launch per call for
-      all its slot-less operands, include/dtc_hip.h).
+    * everything else (outputs of torch ops, tensors a caller of the C ABI brings along) comes without a slot: the library computes the
+      amax of such an operand itself, right in front of the consumer (one zero-fill + one launch per call for all its slot-less
+      operands, include/dtc_hip.h).
     A tensor is identified by its base address, width and row stride; a published or static slot covers every column block of it.
     One registry per device, one phase at a time: entering a WeightImages block zeroes the records of the previous one (a consumer that
     still needed them would scale by 2^141, overflow fp16 and return NaN -- loud, as every misuse of a record is)."""
@@ -172,10 +173,10 @@ class Amax:
 
     def static(self, t):
         """(Re)compute the amax of a tensor that stays unchanged until the next call (on the current stream)."""
+        if t.data_ptr() not in self.static_index and len(self.static_index) >= 64:
+            raise _ffi.DtcError("Amax: out of static slots")
         i = self.static_index.setdefault(t.data_ptr(), len(self.static_index))
         self.keep[t.data_ptr()] = t
-        if i >= 64:
-            raise _ffi.DtcError("Amax: out of static slots")
         p = self.fixed.data_ptr() + self.rec * i
         check(lib().dtc_amax(as_segmat(t.view(-1, t.shape[-1])), t.numel() // t.shape[-1], p, stream()), "dtc_amax")
         return p
