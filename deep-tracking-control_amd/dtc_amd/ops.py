@@ -155,7 +155,9 @@ class Amax:
         self.keep = {}
 
     def reset(self):
-        self.arena.zero_()
+        used = len(self.index)                 # only the records handed out since the last reset can be non-zero
+        if used:
+            self.arena[:used * self.rec // 4].zero_()
         self.fresh.clear()
         self.index.clear()
 
