@@ -1,0 +1,843 @@
+// Dense layers on block-scaled two-term fp16 operand images (round 5; format and rationale: csrc/h2i_core.hpp):
+// the nn.Linear products of rsl_rl/rsl_rl/modules/actor_critic_decoder.py:98-188, 323-349 under ppo.py:197-218, 252, 265, 289, 333.
+//
+//   h2i_pack_kernel     fp32 (segmented / row-gathered: the rollout storage, narrow hand-over tensors) -> image, exponent per row block
+//   h2i_wpack_kernel    weights (W or W^T, any column window / segment walk) -> image, exponent per 128 x 128 block; one launch per phase
+//   linear_h2i_kernel   Y = act(X W^T + b) | dX = (dZ W) act' | the terrain decoder's output layer fused with its MSE:
+//                       BOTH operands by LDS-DMA (no conversion, no operand registers, no ds_write in the K loop: 4 LDS-DMA pieces +
+//                       8 ds_read_b128 + 12 MFMAs per wave and 16-k stage), accumulator rows rescaled at the 128-column block borders,
+//                       results as fp32 and / or as the image the next consumer reads (per-row exponents chosen in the epilogue)
+//   h2i_unpack_kernel   image -> fp32 (tests, debugging)
+// Block tile 128 x 128 x 16, 2 x 2 waves of 64 x 64, double-buffered LDS (32 KiB + 4.5 KiB of exponent deltas), 3 workgroups per CU.
+#include <type_traits>
+
+#include "h2i_core.hpp"
+
+namespace {
+
+constexpr int EPI_FWD = 0, EPI_DGRAD = 1, EPI_MSE = 2;
+constexpr int MAX_TB = 8;            // exponent blocks along the reduction (sum over the row operand's segments)
+
+// ---- fp32 -> image ---------------------------------------------------------------------------------------------------------------
+// block = (row tile, k block); thread = (row r = tid & 127, k half h = tid >> 7): 8 stages x 8 consecutive columns in registers,
+// row maximum (with the other half's thread through LDS), exponent, split, 16-byte pieces.  A wave holds 64 consecutive rows and ONE
+// column group, so the segment a column group lies in is wave-uniform.
+struct PackArgs {
+    SegMatDev X;
+    int M, K, stages, kbs;
+    u32x4* img;
+    int* exps;
+};
+__global__ __launch_bounds__(256) void h2i_pack_kernel(const PackArgs P) {
+    const int tr = blockIdx.x / P.kbs, kb = blockIdx.x - tr * P.kbs;
+    const int tid = threadIdx.x, r = tid & 127, h = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int m = tr * 128 + r;
+    const SegMatDev& X = P.X;
+    float v[HI_KB][8];
+    u32 mx = 0u;
+    const long long src_row = (m < P.M && X.gathers > 0) ? X.idx[m] : (long long)m;
+#pragma unroll
+    for (int s = 0; s < HI_KB; ++s) {
+        const int c = (kb * HI_KB + s) * 16 + 8 * h;          // first of this thread's 8 columns (wave-uniform)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[s][e] = 0.f;
+        if (c >= P.K) continue;
+        const int sg = find_seg(X, c);
+        const SegDev sd = X.s[sg];
+        const long long row = sd.gather ? src_row : (long long)m;
+        if (c + 8 <= sd.start + sd.width) {                    // the 8 columns lie in one block: two 16-byte loads (dword-aligned)
+            const rsrc_t res = make_rsrc_bytes(sd.ptr, (long long)sd.rows * sd.ld * 4);
+            const u32 off = m < P.M ? (u32)((row * sd.ld + sd.col0 + (c - sd.start)) * 4) : INVALID;
+            const f32x4 a = bload4(res, off, 0u), b = bload4(res, off, 16u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[s][e] = a[e];
+                v[s][4 + e] = b[e];
+            }
+        } else {                                               // a block border (or the matrix's right edge) inside the group
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ce = c + e;
+                if (ce < P.K && m < P.M) {
+                    const SegDev se = X.s[find_seg(X, ce)];
+                    v[s][e] = se.ptr[(se.gather ? src_row : (long long)m) * se.ld + se.col0 + (ce - se.start)];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const u32 b = finite_bits(v[s][e]);
+            mx = b > mx ? b : mx;
+        }
+    }
+    __shared__ u32 rm[2][128];
+    rm[h][r] = mx;
+    __syncthreads();
+    mx = rm[0][r] > rm[1][r] ? rm[0][r] : rm[1][r];
+    const int e = hi_exp(mx);
+    if (h == 0) P.exps[(tr * P.kbs + kb) * 128 + r] = e;
+    const int ee = e == HI_EZERO ? 0 : e;
+#pragma unroll
+    for (int s = 0; s < HI_KB; ++s) {
+        const int st = kb * HI_KB + s;
+        if (st >= P.stages) break;
+        const f32x4 q[2] = {f32x4{v[s][0], v[s][1], v[s][2], v[s][3]}, f32x4{v[s][4], v[s][5], v[s][6], v[s][7]}};
+        const HiPiece pc = hi_split8(q, ee);
+        u32x4* chunk = P.img + ((long long)tr * P.stages + st) * (HI_CHUNK / 16);
+        chunk[rslot(r, h)] = pc.p[0];
+        chunk[256 + rslot(r, h)] = pc.p[1];
+    }
+}
+
+// ---- weights -> image ------------------------------------------------------------------------------------------------------------
+// Image rows = `nr` rows of the operand starting at r0; reduction = the concatenation of up to 4 column ranges, each padded to whole
+// stages and carrying its own exponent blocks (the row operand's segments are separate images with their own blocks).  trans: the
+// operand is W^T (element (row, c) = W[c * ld + r0 + row]) -- the data gradient's weight image, rows = a window of W's columns.
+// block = (job, row tile, exponent block); ONE exponent per block (the weight gradient never reads these images, and a 128 x 128 block
+// of a trained layer spans a few octaves).
+constexpr int WP_MAX_JOBS = 40;
+struct WpackJob {
+    const float* W;
+    long long ld;
+    u32x4* img;
+    int* exps;               // [row tiles][tblocks]
+    int trans, r0, nr, nseg, c0[4], cw[4];
+    int tstages, tblocks, block_end;      // block_end: running sum of (row tiles x tblocks) over the jobs
+};
+struct WpackGroup {
+    int count;
+    WpackJob job[WP_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void h2i_wpack_kernel(const WpackGroup G) {
+    int j = 0, b = blockIdx.x;
+    while (j < G.count - 1 && b >= G.job[j].block_end) ++j;
+    if (j > 0) b -= G.job[j - 1].block_end;
+    const WpackJob& J = G.job[j];
+    const int ct = b / J.tblocks;
+    int gb = b - ct * J.tblocks, sg = 0, gs0 = 0;              // gb -> (segment, block inside it); gs0: first global stage of the segment
+    while (sg + 1 < J.nseg && gb >= (int)hi_kblocks(J.cw[sg])) {
+        gb -= (int)hi_kblocks(J.cw[sg]);
+        gs0 += (int)hi_stages(J.cw[sg]);
+        ++sg;
+    }
+    const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;
+    const int row = ct * 128 + r;
+    const int nst = (int)hi_stages(J.cw[sg]);
+    float v[HI_KB][8];
+    u32 mx = 0u;
+#pragma unroll
+    for (int s = 0; s < HI_KB; ++s) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = (gb * HI_KB + s) * 16 + 8 * h + e;
+            const bool ok = row < J.nr && c < J.cw[sg];
+            const long long cc = J.c0[sg] + c;
+            v[s][e] = ok ? (J.trans ? J.W[cc * J.ld + J.r0 + row] : J.W[(long long)(J.r0 + row) * J.ld + cc]) : 0.f;
+            const u32 bb = finite_bits(v[s][e]);
+            mx = bb > mx ? bb : mx;
+        }
+    }
+    mx = wave_max_u32(mx);
+    __shared__ u32 red[4];
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
+    const int e = hi_exp(mx);
+    int gblock = gb;                                             // index of this block in the image's walk
+    for (int i = 0; i < sg; ++i) gblock += (int)hi_kblocks(J.cw[i]);
+    if (tid == 0) J.exps[ct * J.tblocks + gblock] = e;
+    const int ee = e == HI_EZERO ? 0 : e;
+#pragma unroll
+    for (int s = 0; s < HI_KB; ++s) {
+        const int st = gb * HI_KB + s;
+        if (st >= nst) break;
+        const f32x4 q[2] = {f32x4{v[s][0], v[s][1], v[s][2], v[s][3]}, f32x4{v[s][4], v[s][5], v[s][6], v[s][7]}};
+        const HiPiece pc = hi_split8(q, ee);
+        u32x4* chunk = J.img + ((long long)ct * J.tstages + gs0 + st) * (HI_CHUNK / 16);
+        chunk[rslot(r, h)] = pc.p[0];
+        chunk[256 + rslot(r, h)] = pc.p[1];
+    }
+}
+
+// ---- image -> fp32 (tests) -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void h2i_unpack_kernel(const u32x4* __restrict__ img, const int* __restrict__ exps, int M, int K, int stages,
+                                                         int kbs, float* __restrict__ out, long long ld) {
+    const int tr = blockIdx.x / stages, st = blockIdx.x - tr * stages;
+    const int r = threadIdx.x & 127, h = threadIdx.x >> 7;
+    const int m = tr * 128 + r;
+    if (m >= M) return;
+    const u32x4* chunk = img + (long long)blockIdx.x * (HI_CHUNK / 16);
+    const u32x4 hi = chunk[rslot(r, h)], lo = chunk[256 + rslot(r, h)];
+    int e = exps[(tr * kbs + st / HI_KB) * 128 + r];
+    e = e == HI_EZERO ? 0 : e;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = st * 16 + 8 * h + 2 * q;
+        const float a = __builtin_ldexpf(f16_lo(hi[q]) + f16_lo(lo[q]), -e), b = __builtin_ldexpf(f16_hi(hi[q]) + f16_hi(lo[q]), -e);
+        if (c < K) out[(long long)m * ld + c] = a;
+        if (c + 1 < K) out[(long long)m * ld + c + 1] = b;
+    }
+}
+
+// ---- the GEMM ----------------------------------------------------------------------------------------------------------------------
+struct HSeg {
+    const u32x4* img;
+    const int* exps;
+    u32 bytes;               // of the chunks (LDS-DMA descriptor bound)
+    int stages, kbs;
+};
+struct HOperand {            // row operand: up to 4 images over the same M rows, side by side along the reduction
+    int nseg, total, tblocks;
+    HSeg s[4];
+};
+struct HOut {
+    u32x4* img;              // NULL: no image of the result
+    int* exps;
+    int stages, kbs;
+};
+struct MseEpiH {
+    const float* target;
+    const long long* tidx;
+    long long ldt, target_bytes;
+    int tcol0;
+    float scale;
+    double* part;
+};
+struct DgradEpiH {
+    SegMatDev dX;            // fp32 destination over the computed column window (has_dx == 0: none)
+    int has_dx, wide_segs;
+    const float* add;        // fp32 [M, ld_add] added to the product before anything is stored (may be NULL)
+    long long ld_add;
+    const float* Xs;         // saved post-activation output (act != none without a sign record)
+    long long ldxs;
+    const unsigned short* rmask;
+    int ldm;
+};
+
+__device__ __forceinline__ void store8(float* base, long long ld, int row, int col, int M, int N, bool wide, const f32x4 (&v)[2]) {
+    if (row >= M) return;
+    float* p = base + (long long)row * ld + col;
+    if (wide && col + 8 <= N) {
+        *reinterpret_cast<f32x4*>(p) = v[0];
+        *reinterpret_cast<f32x4*>(p + 4) = v[1];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (col + e < N) p[e] = v[e >> 2][e & 3];
+    }
+}
+__device__ __forceinline__ void load8(const float* base, long long ld, int row, int col, int M, int N, bool wide, f32x4 (&v)[2]) {
+    v[0] = v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row >= M) return;
+    const float* p = base + (long long)row * ld + col;
+    if (wide && col + 8 <= N) {
+        v[0] = *reinterpret_cast<const f32x4*>(p);
+        v[1] = *reinterpret_cast<const f32x4*>(p + 4);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (col + e < N) v[e >> 2][e & 3] = p[e];
+    }
+}
+
+// N: result columns (EPI_DGRAD: the computed window of the layer's input columns).  wide bit 0: Y / single fp32 destination takes
+// 16-byte accesses, bit 1: Xs does, bit 2: add does.
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, const u32x4* __restrict__ wimg, u32 wimg_bytes,
+                                                            const int* __restrict__ wexps, const float* __restrict__ bias,
+                                                            float* __restrict__ Y, long long ldy, const HOut yo, int M, int N, int act, int wide,
+                                                            unsigned short* __restrict__ wmask, int ldwm, const DgradEpiH dg, const MseEpiH mse) {
+    constexpr int BN = 128, WN = 2, TM = 2, TN = 2;
+    // separate objects per stage buffer: an LDS-DMA into one cannot alias the fragment reads of the other (see linear_s3_kernel)
+    __shared__ __attribute__((aligned(16))) u32x2 Xs0[2][BM * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Xs1[2][BM * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Ws0[2][BN * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Ws1[2][BN * 4];
+    __shared__ __attribute__((aligned(16))) int Dt[MAX_TB + 1][128];      // exponent deltas per block border and row; [tblocks]: the final scale
+#define XS(b) ((b) ? Xs1 : Xs0)
+#define WS(b) ((b) ? Ws1 : Ws0)
+    int tr, tc;
+    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, tr, tc)) {
+        if (EPI == EPI_MSE && threadIdx.x == 0) mse.part[blockIdx.x] = 0.0;
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = tr * BM, n0 = tc * BN;
+    const int wm_off = (wave / WN) * (32 * TM), wn_off = (wave % WN) * (32 * TN);
+    const int half = lane >> 5, l31 = lane & 31;
+    const rsrc_t wres = make_rsrc_bytes(wimg, wimg_bytes);
+    const u32 lane_off = (u32)(tid * 16);
+
+    // ---- loader cursor (one stage ahead of the MFMAs)
+    int lseg = 0, lleft = A.s[0].stages, left = A.total;
+    rsrc_t xres = make_rsrc_bytes(A.s[0].img, A.s[0].bytes);
+    u32 xchunk = (u32)(tr * A.s[0].stages) * (u32)HI_CHUNK, wchunk = (u32)(tc * A.total) * (u32)HI_CHUNK;
+    auto load_stage = [&](auto nbc) {                   // next stage -> LDS[nbuf]; past the last stage: out-of-range lanes, zeros land
+        constexpr int nbuf = decltype(nbc)::value;
+        const u32 voff = lane_off | (left > 0 ? 0u : INVALID);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)&XS(nbuf)[p][wave * 128], 16, voff, xchunk + p * HI_PLANE, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)&WS(nbuf)[p][wave * 128], 16, voff, wchunk + p * HI_PLANE, 0, 0);
+        }
+        xchunk += HI_CHUNK;
+        wchunk += HI_CHUNK;
+        --left;
+        if (--lleft == 0 && lseg + 1 < A.nseg) {        // (uniform) into the next image of the row operand
+            ++lseg;
+            lleft = A.s[lseg].stages;
+            xres = make_rsrc_bytes(A.s[lseg].img, A.s[lseg].bytes);
+            xchunk = (u32)(tr * A.s[lseg].stages) * (u32)HI_CHUNK;
+        }
+    };
+    load_stage(S0{});
+
+    // ---- exponent deltas: thread r < 128 walks the blocks of row r.  e(b) = row exponent + weight-block exponent; a block without
+    // content (HI_EZERO) inherits its predecessor's (its products are zero whatever the scale)
+    if (tid < 128) {
+        int prev_a = 0, prev_w = 0, prev = 0, b = 0;
+        for (int i = 0; i < A.nseg; ++i) {
+            const int* ex = A.s[i].exps + (long long)tr * A.s[i].kbs * 128 + tid;
+            for (int k = 0; k < A.s[i].kbs; ++k, ++b) {
+                const int ea = ex[k * 128], ew = wexps[tc * A.tblocks + b];
+                prev_a = ea == HI_EZERO ? prev_a : ea;
+                prev_w = ew == HI_EZERO ? prev_w : ew;
+                const int e = prev_a + prev_w;
+                Dt[b][tid] = e - prev;
+                prev = e;
+            }
+        }
+        Dt[A.tblocks][tid] = -prev;
+        // (the first block's "delta" Dt[0] = e(0) is never applied: the accumulators start at zero)
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // rows of this lane's accumulator registers: wm_off + 32 i + 4 half + 8 g + e, register 4 g + e
+    auto rescale = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int4 d = *reinterpret_cast<const int4*>(&Dt[b][wm_off + 32 * i + 4 * half + 8 * g]);
+                const int dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j][4 * g + e] = __builtin_ldexpf(acc[i][j][4 * g + e], dv[e]);
+            }
+    };
+
+    // ---- compute cursor
+    int cseg = 0, cst = 0, blk = 0, done = 0;
+    auto stage = [&](auto bc) {
+        constexpr int buf = decltype(bc)::value;
+        // (uniform) a block border: the rows change scale.  In front of the LDS-DMA: behind it the compiler would wait for the transfer
+        // before the table reads (it cannot tell the two LDS objects apart)
+        if (done > 0 && done < A.total && (cst & (HI_KB - 1)) == 0) {
+            ++blk;
+            rescale(blk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(std::integral_constant<int, buf ^ 1>{});       // the next stage's pieces first (hipcc otherwise sinks them behind the MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 a[TM][2], b[TN][2];
+        auto rda = [&](int i, int p) { a[i][p] = reinterpret_cast<const u32x4*>(&XS(buf)[p][0])[rslot(wm_off + 32 * i + l31, half)]; };
+        auto rdb = [&](int j, int p) { b[j][p] = reinterpret_cast<const u32x4*>(&WS(buf)[p][0])[rslot(wn_off + 32 * j + l31, half)]; };
+        rda(0, 1); rdb(0, 0); rda(1, 1);
+        rda(0, 0); rdb(0, 1); rda(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        using P = Prec<true>;
+        // smallest terms first: lo hi', hi lo', hi hi'
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][0] = P::mfma(a[i][1], b[0][0], acc[i][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        rdb(1, 0); rdb(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][0] = P::mfma(a[i][0], b[0][1], acc[i][0]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][0] = P::mfma(a[i][0], b[0][0], acc[i][0]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][1] = P::mfma(a[i][1], b[1][0], acc[i][1]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][1] = P::mfma(a[i][0], b[1][1], acc[i][1]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][1] = P::mfma(a[i][0], b[1][0], acc[i][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        ++done;
+        if (++cst == A.s[cseg].stages && cseg + 1 < A.nseg) {
+            ++cseg;
+            cst = 0;
+        }
+        __syncthreads();
+    };
+    __syncthreads();
+    for (int trip = (A.total + 1) >> 1; trip > 0; --trip) {
+        stage(S0{});
+        stage(S1{});
+    }
+    // every wave is past its last fragment read and every LDS-DMA has landed (the barrier's wait): LDS becomes the patches
+    rescale(A.tblocks);                                  // back to the values themselves (2^-e of the last block, exact)
+    float* patch = reinterpret_cast<float*>(wave < 2 ? &Xs0[0][0] : &Xs1[0][0]) + (wave & 1) * (32 * LDW);
+    const bool full = (m0 + BM <= M) && (n0 + BN <= N);
+
+    double sq = 0.0;
+    if constexpr (EPI == EPI_MSE) {
+        // (the loss is formed behind the transposition below, where a lane holds 8 consecutive columns of a row)
+    } else if constexpr (EPI == EPI_FWD) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn_off + 32 * j + l31;
+            const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+            if (wmask && full) {                            // sign record of a ReLU layer (see linear_fwd_kernel)
+                unsigned bits = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bits |= acc[i][j][r] > 0.f ? (1u << r) : 0u;
+                wmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * ldwm + col] = (unsigned short)bits;
+            }
+            if (act == DTC_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : 0.f;
+            } else if (act == DTC_ACT_ELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : expm1f(acc[i][j][r]);
+            } else if (act != DTC_ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], act);
+            }
+        }
+    } else {
+        if (dg.rmask && full) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const unsigned bits = dg.rmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * dg.ldm + n0 + wn_off + 32 * j + l31];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = (bits >> r) & 1u ? acc[i][j][r] : 0.f;
+            }
+        }
+    }
+
+    // ---- through the patch: lane -> rows r16 + 16 q of the 32 x 32 tile, the 8 columns 8 c8 .. + 7; final values, fp32 stores, row maxima
+    const int r16 = lane >> 2, c8 = lane & 3;
+    f32x4 T[TM][TN][2][2];
+    u32 mrow[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) mrow[i][0] = mrow[i][1] = 0u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        patch_put(patch, acc[i][j], half, l31);
+        const int col = n0 + wn_off + 32 * j + 8 * c8;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int rl = r16 + 16 * q, row = m0 + wm_off + 32 * i + rl;
+            f32x4(&v)[2] = T[i][j][q];
+            v[0] = patch_get(patch, rl, 2 * c8);
+            v[1] = patch_get(patch, rl, 2 * c8 + 1);
+            if constexpr (EPI == EPI_MSE) {
+                // e = (acc + bias) - target[tidx[row], tcol0 + col];  dY = e * scale;  partial = sum e^2 (double)
+                const rsrc_t tres = make_rsrc_bytes(mse.target, mse.target_bytes), bres = make_rsrc_bytes(bias, bias ? (long long)N * 4 : 0);
+                const long long src = mse.tidx[row < M ? row : 0];
+                const u32 toff = (u32)((src * mse.ldt + mse.tcol0 + col) * 4) | ((row < M && col < N) ? 0u : INVALID);
+                const f32x4 tg[2] = {bload4(tres, toff, 0u), bload4(tres, toff, 16u)};
+                const f32x4 bv[2] = {bload4(bres, (u32)col * 4u, 0u), bload4(bres, (u32)col * 4u, 16u)};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (row < M && col + e < N) ? (v[e >> 2][e & 3] + bv[e >> 2][e & 3]) - tg[e >> 2][e & 3] : 0.f;
+                    v[e >> 2][e & 3] = d * mse.scale;
+                    sq += (double)d * (double)d;
+                }
+                if (Y) store8(Y, ldy, row, col, M, N, (wide & 1) != 0, v);
+            } else if constexpr (EPI == EPI_DGRAD) {
+                if (!dg.rmask && act != DTC_ACT_NONE) {
+                    f32x4 y[2];
+                    load8(dg.Xs, dg.ldxs, row, col, M, N, (wide & 2) != 0, y);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = act_bwd(v[e >> 2][e & 3], y[e >> 2][e & 3], act);
+                }
+                if (dg.add) {
+                    f32x4 o[2];
+                    load8(dg.add, dg.ld_add, row, col, M, N, (wide & 4) != 0, o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = o[e >> 2][e & 3] + v[e >> 2][e & 3];
+                }
+                if (dg.has_dx && col < N) {
+                    const SegMatDev& dX = dg.dX;
+                    const int sj = find_seg(dX, col);
+                    const SegDev sdj = dX.s[sj];
+                    if (col + 8 <= sdj.start + sdj.width || (sj == dX.nseg - 1)) {      // inside one destination block
+                        if (sdj.ptr) {
+                            const int lc = col - sdj.start;
+                            const bool w16 = ((dg.wide_segs >> sj) & 1) && ((lc + sdj.col0) & 3) == 0;
+                            float* base = sdj.ptr + sdj.col0;
+                            if (sdj.accumulate) {
+                                f32x4 o[2];
+                                load8(base, sdj.ld, row, lc, M, sdj.width, w16, o);
+                                f32x4 s2[2];
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) s2[e >> 2][e & 3] = o[e >> 2][e & 3] + v[e >> 2][e & 3];
+                                store8(base, sdj.ld, row, lc, M, sdj.width, w16, s2);
+                            } else {
+                                store8(base, sdj.ld, row, lc, M, sdj.width, w16, v);
+                            }
+                        }
+                    } else if (row < M) {                   // the group straddles a block border: element by element
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int c = col + e;
+                            if (c >= N) break;
+                            const SegDev sc = dX.s[find_seg(dX, c)];
+                            if (sc.ptr == nullptr) continue;
+                            float* qd = sc.ptr + sc.col0 + (c - sc.start) + (long long)row * sc.ld;
+                            *qd = sc.accumulate ? (*qd + v[e >> 2][e & 3]) : v[e >> 2][e & 3];
+                        }
+                    }
+                }
+            } else {
+                if (Y) store8(Y, ldy, row, col, M, N, (wide & 1) != 0, v);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e >> 2][e & 3] = (row < M && col + e < N) ? v[e >> 2][e & 3] : 0.f;       // images hold zeros behind the matrix
+                const u32 bb = finite_bits(v[e >> 2][e & 3]);
+                mrow[i][q] = bb > mrow[i][q] ? bb : mrow[i][q];
+            }
+        }
+    }
+
+    if constexpr (EPI == EPI_MSE) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    }
+    // ---- the image of the result: row maxima over the tile's 128 columns (4 lanes, then the neighbouring wave through LDS), exponents,
+    // split, 16-byte pieces.  (The stage buffers of W are free: every wave passed the loop's last barrier.)
+    u32* rm = reinterpret_cast<u32*>(&Ws0[0][0]);           // [2][128]
+    double* red = reinterpret_cast<double*>(&Ws1[0][0]);
+    if (yo.img) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                u32 m = mrow[i][q];
+                const u32 o1 = (u32)__shfl_xor((int)m, 1, 64);
+                m = o1 > m ? o1 : m;
+                const u32 o2 = (u32)__shfl_xor((int)m, 2, 64);
+                m = o2 > m ? o2 : m;
+                mrow[i][q] = m;
+                if (c8 == 0) rm[(wave % WN) * 128 + wm_off + 32 * i + r16 + 16 * q] = m;
+            }
+    }
+    if (EPI == EPI_MSE && lane == 0) red[wave] = sq;
+    if (yo.img || EPI == EPI_MSE) __syncthreads();
+    if (EPI == EPI_MSE && tid == 0) mse.part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (yo.img == nullptr) return;
+    u32x4* tile_chunks = yo.img + (long long)tr * yo.stages * (HI_CHUNK / 16);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int rloc = wm_off + 32 * i + r16 + 16 * q;
+            const u32 m = rm[rloc] > rm[128 + rloc] ? rm[rloc] : rm[128 + rloc];
+            const int e = hi_exp(m);
+            if (c8 == 0 && (wave % WN) == 0 && tc < yo.kbs) yo.exps[((long long)tr * yo.kbs + tc) * 128 + rloc] = e;
+            const int ee = e == HI_EZERO ? 0 : e;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int lc = n0 + wn_off + 32 * j + 8 * c8;
+                if ((lc >> 4) >= yo.stages) continue;
+                const HiPiece pc = hi_split8(T[i][j][q], ee);
+                u32x4* chunk = tile_chunks + (long long)(lc >> 4) * (HI_CHUNK / 16);
+                chunk[rslot(rloc, (lc >> 3) & 1)] = pc.p[0];
+                chunk[256 + rslot(rloc, (lc >> 3) & 1)] = pc.p[1];
+            }
+        }
+#undef XS
+#undef WS
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+int check_img(const void* img, const char* what) {
+    DTC_REQUIRE(img != nullptr && dtc::aligned16(img), "%s: null / unaligned image", what);
+    return DTC_OK;
+}
+
+int to_operand(const DtcH2iOperand* X, int M, HOperand& A, int& K) {
+    DTC_REQUIRE(X != nullptr && X->nseg >= 1 && X->nseg <= 4, "row operand: 1..4 images");
+    A = HOperand{};
+    A.nseg = X->nseg;
+    K = 0;
+    for (int i = 0; i < X->nseg; ++i) {
+        DTC_REQUIRE(X->img[i] != nullptr && dtc::aligned16(X->img[i]) && X->width[i] > 0, "row operand: image %d null / unaligned / empty", i);
+        DTC_REQUIRE(hi_bytes(M, X->width[i]) < (1ll << 31), "row operand: image %d beyond 2 GiB", i);
+        HSeg& s = A.s[i];
+        s.img = (const u32x4*)X->img[i];
+        s.bytes = (u32)hi_data_bytes(M, X->width[i]);
+        s.exps = reinterpret_cast<const int*>(reinterpret_cast<const char*>(X->img[i]) + s.bytes);
+        s.stages = (int)hi_stages(X->width[i]);
+        s.kbs = (int)hi_kblocks(X->width[i]);
+        A.total += s.stages;
+        A.tblocks += s.kbs;
+        K += X->width[i];
+    }
+    DTC_REQUIRE(A.tblocks <= MAX_TB, "row operand: %d exponent blocks along the reduction, at most %d (1024 columns)", A.tblocks, MAX_TB);
+    return DTC_OK;
+}
+
+HOut to_out(void* img, int M, int N) {
+    HOut o{};
+    if (img) {
+        o.img = (u32x4*)img;
+        o.exps = reinterpret_cast<int*>(reinterpret_cast<char*>(img) + hi_data_bytes(M, N));
+        o.stages = (int)hi_stages(N);
+        o.kbs = (int)hi_kblocks(N);
+    }
+    return o;
+}
+
+// the weight image the caller built with dtc_h2i_wimage_group for exactly this product: rows = nr, reduction walk = the operand's images
+struct WimgView {
+    const u32x4* img;
+    const int* exps;
+    u32 bytes;
+};
+WimgView wimg_view(const void* wimg, int nr, const HOperand& A) {
+    WimgView v;
+    v.img = (const u32x4*)wimg;
+    v.bytes = (u32)(dtc::ceil_div(nr, 128) * A.total * HI_CHUNK);
+    v.exps = reinterpret_cast<const int*>(reinterpret_cast<const char*>(wimg) + v.bytes);
+    return v;
+}
+
+}  // namespace
+
+extern "C" int64_t dtc_h2i_bytes(int M, int K) {
+    if (M <= 0 || K <= 0) return 0;
+    return hi_bytes(M, K);
+}
+
+// image(M, X->cols) of the fp32 operand X (segments side by side, row-gathered where a segment asks for it)
+extern "C" int dtc_h2i_pack(const DtcSegMat* X, int M, void* img, void* stream) {
+    DTC_REQUIRE(X != nullptr && M > 0, "null operand / bad M");
+    int rc = check_img(img, "dtc_h2i_pack");
+    if (rc != DTC_OK) return rc;
+    PackArgs P;
+    rc = to_dev(X, P.X, X->cols, false, M);
+    if (rc != DTC_OK) return rc;
+    P.M = M;
+    P.K = X->cols;
+    DTC_REQUIRE(hi_bytes(M, P.K) < (1ll << 31), "image beyond 2 GiB");
+    P.stages = (int)hi_stages(P.K);
+    P.kbs = (int)hi_kblocks(P.K);
+    P.img = (u32x4*)img;
+    P.exps = reinterpret_cast<int*>(reinterpret_cast<char*>(img) + hi_data_bytes(M, P.K));
+    hipStream_t s = (hipStream_t)stream;
+    dtc::ProfScope prof("h2i_pack", 0.0, s, 8.0 * M * (double)P.K);
+    hipLaunchKernelGGL(h2i_pack_kernel, dim3((unsigned)(hi_rtiles(M) * P.kbs)), dim3(256), 0, s, P);
+    return dtc::check_launch("h2i_pack");
+}
+
+extern "C" int dtc_h2i_unpack(const void* img, int M, int K, float* out, int64_t ld, void* stream) {
+    DTC_REQUIRE(out != nullptr && M > 0 && K > 0 && ld >= K, "null pointer / bad shape");
+    int rc = check_img(img, "dtc_h2i_unpack");
+    if (rc != DTC_OK) return rc;
+    const int stages = (int)hi_stages(K);
+    hipLaunchKernelGGL(h2i_unpack_kernel, dim3((unsigned)(hi_rtiles(M) * stages)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)img,
+                       reinterpret_cast<const int*>(reinterpret_cast<const char*>(img) + hi_data_bytes(M, K)), M, K, stages, (int)hi_kblocks(K),
+                       out, (long long)ld);
+    return dtc::check_launch("h2i_unpack");
+}
+
+extern "C" int64_t dtc_h2i_wimage_bytes(const DtcH2iWJob* job) {
+    if (job == nullptr || job->nr <= 0 || job->nseg < 1 || job->nseg > 4) return -1;
+    long long st = 0, tb = 0;
+    for (int i = 0; i < job->nseg; ++i) {
+        if (job->cw[i] <= 0) return -1;
+        st += hi_stages(job->cw[i]);
+        tb += hi_kblocks(job->cw[i]);
+    }
+    const long long ct = dtc::ceil_div(job->nr, 128);
+    return ct * st * HI_CHUNK + ((ct * tb * 4 + 15) & ~15ll);
+}
+
+// the weight images of `count` products in one launch per WP_MAX_JOBS jobs (a trainer builds the images of all layers of an optimisation
+// step at its start, after the optimiser wrote the weights)
+extern "C" int dtc_h2i_wimage_group(const DtcH2iWJob* jobs, int count, void* stream) {
+    DTC_REQUIRE(jobs != nullptr && count > 0, "no jobs");
+    hipStream_t s = (hipStream_t)stream;
+    double elems = 0.0;
+    for (int i = 0; i < count; ++i) {
+        int red = 0;
+        for (int k = 0; k < jobs[i].nseg && k < 4; ++k) red += jobs[i].cw[k];
+        elems += (double)jobs[i].nr * red;
+    }
+    dtc::ProfScope prof("wimage", 0.0, s, 8.0 * elems);
+    WpackGroup G;
+    G.count = 0;
+    auto flush = [&]() {
+        if (G.count == 0) return;
+        hipLaunchKernelGGL(h2i_wpack_kernel, dim3((unsigned)G.job[G.count - 1].block_end), dim3(256), 0, s, G);
+        G.count = 0;
+    };
+    for (int i = 0; i < count; ++i) {
+        const DtcH2iWJob& h = jobs[i];
+        DTC_REQUIRE(h.W && h.img && dtc::aligned16(h.img) && h.nr > 0 && h.r0 >= 0 && h.ld > 0 && h.nseg >= 1 && h.nseg <= 4, "job %d: null pointer / bad shape", i);
+        WpackJob& J = G.job[G.count];
+        J.W = h.W;
+        J.ld = h.ld;
+        J.img = (u32x4*)h.img;
+        J.trans = h.trans;
+        J.r0 = h.r0;
+        J.nr = h.nr;
+        J.nseg = h.nseg;
+        J.tstages = J.tblocks = 0;
+        for (int k = 0; k < 4; ++k) {
+            J.c0[k] = k < h.nseg ? h.c0[k] : 0;
+            J.cw[k] = k < h.nseg ? h.cw[k] : 0;
+            if (k < h.nseg) {
+                DTC_REQUIRE(h.cw[k] > 0 && h.c0[k] >= 0, "job %d: bad reduction range %d", i, k);
+                J.tstages += (int)hi_stages(h.cw[k]);
+                J.tblocks += (int)hi_kblocks(h.cw[k]);
+            }
+        }
+        DTC_REQUIRE(J.tblocks <= MAX_TB, "job %d: %d exponent blocks along the reduction, at most %d", i, J.tblocks, MAX_TB);
+        const long long ct = dtc::ceil_div(h.nr, 128);
+        DTC_REQUIRE(ct * J.tstages * HI_CHUNK < (1ll << 31), "job %d: image beyond 2 GiB", i);
+        J.exps = reinterpret_cast<int*>(reinterpret_cast<char*>(h.img) + ct * J.tstages * HI_CHUNK);
+        J.block_end = (int)(ct * J.tblocks) + (G.count > 0 ? G.job[G.count - 1].block_end : 0);
+        if (++G.count == WP_MAX_JOBS) flush();
+    }
+    flush();
+    return dtc::check_launch("h2i_wimage_group");
+}
+
+// Y = act(X W^T + b): X = images side by side, wimg = the image of W built for that walk (trans = 0, r0 = 0, nr = N, the operand's widths
+// as reduction ranges).  Results: fp32 Y [M, >= N] (may be NULL) and / or the image of Y (Yimg = image(M, N), may be NULL) -- at least one.
+extern "C" int dtc_linear_fwd_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, float* Y, int64_t ldy, void* Yimg,
+                                  uint16_t* relu_mask, int M, int N, int act, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && (Y == nullptr || ldy >= N), "bad shape M=%d N=%d ldy=%lld", M, N, (long long)ldy);
+    DTC_REQUIRE((Y || Yimg) && dtc::aligned16(Yimg), "no result / unaligned image");
+    DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
+    int rc = check_img(wimg, "dtc_linear_fwd_h2i: weight image");
+    if (rc != DTC_OK) return rc;
+    HOperand A;
+    int K;
+    rc = to_operand(X, M, A, K);
+    if (rc != DTC_OK) return rc;
+    DTC_REQUIRE((long long)M * (ldy > N ? ldy : N) <= MAX_ELEMS * 4 && hi_bytes(M, N) < (1ll << 31), "matrix too large");
+    if (relu_mask) DTC_REQUIRE(act == DTC_ACT_RELU && M % BM == 0 && N % 128 == 0, "sign record: M=%d and N=%d must be multiples of 128", M, N);
+    const WimgView wv = wimg_view(wimg, N, A);
+    hipStream_t s = (hipStream_t)stream;
+    const int wide = (Y && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s,
+                        4.0 * M * (double)K + 4.0 * N * (double)K + (Y ? 4.0 : 0.0) * M * N + (Yimg ? 4.0 : 0.0) * M * N);
+    hipLaunchKernelGGL((linear_h2i_kernel<EPI_FWD>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, A,
+                       wv.img, wv.bytes, wv.exps, b, Y, (long long)ldy, to_out(Yimg, M, N), M, N, act, wide, (unsigned short*)relu_mask, N,
+                       DgradEpiH{}, MseEpiH{});
+    return dtc::check_launch("linear_fwd_h2i");
+}
+
+extern "C" int64_t dtc_linear_fwd_mse_h2i_parts(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128));
+}
+
+// the layer fused with its MSE against target[tidx[row], tcol0 + col] (dtc_linear_fwd_mse): dL/dY = (Y - target) * scale as fp32 (dY, may
+// be NULL) and / or as an image (dYimg); sq_part: dtc_linear_fwd_mse_h2i_parts(M, N) doubles (partials of sum (Y - target)^2)
+extern "C" int dtc_linear_fwd_mse_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, const float* target, int64_t ldt,
+                                      int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy, void* dYimg,
+                                      double* sq_part, int M, int N, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && (dY == nullptr || lddy >= N), "bad shape M=%d N=%d", M, N);
+    DTC_REQUIRE(target && tidx && (dY || dYimg) && sq_part && dtc::aligned16(dYimg), "null / unaligned pointer");
+    DTC_REQUIRE(tcol0 >= 0 && tcol0 + N <= ldt && target_rows > 0, "target columns [%d, %d) outside its %lld-wide rows", tcol0, tcol0 + N, (long long)ldt);
+    DTC_REQUIRE(target_rows * ldt <= MAX_ELEMS && hi_bytes(M, N) < (1ll << 31), "matrix too large");
+    int rc = check_img(wimg, "dtc_linear_fwd_mse_h2i: weight image");
+    if (rc != DTC_OK) return rc;
+    HOperand A;
+    int K;
+    rc = to_operand(X, M, A, K);
+    if (rc != DTC_OK) return rc;
+    const WimgView wv = wimg_view(wimg, N, A);
+    hipStream_t s = (hipStream_t)stream;
+    const MseEpiH mse{target, (const long long*)tidx, (long long)ldt, target_rows * ldt * 4, tcol0, scale, sq_part};
+    const int wide = (dY && lddy % 4 == 0 && dtc::aligned16(dY)) ? 1 : 0;
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s,
+                        4.0 * M * (double)K + 4.0 * N * (double)K + 4.0 * M * N + (dY ? 4.0 : 0.0) * M * N + (dYimg ? 4.0 : 0.0) * M * N);
+    hipLaunchKernelGGL((linear_h2i_kernel<EPI_MSE>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, A,
+                       wv.img, wv.bytes, wv.exps, b, dY, (long long)lddy, to_out(dYimg, M, N), M, N, (int)DTC_ACT_NONE, wide,
+                       (unsigned short*)nullptr, 0, DgradEpiH{}, mse);
+    return dtc::check_launch("linear_fwd_mse_h2i");
+}
+
+// dX[:, window] = (dZ W[:, window]) * act'(.): dZ = image(M, N); wimgT = the image of W^T built for the window (trans = 1, r0 = first
+// column of the window, nr = Kwin, one reduction range (0, N)).  Results over the window: fp32 destination blocks dX (may be NULL;
+// accumulate flags honoured) and / or the image dXimg = image(M, Kwin).  add (may be NULL): fp32 [M, ld_add] added to the product first.
+// Activation derivative: relu_mask (sign record) or Xsaved with act; both need the window to start at the saved tensor's column 0.
+extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT, int Kwin, const DtcSegMat* dX, void* dXimg, const float* add,
+                                    int64_t ld_add, const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, int M, int act, void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && Kwin > 0, "bad shape");
+    DTC_REQUIRE((dX || dXimg) && dtc::aligned16(dXimg), "no result / unaligned image");
+    DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
+    DTC_REQUIRE(relu_mask || act == DTC_ACT_NONE || (Xsaved != nullptr && ldxs >= Kwin), "activation derivative needs Xsaved");
+    DTC_REQUIRE(add == nullptr || ld_add >= Kwin, "bad ld_add");
+    int rc = check_img(dZimg, "dtc_linear_dgrad_h2i: dZ");
+    if (rc != DTC_OK) return rc;
+    rc = check_img(wimgT, "dtc_linear_dgrad_h2i: weight image");
+    if (rc != DTC_OK) return rc;
+    if (relu_mask) DTC_REQUIRE(M % BM == 0 && Kwin % 128 == 0, "sign record: M=%d and the window %d must be multiples of 128", M, Kwin);
+    DTC_REQUIRE(hi_bytes(M, Kwin) < (1ll << 31), "matrix too large");
+    DtcH2iOperand zo{};
+    zo.nseg = 1;
+    zo.img[0] = dZimg;
+    zo.width[0] = N;
+    HOperand A;
+    int nn;
+    rc = to_operand(&zo, M, A, nn);
+    if (rc != DTC_OK) return rc;
+    DgradEpiH dg{};
+    if (dX) {
+        rc = to_dev(dX, dg.dX, Kwin, true, 0);
+        if (rc != DTC_OK) return rc;
+        dg.has_dx = 1;
+        for (int i = 0; i < dg.dX.nseg; ++i) {
+            const SegDev& sd = dg.dX.s[i];
+            if (sd.ptr == nullptr || (dtc::aligned16(sd.ptr) && (sd.ld & 3) == 0)) dg.wide_segs |= 1 << i;
+        }
+    }
+    dg.add = add;
+    dg.ld_add = ld_add;
+    dg.Xs = relu_mask ? nullptr : Xsaved;
+    dg.ldxs = ldxs;
+    dg.rmask = (const unsigned short*)relu_mask;
+    dg.ldm = Kwin;
+    const int wide = ((dg.Xs && ldxs % 4 == 0 && dtc::aligned16(dg.Xs)) ? 2 : 0) | ((add && ld_add % 4 == 0 && dtc::aligned16(add)) ? 4 : 0);
+    const WimgView wv = wimg_view(wimgT, Kwin, A);
+    hipStream_t s = (hipStream_t)stream;
+    double bytes = 4.0 * M * (double)N + 4.0 * N * (double)Kwin + (dXimg ? 4.0 : 0.0) * M * Kwin + (add ? 4.0 : 0.0) * M * Kwin;
+    if (dX)
+        for (int i = 0; i < dg.dX.nseg; ++i)
+            if (dg.dX.s[i].ptr) bytes += 4.0 * M * dg.dX.s[i].width * (dg.dX.s[i].accumulate ? 2.0 : 1.0);
+    if (relu_mask) bytes += 0.125 * M * (double)Kwin;
+    else if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)Kwin;
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, Kwin), 2.0 * M * (double)N * Kwin, s, bytes);
+    hipLaunchKernelGGL((linear_h2i_kernel<EPI_DGRAD>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(Kwin, 128))), dim3(256), 0, s, A,
+                       wv.img, wv.bytes, wv.exps, (const float*)nullptr, (float*)nullptr, 0ll, to_out(dXimg, M, Kwin), M, Kwin,
+                       relu_mask ? (int)DTC_ACT_RELU : act, wide, (unsigned short*)nullptr, 0, dg, MseEpiH{});
+    return dtc::check_launch("linear_dgrad_h2i");
+}

@@ -54,6 +54,20 @@ class DtcWgradImgJob(C.Structure):
     _fields_ = [("dZimg", C.c_void_p), ("Ximg", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32)]
 
 
+class DtcH2iWJob(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("ld", C.c_int64), ("img", C.c_void_p), ("trans", C.c_int32), ("r0", C.c_int32), ("nr", C.c_int32),
+                ("nseg", C.c_int32), ("c0", C.c_int32 * 4), ("cw", C.c_int32 * 4)]
+
+
+class DtcH2iOperand(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("width", C.c_int32 * 4), ("img", C.c_void_p * 4)]
+
+
+class DtcWgradH2iJob(C.Structure):
+    _fields_ = [("dZimg", C.c_void_p), ("Ximg", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("ldw", C.c_int64),
+                ("N", C.c_int32), ("K", C.c_int32), ("wcol0", C.c_int32)]
+
+
 class DtcPpoCfg(C.Structure):
     _fields_ = [("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float),
                 ("desired_kl", C.c_float), ("use_clipped_value_loss", C.c_int32),
@@ -80,7 +94,7 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 9          # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 10         # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
@@ -139,6 +153,20 @@ _SIGS = {
                                       C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_wgrad_group_i3_workspace": (C.c_int64, [C.POINTER(DtcWgradImgJob), C.c_int, C.c_int]),
     "dtc_wgrad_group_i3": (C.c_int, [C.POINTER(DtcWgradImgJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "dtc_h2i_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "dtc_h2i_pack": (C.c_int, [C.POINTER(DtcSegMat), C.c_int, C.c_void_p, c_stream]),
+    "dtc_h2i_unpack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, C.c_int64, c_stream]),
+    "dtc_h2i_wimage_bytes": (C.c_int64, [C.POINTER(DtcH2iWJob)]),
+    "dtc_h2i_wimage_group": (C.c_int, [C.POINTER(DtcH2iWJob), C.c_int, c_stream]),
+    "dtc_linear_fwd_h2i": (C.c_int, [C.POINTER(DtcH2iOperand), C.c_void_p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, c_stream]),
+    "dtc_linear_fwd_mse_h2i_parts": (C.c_int64, [C.c_int, C.c_int]),
+    "dtc_linear_fwd_mse_h2i": (C.c_int, [C.POINTER(DtcH2iOperand), C.c_void_p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, c_i64p, C.c_float,
+                                         c_f32p, C.c_int64, C.c_void_p, c_f64p, C.c_int, C.c_int, c_stream]),
+    "dtc_linear_dgrad_h2i": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(DtcSegMat), C.c_void_p, c_f32p, C.c_int64, c_f32p,
+                                       C.c_int64, C.c_void_p, C.c_int, C.c_int, c_stream]),
+    "dtc_wgrad_group_h2i_workspace": (C.c_int64, [C.POINTER(DtcWgradH2iJob), C.c_int, C.c_int]),
+    "dtc_wgrad_group_h2i": (C.c_int, [C.POINTER(DtcWgradH2iJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_amax_record_bytes": (C.c_int64, []),
     "dtc_amax": (C.c_int, [C.POINTER(DtcSegMat), C.c_int, C.c_void_p, c_stream]),
     "dtc_h2_wimage_group": (C.c_int, [C.POINTER(DtcWimgJob), C.c_int, c_stream]),
@@ -236,7 +264,8 @@ def _check_abi(l):
     """The loaded library must be the revision this binding describes: same ABI version, same by-value struct layouts
     (DTC_LIB may point at a separately built library, e.g. the ASan build: a stale one would misread every descriptor)."""
     global _lib
-    mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcWgradImgJob]
+    mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcWgradImgJob, DtcH2iWJob,
+            DtcH2iOperand, DtcWgradH2iJob]
     sizes = (C.c_int64 * 16)()
     n = l.dtc_abi_sizes(sizes, 16)
     theirs = list(sizes[:n])

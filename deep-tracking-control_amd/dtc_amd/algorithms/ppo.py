@@ -24,7 +24,7 @@ import os
 
 import torch
 
-from .. import _ffi, distributed as dp, ops, tracing
+from .. import _ffi, distributed as dp, h2i, ops, tracing
 from .._ffi import seg, segmat
 from ..modules.actor_critic_decoder import AC_Args, ActorCriticDecoder
 from ..storage import RolloutStorage
@@ -200,12 +200,13 @@ class _TrainWorkspace(_Lanes):
         self.pending, self.held = [], []      # queued weight-gradient jobs; operands of flushed jobs (alive until the join)
         self.pending_img = []                 # queued weight-gradient jobs whose operands are activation images
         self._imgs, self.live_img = {}, set()
+        self.narrow_wgrad = False             # the step in flight runs the image chain: its fp32 weight-gradient jobs are the narrow layers
 
     def img(self, name, width=None):
-        """Activation image (ops.AImage) of the [B, width] activation / gradient `name`, allocated on first use."""
+        """Operand image (h2i.HImage) of the [B, width] activation / gradient `name`, allocated on first use."""
         im = self._imgs.get(name)
         if im is None:
-            im = self._imgs[name] = ops.AImage(self.B, width, self._dev)
+            im = self._imgs[name] = h2i.HImage(self.B, width, self._dev)
         return im
 
     def value(self, name):
@@ -213,7 +214,7 @@ class _TrainWorkspace(_Lanes):
         return self._imgs[name].to_tensor() if name in self.live_img else getattr(self, name)
 
     def group_ws_img(self, jobs):
-        need = ops.wgrad_group_img_workspace_bytes(jobs, self.B)
+        need = h2i.wgrad_group_workspace_bytes(jobs, self.B)
         if self.gws_img is None or self.gws_img.numel() * self.gws_img.element_size() < need:
             torch.cuda.synchronize()
             self.gws_img = ops.workspace(need, self._dev)
@@ -221,9 +222,9 @@ class _TrainWorkspace(_Lanes):
 
     MAX_GROUP = 12           # jobs per grouped weight-gradient launch (MAX_JOBS of csrc/wgrad.hip)
 
-    def group_ws(self, jobs):
+    def group_ws(self, jobs, split=None):
         """Partial-slab workspace of a grouped weight-gradient launch, grown on demand."""
-        need = ops.wgrad_group_workspace_bytes(jobs, self.B)
+        need = ops.wgrad_group_workspace_bytes(jobs, self.B, split)
         if self.gws is None or self.gws.numel() * self.gws.element_size() < need:
             torch.cuda.synchronize()            # nothing may still be reading the buffer being replaced
             self.gws = ops.workspace(need, self._dev)
@@ -298,8 +299,10 @@ class PPO:
         # 4-byte activation (DTC_RELU_MASK=0: derivative through the saved activations; bit-identical results)
         self.relu_masks = os.environ.get("DTC_RELU_MASK", "1") != "0"
         self.pack_inputs = os.environ.get("DTC_PACK_INPUTS", "1") != "0"
-        # hidden activations / gradients of the wide stacks as activation images (ops.AImage; DTC_IMAGES=0: fp32 everywhere)
-        self.use_images = ops.IMAGES
+        # the wide stacks on operand images (dtc_amd/h2i.py: activations / gradients live in HBM as the fp16 (hi, lo) planes the GEMM
+        # kernels read by LDS-DMA, per-row exponents, written once by the producing epilogue); DTC_H2I=0: round 4's converting kernels
+        self.use_images = os.environ.get("DTC_H2I", "1") != "0"
+        self._wsets = {}                   # phase -> h2i.WeightSet (weight images, one grouped launch per phase)
         # tests: callable(fw, which) run between the forward and the backward pass of a step ("vae" | "ppo"); the parity tests
         # use it to teacher-force the ReLU sign records (fw.relu_mask buffers) so that fp32 knife edges -- pre-activations that
         # are 0 within rounding and land on different sides in two correct implementations -- do not enter the gradient comparison
@@ -460,24 +463,29 @@ class PPO:
             ops.lr_adapt(kl, self.optimizer.lr_dev, float(self.desired_kl))
 
     def _image_mode(self, fw):
-        """This step keeps the wide hidden activations / gradients as images (see ActorCriticDecoder.images_ok)."""
+        """This step runs the wide stacks on operand images (see ActorCriticDecoder.images_ok)."""
         return (self.use_images and self.relu_masks and self.group_wgrad and self.fuse_height_loss and self.actor_critic.images_ok(fw)
                 and fw.relu_mask("t1", 512) is not None)
 
-    def _bwd_img(self, tw, L, dZimg, Ximg, dX=None, dXimg=None, accumulate=False, Xsaved=None, act_prev=None, mask=None):
-        """_bwd for a layer whose output gradient dZ and input X are activation images: the weight gradient is queued for the
-        bucket's image-operand grouped launch, the data gradient (fp32 `dX` and / or image `dXimg`) runs on the image-operand kernel."""
-        tw.pending_img.append((dZimg, Ximg, L.gW, L.gb))
+    def _wset(self, phase):
+        ws = self._wsets.get(phase)
+        if ws is None:
+            ws = self._wsets[phase] = h2i.WeightSet()
+        return ws
+
+    def _bwd_img(self, tw, L, dZimg, Ximg, wcol0=0, bias=True):
+        """The weight gradient of a layer (or of the column block of it that meets operand image Ximg) whose operands are images:
+        queued for the bucket's image-operand grouped launch."""
+        tw.pending_img.append((dZimg, Ximg, L.gW, wcol0, L.gb if bias else None))
         if len(tw.pending_img) == tw.MAX_GROUP:
             self._flush_wgrads(tw)
-        if dX is not None or dXimg is not None:
-            ops.linear_dgrad_img(dZimg, L.W, dX, dXimg, accumulate=accumulate, Xsaved=Xsaved, act=act_prev, mask=mask)
 
-    def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None, mask=None, dXimg=None, img_seg=0):
-        """Backward of one dense layer.  The weight gradient (dW = dZ^T X) is off the critical path -- only the
+    def _bwd(self, tw, L, dZ, X, dX=None, Xsaved=None, act_prev=None, mask=None, split=None):
+        """Backward of one dense layer on fp32 operands.  The weight gradient (dW = dZ^T X) is off the critical path -- only the
         optimiser step (and the data-parallel exchange) needs it -- so it is QUEUED: `_flush_wgrads` runs all queued
         layers of a gradient bucket as one grouped launch on the side stream, where it overlaps with the data-gradient
-        chain of the layers below.  (DTC_WGRAD_GROUP=0: one launch pair per layer, issued right here.)"""
+        chain of the layers below.  (DTC_WGRAD_GROUP=0: one launch pair per layer, issued right here.)  `split=False`: the
+        single-pass fp32 kernels whatever the layer's shape (the narrow layers beside the operand-image chain)."""
         if self.group_wgrad:
             tw.pending.append((dZ, X, L.gW, L.gb))
             if len(tw.pending) == tw.MAX_GROUP:
@@ -491,16 +499,17 @@ class PPO:
         else:
             ops.linear_wgrad(dZ, X, L.gW, L.gb, tw.wgrad_ws(L.n_out, L.n_in), M=tw.B)
         if dX is not None:
-            ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B, mask=mask, dXimg=dXimg, img_seg=img_seg)
+            ops.linear_dgrad(dZ, L.W, dX, Xsaved, act_prev, M=tw.B, mask=mask, split=split)
 
     def _flush_wgrads(self, tw):
         """Launch the queued weight gradients (everything both compute lanes have issued so far is their input): one grouped
-        launch for the layers with fp32 operands, one for the layers whose operands are activation images."""
+        launch for the layers whose operands are images, one for the (narrow) layers with fp32 operands."""
         if not tw.pending and not tw.pending_img:
             return
         jobs, tw.pending = tw.pending, []
         jobs_img, tw.pending_img = tw.pending_img, []
-        ws = tw.group_ws(jobs) if jobs else None
+        narrow = tw.narrow_wgrad                               # image chain: the fp32 jobs are the narrow layers -> single-pass kernels
+        ws = tw.group_ws(jobs, False if narrow else None) if jobs else None
         ws_img = tw.group_ws_img(jobs_img) if jobs_img else None
         sp = None
         if self.overlap_wgrad:
@@ -512,37 +521,40 @@ class PPO:
             sp = tw.side.cuda_stream
             tw.side_busy = True
         if jobs_img:
-            tw.held.append(ops.wgrad_group_img(jobs_img, tw.B, ws_img, stream_ptr=sp))
+            tw.held.append(h2i.wgrad_group(jobs_img, tw.B, ws_img, stream_ptr=sp))
         if jobs:
-            tw.held.append(ops.wgrad_group(jobs, tw.B, ws, stream_ptr=sp))
+            tw.held.append(ops.wgrad_group(jobs, tw.B, ws, stream_ptr=sp, split=False if narrow else None))
 
     def _join(self, tw):
         self._flush_wgrads(tw)
+        tw.narrow_wgrad = False
         tw.join()
         tw.held.clear()
 
-    def _terrain_encoder_backward(self, fw, tw, flat, idx):
+    def _terrain_encoder_backward(self, fw, tw, flat, idx, wset=None):
         L = self.actor_critic.L
-        g_te2, g_te1 = tw.g("te2", 512), tw.g("te1", 512)
         rm = self.relu_masks
         if "dlt" in tw.live_img and {"t1", "t2"} <= fw.live_img:
-            # image chain: d l_t arrived as an image (the decoders' / the actor's data gradient wrote it), t1 / t2 are images; the
-            # first layer's input are the gathered fp32 heights, so its output gradient leaves as fp32
-            g_te2i = tw.img("g_te2", L["te2"].n_in)
-            self._bwd_img(tw, L["te2"], tw.img("dlt"), fw.img("t2"), dXimg=g_te2i, mask=fw.relu_mask("t2", 512, rm))
-            self._bwd_img(tw, L["te1"], g_te2i, fw.img("t1"), dX=g_te1, mask=fw.relu_mask("t1", 512, rm))
-            self._bwd(tw, L["te0"], g_te1, segmat([seg(flat["privileged_observations"], 0, 693, gather=True)], idx))
-            tw.live_img |= {"g_te2"}
+            # image chain: d l_t arrived as an image (the decoders' / the actor's data gradient wrote it), t1 / t2 and the packed
+            # heights are images; nothing of this chain exists as fp32
+            g_te2i, g_te1i = tw.img("g_te2", L["te2"].n_in), tw.img("g_te1", L["te1"].n_in)
+            self._bwd_img(tw, L["te2"], tw.img("dlt"), fw.img("t2"))
+            h2i.linear_dgrad(tw.img("dlt"), L["te2"].W, None, g_te2i, mask=fw.relu_mask("t2", 512, rm), wset=wset)
+            self._bwd_img(tw, L["te1"], g_te2i, fw.img("t1"))
+            h2i.linear_dgrad(g_te2i, L["te1"].W, None, g_te1i, mask=fw.relu_mask("t1", 512, rm), wset=wset)
+            self._bwd_img(tw, L["te0"], g_te1i, fw.img("p_te"))
+            tw.live_img |= {"g_te2", "g_te1"}
             return
+        g_te2, g_te1 = tw.g("te2", 512), tw.g("te1", 512)
         self._bwd(tw, L["te2"], tw.dlt, fw.t2, g_te2, fw.t2, "relu", fw.relu_mask("t2", 512, rm))
         self._bwd(tw, L["te1"], g_te2, fw.t1, g_te1, fw.t1, "relu", fw.relu_mask("t1", 512, rm))
         self._bwd(tw, L["te0"], g_te1, segmat([seg(flat["privileged_observations"], 0, 693, gather=True)], idx))
 
-    def _cenet_encoder_backward(self, fw, tw, flat, idx):
+    def _cenet_encoder_backward(self, fw, tw, flat, idx, split=None):
         L = self.actor_critic.L
         g_head, g_ce1 = tw.g("head", 64), tw.g("ce1", 128)
-        self._bwd(tw, L["head"], tw.dmulv, fw.e, g_head, None, None)
-        self._bwd(tw, L["ce1"], g_head, fw.e1, g_ce1, fw.e1, "relu", fw.relu_mask("e1", 128, self.relu_masks))
+        self._bwd(tw, L["head"], tw.dmulv, fw.e, g_head, None, None, split=split)
+        self._bwd(tw, L["ce1"], g_head, fw.e1, g_ce1, fw.e1, "relu", fw.relu_mask("e1", 128, self.relu_masks), split=split)
         self._bwd(tw, L["ce0"], g_ce1, segmat([seg(flat["observation_histories"], 0, flat["observation_histories"].shape[1],
                                                    gather=True)], idx))
 
@@ -555,8 +567,7 @@ class PPO:
         ac = self.actor_critic
         L = ac.L
         _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap_wgrad)))     # weight gradients on the side stream
-        with self._images("vae"):                                  # weight images of the step's split-path layers: one launch
-            early = self._vae_forward_backward(fw, tw, flat, idx, eps, stats)
+        early = self._run_phase("vae", fw, tw, self._vae_forward_backward, flat, idx, eps, stats)
         if not early:
             self._allreduce_grads(self.vae_optimizer)
         if self.capture_grads:
@@ -571,26 +582,39 @@ class PPO:
             self._wimages[phase] = ops.WeightImages()
         return self._wimages[phase]
 
-    def _vae_forward_backward(self, fw, tw, flat, idx, eps, stats):
+    def _run_phase(self, phase, fw, tw, body, *args):
+        """Forward + backward of one optimisation step.  Image chain: the phase's weight images are rebuilt by one grouped launch in
+        front of the lanes' fork (the optimiser wrote the weights since they were last built); nothing else is kept on the host.
+        Otherwise: round 4's converting kernels inside their ops.WeightImages block."""
+        tw.narrow_wgrad = self._image_mode(fw)
+        if tw.narrow_wgrad:
+            wset = self._wset(phase)
+            wset.rebuild()
+            return body(fw, tw, *args, wset)
+        with self._images(phase):
+            return body(fw, tw, *args, None)
+
+    def _vae_forward_backward(self, fw, tw, flat, idx, eps, stats, wset=None):
         ac = self.actor_critic
         L = ac.L
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
         dec_in = segmat([seg(fw.z, 0, 16), seg(fw.mulv, 0, 3), seg(fw.lt, 0, 512)])
         rm = self.relu_masks
-        im = self._image_mode(fw)
+        im = wset is not None                                      # operand-image chain for the 512-wide stacks
+        ns = False if im else None                                 # ... beside it the narrow layers run on the single-pass fp32 kernels
         tw.live_img.clear()
         with tw.lane("aux"):
-            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=rm)
-        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=rm, images=im, lt_img=im)
+            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=rm, split=ns)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=rm, images=im, wset=wset)
         tw.order("main", "aux")                                    # l_t feeds the CE-net decoder
         with tw.lane("aux"):
-            ops.linear_fwd(dec_in, L["cd0"].W, L["cd0"].b, tw.c1, "relu", M=tw.B, mask=fw.relu_mask("c1", 64, rm))
-            ops.linear_fwd(tw.c1, L["cd1"].W, L["cd1"].b, tw.c2, "relu", mask=fw.relu_mask("c2", 128, rm))
-            ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None)
+            ops.linear_fwd(dec_in, L["cd0"].W, L["cd0"].b, tw.c1, "relu", M=tw.B, mask=fw.relu_mask("c1", 64, rm), split=ns)
+            ops.linear_fwd(tw.c1, L["cd1"].W, L["cd1"].b, tw.c2, "relu", mask=fw.relu_mask("c2", 128, rm), split=ns)
+            ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None, split=ns)
         if im:                                                     # terrain decoder on images: d1 / d2 never exist as fp32
             d1i, d2i = tw.img("d1", L["td0"].n_out), tw.img("d2", L["td1"].n_out)
-            ops.linear_fwd_img(fw.img("lt"), L["td0"].W, L["td0"].b, None, d1i, "relu", mask=fw.relu_mask("d1", 512, rm))
-            ops.linear_fwd_img(d1i, L["td1"].W, L["td1"].b, None, d2i, "relu", mask=fw.relu_mask("d2", 512, rm))
+            h2i.linear_fwd(fw.img("lt"), L["td0"].W, L["td0"].b, None, d1i, "relu", mask=fw.relu_mask("d1", 512, rm), wset=wset)
+            h2i.linear_fwd(d1i, L["td1"].W, L["td1"].b, None, d2i, "relu", mask=fw.relu_mask("d2", 512, rm), wset=wset)
             tw.live_img |= {"d1", "d2"}
         else:
             ops.linear_fwd(fw.lt, L["td0"].W, L["td0"].b, tw.d1, "relu", mask=fw.relu_mask("d1", 512, rm))
@@ -604,8 +628,8 @@ class PPO:
             # output layer of the terrain decoder + its MSE against priv[..., 696:] in one kernel: dL/d height_recon comes
             # out of the GEMM epilogue, height_recon itself never reaches HBM
             if im:                                                 # dL/d height_recon leaves as an image only (its two consumers read images)
-                n_hp = ops.linear_fwd_mse_img(tw.img("d2"), L["td2"].W, L["td2"].b, flat["privileged_observations"], 696, idx, None,
-                                              tw.img("g_hr", L["td2"].n_out), tw.hpart)
+                n_hp = h2i.linear_fwd_mse(tw.img("d2"), L["td2"].W, L["td2"].b, flat["privileged_observations"], 696, idx, None,
+                                          tw.img("g_hr", L["td2"].n_out), tw.hpart, wset=wset)
                 tw.live_img |= {"g_hr"}
             else:
                 n_hp = ops.linear_fwd_mse(tw.d2, L["td2"].W, L["td2"].b, flat["privileged_observations"], 696, idx, tw.g_hr, tw.hpart)
@@ -626,29 +650,32 @@ class PPO:
         g_cd2, g_cd1 = tw.g("cd2", 128), tw.g("cd1", 64)
         dst = segmat([seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3, accumulate=True), seg(tw.dlt, 0, 512)])
         with tw.lane("aux"):
-            self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu", fw.relu_mask("c2", 128, rm))
-            self._bwd(tw, L["cd1"], g_cd2, tw.c1, g_cd1, tw.c1, "relu", fw.relu_mask("c1", 64, rm))
-            self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None)
+            self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu", fw.relu_mask("c2", 128, rm), split=ns)
+            self._bwd(tw, L["cd1"], g_cd2, tw.c1, g_cd1, tw.c1, "relu", fw.relu_mask("c1", 64, rm), split=ns)
+            self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None, split=ns)
         # terrain decoder (main)
-        g_td2, g_td1 = tw.g("td2", 512), tw.g("td1", 512)
         if im:
             g_td2i, g_td1i = tw.img("g_td2", L["td2"].n_in), tw.img("g_td1", L["td1"].n_in)
-            self._bwd_img(tw, L["td2"], tw.img("g_hr"), tw.img("d2"), dXimg=g_td2i, mask=fw.relu_mask("d2", 512, rm))
-            self._bwd_img(tw, L["td1"], g_td2i, tw.img("d1"), dXimg=g_td1i, mask=fw.relu_mask("d1", 512, rm))
-            tw.order("aux", "main")                                # d l_t of the CE-net decoder is written first
-            # ... read (fp32), added to, and the sum leaves as the image the terrain encoder's backward reads
-            self._bwd_img(tw, L["td0"], g_td1i, fw.img("lt"), dX=tw.dlt, dXimg=tw.img("dlt", L["td0"].n_in), accumulate=True)
+            self._bwd_img(tw, L["td2"], tw.img("g_hr"), tw.img("d2"))
+            h2i.linear_dgrad(tw.img("g_hr"), L["td2"].W, None, g_td2i, mask=fw.relu_mask("d2", 512, rm), wset=wset)
+            self._bwd_img(tw, L["td1"], g_td2i, tw.img("d1"))
+            h2i.linear_dgrad(g_td2i, L["td1"].W, None, g_td1i, mask=fw.relu_mask("d1", 512, rm), wset=wset)
+            tw.order("aux", "main")                                # d l_t of the CE-net decoder is written first (fp32) ...
+            # ... and added to this layer's product; the sum leaves as the image the terrain encoder's backward reads
+            self._bwd_img(tw, L["td0"], g_td1i, fw.img("lt"))
+            h2i.linear_dgrad(g_td1i, L["td0"].W, None, tw.img("dlt", L["td0"].n_in), add=tw.dlt, wset=wset)
             tw.live_img |= {"g_td2", "g_td1", "dlt"}
         else:
+            g_td2, g_td1 = tw.g("td2", 512), tw.g("td1", 512)
             self._bwd(tw, L["td2"], tw.g_hr, tw.d2, g_td2, tw.d2, "relu", fw.relu_mask("d2", 512, rm))
             self._bwd(tw, L["td1"], g_td2, tw.d1, g_td1, tw.d1, "relu", fw.relu_mask("d1", 512, rm))
             tw.order("aux", "main")                                # d l_t of the CE-net decoder is written first
             self._bwd(tw, L["td0"], g_td1, fw.lt, segmat([seg(tw.dlt, 0, 512, accumulate=True)]), None, None)
         early = self._exchange_bucket(tw, "vae_only")              # decoder gradients are complete (queued on `side`)
-        self._terrain_encoder_backward(fw, tw, flat, idx)
+        self._terrain_encoder_backward(fw, tw, flat, idx, wset)
         with tw.lane("aux"):
             ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
-            self._cenet_encoder_backward(fw, tw, flat, idx)
+            self._cenet_encoder_backward(fw, tw, flat, idx, split=ns)
         if early:
             self._exchange_bucket(tw, "shared")
         self._join(tw)
@@ -661,8 +688,7 @@ class PPO:
         L = ac.L
         act = AC_Args.activation
         _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap_wgrad)))     # weight gradients on the side stream
-        with self._images("ppo"):
-            early = self._ppo_forward_backward(fw, tw, flat, idx, eps, stats, cfg)
+        early = self._run_phase("ppo", fw, tw, self._ppo_forward_backward, flat, idx, eps, stats, cfg)
         if not early:
             self._allreduce_grads(self.optimizer)
         self._lr_from_header(stats)
@@ -670,32 +696,40 @@ class PPO:
             self.captured["main"] = ac.arena.grad.clone()
         self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])
 
-    def _ppo_forward_backward(self, fw, tw, flat, idx, eps, stats, cfg):
+    def _ppo_forward_backward(self, fw, tw, flat, idx, eps, stats, cfg, wset=None):
         ac = self.actor_critic
         L = ac.L
         act = AC_Args.activation
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
-        im = self._image_mode(fw)
+        im = wset is not None                                      # operand-image chain for the wide stacks
+        ns = False if im else None
         tw.live_img.clear()
+        obs, priv = flat["observations"], flat["privileged_observations"]
         with tw.lane("aux"):
-            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=self.relu_masks)
-        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=self.relu_masks, images=im)
+            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=self.relu_masks, split=ns)
+        ac.terrain_encoder_(fw, priv, idx, masks=self.relu_masks, images=im, wset=wset, lt_fp32=not im)
         tw.order("aux", "main")                                    # z, mu feed the actor
         # output layers + losses + their data gradients in one launch when the last hidden width allows it (DTC_FUSE_HEADS)
         # (its partial-sum workspace holds 4096 blocks of 64 rows: larger mini-batches take the unfused kernels)
         fuse = self.fuse_heads and fw.a3.shape[1] == fw.v3.shape[1] and fw.a3.shape[1] in (64, 128, 256) and tw.B <= 4096 * 64
-        # the narrow leading blocks of both layer-0 inputs packed into dense operands (DTC_PACK_INPUTS=0: four / three segments)
-        if self.pack_inputs:
+        a_cols = None
+        if im:
+            # layer-0 inputs as operand images: the critic's whole input (gathered rollout rows) is packed once; the actor's is the
+            # l_t image the terrain encoder just wrote + the packed narrow block [obs | z | mu[:, :3]] (W's columns 72.. and 0..71)
             with tw.lane("aux"):
-                Xc = ac.critic_input_packed(flat["observations"], flat["base_vel"], flat["privileged_observations"], idx,
-                                            tw.g("pack_c", ac.num_obs + 3), tw.B)
-            Xa = ac.actor_input_packed(fw, flat["observations"], idx, tw.g("pack_a", ac.num_obs + 19))
+                Xc = ac.packed_input(fw, "p_c", ac.critic_input(obs, flat["base_vel"], priv, idx), None)
+            Xa = [fw.img("lt"), ac.packed_input(fw, "p_a", segmat([seg(obs, 0, ac.num_obs, gather=True), seg(fw.z, 0, 16), seg(fw.mulv, 0, 3)], idx), None)]
+            a_cols = [ac.num_obs + 19, 0]
+        elif self.pack_inputs:                                     # the narrow leading blocks of both layer-0 inputs packed into dense operands
+            with tw.lane("aux"):
+                Xc = ac.critic_input_packed(obs, flat["base_vel"], priv, idx, tw.g("pack_c", ac.num_obs + 3), tw.B)
+            Xa = ac.actor_input_packed(fw, obs, idx, tw.g("pack_a", ac.num_obs + 19))
         else:
-            Xc = ac.critic_input(flat["observations"], flat["base_vel"], flat["privileged_observations"], idx)
-            Xa = ac.actor_input(fw, flat["observations"], idx)
+            Xc = ac.critic_input(obs, flat["base_vel"], priv, idx)
+            Xa = ac.actor_input(fw, obs, idx)
         with tw.lane("aux"):
-            ac.critic_forward_(fw, flat["observations"], flat["base_vel"], flat["privileged_observations"], idx, head=not fuse, X=Xc, images=im)
-        ac.actor_forward_(fw, flat["observations"], idx, head=not fuse, X=Xa, images=im)
+            ac.critic_forward_(fw, obs, flat["base_vel"], priv, idx, head=not fuse, X=Xc, images=im, wset=wset)
+        ac.actor_forward_(fw, obs, idx, head=not fuse, X=Xa, images=im, wset=wset, cols=a_cols)
         tw.order("aux", "main")
         if self.after_forward_hook is not None:
             self.after_forward_hook(fw, "ppo")
@@ -711,47 +745,66 @@ class PPO:
                          ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
         self._kl_to_header(stats)
         tw.order("main", "aux")
-        # critic (aux)
-        g_c2, g_c1 = tw.g("c2", 256), tw.g("c1", 512)
-        # image chain (im): the gradient of the 256-wide hidden layer leaves the converting kernel as fp32 + image; the layer below reads
-        # both of its operands (that gradient, its own input) as images
-        with tw.lane("aux"):
-            self._bwd(tw, L["c3"], tw.dval, fw.v3, None if fuse else g_c3, fw.v3, act)      # fused: weight gradient only
-            if im:
-                g_c2i = tw.img("g_c2", L["c2"].n_in)
-                self._bwd(tw, L["c2"], g_c3, fw.v2, g_c2, fw.v2, act, dXimg=g_c2i)
-                self._bwd_img(tw, L["c1"], g_c2i, fw.img("v1"), dX=g_c1, Xsaved=fw.v1, act_prev=act)
-            else:
+        tw.dmulv.zero_()
+        if im:
+            self._ppo_backward_images(fw, tw, Xc, Xa, g_a3, g_c3, fuse, wset)
+        else:
+            # critic (aux)
+            g_c2, g_c1 = tw.g("c2", 256), tw.g("c1", 512)
+            with tw.lane("aux"):
+                self._bwd(tw, L["c3"], tw.dval, fw.v3, None if fuse else g_c3, fw.v3, act)      # fused: weight gradient only
                 self._bwd(tw, L["c2"], g_c3, fw.v2, g_c2, fw.v2, act)
                 self._bwd(tw, L["c1"], g_c2, fw.v1, g_c1, fw.v1, act)
-            self._bwd(tw, L["c0"], g_c1, Xc)
-        # actor (main); layer-0 input gradient fans out to z, mu[:, :3], l_t (observations need none)
-        g_a2, g_a1 = tw.g("a2", 256), tw.g("a1", 512)
-        self._bwd(tw, L["a3"], tw.dmean, fw.a3, None if fuse else g_a3, fw.a3, act)
-        if im:
-            g_a2i = tw.img("g_a2", L["a2"].n_in)
-            self._bwd(tw, L["a2"], g_a3, fw.a2, g_a2, fw.a2, act, dXimg=g_a2i)
-            self._bwd_img(tw, L["a1"], g_a2i, fw.img("a1"), dX=g_a1, Xsaved=fw.a1, act_prev=act)
-        else:
+                self._bwd(tw, L["c0"], g_c1, Xc)
+            # actor (main); layer-0 input gradient fans out to z, mu[:, :3], l_t (observations need none)
+            g_a2, g_a1 = tw.g("a2", 256), tw.g("a1", 512)
+            self._bwd(tw, L["a3"], tw.dmean, fw.a3, None if fuse else g_a3, fw.a3, act)
             self._bwd(tw, L["a2"], g_a3, fw.a2, g_a2, fw.a2, act)
             self._bwd(tw, L["a1"], g_a2, fw.a1, g_a1, fw.a1, act)
-        tw.dmulv.zero_()
-        dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
-        if im:                                                     # d l_t also as the image the terrain encoder's backward reads
-            self._bwd(tw, L["a0"], g_a1, Xa, dst, None, None, dXimg=tw.img("dlt", 512), img_seg=3)
-            tw.live_img |= {"dlt"}
-        else:
+            dst = segmat([seg(None, 0, ac.num_obs), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3), seg(tw.dlt, 0, 512)])
             self._bwd(tw, L["a0"], g_a1, Xa, dst, None, None)
         early = self._exchange_bucket(tw, "main_only")             # actor + critic + std gradients are complete
         tw.order("main", "aux")                                    # dz, d mu[:, :3] (and d l_t) are written
-        self._terrain_encoder_backward(fw, tw, flat, idx)          # needs d l_t only: starts right away on main
+        self._terrain_encoder_backward(fw, tw, flat, idx, wset)    # needs d l_t only: starts right away on main
         with tw.lane("aux"):
             ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
-            self._cenet_encoder_backward(fw, tw, flat, idx)
+            self._cenet_encoder_backward(fw, tw, flat, idx, split=ns)
         if early:
             self._exchange_bucket(tw, "shared")
         self._join(tw)
         return early
+
+    def _ppo_backward_images(self, fw, tw, Xc, Xa, g_a3, g_c3, fuse, wset):
+        """Backward of the actor / critic bodies on operand images.  The heads' gradients (fp32, 128 wide) are packed into images; from
+        there every gradient of the two bodies exists as an image only.  The ELU derivative reads the fp32 copy of the saved
+        activation the forward pass kept next to its image."""
+        ac = self.actor_critic
+        L = ac.L
+        act = AC_Args.activation
+        n_a, n_c = L["a2"].n_out, L["c2"].n_out
+        with tw.lane("aux"):                                       # critic
+            self._bwd(tw, L["c3"], tw.dval, fw.v3, None if fuse else g_c3, fw.v3, act, split=False)      # fused: weight gradient only
+            G_c3 = tw.img("G_c3", n_c).pack(g_c3)
+            g_c2i, g_c1i = tw.img("g_c2", L["c2"].n_in), tw.img("g_c1", L["c1"].n_in)
+            self._bwd_img(tw, L["c2"], G_c3, fw.img("v2"))
+            h2i.linear_dgrad(G_c3, L["c2"].W, None, g_c2i, Xsaved=fw.v2, act=act, wset=wset)
+            self._bwd_img(tw, L["c1"], g_c2i, fw.img("v1"))
+            h2i.linear_dgrad(g_c2i, L["c1"].W, None, g_c1i, Xsaved=fw.v1, act=act, wset=wset)
+            self._bwd_img(tw, L["c0"], g_c1i, Xc)
+        # actor (main); layer-0 input gradient fans out to z, mu[:, :3] (fp32) and l_t (image); the observations need none
+        self._bwd(tw, L["a3"], tw.dmean, fw.a3, None if fuse else g_a3, fw.a3, act, split=False)
+        G_a3 = tw.img("G_a3", n_a).pack(g_a3)
+        g_a2i, g_a1i = tw.img("g_a2", L["a2"].n_in), tw.img("g_a1", L["a1"].n_in)
+        self._bwd_img(tw, L["a2"], G_a3, fw.img("a2"))
+        h2i.linear_dgrad(G_a3, L["a2"].W, None, g_a2i, Xsaved=fw.a2, act=act, wset=wset)
+        self._bwd_img(tw, L["a1"], g_a2i, fw.img("a1"))
+        h2i.linear_dgrad(g_a2i, L["a1"].W, None, g_a1i, Xsaved=fw.a1, act=act, wset=wset)
+        nb = ac.num_obs + 19                                       # width of the narrow block [obs | z | mu[:, :3]]
+        self._bwd_img(tw, L["a0"], g_a1i, Xa[0], wcol0=nb)         # columns of dW that meet l_t ...
+        self._bwd_img(tw, L["a0"], g_a1i, Xa[1], wcol0=0, bias=False)        # ... and the narrow block
+        h2i.linear_dgrad(g_a1i, L["a0"].W, None, tw.img("dlt", 512), window=(nb, 512), wset=wset)
+        h2i.linear_dgrad(g_a1i, L["a0"].W, segmat([seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3)]), None, window=(ac.num_obs, 19), wset=wset)
+        tw.live_img |= {"dlt", "g_a2", "g_a1", "g_c2", "g_c1"}
 
     def _adaptive(self):
         return self.desired_kl is not None and self.schedule == 'adaptive'

@@ -1,0 +1,211 @@
+"""Block-scaled two-term fp16 operand images (include/dtc_hip.h "block-scaled ... operand images", csrc/h2i_core.hpp): the
+representation of the wide layers' operands -- rsl_rl/rsl_rl/modules/actor_critic_decoder.py:98-188, 323-349 under
+ppo.py:197-218, 252, 265, 289, 333.
+
+    HImage            a [M, K] activation / gradient as (hi, lo) fp16 planes + one exponent per row and 128-column block
+    WeightSet         the weight images of one trainer phase: learnt on the first pass, rebuilt by ONE launch per phase afterwards
+    linear_fwd / linear_fwd_mse / linear_dgrad / wgrad_group: the products; results as fp32, as an image, or both
+
+Nothing here keeps a scale on the host: every image carries its own exponents, computed by the kernel that wrote it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _ffi
+from ._ffi import ACT, check, cptr, lib, ptr, segmat, seg, stream
+
+f32 = torch.float32
+
+
+class HImage:
+    """image(M, K): written by `pack` (from fp32) or by the epilogue of a product, read by LDS-DMA by every consumer."""
+
+    def __init__(self, M, K, device):
+        self.M, self.K = int(M), int(K)
+        n = int(lib().dtc_h2i_bytes(self.M, self.K))
+        if n <= 0 or n >= 1 << 31:
+            raise _ffi.DtcError(f"operand image of a {M} x {K} matrix: {n} bytes (must be in (0, 2 GiB))")
+        self.buf = torch.zeros((n + 7) // 8, dtype=torch.float64, device=device)      # (zeros: rows behind M read as nothing)
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    def pack(self, X, M=None):
+        """self <- the fp32 operand X (tensor or DtcSegMat: segments side by side, row-gathered where asked)."""
+        Xs = X if isinstance(X, _ffi.DtcSegMat) else segmat([seg(X, 0, X.shape[1])])
+        assert Xs.cols == self.K
+        check(lib().dtc_h2i_pack(Xs, self.M if M is None else M, self.ptr(), stream()), "dtc_h2i_pack")
+        self._src = Xs                  # the launch reads the descriptor's tensors: keep them until the next pack
+        return self
+
+    @staticmethod
+    def from_tensor(X):
+        return HImage(X.shape[0], X.shape[1], X.device).pack(X)
+
+    def to_tensor(self):
+        """Decode (tests / debugging): fp32 [M, K]."""
+        out = torch.empty(self.M, self.K, dtype=f32, device=self.device)
+        check(lib().dtc_h2i_unpack(self.ptr(), self.M, self.K, ptr(out), out.stride(0), stream()), "dtc_h2i_unpack")
+        return out
+
+    def exps(self):
+        """The exponent table [row tiles, k blocks, 128] (tests)."""
+        rt, st = -(-self.M // 128), -(-self.K // 16)
+        kb = -(-st // 8)
+        off = rt * st * 8192
+        return self.buf.view(torch.int32)[off // 4: off // 4 + rt * kb * 128].view(rt, kb, 128)
+
+
+def _operand(X):
+    """HImage | list of HImages (side by side along the reduction) -> DtcH2iOperand"""
+    imgs = [X] if isinstance(X, HImage) else list(X)
+    op = _ffi.DtcH2iOperand()
+    op.nseg = len(imgs)
+    for i, im in enumerate(imgs):
+        op.width[i], op.img[i] = im.K, im.ptr()
+    op._keep = imgs
+    return op, imgs
+
+
+def _wjob(job, W, trans, r0, nr, ranges, img_ptr):
+    job.W, job.ld, job.img = cptr(W, f32), W.stride(0), img_ptr
+    job.trans, job.r0, job.nr, job.nseg = int(trans), int(r0), int(nr), len(ranges)
+    for i, (c0, cw) in enumerate(ranges):
+        job.c0[i], job.cw[i] = int(c0), int(cw)
+
+
+class WeightSet:
+    """Weight images of ONE trainer phase.  `get(W, trans, r0, nr, ranges)` returns the image of that product's weight operand;
+    the first request builds it on the spot (and remembers the job), `rebuild()` -- called once per phase, after the optimiser wrote
+    the weights and before the lanes fork -- builds all remembered images with one grouped launch."""
+
+    def __init__(self):
+        self.entries = {}           # key -> (image buffer, job fields, W)
+        self.jobs = None
+
+    def get(self, W, trans, r0, nr, ranges):
+        key = (W.data_ptr(), W.stride(0), int(trans), int(r0), int(nr), tuple((int(a), int(b)) for a, b in ranges))
+        e = self.entries.get(key)
+        if e is None:
+            job = (_ffi.DtcH2iWJob * 1)()
+            _wjob(job[0], W, trans, r0, nr, ranges, None)
+            n = int(lib().dtc_h2i_wimage_bytes(job))
+            if n <= 0:
+                raise _ffi.DtcError("dtc_h2i_wimage_bytes: bad weight-image job")
+            buf = torch.zeros((n + 7) // 8, dtype=torch.float64, device=W.device)
+            job[0].img = buf.data_ptr()
+            check(lib().dtc_h2i_wimage_group(job, 1, stream()), "dtc_h2i_wimage_group")
+            e = self.entries[key] = (buf, (W, trans, r0, nr, ranges))
+            self.jobs = None
+        return e[0]
+
+    def rebuild(self):
+        if not self.entries:
+            return
+        if self.jobs is None:
+            self.jobs = (_ffi.DtcH2iWJob * len(self.entries))()
+            for j, (buf, (W, trans, r0, nr, ranges)) in zip(self.jobs, self.entries.values()):
+                _wjob(j, W, trans, r0, nr, ranges, buf.data_ptr())
+        check(lib().dtc_h2i_wimage_group(self.jobs, len(self.jobs), stream()), "dtc_h2i_wimage_group")
+
+
+_ONE_SHOT = WeightSet()      # calls outside a trainer phase (tests, direct use): images built per call
+
+
+def _fwd_wimage(W, imgs, col_ranges, wset):
+    """The forward weight image for row operand `imgs`: col_ranges[i] = first column of W that meets image i (default: side by side)."""
+    if col_ranges is None:
+        col_ranges, c = [], 0
+        for im in imgs:
+            col_ranges.append(c)
+            c += im.K
+    ranges = [(c0, im.K) for c0, im in zip(col_ranges, imgs)]
+    ws = wset if wset is not None else WeightSet()
+    return ws.get(W, 0, 0, W.shape[0], ranges), ws
+
+
+def linear_fwd(X, W, b, Y=None, Yimg=None, act=None, mask=None, wset=None, cols=None):
+    """Y = act(X W^T + b).  X: HImage or list of HImages; results: fp32 `Y` [M, >= N] and / or the HImage `Yimg` [M, N].
+    `cols`: first column of W for each image of X (default: the images side by side from column 0)."""
+    op, imgs = _operand(X)
+    N = W.shape[0]
+    M = imgs[0].M
+    assert (Y is not None or Yimg is not None) and (Yimg is None or (Yimg.M, Yimg.K) == (M, N))
+    wimg, ws = _fwd_wimage(W, imgs, cols, wset)
+    check(lib().dtc_linear_fwd_h2i(op, ptr(wimg), cptr(b, f32) if b is not None else None, ptr(Y) if Y is not None else None,
+                                   Y.stride(0) if Y is not None else 0, Yimg.ptr() if Yimg is not None else None,
+                                   ptr(mask) if mask is not None else None, M, N, ACT[act], stream()), "dtc_linear_fwd_h2i")
+    return ws
+
+
+def mse_parts(M, N) -> int:
+    return int(lib().dtc_linear_fwd_mse_h2i_parts(M, N))
+
+
+def linear_fwd_mse(X, W, b, target, tcol0, tidx, dY, dYimg, part, wset=None):
+    """The output layer fused with its MSE against target[tidx, tcol0:tcol0 + N]; dL/dY as fp32 `dY` and / or HImage `dYimg`;
+    returns the number of partial sums written to `part` (float64)."""
+    op, imgs = _operand(X)
+    N = W.shape[0]
+    M = imgs[0].M
+    n = mse_parts(M, N)
+    assert part.numel() >= n and part.dtype == torch.float64
+    wimg, ws = _fwd_wimage(W, imgs, None, wset)
+    check(lib().dtc_linear_fwd_mse_h2i(op, ptr(wimg), cptr(b, f32) if b is not None else None, cptr(target, f32), target.stride(0),
+                                       target.shape[0], tcol0, cptr(tidx, torch.int64), 2.0 / (M * N), ptr(dY) if dY is not None else None,
+                                       dY.stride(0) if dY is not None else 0, dYimg.ptr() if dYimg is not None else None, ptr(part), M, N,
+                                       stream()), "dtc_linear_fwd_mse_h2i")
+    return n
+
+
+def linear_dgrad(dZimg, W, dX=None, dXimg=None, window=None, add=None, Xsaved=None, act=None, mask=None, wset=None):
+    """dX[:, window] = ((dZ W[:, window]) + add) * act'(.).  dZimg: HImage [M, N]; window = (first column, width) of W's columns
+    (default: all); results over the window: fp32 destination `dX` (tensor or DtcSegMat covering the window) and / or the HImage
+    `dXimg` [M, width]; `add`: fp32 [M, >= width] added to the product before anything is stored."""
+    N, K = W.shape
+    c0, kw = (0, K) if window is None else window
+    M = dZimg.M
+    assert dZimg.K == N and (dX is not None or dXimg is not None) and (dXimg is None or (dXimg.M, dXimg.K) == (M, kw))
+    ws = wset if wset is not None else WeightSet()
+    wimg = ws.get(W, 1, c0, kw, [(0, N)])
+    dXs = None
+    if dX is not None:
+        dXs = dX if isinstance(dX, _ffi.DtcSegMat) else segmat([seg(dX, 0, kw)])
+    check(lib().dtc_linear_dgrad_h2i(dZimg.ptr(), N, ptr(wimg), kw, dXs, dXimg.ptr() if dXimg is not None else None,
+                                     ptr(add) if add is not None else None, add.stride(0) if add is not None else 0,
+                                     ptr(Xsaved) if (mask is None and Xsaved is not None) else None, Xsaved.stride(0) if Xsaved is not None else 0,
+                                     ptr(mask) if mask is not None else None, M, ACT[act] if mask is None else ACT["relu"], stream()),
+          "dtc_linear_dgrad_h2i")
+    return ws
+
+
+def _wgrad_jobs(jobs):
+    """jobs: list of (dZimg [M,N], Ximg [M,K], dW (the [N, ldw] gradient tensor), wcol0, db or None)"""
+    arr = (_ffi.DtcWgradH2iJob * len(jobs))()
+    for a, (dZimg, Ximg, dW, wcol0, db) in zip(arr, jobs):
+        assert dZimg.M == Ximg.M and dW.shape[0] == dZimg.K and dW.stride(1) == 1 and wcol0 + Ximg.K <= dW.shape[1] + 15
+        a.dZimg, a.Ximg, a.dW, a.db = dZimg.ptr(), Ximg.ptr(), ptr(dW), (cptr(db, f32) if db is not None else None)
+        a.ldw, a.N, a.K, a.wcol0 = dW.stride(0), dZimg.K, min(Ximg.K, dW.shape[1] - wcol0), wcol0
+    return arr
+
+
+def wgrad_group_workspace_bytes(jobs, M) -> int:
+    n = int(lib().dtc_wgrad_group_h2i_workspace(_wgrad_jobs(jobs), len(jobs), M))
+    if n < 0:
+        raise _ffi.DtcError(f"dtc_wgrad_group_h2i_workspace failed: {lib().dtc_last_error().decode()}")
+    return n
+
+
+def wgrad_group(jobs, M, workspace, stream_ptr=None):
+    """dW[:, wcol0 : wcol0 + K] = dZ^T X, db = colsum(dZ) for up to 12 (dZimg, Ximg) pairs in one launch pair.
+    Returns the objects the launch reads (keep them alive until it has run)."""
+    arr = _wgrad_jobs(jobs)
+    check(lib().dtc_wgrad_group_h2i(arr, len(jobs), M, ptr(workspace), stream() if stream_ptr is None else stream_ptr), "dtc_wgrad_group_h2i")
+    return jobs

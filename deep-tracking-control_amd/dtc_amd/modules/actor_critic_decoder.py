@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import _ffi, ops
+from .. import _ffi, h2i, ops
 from .._ffi import seg, segmat
 
 
@@ -291,12 +291,13 @@ class ActorCriticDecoder(nn.Module):
             self.lat_ws = torch.empty(int(_ffi.lib().dtc_cenet_workspace(B)) // 8 + 1, dtype=torch.float64, device=dev)
             self._dev, self._masks = dev, {}
             self._imgs, self.live_img = {}, set()
+            self.pack_key = {}               # operand image name -> what it was packed from (see ActorCriticDecoder.packed_input)
 
         def img(self, name, width=None):
-            """Activation image (ops.AImage) of the [B, width] activation `name`, allocated on first use."""
+            """Operand image (h2i.HImage) of the [B, width] activation `name`, allocated on first use."""
             im = self._imgs.get(name)
             if im is None:
-                im = self._imgs[name] = ops.AImage(self.B, width, self._dev)
+                im = self._imgs[name] = h2i.HImage(self.B, width, self._dev)
             return im
 
         def value(self, name):
@@ -349,35 +350,51 @@ class ActorCriticDecoder(nn.Module):
         return ch
 
     # ------------------------------------------------------------------ kernel-level forward pieces
-    def cenet_forward_(self, ws, hist, eps, idx=None, masks=False):
+    def cenet_forward_(self, ws, hist, eps, idx=None, masks=False, split=None):
         """vae.cenet_forward (actor_critic_decoder.py:286-302) into ws.mulv / ws.z.  `masks`: training step -- the ReLU
-        layers also record their output signs (ws.relu_mask) for the backward pass."""
+        layers also record their output signs (ws.relu_mask) for the backward pass.  `split=False`: single-pass fp32 kernels."""
         L = self.L
         X = segmat([seg(hist, 0, hist.shape[1], gather=idx is not None)], idx)
-        ops.linear_fwd(X, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=ws.B, mask=ws.relu_mask("e1", 128, masks))
-        ops.linear_fwd(ws.e1, L["ce1"].W, L["ce1"].b, ws.e, None)
-        ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None)
+        ops.linear_fwd(X, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=ws.B, mask=ws.relu_mask("e1", 128, masks), split=split)
+        ops.linear_fwd(ws.e1, L["ce1"].W, L["ce1"].b, ws.e, None, split=split)
+        ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None, split=split)
         ops.cenet_latent_fwd(ws.mulv, eps, ws.z, ws.mask, ws.info, ws.lat_ws)
 
     def images_ok(self, ws):
-        """Activation images (ops.AImage: the hidden activations of the wide stacks live in HBM as the bf16 x 3 planes the split
-        kernels read by LDS-DMA, written once by the producing epilogue) need the split path with weight images and the ReLU sign
-        records (whole 128-row tiles): training steps of mini-batches that are multiples of 128 rows."""
-        return ops.SPLIT and ops.WIMG and ws.B % 128 == 0
+        """The operand-image chain (dtc_amd/h2i.py: the wide stacks' activations live in HBM as the fp16 (hi, lo) planes the GEMM
+        kernels read by LDS-DMA, written once by the producing epilogue) runs on training steps whose mini-batch is a whole number of
+        128-row tiles (ReLU sign records, exponent blocks of the weight gradients)."""
+        return ops.SPLIT and ws.B % 128 == 0
 
-    def terrain_encoder_(self, ws, priv, idx=None, masks=False, images=False, lt_img=False):
-        """`images` (training step, see images_ok): t1 / t2 leave as images only (ws.live_img), l_t as fp32 (+ image: lt_img)."""
+    def packed_input(self, ws, name, X, key):
+        """Operand image `name` of the fp32 operand X (DtcSegMat: the gathered rollout rows, narrow hand-over tensors).  `key`
+        identifies the content (sources' addresses and versions, the index tensor): an image that was packed from the same content --
+        the terrain heights of a mini-batch serve the VAE step and the policy step -- is not packed again."""
+        img = ws.img(name, X.cols)
+        if key is None or ws.pack_key.get(name) != key:
+            img.pack(X, ws.B)
+            ws.pack_key[name] = key
+        return img
+
+    @staticmethod
+    def content_key(idx, *tensors):
+        return (None if idx is None else (idx.data_ptr(), idx.numel(), idx._version),) + tuple((t.data_ptr(), t._version) for t in tensors)
+
+    def terrain_encoder_(self, ws, priv, idx=None, masks=False, images=False, wset=None, lt_fp32=True):
+        """`images` (training step, see images_ok): the gathered heights are packed into an operand image once per mini-batch, t1 / t2
+        leave as images only (ws.live_img), l_t as an image (+ fp32 for the CE-net decoder: lt_fp32)."""
         L = self.L
         X = segmat([seg(priv, 0, 693, gather=idx is not None)], idx)
         if images and masks:
             w1, w2 = L["te0"].n_out, L["te1"].n_out
-            t1i, t2i = ws.img("t1", w1), ws.img("t2", w2)
-            ops.linear_fwd(X, L["te0"].W, L["te0"].b, None, "relu", M=ws.B, mask=ws.relu_mask("t1", w1, masks), Yimg=t1i)
-            ops.linear_fwd_img(t1i, L["te1"].W, L["te1"].b, None, t2i, "relu", mask=ws.relu_mask("t2", w2, masks))
-            ops.linear_fwd_img(t2i, L["te2"].W, L["te2"].b, ws.lt, ws.img("lt", L["te2"].n_out) if lt_img else None, None)
-            ws.live_img |= {"t1", "t2"}
+            pin = self.packed_input(ws, "p_te", X, self.content_key(idx, priv))
+            t1i, t2i, lti = ws.img("t1", w1), ws.img("t2", w2), ws.img("lt", L["te2"].n_out)
+            h2i.linear_fwd(pin, L["te0"].W, L["te0"].b, None, t1i, "relu", mask=ws.relu_mask("t1", w1, masks), wset=wset)
+            h2i.linear_fwd(t1i, L["te1"].W, L["te1"].b, None, t2i, "relu", mask=ws.relu_mask("t2", w2, masks), wset=wset)
+            h2i.linear_fwd(t2i, L["te2"].W, L["te2"].b, ws.lt if lt_fp32 else None, lti, None, wset=wset)
+            ws.live_img |= {"t1", "t2"} | (set() if lt_fp32 else {"lt"})
             return
-        ws.live_img -= {"t1", "t2"}
+        ws.live_img -= {"t1", "t2", "lt"}
         ops.linear_fwd(X, L["te0"].W, L["te0"].b, ws.t1, "relu", M=ws.B, mask=ws.relu_mask("t1", 512, masks))
         ops.linear_fwd(ws.t1, L["te1"].W, L["te1"].b, ws.t2, "relu", mask=ws.relu_mask("t2", 512, masks))
         ops.linear_fwd(ws.t2, L["te2"].W, L["te2"].b, ws.lt, None)
@@ -403,32 +420,33 @@ class ActorCriticDecoder(nn.Module):
         ops.pack_cols(segmat([seg(obs, 0, self.num_obs, gather=g), seg(base_vel, 0, 3, gather=g)], idx), buf, B)
         return segmat([seg(buf, 0, self.num_obs + 3), seg(priv, 693, 696, gather=g)], idx)
 
-    def _body_forward_(self, ws, X, names, outs, images):
-        """First three layers of an actor / critic body.  `images`: the two hidden activations also leave as images (fp32 stays: the
-        ELU derivative of the backward pass reads it), the layers after the first read their input by LDS-DMA."""
+    def _body_forward_(self, ws, X, names, outs, images, wset=None, cols=None):
+        """First three layers of an actor / critic body.  `images`: X is an operand image (or a list of them, `cols` = the first
+        column of the layer's weight each one meets); the two hidden activations leave as fp32 (the ELU derivative of the backward pass
+        reads it) AND as images, the layers after the first read their input by LDS-DMA; the last one writes fp32 only."""
         L, act = self.L, AC_Args.activation
         l0, l1, l2 = (L[n] for n in names)
         o0, o1, o2 = (getattr(ws, n) for n in outs)
         if images:
             i0, i1 = ws.img(outs[0], l0.n_out), ws.img(outs[1], l1.n_out)
-            ops.linear_fwd(X, l0.W, l0.b, o0, act, M=ws.B, Yimg=i0)
-            ops.linear_fwd_img(i0, l1.W, l1.b, o1, i1, act)
-            ops.linear_fwd_img(i1, l2.W, l2.b, o2, None, act)
+            h2i.linear_fwd(X, l0.W, l0.b, o0, i0, act, wset=wset, cols=cols)
+            h2i.linear_fwd(i0, l1.W, l1.b, o1, i1, act, wset=wset)
+            h2i.linear_fwd(i1, l2.W, l2.b, o2, None, act, wset=wset)
             return
         ops.linear_fwd(X, l0.W, l0.b, o0, act, M=ws.B)
         ops.linear_fwd(o0, l1.W, l1.b, o1, act)
         ops.linear_fwd(o1, l2.W, l2.b, o2, act)
 
-    def actor_forward_(self, ws, obs, idx=None, head=True, X=None, images=False):
+    def actor_forward_(self, ws, obs, idx=None, head=True, X=None, images=False, wset=None, cols=None):
         """`head=False`: stop before the output layer (the trainer's fused heads + loss kernel computes it)."""
         L = self.L
-        self._body_forward_(ws, self.actor_input(ws, obs, idx) if X is None else X, ("a0", "a1", "a2"), ("a1", "a2", "a3"), images)
+        self._body_forward_(ws, self.actor_input(ws, obs, idx) if X is None else X, ("a0", "a1", "a2"), ("a1", "a2", "a3"), images, wset, cols)
         if head:
             ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None)
 
-    def critic_forward_(self, ws, obs, base_vel, priv, idx=None, head=True, X=None, images=False):
+    def critic_forward_(self, ws, obs, base_vel, priv, idx=None, head=True, X=None, images=False, wset=None):
         L = self.L
-        self._body_forward_(ws, self.critic_input(obs, base_vel, priv, idx) if X is None else X, ("c0", "c1", "c2"), ("v1", "v2", "v3"), images)
+        self._body_forward_(ws, self.critic_input(obs, base_vel, priv, idx) if X is None else X, ("c0", "c1", "c2"), ("v1", "v2", "v3"), images, wset)
         if head:
             ops.linear_fwd(ws.v3, L["c3"].W, L["c3"].b, ws.val, None)
 

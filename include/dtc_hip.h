@@ -38,10 +38,10 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-#define DTC_ABI_VERSION 9                    /* bumped whenever a signature or a by-value struct layout changes       */
+#define DTC_ABI_VERSION 10                   /* bumped whenever a signature or a by-value struct layout changes       */
 int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
 /* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
-   DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcWgradImgJob: the binding compares them with its own layouts at load time (a library
+   DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcWgradImgJob, DtcH2iWJob, DtcH2iOperand, DtcWgradH2iJob: the binding compares them with its own layouts at load time (a library
    built from another revision -- e.g. a stale DTC_LIB override -- must not receive descriptors it would misread).
    Returns the number of entries (written up to `cap`). */
 int dtc_abi_sizes(int64_t* out, int cap);
@@ -294,6 +294,65 @@ typedef struct DtcWgradImgJob {
 } DtcWgradImgJob;
 int64_t dtc_wgrad_group_i3_workspace(const DtcWgradImgJob* jobs, int count, int M);
 int dtc_wgrad_group_i3(const DtcWgradImgJob* jobs, int count, int M, void* workspace, void* stream);
+/* ---- block-scaled two-term fp16 operand images (round 5; csrc/h2i_core.hpp, gemm_h2i.hip, wgrad_h2i.hip): THE representation of the
+ * wide layers' operands -- the fp32 products of actor_critic_decoder.py:98-188, 323-349 (under ppo.py:197-218, 252, 265, 289, 333) with
+ * every operand held in HBM as the (hi, lo) fp16 planes the K loops read by LDS-DMA, 4 bytes per element, scaled by a power of two chosen
+ * PER ROW and block of 128 columns (weights: per 128 x 128 block) from the block's own largest finite element:
+ *   image(M, K) = ceil(M / 128) x ceil(K / 16) chunks of 8 KiB [plane 2][slot 256][16 bytes] + int32 exps[row tile][k block][128];
+ *   dtc_h2i_bytes(M, K) bytes, 16-byte aligned, < 2 GiB.  Rows >= M and columns >= K are zero.
+ * Every element is exact to 2^-22 of its row block's largest element whatever the rest of the tensor holds (no tensor-wide amax, no
+ * records, nothing to keep in step on the host), and a non-finite element poisons only the outputs that depend on it -- its row in the
+ * forward / data-gradient products, its column of dW in the weight gradient -- as in the fp32 reference.
+ * Producers: dtc_h2i_pack (fp32 segmented / row-gathered operand -> image: the rollout storage, narrow hand-over tensors), the epilogues
+ * of dtc_linear_fwd_h2i / _mse_h2i / dtc_linear_dgrad_h2i (results as fp32, as an image, or both), dtc_h2i_wimage_group (weights).
+ * dtc_h2i_unpack decodes an image (tests). */
+int64_t dtc_h2i_bytes(int M, int K);
+int dtc_h2i_pack(const DtcSegMat* X, int M, void* img, void* stream);
+int dtc_h2i_unpack(const void* img, int M, int K, float* out, int64_t ld, void* stream);
+/* A weight image: `nr` rows of the operand starting at r0, the reduction = up to 4 column ranges (c0, cw) side by side, each padded to
+ * whole 16-column stages -- the walk of the row operand's images.  trans = 0: element (row, c) = W[(r0 + row) * ld + c] (forward:
+ * r0 = 0, nr = N, ranges = the column blocks of W that meet the row operand's images, in that order); trans = 1: W[c * ld + r0 + row]
+ * (data gradient: rows = a window of W's columns, one range (0, N)).  img: dtc_h2i_wimage_bytes(job) bytes. */
+typedef struct DtcH2iWJob {
+    const float* W;
+    int64_t ld;
+    void* img;
+    int32_t trans, r0, nr, nseg;
+    int32_t c0[4], cw[4];
+} DtcH2iWJob;
+int64_t dtc_h2i_wimage_bytes(const DtcH2iWJob* job);
+int dtc_h2i_wimage_group(const DtcH2iWJob* jobs, int count, void* stream);
+/* the row operand of a product: up to 4 images over the same M rows, side by side along the reduction (at most 1024 columns in all) */
+typedef struct DtcH2iOperand {
+    int32_t nseg;
+    int32_t width[4];
+    const void* img[4];
+} DtcH2iOperand;
+/* Y = act(X W^T + b) (actor_critic_decoder.py:98-131, 323-349); results: fp32 Y [M, >= N] (may be NULL) and / or Yimg = image(M, N) */
+int dtc_linear_fwd_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
+                       int M, int N, int act, void* stream);
+/* the terrain decoder's output layer fused with its MSE (ppo.py:223): dL/dY as fp32 (may be NULL) and / or image(M, N) */
+int64_t dtc_linear_fwd_mse_h2i_parts(int M, int N);
+int dtc_linear_fwd_mse_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, const float* target, int64_t ldt, int64_t target_rows,
+                           int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy, void* dYimg, double* sq_part, int M, int N,
+                           void* stream);
+/* dX[:, window] = ((dZ W[:, window]) + add) * act'(.): dZimg = image(M, N), wimgT = image of W^T for the window (Kwin columns); results
+ * over the window: fp32 destination blocks dX (may be NULL) and / or dXimg = image(M, Kwin); add: fp32 [M, ld_add] or NULL */
+int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT, int Kwin, const DtcSegMat* dX, void* dXimg, const float* add,
+                         int64_t ld_add, const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, int M, int act, void* stream);
+/* dW_j = dZ_j^T X_j, db_j = colsum(dZ_j) for `count` <= 12 layers in ONE launch, both operands images over the same M batch rows
+ * (M a multiple of 128 per batch slice: the per-row exponents of the two operands are folded into one operand's fragments per batch
+ * row, csrc/wgrad_h2i.hip).  workspace >= dtc_wgrad_group_h2i_workspace() bytes, 16-byte aligned. */
+typedef struct DtcWgradH2iJob {
+    const void* dZimg;   /* image(M, N) */
+    const void* Ximg;    /* image(M, K) */
+    float* dW;           /* [N, ldw >= K]: columns [wcol0, wcol0 + K) of the layer's weight gradient */
+    float* db;           /* [N] or NULL   */
+    int64_t ldw;
+    int32_t N, K, wcol0;
+} DtcWgradH2iJob;
+int64_t dtc_wgrad_group_h2i_workspace(const DtcWgradH2iJob* jobs, int count, int M);
+int dtc_wgrad_group_h2i(const DtcWgradH2iJob* jobs, int count, int M, void* workspace, void* stream);
 /* ---- two-term fp16 path (round 4, csrc/s3_core.hpp): the same products with every fp32 operand x scaled by a power of two chosen from
  * its tensor's amax (largest |x|: scaled into [2^14, 2^15)) and written as hi + lo, hi = fp16(x 2^e), lo = fp16(x 2^e - hi): 22 significant
  * bits (elements more than 2^18 below amax: absolute error 2^-40 amax), THREE fp16 MFMA passes per product (lo hi', hi lo', hi hi'; exact
