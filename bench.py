@@ -227,6 +227,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--no-in-situ", action="store_true", help="skip the fp64 check of one step's products on their actual operands")
     ap.add_argument("--workload", default=os.environ.get("DTC_BENCH_WORKLOAD", "decoder"), choices=["decoder", "composite", "gru"],
                     help="decoder = BASELINE configs[1] (the headline, default); composite = configs[4]'s model "
                          "(GRU + CE-net + foothold obs, build-defined); gru = configs[2] (ActorCriticRecurrent, GRU 512, BPTT); "
@@ -309,7 +310,7 @@ def run(a, rank, local_rank, world, wd):
         dtc_build.build(verbose=False)
     if world > 1:
         dist.barrier()
-    from dtc_amd import _ffi, foothold, ops, synthetic as S
+    from dtc_amd import _ffi, foothold, h2i, ops, synthetic as S
     from dtc_amd.algorithms import PPO, RecurrentDecoderPPO, RecurrentPPO
     from dtc_amd.modules import ActorCriticDecoder, ActorCriticDecoderRecurrent, ActorCriticRecurrent
 
@@ -447,7 +448,18 @@ def run(a, rank, local_rank, world, wd):
             err = lambda y, r: float((y.double() - r).abs().max() / r.abs().max())
             accuracy[name] = dict(fwd=err(Y, refs["fwd"]), dgrad=err(dX, refs["dgrad"]), wgrad=err(dW, refs["wgrad"]))
         ops.set_split(ops.SPLIT, h2=h2_was)
-        accuracy["measure"] = "max |y - y_fp64| / max |y_fp64| on a 24576 x 512 x 512 layer, random normal operands"
+        if ops.SPLIT:
+            Xi, dZi = h2i.HImage.from_tensor(Xa), h2i.HImage.from_tensor(dZa)
+            Y, dX, dW, db = (torch.empty(Mx, Nx, device=dev), torch.empty(Mx, Kx, device=dev), torch.empty(Nx, Kx, device=dev),
+                             torch.empty(Nx, device=dev))
+            h2i.linear_fwd(Xi, Wa, None, Y, None, None)
+            h2i.linear_dgrad(dZi, Wa, dX)
+            jobs = [(dZi, Xi, dW, 0, db)]
+            h2i.wgrad_group(jobs, Mx, ops.workspace(h2i.wgrad_group_workspace_bytes(jobs, Mx), dev))
+            err = lambda y, r: float((y.double() - r).abs().max() / r.abs().max())
+            accuracy["operand_images_f16x2"] = dict(fwd=err(Y, refs["fwd"]), dgrad=err(dX, refs["dgrad"]), wgrad=err(dW, refs["wgrad"]))
+        accuracy["measure"] = ("max |y - y_fp64| / max |y_fp64| on a 24576 x 512 x 512 layer, random normal operands (the friendliest "
+                               "distribution: see gemm_accuracy_in_situ for the step's real operands)")
         del Xa, Wa, dZa, refs
     if world == 1 and rank == 0:
         # BASELINE configs[3]: ONE planner launch over 4096 envs x 4 legs (12.7 MB: launch / latency-bound, not HBM-bound):
@@ -485,6 +497,27 @@ def run(a, rank, local_rank, world, wd):
     lib = _ffi.lib()
     overlap, overlap_rec = getattr(alg, "overlap_wgrad", False), getattr(alg, "overlap", False)
     alg.overlap_wgrad = alg.overlap = False
+    in_situ = None
+    if rank == 0 and world == 1 and a.workload == "decoder" and getattr(alg, "use_images", False) and not a.no_in_situ:
+        # every wide product of one serialised step checked against fp64 ON ITS ACTUAL OPERANDS (forward: the layer's real input image,
+        # weights and bias; data / weight gradients: the step's real, heavy-tailed dZ), right after its launch, next to the single-pass
+        # fp32 MFMA kernel on the same operands.  First two calls of every (kind, shape); outside the timed region.
+        h2i.capture_begin(per_key=2)
+        try:
+            step()
+            torch.cuda.synchronize()
+        finally:
+            rows = h2i.capture_end()
+        worst = lambda key, which, f: max((r[which][f] for r in rows[key] if r[which] is not None), default=None)
+        in_situ = {k: dict(calls=len(v), max_rel=worst(k, "h2i", "max_rel"), row_rel=worst(k, "h2i", "row_rel"),
+                           fp32_mfma_max_rel=worst(k, "fp32_mfma", "max_rel"), fp32_mfma_row_rel=worst(k, "fp32_mfma", "row_rel"),
+                           rows_span_decades=max(r["ref_rows_span"] for r in v), zero_rows=max(r["zero_rows"] for r in v))
+                   for k, v in sorted(rows.items())}
+        in_situ["measure"] = ("per product of one serialised bench step (first two calls of each shape): max_rel = max |y - y64| / max |y64|, "
+                              "row_rel = max over rows of (max |y - y64| of the row / max |y64| of the row), y64 = fp64 product of the SAME "
+                              "operands (decoded operand images, the step's real X / dZ / W / b; activation, sign record and added terms "
+                              "included); fp32_mfma_* = the single-pass v_mfma_f32_32x32x2_f32 kernels on those operands; rows_span_decades = "
+                              "log10(largest / smallest non-zero row magnitude of the result), zero_rows = rows of the result that are exactly zero")
     dp.trace_collectives(True)                       # N > 1: what one step exchanges, and that all ranks issue the same sequence
     step()
     torch.cuda.synchronize()
@@ -504,27 +537,36 @@ def run(a, rank, local_rank, world, wd):
         lib.dtc_prof_reset()
         # the GEMM family = forward / data-gradient / weight-gradient kernels AND the split-reduce kernels the weight
         # gradients need (their time counts against the family's FLOP; they add no FLOP of their own)
-        fam = ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_reduce", "gru_step_fwd", "wimage")
+        fam = ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_reduce", "gru_step_fwd", "wimage", "h2i_pack")
         gemm = [r for r in rep if r["name"].split("[")[0] in fam]
         # (the composite's GRU steps call the same three kernels from inside dtc_gru_fwd / dtc_gru_bwd)
         ms = sum(r["ms_total"] for r in gemm)
-        fl = sum(r["work"] for r in gemm if not r["name"].startswith(("wgrad_reduce", "wimage")))
+        fl = sum(r["work"] for r in gemm if not r["name"].startswith(("wgrad_reduce", "wimage", "h2i_pack")))
         n_launch = sum(r["launches"] for r in gemm)
         algo_bytes = sum(r["bytes"] for r in gemm)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         split = ops.SPLIT
         peak = split_peak(ops) if split else PEAK_FP32_MFMA_TFLOPS
-        roof = dict(bound="mfma",
-                    kernel=(("linear_s3_kernel<.., H2> (+ the weight-image launches), wgrad_s3_group_kernel<.., H2> (+ its reduce kernel): "
-                             "split-precision GEMM family -- every fp32 operand scaled by a power of two from its tensor's amax and written as "
-                             "two fp16 terms, three v_mfma_f32_32x32x16_f16 passes per product, fp32 accumulate (csrc/s3_core.hpp, gemm_s3.hip, "
-                             "wgrad_s3.hip); the recurrent kernels (gru_s3_kernel) keep three bf16 terms / six passes; the narrow layers "
-                             "(< 128 columns) stay on the single-pass v_mfma_f32_32x32x2_f32 kernels and are part of the family") if ops.H2 else
-                            ("linear_s3_kernel (+ the weight-image launches), wgrad_s3_group_kernel (+ its reduce kernel), gru_s3_kernel: "
-                             "split-precision GEMM family -- every fp32 operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 passes per "
-                             "product, fp32 accumulate (csrc/gemm_s3.hip, wgrad_s3.hip, gru_s3.hip); the narrow layers (< 128 columns) stay on "
-                             "the single-pass v_mfma_f32_32x32x2_f32 kernels and are part of the family")) if split else
-                           "linear_{fwd,dgrad}_kernel, wgrad_group_kernel (+ its split-reduce kernel): fp32 v_mfma_f32_32x32x2_f32 GEMM family",
+        if split and getattr(alg, "use_images", False) and not (composite or gru):
+            kernel_desc = ("linear_h2i_kernel<FWD | DGRAD | MSE> (both operands as block-scaled fp16 (hi, lo) images by LDS-DMA, no conversion in "
+                           "any K loop), wgrad_h2i_group_kernel (+ its reduce kernel), h2i_wpack_kernel (weight images, one launch per phase), "
+                           "h2i_pack_kernel (rollout rows -> images); csrc/gemm_h2i.hip, wgrad_h2i.hip: three v_mfma_f32_32x32x16_f16 passes per "
+                           "product, fp32 accumulate; the narrow layers (< 128 columns) run on the single-pass v_mfma_f32_32x32x2_f32 kernels "
+                           "and are part of the family")
+        elif split and ops.H2:
+            kernel_desc = ("linear_s3_kernel<.., H2> (+ the weight-image launches), wgrad_s3_group_kernel<.., H2> (+ its reduce kernel): "
+                           "split-precision GEMM family -- every fp32 operand scaled by a power of two from its tensor's amax and written as "
+                           "two fp16 terms, three v_mfma_f32_32x32x16_f16 passes per product, fp32 accumulate (csrc/s3_core.hpp, gemm_s3.hip, "
+                           "wgrad_s3.hip); the recurrent kernels (gru_s3_kernel) keep three bf16 terms / six passes; the narrow layers "
+                           "(< 128 columns) stay on the single-pass v_mfma_f32_32x32x2_f32 kernels and are part of the family")
+        elif split:
+            kernel_desc = ("linear_s3_kernel (+ the weight-image launches), wgrad_s3_group_kernel (+ its reduce kernel), gru_s3_kernel: "
+                           "split-precision GEMM family -- every fp32 operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 passes per "
+                           "product, fp32 accumulate (csrc/gemm_s3.hip, wgrad_s3.hip, gru_s3.hip); the narrow layers (< 128 columns) stay on "
+                           "the single-pass v_mfma_f32_32x32x2_f32 kernels and are part of the family")
+        else:
+            kernel_desc = "linear_{fwd,dgrad}_kernel, wgrad_group_kernel (+ its split-reduce kernel): fp32 v_mfma_f32_32x32x2_f32 GEMM family"
+        roof = dict(bound="mfma", kernel=kernel_desc,
                     achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
                     peak_definition=(("dense fp16 / bf16 MFMA peak 2516.6 TFLOP/s / 3 passes = 838.9 TFLOP/s of fp32-equivalent work "
                                       "(MI355X_MICROARCH.md); achieved counts the ALGORITHMIC fp32 FLOP (2 M N K per product), not the fp16 "
@@ -625,17 +667,30 @@ def run(a, rank, local_rank, world, wd):
             "metric": METRIC,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "gemm_arithmetic": (("f32 operands and results; wide layers on the fp16 matrix pipe as 2-term splits (x 2^e = hi + lo, e from the "
+            "vs_baseline": None,
+            "dtype": ("f32 (emulated: f16x2 split per operand, f32 accumulate)" if (ops.SPLIT and (ops.H2 or getattr(alg, "use_images", False)))
+                      else "f32 (emulated: bf16x3 split per operand, f32 accumulate)" if ops.SPLIT else "f32"),
+            "data": "synthetic",
+            "gemm_arithmetic": ("results, accumulation, narrow layers, losses and optimiser in f32; the operands of the wide layers (>= 128 columns) live "
+                                "in HBM as block-scaled two-term fp16 images (x 2^e = hi + lo: 22 significant bits; e per ROW and block of 128 "
+                                "columns from that block's own largest finite element, weights per 128 x 128 block), 3 fp16 MFMA passes per "
+                                "product (exact in the f32 accumulator; dropped lo lo' = 2^-22 of a product), accumulator rows rescaled exactly "
+                                "at block borders: every row is as accurate relative to ITSELF as an f32 dot product, whatever the other rows "
+                                "hold, and a non-finite element poisons only its own row / column (csrc/h2i_core.hpp).  Measured against fp64: "
+                                "gemm_accuracy (random operands) and gemm_accuracy_in_situ (the step's real operands).  DTC_H2I=0: round 4's "
+                                "converting kernels (tensor-amax scale); DTC_GEMM_SPLIT=0: single-pass fp32 MFMA everywhere"
+                                if getattr(alg, "use_images", False) and ops.SPLIT else
+                                ("f32 operands and results; wide layers on the fp16 matrix pipe as 2-term splits (x 2^e = hi + lo, e from the "
                                  "tensor's amax: 22 significant bits, the sums scaled back exactly), 3 MFMA passes, fp32 accumulate -- the error "
                                  "level of the fp32 MFMA chain, measured below against fp64 next to the single-pass fp32 MFMA kernels and the "
                                  "bf16 x 3 / six-pass kernels (DTC_GEMM_SPLIT=1); DTC_GEMM_SPLIT=0 selects the single-pass kernels everywhere")
                                 if ops.H2 else
                                 ("f32 operands and results; wide layers on the bf16 matrix pipe as 3-term splits (a = a1 + a2 + a3 exactly to 2^-24), "
                                  "6 MFMA passes, fp32 accumulate -- fp32-level accuracy, measured below against fp64 next to the single-pass "
-                                 "fp32 MFMA kernels; DTC_GEMM_SPLIT=0 selects the single-pass kernels everywhere")) if ops.SPLIT else
-                               "f32 single-pass v_mfma_f32_32x32x2_f32 (DTC_GEMM_SPLIT=0)",
+                                 "fp32 MFMA kernels; DTC_GEMM_SPLIT=0 selects the single-pass kernels everywhere") if ops.SPLIT else
+                                "f32 single-pass v_mfma_f32_32x32x2_f32 (DTC_GEMM_SPLIT=0)"),
             "gemm_accuracy": accuracy,
+            "gemm_accuracy_in_situ": in_situ,
             "config": {"workload": ("BASELINE configs[1]: 4096 envs x 24 steps per GPU, ActorCriticDecoder (CE-net + "
                                     "terrain encoder latent 512 + MLP actor/critic): foothold planner over the 98304 "
                                     "recorded height maps + compute_returns + PPO.update (5 epochs x 4 mini-batches of 24576)")

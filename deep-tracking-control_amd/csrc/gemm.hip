@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : (BN == 128 ? 2 : DTC_FWD_WAVES)) vo
                 for (int p = 0; p < 4; ++p) {
                     f32x4 v = patch_get(patch, prow + 8 * p, pc4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] <= 0.f ? 0.f : v[e];      // (NaN passes through, as torch.relu)
                     *reinterpret_cast<f32x4*>(yp + (long long)(8 * p) * ldy) = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) seen(v[e]);

@@ -64,7 +64,7 @@ __device__ __attribute__((noinline)) float act_bwd_rare(float g, float y, int ac
     }
 }
 __device__ __forceinline__ float act_fwd(float v, int act) {
-    if (act == DTC_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DTC_ACT_RELU) return v <= 0.f ? 0.f : v;          // (NaN passes through, as torch.relu)
     if (act == DTC_ACT_ELU) return v > 0.f ? v : expm1f(v);
     if (act > DTC_ACT_ELU) return act_fwd_rare(v, act);
     return v;

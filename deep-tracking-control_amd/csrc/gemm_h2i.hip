@@ -101,7 +101,7 @@ struct WpackJob {
     long long ld;
     u32x4* img;
     int* exps;               // [row tiles][tblocks]
-    int trans, r0, nr, nseg, c0[4], cw[4];
+    int trans, nrows, r0[2], nr[2], nseg, c0[4], cw[4];
     int tstages, tblocks, block_end;      // block_end: running sum of (row tiles x tblocks) over the jobs
 };
 struct WpackGroup {
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void h2i_wpack_kernel(const WpackGroup G) {
         ++sg;
     }
     const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;
-    const int row = ct * 128 + r;
+    const int t0 = (J.nr[0] + 127) >> 7, rg = (J.nrows > 1 && ct >= t0) ? 1 : 0;        // the row range this tile lies in
+    const int row = (ct - (rg ? t0 : 0)) * 128 + r, nrg = J.nr[rg], src0 = J.r0[rg];
     const int nst = (int)hi_stages(J.cw[sg]);
     float v[HI_KB][8];
     u32 mx = 0u;
@@ -130,9 +131,9 @@ __global__ __launch_bounds__(256) void h2i_wpack_kernel(const WpackGroup G) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = (gb * HI_KB + s) * 16 + 8 * h + e;
-            const bool ok = row < J.nr && c < J.cw[sg];
+            const bool ok = row < nrg && c < J.cw[sg];
             const long long cc = J.c0[sg] + c;
-            v[s][e] = ok ? (J.trans ? J.W[cc * J.ld + J.r0 + row] : J.W[(long long)(J.r0 + row) * J.ld + cc]) : 0.f;
+            v[s][e] = ok ? (J.trans ? J.W[cc * J.ld + src0 + row] : J.W[(long long)(src0 + row) * J.ld + cc]) : 0.f;
             const u32 bb = finite_bits(v[s][e]);
             mx = bb > mx ? bb : mx;
         }
@@ -248,16 +249,22 @@ template <int EPI>
 __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, const u32x4* __restrict__ wimg, u32 wimg_bytes,
                                                             const int* __restrict__ wexps, const float* __restrict__ bias,
                                                             float* __restrict__ Y, long long ldy, const HOut yo, int M, int N, int act, int wide,
-                                                            unsigned short* __restrict__ wmask, int ldwm, const DgradEpiH dg, const MseEpiH mse) {
+                                                            unsigned short* __restrict__ wmask, int ldwm, const DgradEpiH dg, const MseEpiH mse,
+                                                            unsigned long long* __restrict__ trace) {
     constexpr int BN = 128, WN = 2, TM = 2, TN = 2;
     // separate objects per stage buffer: an LDS-DMA into one cannot alias the fragment reads of the other (see linear_s3_kernel)
+    // THREE stage buffers: the LDS-DMA of stage s + 2 is issued while stage s computes.  (One stage ahead -- the first version of this
+    // kernel -- left every workgroup waiting at its barrier for a transfer issued 12 MFMAs earlier: per-workgroup time stamps, tools/
+    // h2i_trace.py, showed 0.81 us per stage against 0.53 us of matrix-pipe time for the three co-resident waves of a SIMD.)
     __shared__ __attribute__((aligned(16))) u32x2 Xs0[2][BM * 4];
     __shared__ __attribute__((aligned(16))) u32x2 Xs1[2][BM * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Xs2[2][BM * 4];
     __shared__ __attribute__((aligned(16))) u32x2 Ws0[2][BN * 4];
     __shared__ __attribute__((aligned(16))) u32x2 Ws1[2][BN * 4];
+    __shared__ __attribute__((aligned(16))) u32x2 Ws2[2][BN * 4];
     __shared__ __attribute__((aligned(16))) int Dt[MAX_TB + 1][128];      // exponent deltas per block border and row; [tblocks]: the final scale
-#define XS(b) ((b) ? Xs1 : Xs0)
-#define WS(b) ((b) ? Ws1 : Ws0)
+#define XS(b) ((b) == 0 ? Xs0 : (b) == 1 ? Xs1 : Xs2)
+#define WS(b) ((b) == 0 ? Ws0 : (b) == 1 ? Ws1 : Ws2)
     int tr, tc;
     if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, tr, tc)) {
         if (EPI == EPI_MSE && threadIdx.x == 0) mse.part[blockIdx.x] = 0.0;
@@ -265,6 +272,10 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (trace && tid == 0) {                              // debug (dtc_h2i_trace): per-workgroup time stamps (100 MHz) and placement
+        trace[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID
+    }
     const int m0 = tr * BM, n0 = tc * BN;
     const int wm_off = (wave / WN) * (32 * TM), wn_off = (wave % WN) * (32 * TN);
     const int half = lane >> 5, l31 = lane & 31;
@@ -294,6 +305,7 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
         }
     };
     load_stage(S0{});
+    load_stage(S1{});
 
     // ---- exponent deltas: thread r < 128 walks the blocks of row r.  e(b) = row exponent + weight-block exponent; a block without
     // content (HI_EZERO) inherits its predecessor's (its products are zero whatever the scale)
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
             rescale(blk);
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_stage(std::integral_constant<int, buf ^ 1>{});       // the next stage's pieces first (hipcc otherwise sinks them behind the MFMAs)
+        load_stage(std::integral_constant<int, (buf + 2) % 3>{});   // the pieces of stage s + 2 first (hipcc otherwise sinks them behind the MFMAs)
         __builtin_amdgcn_sched_barrier(0);
         u32x4 a[TM][2], b[TN][2];
         auto rda = [&](int i, int p) { a[i][p] = reinterpret_cast<const u32x4*>(&XS(buf)[p][0])[rslot(wm_off + 32 * i + l31, half)]; };
@@ -379,13 +391,19 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
             ++cseg;
             cst = 0;
         }
-        __syncthreads();
+        // stage s + 1 has landed (this wave's four newest transfers -- stage s + 2 -- may still be in flight: vmcnt(4), the other counters
+        // untouched); then every wave's share has.  A raw barrier: __syncthreads() would wait for ALL transfers
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+        __builtin_amdgcn_s_barrier();
     };
     __syncthreads();
-    for (int trip = (A.total + 1) >> 1; trip > 0; --trip) {
+    for (int trip = (A.total + 2) / 3; trip > 0; --trip) {
         stage(S0{});
         stage(S1{});
+        stage(std::integral_constant<int, 2>{});
     }
+    __syncthreads();                                     // (the transfers past the last stage -- zeros -- have landed too)
+    if (trace && tid == 0) trace[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     // every wave is past its last fragment read and every LDS-DMA has landed (the barrier's wait): LDS becomes the patches
     rescale(A.tblocks);                                  // back to the values themselves (2^-e of the last block, exact)
     float* patch = reinterpret_cast<float*>(wave < 2 ? &Xs0[0][0] : &Xs1[0][0]) + (wave & 1) * (32 * LDW);
@@ -411,7 +429,7 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
             }
             if (act == DTC_ACT_RELU) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] <= 0.f ? 0.f : acc[i][j][r];      // (NaN passes through, as torch.relu)
             } else if (act == DTC_ACT_ELU) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : expm1f(acc[i][j][r]);
@@ -547,7 +565,10 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
     if (EPI == EPI_MSE && lane == 0) red[wave] = sq;
     if (yo.img || EPI == EPI_MSE) __syncthreads();
     if (EPI == EPI_MSE && tid == 0) mse.part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
-    if (yo.img == nullptr) return;
+    if (yo.img == nullptr) {
+        if (trace && tid == 0) trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+        return;
+    }
     u32x4* tile_chunks = yo.img + (long long)tr * yo.stages * (HI_CHUNK / 16);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -568,9 +589,12 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
                 chunk[256 + rslot(rloc, (lc >> 3) & 1)] = pc.p[1];
             }
         }
+    if (trace && tid == 0) trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 #undef XS
 #undef WS
 }
+
+unsigned long long* g_trace = nullptr;      // debug: dtc_h2i_trace
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 int check_img(const void* img, const char* what) {
@@ -627,6 +651,10 @@ WimgView wimg_view(const void* wimg, int nr, const HOperand& A) {
 
 }  // namespace
 
+// debug: the image-operand GEMM launches that follow write per-workgroup records {start, K loop done, end (100 MHz ticks), HW_ID} to
+// `buf` (4 x grid uint64, device; NULL: off)
+extern "C" void dtc_h2i_trace(void* buf) { g_trace = (unsigned long long*)buf; }
+
 extern "C" int64_t dtc_h2i_bytes(int M, int K) {
     if (M <= 0 || K <= 0) return 0;
     return hi_bytes(M, K);
@@ -664,15 +692,28 @@ extern "C" int dtc_h2i_unpack(const void* img, int M, int K, float* out, int64_t
     return dtc::check_launch("h2i_unpack");
 }
 
+namespace {
+long long wjob_tiles(const DtcH2iWJob& h) {
+    if (h.nrows < 1 || h.nrows > 2) return -1;
+    long long ct = 0;
+    for (int i = 0; i < h.nrows; ++i) {
+        if (h.nr[i] <= 0 || h.r0[i] < 0 || (i + 1 < h.nrows && h.nr[i] % 128 != 0)) return -1;
+        ct += dtc::ceil_div(h.nr[i], 128);
+    }
+    return ct;
+}
+}  // namespace
+
 extern "C" int64_t dtc_h2i_wimage_bytes(const DtcH2iWJob* job) {
-    if (job == nullptr || job->nr <= 0 || job->nseg < 1 || job->nseg > 4) return -1;
+    if (job == nullptr || job->nseg < 1 || job->nseg > 4) return -1;
+    const long long ct = wjob_tiles(*job);
+    if (ct < 0) return -1;
     long long st = 0, tb = 0;
     for (int i = 0; i < job->nseg; ++i) {
         if (job->cw[i] <= 0) return -1;
         st += hi_stages(job->cw[i]);
         tb += hi_kblocks(job->cw[i]);
     }
-    const long long ct = dtc::ceil_div(job->nr, 128);
     return ct * st * HI_CHUNK + ((ct * tb * 4 + 15) & ~15ll);
 }
 
@@ -685,7 +726,7 @@ extern "C" int dtc_h2i_wimage_group(const DtcH2iWJob* jobs, int count, void* str
     for (int i = 0; i < count; ++i) {
         int red = 0;
         for (int k = 0; k < jobs[i].nseg && k < 4; ++k) red += jobs[i].cw[k];
-        elems += (double)jobs[i].nr * red;
+        elems += (double)(jobs[i].nr[0] + (jobs[i].nrows > 1 ? jobs[i].nr[1] : 0)) * red;
     }
     dtc::ProfScope prof("wimage", 0.0, s, 8.0 * elems);
     WpackGroup G;
@@ -697,14 +738,19 @@ extern "C" int dtc_h2i_wimage_group(const DtcH2iWJob* jobs, int count, void* str
     };
     for (int i = 0; i < count; ++i) {
         const DtcH2iWJob& h = jobs[i];
-        DTC_REQUIRE(h.W && h.img && dtc::aligned16(h.img) && h.nr > 0 && h.r0 >= 0 && h.ld > 0 && h.nseg >= 1 && h.nseg <= 4, "job %d: null pointer / bad shape", i);
+        DTC_REQUIRE(h.W && h.img && dtc::aligned16(h.img) && h.ld > 0 && h.nseg >= 1 && h.nseg <= 4, "job %d: null pointer / bad shape", i);
+        const long long ct = wjob_tiles(h);
+        DTC_REQUIRE(ct > 0, "job %d: bad row ranges (1..2, all but the last a multiple of 128 long)", i);
         WpackJob& J = G.job[G.count];
         J.W = h.W;
         J.ld = h.ld;
         J.img = (u32x4*)h.img;
         J.trans = h.trans;
-        J.r0 = h.r0;
-        J.nr = h.nr;
+        J.nrows = h.nrows;
+        for (int k = 0; k < 2; ++k) {
+            J.r0[k] = k < h.nrows ? h.r0[k] : 0;
+            J.nr[k] = k < h.nrows ? h.nr[k] : 0;
+        }
         J.nseg = h.nseg;
         J.tstages = J.tblocks = 0;
         for (int k = 0; k < 4; ++k) {
@@ -717,7 +763,6 @@ extern "C" int dtc_h2i_wimage_group(const DtcH2iWJob* jobs, int count, void* str
             }
         }
         DTC_REQUIRE(J.tblocks <= MAX_TB, "job %d: %d exponent blocks along the reduction, at most %d", i, J.tblocks, MAX_TB);
-        const long long ct = dtc::ceil_div(h.nr, 128);
         DTC_REQUIRE(ct * J.tstages * HI_CHUNK < (1ll << 31), "job %d: image beyond 2 GiB", i);
         J.exps = reinterpret_cast<int*>(reinterpret_cast<char*>(h.img) + ct * J.tstages * HI_CHUNK);
         J.block_end = (int)(ct * J.tblocks) + (G.count > 0 ? G.job[G.count - 1].block_end : 0);
@@ -749,7 +794,7 @@ extern "C" int dtc_linear_fwd_h2i(const DtcH2iOperand* X, const void* wimg, cons
                         4.0 * M * (double)K + 4.0 * N * (double)K + (Y ? 4.0 : 0.0) * M * N + (Yimg ? 4.0 : 0.0) * M * N);
     hipLaunchKernelGGL((linear_h2i_kernel<EPI_FWD>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, A,
                        wv.img, wv.bytes, wv.exps, b, Y, (long long)ldy, to_out(Yimg, M, N), M, N, act, wide, (unsigned short*)relu_mask, N,
-                       DgradEpiH{}, MseEpiH{});
+                       DgradEpiH{}, MseEpiH{}, g_trace);
     return dtc::check_launch("linear_fwd_h2i");
 }
 
@@ -781,7 +826,7 @@ extern "C" int dtc_linear_fwd_mse_h2i(const DtcH2iOperand* X, const void* wimg, 
                         4.0 * M * (double)K + 4.0 * N * (double)K + 4.0 * M * N + (dY ? 4.0 : 0.0) * M * N + (dYimg ? 4.0 : 0.0) * M * N);
     hipLaunchKernelGGL((linear_h2i_kernel<EPI_MSE>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, A,
                        wv.img, wv.bytes, wv.exps, b, dY, (long long)lddy, to_out(dYimg, M, N), M, N, (int)DTC_ACT_NONE, wide,
-                       (unsigned short*)nullptr, 0, DgradEpiH{}, mse);
+                       (unsigned short*)nullptr, 0, DgradEpiH{}, mse, g_trace);
     return dtc::check_launch("linear_fwd_mse_h2i");
 }
 
@@ -789,9 +834,12 @@ extern "C" int dtc_linear_fwd_mse_h2i(const DtcH2iOperand* X, const void* wimg, 
 // column of the window, nr = Kwin, one reduction range (0, N)).  Results over the window: fp32 destination blocks dX (may be NULL;
 // accumulate flags honoured) and / or the image dXimg = image(M, Kwin).  add (may be NULL): fp32 [M, ld_add] added to the product first.
 // Activation derivative: relu_mask (sign record) or Xsaved with act; both need the window to start at the saved tensor's column 0.
-extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT, int Kwin, const DtcSegMat* dX, void* dXimg, const float* add,
-                                    int64_t ld_add, const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, int M, int act, void* stream) {
-    DTC_REQUIRE(M > 0 && N > 0 && Kwin > 0, "bad shape");
+extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT, int Kwin, const DtcSegMat* dX, void* dXimg, int img_cols,
+                                    const float* add, int64_t ld_add, const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, int M, int act,
+                                    void* stream) {
+    DTC_REQUIRE(M > 0 && N > 0 && Kwin > 0 && img_cols >= 0 && img_cols <= Kwin, "bad shape");
+    if (img_cols == 0) img_cols = Kwin;
+    DTC_REQUIRE(img_cols == Kwin || img_cols % 128 == 0, "image of the window's first %d columns: must be whole 128-column blocks", img_cols);
     DTC_REQUIRE((dX || dXimg) && dtc::aligned16(dXimg), "no result / unaligned image");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
     DTC_REQUIRE(relu_mask || act == DTC_ACT_NONE || (Xsaved != nullptr && ldxs >= Kwin), "activation derivative needs Xsaved");
@@ -829,7 +877,7 @@ extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT,
     const int wide = ((dg.Xs && ldxs % 4 == 0 && dtc::aligned16(dg.Xs)) ? 2 : 0) | ((add && ld_add % 4 == 0 && dtc::aligned16(add)) ? 4 : 0);
     const WimgView wv = wimg_view(wimgT, Kwin, A);
     hipStream_t s = (hipStream_t)stream;
-    double bytes = 4.0 * M * (double)N + 4.0 * N * (double)Kwin + (dXimg ? 4.0 : 0.0) * M * Kwin + (add ? 4.0 : 0.0) * M * Kwin;
+    double bytes = 4.0 * M * (double)N + 4.0 * N * (double)Kwin + (dXimg ? 4.0 : 0.0) * M * img_cols + (add ? 4.0 : 0.0) * M * Kwin;
     if (dX)
         for (int i = 0; i < dg.dX.nseg; ++i)
             if (dg.dX.s[i].ptr) bytes += 4.0 * M * dg.dX.s[i].width * (dg.dX.s[i].accumulate ? 2.0 : 1.0);
@@ -837,7 +885,7 @@ extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT,
     else if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)Kwin;
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, Kwin), 2.0 * M * (double)N * Kwin, s, bytes);
     hipLaunchKernelGGL((linear_h2i_kernel<EPI_DGRAD>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(Kwin, 128))), dim3(256), 0, s, A,
-                       wv.img, wv.bytes, wv.exps, (const float*)nullptr, (float*)nullptr, 0ll, to_out(dXimg, M, Kwin), M, Kwin,
-                       relu_mask ? (int)DTC_ACT_RELU : act, wide, (unsigned short*)nullptr, 0, dg, MseEpiH{});
+                       wv.img, wv.bytes, wv.exps, (const float*)nullptr, (float*)nullptr, 0ll, to_out(dXimg, M, img_cols), M, Kwin,
+                       relu_mask ? (int)DTC_ACT_RELU : act, wide, (unsigned short*)nullptr, 0, dg, MseEpiH{}, g_trace);
     return dtc::check_launch("linear_dgrad_h2i");
 }

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                 }
                 if (act == DTC_ACT_RELU) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : 0.f;
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] <= 0.f ? 0.f : acc[i][j][r];      // (NaN passes through, as torch.relu)
                 } else if (act == DTC_ACT_ELU) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : expm1f(acc[i][j][r]);
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
                     } else if (act == DTC_ACT_RELU) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] <= 0.f ? 0.f : v[e];      // (NaN passes through, as torch.relu)
                     } else if (act != DTC_ACT_NONE) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], act);
@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(256 * RT, RT == 1 ? 3 : 1) void linear_i3_kernel(co
             }
             if (act == DTC_ACT_RELU) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] <= 0.f ? 0.f : acc[i][j][r];      // (NaN passes through, as torch.relu)
             } else if (act == DTC_ACT_ELU) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : expm1f(acc[i][j][r]);

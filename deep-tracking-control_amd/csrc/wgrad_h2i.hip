@@ -43,16 +43,19 @@ struct HGroup {
 
 __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G) {
     // separate objects per stage buffer: an LDS-DMA into one cannot alias the fragment reads of the other
+    // (three stage buffers: the transfers run two stages ahead of the MFMAs, see linear_h2i_kernel)
     __shared__ __attribute__((aligned(16))) unsigned char A0[2][4096];
     __shared__ __attribute__((aligned(16))) unsigned char A1[2][4096];
+    __shared__ __attribute__((aligned(16))) unsigned char A2[2][4096];
     __shared__ __attribute__((aligned(16))) unsigned char B0[2][4096];
     __shared__ __attribute__((aligned(16))) unsigned char B1[2][4096];
+    __shared__ __attribute__((aligned(16))) unsigned char B2[2][4096];
     __shared__ __attribute__((aligned(16))) _Float16 Ft[2][128];      // f[m] of the block in flight / the next one
     __shared__ __attribute__((aligned(16))) _Float16 Fb[2][128];      // fb[m]
     __shared__ int Tt[2][2];                                          // (T, Tz) per table
     __shared__ int Tred[4][2];
-#define AS(b) ((b) ? A1 : A0)
-#define BS(b) ((b) ? B1 : B0)
+#define AS(b) ((b) == 0 ? A0 : (b) == 1 ? A1 : A2)
+#define BS(b) ((b) == 0 ? B0 : (b) == 1 ? B1 : B2)
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int split = xcd + 8 * (jb / G.tiles_total);
     if (split >= G.splits) return;
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G)
     if (KT > 0) {
         table_request(m_begin);
         load_stage(S0{}, m_begin);
+        load_stage(S1{}, m_begin + BK);
         table_minima();
         __syncthreads();
         table_finish(0, 0, 0);
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G)
     }
     auto stage = [&](auto bc, int kt) {
         constexpr int buf = decltype(bc)::value;
+        if (kt >= KT) return;                                 // (uniform) the trip's spare stages: nothing to add (and no scale table behind them)
         const int mb = m_begin + kt * BK, which = (kt >> 3) & 1, ph = kt & 7, srow = ph * 16;
         const bool bias = want_bias && (kt % J.col_tiles) == tc;
         const bool more = kt + (8 - ph) < KT;                 // another block follows this one
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G)
         f16x8 fbv = fv;
         if (bias && wc == 0) fbv = *reinterpret_cast<const f16x8*>(&Fb[which][srow + 8 * khalf]);
         __builtin_amdgcn_sched_barrier(0);
-        load_stage(std::integral_constant<int, buf ^ 1>{}, mb + BK);                  // the next stage's pieces first (see linear_h2i_kernel)
+        load_stage(std::integral_constant<int, (buf + 2) % 3>{}, mb + 2 * BK);        // the pieces of stage kt + 2 first (see linear_h2i_kernel)
         __builtin_amdgcn_sched_barrier(0);
         f16x8 a[2][2], b[2][2];
 #pragma unroll
@@ -239,12 +244,15 @@ __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G)
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ph == 6 && more) table_minima();                  // the exponents requested at the stage's head have long arrived
-        __syncthreads();
+        // stage kt + 1 has landed (this wave's four newest transfers may still be in flight), the table writes are done: raw barrier
+        __builtin_amdgcn_s_waitcnt(0x0070 | 4);               // vmcnt(4), lgkmcnt(0), expcnt untouched
+        __builtin_amdgcn_s_barrier();
     };
-    // two stages per trip (constant buffer indices); KT is even (a multiple of 8)
-    for (int kt = 0; kt < KT; kt += 2) {
+    // three stages per trip (constant buffer indices); KT is a multiple of 8: the last trip's spare stages do nothing
+    for (int kt = 0; kt < KT; kt += 3) {
         stage(S0{}, kt);
         stage(S1{}, kt + 1);
+        stage(std::integral_constant<int, 2>{}, kt + 2);
     }
 
     // ---- epilogue: accumulators (2^T x the sums) -> slab tile [128][128] in logical order (float4 rows through the wave's LDS patch)
@@ -284,13 +292,22 @@ __global__ __launch_bounds__(256) void wgrad_h2i_reduce_kernel(const HGroup G) {
         int j = 0, rt = b;
         while (j < G.count - 1 && rt >= G.job[j].row_tiles) { rt -= G.job[j].row_tiles; ++j; }
         const HJob& J = G.job[j];
-        if (rt >= J.row_tiles || J.db == nullptr || threadIdx.x >= TILE) return;
-        const int n = rt * TILE + threadIdx.x;
-        if (n >= J.N) return;
-        float s = 0.f;
-        for (int sp = 0; sp < G.splits; ++sp)
-            for (int c = 0; c < J.col_tiles; ++c) s += J.bpart[(((long long)sp * J.col_tiles + c) * J.row_tiles + rt) * TILE + threadIdx.x];
-        J.db[n] = s;
+        if (rt >= J.row_tiles || J.db == nullptr) return;
+        // thread = (feature n, half of the slices): independent loads, a fixed order of additions (4 running sums per thread, then the two
+        // halves through LDS)
+        __shared__ float hsum[TILE];
+        const int nl = threadIdx.x & (TILE - 1), hf = threadIdx.x >> 7;
+        const int per = (G.splits + 1) >> 1, s0 = hf * per, s1 = min(G.splits, s0 + per);
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        int q = 0;
+        for (int sp = s0; sp < s1; ++sp)
+            for (int c = 0; c < J.col_tiles; ++c, ++q)
+                a4[q & 3] += J.bpart[(((long long)sp * J.col_tiles + c) * J.row_tiles + rt) * TILE + nl];
+        const float mine = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        if (hf == 1) hsum[nl] = mine;
+        __syncthreads();
+        const int n = rt * TILE + nl;
+        if (hf == 0 && n < J.N) J.db[n] = mine + hsum[nl];
         return;
     }
     int t = b >> 4;

@@ -55,8 +55,8 @@ class DtcWgradImgJob(C.Structure):
 
 
 class DtcH2iWJob(C.Structure):
-    _fields_ = [("W", C.c_void_p), ("ld", C.c_int64), ("img", C.c_void_p), ("trans", C.c_int32), ("r0", C.c_int32), ("nr", C.c_int32),
-                ("nseg", C.c_int32), ("c0", C.c_int32 * 4), ("cw", C.c_int32 * 4)]
+    _fields_ = [("W", C.c_void_p), ("ld", C.c_int64), ("img", C.c_void_p), ("trans", C.c_int32), ("nrows", C.c_int32), ("nseg", C.c_int32),
+                ("r0", C.c_int32 * 2), ("nr", C.c_int32 * 2), ("c0", C.c_int32 * 4), ("cw", C.c_int32 * 4)]
 
 
 class DtcH2iOperand(C.Structure):
@@ -154,6 +154,7 @@ _SIGS = {
     "dtc_wgrad_group_i3_workspace": (C.c_int64, [C.POINTER(DtcWgradImgJob), C.c_int, C.c_int]),
     "dtc_wgrad_group_i3": (C.c_int, [C.POINTER(DtcWgradImgJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_h2i_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "dtc_h2i_trace": (None, [C.c_void_p]),
     "dtc_h2i_pack": (C.c_int, [C.POINTER(DtcSegMat), C.c_int, C.c_void_p, c_stream]),
     "dtc_h2i_unpack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, C.c_int64, c_stream]),
     "dtc_h2i_wimage_bytes": (C.c_int64, [C.POINTER(DtcH2iWJob)]),
@@ -163,7 +164,7 @@ _SIGS = {
     "dtc_linear_fwd_mse_h2i_parts": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_linear_fwd_mse_h2i": (C.c_int, [C.POINTER(DtcH2iOperand), C.c_void_p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, c_i64p, C.c_float,
                                          c_f32p, C.c_int64, C.c_void_p, c_f64p, C.c_int, C.c_int, c_stream]),
-    "dtc_linear_dgrad_h2i": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(DtcSegMat), C.c_void_p, c_f32p, C.c_int64, c_f32p,
+    "dtc_linear_dgrad_h2i": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(DtcSegMat), C.c_void_p, C.c_int, c_f32p, C.c_int64, c_f32p,
                                        C.c_int64, C.c_void_p, C.c_int, C.c_int, c_stream]),
     "dtc_wgrad_group_h2i_workspace": (C.c_int64, [C.POINTER(DtcWgradH2iJob), C.c_int, C.c_int]),
     "dtc_wgrad_group_h2i": (C.c_int, [C.POINTER(DtcWgradH2iJob), C.c_int, C.c_int, C.c_void_p, c_stream]),

@@ -124,12 +124,13 @@ class _Lanes:
 
     def __init__(self, dev):
         self.side = torch.cuda.Stream(device=dev)
+        self.side2 = torch.cuda.Stream(device=dev)      # image chain: the narrow layers' (latency-bound) weight-gradient group beside the wide one
         self.aux = torch.cuda.Stream(device=dev)
         self.main = None                    # torch's current stream at the start of the step
         self.two_lanes = False
         self._events, self._ev_next = [], 0
-        self.joined = torch.cuda.Event()
-        self.side_busy = False
+        self.joined, self.joined2 = torch.cuda.Event(), torch.cuda.Event()
+        self.side_busy = self.side2_busy = False
 
     def begin(self, two_lanes):
         self.main = torch.cuda.current_stream()
@@ -167,6 +168,10 @@ class _Lanes:
             self.joined.record(self.side)
             self.main.wait_event(self.joined)
             self.side_busy = False
+        if self.side2_busy:
+            self.joined2.record(self.side2)
+            self.main.wait_event(self.joined2)
+            self.side2_busy = False
         self._ev_next = 0
 
 
@@ -302,6 +307,7 @@ class PPO:
         # the wide stacks on operand images (dtc_amd/h2i.py: activations / gradients live in HBM as the fp16 (hi, lo) planes the GEMM
         # kernels read by LDS-DMA, per-row exponents, written once by the producing epilogue); DTC_H2I=0: round 4's converting kernels
         self.use_images = os.environ.get("DTC_H2I", "1") != "0"
+        self.side2_wgrad = os.environ.get("DTC_WGRAD_SIDE2", "1") != "0"
         self._wsets = {}                   # phase -> h2i.WeightSet (weight images, one grouped launch per phase)
         # tests: callable(fw, which) run between the forward and the backward pass of a step ("vae" | "ppo"); the parity tests
         # use it to teacher-force the ReLU sign records (fw.relu_mask buffers) so that fp32 knife edges -- pre-activations that
@@ -443,6 +449,10 @@ class PPO:
             ev = tw.event()
             ev.record(lane)
             tw.side.wait_event(ev)
+        if tw.side2_busy:                                          # the narrow layers' group ran beside the wide one: the bucket needs both
+            ev = tw.event()
+            ev.record(tw.side2)
+            tw.side.wait_event(ev)
         with torch.cuda.stream(tw.side):
             dp.allreduce_mean_(self.actor_critic.arena.exchange_view(name))
         tw.side_busy = True
@@ -511,19 +521,25 @@ class PPO:
         narrow = tw.narrow_wgrad                               # image chain: the fp32 jobs are the narrow layers -> single-pass kernels
         ws = tw.group_ws(jobs, False if narrow else None) if jobs else None
         ws_img = tw.group_ws_img(jobs_img) if jobs_img else None
-        sp = None
+        sp = sp2 = None
         if self.overlap_wgrad:
+            two = bool(jobs_img) and bool(jobs) and narrow and self.side2_wgrad      # the narrow group runs BESIDE the wide one
             lanes = (tw.main, tw.aux) if tw.two_lanes else (torch.cuda.current_stream(),)
             for lane in lanes:
                 ev = tw.event()
                 ev.record(lane)
                 tw.side.wait_event(ev)
-            sp = tw.side.cuda_stream
+                if two:
+                    tw.side2.wait_event(ev)
+            sp = sp2 = tw.side.cuda_stream
             tw.side_busy = True
+            if two:
+                sp2 = tw.side2.cuda_stream
+                tw.side2_busy = True
         if jobs_img:
             tw.held.append(h2i.wgrad_group(jobs_img, tw.B, ws_img, stream_ptr=sp))
         if jobs:
-            tw.held.append(ops.wgrad_group(jobs, tw.B, ws, stream_ptr=sp, split=False if narrow else None))
+            tw.held.append(ops.wgrad_group(jobs, tw.B, ws, stream_ptr=sp2, split=False if narrow else None))
 
     def _join(self, tw):
         self._flush_wgrads(tw)
@@ -802,8 +818,9 @@ class PPO:
         nb = ac.num_obs + 19                                       # width of the narrow block [obs | z | mu[:, :3]]
         self._bwd_img(tw, L["a0"], g_a1i, Xa[0], wcol0=nb)         # columns of dW that meet l_t ...
         self._bwd_img(tw, L["a0"], g_a1i, Xa[1], wcol0=0, bias=False)        # ... and the narrow block
-        h2i.linear_dgrad(g_a1i, L["a0"].W, None, tw.img("dlt", 512), window=(nb, 512), wset=wset)
-        h2i.linear_dgrad(g_a1i, L["a0"].W, segmat([seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3)]), None, window=(ac.num_obs, 19), wset=wset)
+        # ONE launch over W's columns [72, 584) then [53, 72): d l_t as an image (four 128-column tiles), dz | d mu[:, :3] as fp32 (a fifth)
+        h2i.linear_dgrad(g_a1i, L["a0"].W, segmat([seg(None, 0, 512), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3)]), tw.img("dlt", 512),
+                         window=[(nb, 512), (ac.num_obs, 19)], wset=wset)
         tw.live_img |= {"dlt", "g_a2", "g_a1", "g_c2", "g_c1"}
 
     def _adaptive(self):

@@ -63,6 +63,72 @@ class HImage:
         return self.buf.view(torch.int32)[off // 4: off // 4 + rt * kb * 128].view(rt, kb, 128)
 
 
+# ---------------------------------------------------------------- in-situ accuracy capture (bench.py: gemm_accuracy_in_situ)
+CAPTURE = None       # dict while a capture runs: every product below is checked against fp64 on its ACTUAL operands, right after its launch
+
+
+def capture_begin(per_key=2):
+    """From here on every image-operand product records, for the first `per_key` calls of each (kind, shape): the largest element error
+    and the largest per-row relative error against an fp64 product of the SAME operands (the decoded images), next to the single-pass
+    fp32 MFMA kernel on those operands.  Synchronous and slow: run one serialised step inside it (overlap off)."""
+    global CAPTURE
+    CAPTURE = dict(per_key=per_key, rows={}, count={})
+
+
+def capture_end():
+    global CAPTURE
+    out, CAPTURE = CAPTURE, None
+    return out["rows"] if out else {}
+
+
+def _errs(y, ref):
+    y, ref = y.double(), ref.double()
+    d = (y - ref).abs()
+    den = ref.abs().amax(dim=1)
+    live = den > 0
+    row = float((d.amax(dim=1)[live] / den[live]).max()) if bool(live.any()) else 0.0
+    return dict(max_rel=float(d.max() / ref.abs().max().clamp_min(1e-300)), row_rel=row)
+
+
+def _cap_want(kind, shape):
+    c = CAPTURE
+    if c is None or c.get("busy"):
+        return None
+    key = f"{kind}[{'x'.join(str(v) for v in shape)}]"
+    n = c["count"].get(key, 0)
+    if n >= c["per_key"]:
+        return None
+    c["count"][key] = n + 1
+    return key
+
+
+def _cap_put(key, got, ref, native):
+    rm = ref.abs().amax(dim=1)
+    rm = rm[rm > 0]
+    e = dict(h2i=_errs(got, ref), fp32_mfma=_errs(native, ref) if native is not None else None,
+             ref_rows_span=float(rm.log10().max() - rm.log10().min()) if rm.numel() else 0.0, zero_rows=int(ref.shape[0] - rm.numel()))
+    CAPTURE["rows"].setdefault(key, []).append(e)
+
+
+def unpack_sign_record(mask, M, N):
+    """The ReLU sign record of an [M, N] layer output (dtc_linear_fwd_mask layout) as a bool matrix."""
+    w = mask.view(torch.int16)[:(M // 32) * 2 * N].view(M // 32, 2, N).to(torch.int32) & 0xffff
+    out = torch.zeros(M // 32, 32, N, dtype=torch.bool, device=mask.device)
+    for r in range(16):
+        for half in range(2):
+            out[:, (r & 3) + 8 * (r >> 2) + 4 * half, :] = ((w[:, half, :] >> r) & 1).bool()
+    return out.view(M, N)
+
+
+def _act64(v, act):
+    if act in ("relu", "crelu"):
+        return torch.relu(v)
+    if act == "elu":
+        return torch.nn.functional.elu(v)
+    assert act in (None, "none"), act
+    return v
+
+
 def _operand(X):
     """HImage | list of HImages (side by side along the reduction) -> DtcH2iOperand"""
     imgs = [X] if isinstance(X, HImage) else list(X)
@@ -74,15 +140,17 @@ def _operand(X):
     return op, imgs
 
 
-def _wjob(job, W, trans, r0, nr, ranges, img_ptr):
+def _wjob(job, W, trans, rows, ranges, img_ptr):
     job.W, job.ld, job.img = cptr(W, f32), W.stride(0), img_ptr
-    job.trans, job.r0, job.nr, job.nseg = int(trans), int(r0), int(nr), len(ranges)
+    job.trans, job.nrows, job.nseg = int(trans), len(rows), len(ranges)
+    for i, (r0, nr) in enumerate(rows):
+        job.r0[i], job.nr[i] = int(r0), int(nr)
     for i, (c0, cw) in enumerate(ranges):
         job.c0[i], job.cw[i] = int(c0), int(cw)
 
 
 class WeightSet:
-    """Weight images of ONE trainer phase.  `get(W, trans, r0, nr, ranges)` returns the image of that product's weight operand;
+    """Weight images of ONE trainer phase.  `get(W, trans, rows, ranges)` (rows: up to two (first row, count) ranges) returns the image of that product's weight operand;
     the first request builds it on the spot (and remembers the job), `rebuild()` -- called once per phase, after the optimiser wrote
     the weights and before the lanes fork -- builds all remembered images with one grouped launch."""
 
@@ -90,19 +158,20 @@ class WeightSet:
         self.entries = {}           # key -> (image buffer, job fields, W)
         self.jobs = None
 
-    def get(self, W, trans, r0, nr, ranges):
-        key = (W.data_ptr(), W.stride(0), int(trans), int(r0), int(nr), tuple((int(a), int(b)) for a, b in ranges))
+    def get(self, W, trans, rows, ranges):
+        rows = [(int(a), int(b)) for a, b in rows]
+        key = (W.data_ptr(), W.stride(0), int(trans), tuple(rows), tuple((int(a), int(b)) for a, b in ranges))
         e = self.entries.get(key)
         if e is None:
             job = (_ffi.DtcH2iWJob * 1)()
-            _wjob(job[0], W, trans, r0, nr, ranges, None)
+            _wjob(job[0], W, trans, rows, ranges, None)
             n = int(lib().dtc_h2i_wimage_bytes(job))
             if n <= 0:
                 raise _ffi.DtcError("dtc_h2i_wimage_bytes: bad weight-image job")
             buf = torch.zeros((n + 7) // 8, dtype=torch.float64, device=W.device)
             job[0].img = buf.data_ptr()
             check(lib().dtc_h2i_wimage_group(job, 1, stream()), "dtc_h2i_wimage_group")
-            e = self.entries[key] = (buf, (W, trans, r0, nr, ranges))
+            e = self.entries[key] = (buf, (W, trans, rows, ranges))
             self.jobs = None
         return e[0]
 
@@ -111,8 +180,8 @@ class WeightSet:
             return
         if self.jobs is None:
             self.jobs = (_ffi.DtcH2iWJob * len(self.entries))()
-            for j, (buf, (W, trans, r0, nr, ranges)) in zip(self.jobs, self.entries.values()):
-                _wjob(j, W, trans, r0, nr, ranges, buf.data_ptr())
+            for j, (buf, (W, trans, rows, ranges)) in zip(self.jobs, self.entries.values()):
+                _wjob(j, W, trans, rows, ranges, buf.data_ptr())
         check(lib().dtc_h2i_wimage_group(self.jobs, len(self.jobs), stream()), "dtc_h2i_wimage_group")
 
 
@@ -128,7 +197,7 @@ def _fwd_wimage(W, imgs, col_ranges, wset):
             c += im.K
     ranges = [(c0, im.K) for c0, im in zip(col_ranges, imgs)]
     ws = wset if wset is not None else WeightSet()
-    return ws.get(W, 0, 0, W.shape[0], ranges), ws
+    return ws.get(W, 0, [(0, W.shape[0])], ranges), ws
 
 
 def linear_fwd(X, W, b, Y=None, Yimg=None, act=None, mask=None, wset=None, cols=None):
@@ -142,6 +211,19 @@ def linear_fwd(X, W, b, Y=None, Yimg=None, act=None, mask=None, wset=None, cols=
     check(lib().dtc_linear_fwd_h2i(op, ptr(wimg), cptr(b, f32) if b is not None else None, ptr(Y) if Y is not None else None,
                                    Y.stride(0) if Y is not None else 0, Yimg.ptr() if Yimg is not None else None,
                                    ptr(mask) if mask is not None else None, M, N, ACT[act], stream()), "dtc_linear_fwd_h2i")
+    key = _cap_want("fwd", (M, N, sum(im.K for im in imgs)))
+    if key:
+        from . import ops
+        CAPTURE["busy"] = True
+        starts = cols if cols is not None else [sum(im.K for im in imgs[:i]) for i in range(len(imgs))]
+        Xf = torch.zeros(M, W.shape[1], dtype=f32, device=W.device)
+        for c0, im in zip(starts, imgs):
+            Xf[:, c0:c0 + im.K] = im.to_tensor()
+        ref = _act64(Xf.double() @ W.double().T + (b.double() if b is not None else 0.0), act)
+        nat = torch.empty(M, N, dtype=f32, device=W.device)
+        ops.linear_fwd(Xf, W, b, nat, act, split=False)
+        _cap_put(key, Y[:, :N] if Y is not None else Yimg.to_tensor(), ref, nat)
+        CAPTURE["busy"] = False
     return ws
 
 
@@ -162,27 +244,68 @@ def linear_fwd_mse(X, W, b, target, tcol0, tidx, dY, dYimg, part, wset=None):
                                        target.shape[0], tcol0, cptr(tidx, torch.int64), 2.0 / (M * N), ptr(dY) if dY is not None else None,
                                        dY.stride(0) if dY is not None else 0, dYimg.ptr() if dYimg is not None else None, ptr(part), M, N,
                                        stream()), "dtc_linear_fwd_mse_h2i")
+    key = _cap_want("fwd_mse", (M, N, sum(im.K for im in imgs)))
+    if key:
+        CAPTURE["busy"] = True
+        Xf = torch.cat([im.to_tensor() for im in imgs], dim=1)
+        ref = ((Xf.double() @ W.double().T + (b.double() if b is not None else 0.0)) - target[tidx][:, tcol0:tcol0 + N].double()) * (2.0 / (M * N))
+        _cap_put(key, dY[:, :N] if dY is not None else dYimg.to_tensor(), ref, None)
+        CAPTURE["busy"] = False
     return n
 
 
 def linear_dgrad(dZimg, W, dX=None, dXimg=None, window=None, add=None, Xsaved=None, act=None, mask=None, wset=None):
-    """dX[:, window] = ((dZ W[:, window]) + add) * act'(.).  dZimg: HImage [M, N]; window = (first column, width) of W's columns
-    (default: all); results over the window: fp32 destination `dX` (tensor or DtcSegMat covering the window) and / or the HImage
-    `dXimg` [M, width]; `add`: fp32 [M, >= width] added to the product before anything is stored."""
+    """dX[:, window] = ((dZ W[:, window]) + add) * act'(.).  dZimg: HImage [M, N]; window = (first column, width) of W's columns, or a
+    list of up to two such ranges computed one after the other (all but the last a multiple of 128 wide; default: all columns); results
+    over the window: fp32 destination `dX` (tensor or DtcSegMat covering the window) and / or the HImage `dXimg` of the window's first
+    dXimg.K columns; `add`: fp32 [M, >= width] added to the product before anything is stored."""
     N, K = W.shape
-    c0, kw = (0, K) if window is None else window
+    wins = [(0, K)] if window is None else ([window] if isinstance(window[0], int) else list(window))
+    kw = sum(w for _, w in wins)
     M = dZimg.M
-    assert dZimg.K == N and (dX is not None or dXimg is not None) and (dXimg is None or (dXimg.M, dXimg.K) == (M, kw))
+    assert dZimg.K == N and (dX is not None or dXimg is not None) and (dXimg is None or (dXimg.M == M and dXimg.K <= kw))
     ws = wset if wset is not None else WeightSet()
-    wimg = ws.get(W, 1, c0, kw, [(0, N)])
+    wimg = ws.get(W, 1, wins, [(0, N)])
     dXs = None
     if dX is not None:
         dXs = dX if isinstance(dX, _ffi.DtcSegMat) else segmat([seg(dX, 0, kw)])
     check(lib().dtc_linear_dgrad_h2i(dZimg.ptr(), N, ptr(wimg), kw, dXs, dXimg.ptr() if dXimg is not None else None,
+                                     dXimg.K if dXimg is not None else 0,
                                      ptr(add) if add is not None else None, add.stride(0) if add is not None else 0,
                                      ptr(Xsaved) if (mask is None and Xsaved is not None) else None, Xsaved.stride(0) if Xsaved is not None else 0,
                                      ptr(mask) if mask is not None else None, M, ACT[act] if mask is None else ACT["relu"], stream()),
           "dtc_linear_dgrad_h2i")
+    key = _cap_want("dgrad", (M, N, kw)) if (dXimg is not None or isinstance(dX, torch.Tensor)) else None
+    if key:
+        from . import ops
+        CAPTURE["busy"] = True
+        kc = dXimg.K if dXimg is not None else kw
+        Wwin = torch.cat([W[:, c0:c0 + w] for c0, w in wins], dim=1)[:, :kc].contiguous()
+        dZf = dZimg.to_tensor()
+        ref = dZf.double() @ Wwin.double()
+        if add is not None:
+            ref = ref + add[:, :kc].double()
+        if mask is not None:
+            ref = ref * unpack_sign_record(mask, M, kw)[:, :kc]
+        elif act not in (None, "none"):
+            assert act == "elu"
+            ys = Xsaved[:, :kc].double()
+            ref = torch.where(ys > 0, ref, ref * (ys + 1.0))
+        # the single-pass fp32 MFMA kernel on the same operands (added term and sign record applied as the image kernel's epilogue does)
+        nat = torch.empty(M, kc, dtype=f32, device=W.device)
+        if mask is None and add is None:
+            ops.linear_dgrad(dZf, Wwin, nat, Xsaved[:, :kc] if act not in (None, "none") else None, act, split=False)
+        else:
+            ops.linear_dgrad(dZf, Wwin, nat, None, None, split=False)
+            if add is not None:
+                nat = add[:, :kc] + nat
+            if mask is not None:
+                nat = nat * unpack_sign_record(mask, M, kw)[:, :kc]
+            elif act not in (None, "none"):
+                ys32 = Xsaved[:, :kc]
+                nat = torch.where(ys32 > 0, nat, nat * (ys32 + 1.0))
+        _cap_put(key, dXimg.to_tensor() if dXimg is not None else dX[:, :kc], ref, nat)
+        CAPTURE["busy"] = False
     return ws
 
 
@@ -208,4 +331,18 @@ def wgrad_group(jobs, M, workspace, stream_ptr=None):
     Returns the objects the launch reads (keep them alive until it has run)."""
     arr = _wgrad_jobs(jobs)
     check(lib().dtc_wgrad_group_h2i(arr, len(jobs), M, ptr(workspace), stream() if stream_ptr is None else stream_ptr), "dtc_wgrad_group_h2i")
+    if CAPTURE is not None and stream_ptr is None:
+        from . import ops
+        for dZimg, Ximg, dW, wcol0, db in jobs:
+            K = min(Ximg.K, dW.shape[1] - wcol0)
+            key = _cap_want("wgrad", (M, dZimg.K, K))
+            if key:
+                CAPTURE["busy"] = True
+                dZf, Xf = dZimg.to_tensor(), Ximg.to_tensor()[:, :K].contiguous()
+                ref = dZf.double().T @ Xf.double()
+                natW, natb = torch.empty(dZimg.K, K, dtype=f32, device=dW.device), torch.empty(dZimg.K, dtype=f32, device=dW.device)
+                nj = [(dZf, Xf, natW, natb)]
+                ops.wgrad_group(nj, M, ops.workspace(ops.wgrad_group_workspace_bytes(nj, M, False), dW.device), split=False)
+                _cap_put(key, dW[:, wcol0:wcol0 + K], ref, natW)
+                CAPTURE["busy"] = False
     return jobs

@@ -380,7 +380,7 @@ class ActorCriticDecoder(nn.Module):
     def content_key(idx, *tensors):
         return (None if idx is None else (idx.data_ptr(), idx.numel(), idx._version),) + tuple((t.data_ptr(), t._version) for t in tensors)
 
-    def terrain_encoder_(self, ws, priv, idx=None, masks=False, images=False, wset=None, lt_fp32=True):
+    def terrain_encoder_(self, ws, priv, idx=None, masks=False, images=False, wset=None, lt_fp32=True, split=None):
         """`images` (training step, see images_ok): the gathered heights are packed into an operand image once per mini-batch, t1 / t2
         leave as images only (ws.live_img), l_t as an image (+ fp32 for the CE-net decoder: lt_fp32)."""
         L = self.L
@@ -395,9 +395,9 @@ class ActorCriticDecoder(nn.Module):
             ws.live_img |= {"t1", "t2"} | (set() if lt_fp32 else {"lt"})
             return
         ws.live_img -= {"t1", "t2", "lt"}
-        ops.linear_fwd(X, L["te0"].W, L["te0"].b, ws.t1, "relu", M=ws.B, mask=ws.relu_mask("t1", 512, masks))
-        ops.linear_fwd(ws.t1, L["te1"].W, L["te1"].b, ws.t2, "relu", mask=ws.relu_mask("t2", 512, masks))
-        ops.linear_fwd(ws.t2, L["te2"].W, L["te2"].b, ws.lt, None)
+        ops.linear_fwd(X, L["te0"].W, L["te0"].b, ws.t1, "relu", M=ws.B, mask=ws.relu_mask("t1", 512, masks), split=split)
+        ops.linear_fwd(ws.t1, L["te1"].W, L["te1"].b, ws.t2, "relu", mask=ws.relu_mask("t2", 512, masks), split=split)
+        ops.linear_fwd(ws.t2, L["te2"].W, L["te2"].b, ws.lt, None, split=split)
 
     def actor_input(self, ws, obs, idx=None):
         return segmat([seg(obs, 0, self.num_obs, gather=idx is not None), seg(ws.z, 0, 16), seg(ws.mulv, 0, 3),
@@ -527,21 +527,24 @@ class ActorCriticDecoder(nn.Module):
             L.update(mm0=d("vae.memory_mlp.0.weight", "vae.memory_mlp.0.bias", "relu"),
                      mm1=d("vae.memory_mlp.2.weight", "vae.memory_mlp.2.bias", "relu"),
                      mm2=d("vae.memory_mlp.4.weight", "vae.memory_mlp.4.bias", None))
-        ops.linear_fwd(hist, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=B)
-        ops.linear_fwd(ws.e1, L["ce1"].W, L["ce1"].b, ws.e, None)
-        ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None)          # [:, :19] = latent_mu
-        self.terrain_encoder_(ws, priv)
+        # deployment / rollout-side rows are independent envs: the single-pass fp32 kernels (the reference's own arithmetic) keep every
+        # row to itself -- a diverged env's inf / NaN observation stays in its row (split=False; PPO.act's layer chains do the same)
+        fp = dict(split=False)
+        ops.linear_fwd(hist, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=B, **fp)
+        ops.linear_fwd(ws.e1, L["ce1"].W, L["ce1"].b, ws.e, None, **fp)
+        ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None, **fp)          # [:, :19] = latent_mu
+        self.terrain_encoder_(ws, priv, split=False)
         m1, m2, m = (torch.empty(B, n, device=dev) for n in (L["mm0"].n_out, L["mm1"].n_out, L["mm2"].n_out))
-        ops.linear_fwd(segmat([seg(hist, 0, hist.shape[1]), seg(ws.lt, 0, 512)]), L["mm0"].W, L["mm0"].b, m1, "relu", M=B)
-        ops.linear_fwd(m1, L["mm1"].W, L["mm1"].b, m2, "relu")
-        ops.linear_fwd(m2, L["mm2"].W, L["mm2"].b, m, None)
+        ops.linear_fwd(segmat([seg(hist, 0, hist.shape[1]), seg(ws.lt, 0, 512)]), L["mm0"].W, L["mm0"].b, m1, "relu", M=B, **fp)
+        ops.linear_fwd(m1, L["mm1"].W, L["mm1"].b, m2, "relu", **fp)
+        ops.linear_fwd(m2, L["mm2"].W, L["mm2"].b, m, None, **fp)
         b_t = m + ws.lt * m
         X = segmat([seg(obs, 0, self.num_obs), seg(ws.mulv, 3, 16), seg(ws.mulv, 0, 3), seg(b_t, 0, 512)])
         act = AC_Args.activation
-        ops.linear_fwd(X, L["a0"].W, L["a0"].b, ws.a1, act, M=B)
-        ops.linear_fwd(ws.a1, L["a1"].W, L["a1"].b, ws.a2, act)
-        ops.linear_fwd(ws.a2, L["a2"].W, L["a2"].b, ws.a3, act)
-        ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None)
+        ops.linear_fwd(X, L["a0"].W, L["a0"].b, ws.a1, act, M=B, **fp)
+        ops.linear_fwd(ws.a1, L["a1"].W, L["a1"].b, ws.a2, act, **fp)
+        ops.linear_fwd(ws.a2, L["a2"].W, L["a2"].b, ws.a3, act, **fp)
+        ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None, **fp)
         return ws.mean.clone()
 
     def act_inference(self, ob):

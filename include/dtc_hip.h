@@ -307,17 +307,20 @@ int dtc_wgrad_group_i3(const DtcWgradImgJob* jobs, int count, int M, void* works
  * of dtc_linear_fwd_h2i / _mse_h2i / dtc_linear_dgrad_h2i (results as fp32, as an image, or both), dtc_h2i_wimage_group (weights).
  * dtc_h2i_unpack decodes an image (tests). */
 int64_t dtc_h2i_bytes(int M, int K);
+void dtc_h2i_trace(void* buf);   /* debug: per-workgroup {start, K loop done, end (100 MHz ticks), HW_ID} records of the launches that follow (NULL: off) */
 int dtc_h2i_pack(const DtcSegMat* X, int M, void* img, void* stream);
 int dtc_h2i_unpack(const void* img, int M, int K, float* out, int64_t ld, void* stream);
-/* A weight image: `nr` rows of the operand starting at r0, the reduction = up to 4 column ranges (c0, cw) side by side, each padded to
- * whole 16-column stages -- the walk of the row operand's images.  trans = 0: element (row, c) = W[(r0 + row) * ld + c] (forward:
- * r0 = 0, nr = N, ranges = the column blocks of W that meet the row operand's images, in that order); trans = 1: W[c * ld + r0 + row]
- * (data gradient: rows = a window of W's columns, one range (0, N)).  img: dtc_h2i_wimage_bytes(job) bytes. */
+/* A weight image.  Rows: up to 2 ranges (r0, nr) of the operand's rows, one after the other, each padded to whole 128-row tiles (all but the
+ * last must be multiples of 128 long).  Reduction: up to 4 column ranges (c0, cw) side by side, each padded to whole 16-column stages --
+ * the walk of the row operand's images.  trans = 0: element (row, c) = W[row * ld + c] (forward: rows (0, N), ranges = the column blocks of
+ * W that meet the row operand's images, in that order); trans = 1: W[c * ld + row] (data gradient: rows = windows of W's columns, one
+ * reduction range (0, N)).  img: dtc_h2i_wimage_bytes(job) bytes. */
 typedef struct DtcH2iWJob {
     const float* W;
     int64_t ld;
     void* img;
-    int32_t trans, r0, nr, nseg;
+    int32_t trans, nrows, nseg;
+    int32_t r0[2], nr[2];
     int32_t c0[4], cw[4];
 } DtcH2iWJob;
 int64_t dtc_h2i_wimage_bytes(const DtcH2iWJob* job);
@@ -336,10 +339,12 @@ int64_t dtc_linear_fwd_mse_h2i_parts(int M, int N);
 int dtc_linear_fwd_mse_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, const float* target, int64_t ldt, int64_t target_rows,
                            int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy, void* dYimg, double* sq_part, int M, int N,
                            void* stream);
-/* dX[:, window] = ((dZ W[:, window]) + add) * act'(.): dZimg = image(M, N), wimgT = image of W^T for the window (Kwin columns); results
- * over the window: fp32 destination blocks dX (may be NULL) and / or dXimg = image(M, Kwin); add: fp32 [M, ld_add] or NULL */
-int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT, int Kwin, const DtcSegMat* dX, void* dXimg, const float* add,
-                         int64_t ld_add, const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, int M, int act, void* stream);
+/* dX[:, window] = ((dZ W[:, window]) + add) * act'(.): dZimg = image(M, N), wimgT = image of W^T for the window (Kwin columns: the job's
+ * row ranges one after the other); results over the window: fp32 destination blocks dX (may be NULL) and / or dXimg = image(M, img_cols)
+ * of the window's first img_cols columns (0: all Kwin); add: fp32 [M, ld_add] or NULL */
+int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT, int Kwin, const DtcSegMat* dX, void* dXimg, int img_cols,
+                         const float* add, int64_t ld_add, const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, int M, int act,
+                         void* stream);
 /* dW_j = dZ_j^T X_j, db_j = colsum(dZ_j) for `count` <= 12 layers in ONE launch, both operands images over the same M batch rows
  * (M a multiple of 128 per batch slice: the per-row exponents of the two operands are folded into one operand's fragments per batch
  * row, csrc/wgrad_h2i.hip).  workspace >= dtc_wgrad_group_h2i_workspace() bytes, 16-byte aligned. */

@@ -157,12 +157,15 @@ def test_hip_rollout_mode_forward_carries_state():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kw", [dict(), dict(schedule="fixed", use_clipped_value_loss=False)])
-def test_hip_teacher_forced_minibatches_vs_oracle(kw):
+@pytest.mark.parametrize("kw,amax_check", [(dict(), False), (dict(schedule="fixed", use_clipped_value_loss=False), False), (dict(), True)])
+def test_hip_teacher_forced_minibatches_vs_oracle(kw, amax_check, monkeypatch):
     """Each of the 4 recurrent mini-batches, both optimisation steps, from identical weights and fresh Adam states:
     per-step scalars to 1e-5 rel, every parameter gradient (BPTT through both GRUs, through the feature blocks into
-    the CE-net / terrain encoders) to 2e-5 of the tensor's max."""
+    the CE-net / terrain encoders) to 2e-5 of the tensor's max.  `amax_check`: the same run with DTC_AMAX_CHECK's re-derivation of every
+    amax record the recurrent step's converting kernels are handed (the operand-image chain of the VAE step keeps no records)."""
+    from dtc_amd import ops
     from dtc_amd.algorithms import ppo as P
+    monkeypatch.setattr(ops, "AMAX_CHECK", bool(amax_check))
     data, hid_a, hid_c, eps, _, _ = composite_case()
     g = torch.Generator().manual_seed(79)
     eps2 = torch.randn(4, T * (N // NMB), 16, generator=g)

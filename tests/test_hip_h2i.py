@@ -179,6 +179,12 @@ def test_dgrad_window_add_and_segmented_destination():
     h2i.linear_dgrad(dZi, Wd, segmat([seg(dz, 0, 16), seg(dmu, 0, 3, accumulate=True)]), None, window=(53, 19))
     assert _row_err(dz, full[:, 53:69]) < ROW_TOL
     assert _row_err(dmu[:, :3], full[:, 69:72] + 1.0) < ROW_TOL and float((dmu[:, 3:] - 1).abs().max()) == 0.0
+    # both windows in ONE launch: four image tiles + one fp32 tile
+    dlt2 = h2i.HImage(M, 512, DEV)
+    dz2, dmu2 = torch.full((M, 16), float("nan"), device=DEV), torch.zeros(M, 35, device=DEV)
+    h2i.linear_dgrad(dZi, Wd, segmat([seg(None, 0, 512), seg(dz2, 0, 16), seg(dmu2, 0, 3)]), dlt2, window=[(72, 512), (53, 19)])
+    assert _row_err(dlt2.to_tensor(), full[:, 72:]) < ROW_TOL and torch.equal(dz2, dz)
+    assert _row_err(dmu2[:, :3], full[:, 69:72]) < ROW_TOL and float(dmu2[:, 3:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("M,shapes", [(1024, [(512, 512)]), (3072, [(512, 693), (693, 512), (128, 256)]), (24576, [(512, 512), (256, 512)]),

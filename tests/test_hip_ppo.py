@@ -318,6 +318,46 @@ def test_forward_act_evaluate_vs_oracle():
     np.testing.assert_allclose(ac.action_std.cpu().numpy(), sig_ref.numpy(), **tol)
 
 
+def test_a_diverged_env_stays_in_its_row_on_the_rollout_side():
+    """ppo.py:137-155 / actor_critic_decoder.py:409-451, 504-551: rows are independent envs.  An env whose observation and privileged
+    observation went inf / NaN (routine in Isaac Gym until reset_idx) must leave the other 4095 envs' actions, values and log-probs
+    BIT-identical to a clean step -- PPO.act, evaluate and the deployment policy act_teacher.  (The observation history stays clean here:
+    the CE-net's outlier statistics are batch-global in the reference itself, actor_critic_decoder.py:293-299.)"""
+    _, alg = _pair(64)
+    N = 4096
+    g = torch.Generator().manual_seed(17)
+    obs, priv, hist, bv = (torch.randn(N, w, generator=g).to(DEV) for w in (53, 1389, 265, 3))
+    eps, noise = torch.randn(N, 16, generator=g).to(DEV), torch.randn(N, 12, generator=g).to(DEV)
+    ac = alg.actor_critic
+
+    def run(o, p):
+        a = ac.act(o, hist, p, None, eps=eps, noise=noise).clone()
+        v = ac.evaluate(o, p, bv).clone()
+        lp = ac.get_actions_log_prob(a).clone()
+        t = ac.act_teacher(o, hist, p).clone()
+        return a, v, lp, t
+
+    clean = run(obs, priv)
+    ob, pb = obs.clone(), priv.clone()
+    ob[7, 3], ob[7, 40] = float("nan"), float("inf")
+    pb[7, 100], pb[7, 900] = float("inf"), float("nan")
+    ob[2049] = float("nan")
+    pb[2049] = float("nan")
+    dirty = run(ob, pb)
+    keep = torch.ones(N, dtype=torch.bool, device=DEV)
+    keep[[7, 2049]] = False
+    for c, d, name in zip(clean, dirty, ("actions", "values", "log-prob", "act_teacher")):
+        assert torch.equal(c[keep], d[keep]), name
+        assert bool((~torch.isfinite(d[~keep].reshape(2, -1))).any(dim=1).all()), name
+    # ... and a poisoned history: the batch statistics of the outlier rule see it (as in the reference), but no other env turns non-finite
+    hb = hist.clone()
+    hb[11] = float("nan")
+    a = ac.act(obs, hb, priv, None, eps=eps, noise=noise)
+    keep[:] = True
+    keep[11] = False
+    assert bool(torch.isfinite(a[keep]).all()) and not bool(torch.isfinite(a[11]).all())
+
+
 def test_cenet_latent_kernel_vs_torch():
     """outlier -> lower-median replacement, z, and the backward scatter, against plain torch."""
     from dtc_amd import _ffi, ops
