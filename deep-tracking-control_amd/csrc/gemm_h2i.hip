@@ -243,38 +243,95 @@ __device__ __forceinline__ void load8(const float* base, long long ld, int row, 
     }
 }
 
-// N: result columns (EPI_DGRAD: the computed window of the layer's input columns).  wide bit 0: Y / single fp32 destination takes
-// 16-byte accesses, bit 1: Xs does, bit 2: add does.
+
+// LDS of the GEMM kernels, at namespace scope: every instance of the tile code shares ONE set.
+// Separate objects per stage buffer: an LDS-DMA into one cannot alias the fragment reads of the other (see linear_s3_kernel).
+// THREE stage buffers: the LDS-DMA of stage s + 2 is issued while stage s computes.  (One stage ahead -- the first version of this
+// kernel -- left the launches with few workgroups per CU waiting at their barriers: 24576 x 256 x 512 48.8 -> 40.7 us, the weight
+// gradients' twin 162 -> 150 us per three-layer bucket; the 768-workgroup launches are bound by LDS traffic + matrix pipe either way.)
+__shared__ __attribute__((aligned(16))) u32x2 Xs0[2][BM * 4];
+__shared__ __attribute__((aligned(16))) u32x2 Xs1[2][BM * 4];
+__shared__ __attribute__((aligned(16))) u32x2 Xs2[2][BM * 4];
+__shared__ __attribute__((aligned(16))) u32x2 Ws0[2][128 * 4];
+__shared__ __attribute__((aligned(16))) u32x2 Ws1[2][128 * 4];
+__shared__ __attribute__((aligned(16))) u32x2 Ws2[2][128 * 4];
+__shared__ __attribute__((aligned(16))) int Dt[MAX_TB + 1][128];      // exponent deltas per block border and row; [tblocks]: the final scale
+
+// ---- device code of the GEMM kernels.  The descriptors are read through the CONSTANT address space, in place from the kernel-argument
+// segment: invariant scalar loads, and no private copy of the by-value argument (binding a generic reference to it copies the struct to
+// scratch as soon as one of its arrays is indexed at run time).  The host pass of hipcc does not convert between address spaces
+// implicitly, so these bodies exist for the device pass only.
+#define AS4 __attribute__((address_space(4)))
+#ifdef __HIP_DEVICE_COMPILE__
+template <class OP>
+__device__ __forceinline__ HSeg hseg_at(const OP& A, int i) {
+    HSeg s = A.s[0];
+    if (i == 1) s = A.s[1];
+    if (i == 2) s = A.s[2];
+    if (i == 3) s = A.s[3];
+    return s;
+}
+// segment i of a descriptor by static selects (a dynamic index into a by-value kernel argument would pin the whole struct to scratch)
+template <class SM>
+__device__ __forceinline__ int find_seg_t(const SM& X, int k) {
+    int s = 0;
+    if (X.nseg > 1 && k >= X.s[1].start) s = 1;
+    if (X.nseg > 2 && k >= X.s[2].start) s = 2;
+    if (X.nseg > 3 && k >= X.s[3].start) s = 3;
+    return s;
+}
+template <class SM>
+__device__ __forceinline__ SegDev seg_at(const SM& X, int i) {
+    SegDev s = X.s[0];
+    if (i == 1) s = X.s[1];
+    if (i == 2) s = X.s[2];
+    if (i == 3) s = X.s[3];
+    return s;
+}
+
+#endif  // __HIP_DEVICE_COMPILE__
+
+// Everything one 128 x 128 result tile needs (N: result columns -- EPI_DGRAD: the computed window of the layer's input columns; wide bit 0:
+// Y takes 16-byte accesses, bit 1: Xs does, bit 2: add does)
+struct TileArgs {
+    HOperand A;
+    const u32x4* wimg;
+    const int* wexps;
+    u32 wimg_bytes;
+    int M, N, act, wide, ldwm;
+    const float* bias;
+    float* Y;
+    long long ldy;
+    HOut yo;
+    unsigned short* wmask;
+    DgradEpiH dg;
+};
+
+// One result tile (tr, tc): K loop + epilogue.  `slot`: index of the tile's loss partial (EPI_MSE) / trace record.  Every thread of the
+// workgroup calls it; on return the tile's global stores are ISSUED (not necessarily complete).
+#ifdef __HIP_DEVICE_COMPILE__
+typedef const AS4 TileArgs CTileArgs;
 template <int EPI>
-__global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, const u32x4* __restrict__ wimg, u32 wimg_bytes,
-                                                            const int* __restrict__ wexps, const float* __restrict__ bias,
-                                                            float* __restrict__ Y, long long ldy, const HOut yo, int M, int N, int act, int wide,
-                                                            unsigned short* __restrict__ wmask, int ldwm, const DgradEpiH dg, const MseEpiH mse,
-                                                            unsigned long long* __restrict__ trace) {
+__device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const int tr, const int tc, const int slot,
+                                         unsigned long long* __restrict__ trace) {
+    const auto& A = L.A;
+    const u32x4* __restrict__ wimg = L.wimg;
+    const int* __restrict__ wexps = L.wexps;
+    const u32 wimg_bytes = L.wimg_bytes;
+    const float* __restrict__ bias = L.bias;
+    float* __restrict__ Y = L.Y;
+    const long long ldy = L.ldy;
+    const auto& yo = L.yo;
+    const int M = L.M, N = L.N, act = L.act, wide = L.wide, ldwm = L.ldwm;
+    unsigned short* __restrict__ wmask = L.wmask;
+    const auto& dg = L.dg;
     constexpr int BN = 128, WN = 2, TM = 2, TN = 2;
-    // separate objects per stage buffer: an LDS-DMA into one cannot alias the fragment reads of the other (see linear_s3_kernel)
-    // THREE stage buffers: the LDS-DMA of stage s + 2 is issued while stage s computes.  (One stage ahead -- the first version of this
-    // kernel -- left every workgroup waiting at its barrier for a transfer issued 12 MFMAs earlier: per-workgroup time stamps, tools/
-    // h2i_trace.py, showed 0.81 us per stage against 0.53 us of matrix-pipe time for the three co-resident waves of a SIMD.)
-    __shared__ __attribute__((aligned(16))) u32x2 Xs0[2][BM * 4];
-    __shared__ __attribute__((aligned(16))) u32x2 Xs1[2][BM * 4];
-    __shared__ __attribute__((aligned(16))) u32x2 Xs2[2][BM * 4];
-    __shared__ __attribute__((aligned(16))) u32x2 Ws0[2][BN * 4];
-    __shared__ __attribute__((aligned(16))) u32x2 Ws1[2][BN * 4];
-    __shared__ __attribute__((aligned(16))) u32x2 Ws2[2][BN * 4];
-    __shared__ __attribute__((aligned(16))) int Dt[MAX_TB + 1][128];      // exponent deltas per block border and row; [tblocks]: the final scale
 #define XS(b) ((b) == 0 ? Xs0 : (b) == 1 ? Xs1 : Xs2)
 #define WS(b) ((b) == 0 ? Ws0 : (b) == 1 ? Ws1 : Ws2)
-    int tr, tc;
-    if (!map_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, tr, tc)) {
-        if (EPI == EPI_MSE && threadIdx.x == 0) mse.part[blockIdx.x] = 0.0;
-        return;
-    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (trace && tid == 0) {                              // debug (dtc_h2i_trace): per-workgroup time stamps (100 MHz) and placement
-        trace[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-        trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID
+        trace[4 * slot] = __builtin_amdgcn_s_memrealtime();
     }
     const int m0 = tr * BM, n0 = tc * BN;
     const int wm_off = (wave / WN) * (32 * TM), wn_off = (wave % WN) * (32 * TN);
@@ -282,6 +339,11 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
     const rsrc_t wres = make_rsrc_bytes(wimg, wimg_bytes);
     const u32 lane_off = (u32)(tid * 16);
 
+    // The K loop exists twice: the row operand as ONE image (every layer but the actor's first) keeps no descriptor state in the loop
+    const int a_total = A.total, a_nseg = A.nseg, a_tblocks = A.tblocks;
+    f32x16 acc[TM][TN];
+    auto k_loop = [&](auto multi_c) {
+    constexpr bool MULTI = decltype(multi_c)::value;
     // ---- loader cursor (one stage ahead of the MFMAs)
     int lseg = 0, lleft = A.s[0].stages, left = A.total;
     rsrc_t xres = make_rsrc_bytes(A.s[0].img, A.s[0].bytes);
@@ -297,11 +359,12 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
         xchunk += HI_CHUNK;
         wchunk += HI_CHUNK;
         --left;
-        if (--lleft == 0 && lseg + 1 < A.nseg) {        // (uniform) into the next image of the row operand
+        if (MULTI && --lleft == 0 && lseg + 1 < a_nseg) {        // (uniform) into the next image of the row operand
             ++lseg;
-            lleft = A.s[lseg].stages;
-            xres = make_rsrc_bytes(A.s[lseg].img, A.s[lseg].bytes);
-            xchunk = (u32)(tr * A.s[lseg].stages) * (u32)HI_CHUNK;
+            const HSeg sg = hseg_at(A, lseg);
+            lleft = sg.stages;
+            xres = make_rsrc_bytes(sg.img, sg.bytes);
+            xchunk = (u32)(tr * sg.stages) * (u32)HI_CHUNK;
         }
     };
     load_stage(S0{});
@@ -312,8 +375,9 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
     if (tid < 128) {
         int prev_a = 0, prev_w = 0, prev = 0, b = 0;
         for (int i = 0; i < A.nseg; ++i) {
-            const int* ex = A.s[i].exps + (long long)tr * A.s[i].kbs * 128 + tid;
-            for (int k = 0; k < A.s[i].kbs; ++k, ++b) {
+            const HSeg sg = hseg_at(A, i);
+            const int* ex = sg.exps + (long long)tr * sg.kbs * 128 + tid;
+            for (int k = 0; k < sg.kbs; ++k, ++b) {
                 const int ea = ex[k * 128], ew = wexps[tc * A.tblocks + b];
                 prev_a = ea == HI_EZERO ? prev_a : ea;
                 prev_w = ew == HI_EZERO ? prev_w : ew;
@@ -326,7 +390,6 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
         // (the first block's "delta" Dt[0] = e(0) is never applied: the accumulators start at zero)
     }
 
-    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -355,7 +418,7 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
         constexpr int buf = decltype(bc)::value;
         // (uniform) a block border: the rows change scale.  In front of the LDS-DMA: behind it the compiler would wait for the transfer
         // before the table reads (it cannot tell the two LDS objects apart)
-        if (done > 0 && done < A.total && (cst & (HI_KB - 1)) == 0) {
+        if (done > 0 && done < a_total && (cst & (HI_KB - 1)) == 0) {
             ++blk;
             rescale(blk);
         }
@@ -387,7 +450,8 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
         for (int i = 0; i < TM; ++i) acc[i][1] = P::mfma(a[i][0], b[1][0], acc[i][1]);
         __builtin_amdgcn_sched_barrier(0);
         ++done;
-        if (++cst == A.s[cseg].stages && cseg + 1 < A.nseg) {
+        ++cst;
+        if (MULTI && cst == hseg_at(A, cseg).stages && cseg + 1 < a_nseg) {
             ++cseg;
             cst = 0;
         }
@@ -397,15 +461,18 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
         __builtin_amdgcn_s_barrier();
     };
     __syncthreads();
-    for (int trip = (A.total + 2) / 3; trip > 0; --trip) {
+    for (int trip = (a_total + 2) / 3; trip > 0; --trip) {
         stage(S0{});
         stage(S1{});
         stage(std::integral_constant<int, 2>{});
     }
     __syncthreads();                                     // (the transfers past the last stage -- zeros -- have landed too)
-    if (trace && tid == 0) trace[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    rescale(a_tblocks);                                  // back to the values themselves (2^-e of the last block, exact)
+    };
+    if (a_nseg > 1) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
+    if (trace && tid == 0) trace[4 * slot + 1] = __builtin_amdgcn_s_memrealtime();
     // every wave is past its last fragment read and every LDS-DMA has landed (the barrier's wait): LDS becomes the patches
-    rescale(A.tblocks);                                  // back to the values themselves (2^-e of the last block, exact)
     float* patch = reinterpret_cast<float*>(wave < 2 ? &Xs0[0][0] : &Xs1[0][0]) + (wave & 1) * (32 * LDW);
     const bool full = (m0 + BM <= M) && (n0 + BN <= N);
 
@@ -497,9 +564,9 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
                     for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = o[e >> 2][e & 3] + v[e >> 2][e & 3];
                 }
                 if (dg.has_dx && col < N) {
-                    const SegMatDev& dX = dg.dX;
-                    const int sj = find_seg(dX, col);
-                    const SegDev sdj = dX.s[sj];
+                    const auto& dX = dg.dX;
+                    const int sj = find_seg_t(dX, col);
+                    const SegDev sdj = seg_at(dX, sj);
                     if (col + 8 <= sdj.start + sdj.width || (sj == dX.nseg - 1)) {      // inside one destination block
                         if (sdj.ptr) {
                             const int lc = col - sdj.start;
@@ -521,7 +588,7 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
                         for (int e = 0; e < 8; ++e) {
                             const int c = col + e;
                             if (c >= N) break;
-                            const SegDev sc = dX.s[find_seg(dX, c)];
+                            const SegDev sc = seg_at(dX, find_seg_t(dX, c));
                             if (sc.ptr == nullptr) continue;
                             float* qd = sc.ptr + sc.col0 + (c - sc.start) + (long long)row * sc.ld;
                             *qd = sc.accumulate ? (*qd + v[e >> 2][e & 3]) : v[e >> 2][e & 3];
@@ -531,12 +598,36 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
             } else {
                 if (Y) store8(Y, ldy, row, col, M, N, (wide & 1) != 0, v);
             }
+            if (!full) {                                    // (uniform) images hold zeros behind the matrix
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = (row < M && col + e < N) ? v[e >> 2][e & 3] : 0.f;
+            }
+            // largest |value| of the row so far as a bit pattern (2 VALU per element); a non-finite element makes the pattern >= inf's and
+            // sends the wave through the filtered pass below
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                v[e >> 2][e & 3] = (row < M && col + e < N) ? v[e >> 2][e & 3] : 0.f;       // images hold zeros behind the matrix
-                const u32 bb = finite_bits(v[e >> 2][e & 3]);
+                const u32 bb = EPI == EPI_MSE ? finite_bits(v[e >> 2][e & 3]) : abs_bits(v[e >> 2][e & 3]);      // (the loss epilogue has no registers to spare for the second pass)
                 mrow[i][q] = bb > mrow[i][q] ? bb : mrow[i][q];
             }
+        }
+    }
+    if constexpr (EPI != EPI_MSE) {
+        u32 any = mrow[0][0] | mrow[0][1] | mrow[1][0] | mrow[1][1];
+        if (__builtin_amdgcn_ballot_w64(any >= 0x7f800000u) != 0ull) {      // (rare) some row of this wave holds inf / NaN: finite elements only
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    u32 m = 0u;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const u32 bb = finite_bits(T[i][j][q][e >> 2][e & 3]);
+                            m = bb > m ? bb : m;
+                        }
+                    mrow[i][q] = m;
+                }
         }
     }
 
@@ -564,9 +655,9 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
     }
     if (EPI == EPI_MSE && lane == 0) red[wave] = sq;
     if (yo.img || EPI == EPI_MSE) __syncthreads();
-    if (EPI == EPI_MSE && tid == 0) mse.part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (EPI == EPI_MSE && tid == 0) mse.part[slot] = ((red[0] + red[1]) + red[2]) + red[3];
     if (yo.img == nullptr) {
-        if (trace && tid == 0) trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+        if (trace && tid == 0) trace[4 * slot + 2] = __builtin_amdgcn_s_memrealtime();
         return;
     }
     u32x4* tile_chunks = yo.img + (long long)tr * yo.stages * (HI_CHUNK / 16);
@@ -589,9 +680,28 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const HOperand A, co
                 chunk[256 + rslot(rloc, (lc >> 3) & 1)] = pc.p[1];
             }
         }
-    if (trace && tid == 0) trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    if (trace && tid == 0) trace[4 * slot + 2] = __builtin_amdgcn_s_memrealtime();
 #undef XS
 #undef WS
+}
+
+#endif  // __HIP_DEVICE_COMPILE__
+
+// one launch = one layer: XCD-aware block -> tile map (all column tiles of a row tile share an L2)
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const TileArgs L_, const MseEpiH mse, unsigned long long* __restrict__ trace) {
+    // the descriptors are read IN PLACE from the kernel-argument segment (first argument = offset 0): binding a reference to the by-value
+    // argument would copy it to scratch as soon as one of its arrays is indexed at run time
+#ifdef __HIP_DEVICE_COMPILE__
+    CTileArgs& L = *(CTileArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)L_;
+    int tr, tc;
+    if (!map_tile(blockIdx.x, (L.M + BM - 1) / BM, (L.N + 127) / 128, tr, tc)) {
+        if (EPI == EPI_MSE && threadIdx.x == 0) mse.part[blockIdx.x] = 0.0;
+        return;
+    }
+    h2i_tile<EPI>(L, mse, tr, tc, (int)blockIdx.x, trace);
+#endif
 }
 
 unsigned long long* g_trace = nullptr;      // debug: dtc_h2i_trace
@@ -772,71 +882,46 @@ extern "C" int dtc_h2i_wimage_group(const DtcH2iWJob* jobs, int count, void* str
     return dtc::check_launch("h2i_wimage_group");
 }
 
-// Y = act(X W^T + b): X = images side by side, wimg = the image of W built for that walk (trans = 0, r0 = 0, nr = N, the operand's widths
-// as reduction ranges).  Results: fp32 Y [M, >= N] (may be NULL) and / or the image of Y (Yimg = image(M, N), may be NULL) -- at least one.
-extern "C" int dtc_linear_fwd_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, float* Y, int64_t ldy, void* Yimg,
-                                  uint16_t* relu_mask, int M, int N, int act, void* stream) {
+namespace {
+// arguments of one forward layer / one data-gradient layer: validation + descriptors, one place for both
+struct LayerInfo {
+    TileArgs t;
+    int K;              // reduction length (profile names)
+    double flop, bytes;
+};
+int fwd_args(const DtcH2iOperand* X, const void* wimg, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask, int M, int N,
+             int act, LayerInfo& out) {
     DTC_REQUIRE(M > 0 && N > 0 && (Y == nullptr || ldy >= N), "bad shape M=%d N=%d ldy=%lld", M, N, (long long)ldy);
     DTC_REQUIRE((Y || Yimg) && dtc::aligned16(Yimg), "no result / unaligned image");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
-    int rc = check_img(wimg, "dtc_linear_fwd_h2i: weight image");
+    int rc = check_img(wimg, "forward layer: weight image");
     if (rc != DTC_OK) return rc;
-    HOperand A;
-    int K;
-    rc = to_operand(X, M, A, K);
+    TileArgs& t = out.t;
+    t = TileArgs{};
+    rc = to_operand(X, M, t.A, out.K);
     if (rc != DTC_OK) return rc;
     DTC_REQUIRE((long long)M * (ldy > N ? ldy : N) <= MAX_ELEMS * 4 && hi_bytes(M, N) < (1ll << 31), "matrix too large");
     if (relu_mask) DTC_REQUIRE(act == DTC_ACT_RELU && M % BM == 0 && N % 128 == 0, "sign record: M=%d and N=%d must be multiples of 128", M, N);
-    const WimgView wv = wimg_view(wimg, N, A);
-    hipStream_t s = (hipStream_t)stream;
-    const int wide = (Y && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s,
-                        4.0 * M * (double)K + 4.0 * N * (double)K + (Y ? 4.0 : 0.0) * M * N + (Yimg ? 4.0 : 0.0) * M * N);
-    hipLaunchKernelGGL((linear_h2i_kernel<EPI_FWD>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, A,
-                       wv.img, wv.bytes, wv.exps, b, Y, (long long)ldy, to_out(Yimg, M, N), M, N, act, wide, (unsigned short*)relu_mask, N,
-                       DgradEpiH{}, MseEpiH{}, g_trace);
-    return dtc::check_launch("linear_fwd_h2i");
+    const WimgView wv = wimg_view(wimg, N, t.A);
+    t.wimg = wv.img;
+    t.wexps = wv.exps;
+    t.wimg_bytes = wv.bytes;
+    t.M = M;
+    t.N = N;
+    t.act = act;
+    t.wide = (Y && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
+    t.ldwm = N;
+    t.bias = b;
+    t.Y = Y;
+    t.ldy = ldy;
+    t.yo = to_out(Yimg, M, N);
+    t.wmask = (unsigned short*)relu_mask;
+    out.flop = 2.0 * M * (double)N * out.K;
+    out.bytes = 4.0 * M * (double)out.K + 4.0 * N * (double)out.K + (Y ? 4.0 : 0.0) * M * N + (Yimg ? 4.0 : 0.0) * M * N;
+    return DTC_OK;
 }
-
-extern "C" int64_t dtc_linear_fwd_mse_h2i_parts(int M, int N) {
-    if (M <= 0 || N <= 0) return 0;
-    return grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128));
-}
-
-// the layer fused with its MSE against target[tidx[row], tcol0 + col] (dtc_linear_fwd_mse): dL/dY = (Y - target) * scale as fp32 (dY, may
-// be NULL) and / or as an image (dYimg); sq_part: dtc_linear_fwd_mse_h2i_parts(M, N) doubles (partials of sum (Y - target)^2)
-extern "C" int dtc_linear_fwd_mse_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, const float* target, int64_t ldt,
-                                      int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy, void* dYimg,
-                                      double* sq_part, int M, int N, void* stream) {
-    DTC_REQUIRE(M > 0 && N > 0 && (dY == nullptr || lddy >= N), "bad shape M=%d N=%d", M, N);
-    DTC_REQUIRE(target && tidx && (dY || dYimg) && sq_part && dtc::aligned16(dYimg), "null / unaligned pointer");
-    DTC_REQUIRE(tcol0 >= 0 && tcol0 + N <= ldt && target_rows > 0, "target columns [%d, %d) outside its %lld-wide rows", tcol0, tcol0 + N, (long long)ldt);
-    DTC_REQUIRE(target_rows * ldt <= MAX_ELEMS && hi_bytes(M, N) < (1ll << 31), "matrix too large");
-    int rc = check_img(wimg, "dtc_linear_fwd_mse_h2i: weight image");
-    if (rc != DTC_OK) return rc;
-    HOperand A;
-    int K;
-    rc = to_operand(X, M, A, K);
-    if (rc != DTC_OK) return rc;
-    const WimgView wv = wimg_view(wimg, N, A);
-    hipStream_t s = (hipStream_t)stream;
-    const MseEpiH mse{target, (const long long*)tidx, (long long)ldt, target_rows * ldt * 4, tcol0, scale, sq_part};
-    const int wide = (dY && lddy % 4 == 0 && dtc::aligned16(dY)) ? 1 : 0;
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s,
-                        4.0 * M * (double)K + 4.0 * N * (double)K + 4.0 * M * N + (dY ? 4.0 : 0.0) * M * N + (dYimg ? 4.0 : 0.0) * M * N);
-    hipLaunchKernelGGL((linear_h2i_kernel<EPI_MSE>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, A,
-                       wv.img, wv.bytes, wv.exps, b, dY, (long long)lddy, to_out(dYimg, M, N), M, N, (int)DTC_ACT_NONE, wide,
-                       (unsigned short*)nullptr, 0, DgradEpiH{}, mse, g_trace);
-    return dtc::check_launch("linear_fwd_mse_h2i");
-}
-
-// dX[:, window] = (dZ W[:, window]) * act'(.): dZ = image(M, N); wimgT = the image of W^T built for the window (trans = 1, r0 = first
-// column of the window, nr = Kwin, one reduction range (0, N)).  Results over the window: fp32 destination blocks dX (may be NULL;
-// accumulate flags honoured) and / or the image dXimg = image(M, Kwin).  add (may be NULL): fp32 [M, ld_add] added to the product first.
-// Activation derivative: relu_mask (sign record) or Xsaved with act; both need the window to start at the saved tensor's column 0.
-extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT, int Kwin, const DtcSegMat* dX, void* dXimg, int img_cols,
-                                    const float* add, int64_t ld_add, const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, int M, int act,
-                                    void* stream) {
+int dgrad_args(const void* dZimg, int N, const void* wimgT, int Kwin, const DtcSegMat* dX, void* dXimg, int img_cols, const float* add,
+               int64_t ld_add, const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, int M, int act, LayerInfo& out) {
     DTC_REQUIRE(M > 0 && N > 0 && Kwin > 0 && img_cols >= 0 && img_cols <= Kwin, "bad shape");
     if (img_cols == 0) img_cols = Kwin;
     DTC_REQUIRE(img_cols == Kwin || img_cols % 128 == 0, "image of the window's first %d columns: must be whole 128-column blocks", img_cols);
@@ -844,9 +929,9 @@ extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT,
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
     DTC_REQUIRE(relu_mask || act == DTC_ACT_NONE || (Xsaved != nullptr && ldxs >= Kwin), "activation derivative needs Xsaved");
     DTC_REQUIRE(add == nullptr || ld_add >= Kwin, "bad ld_add");
-    int rc = check_img(dZimg, "dtc_linear_dgrad_h2i: dZ");
+    int rc = check_img(dZimg, "data gradient: dZ");
     if (rc != DTC_OK) return rc;
-    rc = check_img(wimgT, "dtc_linear_dgrad_h2i: weight image");
+    rc = check_img(wimgT, "data gradient: weight image");
     if (rc != DTC_OK) return rc;
     if (relu_mask) DTC_REQUIRE(M % BM == 0 && Kwin % 128 == 0, "sign record: M=%d and the window %d must be multiples of 128", M, Kwin);
     DTC_REQUIRE(hi_bytes(M, Kwin) < (1ll << 31), "matrix too large");
@@ -854,11 +939,12 @@ extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT,
     zo.nseg = 1;
     zo.img[0] = dZimg;
     zo.width[0] = N;
-    HOperand A;
+    TileArgs& t = out.t;
+    t = TileArgs{};
     int nn;
-    rc = to_operand(&zo, M, A, nn);
+    rc = to_operand(&zo, M, t.A, nn);
     if (rc != DTC_OK) return rc;
-    DgradEpiH dg{};
+    DgradEpiH& dg = t.dg;
     if (dX) {
         rc = to_dev(dX, dg.dX, Kwin, true, 0);
         if (rc != DTC_OK) return rc;
@@ -874,18 +960,79 @@ extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT,
     dg.ldxs = ldxs;
     dg.rmask = (const unsigned short*)relu_mask;
     dg.ldm = Kwin;
-    const int wide = ((dg.Xs && ldxs % 4 == 0 && dtc::aligned16(dg.Xs)) ? 2 : 0) | ((add && ld_add % 4 == 0 && dtc::aligned16(add)) ? 4 : 0);
-    const WimgView wv = wimg_view(wimgT, Kwin, A);
-    hipStream_t s = (hipStream_t)stream;
-    double bytes = 4.0 * M * (double)N + 4.0 * N * (double)Kwin + (dXimg ? 4.0 : 0.0) * M * img_cols + (add ? 4.0 : 0.0) * M * Kwin;
+    const WimgView wv = wimg_view(wimgT, Kwin, t.A);
+    t.wimg = wv.img;
+    t.wexps = wv.exps;
+    t.wimg_bytes = wv.bytes;
+    t.M = M;
+    t.N = Kwin;
+    t.act = relu_mask ? (int)DTC_ACT_RELU : act;
+    t.wide = ((dg.Xs && ldxs % 4 == 0 && dtc::aligned16(dg.Xs)) ? 2 : 0) | ((add && ld_add % 4 == 0 && dtc::aligned16(add)) ? 4 : 0);
+    t.yo = to_out(dXimg, M, img_cols);
+    out.K = N;
+    out.flop = 2.0 * M * (double)N * Kwin;
+    out.bytes = 4.0 * M * (double)N + 4.0 * N * (double)Kwin + (dXimg ? 4.0 : 0.0) * M * img_cols + (add ? 4.0 : 0.0) * M * Kwin;
     if (dX)
         for (int i = 0; i < dg.dX.nseg; ++i)
-            if (dg.dX.s[i].ptr) bytes += 4.0 * M * dg.dX.s[i].width * (dg.dX.s[i].accumulate ? 2.0 : 1.0);
-    if (relu_mask) bytes += 0.125 * M * (double)Kwin;
-    else if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)Kwin;
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, Kwin), 2.0 * M * (double)N * Kwin, s, bytes);
-    hipLaunchKernelGGL((linear_h2i_kernel<EPI_DGRAD>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(Kwin, 128))), dim3(256), 0, s, A,
-                       wv.img, wv.bytes, wv.exps, (const float*)nullptr, (float*)nullptr, 0ll, to_out(dXimg, M, img_cols), M, Kwin,
-                       relu_mask ? (int)DTC_ACT_RELU : act, wide, (unsigned short*)nullptr, 0, dg, MseEpiH{}, g_trace);
+            if (dg.dX.s[i].ptr) out.bytes += 4.0 * M * dg.dX.s[i].width * (dg.dX.s[i].accumulate ? 2.0 : 1.0);
+    if (relu_mask) out.bytes += 0.125 * M * (double)Kwin;
+    else if (act != DTC_ACT_NONE) out.bytes += 4.0 * M * (double)Kwin;
+    return DTC_OK;
+}
+}  // namespace
+
+// Y = act(X W^T + b): X = images side by side, wimg = the image of W built for that walk (trans = 0, rows (0, N), the operand's widths
+// as reduction ranges).  Results: fp32 Y [M, >= N] (may be NULL) and / or the image of Y (Yimg = image(M, N), may be NULL) -- at least one.
+extern "C" int dtc_linear_fwd_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, float* Y, int64_t ldy, void* Yimg,
+                                  uint16_t* relu_mask, int M, int N, int act, void* stream) {
+    LayerInfo L;
+    int rc = fwd_args(X, wimg, b, Y, ldy, Yimg, relu_mask, M, N, act, L);
+    if (rc != DTC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, L.K), L.flop, s, L.bytes);
+    hipLaunchKernelGGL((linear_h2i_kernel<EPI_FWD>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, L.t,
+                       MseEpiH{}, g_trace);
+    return dtc::check_launch("linear_fwd_h2i");
+}
+
+extern "C" int64_t dtc_linear_fwd_mse_h2i_parts(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128));
+}
+
+// the layer fused with its MSE against target[tidx[row], tcol0 + col] (dtc_linear_fwd_mse): dL/dY = (Y - target) * scale as fp32 (dY, may
+// be NULL) and / or as an image (dYimg); sq_part: dtc_linear_fwd_mse_h2i_parts(M, N) doubles (partials of sum (Y - target)^2)
+extern "C" int dtc_linear_fwd_mse_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, const float* target, int64_t ldt,
+                                      int64_t target_rows, int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy, void* dYimg,
+                                      double* sq_part, int M, int N, void* stream) {
+    DTC_REQUIRE(target && tidx && sq_part, "null pointer");
+    DTC_REQUIRE(tcol0 >= 0 && tcol0 + N <= ldt && target_rows > 0, "target columns [%d, %d) outside its %lld-wide rows", tcol0, tcol0 + N, (long long)ldt);
+    DTC_REQUIRE(target_rows * ldt <= MAX_ELEMS, "matrix too large");
+    LayerInfo L;
+    int rc = fwd_args(X, wimg, b, dY, lddy, dYimg, nullptr, M, N, (int)DTC_ACT_NONE, L);
+    if (rc != DTC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const MseEpiH mse{target, (const long long*)tidx, (long long)ldt, target_rows * ldt * 4, tcol0, scale, sq_part};
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, L.K), L.flop, s, L.bytes + 4.0 * M * N);
+    hipLaunchKernelGGL((linear_h2i_kernel<EPI_MSE>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, L.t,
+                       mse, g_trace);
+    return dtc::check_launch("linear_fwd_mse_h2i");
+}
+
+// dX[:, window] = (dZ W[:, window]) * act'(.): dZ = image(M, N); wimgT = the image of W^T built for the window (trans = 1, rows = the
+// window's column ranges of W, one reduction range (0, N)).  Results over the window: fp32 destination blocks dX (may be NULL;
+// accumulate flags honoured) and / or the image dXimg of the window's first img_cols columns.  add (may be NULL): fp32 [M, ld_add] added
+// to the product first.  Activation derivative: relu_mask (sign record) or Xsaved with act; both need the window to start at the saved
+// tensor's column 0.
+extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT, int Kwin, const DtcSegMat* dX, void* dXimg, int img_cols,
+                                    const float* add, int64_t ld_add, const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, int M, int act,
+                                    void* stream) {
+    LayerInfo L;
+    int rc = dgrad_args(dZimg, N, wimgT, Kwin, dX, dXimg, img_cols, add, ld_add, Xsaved, ldxs, relu_mask, M, act, L);
+    if (rc != DTC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, Kwin), L.flop, s, L.bytes);
+    hipLaunchKernelGGL((linear_h2i_kernel<EPI_DGRAD>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(Kwin, 128))), dim3(256), 0, s, L.t,
+                       MseEpiH{}, g_trace);
     return dtc::check_launch("linear_dgrad_h2i");
 }

@@ -159,86 +159,6 @@ __global__ __launch_bounds__(256) void wimage_kernel(const WimgGroup G) {
     for (int p = 0; p < P::NP; ++p) dst[p * 256 + rslot(r, h)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
 }
 
-// ---- activation-image results (round 4; the format and its consumers: see "ACTIVATION IMAGES" below) ----------------------------
-struct ImgOut {
-    u32x4* img;         // NULL: no image of the result
-    int stages;         // ceil(result columns / 16)
-};
-struct DgradEpiI3 {
-    float* dst;                   // fp32 destination [M, N] (may be NULL)
-    long long ldd;
-    int accumulate;               // result = dst + product (dst is only READ when an image is written: the sum goes to the image)
-    const float* Xs;              // saved post-activation output (act != none and no sign record)
-    long long ldxs;
-    const unsigned short* rmask;
-    int ldm;
-};
-
-// fp32 [M, K] (row stride lda) -> image; block = (row tile, stage), thread = (row, k half)
-__global__ __launch_bounds__(256) void aimage_kernel(const float* __restrict__ A, long long lda, int M, int K, u32x4* __restrict__ img, int stages) {
-    const int tr = blockIdx.x / stages, s = blockIdx.x - tr * stages;
-    const int r = threadIdx.x >> 1, h = threadIdx.x & 1;
-    const int row = tr * 128 + r, k0 = s * BK + 8 * h;
-    f32x4 v[2];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = (row < M && k0 + e < K) ? A[(long long)row * lda + k0 + e] : 0.f;
-    const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
-    u32x4* dst = img + (long long)blockIdx.x * (WIMG_CHUNK / 16);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) dst[p * 256 + rslot(r, h)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
-}
-
-// The wave's 32 x 32 tile sits in its LDS patch; lane -> rows (lane >> 2) + 16 q, the 8 columns 8 (lane & 3) .. + 7.  `fin(v, row, col)`
-// turns the 8 raw values of a row into final ones (activation derivative, accumulation, fp32 store); what it returns is split into
-// the image.  trow: the tile's first row inside its 128-row tile; col_t: its first result column.
-template <class F>
-__device__ __forceinline__ void patch_rows8(const float* patch, int lane, int tr, int trow, int col_t, int M, int N, const ImgOut& yo, F fin) {
-    const int r16 = lane >> 2, c8 = lane & 3;
-    const int col = col_t + 8 * c8;
-    u32x4* chunk = yo.img ? yo.img + ((long long)tr * yo.stages + (col >> 4)) * (WIMG_CHUNK / 16) : nullptr;
-    const bool in_img = yo.img && (col >> 4) < yo.stages && tr * 128 < M;      // (a 12-wave workgroup's row tiles behind the matrix have no chunk)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int rl = r16 + 16 * q, row = tr * 128 + trow + rl;
-        f32x4 v[2] = {patch_get(patch, rl, 2 * c8), patch_get(patch, rl, 2 * c8 + 1)};
-        fin(v, row, col);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = (row < M && col + e < N) ? v[e >> 2][e & 3] : 0.f;
-        if (in_img) {
-            const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) chunk[p * 256 + rslot(trow + rl, (col >> 3) & 1)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
-        }
-    }
-}
-// 8 consecutive floats of a row to / from global memory: two 16-byte accesses when the row allows it (aligned base, ld % 4 == 0,
-// all 8 inside the matrix), element-wise otherwise
-__device__ __forceinline__ void store8(float* base, long long ld, int row, int col, int M, int N, bool wide, const f32x4 (&v)[2]) {
-    if (row >= M) return;
-    float* p = base + (long long)row * ld + col;
-    if (wide && col + 8 <= N) {
-        *reinterpret_cast<f32x4*>(p) = v[0];
-        *reinterpret_cast<f32x4*>(p + 4) = v[1];
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (col + e < N) p[e] = v[e >> 2][e & 3];
-    }
-}
-__device__ __forceinline__ void load8(const float* base, long long ld, int row, int col, int M, int N, bool wide, f32x4 (&v)[2]) {
-    v[0] = v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row >= M) return;
-    const float* p = base + (long long)row * ld + col;
-    if (wide && col + 8 <= N) {
-        v[0] = *reinterpret_cast<const f32x4*>(p);
-        v[1] = *reinterpret_cast<const f32x4*>(p + 4);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (col + e < N) v[e >> 2][e & 3] = p[e];
-    }
-}
-
 // amax slots of a two-term fp16 launch (s3_core.hpp): operand segments in, weight image partials in, results out
 struct H2Arg {
     const u32* xa[4];             // one slot per segment of the row operand (X resp. dZ)
@@ -253,9 +173,7 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
                                                            long long ldy, int M, int N, int K, int act, int wide,
                                                            unsigned short* __restrict__ wmask, int ldwm, const DgradEpi dg,
                                                            const MseEpiS3 mse, const u32x4* __restrict__ wimg, long long wimg_bytes,
-                                                           const ImgOut yo, int yo_seg, const H2Arg h2) {
-    // yo.img != NULL (round 4): the result ALSO (EPI_FWD: Y may then be NULL) leaves as an activation image -- of the whole result
-    // (EPI_FWD) or of destination block yo_seg (EPI_DGRAD) -- for the image-operand kernels that consume it
+                                                           const H2Arg h2) {
     static_assert(!H2 || WIMG, "the fp16 path reads its weights as an image");
     using P = Prec<H2>;
     constexpr int NP = P::NP, NT = P::NT, WCH = NP * WIMG_PLANE;
@@ -621,38 +539,6 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
         return;
     }
     if constexpr (EPI == EPI_FWD) {
-        if (!H2 && yo.img) {                                   // the epilogue of linear_i3_kernel: final values -> patch -> fp32 rows and / or image pieces
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn_off + 32 * j + l31;
-                const float bv = (bias && col < N) ? bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
-                if (wmask && full) {
-                    unsigned bits = 0u;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) bits |= acc[i][j][r] > 0.f ? (1u << r) : 0u;
-                    wmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * ldwm + col] = (unsigned short)bits;
-                }
-                if (act == DTC_ACT_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] <= 0.f ? 0.f : acc[i][j][r];      // (NaN passes through, as torch.relu)
-                } else if (act == DTC_ACT_ELU) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : expm1f(acc[i][j][r]);
-                } else if (act != DTC_ACT_NONE) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], act);
-                }
-                patch_put(patch, acc[i][j], half, l31);
-                patch_rows8(patch, lane, tr, wm_off + 32 * i, n0 + wn_off + 32 * j, M, N, yo, [&](f32x4 (&v)[2], int row, int c) {
-                    if (Y) store8(Y, ldy, row, c, M, N, wide != 0, v);
-                });
-            }
-            return;
-        }
         if (wide && full) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -712,73 +598,6 @@ __global__ __launch_bounds__(256, 3) void linear_s3_kernel(const SegMatDev X, co
     } else {
         // ---- data-gradient epilogue: activation derivative, segmented destination (csrc/gemm.hip: linear_dgrad_kernel)
         const SegMatDev& dX = dg.dX;
-        if (!H2 && yo.img) {
-            // every tile through the patch; lane -> 8 consecutive result columns of a row.  A group that lies inside ONE destination
-            // block takes 16-byte accesses (derivative through the saved output, accumulation, fp32 store) and, in block yo_seg, the
-            // image pieces; a group that straddles a block border (never in the image's block: its borders are multiples of 8) goes
-            // element by element.
-            const int r16 = lane >> 2, c8 = lane & 3;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (dg.rmask && full) {
-                    const unsigned bits = dg.rmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * dg.ldm + n0 + wn_off + 32 * j + l31];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = (bits >> r) & 1u ? acc[i][j][r] : 0.f;
-                }
-                patch_put(patch, acc[i][j], half, l31);
-                const int col = n0 + wn_off + 32 * j + 8 * c8;
-                if (col >= N) continue;
-                const int sj = find_seg(dX, col);
-                const SegDev sdj = dX.s[sj];
-                const bool whole = col + 8 <= sdj.start + sdj.width;
-                const bool w16 = whole && ((dg.wide_segs >> sj) & 1) && ((col - sdj.start + sdj.col0) & 3) == 0;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int rl = r16 + 16 * q, row = m0 + wm_off + 32 * i + rl;
-                    f32x4 v[2] = {patch_get(patch, rl, 2 * c8), patch_get(patch, rl, 2 * c8 + 1)};
-                    if (!dg.rmask && act != DTC_ACT_NONE) {         // (single destination block: host-checked)
-                        f32x4 y[2];
-                        load8(dg.Xs, dg.ldxs, row, col, M, N, ((dg.wide_segs >> 4) & 1) != 0, y);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = act_bwd(v[e >> 2][e & 3], y[e >> 2][e & 3], act);
-                    }
-                    if (whole) {
-                        const int lc = col - sdj.start;             // column inside the block
-                        float* base = sdj.ptr ? sdj.ptr + sdj.col0 : nullptr;
-                        if (sdj.ptr && sdj.accumulate) {
-                            f32x4 o[2];
-                            load8(base, sdj.ld, row, lc, M, sdj.width, w16, o);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = o[e >> 2][e & 3] + v[e >> 2][e & 3];
-                        }
-                        const bool to_img = sj == yo_seg;
-                        if (sdj.ptr && !(sdj.accumulate && to_img)) store8(base, sdj.ld, row, lc, M, sdj.width, w16, v);
-                        if (to_img && (lc >> 4) < yo.stages) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = (row < M) ? v[e >> 2][e & 3] : 0.f;
-                            const Split3 s0 = split3(v[0]), s1 = split3(v[1]);
-                            u32x4* chunk = yo.img + ((long long)tr * yo.stages + (lc >> 4)) * (WIMG_CHUNK / 16);
-#pragma unroll
-                            for (int p = 0; p < 3; ++p)
-                                chunk[p * 256 + rslot(wm_off + 32 * i + rl, (lc >> 3) & 1)] = u32x4{s0.p[p].x, s0.p[p].y, s1.p[p].x, s1.p[p].y};
-                        }
-                    } else if (row < M) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int c = col + e;
-                            if (c >= N) break;
-                            const SegDev sc = dX.s[find_seg(dX, c)];
-                            if (sc.ptr == nullptr) continue;
-                            float* qd = sc.ptr + sc.col0 + (c - sc.start) + (long long)row * sc.ld;
-                            *qd = sc.accumulate ? (*qd + v[e >> 2][e & 3]) : v[e >> 2][e & 3];
-                        }
-                    }
-                }
-            }
-            return;
-        }
         if (dg.rmask && full) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -970,14 +789,20 @@ extern "C" int64_t dtc_s3_planes_bytes(int N, int K) {
     return (img > wt ? img : wt) + 64;
 }
 
+namespace {
+int fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask, void* wplanes, int wimage_ready,
+           int M, int N, int K, int act, void* stream, bool h2, uint32_t* y_amax);
+int dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask,
+             void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream, bool h2, const uint32_t* dz_amax);
+}  // namespace
+
 // Y = act(X W^T + b) [+ the ReLU sign record when relu_mask != NULL] on the split-precision path
 extern "C" int dtc_linear_fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
                                  void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream) {
     DTC_REQUIRE(Y, "null pointer");
-    return dtc_linear_fwd_s3i(X, W, b, Y, ldy, nullptr, relu_mask, wplanes, wimage_ready, M, N, K, act, stream);
+    return fwd_s3(X, W, b, Y, ldy, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, false, nullptr);
 }
 
-// dtc_linear_fwd_s3 whose result also (Y != NULL) or only (Y == NULL) leaves as the activation image Yimg = image(M, N)
 namespace {
 // The row operand's amax slots of an fp16 launch.  A segment that brings none gets the amax of exactly its block (rows < M, its
 // columns) computed here, into the call's own scratch: `scratch` = four records behind the weight image's partial maxima
@@ -997,12 +822,10 @@ int h2_operand(const DtcSegMat* X, const SegMatDev& xd, int M, H2Arg& a, void* s
     DTC_REQUIRE(amax_group_run(G, scratch, 4 * AMAX_RECORD_BYTES, s), "hipMemsetAsync failed");
     return DTC_OK;
 }
-int fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
+int fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
            void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream, bool h2, uint32_t* y_amax) {
-    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && (Y == nullptr || ldy >= N), "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
-    DTC_REQUIRE(W && (Y || Yimg) && dtc::aligned16(Yimg), "null / unaligned pointer");
-    DTC_REQUIRE(Yimg == nullptr || dtc_s3_aimage_bytes(M, N) < (1ll << 31), "image beyond 2 GiB");
-    const ImgOut yo{(u32x4*)Yimg, (int)dtc::ceil_div(N, BK)};
+    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && Y != nullptr && ldy >= N, "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
+    DTC_REQUIRE(W, "null pointer");
     DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
     DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * ldy <= MAX_ELEMS * 4, "matrix too large");
     SegMatDev xd;
@@ -1012,10 +835,10 @@ int fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128));
     const int wide = (Y && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
     if (relu_mask)
-        DTC_REQUIRE(act == DTC_ACT_RELU && (wide || Yimg) && M % BM == 0 && N % 128 == 0, "sign record (split path): M=%d and N=%d must be multiples of 128", M, N);
+        DTC_REQUIRE(act == DTC_ACT_RELU && wide && M % BM == 0 && N % 128 == 0, "sign record (split path): M=%d and N=%d must be multiples of 128", M, N);
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     if (h2) {
-        DTC_REQUIRE(wimage_on() && Yimg == nullptr, "fp16 path: needs weight images (DTC_S3_WIMG) and writes no activation image");
+        DTC_REQUIRE(wimage_on(), "fp16 path: needs weight images (DTC_S3_WIMG)");
         DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
         H2Arg a;
         const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0, true, (long long)N * K);
@@ -1025,31 +848,26 @@ int fwd_s3(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t
         a.ya[0] = y_amax;
         a.wa = reinterpret_cast<const u32*>(reinterpret_cast<const char*>(wplanes) + ib);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD, true, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
-                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)wplanes, ib, yo, 0, a);
+                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)wplanes, ib, a);
     } else if (wimage_on()) {
         DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
         const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD, true>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
-                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)wplanes, ib, yo, 0, H2Arg{});
+                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)wplanes, ib, H2Arg{});
     } else {
         hipLaunchKernelGGL((linear_s3_kernel<EPI_FWD, false>), dim3(grid), dim3(256), 0, s, xd, W, b, Y, (long long)ldy,
-                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)nullptr, 0ll, yo, 0, H2Arg{});
+                           M, N, K, act, wide, (unsigned short*)relu_mask, N, DgradEpi{}, MseEpiS3{}, (const u32x4*)nullptr, 0ll, H2Arg{});
     }
     return dtc::check_launch("linear_fwd_s3");
 }
 }  // namespace
-
-extern "C" int dtc_linear_fwd_s3i(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
-                                  void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream) {
-    return fwd_s3(X, W, b, Y, ldy, Yimg, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, false, nullptr);
-}
 
 // The same layer on the two-term fp16 path (s3_core.hpp): a segment of X brings the amax slot of its source tensor (DtcSeg.amax) or
 // none (NULL: computed here, one memset + one small launch in front of the GEMM), y_amax (may be NULL) receives max(*y_amax, largest |Y| written) -- zero it before the first kernel that writes Y
 extern "C" int dtc_linear_fwd_h2(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, uint16_t* relu_mask,
                                  void* wplanes, int wimage_ready, uint32_t* y_amax, int M, int N, int K, int act, void* stream) {
     DTC_REQUIRE(Y, "null pointer");
-    return fwd_s3(X, W, b, Y, ldy, nullptr, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, true, y_amax);
+    return fwd_s3(X, W, b, Y, ldy, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, true, y_amax);
 }
 
 // dX = (dZ W) * act'(.), W [N, K] as stored (the kernel's reduction-contiguous operand, the planes of W^T, is prepared here);
@@ -1058,13 +876,11 @@ extern "C" int dtc_linear_fwd_h2(const DtcSegMat* X, const float* W, const float
 extern "C" int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, const float* Xsaved,
                                    int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
                                    void* stream) {
-    return dtc_linear_dgrad_s3i(dZ, lddz, W, dX, nullptr, 0, Xsaved, ldxs, relu_mask, wplanes, wimage_ready, M, N, K, act, stream);
+    return dgrad_s3(dZ, lddz, W, dX, Xsaved, ldxs, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, false, nullptr);
 }
 
-// dtc_linear_dgrad_s3 whose destination block `img_seg` (its first column and width multiples of 8 / 16) ALSO leaves as the activation
-// image dXimg = image(M, width of the block); a block that accumulates is then only read (the sum exists as the image)
 namespace {
-int dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, void* dXimg, int img_seg,
+int dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX,
              const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N,
              int K, int act, void* stream, bool h2, const uint32_t* dz_amax) {
     DTC_REQUIRE(M > 0 && N > 0 && K > 0 && lddz >= N, "bad shape");
@@ -1087,14 +903,6 @@ int dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX,
     dg.col_skip = col_skip;
     dg.wide_segs = wide_mask_s3(dg.dX, dg.Xs, ldxs, col_skip);
     if (relu_mask) DTC_REQUIRE(M % BM == 0 && K % 128 == 0 && col_skip == 0, "sign record (split path): M=%d and K=%d must be multiples of 128", M, K);
-    ImgOut yo{nullptr, 0};
-    if (dXimg) {
-        DTC_REQUIRE(dtc::aligned16(dXimg) && img_seg >= 0 && img_seg < dg.dX.nseg, "image block %d outside the destination's %d blocks", img_seg, dg.dX.nseg);
-        const SegDev& sg = dg.dX.s[img_seg];
-        DTC_REQUIRE(sg.start % 8 == 0 && sg.width % 16 == 0 && sg.start >= col_skip, "image block: first column %d / width %d must be multiples of 8 / 16", sg.start, sg.width);
-        DTC_REQUIRE(dtc_s3_aimage_bytes(M, sg.width) < (1ll << 31), "image beyond 2 GiB");
-        yo = ImgOut{(u32x4*)dXimg, sg.width / BK};
-    }
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(K - col_skip, 128));
     double bytes = 4.0 * ((double)M * N + (double)N * K);
@@ -1105,7 +913,7 @@ int dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX,
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * (K - col_skip), s, bytes);
     // roles inside the kernel: output columns = K of the layer, reduction = N of the layer
     if (h2) {
-        DTC_REQUIRE(wimage_on() && dXimg == nullptr, "fp16 path: needs weight images and writes no activation image");
+        DTC_REQUIRE(wimage_on(), "fp16 path: needs weight images");
         H2Arg a{};
         for (int i = 0; i < dX->nseg; ++i) a.ya[i] = dX->seg[i].amax;
         const long long ib = build_wimage(W, wplanes, K, col_skip, K, 1, zin, (int)dtc::ceil_div(K - col_skip, 128), s, wimage_ready != 0, true, (long long)N * K);
@@ -1122,35 +930,29 @@ int dgrad_s3(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX,
         a.wa = reinterpret_cast<const u32*>(reinterpret_cast<const char*>(wplanes) + ib);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, true, true>), dim3(grid), dim3(256), 0, s, zin, (const float*)nullptr, (const float*)nullptr,
                            (float*)nullptr, 0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{},
-                           (const u32x4*)wplanes, ib, yo, img_seg, a);
+                           (const u32x4*)wplanes, ib, a);
     } else if (wimage_on()) {
         const long long ib = build_wimage(W, wplanes, K, col_skip, K, 1, zin, (int)dtc::ceil_div(K - col_skip, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, true>), dim3(grid), dim3(256), 0, s, zin, (const float*)nullptr, (const float*)nullptr,
                            (float*)nullptr, 0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{},
-                           (const u32x4*)wplanes, ib, yo, img_seg, H2Arg{});
+                           (const u32x4*)wplanes, ib, H2Arg{});
     } else {
         float* WT = (float*)wplanes;
         hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dtc::ceil_div(K, 32), (unsigned)dtc::ceil_div(N, 32)), dim3(256), 0, s, W, WT, N, K);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_DGRAD, false>), dim3(grid), dim3(256), 0, s, zin, (const float*)WT, (const float*)nullptr,
                            (float*)nullptr, 0ll, M, K, N, relu_mask ? (int)DTC_ACT_RELU : act, 0, (unsigned short*)nullptr, 0, dg, MseEpiS3{},
-                           (const u32x4*)nullptr, 0ll, yo, img_seg, H2Arg{});
+                           (const u32x4*)nullptr, 0ll, H2Arg{});
     }
     return dtc::check_launch("linear_dgrad_s3");
 }
 }  // namespace
-
-extern "C" int dtc_linear_dgrad_s3i(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, void* dXimg, int img_seg,
-                                    const float* Xsaved, int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N,
-                                    int K, int act, void* stream) {
-    return dgrad_s3(dZ, lddz, W, dX, dXimg, img_seg, Xsaved, ldxs, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, false, nullptr);
-}
 
 // The data gradient on the two-term fp16 path: dz_amax = amax slot of dZ; every destination block with a slot (dX->seg[i].amax, may be
 // NULL) receives max(slot, largest |value| written to it) -- for an accumulating block the value written is the sum
 extern "C" int dtc_linear_dgrad_h2(const float* dZ, int64_t lddz, const uint32_t* dz_amax, const float* W, const DtcSegMat* dX, const float* Xsaved,
                                    int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
                                    void* stream) {
-    return dgrad_s3(dZ, lddz, W, dX, nullptr, 0, Xsaved, ldxs, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, true, dz_amax);
+    return dgrad_s3(dZ, lddz, W, dX, Xsaved, ldxs, relu_mask, wplanes, wimage_ready, M, N, K, act, stream, true, dz_amax);
 }
 
 extern "C" int64_t dtc_linear_fwd_mse_s3_parts(int M, int N) {
@@ -1186,15 +988,15 @@ int fwd_mse_s3(const DtcSegMat* X, const float* W, const float* b, const float* 
         a.ya[0] = dy_amax;
         a.wa = reinterpret_cast<const u32*>(reinterpret_cast<const char*>(wplanes) + ib);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE, true, true>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
-                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)wplanes, ib, ImgOut{nullptr, 0}, 0, a);
+                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)wplanes, ib, a);
     } else if (wimage_on()) {
         DTC_REQUIRE(wplanes && dtc::aligned16(wplanes), "null / unaligned weight-image scratch");
         const long long ib = build_wimage(W, wplanes, N, 0, K, 0, xd, (int)dtc::ceil_div(N, 128), s, wimage_ready != 0);
         hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE, true>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
-                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)wplanes, ib, ImgOut{nullptr, 0}, 0, H2Arg{});
+                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)wplanes, ib, H2Arg{});
     } else {
         hipLaunchKernelGGL((linear_s3_kernel<EPI_MSE, false>), dim3(grid), dim3(256), 0, s, xd, W, b, dY, (long long)lddy,
-                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)nullptr, 0ll, ImgOut{nullptr, 0}, 0, H2Arg{});
+                           M, N, K, (int)DTC_ACT_NONE, 0, (unsigned short*)nullptr, 0, DgradEpi{}, mse, (const u32x4*)nullptr, 0ll, H2Arg{});
     }
     return dtc::check_launch("linear_fwd_mse_s3");
 }
@@ -1299,393 +1101,3 @@ extern "C" int dtc_amax(const DtcSegMat* X, int M, uint32_t* slot, void* stream)
     hipLaunchKernelGGL(amax_kernel, dim3(grid), dim3(256), 0, s, xd, M, (u32*)slot);
     return dtc::check_launch("amax");
 }
-
-// =====================================================================================================================
-// Round 4: ACTIVATION IMAGES.  The X side of linear_s3_kernel is converted fp32 -> bf16 x 3 inside the K loop of every one of
-// the N / 128 column tiles that reads it (and again by the weight-gradient kernel); profiles/r03_gemm_pmc.md: 3.2 VALU per MFMA,
-// MFMA pipe 0.44-0.51 busy.  An activation image is the operand in the layout of the WEIGHT image -- for every 128-ROW tile and
-// 16-k stage one 12 KiB chunk [plane 3][slot 256][16 bytes], slot = rslot(row, k half) -- written ONCE by the epilogue of the
-// kernel that produces the activation (the split happens on the accumulator's final values) and copied into LDS by LDS-DMA by
-// every consumer: linear_i3_kernel's K loop is 6 LDS-DMA + 12 ds_read_b128 + 24 MFMA per wave and stage, no conversion, no
-// operand registers.  Rows >= M and columns >= K of an image are zero (the producers write whole chunks).
-//   image(M, K): ceil(M / 128) x ceil(K / 16) chunks; chunk (r, s) at ((r * stages + s) * 12 KiB).
-namespace {
-
-// Both operands as images.  EPI_FWD: Y = act(X W^T + b) as fp32 (Y != NULL) and / or as an image (yo.img), sign record optional.
-// EPI_MSE: the loss epilogue of dtc_linear_fwd_mse.  EPI_DGRAD: dX = (dZ W) * act'(.), single destination (dg).
-// RT = 128-row tiles per workgroup.  RT = 1: 4 waves, three workgroups per CU.  RT = 3 (round 4): ONE workgroup of 12 waves per CU whose
-// three row tiles share the W stage -- 48 instead of 72 KiB of LDS-DMA per CU and stage for the same 12 waves of MFMA work.  (Measured on
-// the RT = 1 kernel, tools/jobs/r4_ablate.sh: the K loop costs the same with the LDS-DMA or the fragment reads removed, and 16 us more
-// -- 55 -> 71 us on 24576 x 512 x 512 -- with both: what bounds it is the LDS / vector-memory path that carries both, not the
-// conversion work the activation images removed.)
-template <int EPI, int RT>
-__global__ __launch_bounds__(256 * RT, RT == 1 ? 3 : 1) void linear_i3_kernel(const u32x4* __restrict__ ximg, long long ximg_bytes,
-                                                                              const u32x4* __restrict__ wimg, long long wimg_bytes, int total,
-                                                                              const float* __restrict__ bias, float* __restrict__ Y, long long ldy,
-                                                                              const ImgOut yo, int M, int N, int act, int wide,
-                                                                              unsigned short* __restrict__ wmask, int ldwm, const DgradEpiI3 dg,
-                                                                              const MseEpiS3 mse) {
-    constexpr int BN = 128, WN = 2, TM = 2, TN = 2, BMW = BM * RT;
-    // four separate objects: an LDS-DMA into one stage buffer cannot alias the fragment reads of the other (see linear_s3_kernel)
-    __shared__ __attribute__((aligned(16))) u32x2 Xs0[RT * 3][BM * 4];
-    __shared__ __attribute__((aligned(16))) u32x2 Xs1[RT * 3][BM * 4];
-    __shared__ __attribute__((aligned(16))) u32x2 Ws0[3][BN * 4];
-    __shared__ __attribute__((aligned(16))) u32x2 Ws1[3][BN * 4];
-#define XS(b) ((b) ? Xs1 : Xs0)
-#define WS(b) ((b) ? Ws1 : Ws0)
-    int trw, tc;
-    if (!map_tile(blockIdx.x, (M + BMW - 1) / BMW, (N + BN - 1) / BN, trw, tc)) {
-        if (EPI == EPI_MSE && threadIdx.x == 0) mse.part[blockIdx.x] = 0.0;
-        return;
-    }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int rt = wave_u >> 2, w4 = wave_u & 3;        // the wave's row tile inside the workgroup, its index inside that tile
-    const int tr = trw * RT + rt;                       // the wave's 128-row tile of the matrix
-    const int m0 = tr * BM, n0 = tc * BN;
-    const int wm_off = (w4 / WN) * (32 * TM), wn_off = (w4 % WN) * (32 * TN);
-    const int half = lane >> 5, l31 = lane & 31;
-    const rsrc_t xres = make_rsrc_bytes(ximg, ximg_bytes), wres = make_rsrc_bytes(wimg, wimg_bytes);
-    // LDS-DMA shares: every wave its quarter (rows 32 w4 ..) of the three planes of ITS row tile; of the W stage the same quarter of
-    // all three planes (RT = 1) or of plane rt (RT = 3: twelve waves, twelve pieces)
-    const u32 lane_off = (u32)((tid & 255) * 16);
-    u32 xchunk = (u32)(tr * total) * (u32)WIMG_CHUNK, wchunk = (u32)(tc * total) * (u32)WIMG_CHUNK;
-    int left = total;                                   // stages not yet requested
-    auto load_stage = [&](auto nbc) {                   // next stage -> LDS[nbuf]; past the last stage: out-of-range lanes, zeros land
-#if DTC_I3_PROBE & 16
-        constexpr int nbuf = 1;
-#else
-        constexpr int nbuf = decltype(nbc)::value;
-#endif
-        const u32 voff = lane_off | (left > 0 ? 0u : INVALID);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)&XS(nbuf)[rt * 3 + p][w4 * 128], 16, voff, xchunk + p * WIMG_PLANE, 0, 0);
-            if (RT == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)&WS(nbuf)[p][w4 * 128], 16, voff, wchunk + p * WIMG_PLANE, 0, 0);
-        }
-        if (RT == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)&WS(nbuf)[rt][w4 * 128], 16, voff, wchunk + rt * WIMG_PLANE, 0, 0);
-        xchunk += WIMG_CHUNK;
-        wchunk += WIMG_CHUNK;
-        --left;
-    };
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // One stage: (1) the six LDS-DMA pieces of the NEXT stage are issued first -- hipcc otherwise sinks them behind the MFMAs and waits for
-    // them at once, i.e. no transfer runs under any arithmetic (first build of this kernel: 66 us on 24576 x 512 x 512, the speed of the
-    // converting kernel) --, (2) the fragments in the order the MFMAs consume them, the second column tile's while the first computes.
-    // The fences pin that order; inside a group the compiler schedules freely.
-#ifndef DTC_I3_PROBE
-#define DTC_I3_PROBE 0         // timing-only ablations (tools/jobs/r4_ablate.sh): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no barrier, 8 no stores
-#endif
-#if DTC_I3_PROBE & 2
-    bf16x8 a[TM][3], b[TN][3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Xs0[p][0])[rslot(wm_off + 32 * i + l31, half)]);
-            b[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Ws0[p][0])[rslot(wn_off + 32 * i + l31, half)]);
-        }
-#endif
-    auto stage = [&](auto bc) {
-        constexpr int buf = decltype(bc)::value;
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};      // smallest terms first
-        __builtin_amdgcn_sched_barrier(0);
-#if !(DTC_I3_PROBE & 1) && !defined(DTC_I3_DMA_MID)
-        load_stage(std::integral_constant<int, buf ^ 1>{});
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#if !(DTC_I3_PROBE & 2)
-        bf16x8 a[TM][3], b[TN][3];
-#if DTC_I3_PROBE & 16          // (probe) every LDS-DMA lands in buffer 1, every fragment is read from buffer 0: traffic without data dependence
-        auto rda = [&](int i, int p) { a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Xs0[rt * 3 + p][0])[rslot(wm_off + 32 * i + l31, half)]); };
-        auto rdb = [&](int j, int p) { b[j][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&Ws0[p][0])[rslot(wn_off + 32 * j + l31, half)]); };
-#else
-        auto rda = [&](int i, int p) { a[i][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&XS(buf)[rt * 3 + p][0])[rslot(wm_off + 32 * i + l31, half)]); };
-        auto rdb = [&](int j, int p) { b[j][p] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(&WS(buf)[p][0])[rslot(wn_off + 32 * j + l31, half)]); };
-#endif
-        rda(0, 2); rdb(0, 0); rda(1, 2);
-        rda(0, 1); rdb(0, 1); rda(1, 1);
-        rda(0, 0); rdb(0, 2); rda(1, 0);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[0][PB[t]], acc[i][0], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#if !(DTC_I3_PROBE & 2)
-        rdb(1, 0); rdb(1, 1); rdb(1, 2);
-#endif
-#if !(DTC_I3_PROBE & 1) && defined(DTC_I3_DMA_MID)
-        load_stage(std::integral_constant<int, buf ^ 1>{});      // (variant) the pieces issue under the stage's first six MFMAs
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 3; t < 6; ++t)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[0][PB[t]], acc[i][0], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[1][PB[t]], acc[i][1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#if !(DTC_I3_PROBE & 4)
-        __syncthreads();
-#endif
-    };
-    load_stage(S0{});
-    __syncthreads();
-    for (int trip = (total + 1) >> 1; trip > 0; --trip) {
-        stage(S0{});
-        stage(S1{});
-    }
-    // every wave is past its last fragment read and every LDS-DMA has landed (the barrier's wait): LDS becomes the patches
-    float* patch = wave_u < 3 * RT ? reinterpret_cast<float*>(&Xs0[0][0]) + wave_u * (32 * LDW)
-                                   : reinterpret_cast<float*>(&Xs1[0][0]) + (wave_u - 3 * RT) * (32 * LDW);
-
-    if constexpr (EPI == EPI_FWD) {
-        const bool full = (m0 + BM <= M) && (n0 + BN <= N);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn_off + 32 * j + l31;
-            const float bv = (bias && col < N) ? bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
-            if (wmask && full) {
-                unsigned bits = 0u;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) bits |= acc[i][j][r] > 0.f ? (1u << r) : 0u;
-                wmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * ldwm + col] = (unsigned short)bits;
-            }
-            if (act == DTC_ACT_RELU) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] <= 0.f ? 0.f : acc[i][j][r];      // (NaN passes through, as torch.relu)
-            } else if (act == DTC_ACT_ELU) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] > 0.f ? acc[i][j][r] : expm1f(acc[i][j][r]);
-            } else if (act != DTC_ACT_NONE) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], act);
-            }
-            patch_put(patch, acc[i][j], half, l31);
-#if DTC_I3_PROBE & 8
-            if (acc[i][j][0] == 123.456f)
-#endif
-            patch_rows8(patch, lane, tr, wm_off + 32 * i, n0 + wn_off + 32 * j, M, N, yo, [&](f32x4 (&v)[2], int row, int c) {
-                if (Y) store8(Y, ldy, row, c, M, N, wide != 0, v);
-            });
-        }
-    } else if constexpr (EPI == EPI_MSE) {
-        // e = (acc + bias) - target[tidx[row], tcol0 + col];  dY = e * scale (fp32 and / or image);  partial = sum e^2 (double)
-        const rsrc_t tres = make_rsrc_bytes(mse.target, mse.target_bytes);
-        double sq = 0.0;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn_off + 32 * j + l31;
-            const bool cok = col < N;
-            const float bv = (bias && cok) ? bias[col] : 0.f;
-            const int row0 = m0 + wm_off + 32 * i + 4 * half;
-            float tg[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2);
-                const long long src = mse.tidx[row < M ? row : 0];
-                tg[r] = bload(tres, (u32)((src * mse.ldt + mse.tcol0 + col) * 4) | (cok ? 0u : INVALID), 0u);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2);
-                const float e = (cok && row < M) ? (acc[i][j][r] + bv) - tg[r] : 0.f;
-                acc[i][j][r] = e * mse.scale;
-                sq += (double)e * (double)e;
-            }
-            patch_put(patch, acc[i][j], half, l31);
-            patch_rows8(patch, lane, tr, wm_off + 32 * i, n0 + wn_off + 32 * j, M, N, yo, [&](f32x4 (&v)[2], int row, int c) {
-                if (Y) store8(Y, ldy, row, c, M, N, wide != 0, v);
-            });
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
-        __syncthreads();                                   // the patches (Xs0 / Xs1) are done; the partial sums use another buffer anyway
-        double* red = reinterpret_cast<double*>(&Ws0[0][0]);
-        if (lane == 0) red[wave] = sq;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-#pragma unroll
-            for (int w = 0; w < 4 * RT; ++w) t += red[w];
-            mse.part[blockIdx.x] = t;
-        }
-    } else {
-        const bool full = (m0 + BM <= M) && (n0 + BN <= N);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            if (dg.rmask && full) {
-                const unsigned bits = dg.rmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * dg.ldm + n0 + wn_off + 32 * j + l31];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = (bits >> r) & 1u ? acc[i][j][r] : 0.f;
-            }
-            patch_put(patch, acc[i][j], half, l31);
-            patch_rows8(patch, lane, tr, wm_off + 32 * i, n0 + wn_off + 32 * j, M, N, yo, [&](f32x4 (&v)[2], int row, int c) {
-                if (!dg.rmask && act != DTC_ACT_NONE) {
-                    f32x4 y[2];
-                    load8(dg.Xs, dg.ldxs, row, c, M, N, (wide & 2) != 0, y);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = act_bwd(v[e >> 2][e & 3], y[e >> 2][e & 3], act);
-                }
-                if (dg.accumulate) {
-                    f32x4 o[2];
-                    load8(dg.dst, dg.ldd, row, c, M, N, (wide & 1) != 0, o);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = o[e >> 2][e & 3] + v[e >> 2][e & 3];
-                }
-                if (dg.dst && !(dg.accumulate && yo.img)) store8(dg.dst, dg.ldd, row, c, M, N, (wide & 1) != 0, v);
-            });
-        }
-    }
-#undef XS
-#undef WS
-}
-
-}  // namespace
-
-// ---- activation images: host side --------------------------------------------------------------------------------------------------
-extern "C" int64_t dtc_s3_aimage_bytes(int M, int K) {
-    if (M <= 0 || K <= 0) return 0;
-    return (long long)WIMG_CHUNK * dtc::ceil_div(M, 128) * dtc::ceil_div(K, BK);
-}
-
-// fp32 A [M, K] -> its activation image (for operands no split kernel produces: tests, hand-over points)
-extern "C" int dtc_s3_aimage(const float* A, int64_t lda, int M, int K, void* img, void* stream) {
-    DTC_REQUIRE(A && img && dtc::aligned16(img) && M > 0 && K > 0 && lda >= K, "null pointer / bad shape");
-    const int stages = (int)dtc::ceil_div(K, BK);
-    dtc::ProfScope prof("aimage", 0.0, (hipStream_t)stream, 10.0 * M * (double)K);
-    hipLaunchKernelGGL(aimage_kernel, dim3((unsigned)(dtc::ceil_div(M, 128) * stages)), dim3(256), 0, (hipStream_t)stream, A, (long long)lda, M, K,
-                       (u32x4*)img, stages);
-    return dtc::check_launch("s3_aimage");
-}
-
-namespace {
-// Row tiles per workgroup of an image-operand launch: 3 (one 12-wave workgroup per CU, 384 x 128 tiles) when that still gives every CU
-// a workgroup, else 1 (128 x 128 tiles, three workgroups per CU).  DTC_I3_RT=1 / 3 forces one of them (A/B runs).
-int i3_row_tiles(int M, int cols) {
-    static const int forced = [] {
-        const char* e = getenv("DTC_I3_RT");
-        return e ? atoi(e) : 0;
-    }();
-    // measured (tools/img_probe.py, DTC_I3_RT=1 / 3): 24576 x 512 x 512 64.4 vs 66.7 us for 3 (256 workgroups: one per CU), but 24576 x 693
-    // x 512 147.6 vs 122.0 (384 workgroups: a round and a half) and 256-wide layers 49 vs 41 (half the CUs): the default is 1
-    (void)M;
-    (void)cols;
-    return forced == 3 ? 3 : 1;
-}
-template <int EPI, typename... Args>
-void launch_i3(int M, int cols, hipStream_t s, Args... args) {
-    if (i3_row_tiles(M, cols) == 3)
-        hipLaunchKernelGGL((linear_i3_kernel<EPI, 3>), dim3(grid_for((int)dtc::ceil_div(M, 384), (int)dtc::ceil_div(cols, 128))), dim3(768), 0, s, args...);
-    else
-        hipLaunchKernelGGL((linear_i3_kernel<EPI, 1>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(cols, 128))), dim3(256), 0, s, args...);
-}
-// the weight image of an image-operand call: one plain segment of K (N for the data gradient) reduction columns
-long long wimage_plain(const float* W, void* wplanes, int rows, long long ld, int trans, int red, hipStream_t s, bool ready) {
-    SegMatDev xd;
-    xd.nseg = 1;
-    xd.gathers = 0;
-    xd.idx = nullptr;
-    for (int i = 0; i < 4; ++i) xd.s[i] = SegDev{nullptr, 0, 0, 0x7fffffff, 0, 0, 0, 0};
-    xd.s[0] = SegDev{nullptr, 0, 0, 0, red, 0, 0, 0};
-    return build_wimage(W, wplanes, rows, 0, ld, trans, xd, (int)dtc::ceil_div(rows, 128), s, ready);
-}
-}  // namespace
-
-// Y = act(X W^T + b) with X given as its activation image (dtc_s3_aimage_bytes(M, K)).  Results: fp32 Y (may be NULL) and / or the
-// image of Y (Yimg, dtc_s3_aimage_bytes(M, N), may be NULL) -- at least one.  relu_mask as dtc_linear_fwd_s3.
-extern "C" int dtc_linear_fwd_i3(const void* Ximg, const float* W, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
-                                 void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream) {
-    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && (Y == nullptr || ldy >= N), "bad shape M=%d N=%d K=%d ldy=%lld", M, N, K, (long long)ldy);
-    DTC_REQUIRE(Ximg && W && (Y || Yimg) && wplanes && dtc::aligned16(Ximg) && dtc::aligned16(wplanes) && dtc::aligned16(Yimg), "null / unaligned pointer");
-    DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
-    DTC_REQUIRE(wimage_on(), "image operands need the weight images (DTC_S3_WIMG=0 is set)");
-    DTC_REQUIRE((long long)N * K <= MAX_ELEMS && (long long)M * (ldy > N ? ldy : N) <= MAX_ELEMS * 4 && dtc_s3_aimage_bytes(M, K) < (1ll << 31) &&
-                dtc_s3_aimage_bytes(M, N) < (1ll << 31), "matrix too large");
-    hipStream_t s = (hipStream_t)stream;
-    const int wide = (Y && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
-    if (relu_mask) DTC_REQUIRE(act == DTC_ACT_RELU && M % BM == 0 && N % 128 == 0, "sign record (split path): M=%d and N=%d must be multiples of 128", M, N);
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s,
-                        6.0 * M * (double)K + 6.0 * N * (double)K + (Y ? 4.0 : 0.0) * M * N + (Yimg ? 6.0 : 0.0) * M * N);
-    const long long ib = wimage_plain(W, wplanes, N, K, 0, K, s, wimage_ready != 0);
-    launch_i3<EPI_FWD>(M, N, s, (const u32x4*)Ximg, (long long)dtc_s3_aimage_bytes(M, K),
-                       (const u32x4*)wplanes, ib, (int)dtc::ceil_div(K, BK), b, Y, (long long)ldy, ImgOut{(u32x4*)Yimg, (int)dtc::ceil_div(N, BK)}, M, N, act,
-                       wide, (unsigned short*)relu_mask, N, DgradEpiI3{}, MseEpiS3{});
-    return dtc::check_launch("linear_fwd_i3");
-}
-
-// dtc_linear_fwd_mse_s3 with X as an image; dY as fp32 (may be NULL) and / or as an image (dYimg)
-extern "C" int dtc_linear_fwd_mse_i3(const void* Ximg, const float* W, const float* b, const float* target, int64_t ldt, int64_t target_rows,
-                                     int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy, void* dYimg, double* sq_part,
-                                     void* wplanes, int wimage_ready, int M, int N, int K, void* stream) {
-    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && (dY == nullptr || lddy >= N), "bad shape M=%d N=%d K=%d", M, N, K);
-    DTC_REQUIRE(Ximg && W && target && tidx && (dY || dYimg) && sq_part && wplanes && dtc::aligned16(Ximg) && dtc::aligned16(wplanes) &&
-                dtc::aligned16(dYimg), "null / unaligned pointer");
-    DTC_REQUIRE(tcol0 >= 0 && tcol0 + N <= ldt && target_rows > 0, "target columns [%d, %d) outside its %lld-wide rows", tcol0, tcol0 + N, (long long)ldt);
-    DTC_REQUIRE(wimage_on(), "image operands need the weight images (DTC_S3_WIMG=0 is set)");
-    DTC_REQUIRE((long long)N * K <= MAX_ELEMS && target_rows * ldt <= MAX_ELEMS && dtc_s3_aimage_bytes(M, K) < (1ll << 31) &&
-                dtc_s3_aimage_bytes(M, N) < (1ll << 31), "matrix too large");
-    hipStream_t s = (hipStream_t)stream;
-    const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128));
-    const MseEpiS3 mse{target, (const long long*)tidx, (long long)ldt, target_rows * ldt * 4, tcol0, scale, sq_part};
-    const int wide = (dY && lddy % 4 == 0 && dtc::aligned16(dY)) ? 1 : 0;
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s,
-                        6.0 * M * (double)K + 6.0 * N * (double)K + 4.0 * M * N + (dY ? 4.0 : 0.0) * M * N + (dYimg ? 6.0 : 0.0) * M * N);
-    const long long ib = wimage_plain(W, wplanes, N, K, 0, K, s, wimage_ready != 0);
-    if (i3_row_tiles(M, N) == 3) {                      // fewer workgroups than dtc_linear_fwd_mse_s3_parts slots: the rest must read as 0
-        const int used = grid_for((int)dtc::ceil_div(M, 384), (int)dtc::ceil_div(N, 128));
-        DTC_REQUIRE(used >= grid || hipMemsetAsync(sq_part + used, 0, (size_t)(grid - used) * sizeof(double), s) == hipSuccess, "hipMemsetAsync failed");
-    }
-    launch_i3<EPI_MSE>(M, N, s, (const u32x4*)Ximg, (long long)dtc_s3_aimage_bytes(M, K),
-                       (const u32x4*)wplanes, ib, (int)dtc::ceil_div(K, BK), b, dY, (long long)lddy, ImgOut{(u32x4*)dYimg, (int)dtc::ceil_div(N, BK)}, M, N,
-                       (int)DTC_ACT_NONE, wide, (unsigned short*)nullptr, 0, DgradEpiI3{}, mse);
-    return dtc::check_launch("linear_fwd_mse_i3");
-}
-
-// dX = (dZ W) * act'(.) with dZ [M, N] given as its image.  ONE destination: fp32 dX [M, K] (may be NULL; accumulate != 0: dX += ...)
-// and / or the image of the result (dXimg).  With an image AND accumulate the fp32 matrix is only read: the sum exists as the image.
-extern "C" int dtc_linear_dgrad_i3(const void* dZimg, const float* W, float* dX, int64_t lddx, int accumulate, void* dXimg, const float* Xsaved,
-                                   int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
-                                   void* stream) {
-    DTC_REQUIRE(M > 0 && N > 0 && K > 0 && (dX == nullptr || lddx >= K), "bad shape");
-    DTC_REQUIRE(dZimg && W && (dX || dXimg) && wplanes && dtc::aligned16(dZimg) && dtc::aligned16(wplanes) && dtc::aligned16(dXimg), "null / unaligned pointer");
-    DTC_REQUIRE(!accumulate || dX, "accumulate needs the fp32 destination");
-    DTC_REQUIRE(act >= 0 && act <= DTC_ACT_SIGMOID, "bad activation %d", act);
-    DTC_REQUIRE(relu_mask || act == DTC_ACT_NONE || (Xsaved != nullptr && ldxs >= K), "activation derivative needs Xsaved");
-    DTC_REQUIRE(wimage_on(), "image operands need the weight images (DTC_S3_WIMG=0 is set)");
-    DTC_REQUIRE((long long)N * K <= MAX_ELEMS && dtc_s3_aimage_bytes(M, K) < (1ll << 31) && dtc_s3_aimage_bytes(M, N) < (1ll << 31), "matrix too large");
-    if (relu_mask) DTC_REQUIRE(M % BM == 0 && K % 128 == 0, "sign record (split path): M=%d and K=%d must be multiples of 128", M, K);
-    DgradEpiI3 dg{dX, (long long)lddx, accumulate, relu_mask ? nullptr : Xsaved, (long long)ldxs, (const unsigned short*)relu_mask, K};
-    const int wide = ((dX && lddx % 4 == 0 && dtc::aligned16(dX)) ? 1 : 0) | ((dg.Xs && ldxs % 4 == 0 && dtc::aligned16(dg.Xs)) ? 2 : 0);
-    hipStream_t s = (hipStream_t)stream;
-    double bytes = 6.0 * M * (double)N + 6.0 * N * (double)K + (dXimg ? 6.0 : 0.0) * M * K + (dX ? 4.0 : 0.0) * M * K;
-    if (relu_mask) bytes += 0.125 * M * (double)K;
-    else if (act != DTC_ACT_NONE) bytes += 4.0 * M * (double)K;
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, K), 2.0 * M * (double)N * K, s, bytes);
-    // roles inside the kernel: result columns = K of the layer, reduction = N of the layer; the W operand is the image of W^T
-    const long long ib = wimage_plain(W, wplanes, K, K, 1, N, s, wimage_ready != 0);
-    launch_i3<EPI_DGRAD>(M, K, s, (const u32x4*)dZimg, (long long)dtc_s3_aimage_bytes(M, N),
-                       (const u32x4*)wplanes, ib, (int)dtc::ceil_div(N, BK), (const float*)nullptr, (float*)nullptr, 0ll,
-                       ImgOut{(u32x4*)dXimg, (int)dtc::ceil_div(K, BK)}, M, K, relu_mask ? (int)DTC_ACT_RELU : act, wide, (unsigned short*)nullptr, 0, dg,
-                       MseEpiS3{});
-    return dtc::check_launch("linear_dgrad_i3");
-}
-

@@ -287,27 +287,32 @@ __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G)
 __global__ __launch_bounds__(256) void wgrad_h2i_reduce_kernel(const HGroup G) {
     int b = blockIdx.x;
     const int blocks_tiles = G.tiles_total * 16;
-    if (b >= blocks_tiles) {                           // bias blocks: one per (job, row tile)
+    if (b >= blocks_tiles) {                           // bias blocks: four per (job, row tile), 32 features each
         b -= blocks_tiles;
-        int j = 0, rt = b;
+        const int quarter = b & 3;
+        int j = 0, rt = b >> 2;
         while (j < G.count - 1 && rt >= G.job[j].row_tiles) { rt -= G.job[j].row_tiles; ++j; }
         const HJob& J = G.job[j];
         if (rt >= J.row_tiles || J.db == nullptr) return;
-        // thread = (feature n, half of the slices): independent loads, a fixed order of additions (4 running sums per thread, then the two
-        // halves through LDS)
-        __shared__ float hsum[TILE];
-        const int nl = threadIdx.x & (TILE - 1), hf = threadIdx.x >> 7;
-        const int per = (G.splits + 1) >> 1, s0 = hf * per, s1 = min(G.splits, s0 + per);
-        float a4[4] = {0.f, 0.f, 0.f, 0.f};
-        int q = 0;
-        for (int sp = s0; sp < s1; ++sp)
-            for (int c = 0; c < J.col_tiles; ++c, ++q)
-                a4[q & 3] += J.bpart[(((long long)sp * J.col_tiles + c) * J.row_tiles + rt) * TILE + nl];
-        const float mine = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        if (hf == 1) hsum[nl] = mine;
+        // thread = (group g of 8, feature): group g sums the partials q = g, g + 8, ... of the (slice, column tile) pairs -- all its loads
+        // in flight at once, a fixed order of additions --, then the eight group sums are added in order
+        __shared__ float gsum[8][32];
+        const int nl = quarter * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+        const int pairs = G.splits * J.col_tiles;
+        const long long stride = (long long)J.row_tiles * TILE;               // between consecutive (slice, column tile) pairs
+        const float* src = J.bpart + (long long)rt * TILE + nl;
+        float acc = 0.f;
+#pragma unroll 16
+        for (int q = grp; q < pairs; q += 8) acc += src[(long long)q * stride];
+        gsum[grp][threadIdx.x & 31] = acc;
         __syncthreads();
         const int n = rt * TILE + nl;
-        if (hf == 0 && n < J.N) J.db[n] = mine + hsum[nl];
+        if (grp == 0 && n < J.N) {
+            float t = gsum[0][threadIdx.x];
+#pragma unroll
+            for (int g2 = 1; g2 < 8; ++g2) t += gsum[g2][threadIdx.x];
+            J.db[n] = t;
+        }
         return;
     }
     int t = b >> 4;
@@ -325,10 +330,14 @@ __global__ __launch_bounds__(256) void wgrad_h2i_reduce_kernel(const HGroup G) {
     const long long step = (long long)tiles_j * (TILE * TILE / 4);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int sp = 0;
-    for (; sp + 3 < G.splits; sp += 4) {
-        const f32x4 v0 = p[(long long)sp * step], v1 = p[(long long)(sp + 1) * step], v2 = p[(long long)(sp + 2) * step], v3 = p[(long long)(sp + 3) * step];
+    for (; sp + 7 < G.splits; sp += 8) {               // eight slabs in flight per thread; the order of the additions is fixed
+        f32x4 v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = (((acc[e] + v0[e]) + v1[e]) + v2[e]) + v3[e];
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(sp + u) * step];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[u][e];
     }
     for (; sp < G.splits; ++sp) {
         const f32x4 v0 = p[(long long)sp * step];
@@ -417,7 +426,7 @@ int plan_h2i(const DtcWgradH2iJob* jobs, int count, int M, void* workspace, HPla
         P.algo_bytes += 4.0 * ((double)M * d.N + (double)M * d.K) + 4.0 * (double)d.N * (d.K + 1);
     }
     P.bytes = off;
-    P.red_blocks = tiles * 16 + row_tiles;
+    P.red_blocks = tiles * 16 + 4 * row_tiles;
     return DTC_OK;
 }
 

@@ -50,10 +50,6 @@ class DtcWimgJob(C.Structure):
                 ("trans", C.c_int32)]
 
 
-class DtcWgradImgJob(C.Structure):
-    _fields_ = [("dZimg", C.c_void_p), ("Ximg", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32)]
-
-
 class DtcH2iWJob(C.Structure):
     _fields_ = [("W", C.c_void_p), ("ld", C.c_int64), ("img", C.c_void_p), ("trans", C.c_int32), ("nrows", C.c_int32), ("nseg", C.c_int32),
                 ("r0", C.c_int32 * 2), ("nr", C.c_int32 * 2), ("c0", C.c_int32 * 4), ("cw", C.c_int32 * 4)]
@@ -94,7 +90,7 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 10         # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 11         # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
@@ -137,22 +133,8 @@ _SIGS = {
     "dtc_gru_s3_image": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, c_stream]),
     "dtc_gru_step_fwd_s3": (C.c_int, [c_f32p, C.c_void_p] + [c_f32p] * 5 + [C.c_int, C.c_int, c_stream]),
     "dtc_gru_dgrad_parts_s3": (C.c_int, [c_f32p, C.c_void_p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_stream]),
-    "dtc_linear_fwd_s3i": (C.c_int, [C.POINTER(DtcSegMat), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                     C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
-    "dtc_linear_dgrad_s3i": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.POINTER(DtcSegMat), C.c_void_p, C.c_int, c_f32p, C.c_int64, C.c_void_p,
-                                       C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_probe_mfma_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, c_stream]),
     "dtc_probe_mfma_stream_h2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, c_stream]),
-    "dtc_s3_aimage_bytes": (C.c_int64, [C.c_int, C.c_int]),
-    "dtc_s3_aimage": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p, c_stream]),
-    "dtc_linear_fwd_i3": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                    C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
-    "dtc_linear_fwd_mse_i3": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int, c_i64p, C.c_float, c_f32p,
-                                        C.c_int64, C.c_void_p, c_f64p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
-    "dtc_linear_dgrad_i3": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_void_p, c_f32p, C.c_int64, C.c_void_p,
-                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
-    "dtc_wgrad_group_i3_workspace": (C.c_int64, [C.POINTER(DtcWgradImgJob), C.c_int, C.c_int]),
-    "dtc_wgrad_group_i3": (C.c_int, [C.POINTER(DtcWgradImgJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_h2i_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_h2i_trace": (None, [C.c_void_p]),
     "dtc_h2i_pack": (C.c_int, [C.POINTER(DtcSegMat), C.c_int, C.c_void_p, c_stream]),
@@ -265,7 +247,7 @@ def _check_abi(l):
     """The loaded library must be the revision this binding describes: same ABI version, same by-value struct layouts
     (DTC_LIB may point at a separately built library, e.g. the ASan build: a stale one would misread every descriptor)."""
     global _lib
-    mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcWgradImgJob, DtcH2iWJob,
+    mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcH2iWJob,
             DtcH2iOperand, DtcWgradH2iJob]
     sizes = (C.c_int64 * 16)()
     n = l.dtc_abi_sizes(sizes, 16)

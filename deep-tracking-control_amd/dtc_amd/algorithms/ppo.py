@@ -558,7 +558,7 @@ class PPO:
             h2i.linear_dgrad(tw.img("dlt"), L["te2"].W, None, g_te2i, mask=fw.relu_mask("t2", 512, rm), wset=wset)
             self._bwd_img(tw, L["te1"], g_te2i, fw.img("t1"))
             h2i.linear_dgrad(g_te2i, L["te1"].W, None, g_te1i, mask=fw.relu_mask("t1", 512, rm), wset=wset)
-            self._bwd_img(tw, L["te0"], g_te1i, fw.img("p_te"))
+            self._bwd_img(tw, L["te0"], g_te1i, fw.cur["p_te"])
             tw.live_img |= {"g_te2", "g_te1"}
             return
         g_te2, g_te1 = tw.g("te2", 512), tw.g("te1", 512)
@@ -733,8 +733,8 @@ class PPO:
             # layer-0 inputs as operand images: the critic's whole input (gathered rollout rows) is packed once; the actor's is the
             # l_t image the terrain encoder just wrote + the packed narrow block [obs | z | mu[:, :3]] (W's columns 72.. and 0..71)
             with tw.lane("aux"):
-                Xc = ac.packed_input(fw, "p_c", ac.critic_input(obs, flat["base_vel"], priv, idx), None)
-            Xa = [fw.img("lt"), ac.packed_input(fw, "p_a", segmat([seg(obs, 0, ac.num_obs, gather=True), seg(fw.z, 0, 16), seg(fw.mulv, 0, 3)], idx), None)]
+                Xc = ac.packed_input(fw, "p_c", ac.critic_input(obs, flat["base_vel"], priv, idx), idx, reuse=True)
+            Xa = [fw.img("lt"), ac.packed_input(fw, "p_a", segmat([seg(obs, 0, ac.num_obs, gather=True), seg(fw.z, 0, 16), seg(fw.mulv, 0, 3)], idx))]
             a_cols = [ac.num_obs + 19, 0]
         elif self.pack_inputs:                                     # the narrow leading blocks of both layer-0 inputs packed into dense operands
             with tw.lane("aux"):
@@ -839,6 +839,8 @@ class PPO:
         flat = {k: st.flat(k) for k in self._FLAT_NAMES}
         self._amax_static(flat)
         fw, tw = ac._fwd_ws(B), self._train_ws(B)
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1
+        fw.pack_gen, fw.pack_slot = self._pack_gen, 0
         self.optimizer.set_lr(self.learning_rate)
         stats = torch.zeros(STAT_COLS, dtype=torch.float32, device=dev) if stats is None else stats.to(dev)
         if which in ("vae", "both"):
@@ -846,6 +848,7 @@ class PPO:
         if which in ("ppo", "both"):
             self._ppo_step(fw, tw, flat, idx, eps2.to(dev).contiguous(), stats, self._loss_cfg())
         ops.amax_static_clear()
+        fw.pack_gen = None
         self.learning_rate = float(self.optimizer.lr_dev.item())
         for g in self.optimizer.param_groups:
             g['lr'] = self.learning_rate
@@ -898,8 +901,11 @@ class PPO:
         stats = torch.zeros(steps, STAT_COLS, dtype=torch.float32, device=dev)
         lr_hist = torch.zeros(steps, dtype=torch.float64, device=dev) if return_stats else None
         k = 0
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1
+        fw.pack_gen = self._pack_gen                   # the packed rollout rows of a mini-batch serve all five epochs (packed_input)
         for _ in range(epochs):
             for i in range(nmb):
+                fw.pack_slot = i
                 idx = perm[i * B:(i + 1) * B]
                 with tracing.span("vae_step"):
                     self._vae_step(fw, tw, flat, idx, eps1[k], stats[k])
@@ -908,6 +914,7 @@ class PPO:
                 if lr_hist is not None:
                     lr_hist[k:k + 1].copy_(self.optimizer.lr_dev)
                 k += 1
+        fw.pack_gen = None
         ops.amax_static_clear()                        # the storage is about to be refilled: its amax slots are void
         # the single device -> host synchronisation of the update
         host = stats.cpu()

@@ -292,6 +292,8 @@ class ActorCriticDecoder(nn.Module):
             self._dev, self._masks = dev, {}
             self._imgs, self.live_img = {}, set()
             self.pack_key = {}               # operand image name -> what it was packed from (see ActorCriticDecoder.packed_input)
+            self.pack_gen, self.pack_slot = None, 0      # set by the trainer for the duration of an update (packed_input)
+            self.cur = {}                    # logical name -> the packed image the step in flight uses
 
         def img(self, name, width=None):
             """Operand image (h2i.HImage) of the [B, width] activation `name`, allocated on first use."""
@@ -366,19 +368,21 @@ class ActorCriticDecoder(nn.Module):
         128-row tiles (ReLU sign records, exponent blocks of the weight gradients)."""
         return ops.SPLIT and ws.B % 128 == 0
 
-    def packed_input(self, ws, name, X, key):
-        """Operand image `name` of the fp32 operand X (DtcSegMat: the gathered rollout rows, narrow hand-over tensors).  `key`
-        identifies the content (sources' addresses and versions, the index tensor): an image that was packed from the same content --
-        the terrain heights of a mini-batch serve the VAE step and the policy step -- is not packed again."""
-        img = ws.img(name, X.cols)
-        if key is None or ws.pack_key.get(name) != key:
+    def packed_input(self, ws, name, X, idx=None, reuse=False):
+        """Operand image `name` of the fp32 operand X (DtcSegMat: the gathered rollout rows, narrow hand-over tensors).
+        `reuse`: X is a function of the rollout storage and the mini-batch index only.  The reference's mini-batches are the SAME four
+        index sets in all five epochs of an update (rollout_storage.py:165, 188-193: one randperm, then the epoch loop), so inside an
+        update -- the trainer sets `ws.pack_gen` / `ws.pack_slot` for its duration -- each mini-batch's image is packed once, into its
+        own buffer, and serves both optimisation steps of all epochs.  Outside an update (pack_gen None) every call packs."""
+        gen = ws.pack_gen if reuse else None
+        slot = ws.pack_slot if gen is not None else 0
+        img = ws.img(f"{name}@{slot}", X.cols)
+        key = None if gen is None else (gen, None if idx is None else (idx.data_ptr(), idx.numel()))
+        if key is None or ws.pack_key.get((name, slot)) != key:
             img.pack(X, ws.B)
-            ws.pack_key[name] = key
+            ws.pack_key[(name, slot)] = key
+        ws.cur[name] = img
         return img
-
-    @staticmethod
-    def content_key(idx, *tensors):
-        return (None if idx is None else (idx.data_ptr(), idx.numel(), idx._version),) + tuple((t.data_ptr(), t._version) for t in tensors)
 
     def terrain_encoder_(self, ws, priv, idx=None, masks=False, images=False, wset=None, lt_fp32=True, split=None):
         """`images` (training step, see images_ok): the gathered heights are packed into an operand image once per mini-batch, t1 / t2
@@ -387,7 +391,7 @@ class ActorCriticDecoder(nn.Module):
         X = segmat([seg(priv, 0, 693, gather=idx is not None)], idx)
         if images and masks:
             w1, w2 = L["te0"].n_out, L["te1"].n_out
-            pin = self.packed_input(ws, "p_te", X, self.content_key(idx, priv))
+            pin = self.packed_input(ws, "p_te", X, idx, reuse=True)
             t1i, t2i, lti = ws.img("t1", w1), ws.img("t2", w2), ws.img("lt", L["te2"].n_out)
             h2i.linear_fwd(pin, L["te0"].W, L["te0"].b, None, t1i, "relu", mask=ws.relu_mask("t1", w1, masks), wset=wset)
             h2i.linear_fwd(t1i, L["te1"].W, L["te1"].b, None, t2i, "relu", mask=ws.relu_mask("t2", w2, masks), wset=wset)

@@ -102,12 +102,6 @@ SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "128"))
 SPLIT_MIN_RED = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_RED", "128"))
 # recurrent trainers: weight gradients over the valid slots of the padded trajectory layout only (0: over all T x R rows)
 WGRAD_ROWS = _os.environ.get("DTC_WGRAD_ROWS", "1") != "0"
-# activation images (AImage): the hidden activations of the wide stacks as bf16 x 3 planes in HBM, written by the producing epilogue,
-# read by LDS-DMA.  OFF by default (DTC_IMAGES=1 / trainer.use_images = True switches the trainers' image chain on): measured in round 4,
-# the image-operand kernels are 3-7 % faster per launch in isolation (no conversion in any K loop), but the whole step is 7 % SLOWER
-# (71.1 vs 66.4 ms, three interleaved runs: DESIGN.md 4.2c) -- two grouped weight-gradient launches per bucket instead of one, fp32 + image
-# double writes at the hand-over points, and a GEMM family that is limited by the clock the chip sustains, not by its issue slots
-IMAGES = _os.environ.get("DTC_IMAGES", "0") == "1"
 WIMG_CHECK = _os.environ.get("DTC_WIMG_CHECK", "0") == "1"  # debug: re-derive every cached weight image at its use and compare
 _NOT_NULL = 16                                             # stand-in address of a non-NULL operand block in a cached descriptor
 WIMG = _os.environ.get("DTC_S3_WIMG", "1") != "0"          # the library's weight-image switch (csrc/gemm_s3.hip reads the same variable)
@@ -406,20 +400,13 @@ def pack_cols(X, dst, rows=None):
     return dst
 
 
-def linear_fwd(X, W, b, Y, act=None, M=None, mask=None, split=None, Yimg=None):
-    """Y = act(X W^T + b).  X: tensor or DtcSegMat; W [N,K]; Y [M,>=N] (row stride may exceed N).  `mask` (relu_mask
-    buffer, act must be "relu"): also record the output signs for linear_dgrad(..., mask=).  `Yimg` (AImage [M, N], split path only):
-    the result also (Y given) or only (Y None) leaves as the activation image the image-operand kernels read."""
+def linear_fwd(X, W, b, Y, act=None, M=None, mask=None, split=None):
+    """Y = act(X W^T + b) on fp32 operands.  X: tensor or DtcSegMat; W [N,K]; Y [M,>=N] (row stride may exceed N).  `mask` (relu_mask
+    buffer, act must be "relu"): also record the output signs for linear_dgrad(..., mask=).  (The trainers' wide stacks run on operand
+    images: dtc_amd/h2i.py.)"""
     Xs = as_segmat(X)
     N, K = W.shape
-    M = (Y.shape[0] if Y is not None else Yimg.M) if M is None else M
-    if Yimg is not None:
-        assert (Yimg.M, Yimg.K) == (M, N)
-        img, ready = _wimage(W, Xs, N, K, 0)
-        check(lib().dtc_linear_fwd_s3i(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y) if Y is not None else None,
-                                       Y.stride(0) if Y is not None else 0, Yimg.ptr(), ptr(mask) if mask is not None else None, ptr(img), ready,
-                                       M, N, K, ACT[act], stream()), "dtc_linear_fwd_s3i")
-        return Y
+    M = Y.shape[0] if M is None else M
     if (SPLIT if split is None else split) and (split or (N >= SPLIT_MIN_COLS and K >= SPLIT_MIN_RED)) and (mask is None or N % 128 == 0):
         img, ready = _wimage(W, Xs, N, K, 0, H2)
         if H2:
@@ -478,20 +465,12 @@ class FwdChain:
               "dtc_linear_fwd_list")
 
 
-def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None, dXimg=None, img_seg=0):
-    """dX = (dZ W) * act'(Xsaved); dX: tensor or DtcSegMat (destination).  `mask`: the sign record of the ReLU layer that
-    produced Xsaved (then Xsaved itself is not read).  `dXimg` (AImage, split path only): destination block `img_seg` also leaves as
-    an activation image (an accumulating block is then only read: the sum exists as the image)."""
+def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None):
+    """dX = (dZ W) * act'(Xsaved) on fp32 operands; dX: tensor or DtcSegMat (destination).  `mask`: the sign record of the ReLU layer
+    that produced Xsaved (then Xsaved itself is not read)."""
     dXs = as_segmat(dX)
     N, K = W.shape
     M = dZ.shape[0] if M is None else M
-    if dXimg is not None:
-        assert dXimg.M == M and dXimg.K == dXs.seg[img_seg].width
-        img, ready = _wimage(W, dXs, N, K, 1)
-        check(lib().dtc_linear_dgrad_s3i(ptr(dZ), dZ.stride(0), cptr(W, f32), dXs, dXimg.ptr(), img_seg, ptr(Xsaved) if mask is None else None,
-                                         Xsaved.stride(0) if Xsaved is not None else 0, ptr(mask) if mask is not None else None,
-                                         ptr(img), ready, M, N, K, ACT[act] if mask is None else ACT["relu"], stream()), "dtc_linear_dgrad_s3i")
-        return
     if (SPLIT if split is None else split) and (split or (K >= SPLIT_MIN_COLS and N >= SPLIT_MIN_RED)) and (mask is None or K % 128 == 0):
         img, ready = _wimage(W, dXs, N, K, 1, H2)
         if H2:
@@ -519,94 +498,6 @@ def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None
     check(lib().dtc_linear_dgrad(ptr(dZ), dZ.stride(0), cptr(W, f32), dXs, ptr(Xsaved),
                                  Xsaved.stride(0) if Xsaved is not None else 0, M, N, K, ACT[act], stream()),
           "dtc_linear_dgrad")
-
-
-# ---------------------------------------------------------------- activation images (include/dtc_hip.h, round 4)
-class AImage:
-    """A [M, K] matrix as the split kernels' LDS planes (three bf16 terms per element, 12 KiB chunk per 128-row tile and 16-k
-    stage): written by the epilogue of the kernel that produces the matrix, read by LDS-DMA by every kernel that consumes it."""
-
-    def __init__(self, M, K, device):
-        self.M, self.K = int(M), int(K)
-        n = int(lib().dtc_s3_aimage_bytes(self.M, self.K))
-        if n <= 0 or n >= 1 << 31:
-            raise _ffi.DtcError(f"activation image of a {M} x {K} matrix: {n} bytes (must be in (0, 2 GiB))")
-        self.buf = torch.empty(n // 8, dtype=torch.float64, device=device)
-
-    @property
-    def device(self):
-        return self.buf.device
-
-    def ptr(self):
-        return self.buf.data_ptr()
-
-    @staticmethod
-    def from_tensor(X, out=None):
-        """dtc_s3_aimage: the image of an fp32 matrix (row stride free)."""
-        M, K = X.shape
-        img = AImage(M, K, X.device) if out is None else out
-        assert (img.M, img.K) == (M, K) and X.stride(1) == 1 and X.dtype == f32 and X.is_cuda
-        check(lib().dtc_s3_aimage(ptr(X), X.stride(0), M, K, img.ptr(), stream()), "dtc_s3_aimage")
-        return img
-
-    def to_tensor(self):
-        """Decode (tests / debugging): the fp32 sum of the three planes, [M, K]."""
-        rt, st = -(-self.M // 128), -(-self.K // 16)
-        raw = self.buf.view(torch.int16).view(rt, st, 3, 256, 8).to(torch.int32)
-        vals = ((raw & 0xFFFF) << 16).view(torch.float32)                       # bf16 bits -> fp32
-        r = torch.arange(128, device=self.buf.device)
-        h = torch.arange(2, device=self.buf.device)
-        slot = (r[:, None] * 2 + (h[None, :] ^ ((r[:, None] >> 3) & 1))).reshape(-1)             # [row, half] -> slot
-        planes = vals[:, :, :, slot].view(rt, st, 3, 128, 2, 8)                 # [rt, st, plane, row, half, 8]
-        total = (planes[:, :, 0] + planes[:, :, 1]) + planes[:, :, 2]           # [rt, st, row, half, 8]
-        return total.permute(0, 2, 1, 3, 4).reshape(rt * 128, st * 16)[:self.M, :self.K].contiguous()
-
-
-def _plain_segs(width):
-    """Descriptor of a one-block operand of `width` columns for the weight-image cache (only the segment walk is read)."""
-    sm = _ffi.DtcSegMat()
-    sm.nseg, sm.cols = 1, width
-    sm.seg[0].ptr, sm.seg[0].ld, sm.seg[0].width, sm.seg[0].rows = _NOT_NULL, width, width, 1
-    return sm
-
-
-def linear_fwd_img(Ximg, W, b, Y=None, Yimg=None, act=None, mask=None):
-    """Y = act(X W^T + b), X an AImage; results as fp32 `Y` [M, >=N] and / or as the AImage `Yimg` [M, N]."""
-    N, K = W.shape
-    M = Ximg.M
-    assert Ximg.K == K and (Y is not None or Yimg is not None) and (Yimg is None or (Yimg.M, Yimg.K) == (M, N))
-    img, ready = _wimage(W, _plain_segs(K), N, K, 0)
-    check(lib().dtc_linear_fwd_i3(Ximg.ptr(), cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y) if Y is not None else None,
-                                  Y.stride(0) if Y is not None else 0, Yimg.ptr() if Yimg is not None else None,
-                                  ptr(mask) if mask is not None else None, ptr(img), ready, M, N, K, ACT[act], stream()), "dtc_linear_fwd_i3")
-
-
-def linear_fwd_mse_img(Ximg, W, b, target, tcol0, tidx, dY, dYimg, part):
-    """linear_fwd_mse with X an AImage; dL/dY as fp32 `dY` and / or as the AImage `dYimg`; returns the number of partials."""
-    N, K = W.shape
-    M = Ximg.M
-    n = int(lib().dtc_linear_fwd_mse_s3_parts(M, N))
-    assert part.numel() >= n and part.dtype == torch.float64 and Ximg.K == K
-    img, ready = _wimage(W, _plain_segs(K), N, K, 0)
-    check(lib().dtc_linear_fwd_mse_i3(Ximg.ptr(), cptr(W, f32), cptr(b, f32) if b is not None else None, cptr(target, f32), target.stride(0),
-                                      target.shape[0], tcol0, cptr(tidx, torch.int64), 2.0 / (M * N), ptr(dY) if dY is not None else None,
-                                      dY.stride(0) if dY is not None else 0, dYimg.ptr() if dYimg is not None else None, ptr(part), ptr(img), ready,
-                                      M, N, K, stream()), "dtc_linear_fwd_mse_i3")
-    return n
-
-
-def linear_dgrad_img(dZimg, W, dX=None, dXimg=None, accumulate=False, Xsaved=None, act=None, mask=None):
-    """dX = (dZ W) * act'(.), dZ an AImage [M, N]; ONE destination: fp32 `dX` [M, >=K] (accumulate: dX += ...) and / or the
-    AImage `dXimg`.  With an image AND accumulate the fp32 matrix is only read."""
-    N, K = W.shape
-    M = dZimg.M
-    assert dZimg.K == N and (dX is not None or dXimg is not None) and (dXimg is None or (dXimg.M, dXimg.K) == (M, K))
-    img, ready = _wimage(W, _plain_segs(K), N, K, 1)
-    check(lib().dtc_linear_dgrad_i3(dZimg.ptr(), cptr(W, f32), ptr(dX) if dX is not None else None, dX.stride(0) if dX is not None else 0,
-                                    int(bool(accumulate)), dXimg.ptr() if dXimg is not None else None,
-                                    ptr(Xsaved) if (mask is None and Xsaved is not None) else None, Xsaved.stride(0) if Xsaved is not None else 0,
-                                    ptr(mask) if mask is not None else None, ptr(img), ready, M, N, K,
-                                    ACT[act] if mask is None else ACT["relu"], stream()), "dtc_linear_dgrad_i3")
 
 
 def wgrad_workspace_bytes(M, N, K) -> int:
@@ -677,30 +568,6 @@ def wgrad_group(jobs, M, workspace, stream_ptr=None, split=None):
     check((lib().dtc_wgrad_group_s3 if s3 else lib().dtc_wgrad_group)(arr, len(jobs), M, ptr(workspace), sp),
           "dtc_wgrad_group_s3" if s3 else "dtc_wgrad_group")
     return keep
-
-
-def _wgrad_img_jobs(jobs):
-    arr = (_ffi.DtcWgradImgJob * len(jobs))()
-    for a, (dZimg, Ximg, dW, db) in zip(arr, jobs):
-        assert dZimg.M == Ximg.M and tuple(dW.shape) == (dZimg.K, Ximg.K) and dW.is_contiguous()
-        a.dZimg, a.Ximg, a.dW, a.db = dZimg.ptr(), Ximg.ptr(), cptr(dW, f32), (cptr(db, f32) if db is not None else None)
-        a.N, a.K = dZimg.K, Ximg.K
-    return arr
-
-
-def wgrad_group_img_workspace_bytes(jobs, M) -> int:
-    n = int(lib().dtc_wgrad_group_i3_workspace(_wgrad_img_jobs(jobs), len(jobs), M))
-    if n < 0:
-        raise _ffi.DtcError(f"dtc_wgrad_group_i3_workspace failed: {lib().dtc_last_error().decode()}")
-    return n
-
-
-def wgrad_group_img(jobs, M, workspace, stream_ptr=None):
-    """wgrad_group with both operands of every layer as AImages: jobs = list of (dZimg [M,N], Ximg [M,K], dW [N,K], db [N] | None).
-    Returns the objects the launch reads (keep them alive until it has run)."""
-    arr = _wgrad_img_jobs(jobs)
-    check(lib().dtc_wgrad_group_i3(arr, len(jobs), M, ptr(workspace), stream() if stream_ptr is None else stream_ptr), "dtc_wgrad_group_i3")
-    return jobs
 
 
 def mfma_sustained(device, random_operands: bool, launches=12, iters=2000, blocks=768, h2=None):

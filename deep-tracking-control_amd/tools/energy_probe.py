@@ -11,7 +11,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from dtc_amd import ops  # noqa: E402
+from dtc_amd import h2i, ops  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -63,7 +63,8 @@ def main():
     X, W, b, dZ = torch.relu(rn(M, 512)), rn(512, 512) / 22.0, rn(512), rn(M, 512) * 1e-3
     Y, dX = torch.empty(M, 512, device=DEV), torch.empty(M, 512, device=DEV)
     mask = ops.relu_mask(M, 512, DEV)
-    Ximg, dZimg, Yimg = ops.AImage.from_tensor(X), ops.AImage.from_tensor(dZ), ops.AImage(M, 512, DEV)
+    Ximg, dZimg, Yimg, dXimg = h2i.HImage.from_tensor(X), h2i.HImage.from_tensor(dZ), h2i.HImage(M, 512, DEV), h2i.HImage(M, 512, DEV)
+    wset = h2i.WeightSet()
     imgs = ops.WeightImages()
     total = 0.0
     for t in (X, dZ):                       # two-term fp16 path: the operands bring their amax (no fallback launch inside the timed loops)
@@ -71,13 +72,15 @@ def main():
     with imgs:
         ops.linear_fwd(X, W, b, Y, "relu", mask=mask, split=True)
         ops.linear_dgrad(dZ, W, dX, None, "relu", mask=mask, split=True)
-        ops.linear_fwd_img(Ximg, W, b, Y, None, "relu", mask=mask)
+        h2i.linear_fwd(Ximg, W, b, Y, None, "relu", mask=mask, wset=wset)
+        h2i.linear_dgrad(dZimg, W, None, dXimg, mask=mask, wset=wset)
     print(f"idle: {power_now()}")
     with imgs:
         total += measure("forward 512 x 512, converting kernel (ReLU input: half zeros)", lambda: ops.linear_fwd(X, W, b, Y, "relu", mask=mask, split=True), 240)
         total += measure("data gradient 512 x 512, converting kernel", lambda: ops.linear_dgrad(dZ, W, dX, None, "relu", mask=mask, split=True), 240)
-        measure("forward 512 x 512, image operands -> fp32", lambda: ops.linear_fwd_img(Ximg, W, b, Y, None, "relu", mask=mask), 0)
-        measure("forward 512 x 512, image operands -> image", lambda: ops.linear_fwd_img(Ximg, W, b, None, Yimg, "relu", mask=mask), 0)
+        measure("forward 512 x 512, operand images -> fp32", lambda: h2i.linear_fwd(Ximg, W, b, Y, None, "relu", mask=mask, wset=wset), 0)
+        measure("forward 512 x 512, operand images -> image", lambda: h2i.linear_fwd(Ximg, W, b, None, Yimg, "relu", mask=mask, wset=wset), 240)
+        measure("data gradient 512 x 512, operand images -> image", lambda: h2i.linear_dgrad(dZimg, W, None, dXimg, mask=mask, wset=wset), 240)
     s3, i3 = [], []
     for N, K in ((512, 512), (512, 512), (693, 512)):
         dz, x = rn(M, N) * 1e-3, torch.relu(rn(M, K))
@@ -85,12 +88,12 @@ def main():
         ops.amax_static(dz)
         ops.amax_static(x)
         s3.append((dz, x, dW, db))
-        i3.append((ops.AImage.from_tensor(dz), ops.AImage.from_tensor(x), dW, db))
+        i3.append((h2i.HImage.from_tensor(dz), h2i.HImage.from_tensor(x), dW, 0, db))
     ws = ops.workspace(ops.wgrad_group_workspace_bytes(s3, M, split=True), DEV)
-    wi = ops.workspace(ops.wgrad_group_img_workspace_bytes(i3, M), DEV)
+    wi = ops.workspace(h2i.wgrad_group_workspace_bytes(i3, M), DEV)
     with imgs:
         total += measure("grouped weight gradient, 3 wide layers, converting kernel", lambda: ops.wgrad_group(s3, M, ws, split=True), 80)
-    measure("grouped weight gradient, 3 wide layers, image operands", lambda: ops.wgrad_group_img(i3, M, wi), 0)
+    measure("grouped weight gradient, 3 wide layers, operand images", lambda: h2i.wgrad_group(i3, M, wi), 80)
     Xn, Wn, bn, Yn = rn(M, 265), rn(128, 265) / 16.0, rn(128), torch.empty(M, 128, device=DEV)
     total += measure("narrow forward 24576 x 128 x 265 (single-pass fp32 MFMA)", lambda: ops.linear_fwd(Xn, Wn, bn, Yn, "relu", split=False), 280)
     fs = torch.empty(M, 512, device=DEV)

@@ -38,10 +38,10 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-#define DTC_ABI_VERSION 10                   /* bumped whenever a signature or a by-value struct layout changes       */
+#define DTC_ABI_VERSION 11                   /* bumped whenever a signature or a by-value struct layout changes       */
 int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
 /* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
-   DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcWgradImgJob, DtcH2iWJob, DtcH2iOperand, DtcWgradH2iJob: the binding compares them with its own layouts at load time (a library
+   DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcH2iWJob, DtcH2iOperand, DtcWgradH2iJob: the binding compares them with its own layouts at load time (a library
    built from another revision -- e.g. a stale DTC_LIB override -- must not receive descriptors it would misread).
    Returns the number of entries (written up to `cap`). */
 int dtc_abi_sizes(int64_t* out, int cap);
@@ -252,48 +252,6 @@ int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W, const Dtc
                         int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
                         void* stream);
 /* dtc_linear_fwd_mse / dtc_linear_fwd_mse_parts on the split-precision path */
-/* Activation images (round 4).  The split kernels convert the fp32 X operand to three bf16 planes inside their K loop, once per
- * 128-column tile that reads it (and again in the weight gradient).  An ACTIVATION IMAGE is a matrix [M, K] stored the way the
- * weight image stores W: for every 128-row tile and 16-k stage one 12 KiB chunk of the kernel's own LDS planes.  The *_i3 entry
- * points read their row operand as an image by LDS-DMA (no conversion in any K loop) and can write their result as fp32, as
- * an image (for the next consumer), or both -- the activations of the nn.Linear stacks of actor_critic_decoder.py:98-188 /
- * :323-349 then exist in HBM as images only.  Rows >= M and columns >= K of an image are zero.
- * dtc_s3_aimage converts an fp32 matrix (operands no split kernel produces).  All image buffers: 16-byte aligned,
- * dtc_s3_aimage_bytes(M, K) bytes (< 2 GiB). */
-int64_t dtc_s3_aimage_bytes(int M, int K);
-int dtc_s3_aimage(const float* A, int64_t lda, int M, int K, void* img, void* stream);
-/* dtc_linear_fwd_s3 / dtc_linear_dgrad_s3 (fp32 row operand, converted in the K loop: gathered / segmented inputs) whose result also
- * leaves as an image.  Forward: Y may be NULL (image only).  Data gradient: destination block `img_seg` of dX (first column / width
- * multiples of 8 / 16) as dXimg = image(M, width); a block that accumulates is then only read. */
-int dtc_linear_fwd_s3i(const DtcSegMat* X, const float* W, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
-                       void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream);
-int dtc_linear_dgrad_s3i(const float* dZ, int64_t lddz, const float* W, const DtcSegMat* dX, void* dXimg, int img_seg, const float* Xsaved,
-                         int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
-                         void* stream);
-/* dtc_linear_fwd_s3 with X = image(M, K); results: Y fp32 (may be NULL) and / or Yimg = image(M, N) (may be NULL), one at least */
-int dtc_linear_fwd_i3(const void* Ximg, const float* W, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
-                      void* wplanes, int wimage_ready, int M, int N, int K, int act, void* stream);
-/* dtc_linear_fwd_mse_s3 with X = image(M, K); dY as fp32 (may be NULL) and / or as image(M, N) */
-int dtc_linear_fwd_mse_i3(const void* Ximg, const float* W, const float* b, const float* target, int64_t ldt, int64_t target_rows,
-                          int tcol0, const int64_t* tidx, float scale, float* dY, int64_t lddy, void* dYimg, double* sq_part,
-                          void* wplanes, int wimage_ready, int M, int N, int K, void* stream);
-/* dtc_linear_dgrad_s3 with dZ = image(M, N) and ONE destination: fp32 dX [M, K] (may be NULL; accumulate != 0: dX += product) and / or
- * dXimg = image(M, K).  With an image AND accumulate the fp32 matrix is only read (the sum exists as the image). */
-int dtc_linear_dgrad_i3(const void* dZimg, const float* W, float* dX, int64_t lddx, int accumulate, void* dXimg, const float* Xsaved,
-                        int64_t ldxs, const uint16_t* relu_mask, void* wplanes, int wimage_ready, int M, int N, int K, int act,
-                        void* stream);
-/* dtc_wgrad_group_s3 with BOTH operands of every layer given as activation images over the same M batch rows: dZimg = image(M, N),
- * Ximg = image(M, K).  No conversion, no operand registers: the stages arrive by LDS-DMA, the fragments by the hardware transpose
- * read (csrc/wgrad_i3.hip).  count <= 12; workspace >= dtc_wgrad_group_i3_workspace() bytes, 16-byte aligned. */
-typedef struct DtcWgradImgJob {
-    const void* dZimg;
-    const void* Ximg;
-    float* dW;           /* [N, K]        */
-    float* db;           /* [N] or NULL   */
-    int32_t N, K;
-} DtcWgradImgJob;
-int64_t dtc_wgrad_group_i3_workspace(const DtcWgradImgJob* jobs, int count, int M);
-int dtc_wgrad_group_i3(const DtcWgradImgJob* jobs, int count, int M, void* workspace, void* stream);
 /* ---- block-scaled two-term fp16 operand images (round 5; csrc/h2i_core.hpp, gemm_h2i.hip, wgrad_h2i.hip): THE representation of the
  * wide layers' operands -- the fp32 products of actor_critic_decoder.py:98-188, 323-349 (under ppo.py:197-218, 252, 265, 289, 333) with
  * every operand held in HBM as the (hi, lo) fp16 planes the K loops read by LDS-DMA, 4 bytes per element, scaled by a power of two chosen
