@@ -521,8 +521,20 @@ def run(a, rank, local_rank, world, wd):
     dp.trace_collectives(True)                       # N > 1: what one step exchanges, and that all ranks issue the same sequence
     step()
     torch.cuda.synchronize()
-    coll_log = dp.assert_same_collective_sequence()
+    coll_log = dp.assert_same_collective_sequence()      # raises on any rank whose sequence differs
     dp.trace_collectives(False)
+    world_facts = None
+    if world > 1:
+        # what the job actually ran on: the communicator's backend and size, and every rank's device (PCI bus id + name) --
+        # two ranks on one device, or a gloo rehearsal, must be visible in the line
+        pr = torch.cuda.get_device_properties(local_rank)
+        mine_dev = dict(rank=rank, local_rank=local_rank, name=pr.name,
+                        pci_bus_id="%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+                        uuid=str(getattr(pr, "uuid", "")))
+        devs = [None] * world
+        dist.all_gather_object(devs, mine_dev)
+        world_facts = dict(backend=dist.get_backend(), world=dist.get_world_size(), devices=devs,
+                           distinct_devices=len({d["pci_bus_id"] for d in devs}))
     if rank == 0:
         lib.dtc_prof_reset()
         lib.dtc_prof_enable(1)
@@ -630,9 +642,10 @@ def run(a, rank, local_rank, world, wd):
             planner = dict(bound="hbm", kernel="foothold_plan_fast_kernel", achieved=pby / (pms * 1e-3) / 1e9, peak=8000.0,
                            unit="GB/s", frac=pby / (pms * 1e-3) / 1e9 / 8000.0,
                            traffic=301.8e6 * (pby / pn) / (3096.0 * 98304),
-                           traffic_source="rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_planner_pmc.md "
+                           traffic_source="rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r05_planner_pmc.md (round 5 re-collection, "
+                                          "tools/jobs/r5_refresh_profiles.sh; the kernel is unchanged since round 2) "
                                           "(instruction-bound: SQ_ACTIVE_INST_VALU = 86 % of the kernel's cycles; rocprofv3 "
-                                          "kernel durations over 110 launches: 110 us average, 102 us minimum)",
+                                          "kernel durations over 30 launches: 104.9 us average, 102.4 us minimum)",
                            launches=pn, avg_launch_us=pms * 1e3 / pn, bytes_per_launch=pby / pn)
         classes = {r["name"]: dict(ms=round(r["ms_total"], 3), launches=r["launches"],
                                    rate=(r["work"] / (r["ms_total"] * 1e-3) / 1e12) if r["ms_total"] > 0 else 0.0)
@@ -708,7 +721,10 @@ def run(a, rank, local_rank, world, wd):
                        (FLOP_PER_ENV_STEP * value / world) / ((split_peak(ops) if ops.SPLIT else PEAK_FP32_MFMA_TFLOPS) * 1e12),
                        "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
                        "allreduce_bytes_per_step_per_rank": dp.bytes_reduced(coll_log) if world > 1 else 0,
-                       "collectives_per_step": len(coll_log)},
+                       "collectives_per_step": len(coll_log),
+                       "collective_sequence_ok": True,      # assert_same_collective_sequence() above passed on every rank
+                       "rccl_world": (world_facts["world"] if world_facts and world_facts["backend"] == "nccl" else None),
+                       "world": world_facts},
             "configs4_composite": configs4,
             "roofline": roof,
             "roofline_planner": planner,

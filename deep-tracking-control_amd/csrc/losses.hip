@@ -540,6 +540,40 @@ extern "C" int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc
     return dtc::check_launch("ppo_heads_loss");
 }
 
+// actor_critic_decoder.py:404-407: 1 - tanh(std(r) / mean(r)), unbiased std (torch.std).  One block: the buffer is one reward
+// per env (4096-32768 values); two passes in double so that a buffer of near-equal rewards keeps its small variance.
+__global__ __launch_bounds__(1024) void bootstrap_prob_kernel(const float* __restrict__ r, int64_t n, float* __restrict__ out) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    auto block_sum = [&](double v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        double t = 0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        return t;
+    };
+    double a = 0;
+    for (int64_t i = tid; i < n; i += 1024) a += (double)r[i];
+    const double mean = block_sum(a) / (double)n;
+    double q = 0;
+    for (int64_t i = tid; i < n; i += 1024) { const double d = (double)r[i] - mean; q += d * d; }
+    const double var = block_sum(q) / (double)(n - 1);        // n == 1: 0 / 0 = NaN, as torch.std
+    if (tid == 0) {
+        // the reference's arithmetic from here on is fp32 tensors: std and mean rounded to float before the division
+        const float cv = (float)sqrt(var) / (float)mean;
+        out[0] = 1.0f - tanhf(cv);
+    }
+}
+
+extern "C" int dtc_bootstrap_probability(const float* rewards, int64_t n, float* out, void* stream) {
+    DTC_REQUIRE(n > 0, "empty reward buffer");
+    DTC_REQUIRE(rewards && out, "null pointer");
+    hipLaunchKernelGGL(bootstrap_prob_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rewards, n, out);
+    return dtc::check_launch("bootstrap_probability");
+}
+
 extern "C" int dtc_gaussian_act(const float* mean, const float* std, const float* noise, float* actions, float* logp,
                                 float* mu_out, float* sigma_out, int B, int num_actions, void* stream) {
     DTC_REQUIRE(B > 0 && num_actions > 0, "bad shape");

@@ -202,6 +202,7 @@ _SIGS = {
                                                                       C.c_void_p, c_stream]),
     "dtc_lr_adapt": (C.c_int, [c_f32p, c_f64p, C.c_float, c_stream]),
     "dtc_gaussian_act": (C.c_int, [c_f32p] * 7 + [C.c_int, C.c_int, c_stream]),
+    "dtc_bootstrap_probability": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_stream]),
     "dtc_adam_workspace": (C.c_int64, [C.c_int64]),
     "dtc_clip_adam": (C.c_int, [c_f32p] * 4 + [C.c_int64, C.c_float, c_f64p, C.c_double, C.c_double, C.c_double,
                                                C.c_int64, c_f32p, C.c_void_p, c_stream]),

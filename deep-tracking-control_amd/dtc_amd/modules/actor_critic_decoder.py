@@ -551,6 +551,35 @@ class ActorCriticDecoder(nn.Module):
         ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None, **fp)
         return ws.mean.clone()
 
+    def act_student(self, observations, observations_history, privileged_obs, lidar_latent, masks=None, hidden_states=None):
+        """actor_critic_decoder.py:459-502: mean action of the student head from latent_mu (no sampling) and a caller-supplied
+        terrain latent.  The reference's body reads `self.cenet_encoder`, `self.latent_mu` (as a layer), `self.actor_student` and
+        an exporter loaded from an absolute path, none of which its class defines; here those names mean what the rest of the class
+        calls them (vae.cenet_encoder, vae.latent_mu, actor_body -- the only actor, same input width), the exporter side effect is
+        not restated (its output is discarded there).  `privileged_obs`, `masks`, `hidden_states` are accepted and unused, as there."""
+        self.ensure_arena()
+        obs, hist, lid = self._prep(observations), self._prep(observations_history), self._prep(lidar_latent)
+        B = obs.shape[0]
+        if lid.shape != (B, 512):
+            raise ValueError(f"act_student: lidar_latent must be ({B}, 512), got {tuple(lid.shape)}")
+        ws, L = self._fwd_ws(B), self.L
+        fp = dict(split=False)                          # rows are independent envs: single-pass fp32 kernels (see act_teacher)
+        ops.linear_fwd(hist, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=B, **fp)
+        ops.linear_fwd(ws.e1, L["ce1"].W, L["ce1"].b, ws.e, None, **fp)
+        ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None, **fp)          # [:, :19] = latent_mu
+        X = segmat([seg(obs, 0, self.num_obs), seg(ws.mulv, 3, 16), seg(ws.mulv, 0, 3), seg(lid, 0, 512)])
+        act = AC_Args.activation
+        ops.linear_fwd(X, L["a0"].W, L["a0"].b, ws.a1, act, M=B, **fp)
+        ops.linear_fwd(ws.a1, L["a1"].W, L["a1"].b, ws.a2, act, **fp)
+        ops.linear_fwd(ws.a2, L["a2"].W, L["a2"].b, ws.a3, act, **fp)
+        ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None, **fp)
+        return ws.mean.clone()
+
+    def adapt_bootstrap_probability(self, rewards):
+        """actor_critic_decoder.py:404-407: 1 - tanh(std / mean) of a reward buffer (unbiased std, as torch.std), a Python float.
+        One fused reduction on the device (`ops.bootstrap_probability`), one host read -- the `.item()` of the reference."""
+        return ops.bootstrap_probability(self._prep(rewards))
+
     def act_inference(self, ob):
         """Deterministic policy output (mean action) for deployment-style evaluation."""
         self.update_distribution(ob["obs"], ob["obs_history"], ob["privileged_obs"],

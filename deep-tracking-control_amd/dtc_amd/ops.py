@@ -699,6 +699,16 @@ def gaussian_act(mean, std, noise, actions, logp, mu_out=None, sigma_out=None):
                                  ptr(mu_out), ptr(sigma_out), B, A, stream()), "dtc_gaussian_act")
 
 
+def bootstrap_probability(rewards) -> float:
+    """actor_critic_decoder.py:404-407 (1 - tanh(std / mean), unbiased std); one launch + the reference's own `.item()`."""
+    r = rewards.reshape(-1)
+    if r.dtype != f32 or not r.is_contiguous():
+        r = r.to(f32).contiguous()
+    out = torch.empty(1, dtype=f32, device=r.device)
+    check(lib().dtc_bootstrap_probability(cptr(r, f32), r.numel(), cptr(out, f32), stream()), "dtc_bootstrap_probability")
+    return out.item()
+
+
 def clip_adam(params, grads, exp_avg, exp_avg_sq, max_grad_norm, lr, beta1, beta2, eps, step, gnorm_out, ws):
     n = params.numel()
     check(lib().dtc_clip_adam(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), n, max_grad_norm, ptr(lr),

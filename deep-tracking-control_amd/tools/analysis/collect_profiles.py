@@ -35,11 +35,12 @@ def short(name):
 
 d = last_json(f"{src}/{tag}_bench_n1.json")
 json.dump(d, open(f"{dst}/{tag}_bench_n1.json", "w"), indent=1)
-for w in ("gru", "composite", "fp32mfma", "bf16x3"):
+for w in ("gru", "composite", "fp32mfma", "bf16x3", "converting"):
     p = f"{src}/{tag}_bench_{w}.json"
     if os.path.exists(p):
         json.dump(last_json(p), open(f"{dst}/{tag}_bench_{w}_informative.json", "w"), indent=1)
-for name in (f"{tag}_gemm_pmc.md", f"{tag}_gemm_pmc_fp32mfma.md", f"{tag}_split_accuracy.log", f"{tag}_cpu_baseline_full.json"):
+for name in (f"{tag}_gemm_pmc.md", f"{tag}_gemm_pmc_fp32mfma.md", f"{tag}_split_accuracy.log", f"{tag}_cpu_baseline_full.json",
+             f"{tag}_h2i_accuracy.log", f"{tag}_h2i_timeline.txt"):
     if os.path.exists(f"{src}/{name}"):
         shutil.copy(f"{src}/{name}", f"{dst}/{name}")
 
@@ -77,8 +78,8 @@ if r.get("traffic_kernels"):
         f.write(f"* algorithmic (every operand read once, every output written once; in-library accounting): **{r['traffic_algorithmic_step_bytes'] / 1e9:.1f} GB per step** "
                 f"= {r['traffic_algorithmic'] / 1e6:.1f} MB per launch\n* ratio **{r['traffic_over_algorithmic']:.3f}**\n\n")
         f.write("Where the excess comes from: the partial slabs of the weight gradients (written once by the grouped kernel, read once by its "
-                "reduce kernel -- not counted as algorithmic), the weight images (6 bytes per weight written per call and fetched once by "
-                "every XCD's L2 instead of 4) and operand re-reads that miss the 4 MB per-XCD L2.\n")
+                "reduce kernel -- not counted as algorithmic), the weight images (round 5: 4 bytes per weight + block exponents, written once per phase and fetched once by "
+                "every XCD's L2), the one-off packing of the rollout rows into operand images (read 4 B, write 4 B per element, once per mini-batch and update) and operand re-reads that miss the 4 MB per-XCD L2.\n")
 
 # ---- rocprofv3 kernel stats
 for mode in ("serial", "overlap"):
@@ -91,7 +92,7 @@ for mode in ("serial", "overlap"):
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for x in rows:
             w.writerow([short(x["Name"]), x["Calls"], x["TotalDurationNs"], x["AverageNs"], x["Percentage"], x["MinNs"], x["MaxNs"], x["StdDev"]])
-    fam = [x for x in rows if any(k in x["Name"] for k in ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_group", "wgrad_reduce", "gru_step_fwd", "linear_s3", "wgrad_s3"))]
+    fam = [x for x in rows if any(k in x["Name"] for k in ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_group", "wgrad_reduce", "gru_step_fwd", "linear_s3", "wgrad_s3", "linear_h2i", "wgrad_h2i", "h2i_pack", "h2i_wpack"))]
     tot, calls = sum(float(x["TotalDurationNs"]) for x in fam), sum(int(x["Calls"]) for x in fam)
     print(f"{mode}: GEMM family {tot / 1e6:.1f} ms over {calls} launches -> {tot / calls / 1e3:.2f} us per launch")
 

@@ -25,6 +25,7 @@ PASSES = {
 BY_GRID = os.environ.get("DTC_PMC_BY_GRID", "1") != "0"      # one row per (kernel, workgroup count) = per layer shape
 FAMILY = ("linear_fwd_kernel", "linear_dgrad_kernel", "linear_wgrad_kernel", "wgrad_group_kernel", "wgrad_reduce_kernel",
           "wgrad_group_reduce_kernel", "gru_step_fwd_kernel", "linear_s3_kernel", "wgrad_s3_group_kernel", "wgrad_s3_reduce_kernel", "wimage_kernel",
+          "linear_h2i_kernel", "wgrad_h2i_group_kernel", "wgrad_h2i_reduce_kernel", "h2i_pack_kernel", "h2i_wpack_kernel",
           "gru_s3_kernel")
 
 
@@ -104,11 +105,13 @@ def summarise(out_dir):
         busy, gui = ca.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), ca.get("GRBM_GUI_ACTIVE", 0.0)
         # single-pass kernels: v_mfma_f32_32x32x2_f32 = 64 busy cycles, 4096 FLOP; split kernels (_s3_): v_mfma_f32_32x32x16_bf16 =
         # 32 busy cycles, 32768 bf16 FLOP = 32768 / 6 fp32-equivalent FLOP (six passes per product)
-        s3 = "_s3_" in k
+        # operand-image kernels (_h2i_): v_mfma_f32_32x32x16_f16, three passes per product
+        h2 = "_h2i_" in k
+        s3 = "_s3_" in k or h2
         n_mfma = busy / (32.0 if s3 else 64.0)
         sec = ca["_ns"] * 1e-9
         res[k] = dict(launches=ca["_n"], ms=ca["_ns"] * 1e-6, mfma_busy=busy / (1024.0 * gui / 8.0) if gui else 0.0,
-                      executed_tflops=n_mfma * (32768.0 / 6.0 if s3 else 4096.0) / sec / 1e12 if sec > 0 else 0.0,
+                      executed_tflops=n_mfma * (32768.0 / 3.0 if h2 else 32768.0 / 6.0 if s3 else 4096.0) / sec / 1e12 if sec > 0 else 0.0,
                       clock_ghz=gui / 8.0 / (ca["_ns"]) if ca["_ns"] else 0.0,
                       valu_per_mfma=cb.get("SQ_INSTS_VALU", 0.0) / n_mfma - 1.0 if n_mfma else 0.0,
                       salu_per_mfma=cb.get("SQ_INSTS_SALU", 0.0) / n_mfma if n_mfma else 0.0,

@@ -494,6 +494,10 @@ int dtc_lr_adapt(float* kl_mean, double* lr, float desired_kl, void* stream);
 int dtc_gaussian_act(const float* mean, const float* std, const float* noise, float* actions,
                      float* logp, float* mu_out, float* sigma_out, int B, int num_actions, void* stream);
 
+/* ActorCriticDecoder.adapt_bootstrap_probability (actor_critic_decoder.py:404-407): out[0] = 1 - tanh(std(rewards) / mean(rewards)),
+ * unbiased std as torch.std; rewards: n contiguous floats on the device, out: one device float. */
+int dtc_bootstrap_probability(const float* rewards, int64_t n, float* out, void* stream);
+
 /* ---- clip_grad_norm_ + Adam over one flat parameter range (ppo.py:253-254, 334-335) --------- */
 /* gnorm_out (float, device) receives the pre-clip global L2 norm.  lr is a device double;
  * step is the 1-based Adam step count of this range. */

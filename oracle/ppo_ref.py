@@ -102,6 +102,18 @@ class RefActorCriticDecoder(nn.Module):
         b_t = b_t1 + torch.mul(l_t, b_t1)
         return self.actor_body(torch.cat((obs, latent[:, 3:], latent[:, :3], b_t), dim=-1))
 
+    # actor_critic_decoder.py:459-502 with its dangling names resolved (cenet_encoder / latent_mu -> vae.*, actor_student -> actor_body;
+    # the exporter side effect dropped: its output is discarded there): mean action from latent_mu and a caller-supplied lidar latent
+    def act_student(self, obs, hist, priv, lidar_latent):
+        latent = self.vae.latent_mu(self.vae.cenet_encoder(hist))
+        return self.actor_body(torch.cat((obs, latent[:, 3:], latent[:, :3], lidar_latent), dim=-1))
+
+    # actor_critic_decoder.py:404-407
+    @staticmethod
+    def adapt_bootstrap_probability(rewards):
+        cv = torch.std(rewards) / torch.mean(rewards)
+        return (1 - torch.tanh(cv)).item()
+
     # actor_critic_decoder.py:540-551
     def evaluate(self, obs, priv, base_vel):
         return self.critic_body(torch.cat((obs, base_vel, priv[:, 693:696], priv[:, 696:]), dim=-1))

@@ -472,6 +472,31 @@ def gen_teacher():
          n_group_params=np.array([len(osd['param_groups'][0]['params'])]))
 
 
+def gen_student():
+    """`ActorCriticDecoder.act_student` (actor_critic_decoder.py:459-502) and `.adapt_bootstrap_probability` (:404-407).
+    As written, `act_student` stops at its first statement: it reads `self.cenet_encoder`, `self.latent_mu` (as a layer),
+    `self.actor_student` and `self.exporter`, none of which the class defines (the encoder and the head live under `self.vae`, the only
+    actor is `actor_body`, and the exporter loads a file from an absolute path of the authors' machine).  The vector here is the body of the
+    reference's own function run with exactly those names bound: cenet_encoder / latent_mu -> the `vae` modules of the same name,
+    actor_student -> actor_body (same input width: obs 53 + 16 + 3 + 512), count = 1 and a no-op exporter (its output is discarded)."""
+    torch.set_num_threads(GOLDEN_THREADS)
+    alg = _ref_alg(64, seed_fill=11)
+    ac = alg.actor_critic
+    ac.cenet_encoder, ac.latent_mu, ac.actor_student = ac.vae.cenet_encoder, ac.vae.latent_mu, ac.actor_body
+    ac.count, ac.exporter = 1, (lambda x: None)
+    d = S.rollout(64, 24, seed=4)
+    obs, hist, priv = (d[k].flatten(0, 1)[:512] for k in ("observations", "observation_histories", "privileged_observations"))
+    g = torch.Generator().manual_seed(91)
+    lidar = torch.randn(512, 512, generator=g)
+    with torch.no_grad():
+        mean = ac.act_student(obs, hist, priv, lidar)
+    rew = [torch.rand(4096, generator=g) + 0.5, torch.randn(4096, generator=g) * 3 + 1.0, torch.full((64,), 2.0),
+           torch.randn(1024, generator=g) * 0.01 - 1.0]
+    probs = np.array([type(ac).adapt_bootstrap_probability(ac, r) for r in rew])
+    save("student", mean=mean.numpy(), lidar_seed=np.array([91]), bootstrap_prob=probs,
+         **{f"rew{i}": r.numpy() for i, r in enumerate(rew)})
+
+
 # ------------------------------------------------------------------------------------ f3: observations / termination
 def gen_observations():
     """`LeggedRobotDTC.compute_observations` and `.check_termination` (legged_robot_dtc.py:229-288) run as
@@ -590,7 +615,7 @@ def gen_composite():
     save("composite", **out)
 
 
-TASKS = dict(lstm=gen_lstm, teacher=gen_teacher, observations=gen_observations, composite=gen_composite, gru=gen_gru, gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
+TASKS = dict(lstm=gen_lstm, teacher=gen_teacher, student=gen_student, observations=gen_observations, composite=gen_composite, gru=gen_gru, gae=gen_gae, ppo=gen_ppo, init=gen_init, scorer=gen_scorer, heights=gen_heights)
 
 if __name__ == "__main__":
     for t in (sys.argv[1:] or list(TASKS)):

@@ -666,6 +666,30 @@ def jsonable(sd):
                 param_groups=sd["param_groups"])
 
 
+def test_act_student_and_bootstrap_probability(golden):
+    """`act_student` (actor_critic_decoder.py:459-502, names bound as make_golden.py:gen_student states) and
+    `adapt_bootstrap_probability` (:404-407) against the reference's own outputs; tolerance 1e-5 relative / 2e-6 absolute on the
+    mean action, 2e-6 on the probability (one fp32 tanh of an fp32 quotient; the sums run in double)."""
+    g = golden("student")
+    ref, alg = _pair(64)
+    ac = alg.actor_critic
+    d = S.rollout(64, 24, seed=4)
+    obs, hist, priv = (d[k].flatten(0, 1)[:512] for k in ("observations", "observation_histories", "privileged_observations"))
+    lidar = torch.randn(512, 512, generator=torch.Generator().manual_seed(int(g["lidar_seed"][0])))
+    got = ac.act_student(obs.to(DEV), hist.to(DEV), priv.to(DEV), lidar.to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), g["mean"], rtol=1e-5, atol=2e-6)
+    with torch.no_grad():
+        want = ref.actor_critic.act_student(obs, hist, priv, lidar)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=2e-6)
+    with pytest.raises(ValueError):
+        ac.act_student(obs.to(DEV), hist.to(DEV), priv.to(DEV), lidar[:, :256].to(DEV))
+    for i, p in enumerate(g["bootstrap_prob"]):
+        r = torch.from_numpy(g[f"rew{i}"])
+        assert abs(ac.adapt_bootstrap_probability(r.to(DEV)) - p) <= 2e-6, i
+        assert abs(ac.adapt_bootstrap_probability(r.to(DEV).reshape(-1, 1)) - p) <= 2e-6          # (num_envs, 1) reward buffers
+    assert np.isnan(ac.adapt_bootstrap_probability(torch.ones(1, device=DEV)))                  # torch.std of one value
+
+
 def test_act_teacher_and_checkpoint_roundtrip(golden, tmp_path):
     """f4: `act_expert` (deployment path through memory_mlp) vs the oracle, and OnPolicyRunner.save / load: the
     dictionary has the reference's layout (tests/golden/teacher.npz) and restores model, optimiser and iteration."""

@@ -283,3 +283,21 @@ def test_act_teacher_oracle_and_checkpoint_layout(golden):
     mine = ActorCriticDecoder(53, 1389, 12).state_dict()
     assert list(mine.keys()) == [str(k) for k in g["model_keys"]]
     assert [str(tuple(v.shape)) for v in mine.values()] == [str(s) for s in g["model_shapes"]]
+
+
+def test_act_student_and_bootstrap_probability_oracle(golden):
+    """actor_critic_decoder.py:459-502 (with the dangling names bound as tests/golden/make_golden.py:gen_student states) and :404-407."""
+    from dtc_amd import synthetic as S
+    from oracle import ppo_ref as OP
+    g = golden("student")
+    torch.manual_seed(3)
+    ac = OP.fill_parameters_(OP.RefActorCriticDecoder(), 11)
+    d = S.rollout(64, 24, seed=4)
+    obs, hist, priv = (d[k].flatten(0, 1)[:512] for k in ("observations", "observation_histories", "privileged_observations"))
+    lidar = torch.randn(512, 512, generator=torch.Generator().manual_seed(int(g["lidar_seed"][0])))
+    with torch.no_grad():
+        mean = ac.act_student(obs, hist, priv, lidar)
+    np.testing.assert_allclose(mean.numpy(), g["mean"], rtol=1e-5, atol=1e-6)
+    for i, want in enumerate(g["bootstrap_prob"]):
+        got = OP.RefActorCriticDecoder.adapt_bootstrap_probability(torch.from_numpy(g[f"rew{i}"]))
+        assert abs(got - want) <= 1e-6, (i, got, want)
