@@ -492,6 +492,42 @@ def run(a, rank, local_rank, world, wd):
                             env_steps_per_s=NUM_ENVS / (call_us * 1e-6), call_us=call_us,
                             measured="avg_launch_us: HIP events around each of 50 launches on the launch stream (incl. ~3 us of event overhead); "
                                      "call_us / env_steps_per_s: 50 back-to-back calls through the Python / ctypes boundary (launch-path bound)")
+        # the whole post-physics block of one env step at this size: ONE launch (foothold.EnvStep: planner + check_termination +
+        # foothold rewards + compute_observations on the env's buffers) against the four separate launches
+        es = S.env_state(NUM_ENVS, seed=13, device=dev)
+        gq = torch.Generator(device=dev).manual_seed(90)
+        es["foot_positions"] = torch.cat([es["root_states"][:, None, :2] + 0.3 * torch.randn(NUM_ENVS, 4, 2, generator=gq, device=dev),
+                                          0.05 * torch.randn(NUM_ENVS, 4, 1, generator=gq, device=dev)], dim=2)
+        es["contact_filt"] = torch.rand(NUM_ENVS, 4, generator=gq, device=dev) < 0.6
+        fused = foothold.EnvStep(NUM_ENVS, dev)
+        fkw = {k: es[k] for k in ("root_states", "thigh_pos", "commands", "contact_forces", "termination_contact_indices", "episode_length_buf",
+                                  "projected_gravity", "foot_positions", "contact_filt", "base_ang_vel", "dof_pos", "default_dof_pos", "dof_vel",
+                                  "actions", "forces", "height_noise_offset", "u_obs", "noise_scale_vec", "u_heights", "measured_heights")}
+
+        def four_launches():
+            p = foothold.plan(es["measured_heights"], es["root_states"], es["thigh_pos"], es["commands"])
+            foothold.check_termination(es["contact_forces"], es["termination_contact_indices"], es["episode_length_buf"], 1000,
+                                       es["projected_gravity"], es["root_states"], es["measured_heights"])
+            foothold.rewards(es["foot_positions"], p["optimal_footholds_world"], es["contact_filt"])
+            foothold.compute_observations(es["base_ang_vel"], es["projected_gravity"], es["commands"], es["dof_pos"], es["default_dof_pos"],
+                                          es["dof_vel"], es["actions"], p["foothold_obs"], es["root_states"], es["measured_heights"],
+                                          es["forces"], es["height_noise_offset"], es["u_obs"], es["noise_scale_vec"], es["u_heights"])
+
+        def per_call_us(fn):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e6
+        us_fused, us_four = per_call_us(lambda: fused(max_episode_length=1000, **fkw)), per_call_us(four_launches)
+        planner_4096["env_step_block"] = dict(
+            workload="one env step's post-physics block at 4096 envs: planner + check_termination + foothold rewards + compute_observations",
+            one_launch_us=us_fused, four_launches_us=us_four, env_steps_per_s=NUM_ENVS / (us_fused * 1e-6),
+            measured="wall clock of 50 back-to-back calls incl. the Python / ctypes path, device synchronised at both ends; same outputs bit "
+                     "for bit (tests/test_hip_envstep.py)")
 
     # EVERY rank runs these two extra steps (they contain the data-parallel collectives); only rank 0 records events
     lib = _ffi.lib()

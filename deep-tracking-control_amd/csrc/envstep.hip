@@ -24,12 +24,14 @@ struct ObsArgs {
     float* heights;
     DtcObsCfg cfg;
     int N;
+    const unsigned char* where;      // NULL: all rows; else only rows with where[n] != 0
 };
 
 __global__ __launch_bounds__(256) void env_observations_kernel(const ObsArgs a) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= a.N) return;
+    if (a.where && !a.where[n]) return;
     const DtcObsCfg& c = a.cfg;
     const int D = c.num_dof, F = c.num_foothold_obs, P = c.num_points;
     const int n_obs = 9 + 3 * D + F;
@@ -181,6 +183,18 @@ extern "C" int dtc_compute_observations(const float* base_ang_vel, const float* 
                                         const float* height_noise_offset, const float* u_obs, const float* noise_scale_vec,
                                         const float* u_heights, const DtcObsCfg* cfg, float* obs_buf,
                                         float* privileged_obs_buf, float* heights, int N, void* stream) {
+    return dtc_compute_observations_where(base_ang_vel, projected_gravity, commands, dof_pos, default_dof_pos, dof_vel, actions,
+                                          foothold_obs, root_states, measured_heights, forces, ld_forces, height_noise_offset, u_obs,
+                                          noise_scale_vec, u_heights, cfg, obs_buf, privileged_obs_buf, heights, nullptr, N, stream);
+}
+
+extern "C" int dtc_compute_observations_where(const float* base_ang_vel, const float* projected_gravity, const float* commands,
+                                              const float* dof_pos, const float* default_dof_pos, const float* dof_vel,
+                                              const float* actions, const float* foothold_obs, const float* root_states,
+                                              const float* measured_heights, const float* forces, int64_t ld_forces,
+                                              const float* height_noise_offset, const float* u_obs, const float* noise_scale_vec,
+                                              const float* u_heights, const DtcObsCfg* cfg, float* obs_buf,
+                                              float* privileged_obs_buf, float* heights, const uint8_t* where, int N, void* stream) {
     DTC_REQUIRE(N >= 0 && cfg, "bad arguments");
     if (N == 0) return DTC_OK;
     DTC_REQUIRE(base_ang_vel && projected_gravity && commands && dof_pos && default_dof_pos && dof_vel && actions &&
@@ -189,7 +203,7 @@ extern "C" int dtc_compute_observations(const float* base_ang_vel, const float* 
     DTC_REQUIRE(cfg->num_dof > 0 && cfg->num_points > 0 && cfg->num_foothold_obs >= 0 && ld_forces >= 3, "bad config");
     ObsArgs a{base_ang_vel, projected_gravity, commands, dof_pos, default_dof_pos, dof_vel, actions, foothold_obs,
               root_states, measured_heights, forces, height_noise_offset, u_obs, noise_scale_vec, u_heights,
-              (long long)ld_forces, obs_buf, privileged_obs_buf, heights, *cfg, N};
+              (long long)ld_forces, obs_buf, privileged_obs_buf, heights, *cfg, N, where};
     hipStream_t s = (hipStream_t)stream;
     const double bytes = (double)N * (cfg->num_points * 4.0 * 6 + 400.0);
     dtc::ProfScope prof("compute_observations", bytes, s);

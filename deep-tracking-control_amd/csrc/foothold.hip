@@ -477,12 +477,38 @@ struct TableParams {
     float border, hscale, vscale;
 };
 
-template <int NX, int NY, bool TABLE>
-__global__ __launch_bounds__(256, TABLE ? 3 : DTC_FH_WAVES) void foothold_plan_fast_kernel(
+// the rest of one env step (STEP = true): what LeggedRobotDTC.post_physics_step does with the SAME per-env data right after the
+// foothold block -- check_termination (legged_robot_dtc.py:229-248), the two foothold rewards (:577-586, :536-539) and
+// compute_observations (:255-288) -- appended to the planner's per-env loop while the env's height row is still in LDS.  Every
+// value is produced by the operations, lane assignment and reduction order of the stand-alone kernels (check_termination_kernel,
+// foothold_rewards_kernel, env_observations_kernel), so the outputs are the same bits (tests/test_hip_envstep.py).
+struct StepArgs {
+    // check_termination
+    const float* contact_forces;
+    const int* term_idx;
+    const long long* episode_length;
+    const float* gravity;
+    unsigned char *reset_buf, *time_out_buf;
+    float* height_mean;
+    long long max_episode_length;
+    int num_bodies, n_term;
+    // rewards
+    const float* foot_positions;
+    const unsigned char* contact_filt;
+    float *rew_tracking, *rew_miss;
+    // compute_observations
+    const float *ang_vel, *dof_pos, *default_dof_pos, *dof_vel, *actions, *forces, *noise_offset, *u_obs, *noise_scale, *u_heights;
+    long long ld_forces;
+    float *obs, *priv, *heights;
+    DtcObsCfg cfg;
+};
+
+template <int NX, int NY, bool TABLE, bool STEP = false>
+__global__ __launch_bounds__(256, (TABLE || STEP) ? 3 : DTC_FH_WAVES) void foothold_plan_fast_kernel(
     float* __restrict__ mh, const float* __restrict__ root, const float* __restrict__ thigh,
     const float* __restrict__ cmd, const GridParams gp, const TableParams tp, int64_t* __restrict__ idx_out,
     float* __restrict__ obs_out, float* __restrict__ world_out, float* __restrict__ pred_out, float* __restrict__ p2r_out,
-    int N) {
+    int N, const StepArgs sa) {
     constexpr int P = NX * NY, NCH = (P + 255) / 256, RS = (P + 3) & ~3;
     constexpr int PX = (NX + 7) / 8, PY = (NY + 7) / 8;                // 8 x 8 patches that tile the grid (fallback)
     static_assert(NY >= 10 && NX >= 10, "the flat index must grow with the lane id inside a patch");
@@ -681,6 +707,46 @@ __global__ __launch_bounds__(256, TABLE ? 3 : DTC_FH_WAVES) void foothold_plan_f
         }
         if (!TABLE && e + 1 < cnt) load_row(g0 + e + 1, cur);          // next env's row travels while this one is scored
 
+        if constexpr (STEP) {
+            const int n = g0 + e;
+            const DtcObsCfg& c = sa.cfg;
+            // ---- check_termination: lanes stride over the termination bodies / the height slice exactly as check_termination_kernel
+            bool hit = false;
+            for (int j = lane; j < sa.n_term; j += 64) {
+                const float* f = sa.contact_forces + ((long long)n * sa.num_bodies + sa.term_idx[j]) * 3;
+                hit |= sqrtf((f[0] * f[0] + f[1] * f[1]) + f[2] * f[2]) > 100.0f;
+            }
+            const bool contact = __ballot(hit) != 0ull;
+            float part = 0.f;
+            bool first = true;
+            for (int p = c.term_row0 + lane; p < c.term_row1; p += 64) {
+                const float d = bz - fmaxf(rawE[p], -0.0f);
+                part = first ? d : part + d;
+                first = false;
+            }
+            const float tmean = wave_sum(part) / (float)(c.term_row1 - c.term_row0);
+            if (lane == 0) {
+                const bool to = sa.episode_length[n] > sa.max_episode_length;
+                const bool r = contact || to || sa.gravity[n * 3 + 2] > 0.2f || tmean < c.term_height;
+                sa.reset_buf[n] = r ? 1 : 0;
+                if (sa.time_out_buf) sa.time_out_buf[n] = to ? 1 : 0;
+                if (sa.height_mean) sa.height_mean[n] = tmean;
+            }
+            // ---- height part of compute_observations: privileged = [noisy heights | force | clean heights]
+            const float zt = bz - c.base_height_target;
+            float* pv = sa.priv + (long long)n * (2 * P + 3);
+            for (int p = lane; p < P; p += 64) {
+                const float h = fminf(fmaxf(zt - rawE[p], -1.0f), 1.0f) * c.height_measurements;
+                float nz = h;
+                if (sa.u_heights) nz = nz + (2.0f * sa.u_heights[(long long)n * P + p] - 1.0f) * c.height_noise;
+                if (sa.noise_offset) nz = nz + sa.noise_offset[(long long)n * P + p];
+                pv[p] = nz;
+                pv[P + 3 + p] = h;
+                if (sa.heights) sa.heights[(long long)n * P + p] = h;
+            }
+            if (lane < 3) pv[P + lane] = sa.forces[(long long)n * sa.ld_forces + lane] * c.force;
+        }
+
         // ================= scoring of one 8 x 8 patch whose candidates and their four neighbours are all grid points
         // (1 <= sx, sx + 8 <= NX - 1, same in y): fixed LDS offsets, the constant 0.1 divisor, both axes packed
         auto score_interior = [&](int sx, int sy, float pxl, float pyl, float& tot, int& ii) {
@@ -814,16 +880,70 @@ __global__ __launch_bounds__(256, TABLE ? 3 : DTC_FH_WAVES) void foothold_plan_f
     }
 
     // ================= decode (legged_robot_dtc.py:184-201) on lanes (env of the wave, leg)
+    float fo_x = 0.0f, fo_y = 0.0f, ow_x = 0.0f, ow_y = 0.0f;
     if (lane_valid) {
         const int bi = my_bi, yi = bi / NY, xi = bi - yi * NY;       // xi = idx % ny, yi = idx / ny
         __builtin_amdgcn_raw_buffer_store_b64(u2{(unsigned)bi, 0u}, r_idx, vo_idx, g0 * 32, 0);
         // the reference gathers the x table with the y-index and vice versa (sic); xi < ny, yi < nx
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(xs[xi < NX ? xi : xi % NX]), r_obs, vo_obs, g0 * 32, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ys[yi < NY ? yi : yi % NY]), r_obs, vo_obs + 16, g0 * 32, 0);
+        fo_x = xs[xi < NX ? xi : xi % NX];
+        fo_y = ys[yi < NY ? yi : yi % NY];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(fo_x), r_obs, vo_obs, g0 * 32, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(fo_y), r_obs, vo_obs + 16, g0 * 32, 0);
         const float px = xs[yi], py = ys[xi];
         const float t0 = -(zq_l * py) * 2.0f;
         const float t1 = (zq_l * px) * 2.0f;
-        st3(r_world, vo_leg, g0 * 48, ((px + wq_l * t0) + (-(zq_l * t1))) + bx_l, ((py + wq_l * t1) + (zq_l * t0)) + by_l, my_z);
+        ow_x = ((px + wq_l * t0) + (-(zq_l * t1))) + bx_l;
+        ow_y = ((py + wq_l * t1) + (zq_l * t0)) + by_l;
+        st3(r_world, vo_leg, g0 * 48, ow_x, ow_y, my_z);
+    }
+
+    if constexpr (STEP) {
+        const DtcObsCfg& c = sa.cfg;
+        // ---- foothold rewards: lane (env, leg) evaluates its leg, the env's first lane adds the four terms in leg order
+        // (foothold_rewards_kernel: sum = ((0 + t0) + t1) + t2) + t3)
+        float term = 0.0f, fz = __builtin_inff();
+        if (lane_valid) {
+            const float* f = sa.foot_positions + (long long)(g0 + e_l) * 12 + l_l * 3;
+            const float dx = f[0] - ow_x, dy = f[1] - ow_y;
+            const float dis = sqrtf(dx * dx + dy * dy);
+            const float r = -logf(0.8f + dis);
+            term = sa.contact_filt[(g0 + e_l) * 4 + l_l] ? r : 0.0f;
+            fz = f[2];
+        }
+        float sum = 0.0f, minz = __builtin_inff();
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            sum = sum + __shfl(term, (lane & ~3) + l, 64);
+            minz = fminf(minz, __shfl(fz, (lane & ~3) + l, 64));
+        }
+        if (lane_valid && l_l == 0) {
+            if (sa.rew_tracking) sa.rew_tracking[g0 + e_l] = sum;
+            if (sa.rew_miss) sa.rew_miss[g0 + e_l] = minz < 0.0f ? 1.0f : 0.0f;
+        }
+        // ---- proprioceptive observation rows (one lane per element, as env_observations_kernel); the eight foothold
+        // observations come from the lanes that decoded them
+        const int D = c.num_dof, F = c.num_foothold_obs, n_obs = 9 + 3 * D + F;
+        for (int e = 0; e < cnt; ++e) {
+            const int n = g0 + e;
+            for (int base = 0; base < n_obs; base += 64) {
+                const int el = base + lane;
+                const int k = el - (9 + 3 * D);
+                const int srcl = e * 4 + (k >= 0 && k < 8 ? (k & 3) : 0);
+                const float fx = __shfl(fo_x, srcl, 64), fy = __shfl(fo_y, srcl, 64);
+                if (el < n_obs) {
+                    float v;
+                    if (el < 3) v = sa.ang_vel[n * 3 + el] * c.ang_vel;
+                    else if (el < 6) v = sa.gravity[n * 3 + (el - 3)];
+                    else if (el < 9) v = cmd[n * 4 + (el - 6)] * c.commands_scale[el - 6];
+                    else if (el < 9 + D) v = (sa.dof_pos[n * D + (el - 9)] - sa.default_dof_pos[el - 9]) * c.dof_pos;
+                    else if (el < 9 + 2 * D) v = sa.dof_vel[n * D + (el - 9 - D)] * c.dof_vel;
+                    else if (el < 9 + 3 * D) v = sa.actions[n * D + (el - 9 - 2 * D)];
+                    else v = k < 4 ? fx : fy;
+                    if (sa.u_obs) v = v + (2.0f * sa.u_obs[(long long)n * n_obs + el] - 1.0f) * sa.noise_scale[el];
+                    sa.obs[(long long)n * n_obs + el] = v;
+                }
+            }
+        }
     }
 }
 
@@ -939,7 +1059,7 @@ extern "C" int dtc_foothold_plan(const float* measured_heights, const float* roo
         dtc::ProfScope prof("foothold_plan", bytes, s);
         hipLaunchKernelGGL((foothold_plan_fast_kernel<33, 21, false>), dim3(fgrid), dim3(256), 0, s,
                            const_cast<float*>(measured_heights), root_states, thigh_pos, commands, gp, TableParams{}, idx,
-                           foothold_obs, opt_world, pred, pred_to_robot, N);
+                           foothold_obs, opt_world, pred, pred_to_robot, N, StepArgs{});
         return dtc::check_launch("foothold_plan");
     }
     const bool vec = dtc::aligned16(measured_heights);
@@ -998,7 +1118,7 @@ extern "C" int dtc_foothold_plan_from_table(const int16_t* height_samples, int r
     const TableParams tp{height_samples, rows, cols, border_size, horizontal_scale, vertical_scale};
     hipLaunchKernelGGL((foothold_plan_fast_kernel<33, 21, true>), dim3((unsigned)dtc::ceil_div((int64_t)N, FAST_ENVS_PER_BLOCK)),
                        dim3(256), 0, s, measured_heights, root_states, thigh_pos, commands, gp, tp, idx, foothold_obs,
-                       opt_world, pred, pred_to_robot, N);
+                       opt_world, pred, pred_to_robot, N, StepArgs{});
     return dtc::check_launch("foothold_plan_from_table");
 }
 
@@ -1010,4 +1130,93 @@ extern "C" int dtc_foothold_rewards(const float* foot_positions, const float* op
     hipLaunchKernelGGL(foothold_rewards_kernel, dim3((unsigned)dtc::ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream,
                        foot_positions, opt_world, contact, tracking, miss, N);
     return dtc::check_launch("foothold_rewards");
+}
+
+// One env step's post-physics block as ONE launch (33 x 21 grid): [heights from the terrain table +] foothold plan + check_termination
+// + foothold rewards + compute_observations.  Any other grid: the separate launches, in the reference's order.
+extern "C" int dtc_env_post_physics(const DtcEnvStep* st, const DtcGridCfg* grid, const DtcObsCfg* oc, int N, void* stream) {
+    DTC_REQUIRE(st && grid && oc, "null descriptor");
+    GridParams gp;
+    int rc = make_params(grid, gp);
+    if (rc != DTC_OK) return rc;
+    DTC_REQUIRE(N >= 0, "N < 0");
+    if (N == 0) return DTC_OK;
+    const bool table = st->height_samples != nullptr;
+    DTC_REQUIRE(!table || (st->rows >= 2 && st->cols >= 2), "bad terrain table shape");
+    DTC_REQUIRE(st->root_states && st->thigh_pos && st->commands && st->measured_heights, "null planner input");
+    DTC_REQUIRE(st->idx && st->foothold_obs && st->opt_world && st->pred && st->pred_to_robot, "null planner output");
+    DTC_REQUIRE(st->contact_forces && st->episode_length_buf && st->projected_gravity && st->reset_buf, "null termination argument");
+    DTC_REQUIRE(st->n_term >= 0 && (st->n_term == 0 || st->termination_contact_indices), "bad termination index list");
+    DTC_REQUIRE(st->foot_positions && st->contact_filt && (st->rew_tracking || st->rew_miss), "null reward argument");
+    DTC_REQUIRE(st->base_ang_vel && st->dof_pos && st->default_dof_pos && st->dof_vel && st->actions && st->forces && st->obs_buf &&
+                st->privileged_obs_buf, "null observation argument");
+    DTC_REQUIRE(!st->u_obs || st->noise_scale_vec, "observation noise needs noise_scale_vec");
+    DTC_REQUIRE(oc->num_dof > 0 && oc->num_points == gp.P && oc->num_foothold_obs == 8 && st->ld_forces >= 3,
+                "observation config does not match the grid (num_points %d vs %d, 8 foothold observations)", oc->num_points, gp.P);
+    DTC_REQUIRE(oc->term_row0 >= 0 && oc->term_row1 > oc->term_row0 && oc->term_row1 <= oc->num_points, "bad height slice");
+    if (gp.nx != 33 || gp.ny != 21 || (table && (int64_t)st->rows * st->cols >= (1ll << 30)) || getenv("DTC_PLANNER_GENERIC")) {
+        rc = table ? dtc_foothold_plan_from_table(st->height_samples, st->rows, st->cols, st->border_size, st->horizontal_scale,
+                                                  st->vertical_scale, st->root_states, st->thigh_pos, st->commands, grid,
+                                                  st->measured_heights, st->idx, st->foothold_obs, st->opt_world, st->pred,
+                                                  st->pred_to_robot, N, stream)
+                   : dtc_foothold_plan(st->measured_heights, st->root_states, st->thigh_pos, st->commands, grid, st->idx, st->foothold_obs,
+                                       st->opt_world, st->pred, st->pred_to_robot, nullptr, nullptr, nullptr, nullptr, N, stream);
+        if (rc != DTC_OK) return rc;
+        rc = dtc_check_termination(st->contact_forces, st->num_bodies, st->termination_contact_indices, st->n_term, st->episode_length_buf,
+                                   st->max_episode_length, st->projected_gravity, st->root_states, st->measured_heights, oc, st->reset_buf,
+                                   st->time_out_buf, st->height_mean, N, stream);
+        if (rc != DTC_OK) return rc;
+        rc = dtc_foothold_rewards(st->foot_positions, st->opt_world, st->contact_filt, st->rew_tracking, st->rew_miss, N, stream);
+        if (rc != DTC_OK) return rc;
+        return dtc_compute_observations(st->base_ang_vel, st->projected_gravity, st->commands, st->dof_pos, st->default_dof_pos, st->dof_vel,
+                                        st->actions, st->foothold_obs, st->root_states, st->measured_heights, st->forces, st->ld_forces,
+                                        st->height_noise_offset, st->u_obs, st->noise_scale_vec, st->u_heights, oc, st->obs_buf,
+                                        st->privileged_obs_buf, st->heights, N, stream);
+    }
+    DTC_REQUIRE(N <= 40000000, "N too large for the 32-bit buffer offsets of the planner");
+    hipStream_t s = (hipStream_t)stream;
+    StepArgs sa{};
+    sa.contact_forces = st->contact_forces;
+    sa.term_idx = st->termination_contact_indices;
+    sa.episode_length = (const long long*)st->episode_length_buf;
+    sa.gravity = st->projected_gravity;
+    sa.reset_buf = st->reset_buf;
+    sa.time_out_buf = st->time_out_buf;
+    sa.height_mean = st->height_mean;
+    sa.max_episode_length = (long long)st->max_episode_length;
+    sa.num_bodies = st->num_bodies;
+    sa.n_term = st->n_term;
+    sa.foot_positions = st->foot_positions;
+    sa.contact_filt = st->contact_filt;
+    sa.rew_tracking = st->rew_tracking;
+    sa.rew_miss = st->rew_miss;
+    sa.ang_vel = st->base_ang_vel;
+    sa.dof_pos = st->dof_pos;
+    sa.default_dof_pos = st->default_dof_pos;
+    sa.dof_vel = st->dof_vel;
+    sa.actions = st->actions;
+    sa.forces = st->forces;
+    sa.noise_offset = st->height_noise_offset;
+    sa.u_obs = st->u_obs;
+    sa.noise_scale = st->noise_scale_vec;
+    sa.u_heights = st->u_heights;
+    sa.ld_forces = (long long)st->ld_forces;
+    sa.obs = st->obs_buf;
+    sa.priv = st->privileged_obs_buf;
+    sa.heights = st->heights;
+    sa.cfg = *oc;
+    // bytes: the planner's 3096 B/env + what the three other kernels move that the row in LDS does not already cover
+    const double bytes = (double)N * (gp.P * 4.0 * (1 + 3 + (st->u_heights ? 1 : 0) + (st->height_noise_offset ? 1 : 0)) + 13 * 4 + 16 + 48 +
+                                      208 + 53 * 4.0 * 3 + st->n_term * 12.0 + 64);
+    dtc::ProfScope prof("env_post_physics", bytes, s);
+    const TableParams tp{st->height_samples, st->rows, st->cols, st->border_size, st->horizontal_scale, st->vertical_scale};
+    const dim3 g((unsigned)dtc::ceil_div((int64_t)N, FAST_ENVS_PER_BLOCK));
+    if (table)
+        hipLaunchKernelGGL((foothold_plan_fast_kernel<33, 21, true, true>), g, dim3(256), 0, s, st->measured_heights, st->root_states,
+                           st->thigh_pos, st->commands, gp, tp, st->idx, st->foothold_obs, st->opt_world, st->pred, st->pred_to_robot, N, sa);
+    else
+        hipLaunchKernelGGL((foothold_plan_fast_kernel<33, 21, false, true>), g, dim3(256), 0, s, st->measured_heights, st->root_states,
+                           st->thigh_pos, st->commands, gp, TableParams{}, st->idx, st->foothold_obs, st->opt_world, st->pred,
+                           st->pred_to_robot, N, sa);
+    return dtc::check_launch("env_post_physics");
 }

@@ -78,6 +78,21 @@ class DtcObsCfg(C.Structure):
                 ("term_row0", C.c_int32), ("term_row1", C.c_int32)]
 
 
+class DtcEnvStep(C.Structure):
+    """include/dtc_hip.h: the buffers of one env step's post-physics block (dtc_env_post_physics); field order as there."""
+    _fields_ = ([("height_samples", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("border_size", C.c_float),
+                 ("horizontal_scale", C.c_float), ("vertical_scale", C.c_float)] +
+                [(k, C.c_void_p) for k in ("root_states", "thigh_pos", "commands", "measured_heights", "idx", "foothold_obs", "opt_world",
+                                           "pred", "pred_to_robot", "contact_forces", "termination_contact_indices", "episode_length_buf",
+                                           "projected_gravity")] +
+                [("max_episode_length", C.c_int64), ("num_bodies", C.c_int32), ("n_term", C.c_int32)] +
+                [(k, C.c_void_p) for k in ("reset_buf", "time_out_buf", "height_mean", "foot_positions", "contact_filt", "rew_tracking",
+                                           "rew_miss", "base_ang_vel", "dof_pos", "default_dof_pos", "dof_vel", "actions", "forces")] +
+                [("ld_forces", C.c_int64)] +
+                [(k, C.c_void_p) for k in ("height_noise_offset", "u_obs", "noise_scale_vec", "u_heights", "obs_buf", "privileged_obs_buf",
+                                           "heights")])
+
+
 class DtcRowCopy(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_stride_bytes", C.c_int64), ("width_bytes", C.c_int32)]
 
@@ -90,7 +105,7 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 11         # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 12         # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
@@ -106,6 +121,9 @@ _SIGS = {
                                      [C.c_int, c_stream]),
     "dtc_compute_observations": (C.c_int, [c_f32p] * 11 + [C.c_int64] + [c_f32p] * 4 + [C.POINTER(DtcObsCfg)] +
                                  [c_f32p] * 3 + [C.c_int, c_stream]),
+    "dtc_compute_observations_where": (C.c_int, [c_f32p] * 11 + [C.c_int64] + [c_f32p] * 4 + [C.POINTER(DtcObsCfg)] +
+                                       [c_f32p] * 3 + [c_u8p, C.c_int, c_stream]),
+    "dtc_env_post_physics": (C.c_int, [C.POINTER(DtcEnvStep), C.POINTER(DtcGridCfg), C.POINTER(DtcObsCfg), C.c_int, c_stream]),
     "dtc_check_termination": (C.c_int, [c_f32p, C.c_int, c_i32p, C.c_int, c_i64p, C.c_int64, c_f32p, c_f32p, c_f32p,
                                         C.POINTER(DtcObsCfg), c_u8p, c_u8p, c_f32p, C.c_int, c_stream]),
     "dtc_store_transition": (C.c_int, [C.POINTER(DtcRowCopy), C.c_int, c_f32p, c_f32p, c_u8p, C.c_float, c_f32p,
@@ -249,7 +267,7 @@ def _check_abi(l):
     (DTC_LIB may point at a separately built library, e.g. the ASan build: a stale one would misread every descriptor)."""
     global _lib
     mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcH2iWJob,
-            DtcH2iOperand, DtcWgradH2iJob]
+            DtcH2iOperand, DtcWgradH2iJob, DtcEnvStep]
     sizes = (C.c_int64 * 16)()
     n = l.dtc_abi_sizes(sizes, 16)
     theirs = list(sizes[:n])

@@ -172,26 +172,37 @@ class ObsConfig:
 
 def compute_observations(base_ang_vel, projected_gravity, commands, dof_pos, default_dof_pos, dof_vel, actions,
                          foothold_obs, root_states, measured_heights, forces, height_noise_offset=None, u_obs=None,
-                         noise_scale_vec=None, u_heights=None, cfg: ObsConfig | None = None):
+                         noise_scale_vec=None, u_heights=None, cfg: ObsConfig | None = None, where=None, out=None):
     """LeggedRobotDTC.compute_observations (legged_robot_dtc.py:255-288) as one kernel.  `forces` is the env's
     [N, num_bodies, 3] force buffer (body 0 is used); `u_obs` / `u_heights` are the uniform [0,1) draws the reference
-    takes with torch.rand_like (pass None to omit the noise term).  Returns dict(obs_buf, privileged_obs_buf, heights)."""
+    takes with torch.rand_like (pass None to omit the noise term).  Returns dict(obs_buf, privileged_obs_buf, heights).
+    `where` ([N] bool / uint8) + `out` (the dict a previous call or `EnvStep` returned): only the rows with where != 0 are
+    recomputed, in place -- the pass after `reset_idx` when `EnvStep` has written the rows of the envs that were not reset."""
     cfg = cfg or ObsConfig()
     N, dev, P = root_states.shape[0], root_states.device, cfg.num_points
     n_obs = 9 + 3 * cfg.num_dof + cfg.num_foothold_obs
-    obs = torch.empty(N, n_obs, device=dev)
-    priv = torch.empty(N, 2 * P + 3, device=dev)
-    heights = torch.empty(N, P, device=dev)
+    if where is not None and out is None:
+        raise ValueError("compute_observations(where=...) updates rows in place: pass the buffers as out=")
+    if out is not None:
+        obs, priv, heights = out["obs_buf"], out["privileged_obs_buf"], out["heights"]
+        if obs.shape != (N, n_obs) or priv.shape != (N, 2 * P + 3) or heights.shape != (N, P) or not (
+                obs.is_contiguous() and priv.is_contiguous() and heights.is_contiguous()):
+            raise ValueError("out= buffers do not match the observation shapes")
+    else:
+        obs = torch.empty(N, n_obs, device=dev)
+        priv = torch.empty(N, 2 * P + 3, device=dev)
+        heights = torch.empty(N, P, device=dev)
+    wh = where.to(torch.uint8).contiguous() if where is not None else None
     forces = forces.contiguous().float()
     ld_f = forces.stride(0) if forces.dim() > 1 else 3          # floats between consecutive envs (num_bodies * 3)
     keep = [t.contiguous().float() if t is not None else None for t in
             (base_ang_vel, projected_gravity, commands, dof_pos, default_dof_pos.reshape(-1), dof_vel, actions, foothold_obs,
              root_states, measured_heights)]
     opt = [t.contiguous().float() if t is not None else None for t in (height_noise_offset, u_obs, noise_scale_vec, u_heights)]
-    rc = _ffi.lib().dtc_compute_observations(*[_ffi.ptr(t) for t in keep], _ffi.ptr(forces), ld_f, _ffi.ptr(opt[0]),
-                                             _ffi.ptr(opt[1]), _ffi.ptr(opt[2]), _ffi.ptr(opt[3]), cfg.c_struct(),
-                                             _ffi.ptr(obs), _ffi.ptr(priv), _ffi.ptr(heights), N, _ffi.stream())
-    _ffi.check(rc, "dtc_compute_observations")
+    rc = _ffi.lib().dtc_compute_observations_where(*[_ffi.ptr(t) for t in keep], _ffi.ptr(forces), ld_f, _ffi.ptr(opt[0]),
+                                                   _ffi.ptr(opt[1]), _ffi.ptr(opt[2]), _ffi.ptr(opt[3]), cfg.c_struct(),
+                                                   _ffi.ptr(obs), _ffi.ptr(priv), _ffi.ptr(heights), _ffi.ptr(wh), N, _ffi.stream())
+    _ffi.check(rc, "dtc_compute_observations_where")
     return dict(obs_buf=obs, privileged_obs_buf=priv, heights=heights)
 
 
@@ -212,6 +223,87 @@ def check_termination(contact_forces, termination_contact_indices, episode_lengt
                                           _ffi.ptr(reset), _ffi.ptr(tout), _ffi.ptr(mean), N, _ffi.stream())
     _ffi.check(rc, "dtc_check_termination")
     return reset.bool(), tout.bool(), mean
+
+
+class EnvStep:
+    """One env step's post-physics block as ONE launch (`dtc_env_post_physics`; BASELINE configs[3] -- 4096 envs, where each of the
+    separate calls is launch-bound): [`_get_heights`] + the foothold block (legged_robot_dtc.py:98-201) + `check_termination`
+    (:229-248) + the two foothold rewards (:577-586, :536-539) + `compute_observations` (:255-288), on persistent output buffers.
+    Same bits as `plan[_from_table]` + `check_termination` + `rewards` + `compute_observations` (tests/test_hip_envstep.py).
+
+    The reference resets envs between the rewards and the observations (`reset_idx`, :209-211): the observation rows returned are
+    those of the state passed in; after resetting, call `compute_observations(..., where=reset_buf, out=<this result>)`."""
+
+    def __init__(self, num_envs: int, device, grid: GridConfig | None = None, cfg: ObsConfig | None = None):
+        self.N, self.device = num_envs, torch.device(device)
+        self.grid, self.cfg = grid or GridConfig(), cfg or ObsConfig()
+        N, P, f = num_envs, self.grid.num_points, dict(dtype=torch.float32, device=self.device)
+        n_obs = 9 + 3 * self.cfg.num_dof + self.cfg.num_foothold_obs
+        u8 = dict(dtype=torch.uint8, device=self.device)
+        self.out = dict(measured_heights=torch.empty(N, P, **f), optimal_foothold_indice=torch.empty(N, 1, 4, dtype=torch.int64, device=self.device),
+                        foothold_obs=torch.empty(N, 8, **f), optimal_footholds_world=torch.empty(N, 4, 3, **f),
+                        pred_footholds=torch.empty(N, 4, 3, **f), pred_footholds_to_robot=torch.empty(N, 4, 3, **f),
+                        reset_buf=torch.empty(N, **u8), time_out_buf=torch.empty(N, **u8), height_mean=torch.empty(N, **f),
+                        rew_tracking_optimal_footholds=torch.empty(N, **f), rew_foothold_miss=torch.empty(N, **f),
+                        obs_buf=torch.empty(N, n_obs, **f), privileged_obs_buf=torch.empty(N, 2 * P + 3, **f), heights=torch.empty(N, P, **f))
+        self._grid_c, self._cfg_c = self.grid.c_struct(), self.cfg.c_struct()
+
+    def __call__(self, *, root_states, thigh_pos, commands, contact_forces, termination_contact_indices, episode_length_buf,
+                 max_episode_length, projected_gravity, foot_positions, contact_filt, base_ang_vel, dof_pos, default_dof_pos, dof_vel,
+                 actions, forces, measured_heights=None, height_samples=None, border_size=20.0, horizontal_scale=0.05,
+                 vertical_scale=0.005, height_noise_offset=None, u_obs=None, noise_scale_vec=None, u_heights=None) -> dict:
+        N, o = self.N, self.out
+        if (measured_heights is None) == (height_samples is None):
+            raise ValueError("EnvStep: pass exactly one of measured_heights (an input) and height_samples (the terrain table)")
+        f32 = lambda t: t.contiguous().float()            # noqa: E731  (no copies for the env's own fp32 buffers)
+        rs, th = f32(root_states), f32(thigh_pos)
+        cmd = f32(commands[:, :4]) if commands.shape[1] >= 4 else torch.nn.functional.pad(commands.float(), (0, 4 - commands.shape[1]))
+        if rs.shape != (N, 13) or th.shape != (N, 4, 3) or cmd.shape[0] != N:
+            raise ValueError("bad input shapes")
+        cf, fr = f32(contact_forces), f32(forces)
+        keep = [rs, th, cmd, cf, fr]
+        st = _ffi.DtcEnvStep()
+        if height_samples is not None:
+            assert height_samples.dtype == torch.int16 and height_samples.dim() == 2
+            hs = height_samples.contiguous()
+            keep.append(hs)
+            st.height_samples, st.rows, st.cols = _ffi.ptr(hs), hs.shape[0], hs.shape[1]
+            st.border_size, st.horizontal_scale, st.vertical_scale = border_size, horizontal_scale, vertical_scale
+            mh = o["measured_heights"]
+        else:
+            mh = f32(measured_heights)
+            if mh.shape != (N, self.grid.num_points):
+                raise ValueError(f"measured_heights must be ({N}, {self.grid.num_points})")
+            keep.append(mh)
+        # the index list is static in an env: converted once per tensor object (the conversion is a launch of its own)
+        key = (id(termination_contact_indices), termination_contact_indices._version)
+        if getattr(self, "_tidx_key", None) != key:
+            self._tidx_key, self._tidx = key, termination_contact_indices.to(device=self.device, dtype=torch.int32).contiguous()
+            self._tidx_src = termination_contact_indices          # keeps id() unique while cached
+        tidx = self._tidx
+        ep = episode_length_buf.to(torch.int64).contiguous()
+        cflt = contact_filt.contiguous()
+        cflt = cflt.view(torch.uint8) if cflt.dtype == torch.bool else cflt.to(torch.uint8)      # bool is one byte of 0 / 1: no copy
+        named = dict(root_states=rs, thigh_pos=th, commands=cmd, measured_heights=mh, idx=o["optimal_foothold_indice"],
+                     foothold_obs=o["foothold_obs"], opt_world=o["optimal_footholds_world"], pred=o["pred_footholds"],
+                     pred_to_robot=o["pred_footholds_to_robot"], contact_forces=cf, termination_contact_indices=tidx,
+                     episode_length_buf=ep, projected_gravity=f32(projected_gravity), reset_buf=o["reset_buf"],
+                     time_out_buf=o["time_out_buf"], height_mean=o["height_mean"], foot_positions=f32(foot_positions), contact_filt=cflt,
+                     rew_tracking=o["rew_tracking_optimal_footholds"], rew_miss=o["rew_foothold_miss"], base_ang_vel=f32(base_ang_vel),
+                     dof_pos=f32(dof_pos), default_dof_pos=f32(default_dof_pos.reshape(-1)), dof_vel=f32(dof_vel), actions=f32(actions),
+                     forces=fr, height_noise_offset=None if height_noise_offset is None else f32(height_noise_offset),
+                     u_obs=None if u_obs is None else f32(u_obs), noise_scale_vec=None if noise_scale_vec is None else f32(noise_scale_vec),
+                     u_heights=None if u_heights is None else f32(u_heights), obs_buf=o["obs_buf"],
+                     privileged_obs_buf=o["privileged_obs_buf"], heights=o["heights"])
+        for k, t in named.items():
+            setattr(st, k, _ffi.ptr(t))
+        st.max_episode_length, st.num_bodies, st.n_term = int(max_episode_length), cf.shape[1], tidx.numel()
+        st.ld_forces = fr.stride(0) if fr.dim() > 1 else 3
+        rc = _ffi.lib().dtc_env_post_physics(st, self._grid_c, self._cfg_c, N, _ffi.stream())
+        _ffi.check(rc, "dtc_env_post_physics")
+        res = dict(o)
+        res["measured_heights"] = mh
+        return res
 
 
 def patch_env(env, grid: GridConfig | None = None):

@@ -38,10 +38,10 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-#define DTC_ABI_VERSION 11                   /* bumped whenever a signature or a by-value struct layout changes       */
+#define DTC_ABI_VERSION 12                   /* bumped whenever a signature or a by-value struct layout changes       */
 int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
 /* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
-   DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcH2iWJob, DtcH2iOperand, DtcWgradH2iJob: the binding compares them with its own layouts at load time (a library
+   DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcH2iWJob, DtcH2iOperand, DtcWgradH2iJob, DtcEnvStep: the binding compares them with its own layouts at load time (a library
    built from another revision -- e.g. a stale DTC_LIB override -- must not receive descriptors it would misread).
    Returns the number of entries (written up to `cap`). */
 int dtc_abi_sizes(int64_t* out, int cap);
@@ -126,6 +126,57 @@ int dtc_check_termination(const float* contact_forces, int num_bodies, const int
                           const float* projected_gravity /*[N,3]*/, const float* root_states /*[N,13]*/,
                           const float* measured_heights /*[N,P]*/, const DtcObsCfg* cfg, uint8_t* reset_buf,
                           uint8_t* time_out_buf /*or NULL*/, float* height_mean_or_null, int N, void* stream);
+
+/* Same as dtc_compute_observations for the rows with where[n] != 0 only (the other rows of the three outputs are left untouched):
+ * the observation pass AFTER `reset_idx` (legged_robot_dtc.py:209-211) when dtc_env_post_physics has already written the rows
+ * of the envs that were not reset.  where == NULL: all rows. */
+int dtc_compute_observations_where(const float* base_ang_vel, const float* projected_gravity, const float* commands,
+                                   const float* dof_pos, const float* default_dof_pos, const float* dof_vel,
+                                   const float* actions, const float* foothold_obs, const float* root_states,
+                                   const float* measured_heights, const float* forces, int64_t ld_forces,
+                                   const float* height_noise_offset, const float* u_obs, const float* noise_scale_vec,
+                                   const float* u_heights, const DtcObsCfg* cfg, float* obs_buf, float* privileged_obs_buf,
+                                   float* heights, const uint8_t* where, int N, void* stream);
+
+/* ---- one env step's post-physics block as ONE launch (BASELINE configs[3]: 4096 envs, launch-bound) -----------------------
+ * LeggedRobotDTC.post_physics_step, legged_gym/envs/base/legged_robot_dtc.py:98-211, on the env's own buffers:
+ *   [measured_heights = _get_heights() (legged_robot.py:1279-1317) when height_samples != NULL]
+ *   foothold block :98-201  ->  check_termination :229-248  ->  foothold rewards :577-586 / :536-539  ->  compute_observations :255-288
+ * = dtc_foothold_plan[_from_table] + dtc_check_termination + dtc_foothold_rewards + dtc_compute_observations with the same
+ * arguments, same bits, one launch (each env's height row is read once and stays in LDS for all four).  The reference resets
+ * envs (`reset_idx`, simulator state) BETWEEN the rewards and the observations: the observation rows written here are those of
+ * the state passed in; after resetting, refresh the rows of the reset envs with dtc_compute_observations_where(..., where =
+ * reset_buf).  All pointers are device pointers; optional ones may be NULL where the separate entry points allow it.
+ * Grids other than 33 x 21 run the separate launches in that order.  `st`, `grid`, `obs` are HOST pointers. */
+typedef struct DtcEnvStep {
+    /* planner */
+    const int16_t* height_samples;   /* terrain table [rows, cols] or NULL (then measured_heights is an input) */
+    int rows, cols;
+    float border_size, horizontal_scale, vertical_scale;
+    const float *root_states, *thigh_pos, *commands;
+    float* measured_heights;         /* [N,P]: written when height_samples != NULL, read otherwise */
+    int64_t* idx;
+    float *foothold_obs, *opt_world, *pred, *pred_to_robot;
+    /* check_termination */
+    const float* contact_forces;
+    const int32_t* termination_contact_indices;
+    const int64_t* episode_length_buf;
+    const float* projected_gravity;
+    int64_t max_episode_length;
+    int num_bodies, n_term;
+    uint8_t *reset_buf, *time_out_buf;
+    float* height_mean;
+    /* rewards */
+    const float* foot_positions;
+    const uint8_t* contact_filt;
+    float *rew_tracking, *rew_miss;
+    /* compute_observations (commands, root_states, projected_gravity, foothold_obs, measured_heights: the ones above) */
+    const float *base_ang_vel, *dof_pos, *default_dof_pos, *dof_vel, *actions, *forces;
+    int64_t ld_forces;
+    const float *height_noise_offset, *u_obs, *noise_scale_vec, *u_heights;
+    float *obs_buf, *privileged_obs_buf, *heights;
+} DtcEnvStep;
+int dtc_env_post_physics(const DtcEnvStep* st, const DtcGridCfg* grid, const DtcObsCfg* obs, int N, void* stream);
 
 /* ---- rollout-side store (row f2) ---------------------------------------------------------
  * RolloutStorage.add_transitions, rsl_rl/rsl_rl/storage/rollout_storage.py:99-116: the 13 `copy_` of one env step as
