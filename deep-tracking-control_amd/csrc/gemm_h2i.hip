@@ -488,7 +488,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
             const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
-            if (wmask && full) {                            // sign record of a ReLU layer (see linear_fwd_kernel)
+            if (wmask && col < N) {                         // sign record of a ReLU layer (see linear_fwd_kernel); M % 128 == 0 (host)
                 unsigned bits = 0u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bits |= acc[i][j][r] > 0.f ? (1u << r) : 0u;
@@ -506,12 +506,13 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
             }
         }
     } else {
-        if (dg.rmask && full) {
+        if (dg.rmask) {                                     // M % 128 == 0 (host); columns past the window read no record (results unused)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const unsigned bits = dg.rmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * dg.ldm + n0 + wn_off + 32 * j + l31];
+                const int mcol = n0 + wn_off + 32 * j + l31;
+                const unsigned bits = mcol < N ? dg.rmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * dg.ldm + mcol] : 0u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = (bits >> r) & 1u ? acc[i][j][r] : 0.f;
             }
@@ -901,7 +902,7 @@ int fwd_args(const DtcH2iOperand* X, const void* wimg, const float* b, float* Y,
     rc = to_operand(X, M, t.A, out.K);
     if (rc != DTC_OK) return rc;
     DTC_REQUIRE((long long)M * (ldy > N ? ldy : N) <= MAX_ELEMS * 4 && hi_bytes(M, N) < (1ll << 31), "matrix too large");
-    if (relu_mask) DTC_REQUIRE(act == DTC_ACT_RELU && M % BM == 0 && N % 128 == 0, "sign record: M=%d and N=%d must be multiples of 128", M, N);
+    if (relu_mask) DTC_REQUIRE(act == DTC_ACT_RELU && M % BM == 0 && (N % 128 == 0 || N == 64), "sign record: M=%d must be a multiple of 128, N=%d a multiple of 128 or 64", M, N);
     const WimgView wv = wimg_view(wimg, N, t.A);
     t.wimg = wv.img;
     t.wexps = wv.exps;
@@ -933,7 +934,7 @@ int dgrad_args(const void* dZimg, int N, const void* wimgT, int Kwin, const DtcS
     if (rc != DTC_OK) return rc;
     rc = check_img(wimgT, "data gradient: weight image");
     if (rc != DTC_OK) return rc;
-    if (relu_mask) DTC_REQUIRE(M % BM == 0 && Kwin % 128 == 0, "sign record: M=%d and the window %d must be multiples of 128", M, Kwin);
+    if (relu_mask) DTC_REQUIRE(M % BM == 0 && (Kwin % 128 == 0 || Kwin == 64), "sign record: M=%d must be a multiple of 128, the window %d a multiple of 128 or 64", M, Kwin);
     DTC_REQUIRE(hi_bytes(M, Kwin) < (1ll << 31), "matrix too large");
     DtcH2iOperand zo{};
     zo.nseg = 1;

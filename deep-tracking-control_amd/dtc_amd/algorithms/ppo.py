@@ -308,6 +308,9 @@ class PPO:
         # kernels read by LDS-DMA, per-row exponents, written once by the producing epilogue); DTC_H2I=0: round 4's converting kernels
         self.use_images = os.environ.get("DTC_H2I", "1") != "0"
         self.side2_wgrad = os.environ.get("DTC_WGRAD_SIDE2", "1") != "0"
+        # ... and the narrow CE-net stacks (128 / 64 / 35 / 53 columns) on them as well: same kernels (a column tile partly used), their
+        # weight gradients as extra jobs of the wide layers' grouped launches instead of single-pass groups of their own (DTC_H2I_NARROW=0)
+        self.narrow_images = os.environ.get("DTC_H2I_NARROW", "1") != "0"
         self._wsets = {}                   # phase -> h2i.WeightSet (weight images, one grouped launch per phase)
         # tests: callable(fw, which) run between the forward and the backward pass of a step ("vae" | "ppo"); the parity tests
         # use it to teacher-force the ReLU sign records (fw.relu_mask buffers) so that fp32 knife edges -- pre-activations that
@@ -566,8 +569,20 @@ class PPO:
         self._bwd(tw, L["te1"], g_te2, fw.t1, g_te1, fw.t1, "relu", fw.relu_mask("t1", 512, rm))
         self._bwd(tw, L["te0"], g_te1, segmat([seg(flat["privileged_observations"], 0, 693, gather=True)], idx))
 
-    def _cenet_encoder_backward(self, fw, tw, flat, idx, split=None):
+    def _cenet_encoder_backward(self, fw, tw, flat, idx, split=None, wset=None):
         L = self.actor_critic.L
+        if wset is not None and {"e1", "e"} <= fw.live_img:
+            # image chain: d mulv (written as fp32 by the latent kernel, 35 wide) is packed once; from there every gradient of the
+            # encoder exists as an image only, and its three weight gradients join the bucket's image-operand grouped launch
+            dmi = tw.img("dmulv", L["head"].n_out).pack(tw.dmulv)
+            g_headi, g_ce1i = tw.img("g_head", L["head"].n_in), tw.img("g_ce1", L["ce1"].n_in)
+            self._bwd_img(tw, L["head"], dmi, fw.img("e"))
+            h2i.linear_dgrad(dmi, L["head"].W, None, g_headi, wset=wset)
+            self._bwd_img(tw, L["ce1"], g_headi, fw.img("e1"))
+            h2i.linear_dgrad(g_headi, L["ce1"].W, None, g_ce1i, mask=fw.relu_mask("e1", L["ce0"].n_out, self.relu_masks), wset=wset)
+            self._bwd_img(tw, L["ce0"], g_ce1i, fw.cur["p_hist"])
+            tw.live_img |= {"g_head", "g_ce1"}
+            return
         g_head, g_ce1 = tw.g("head", 64), tw.g("ce1", 128)
         self._bwd(tw, L["head"], tw.dmulv, fw.e, g_head, None, None, split=split)
         self._bwd(tw, L["ce1"], g_head, fw.e1, g_ce1, fw.e1, "relu", fw.relu_mask("e1", 128, self.relu_masks), split=split)
@@ -619,14 +634,24 @@ class PPO:
         im = wset is not None                                      # operand-image chain for the 512-wide stacks
         ns = False if im else None                                 # ... beside it the narrow layers run on the single-pass fp32 kernels
         tw.live_img.clear()
-        with tw.lane("aux"):
-            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=rm, split=ns)
-        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=rm, images=im, wset=wset)
+        imn = im and self.narrow_images                            # ... unless they run on images too (their weight gradients then
+        with tw.lane("aux"):                                       # ride in the wide layers' grouped launches)
+            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=rm, split=ns, images=imn, wset=wset)
+        ac.terrain_encoder_(fw, flat["privileged_observations"], idx, masks=rm, images=im, wset=wset, lt_fp32=not imn)
         tw.order("main", "aux")                                    # l_t feeds the CE-net decoder
         with tw.lane("aux"):
-            ops.linear_fwd(dec_in, L["cd0"].W, L["cd0"].b, tw.c1, "relu", M=tw.B, mask=fw.relu_mask("c1", 64, rm), split=ns)
-            ops.linear_fwd(tw.c1, L["cd1"].W, L["cd1"].b, tw.c2, "relu", mask=fw.relu_mask("c2", 128, rm), split=ns)
-            ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None, split=ns)
+            if imn:
+                # decoder input = [z | mu[:, :3]] (packed, 19 wide) beside the l_t image; c1 / c2 leave as images only
+                p_d = ac.packed_input(fw, "p_d", segmat([seg(fw.z, 0, 16), seg(fw.mulv, 0, 3)]))
+                c1i, c2i = tw.img("c1", L["cd0"].n_out), tw.img("c2", L["cd1"].n_out)
+                h2i.linear_fwd([p_d, fw.img("lt")], L["cd0"].W, L["cd0"].b, None, c1i, "relu", mask=fw.relu_mask("c1", 64, rm), wset=wset)
+                h2i.linear_fwd(c1i, L["cd1"].W, L["cd1"].b, None, c2i, "relu", mask=fw.relu_mask("c2", 128, rm), wset=wset)
+                h2i.linear_fwd(c2i, L["cd2"].W, L["cd2"].b, tw.rec, None, None, wset=wset)
+                tw.live_img |= {"c1", "c2"}
+            else:
+                ops.linear_fwd(dec_in, L["cd0"].W, L["cd0"].b, tw.c1, "relu", M=tw.B, mask=fw.relu_mask("c1", 64, rm), split=ns)
+                ops.linear_fwd(tw.c1, L["cd1"].W, L["cd1"].b, tw.c2, "relu", mask=fw.relu_mask("c2", 128, rm), split=ns)
+                ops.linear_fwd(tw.c2, L["cd2"].W, L["cd2"].b, tw.rec, None, split=ns)
         if im:                                                     # terrain decoder on images: d1 / d2 never exist as fp32
             d1i, d2i = tw.img("d1", L["td0"].n_out), tw.img("d2", L["td1"].n_out)
             h2i.linear_fwd(fw.img("lt"), L["td0"].W, L["td0"].b, None, d1i, "relu", mask=fw.relu_mask("d1", 512, rm), wset=wset)
@@ -666,9 +691,21 @@ class PPO:
         g_cd2, g_cd1 = tw.g("cd2", 128), tw.g("cd1", 64)
         dst = segmat([seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3, accumulate=True), seg(tw.dlt, 0, 512)])
         with tw.lane("aux"):
-            self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu", fw.relu_mask("c2", 128, rm), split=ns)
-            self._bwd(tw, L["cd1"], g_cd2, tw.c1, g_cd1, tw.c1, "relu", fw.relu_mask("c1", 64, rm), split=ns)
-            self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None, split=ns)
+            if imn:
+                g_reci = tw.img("g_rec", L["cd2"].n_out).pack(tw.g_rec)
+                g_cd2i, g_cd1i = tw.img("g_cd2", L["cd2"].n_in), tw.img("g_cd1", L["cd1"].n_in)
+                self._bwd_img(tw, L["cd2"], g_reci, tw.img("c2"))
+                h2i.linear_dgrad(g_reci, L["cd2"].W, None, g_cd2i, mask=fw.relu_mask("c2", 128, rm), wset=wset)
+                self._bwd_img(tw, L["cd1"], g_cd2i, tw.img("c1"))
+                h2i.linear_dgrad(g_cd2i, L["cd1"].W, None, g_cd1i, mask=fw.relu_mask("c1", 64, rm), wset=wset)
+                self._bwd_img(tw, L["cd0"], g_cd1i, fw.img("lt"), wcol0=19)          # columns of dW that meet l_t ...
+                self._bwd_img(tw, L["cd0"], g_cd1i, fw.cur["p_d"], wcol0=0, bias=False)      # ... and [z | mu[:, :3]]
+                h2i.linear_dgrad(g_cd1i, L["cd0"].W, dst, None, wset=wset)
+                tw.live_img |= {"g_cd2", "g_cd1"}
+            else:
+                self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu", fw.relu_mask("c2", 128, rm), split=ns)
+                self._bwd(tw, L["cd1"], g_cd2, tw.c1, g_cd1, tw.c1, "relu", fw.relu_mask("c1", 64, rm), split=ns)
+                self._bwd(tw, L["cd0"], g_cd1, dec_in, dst, None, None, split=ns)
         # terrain decoder (main)
         if im:
             g_td2i, g_td1i = tw.img("g_td2", L["td2"].n_in), tw.img("g_td1", L["td1"].n_in)
@@ -691,7 +728,7 @@ class PPO:
         self._terrain_encoder_backward(fw, tw, flat, idx, wset)
         with tw.lane("aux"):
             ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
-            self._cenet_encoder_backward(fw, tw, flat, idx, split=ns)
+            self._cenet_encoder_backward(fw, tw, flat, idx, split=ns, wset=wset if imn else None)
         if early:
             self._exchange_bucket(tw, "shared")
         self._join(tw)
@@ -721,8 +758,9 @@ class PPO:
         ns = False if im else None
         tw.live_img.clear()
         obs, priv = flat["observations"], flat["privileged_observations"]
+        imn = im and self.narrow_images
         with tw.lane("aux"):
-            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=self.relu_masks, split=ns)
+            ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=self.relu_masks, split=ns, images=imn, wset=wset)
         ac.terrain_encoder_(fw, priv, idx, masks=self.relu_masks, images=im, wset=wset, lt_fp32=not im)
         tw.order("aux", "main")                                    # z, mu feed the actor
         # output layers + losses + their data gradients in one launch when the last hidden width allows it (DTC_FUSE_HEADS)
@@ -784,7 +822,7 @@ class PPO:
         self._terrain_encoder_backward(fw, tw, flat, idx, wset)    # needs d l_t only: starts right away on main
         with tw.lane("aux"):
             ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
-            self._cenet_encoder_backward(fw, tw, flat, idx, split=ns)
+            self._cenet_encoder_backward(fw, tw, flat, idx, split=ns, wset=wset if imn else None)
         if early:
             self._exchange_bucket(tw, "shared")
         self._join(tw)

@@ -352,14 +352,26 @@ class ActorCriticDecoder(nn.Module):
         return ch
 
     # ------------------------------------------------------------------ kernel-level forward pieces
-    def cenet_forward_(self, ws, hist, eps, idx=None, masks=False, split=None):
+    def cenet_forward_(self, ws, hist, eps, idx=None, masks=False, split=None, images=False, wset=None):
         """vae.cenet_forward (actor_critic_decoder.py:286-302) into ws.mulv / ws.z.  `masks`: training step -- the ReLU
-        layers also record their output signs (ws.relu_mask) for the backward pass.  `split=False`: single-pass fp32 kernels."""
+        layers also record their output signs (ws.relu_mask) for the backward pass.  `split=False`: single-pass fp32 kernels.
+        `images` (training step, see images_ok): the gathered history rows are packed into an operand image once per mini-batch and
+        update, e1 / e leave as images only (ws.live_img) -- their consumers (next layer, weight gradient) read images --, the heads'
+        output as fp32 for the latent kernel."""
         L = self.L
         X = segmat([seg(hist, 0, hist.shape[1], gather=idx is not None)], idx)
-        ops.linear_fwd(X, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=ws.B, mask=ws.relu_mask("e1", 128, masks), split=split)
-        ops.linear_fwd(ws.e1, L["ce1"].W, L["ce1"].b, ws.e, None, split=split)
-        ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None, split=split)
+        if images and masks:
+            pin = self.packed_input(ws, "p_hist", X, idx, reuse=True)
+            e1i, ei = ws.img("e1", L["ce0"].n_out), ws.img("e", L["ce1"].n_out)
+            h2i.linear_fwd(pin, L["ce0"].W, L["ce0"].b, None, e1i, "relu", mask=ws.relu_mask("e1", L["ce0"].n_out, masks), wset=wset)
+            h2i.linear_fwd(e1i, L["ce1"].W, L["ce1"].b, None, ei, None, wset=wset)
+            h2i.linear_fwd(ei, L["head"].W, L["head"].b, ws.mulv, None, None, wset=wset)
+            ws.live_img |= {"e1", "e"}
+        else:
+            ws.live_img -= {"e1", "e"}
+            ops.linear_fwd(X, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=ws.B, mask=ws.relu_mask("e1", 128, masks), split=split)
+            ops.linear_fwd(ws.e1, L["ce1"].W, L["ce1"].b, ws.e, None, split=split)
+            ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None, split=split)
         ops.cenet_latent_fwd(ws.mulv, eps, ws.z, ws.mask, ws.info, ws.lat_ws)
 
     def images_ok(self, ws):

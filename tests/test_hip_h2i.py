@@ -70,7 +70,8 @@ def test_pack_gathered_segments():
 
 
 @pytest.mark.parametrize("M,N,K,act", [(1024, 512, 512, "relu"), (384, 512, 693, "relu"), (300, 693, 512, None), (1000, 256, 512, "elu"),
-                                       (4096, 512, 752, "elu"), (130, 128, 265, "relu"), (200, 140, 70, "elu"), (24576, 512, 512, "relu")])
+                                       (4096, 512, 752, "elu"), (130, 128, 265, "relu"), (200, 140, 70, "elu"), (24576, 512, 512, "relu"),
+                                       (1024, 64, 531, "relu"), (256, 128, 64, "relu"), (384, 53, 128, None), (512, 35, 64, None), (640, 64, 128, None)])
 def test_forward_per_row_accuracy_and_image_result(M, N, K, act):
     from dtc_amd import h2i, ops
     g = torch.Generator().manual_seed(M + N + 3 * K)
@@ -81,11 +82,13 @@ def test_forward_per_row_accuracy_and_image_result(M, N, K, act):
     Xd, Wd, bd = X.to(DEV), W.to(DEV), b.to(DEV)
     Y = torch.full((M, N), float("nan"), device=DEV)
     Yimg = h2i.HImage(M, N, DEV)
-    mask = ops.relu_mask(M, N, DEV) if (act == "relu" and M % 128 == 0 and N % 128 == 0) else None
+    mask = ops.relu_mask(M, N, DEV) if (act == "relu" and ops.relu_mask_ok(M, N)) else None      # N % 128 == 0 or N == 64
     h2i.linear_fwd(h2i.HImage.from_tensor(Xd), Wd, bd, Y, Yimg, act, mask=mask)
     err = _row_err(Y, ref)
     print(f"fwd {M}x{N}x{K}: per-row err {err:.2e}")
     assert err < ROW_TOL
+    if mask is not None:                                   # the sign record = the signs of the result (ReLU output > 0)
+        assert torch.equal(h2i.unpack_sign_record(mask, M, N), Y > 0)
     dec = Yimg.to_tensor()
     blk = torch.zeros(M, -(-N // 128) * 128, device=DEV)
     blk[:, :N] = Y.abs()
@@ -129,7 +132,8 @@ def test_fused_mse_layer(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,mode", [(1024, 512, 512, "mask"), (640, 256, 512, "elu"), (300, 693, 512, "none"), (512, 512, 693, "none"),
-                                        (384, 128, 256, "elu"), (24576, 512, 512, "mask")])
+                                        (384, 128, 256, "elu"), (24576, 512, 512, "mask"), (1024, 128, 64, "mask"), (512, 53, 128, "mask"),
+                                        (640, 35, 64, "none"), (256, 64, 531, "none"), (384, 64, 128, "mask")])
 def test_dgrad_heavy_tailed_rows(M, N, K, mode):
     """dX = (dZ W) act'(.), dZ heavy-tailed: rows log-uniform over 1e-8 .. 1 of the largest, 30 % of the rows exactly zero
     (clipped PPO samples) -- every row to 1e-5 of ITSELF (measured ~3e-7)"""

@@ -77,9 +77,9 @@ def _relu_mask_mismatches(ref, alg, which):
     B = next(iter(ref.relu_masks.values())).shape[0]
     fw, tw = alg.actor_critic._fwd_ws(B), alg._train_ws(B)
     # (value(): the wide hidden activations may exist as activation images only -- decoded here)
-    mine = {"cenet_encoder.1": fw.e1, "terrain_encoder.1": fw.value("t1"), "terrain_encoder.3": fw.value("t2")}
+    mine = {"cenet_encoder.1": fw.value("e1"), "terrain_encoder.1": fw.value("t1"), "terrain_encoder.3": fw.value("t2")}
     if which == "vae":
-        mine.update({"cenet_decoder.1": tw.c1, "cenet_decoder.3": tw.c2, "terrain_decoder.1": tw.value("d1"),
+        mine.update({"cenet_decoder.1": tw.value("c1"), "cenet_decoder.3": tw.value("c2"), "terrain_decoder.1": tw.value("d1"),
                      "terrain_decoder.3": tw.value("d2")})
     return sum(int(((buf.cpu() > 0) != ref.relu_masks[name]).sum()) for name, buf in mine.items()), B
 
@@ -509,9 +509,9 @@ def _unforced_half(ref, alg, which, idx, eps_ref, e1, e2, rec, budget):
     alg.step_minibatch(idx, e1, e2, which=which)
     B = idx.numel()
     fw, tw = alg.actor_critic._fwd_ws(B), alg._train_ws(B)
-    mine = {"cenet_encoder.1": fw.e1, "terrain_encoder.1": fw.value("t1"), "terrain_encoder.3": fw.value("t2")}
+    mine = {"cenet_encoder.1": fw.value("e1"), "terrain_encoder.1": fw.value("t1"), "terrain_encoder.3": fw.value("t2")}
     if which == "vae":
-        mine.update({"cenet_decoder.1": tw.c1, "cenet_decoder.3": tw.c2, "terrain_decoder.1": tw.value("d1"), "terrain_decoder.3": tw.value("d2")})
+        mine.update({"cenet_decoder.1": tw.value("c1"), "cenet_decoder.3": tw.value("c2"), "terrain_decoder.1": tw.value("d1"), "terrain_decoder.3": tw.value("d2")})
     per_layer = {name: int(((buf.cpu() > 0) != ref.relu_masks[name]).sum()) for name, buf in mine.items()}
     decisions = sum(buf.numel() for buf in mine.values())
     n_relu = sum(per_layer.values())
