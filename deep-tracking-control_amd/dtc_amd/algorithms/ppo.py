@@ -123,9 +123,14 @@ class _Lanes:
     synchronisation primitive: everything launched so far on lane a happens before what lane b launches next."""
 
     def __init__(self, dev):
-        self.side = torch.cuda.Stream(device=dev)
-        self.side2 = torch.cuda.Stream(device=dev)      # image chain: the narrow layers' (latency-bound) weight-gradient group beside the wide one
-        self.aux = torch.cuda.Stream(device=dev)
+        # the second compute lane and the weight-gradient streams are high-priority HIP streams: their (short, latency-bound) kernels get
+        # the workgroup slots the main lane's 768-workgroup launches free up first -- 50.3 vs 50.9 ms per step, two interleaved rounds
+        # (tools/jobs/r5_prio.sh; "aux" alone 50.85, "side" alone 50.6).  DTC_LANE_PRIO=none: default priorities everywhere
+        prio = os.environ.get("DTC_LANE_PRIO", "aux,side")
+        hp = lambda name: dict(priority=-1) if name in prio.split(",") else {}      # noqa: E731
+        self.side = torch.cuda.Stream(device=dev, **hp("side"))
+        self.side2 = torch.cuda.Stream(device=dev, **hp("side"))     # image chain: the narrow layers' (latency-bound) weight-gradient group beside the wide one
+        self.aux = torch.cuda.Stream(device=dev, **hp("aux"))
         self.main = None                    # torch's current stream at the start of the step
         self.two_lanes = False
         self._events, self._ev_next = [], 0
