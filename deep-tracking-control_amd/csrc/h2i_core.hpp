@@ -61,4 +61,22 @@ __device__ __forceinline__ HiPiece hi_split8(const f32x4 (&v)[2], int e) {
     return r;
 }
 
+// ---- narrow rows written straight by the kernel that produces them (latent / loss kernels; K <= 128: one exponent per row): element
+// (row, col) of image(M, K) as two 2-byte stores, and the row's exponent.  Same values as h2i_pack_kernel writes for the same row
+// (x 2^e rounded to nearest-even fp16, remainder exact in fp32 then rounded); the buffer's padding columns stay as allocated (zero).
+__device__ __forceinline__ void hi_store_elem(void* img, int K, int row, int col, float x, int e) {
+    const float xs = __builtin_ldexpf(x, e == HI_EZERO ? 0 : e);
+    const _Float16 h = (_Float16)xs;
+    const _Float16 l = (_Float16)(xs - (float)h);
+    const int r = row & 127;
+    const long long off = ((long long)(row >> 7) * hi_stages(K) + (col >> 4)) * HI_CHUNK +
+                          (2 * r + (((col >> 3) & 1) ^ ((r >> 3) & 1))) * 16 + (col & 7) * 2;
+    *reinterpret_cast<_Float16*>(static_cast<char*>(img) + off) = h;
+    *reinterpret_cast<_Float16*>(static_cast<char*>(img) + off + HI_PLANE) = l;
+}
+__device__ __forceinline__ void hi_store_row_exp(void* img, long long M, int K, int row, int e) {
+    int* exps = reinterpret_cast<int*>(static_cast<char*>(img) + hi_data_bytes(M, K));
+    exps[(long long)(row >> 7) * hi_kblocks(K) * 128 + (row & 127)] = e;
+}
+
 }  // namespace

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "h2i_core.hpp"
 
 // The backward kernel's cross-workgroup hand-off (partial sums, the median element, the arrival ticket) uses RELAXED
 // agent-scope atomics + `s_waitcnt vmcnt(0)` instead of a release / acquire pair.  That is an architecture contract, not
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void lat_hist_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void lat_apply_kernel(float* __restrict__ mulv, const float* __restrict__ eps,
                                                         float* __restrict__ z, uint8_t* __restrict__ mask,
                                                         int* __restrict__ info, long long n, int nblk_stats, Ws* ws,
-                                                        amax_u32* __restrict__ z_amax) {
+                                                        amax_u32* __restrict__ z_amax, void* __restrict__ zmu_img) {
     __shared__ amax_u32 red_z[4];
     amax_u32 mz = 0u;                                  // largest |z| this thread writes (amax record, two-term fp16 GEMM path)
     __shared__ double shd[4];
@@ -218,6 +219,23 @@ __global__ __launch_bounds__(256) void lat_apply_kernel(float* __restrict__ mulv
         const float zv = eps[e] * expf(0.5f * x) + mulv[b * LD + 3 + j];
         z[e] = zv;
         mz = abs_bits(zv) > mz ? abs_bits(zv) : mz;
+        if (zmu_img) {
+            // operand image of [z | mu[:, :3]] (19 columns: the decoder's / the actor's narrow input block), written here instead of by
+            // a pack launch: the 16 lanes of a row (n and the stride are multiples of 16) agree on the row's exponent
+            const float mu3 = j < 3 ? mulv[b * LD + j] : 0.0f;
+            u32 mb = finite_bits(zv);
+            mb = finite_bits(mu3) > mb ? finite_bits(mu3) : mb;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                const u32 o = (u32)__shfl_xor((int)mb, off, 16);
+                mb = o > mb ? o : mb;
+            }
+            const int ex = hi_exp(mb);
+            const long long B = n >> 4;
+            hi_store_elem(zmu_img, MU, (int)b, j, zv, ex);
+            hi_store_elem(zmu_img, MU, (int)b, 16 + j, mu3, ex);          // columns 16..18 = mu[:, :3], 19..31 = padding (zero)
+            if (j == 0) hi_store_row_exp(zmu_img, B, MU, (int)b, ex);
+        }
     }
     amax_publish_block(z_amax, mz, red_z);
 #pragma unroll
@@ -310,7 +328,13 @@ extern "C" int64_t dtc_cenet_workspace(int B) {
 
 extern "C" int dtc_cenet_latent_fwd(float* mulv, const float* eps, float* z, uint8_t* mask, int32_t* info,
                                     void* workspace, int B, uint32_t* z_amax, void* stream) {
+    return dtc_cenet_latent_fwd_img(mulv, eps, z, mask, info, workspace, B, z_amax, nullptr, stream);
+}
+
+extern "C" int dtc_cenet_latent_fwd_img(float* mulv, const float* eps, float* z, uint8_t* mask, int32_t* info,
+                                        void* workspace, int B, uint32_t* z_amax, void* zmu_img, void* stream) {
     DTC_REQUIRE(B > 0 && (long long)B * LAT >= 2, "bad batch %d", B);
+    DTC_REQUIRE(dtc::aligned16(zmu_img), "unaligned image");
     DTC_REQUIRE(mulv && eps && z && mask && info && workspace, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     Ws* ws = (Ws*)workspace;
@@ -321,7 +345,7 @@ extern "C" int dtc_cenet_latent_fwd(float* mulv, const float* eps, float* z, uin
     hipLaunchKernelGGL(lat_hist_kernel<1>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
     hipLaunchKernelGGL(lat_hist_kernel<2>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
     hipLaunchKernelGGL(lat_hist_kernel<3>, dim3(g), dim3(256), 0, s, mulv, n, g, ws);
-    hipLaunchKernelGGL(lat_apply_kernel, dim3(g), dim3(256), 0, s, mulv, eps, z, mask, info, n, g, ws, (amax_u32*)z_amax);
+    hipLaunchKernelGGL(lat_apply_kernel, dim3(g), dim3(256), 0, s, mulv, eps, z, mask, info, n, g, ws, (amax_u32*)z_amax, zmu_img);
     return dtc::check_launch("cenet_latent_fwd");
 }
 

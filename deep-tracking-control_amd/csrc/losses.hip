@@ -12,6 +12,7 @@
 // All reductions: per-block partials in fp64 + a single-block finalize (deterministic order).
 #include "amax.hpp"
 #include "gemm_core.hpp"
+#include "h2i_core.hpp"
 
 namespace {
 
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
                                                        const long long* __restrict__ idx, float* __restrict__ d_recons,
                                                        float* __restrict__ d_hrecon, float* __restrict__ dmulv,
                                                        double* __restrict__ part, int B, int nb_h, int nb_r,
-                                                       amax_u32* __restrict__ drec_amax) {
+                                                       amax_u32* __restrict__ drec_amax, void* __restrict__ drec_img) {
     __shared__ double sh[4];
     __shared__ amax_u32 red_m[4];
     amax_u32 mrec = 0u;                                // largest |d_recons| this thread writes (amax record, two-term fp16 GEMM path)
@@ -68,11 +69,25 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
     } else if (blk < nb_h + nb_r) {
         const float scale = 2.0f / ((float)OBS * (float)B);
         for (int b = (blk - nb_h) * 4 + wv; b < B; b += nb_r * 4) {
+            float gv = 0.0f;
             if (lane < OBS) {
                 const float diff = recons[(long long)b * OBS + lane] - next_obs[idx[b] * OBS + lane];
                 acc0 += (double)diff * (double)diff;
-                d_recons[(long long)b * OBS + lane] = diff * scale;
-                mrec = abs_bits(diff * scale) > mrec ? abs_bits(diff * scale) : mrec;
+                gv = diff * scale;
+                d_recons[(long long)b * OBS + lane] = gv;
+                mrec = abs_bits(gv) > mrec ? abs_bits(gv) : mrec;
+            }
+            if (drec_img) {
+                // operand image of dL/d recons (53 columns) written here instead of by a pack launch: one row per wavefront
+                u32 mb = finite_bits(gv);
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const u32 o = (u32)__shfl_xor((int)mb, off, 64);
+                    mb = o > mb ? o : mb;
+                }
+                const int ex = hi_exp(mb);
+                hi_store_elem(drec_img, OBS, b, lane, gv, ex);            // lanes 53..63: the padding columns (zero)
+                if (lane == 0) hi_store_row_exp(drec_img, B, OBS, b, ex);
             }
         }
         slot0 = 0;
@@ -451,7 +466,7 @@ extern "C" int dtc_vae_loss(const float* recons, const float* hrecon, const floa
     double* part = (double*)workspace;
     dtc::ProfScope prof("vae_loss", (double)B * (HGT * 12.0 + OBS * 12.0 + LD * 8.0), s);
     hipLaunchKernelGGL(vae_loss_kernel, dim3(nblk), dim3(256), 0, s, recons, hrecon, mulv, next_obs, priv, base_vel,
-                       (const long long*)idx, d_recons, d_hrecon, dmulv, part, B, nb_h, nb_r, (amax_u32*)drec_amax);
+                       (const long long*)idx, d_recons, d_hrecon, dmulv, part, B, nb_h, nb_r, (amax_u32*)drec_amax, (void*)nullptr);
     hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, B, losses, (const double*)nullptr, 0);
     return dtc::check_launch("vae_loss");
 }
@@ -459,6 +474,15 @@ extern "C" int dtc_vae_loss(const float* recons, const float* hrecon, const floa
 extern "C" int dtc_vae_loss_fused(const float* recons, const float* mulv, const float* next_obs, const float* base_vel,
                                   const int64_t* idx, float* d_recons, float* dmulv, const double* height_sq_part,
                                   int n_height_part, float* losses, void* workspace, int B, uint32_t* drec_amax, void* stream) {
+    return dtc_vae_loss_fused_img(recons, mulv, next_obs, base_vel, idx, d_recons, dmulv, height_sq_part, n_height_part, losses, workspace, B,
+                                  drec_amax, nullptr, stream);
+}
+
+extern "C" int dtc_vae_loss_fused_img(const float* recons, const float* mulv, const float* next_obs, const float* base_vel,
+                                      const int64_t* idx, float* d_recons, float* dmulv, const double* height_sq_part,
+                                      int n_height_part, float* losses, void* workspace, int B, uint32_t* drec_amax, void* drec_img,
+                                      void* stream) {
+    DTC_REQUIRE(dtc::aligned16(drec_img), "unaligned image");
     DTC_REQUIRE(B > 0 && n_height_part >= 0, "bad batch %d", B);
     DTC_REQUIRE(recons && mulv && next_obs && base_vel && idx, "null input");
     DTC_REQUIRE(d_recons && dmulv && losses && workspace && (height_sq_part || n_height_part == 0), "null output");
@@ -472,7 +496,7 @@ extern "C" int dtc_vae_loss_fused(const float* recons, const float* mulv, const 
     dtc::ProfScope prof("vae_loss", (double)B * (OBS * 12.0 + LD * 8.0), s);
     hipLaunchKernelGGL(vae_loss_kernel, dim3(nblk), dim3(256), 0, s, recons, (const float*)nullptr, mulv, next_obs,
                        (const float*)nullptr, base_vel, (const long long*)idx, d_recons, (float*)nullptr, dmulv, part, B, 0, nb_r,
-                       (amax_u32*)drec_amax);
+                       (amax_u32*)drec_amax, drec_img);
     hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, B, losses, height_sq_part, n_height_part);
     return dtc::check_launch("vae_loss_fused");
 }

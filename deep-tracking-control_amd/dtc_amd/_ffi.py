@@ -203,6 +203,7 @@ _SIGS = {
     "dtc_wgrad_group_s3": (C.c_int, [C.POINTER(DtcWgradJob), C.c_int, C.c_int, C.c_void_p, c_stream]),
     "dtc_cenet_workspace": (C.c_int64, [C.c_int]),
     "dtc_cenet_latent_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int, C.c_void_p, c_stream]),
+    "dtc_cenet_latent_fwd_img": (C.c_int, [c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, c_stream]),
     "dtc_cenet_latent_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_i32p, C.c_void_p, C.c_int, C.c_void_p,
                                        c_stream]),
     "dtc_loss_workspace": (C.c_int64, [C.c_int]),
@@ -212,6 +213,8 @@ _SIGS = {
                                      C.c_float, c_f32p, C.c_int64, c_f64p, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_vae_loss_fused": (C.c_int, [c_f32p] * 4 + [c_i64p] + [c_f32p] * 2 + [c_f64p, C.c_int, c_f32p, C.c_void_p, C.c_int,
                                                                              C.c_void_p, c_stream]),
+    "dtc_vae_loss_fused_img": (C.c_int, [c_f32p] * 4 + [c_i64p] + [c_f32p] * 2 + [c_f64p, C.c_int, c_f32p, C.c_void_p, C.c_int,
+                                                                                 C.c_void_p, C.c_void_p, c_stream]),
     "dtc_ppo_loss": (C.c_int, [c_f32p] * 10 + [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 4 +
                      [c_f64p, C.c_void_p, C.c_int, C.c_int, c_stream]),
     "dtc_ppo_heads_loss": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int] + [c_f32p] * 4 + [C.c_int] + [c_f32p] * 8 +

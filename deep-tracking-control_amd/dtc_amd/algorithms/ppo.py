@@ -646,8 +646,8 @@ class PPO:
         tw.order("main", "aux")                                    # l_t feeds the CE-net decoder
         with tw.lane("aux"):
             if imn:
-                # decoder input = [z | mu[:, :3]] (packed, 19 wide) beside the l_t image; c1 / c2 leave as images only
-                p_d = ac.packed_input(fw, "p_d", segmat([seg(fw.z, 0, 16), seg(fw.mulv, 0, 3)]))
+                # decoder input = the [z | mu[:, :3]] image the latent kernel wrote (19 wide) beside the l_t image; c1 / c2 leave as images only
+                p_d = fw.cur["p_zmu"]
                 c1i, c2i = tw.img("c1", L["cd0"].n_out), tw.img("c2", L["cd1"].n_out)
                 h2i.linear_fwd([p_d, fw.img("lt")], L["cd0"].W, L["cd0"].b, None, c1i, "relu", mask=fw.relu_mask("c1", 64, rm), wset=wset)
                 h2i.linear_fwd(c1i, L["cd1"].W, L["cd1"].b, None, c2i, "relu", mask=fw.relu_mask("c2", 128, rm), wset=wset)
@@ -682,7 +682,8 @@ class PPO:
             tw.order("main", "aux")
             with tw.lane("aux"):
                 ops.vae_loss_fused(tw.rec, fw.mulv, flat["next_observations"], flat["base_vel"], idx, tw.g_rec, tw.dmulv,
-                                   tw.hpart, n_hp, stats[S_RECONS:S_RECONS + 4], tw.loss_ws)
+                                   tw.hpart, n_hp, stats[S_RECONS:S_RECONS + 4], tw.loss_ws,
+                                   drec_img=tw.img("g_rec", L["cd2"].n_out) if imn else None)
         else:
             ops.linear_fwd(tw.d2, L["td2"].W, L["td2"].b, tw.hr, None)
             tw.order("main", "aux")
@@ -697,15 +698,17 @@ class PPO:
         dst = segmat([seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3, accumulate=True), seg(tw.dlt, 0, 512)])
         with tw.lane("aux"):
             if imn:
-                g_reci = tw.img("g_rec", L["cd2"].n_out).pack(tw.g_rec)
+                g_reci = tw.img("g_rec", L["cd2"].n_out)              # written by the loss kernel
                 g_cd2i, g_cd1i = tw.img("g_cd2", L["cd2"].n_in), tw.img("g_cd1", L["cd1"].n_in)
                 self._bwd_img(tw, L["cd2"], g_reci, tw.img("c2"))
                 h2i.linear_dgrad(g_reci, L["cd2"].W, None, g_cd2i, mask=fw.relu_mask("c2", 128, rm), wset=wset)
                 self._bwd_img(tw, L["cd1"], g_cd2i, tw.img("c1"))
                 h2i.linear_dgrad(g_cd2i, L["cd1"].W, None, g_cd1i, mask=fw.relu_mask("c1", 64, rm), wset=wset)
                 self._bwd_img(tw, L["cd0"], g_cd1i, fw.img("lt"), wcol0=19)          # columns of dW that meet l_t ...
-                self._bwd_img(tw, L["cd0"], g_cd1i, fw.cur["p_d"], wcol0=0, bias=False)      # ... and [z | mu[:, :3]]
-                h2i.linear_dgrad(g_cd1i, L["cd0"].W, dst, None, wset=wset)
+                self._bwd_img(tw, L["cd0"], g_cd1i, fw.cur["p_zmu"], wcol0=0, bias=False)      # ... and [z | mu[:, :3]]
+                # W's columns [19, 531) first (d l_t: four whole 128-column tiles, 16-byte stores), then [0, 19) (dz | d mu[:, :3] accumulating)
+                h2i.linear_dgrad(g_cd1i, L["cd0"].W, segmat([seg(tw.dlt, 0, 512), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3, accumulate=True)]), None,
+                                 window=[(19, 512), (0, 19)], wset=wset)
                 tw.live_img |= {"g_cd2", "g_cd1"}
             else:
                 self._bwd(tw, L["cd2"], tw.g_rec, tw.c2, g_cd2, tw.c2, "relu", fw.relu_mask("c2", 128, rm), split=ns)
@@ -777,8 +780,12 @@ class PPO:
             # l_t image the terrain encoder just wrote + the packed narrow block [obs | z | mu[:, :3]] (W's columns 72.. and 0..71)
             with tw.lane("aux"):
                 Xc = ac.packed_input(fw, "p_c", ac.critic_input(obs, flat["base_vel"], priv, idx), idx, reuse=True)
-            Xa = [fw.img("lt"), ac.packed_input(fw, "p_a", segmat([seg(obs, 0, ac.num_obs, gather=True), seg(fw.z, 0, 16), seg(fw.mulv, 0, 3)], idx))]
-            a_cols = [ac.num_obs + 19, 0]
+            if imn:        # ... as two images: the gathered observations (packed once per update and mini-batch) and the latent kernel's [z | mu[:, :3]]
+                Xa = [fw.img("lt"), ac.packed_input(fw, "p_obs", segmat([seg(obs, 0, ac.num_obs, gather=True)], idx), idx, reuse=True), fw.cur["p_zmu"]]
+                a_cols = [ac.num_obs + 19, 0, ac.num_obs]
+            else:
+                Xa = [fw.img("lt"), ac.packed_input(fw, "p_a", segmat([seg(obs, 0, ac.num_obs, gather=True), seg(fw.z, 0, 16), seg(fw.mulv, 0, 3)], idx))]
+                a_cols = [ac.num_obs + 19, 0]
         elif self.pack_inputs:                                     # the narrow leading blocks of both layer-0 inputs packed into dense operands
             with tw.lane("aux"):
                 Xc = ac.critic_input_packed(obs, flat["base_vel"], priv, idx, tw.g("pack_c", ac.num_obs + 3), tw.B)
@@ -806,7 +813,7 @@ class PPO:
         tw.order("main", "aux")
         tw.dmulv.zero_()
         if im:
-            self._ppo_backward_images(fw, tw, Xc, Xa, g_a3, g_c3, fuse, wset)
+            self._ppo_backward_images(fw, tw, Xc, Xa, a_cols, g_a3, g_c3, fuse, wset)
         else:
             # critic (aux)
             g_c2, g_c1 = tw.g("c2", 256), tw.g("c1", 512)
@@ -833,7 +840,7 @@ class PPO:
         self._join(tw)
         return early
 
-    def _ppo_backward_images(self, fw, tw, Xc, Xa, g_a3, g_c3, fuse, wset):
+    def _ppo_backward_images(self, fw, tw, Xc, Xa, a_cols, g_a3, g_c3, fuse, wset):
         """Backward of the actor / critic bodies on operand images.  The heads' gradients (fp32, 128 wide) are packed into images; from
         there every gradient of the two bodies exists as an image only.  The ELU derivative reads the fp32 copy of the saved
         activation the forward pass kept next to its image."""
@@ -859,8 +866,8 @@ class PPO:
         self._bwd_img(tw, L["a1"], g_a2i, fw.img("a1"))
         h2i.linear_dgrad(g_a2i, L["a1"].W, None, g_a1i, Xsaved=fw.a1, act=act, wset=wset)
         nb = ac.num_obs + 19                                       # width of the narrow block [obs | z | mu[:, :3]]
-        self._bwd_img(tw, L["a0"], g_a1i, Xa[0], wcol0=nb)         # columns of dW that meet l_t ...
-        self._bwd_img(tw, L["a0"], g_a1i, Xa[1], wcol0=0, bias=False)        # ... and the narrow block
+        for i, (xi, c0) in enumerate(zip(Xa, a_cols)):             # columns of dW that meet l_t, then the narrow block(s)
+            self._bwd_img(tw, L["a0"], g_a1i, xi, wcol0=c0, bias=i == 0)
         # ONE launch over W's columns [72, 584) then [53, 72): d l_t as an image (four 128-column tiles), dz | d mu[:, :3] as fp32 (a fifth)
         h2i.linear_dgrad(g_a1i, L["a0"].W, segmat([seg(None, 0, 512), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3)]), tw.img("dlt", 512),
                          window=[(nb, 512), (ac.num_obs, 19)], wset=wset)

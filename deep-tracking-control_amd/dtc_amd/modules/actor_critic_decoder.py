@@ -372,7 +372,10 @@ class ActorCriticDecoder(nn.Module):
             ops.linear_fwd(X, L["ce0"].W, L["ce0"].b, ws.e1, "relu", M=ws.B, mask=ws.relu_mask("e1", 128, masks), split=split)
             ops.linear_fwd(ws.e1, L["ce1"].W, L["ce1"].b, ws.e, None, split=split)
             ops.linear_fwd(ws.e, L["head"].W, L["head"].b, ws.mulv, None, split=split)
-        ops.cenet_latent_fwd(ws.mulv, eps, ws.z, ws.mask, ws.info, ws.lat_ws)
+        zmu = None
+        if images and masks:                    # [z | mu[:, :3]] also leaves as an operand image (the decoder's / the actor's narrow input block)
+            zmu = ws.cur["p_zmu"] = ws.img("p_zmu", 19)
+        ops.cenet_latent_fwd(ws.mulv, eps, ws.z, ws.mask, ws.info, ws.lat_ws, zmu_img=zmu)
 
     def images_ok(self, ws):
         """The operand-image chain (dtc_amd/h2i.py: the wide stacks' activations live in HBM as the fp16 (hi, lo) planes the GEMM

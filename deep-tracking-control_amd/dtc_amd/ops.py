@@ -617,10 +617,13 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(1, (int(nbytes) + 7) // 8), dtype=torch.float64, device=device)
 
 
-def cenet_latent_fwd(mulv, eps, z, mask, info, ws):
+def cenet_latent_fwd(mulv, eps, z, mask, info, ws, zmu_img=None):
+    """`zmu_img` (h2i.HImage [B, 19]): also written by the launch -- the operand image of [z | mu[:, :3]]."""
     B = mulv.shape[0]
-    check(lib().dtc_cenet_latent_fwd(cptr(mulv, f32), cptr(eps, f32), cptr(z, f32), cptr(mask, torch.uint8),
-                                     cptr(info, torch.int32), ptr(ws), B, _pub(z), stream()), "dtc_cenet_latent_fwd")
+    assert zmu_img is None or (zmu_img.M, zmu_img.K) == (B, 19)
+    check(lib().dtc_cenet_latent_fwd_img(cptr(mulv, f32), cptr(eps, f32), cptr(z, f32), cptr(mask, torch.uint8),
+                                         cptr(info, torch.int32), ptr(ws), B, _pub(z), zmu_img.ptr() if zmu_img is not None else None,
+                                         stream()), "dtc_cenet_latent_fwd")
 
 
 def cenet_latent_bwd(dmulv, dz, eps, mulv, mask, info, ws):
@@ -661,11 +664,14 @@ def linear_fwd_mse(X, W, b, target, tcol0, tidx, dY, sq_part, M=None, split=None
     return n_part
 
 
-def vae_loss_fused(recons, mulv, next_obs, base_vel, idx, d_recons, dmulv, height_sq_part, n_height_part, losses, ws):
+def vae_loss_fused(recons, mulv, next_obs, base_vel, idx, d_recons, dmulv, height_sq_part, n_height_part, losses, ws, drec_img=None):
+    """`drec_img` (h2i.HImage [B, 53]): also written by the launch -- the operand image of d_recons."""
     B = recons.shape[0]
-    check(lib().dtc_vae_loss_fused(cptr(recons, f32), cptr(mulv, f32), cptr(next_obs, f32), cptr(base_vel, f32),
-                                   cptr(idx, torch.int64), cptr(d_recons, f32), cptr(dmulv, f32), ptr(height_sq_part),
-                                   n_height_part, ptr(losses), ptr(ws), B, _pub(d_recons), stream()), "dtc_vae_loss_fused")
+    assert drec_img is None or (drec_img.M, drec_img.K) == (B, d_recons.shape[1])
+    check(lib().dtc_vae_loss_fused_img(cptr(recons, f32), cptr(mulv, f32), cptr(next_obs, f32), cptr(base_vel, f32),
+                                       cptr(idx, torch.int64), cptr(d_recons, f32), cptr(dmulv, f32), ptr(height_sq_part),
+                                       n_height_part, ptr(losses), ptr(ws), B, _pub(d_recons),
+                                       drec_img.ptr() if drec_img is not None else None, stream()), "dtc_vae_loss_fused")
 
 
 def ppo_heads_loss(Ha, Hc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, advantages, returns, old_values,

@@ -479,6 +479,10 @@ int64_t dtc_cenet_workspace(int B);
 int dtc_cenet_latent_fwd(float* mulv, const float* eps, float* z, uint8_t* mask, int32_t* info,
                          void* workspace, int B, uint32_t* z_amax /* amax record of z (two-term fp16 GEMM path, DtcSeg.amax) or NULL */,
                          void* stream);
+/* ... and zmu_img (may be NULL): the operand image (dtc_h2i_bytes(B, 19)) of [z | mu[:, :3]] -- the narrow input block of the CE-net
+ * decoder's and the actor's first layer (actor_critic_decoder.py:431, 300) -- written by the same launch instead of a pack launch. */
+int dtc_cenet_latent_fwd_img(float* mulv, const float* eps, float* z, uint8_t* mask, int32_t* info, void* workspace, int B,
+                             uint32_t* z_amax, void* zmu_img, void* stream);
 /* backward of the above: dmulv [B,35] holds the direct gradients w.r.t. (mu, lv_fixed) on entry
  * and the gradients w.r.t. the raw head outputs on exit. */
 int dtc_cenet_latent_bwd(float* dmulv, const float* dz, const float* eps, const float* mulv,
@@ -506,6 +510,10 @@ int dtc_linear_fwd_mse(const DtcSegMat* X, const float* W, const float* b, const
 int dtc_vae_loss_fused(const float* recons, const float* mulv, const float* next_obs, const float* base_vel,
                        const int64_t* idx, float* d_recons, float* dmulv, const double* height_sq_part, int n_height_part,
                        float* losses, void* workspace, int B, uint32_t* drec_amax /* as dtc_vae_loss */, void* stream);
+/* ... and drec_img (may be NULL): the operand image (dtc_h2i_bytes(B, 53)) of d_recons, written by the same launch. */
+int dtc_vae_loss_fused_img(const float* recons, const float* mulv, const float* next_obs, const float* base_vel,
+                           const int64_t* idx, float* d_recons, float* dmulv, const double* height_sq_part, int n_height_part,
+                           float* losses, void* workspace, int B, uint32_t* drec_amax, void* drec_img, void* stream);
 int64_t dtc_loss_workspace(int B);
 
 typedef struct DtcPpoCfg {

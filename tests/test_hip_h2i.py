@@ -298,3 +298,39 @@ def test_timing_next_to_the_converting_kernels(capsys):
     )
     with capsys.disabled():
         print("\n[h2i timing, us] " + ", ".join(f"{k} {v:.1f}" for k, v in t.items()))
+
+
+def test_images_written_by_the_latent_and_loss_kernels_equal_a_pack_of_their_fp32_outputs():
+    """[z | mu[:, :3]] (dtc_cenet_latent_fwd_img) and dL/d recons (dtc_vae_loss_fused_img) leave their kernels as operand images
+    too: byte for byte what h2i_pack_kernel makes of the fp32 tensors the same launches write (rows with a zero / huge entry incl.)."""
+    from dtc_amd import _ffi, h2i, ops
+    B = 1024 + 128
+    g = torch.Generator().manual_seed(17)
+    mulv = torch.randn(B, 35, generator=g)
+    mulv[:, 19:] = 0.3 * mulv[:, 19:] - 1.0
+    mulv[5, 19:] = 9.0                                   # outliers -> replaced by the median
+    mulv[7, :3] = 0.0
+    mulv[9, 0] = 3.0e4
+    eps = torch.randn(B, 16, generator=g)
+    eps[11] = 0.0
+    mulv_d, eps_d = mulv.to(DEV), eps.to(DEV)
+    z = torch.empty(B, 16, device=DEV)
+    mask = torch.empty(B, 16, dtype=torch.uint8, device=DEV)
+    info = torch.zeros(4, dtype=torch.int32, device=DEV)
+    ws = torch.empty(int(_ffi.lib().dtc_cenet_workspace(B)) // 8 + 1, dtype=torch.float64, device=DEV)
+    img = h2i.HImage(B, 19, DEV)
+    ops.cenet_latent_fwd(mulv_d, eps_d, z, mask, info, ws, zmu_img=img)
+    want = h2i.HImage.from_tensor(torch.cat([z, mulv_d[:, :3]], dim=1))
+    assert torch.equal(img.buf, want.buf)
+    # loss kernel
+    rec, nxt = torch.randn(B, 53, generator=g).to(DEV), torch.randn(2 * B, 53, generator=g).to(DEV)
+    rec[3] = nxt[3]                                      # an all-zero gradient row
+    bv = torch.randn(2 * B, 3, generator=g).to(DEV)
+    idx = torch.arange(B, device=DEV)
+    d_rec, dmulv = torch.empty(B, 53, device=DEV), torch.empty(B, 35, device=DEV)
+    losses = torch.zeros(4, device=DEV)
+    lws = ops.workspace(_ffi.lib().dtc_loss_workspace(B), DEV)
+    gimg = h2i.HImage(B, 53, DEV)
+    ops.vae_loss_fused(rec, mulv_d, nxt, bv, idx, d_rec, dmulv, None, 0, losses, lws, drec_img=gimg)
+    assert torch.equal(gimg.buf, h2i.HImage.from_tensor(d_rec).buf)
+    assert float(d_rec[3].abs().max()) == 0.0
