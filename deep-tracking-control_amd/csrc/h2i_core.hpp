@@ -74,6 +74,15 @@ __device__ __forceinline__ void hi_store_elem(void* img, int K, int row, int col
     *reinterpret_cast<_Float16*>(static_cast<char*>(img) + off) = h;
     *reinterpret_cast<_Float16*>(static_cast<char*>(img) + off + HI_PLANE) = l;
 }
+// four consecutive columns (col0 % 4 == 0) of one row: 8-byte stores into both planes
+__device__ __forceinline__ void hi_store4(void* img, int K, int row, int col0, f32x4 v, int e) {
+    const Split2 s = split2(v, e == HI_EZERO ? 0 : e);
+    const int r = row & 127;
+    const long long off = ((long long)(row >> 7) * hi_stages(K) + (col0 >> 4)) * HI_CHUNK +
+                          (2 * r + (((col0 >> 3) & 1) ^ ((r >> 3) & 1))) * 16 + (col0 & 7) * 2;
+    *reinterpret_cast<u32x2*>(static_cast<char*>(img) + off) = s.p[0];
+    *reinterpret_cast<u32x2*>(static_cast<char*>(img) + off + HI_PLANE) = s.p[1];
+}
 __device__ __forceinline__ void hi_store_row_exp(void* img, long long M, int K, int row, int e) {
     int* exps = reinterpret_cast<int*>(static_cast<char*>(img) + hi_data_bytes(M, K));
     exps[(long long)(row >> 7) * hi_kblocks(K) * 128 + (row & 127)] = e;

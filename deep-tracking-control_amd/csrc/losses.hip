@@ -267,6 +267,12 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__
 // the backward products), the head weights sit in LDS (broadcast reads), the four partial dot products of a row are
 // combined by two quad butterflies, every thread of the row then holds mean / value and evaluates the row's loss.
 // dH = (d_out W) * act'(H) with the derivative through the saved post-activation value, as linear_dgrad_kernel does.
+// operand images (csrc/h2i_core.hpp) of the four gradients the kernel writes, for the image-operand consumers of the trainer: the two
+// [B, H] data gradients (H <= 128: one exponent per row) and dmean [B, A] / dvalue [B, 1] (the heads' own weight gradients); each may be NULL
+struct HeadImgs {
+    void *dHa, *dHc, *dmean, *dval;
+};
+
 template <int H, int TPR = 4>
 __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     const float* __restrict__ Ha, long long ldha, const float* __restrict__ Hc, long long ldhc, const float* __restrict__ Wa,
@@ -276,7 +282,8 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     const float* __restrict__ returns, const float* __restrict__ old_values, const long long* __restrict__ idx, DtcPpoCfg cfg,
     float* __restrict__ mean, float* __restrict__ value, float* __restrict__ dmean, float* __restrict__ dvalue,
     float* __restrict__ dHa, long long lddha, float* __restrict__ dHc, long long lddhc, double* __restrict__ part, int B, int A,
-    amax_u32* __restrict__ dha_amax, amax_u32* __restrict__ dhc_amax, amax_u32* __restrict__ dmean_amax, amax_u32* __restrict__ dval_amax) {
+    amax_u32* __restrict__ dha_amax, amax_u32* __restrict__ dhc_amax, amax_u32* __restrict__ dmean_amax, amax_u32* __restrict__ dval_amax,
+    const HeadImgs im) {
     // TPR threads per row (4: 64 rows per workgroup; 8: 32 rows per workgroup = twice the workgroups, half the serial work
     // per thread -- the kernel is a latency chain per row, not a bandwidth problem)
     constexpr int NC = H / (4 * TPR);                // chunks per thread
@@ -341,9 +348,24 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
             dmean[(long long)row * A + j] = dm[j];
             mdm = abs_bits(dm[j]) > mdm ? abs_bits(dm[j]) : mdm;
         }
+        if (im.dmean) {
+            u32 mb = 0u;
+            for (int j = 0; j < A; ++j) mb = finite_bits(dm[j]) > mb ? finite_bits(dm[j]) : mb;
+            const int ex = hi_exp(mb);
+            for (int j = 0; j < A; ++j) hi_store_elem(im.dmean, A, row, j, dm[j], ex);
+            hi_store_row_exp(im.dmean, B, A, row, ex);
+        }
+        if (im.dval) {
+            const int ex = hi_exp(finite_bits(o.dvalue));
+            hi_store_elem(im.dval, 1, row, 0, o.dvalue, ex);
+            hi_store_row_exp(im.dval, B, 1, row, ex);
+        }
     }
     // ---- backward through the two heads: dHa = (dmean Wa) * act'(Ha), dHc = (dvalue Wc) * act'(Hc)
     amax_u32 ma = 0u, mc = 0u;             // largest |dHa| / |dHc| this thread writes (amax records of the two-term fp16 GEMM path)
+    f4 GA[NC], GC[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) GA[i] = GC[i] = f4{0.f, 0.f, 0.f, 0.f};
     if (rok) {
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
@@ -363,6 +385,36 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
             }
             *reinterpret_cast<f4*>(dHa + rr * lddha + 4 * (p + TPR * i)) = ga;
             *reinterpret_cast<f4*>(dHc + rr * lddhc + 4 * (p + TPR * i)) = gc;
+            GA[i] = ga;
+            GC[i] = gc;
+        }
+    }
+    if (im.dHa || im.dHc) {                    // (uniform) the row's threads agree on the row's exponents, then store their own chunks
+        u32 xa = 0u, xc = 0u;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xa = finite_bits(GA[i][e]) > xa ? finite_bits(GA[i][e]) : xa;
+                xc = finite_bits(GC[i][e]) > xc ? finite_bits(GC[i][e]) : xc;
+            }
+#pragma unroll
+        for (int off = 1; off < TPR; off <<= 1) {
+            const u32 oa = (u32)__shfl_xor((int)xa, off, 64), oc = (u32)__shfl_xor((int)xc, off, 64);
+            xa = oa > xa ? oa : xa;
+            xc = oc > xc ? oc : xc;
+        }
+        const int ea = hi_exp(xa), ec = hi_exp(xc);
+        if (rok) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                if (im.dHa) hi_store4(im.dHa, H, row, 4 * (p + TPR * i), GA[i], ea);
+                if (im.dHc) hi_store4(im.dHc, H, row, 4 * (p + TPR * i), GC[i], ec);
+            }
+            if (p == 0) {
+                if (im.dHa) hi_store_row_exp(im.dHa, B, H, row, ea);
+                if (im.dHc) hi_store_row_exp(im.dHc, B, H, row, ec);
+            }
         }
     }
     __shared__ amax_u32 red_a[4], red_c[4], red_m[4], red_v[4];
@@ -531,7 +583,24 @@ extern "C" int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc
                                   int64_t lddha, float* dHc, int64_t lddhc, float* dstd, float* losses, double* lr,
                                   void* workspace, int B, int num_actions, uint32_t* dha_amax, uint32_t* dhc_amax, uint32_t* dmean_amax,
                                   uint32_t* dval_amax, void* stream) {
+    return dtc_ppo_heads_loss_img(Ha, ldha, Hc, ldhc, H, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, advantages, returns,
+                                  old_values, idx, cfg, mean, value, dmean, dvalue, dHa, lddha, dHc, lddhc, dstd, losses, lr, workspace, B,
+                                  num_actions, dha_amax, dhc_amax, dmean_amax, dval_amax, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int dtc_ppo_heads_loss_img(const float* Ha, int64_t ldha, const float* Hc, int64_t ldhc, int H, const float* Wa,
+                                      const float* ba, const float* Wc, const float* bc, int act_prev, const float* std,
+                                      const float* actions, const float* old_logp, const float* old_mu, const float* old_sigma,
+                                      const float* advantages, const float* returns, const float* old_values, const int64_t* idx,
+                                      const DtcPpoCfg* cfg, float* mean, float* value, float* dmean, float* dvalue, float* dHa,
+                                      int64_t lddha, float* dHc, int64_t lddhc, float* dstd, float* losses, double* lr,
+                                      void* workspace, int B, int num_actions, uint32_t* dha_amax, uint32_t* dhc_amax,
+                                      uint32_t* dmean_amax, uint32_t* dval_amax, void* dHa_img, void* dHc_img, void* dmean_img,
+                                      void* dval_img, void* stream) {
     DTC_REQUIRE(B > 0 && num_actions > 0 && num_actions <= MAX_ACT, "bad shape B=%d A=%d", B, num_actions);
+    DTC_REQUIRE((!dHa_img && !dHc_img) || H <= 128, "operand images of the hidden gradients need H <= 128 (one exponent per row), H = %d", H);
+    DTC_REQUIRE(dtc::aligned16(dHa_img) && dtc::aligned16(dHc_img) && dtc::aligned16(dmean_img) && dtc::aligned16(dval_img), "unaligned image");
+    const HeadImgs him{dHa_img, dHc_img, dmean_img, dval_img};
     DTC_REQUIRE(H == 64 || H == 128 || H == 256, "hidden width %d unsupported by the fused heads (64, 128, 256)", H);
     DTC_REQUIRE(Ha && Hc && Wa && Wc && std && actions && old_logp && old_mu && old_sigma && advantages && returns && old_values,
                 "null input");
@@ -551,7 +620,7 @@ extern "C" int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc
 #define DTC_HL_ARGS Ha, (long long)ldha, Hc, (long long)ldhc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, \
                     advantages, returns, old_values, (const long long*)idx, *cfg, mean, value, dmean, dvalue, dHa, (long long)lddha, \
                     dHc, (long long)lddhc, part, B, num_actions, (amax_u32*)dha_amax, (amax_u32*)dhc_amax, (amax_u32*)dmean_amax, \
-                    (amax_u32*)dval_amax
+                    (amax_u32*)dval_amax, him
     if (tpr == 8) {
         if (H == 64) hipLaunchKernelGGL((ppo_heads_loss_kernel<64, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
         else if (H == 128) hipLaunchKernelGGL((ppo_heads_loss_kernel<128, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);

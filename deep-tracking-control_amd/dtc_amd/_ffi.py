@@ -221,6 +221,9 @@ _SIGS = {
                            [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 5 + [C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f64p,
                                                                       C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                                       C.c_void_p, c_stream]),
+    "dtc_ppo_heads_loss_img": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int] + [c_f32p] * 4 + [C.c_int] + [c_f32p] * 8 +
+                               [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 5 + [C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f64p,
+                                                                          C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [c_stream]),
     "dtc_lr_adapt": (C.c_int, [c_f32p, c_f64p, C.c_float, c_stream]),
     "dtc_gaussian_act": (C.c_int, [c_f32p] * 7 + [C.c_int, C.c_int, c_stream]),
     "dtc_bootstrap_probability": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_stream]),

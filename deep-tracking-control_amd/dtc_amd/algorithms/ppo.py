@@ -793,9 +793,12 @@ class PPO:
         else:
             Xc = ac.critic_input(obs, flat["base_vel"], priv, idx)
             Xa = ac.actor_input(fw, obs, idx)
+        himg = None                                                # fused heads in the image chain: the kernel writes its four gradients as images too
+        if imn and fuse and fw.a3.shape[1] <= 128:
+            himg = (tw.img("G_a3", fw.a3.shape[1]), tw.img("G_c3", fw.v3.shape[1]), tw.img("dmean", tw.dmean.shape[1]), tw.img("dval", 1))
         with tw.lane("aux"):
-            ac.critic_forward_(fw, obs, flat["base_vel"], priv, idx, head=not fuse, X=Xc, images=im, wset=wset)
-        ac.actor_forward_(fw, obs, idx, head=not fuse, X=Xa, images=im, wset=wset, cols=a_cols)
+            ac.critic_forward_(fw, obs, flat["base_vel"], priv, idx, head=not fuse, X=Xc, images=im, wset=wset, last_img=himg is not None)
+        ac.actor_forward_(fw, obs, idx, head=not fuse, X=Xa, images=im, wset=wset, cols=a_cols, last_img=himg is not None)
         tw.order("aux", "main")
         if self.after_forward_hook is not None:
             self.after_forward_hook(fw, "ppo")
@@ -804,7 +807,7 @@ class PPO:
             ops.ppo_heads_loss(fw.a3, fw.v3, L["a3"].W, L["a3"].b, L["c3"].W, L["c3"].b, act, ac.std_view, flat["actions"],
                                flat["actions_log_prob"], flat["mu"], flat["sigma"], flat["advantages"], flat["returns"],
                                flat["values"], idx, cfg, fw.mean, fw.val, tw.dmean, tw.dval, g_a3, g_c3, ac.std_grad,
-                               stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
+                               stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws, imgs=himg)
         else:
             ops.ppo_loss(fw.mean, ac.std_view, fw.val, flat["actions"], flat["actions_log_prob"], flat["mu"],
                          flat["sigma"], flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval,
@@ -813,7 +816,7 @@ class PPO:
         tw.order("main", "aux")
         tw.dmulv.zero_()
         if im:
-            self._ppo_backward_images(fw, tw, Xc, Xa, a_cols, g_a3, g_c3, fuse, wset)
+            self._ppo_backward_images(fw, tw, Xc, Xa, a_cols, g_a3, g_c3, fuse, wset, himg)
         else:
             # critic (aux)
             g_c2, g_c1 = tw.g("c2", 256), tw.g("c1", 512)
@@ -840,7 +843,7 @@ class PPO:
         self._join(tw)
         return early
 
-    def _ppo_backward_images(self, fw, tw, Xc, Xa, a_cols, g_a3, g_c3, fuse, wset):
+    def _ppo_backward_images(self, fw, tw, Xc, Xa, a_cols, g_a3, g_c3, fuse, wset, himg=None):
         """Backward of the actor / critic bodies on operand images.  The heads' gradients (fp32, 128 wide) are packed into images; from
         there every gradient of the two bodies exists as an image only.  The ELU derivative reads the fp32 copy of the saved
         activation the forward pass kept next to its image."""
@@ -849,8 +852,12 @@ class PPO:
         act = AC_Args.activation
         n_a, n_c = L["a2"].n_out, L["c2"].n_out
         with tw.lane("aux"):                                       # critic
-            self._bwd(tw, L["c3"], tw.dval, fw.v3, None if fuse else g_c3, fw.v3, act, split=False)      # fused: weight gradient only
-            G_c3 = tw.img("G_c3", n_c).pack(g_c3)
+            if himg is not None:                                   # the heads kernel wrote G_c3 / d value as images: the output layer's
+                G_c3 = himg[1]                                     # weight gradient joins the bucket's image-operand launch, nothing to pack
+                self._bwd_img(tw, L["c3"], himg[3], fw.img("v3"))
+            else:
+                self._bwd(tw, L["c3"], tw.dval, fw.v3, None if fuse else g_c3, fw.v3, act, split=False)      # fused: weight gradient only
+                G_c3 = tw.img("G_c3", n_c).pack(g_c3)
             g_c2i, g_c1i = tw.img("g_c2", L["c2"].n_in), tw.img("g_c1", L["c1"].n_in)
             self._bwd_img(tw, L["c2"], G_c3, fw.img("v2"))
             h2i.linear_dgrad(G_c3, L["c2"].W, None, g_c2i, Xsaved=fw.v2, act=act, wset=wset)
@@ -858,8 +865,12 @@ class PPO:
             h2i.linear_dgrad(g_c2i, L["c1"].W, None, g_c1i, Xsaved=fw.v1, act=act, wset=wset)
             self._bwd_img(tw, L["c0"], g_c1i, Xc)
         # actor (main); layer-0 input gradient fans out to z, mu[:, :3] (fp32) and l_t (image); the observations need none
-        self._bwd(tw, L["a3"], tw.dmean, fw.a3, None if fuse else g_a3, fw.a3, act, split=False)
-        G_a3 = tw.img("G_a3", n_a).pack(g_a3)
+        if himg is not None:
+            G_a3 = himg[0]
+            self._bwd_img(tw, L["a3"], himg[2], fw.img("a3"))
+        else:
+            self._bwd(tw, L["a3"], tw.dmean, fw.a3, None if fuse else g_a3, fw.a3, act, split=False)
+            G_a3 = tw.img("G_a3", n_a).pack(g_a3)
         g_a2i, g_a1i = tw.img("g_a2", L["a2"].n_in), tw.img("g_a1", L["a1"].n_in)
         self._bwd_img(tw, L["a2"], G_a3, fw.img("a2"))
         h2i.linear_dgrad(G_a3, L["a2"].W, None, g_a2i, Xsaved=fw.a2, act=act, wset=wset)

@@ -29,6 +29,10 @@ class HImage:
         if n <= 0 or n >= 1 << 31:
             raise _ffi.DtcError(f"operand image of a {M} x {K} matrix: {n} bytes (must be in (0, 2 GiB))")
         self.buf = torch.zeros((n + 7) // 8, dtype=torch.float64, device=device)      # (zeros: rows behind M read as nothing)
+        # exponents start as "nothing here" (HI_EZERO): producers that write only their own rows (the latent / loss kernels) leave the
+        # rows behind M of the last row tile marked empty, as the pack kernel and the GEMM epilogues do
+        data = -(-self.M // 128) * -(-self.K // 16) * 8192
+        self.buf.view(torch.int32)[data // 4: n // 4].fill_(0x7fff)
 
     @property
     def device(self):

@@ -439,7 +439,7 @@ class ActorCriticDecoder(nn.Module):
         ops.pack_cols(segmat([seg(obs, 0, self.num_obs, gather=g), seg(base_vel, 0, 3, gather=g)], idx), buf, B)
         return segmat([seg(buf, 0, self.num_obs + 3), seg(priv, 693, 696, gather=g)], idx)
 
-    def _body_forward_(self, ws, X, names, outs, images, wset=None, cols=None):
+    def _body_forward_(self, ws, X, names, outs, images, wset=None, cols=None, last_img=False):
         """First three layers of an actor / critic body.  `images`: X is an operand image (or a list of them, `cols` = the first
         column of the layer's weight each one meets); the two hidden activations leave as fp32 (the ELU derivative of the backward pass
         reads it) AND as images, the layers after the first read their input by LDS-DMA; the last one writes fp32 only."""
@@ -450,22 +450,23 @@ class ActorCriticDecoder(nn.Module):
             i0, i1 = ws.img(outs[0], l0.n_out), ws.img(outs[1], l1.n_out)
             h2i.linear_fwd(X, l0.W, l0.b, o0, i0, act, wset=wset, cols=cols)
             h2i.linear_fwd(i0, l1.W, l1.b, o1, i1, act, wset=wset)
-            h2i.linear_fwd(i1, l2.W, l2.b, o2, None, act, wset=wset)
+            # (last_img: the third activation as an image as well -- the X operand of the output layer's image-operand weight gradient)
+            h2i.linear_fwd(i1, l2.W, l2.b, o2, ws.img(outs[2], l2.n_out) if last_img else None, act, wset=wset)
             return
         ops.linear_fwd(X, l0.W, l0.b, o0, act, M=ws.B)
         ops.linear_fwd(o0, l1.W, l1.b, o1, act)
         ops.linear_fwd(o1, l2.W, l2.b, o2, act)
 
-    def actor_forward_(self, ws, obs, idx=None, head=True, X=None, images=False, wset=None, cols=None):
+    def actor_forward_(self, ws, obs, idx=None, head=True, X=None, images=False, wset=None, cols=None, last_img=False):
         """`head=False`: stop before the output layer (the trainer's fused heads + loss kernel computes it)."""
         L = self.L
-        self._body_forward_(ws, self.actor_input(ws, obs, idx) if X is None else X, ("a0", "a1", "a2"), ("a1", "a2", "a3"), images, wset, cols)
+        self._body_forward_(ws, self.actor_input(ws, obs, idx) if X is None else X, ("a0", "a1", "a2"), ("a1", "a2", "a3"), images, wset, cols, last_img)
         if head:
             ops.linear_fwd(ws.a3, L["a3"].W, L["a3"].b, ws.mean, None)
 
-    def critic_forward_(self, ws, obs, base_vel, priv, idx=None, head=True, X=None, images=False, wset=None):
+    def critic_forward_(self, ws, obs, base_vel, priv, idx=None, head=True, X=None, images=False, wset=None, last_img=False):
         L = self.L
-        self._body_forward_(ws, self.critic_input(obs, base_vel, priv, idx) if X is None else X, ("c0", "c1", "c2"), ("v1", "v2", "v3"), images, wset)
+        self._body_forward_(ws, self.critic_input(obs, base_vel, priv, idx) if X is None else X, ("c0", "c1", "c2"), ("v1", "v2", "v3"), images, wset, None, last_img)
         if head:
             ops.linear_fwd(ws.v3, L["c3"].W, L["c3"].b, ws.val, None)
 

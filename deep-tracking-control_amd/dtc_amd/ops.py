@@ -675,18 +675,23 @@ def vae_loss_fused(recons, mulv, next_obs, base_vel, idx, d_recons, dmulv, heigh
 
 
 def ppo_heads_loss(Ha, Hc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, advantages, returns, old_values,
-                   idx, cfg, mean, value, dmean, dvalue, dHa, dHc, dstd, losses, lr, ws):
+                   idx, cfg, mean, value, dmean, dvalue, dHa, dHc, dstd, losses, lr, ws, imgs=None):
     """Output layers of actor and critic + dtc_ppo_loss + their data gradients in one launch (see dtc_hip.h).
-    Ha / Hc [B,H] last hidden activations (post-activation, `act_prev`), dHa / dHc [B,H] receive their gradients."""
+    Ha / Hc [B,H] last hidden activations (post-activation, `act_prev`), dHa / dHc [B,H] receive their gradients.
+    `imgs` = (dHa, dHc, dmean, dvalue) as h2i.HImage or None each: also written by the launch."""
     B, H = Ha.shape
     A = Wa.shape[0]
-    check(lib().dtc_ppo_heads_loss(cptr(Ha, f32), Ha.stride(0), cptr(Hc, f32), Hc.stride(0), H, cptr(Wa, f32), cptr(ba, f32),
+    ip = [None] * 4 if imgs is None else [im.ptr() if im is not None else None for im in imgs]
+    if imgs is not None:
+        for im, w in zip(imgs, (H, H, A, 1)):
+            assert im is None or (im.M, im.K) == (B, w)
+    check(lib().dtc_ppo_heads_loss_img(cptr(Ha, f32), Ha.stride(0), cptr(Hc, f32), Hc.stride(0), H, cptr(Wa, f32), cptr(ba, f32),
                                    cptr(Wc, f32), cptr(bc, f32), ACT[act_prev], ptr(std), cptr(actions, f32), cptr(old_logp, f32),
                                    cptr(old_mu, f32), cptr(old_sigma, f32), cptr(advantages, f32), cptr(returns, f32),
                                    cptr(old_values, f32), cptr(idx, torch.int64) if idx is not None else None, cfg,
                                    cptr(mean, f32), cptr(value, f32), cptr(dmean, f32), cptr(dvalue, f32), cptr(dHa, f32),
                                    dHa.stride(0), cptr(dHc, f32), dHc.stride(0), ptr(dstd), ptr(losses), ptr(lr), ptr(ws), B, A,
-                                   _pub(dHa), _pub(dHc), _pub(dmean), _pub(dvalue), stream()), "dtc_ppo_heads_loss")
+                                   _pub(dHa), _pub(dHc), _pub(dmean), _pub(dvalue), *ip, stream()), "dtc_ppo_heads_loss")
 
 
 def ppo_loss(mean, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, old_values, idx, cfg,

@@ -543,6 +543,16 @@ int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc, int64_t l
                        int B, int num_actions, uint32_t* dha_amax, uint32_t* dhc_amax, uint32_t* dmean_amax,
                        uint32_t* dval_amax /* amax records of dHa / dHc / dmean / dvalue (two-term fp16 GEMM path, see DtcSeg.amax), each
                        may be NULL */, void* stream);
+/* ... and the operand images (dtc_h2i_bytes(B, H), (B, H), (B, A), (B, 1); each may be NULL; the first two need H <= 128) of dHa, dHc, dmean,
+ * dvalue, written by the same launch: the trainer's image-operand data / weight gradients read them without a pack launch. */
+int dtc_ppo_heads_loss_img(const float* Ha, int64_t ldha, const float* Hc, int64_t ldhc, int H, const float* Wa, const float* ba,
+                           const float* Wc, const float* bc, int act_prev, const float* std, const float* actions,
+                           const float* old_logp, const float* old_mu, const float* old_sigma, const float* advantages,
+                           const float* returns, const float* old_values, const int64_t* idx, const DtcPpoCfg* cfg, float* mean,
+                           float* value, float* dmean, float* dvalue, float* dHa, int64_t lddha, float* dHc, int64_t lddhc,
+                           float* dstd, float* losses, double* lr, void* workspace, int B, int num_actions, uint32_t* dha_amax,
+                           uint32_t* dhc_amax, uint32_t* dmean_amax, uint32_t* dval_amax, void* dHa_img, void* dHc_img,
+                           void* dmean_img, void* dval_img, void* stream);
 /* The learning-rate rule of ppo.py:301-307 alone (data-parallel callers run dtc_ppo_loss with
  * adaptive_schedule = 0, all-reduce the KL mean, then call this so every rank takes the same branch).
  * The slot is CONSUMED: it is overwritten with NaN, and a NaN found in it (a caller that exchanged the gradient header

@@ -334,3 +334,33 @@ def test_images_written_by_the_latent_and_loss_kernels_equal_a_pack_of_their_fp3
     ops.vae_loss_fused(rec, mulv_d, nxt, bv, idx, d_rec, dmulv, None, 0, losses, lws, drec_img=gimg)
     assert torch.equal(gimg.buf, h2i.HImage.from_tensor(d_rec).buf)
     assert float(d_rec[3].abs().max()) == 0.0
+
+
+def test_images_written_by_the_fused_heads_kernel_equal_a_pack_of_its_fp32_outputs():
+    """dtc_ppo_heads_loss_img: dHa / dHc [B, 128] and dmean [B, 12] / dvalue [B, 1] as operand images, byte for byte a pack of the fp32
+    tensors the same launch writes (ragged last row tile, rows whose advantage is zero -> all-zero gradient rows)."""
+    from dtc_amd import _ffi, h2i, ops
+    B, H, A = 1024 + 37, 128, 12
+    g = torch.Generator().manual_seed(23)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)          # noqa: E731
+    Ha, Hc = torch.nn.functional.elu(r(B, H)), torch.nn.functional.elu(r(B, H))
+    Wa, ba, Wc, bc = r(A, H) / 11, r(A) * 0.1, r(1, H) / 11, r(1) * 0.1
+    std = torch.rand(A, generator=g).to(DEV) + 0.5
+    R = 2 * B
+    actions, old_mu = r(R, A), r(R, A)
+    old_sigma = torch.rand(R, A, generator=g).to(DEV) + 0.5
+    old_logp, adv, ret, oldv = r(R), r(R), r(R), r(R)
+    idx = torch.randperm(R, generator=g)[:B].to(DEV)
+    adv[idx[:20]] = 0.0
+    cfg = _ffi.DtcPpoCfg()
+    cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.desired_kl, cfg.use_clipped_value_loss, cfg.adaptive_schedule = 0.2, 1.0, 0.003, 0.01, 1, 0
+    mean, val, dmean, dval = (torch.empty(B, w, device=DEV) for w in (A, 1, A, 1))
+    dHa, dHc = torch.empty(B, H, device=DEV), torch.empty(B, H, device=DEV)
+    dstd, losses = torch.zeros(A, device=DEV), torch.zeros(4, device=DEV)
+    lr = torch.full((1,), 1e-3, dtype=torch.float64, device=DEV)
+    ws = ops.workspace(_ffi.lib().dtc_loss_workspace(B), DEV)
+    imgs = (h2i.HImage(B, H, DEV), h2i.HImage(B, H, DEV), h2i.HImage(B, A, DEV), h2i.HImage(B, 1, DEV))
+    ops.ppo_heads_loss(Ha, Hc, Wa, ba, Wc, bc, "elu", std, actions, old_logp, old_mu, old_sigma, adv, ret, oldv, idx, cfg, mean, val,
+                       dmean, dval, dHa, dHc, dstd, losses, lr, ws, imgs=imgs)
+    for im, t in zip(imgs, (dHa, dHc, dmean, dval)):
+        assert torch.equal(im.buf, h2i.HImage.from_tensor(t).buf)
