@@ -8,7 +8,7 @@
 //                       8 ds_read_b128 + 12 MFMAs per wave and 16-k stage), accumulator rows rescaled at the 128-column block borders,
 //                       results as fp32 and / or as the image the next consumer reads (per-row exponents chosen in the epilogue)
 //   h2i_unpack_kernel   image -> fp32 (tests, debugging)
-// Block tile 128 x 128 x 16, 2 x 2 waves of 64 x 64, double-buffered LDS (32 KiB + 4.5 KiB of exponent deltas), 3 workgroups per CU.
+// Block tile 128 x 128 x 16, 2 x 2 waves of 64 x 64, double-buffered LDS (48 KiB + 4.25 KiB of exponent deltas), 3 workgroups per CU.
 #include <type_traits>
 
 #include "h2i_core.hpp"
@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int EPI_FWD = 0, EPI_DGRAD = 1, EPI_MSE = 2;
-constexpr int MAX_TB = 8;            // exponent blocks along the reduction (sum over the row operand's segments)
+constexpr int MAX_TB = 16;           // exponent blocks along the reduction (sum over the row operand's segments): 2048 columns
 
 // ---- fp32 -> image ---------------------------------------------------------------------------------------------------------------
 // block = (row tile, k block); thread = (row r = tid & 127, k half h = tid >> 7): 8 stages x 8 consecutive columns in registers,
@@ -255,7 +255,7 @@ __shared__ __attribute__((aligned(16))) u32x2 Xs2[2][BM * 4];
 __shared__ __attribute__((aligned(16))) u32x2 Ws0[2][128 * 4];
 __shared__ __attribute__((aligned(16))) u32x2 Ws1[2][128 * 4];
 __shared__ __attribute__((aligned(16))) u32x2 Ws2[2][128 * 4];
-__shared__ __attribute__((aligned(16))) int Dt[MAX_TB + 1][128];      // exponent deltas per block border and row; [tblocks]: the final scale
+__shared__ __attribute__((aligned(16))) short Dt[MAX_TB + 1][128];    // exponent deltas per block border and row (|e| <= 2 x 113: int16); [tblocks]: the final scale
 
 // ---- device code of the GEMM kernels.  The descriptors are read through the CONSTANT address space, in place from the kernel-argument
 // segment: invariant scalar loads, and no private copy of the by-value argument (binding a generic reference to it copies the struct to
@@ -382,11 +382,11 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
                 prev_a = ea == HI_EZERO ? prev_a : ea;
                 prev_w = ew == HI_EZERO ? prev_w : ew;
                 const int e = prev_a + prev_w;
-                Dt[b][tid] = e - prev;
+                Dt[b][tid] = (short)(e - prev);
                 prev = e;
             }
         }
-        Dt[A.tblocks][tid] = -prev;
+        Dt[A.tblocks][tid] = (short)(-prev);
         // (the first block's "delta" Dt[0] = e(0) is never applied: the accumulators start at zero)
     }
 
@@ -403,8 +403,8 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int4 d = *reinterpret_cast<const int4*>(&Dt[b][wm_off + 32 * i + 4 * half + 8 * g]);
-                const int dv[4] = {d.x, d.y, d.z, d.w};
+                const int2 d = *reinterpret_cast<const int2*>(&Dt[b][wm_off + 32 * i + 4 * half + 8 * g]);      // four int16
+                const int dv[4] = {(d.x << 16) >> 16, d.x >> 16, (d.y << 16) >> 16, d.y >> 16};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -731,7 +731,7 @@ int to_operand(const DtcH2iOperand* X, int M, HOperand& A, int& K) {
         A.tblocks += s.kbs;
         K += X->width[i];
     }
-    DTC_REQUIRE(A.tblocks <= MAX_TB, "row operand: %d exponent blocks along the reduction, at most %d (1024 columns)", A.tblocks, MAX_TB);
+    DTC_REQUIRE(A.tblocks <= MAX_TB, "row operand: %d exponent blocks along the reduction, at most %d (2048 columns)", A.tblocks, MAX_TB);
     return DTC_OK;
 }
 

@@ -135,6 +135,13 @@ extern "C" int64_t dtc_gru_workspace(int T, int R, int H) {
     return a + b + 16 + ((dtc_linear_wgrad_workspace(T * R, 3 * H, H) + 15) & ~(int64_t)15) + img;     // +16: 16-byte alignment
 }
 
+// byte offset of dgh_all [T, R, 3H] (the gradient w.r.t. the recurrent pre-activations, written by dtc_gru_bwd) inside the workspace
+extern "C" int64_t dtc_gru_dgh_offset(int T, int R, int H) {
+    (void)T;
+    if (R <= 0 || H <= 0) return -1;
+    return (int64_t)MAX_PARTS * R * H * (int64_t)sizeof(float);
+}
+
 extern "C" int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, const float* b_hh, float* hs_all,
                            float* gates, float* hn, void* workspace, int T, int R, int H, void* stream) {
     DTC_REQUIRE(T > 0 && R > 0 && H > 0, "bad shape T=%d R=%d H=%d", T, R, H);
@@ -184,7 +191,8 @@ extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* g
                            float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace, const int64_t* valid_rows, int n_valid,
                            int T, int R, int H, void* stream) {
     DTC_REQUIRE(T > 0 && R > 0 && H > 0, "bad shape T=%d R=%d H=%d", T, R, H);
-    DTC_REQUIRE(dhs && hs_all && gates && hn && W_hh && dgi && dW_hh && db_hh && dh0 && workspace, "null pointer");
+    DTC_REQUIRE(dhs && hs_all && gates && hn && W_hh && dgi && dh0 && workspace, "null pointer");
+    DTC_REQUIRE((dW_hh == nullptr) == (db_hh == nullptr), "dW_hh and db_hh: both or neither");
     hipStream_t s = (hipStream_t)stream;
     const size_t RH = (size_t)R * H, R3H = (size_t)R * 3 * H;
     float* dgh_all = (float*)workspace + (size_t)MAX_PARTS * RH;
@@ -216,6 +224,9 @@ extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* g
         if (rc != DTC_OK) return rc;
     }
     hipLaunchKernelGGL(gru_add_parts_kernel, dim3(grid), dim3(256), 0, s, dh0, part, (long long)RH, nparts);
+    // dW_hh == NULL: the caller forms the W_hh weight gradient itself from dgh_all (workspace + dtc_gru_dgh_offset: the operand-image
+    // trainers pack it with the other operands of their grouped weight-gradient launch)
+    if (dW_hh == nullptr) return dtc::check_launch("gru_bwd");
     // the padding slots of the padded trajectory layout have dgh = 0: with the caller's list of valid slots the product skips them
     if (valid_rows && n_valid >= 1024 && n_valid < T * R && dtc_get_gemm_split() && 3ll * H * H >= 128 * 128)
         return dtc_linear_wgrad_rows(dgh_all, 3 * H, (int64_t)T * R, hs_all, H, (int64_t)T * R, valid_rows, dW_hh, db_hh, wg_ws, n_valid, 3 * H, H,

@@ -234,6 +234,7 @@ _SIGS = {
     "dtc_randperm": (C.c_int, [c_i64p, C.c_int64, C.c_uint64, c_stream]),
     "dtc_gru_step_fwd": (C.c_int, [c_f32p] * 7 + [C.c_int, C.c_int, c_stream]),
     "dtc_gru_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "dtc_gru_dgh_offset": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dtc_gru_fwd": (C.c_int, [c_f32p] * 7 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_gru_bwd": (C.c_int, [c_f32p] * 9 + [C.c_void_p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_set_concurrency_hint": (None, [C.c_int]),

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import torch
 
-from .. import _ffi, distributed as dp, ops
+from .. import _ffi, distributed as dp, h2i, ops
 from .._ffi import seg, segmat
 from ..modules.actor_critic_recurrent import ActorCriticRecurrent
 from ..storage import RolloutStorage
@@ -55,6 +55,15 @@ class RecurrentPPO:
         self.overlap = os.environ.get("DTC_OVERLAP_LANES", "1") != "0" and os.environ.get("DTC_OVERLAP_WGRAD", "1") != "0"
         self._lanes = None
         self._wimages = None
+        # every GEMM outside the GRU time steps on block-scaled fp16 operand images (dtc_amd/h2i.py; DTC_H2I=0: round 4's converting
+        # kernels): the input projection reads the padded observations' valid rows as an image packed once per update and mini-batch,
+        # the MLP activations / gradients live as images, and the weight gradients of a recurrence -- W_ih, W_hh and the MLP layers --
+        # are ONE grouped image-operand launch on the weight-gradient stream
+        self.use_images = os.environ.get("DTC_H2I", "1") != "0"
+        self._imgs = {}                    # name -> h2i.HImage (persistent per name and shape)
+        self._wset = None                  # h2i.WeightSet: the step's weight images, rebuilt by one launch per optimisation step
+        self._pack_gen, self._pack_slot, self._pack_key = None, 0, {}
+        self._wg_ws = {}
 
     def _require_gpu(self):
         if self.optimizer is None:
@@ -176,8 +185,14 @@ class RecurrentPPO:
         _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap)))
         if self._wimages is None:
             self._wimages = ops.WeightImages()
-        with self._wimages:                          # weight images of the step's split-path layers: one launch
-            self._forward_backward(ln, batch, stats, unpad_idx, store_idx, M, T, R, dev)
+        if self._image_mode(M):
+            if self._wset is None:
+                self._wset = h2i.WeightSet()
+            self._wset.rebuild()                     # the optimiser wrote the weights since the images were built: one grouped launch
+            self._forward_backward_images(ln, batch, stats, unpad_idx, store_idx, M, T, R, dev)
+        else:
+            with self._wimages:                      # weight images of the step's split-path layers: one launch
+                self._forward_backward(ln, batch, stats, unpad_idx, store_idx, M, T, R, dev)
         arena = ac.arena
         dp_adaptive = dp.world_size() > 1 and self.desired_kl is not None and self.schedule == 'adaptive'
         if dp.world_size() > 1:
@@ -234,6 +249,126 @@ class RecurrentPPO:
         head_backward(ac.A, a_outs, a_saved, ac.memory_a, dmean)
         ln.join()
 
+    # ---------------------------------------------------------------- the same step on operand images
+    def _image_mode(self, M):
+        ac = self.actor_critic
+        return (self.use_images and ops.SPLIT and M % 128 == 0 and ac.memory_a.kind == 'gru' and ac.memory_c.kind == 'gru'
+                and ac.memory_a.num_layers == 1 and ac.memory_c.num_layers == 1 and ac.rnn_hidden_size % 128 == 0)
+
+    def _img(self, name, M, K, dev):
+        key = (name, int(M), int(K))
+        im = self._imgs.get(key)
+        if im is None:
+            im = self._imgs[key] = h2i.HImage(M, K, dev)
+        return im
+
+    def _packed_obs(self, name, x, unpad_idx, M, dev):
+        """Image of the valid rows of the padded observations x [T, R, I].  Inside an update the generator yields the SAME
+        trajectories for mini-batch i in every epoch (rollout_storage.py:217-267: no shuffling), so each mini-batch's image is packed
+        once per update into its own buffer; outside an update (pack_gen None) every call packs."""
+        slot = self._pack_slot if self._pack_gen is not None else 0
+        im = self._img(f"{name}@{slot}", M, x.shape[-1], dev)
+        key = None if self._pack_gen is None else self._pack_gen
+        if key is None or self._pack_key.get((name, slot)) != key:
+            x2 = x.float().contiguous().view(-1, x.shape[-1])     # (the generator's slice of the padded trajectories: copied only here)
+            im.pack(segmat([seg(x2, 0, x2.shape[1], gather=True)], unpad_idx), M)
+            self._pack_key[(name, slot)] = key
+        return im
+
+    def _forward_backward_images(self, ln, batch, stats, unpad_idx, store_idx, M, T, R, dev):
+        ac, st = self.actor_critic, self.storage
+        arena, wset = ac.arena, self._wset
+        (obs_b, cobs_b, _a, _v, _adv, _r, _lp, _mu, _sg, (hid_a, hid_c), masks) = batch
+        H = ac.rnn_hidden_size
+        ln.begin(self.overlap)
+
+        def head_forward(name, mem, layers, x, hidden):
+            ximg = self._packed_obs("x_" + name, x, unpad_idx, M, dev)
+            gi_c = torch.empty(M, 3 * H, device=dev)
+            h2i.linear_fwd(ximg, mem.W_ih, mem.b_ih, gi_c, None, None, wset=wset)
+            gi = mem._padded_gi(T * R, 3 * H, dev)
+            ops.scatter_rows(gi_c, unpad_idx, gi)
+            h0, _ = mem._split(hidden)
+            hs_all, gates, hn = torch.empty(T + 1, R, H, device=dev), torch.empty(T, R, 3 * H, device=dev), torch.empty(T, R, H, device=dev)
+            ws = ops.workspace(ops.gru_workspace_bytes(T, R, H), dev)
+            ops.gru_fwd(gi.view(T, R, 3 * H), h0[0].contiguous(), mem.W_hh, mem.b_hh, hs_all, gates, hn, ws)
+            # the MLP reads the un-padded outputs as an image; its hidden activations leave as fp32 (ELU derivative) AND as images
+            hx = self._img("hx_" + name, M, H, dev).pack(segmat([seg(hs_all[1:].reshape(T * R, H), 0, H, gather=True)], unpad_idx), M)
+            outs, imgs = [], [hx]
+            for li, L in enumerate(layers):
+                o = torch.empty(M, L.n_out, device=dev)
+                oi = self._img(f"o{li}_{name}", M, L.n_out, dev) if li < len(layers) - 1 else None
+                h2i.linear_fwd(imgs[-1], L.W, L.b, o, oi, L.act, wset=wset)
+                outs.append(o)
+                imgs.append(oi)
+            return dict(name=name, mem=mem, layers=layers, ximg=ximg, hs_all=hs_all, gates=gates, hn=hn, ws=ws, outs=outs, imgs=imgs,
+                        keep=[gi_c])
+
+        def head_backward(hd, dOut):
+            name, mem, layers, outs, imgs = hd["name"], hd["mem"], hd["layers"], hd["outs"], hd["imgs"]
+            jobs = []
+            dZi = self._img("dout_" + name, M, dOut.shape[1], dev).pack(dOut)
+            d_in = torch.empty(M, H, device=dev)
+            for li in range(len(layers) - 1, -1, -1):
+                L = layers[li]
+                jobs.append((dZi, imgs[li], L.gW, 0, L.gb))
+                if li > 0:
+                    dXi = self._img(f"d{li}_{name}", M, L.n_in, dev)
+                    h2i.linear_dgrad(dZi, L.W, None, dXi, Xsaved=outs[li - 1], act=layers[li - 1].act, wset=wset)
+                    dZi = dXi
+                else:
+                    h2i.linear_dgrad(dZi, L.W, d_in, None, wset=wset)
+            dhs = torch.zeros(T * R, H, device=dev)
+            ops.scatter_rows(d_in, unpad_idx, dhs)
+            dgi, dh0 = torch.empty(T, R, 3 * H, device=dev), torch.empty(R, H, device=dev)
+            ops.gru_bwd(dhs.view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], mem.W_hh, dgi, None, None, dh0, hd["ws"])
+            # the recurrence's two weight gradients over the VALID (t, r) slots: dgh / dgi / h_{t-1} rows gathered into images
+            rows = lambda t, w: segmat([seg(t, 0, w, gather=True)], unpad_idx)
+            dghi = self._img("dgh_" + name, M, 3 * H, dev).pack(rows(ops.gru_dgh_all(hd["ws"], T, R, H), 3 * H), M)
+            dgii = self._img("dgi_" + name, M, 3 * H, dev).pack(rows(dgi.view(T * R, 3 * H), 3 * H), M)
+            hpi = self._img("hp_" + name, M, H, dev).pack(rows(hd["hs_all"][:T].reshape(T * R, H), H), M)
+            jobs.append((dghi, hpi, mem.gW_hh, 0, mem.gb_hh))
+            jobs.append((dgii, hd["ximg"], mem.gW_ih, 0, mem.gb_ih))
+            # one grouped launch on the weight-gradient stream, behind everything this lane has issued
+            need = h2i.wgrad_group_workspace_bytes(jobs, M)
+            wg = self._wg_ws.get(name)
+            if wg is None or wg.numel() * wg.element_size() < need:
+                torch.cuda.synchronize()
+                wg = self._wg_ws[name] = ops.workspace(need, dev)
+            if self.overlap:
+                ev = ln.event()
+                ev.record()
+                ln.side.wait_event(ev)
+                h2i.wgrad_group(jobs, M, wg, stream_ptr=ln.side.cuda_stream)
+                ln.side_busy = True
+            else:
+                h2i.wgrad_group(jobs, M, wg)
+            hd["keep"] += [d_in, dhs, dgi, dh0, jobs]
+
+        with ln.lane("aux"):
+            hc = head_forward("c", ac.memory_c, ac.Cr, cobs_b, hid_c)
+        ha = head_forward("a", ac.memory_a, ac.A, obs_b, hid_a)
+        ln.order("aux", "main")
+        mean, value = ha["outs"][-1], hc["outs"][-1]
+        ac._dist = (mean, ac.std_view.detach().expand_as(mean))
+        ac._actor_outs, ac._critic_outs = ha["outs"], hc["outs"]
+        ac.memory_a.saved = dict(hs_all=ha["hs_all"], out=ha["hs_all"][1:])
+        ac.memory_c.saved = dict(hs_all=hc["hs_all"], out=hc["hs_all"][1:])
+        dmean, dval = torch.empty_like(mean), torch.empty(M, 1, device=dev)
+        lws = ops.workspace(_ffi.lib().dtc_loss_workspace(M), dev)
+        flat = lambda k: st.flat(k)
+        ops.ppo_loss(mean, ac.std_view, value, flat("actions"), flat("actions_log_prob"), flat("mu"), flat("sigma"),
+                     flat("advantages"), flat("returns"), flat("values"), store_idx, self._loss_cfg(), dmean, dval,
+                     ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, lws)
+        if dp.world_size() > 1 and self.desired_kl is not None and self.schedule == 'adaptive':
+            arena.kl_slot.copy_(stats[S_KL:S_KL + 1])            # the KL mean travels in the header of the gradient exchange
+        ln.order("main", "aux")
+        with ln.lane("aux"):
+            head_backward(hc, dval)
+        head_backward(ha, dmean)
+        ln.join()
+        self._held = (ha, hc, dmean, dval, lws)                 # (until the next step: nothing here returns to the allocator early)
+
     def update(self):
         self._require_gpu()
         st = self.storage
@@ -244,10 +379,15 @@ class RecurrentPPO:
         k = 0
         for mem in (self.actor_critic.memory_a, self.actor_critic.memory_c):
             mem.new_update()
-        for batch in st.reccurent_mini_batch_generator(nmb, epochs):
-            i = k % nmb
-            self.step_minibatch(batch, i * mb, (i + 1) * mb, stats[k])
-            k += 1
+        self._pack_gen = (self._pack_gen or 0) + 1      # the observation images of this update: packed once per mini-batch
+        try:
+            for batch in st.reccurent_mini_batch_generator(nmb, epochs):
+                i = k % nmb
+                self._pack_slot = i
+                self.step_minibatch(batch, i * mb, (i + 1) * mb, stats[k])
+                k += 1
+        finally:
+            self._pack_gen = None
         host = stats.cpu()
         self.learning_rate = float(self.optimizer.lr_dev.item())
         self.last_update_stats = host

@@ -744,13 +744,21 @@ def gru_fwd(gi, h0, W_hh, b_hh, hs_all, gates, hn, ws):
 
 def gru_bwd(dhs, hs_all, gates, hn, W_hh, dgi, dW_hh, db_hh, dh0, ws, rows=None):
     """`rows`: the valid (t, r) slots t * R + r of a padded trajectory batch (int64 device index): the W_hh weight gradient skips
-    the padding slots (their gradients are zero)."""
+    the padding slots (their gradients are zero).  dW_hh = db_hh = None: no W_hh weight gradient (see gru_dgh_all)."""
     T, R, H = dhs.shape
-    use = rows is not None and WGRAD_ROWS
+    use = rows is not None and WGRAD_ROWS and dW_hh is not None
     check(lib().dtc_gru_bwd(cptr(dhs, f32), cptr(hs_all, f32), cptr(gates, f32), cptr(hn, f32), cptr(W_hh, f32),
-                            cptr(dgi, f32), cptr(dW_hh, f32), cptr(db_hh, f32), cptr(dh0, f32), ptr(ws),
+                            cptr(dgi, f32), cptr(dW_hh, f32) if dW_hh is not None else None,
+                            cptr(db_hh, f32) if db_hh is not None else None, cptr(dh0, f32), ptr(ws),
                             cptr(rows, torch.int64) if use else None, rows.numel() if use else 0, T, R, H,
                             stream()), "dtc_gru_bwd")
+
+
+def gru_dgh_all(ws, T, R, H):
+    """dgh_all [T * R, 3H] inside the workspace of a dtc_gru_bwd call (the gradient w.r.t. the recurrent pre-activations; valid once
+    the call has run): the dZ operand of the W_hh weight gradient when the caller forms it itself (dW_hh = None)."""
+    off = int(lib().dtc_gru_dgh_offset(T, R, H))
+    return ws.view(torch.float32)[off // 4: off // 4 + T * R * 3 * H].view(T * R, 3 * H)
 
 
 def lstm_workspace_bytes(T, R, H) -> int:

@@ -334,7 +334,7 @@ typedef struct DtcH2iWJob {
 } DtcH2iWJob;
 int64_t dtc_h2i_wimage_bytes(const DtcH2iWJob* job);
 int dtc_h2i_wimage_group(const DtcH2iWJob* jobs, int count, void* stream);
-/* the row operand of a product: up to 4 images over the same M rows, side by side along the reduction (at most 1024 columns in all) */
+/* the row operand of a product: up to 4 images over the same M rows, side by side along the reduction (at most 2048 columns in all) */
 typedef struct DtcH2iOperand {
     int32_t nseg;
     int32_t width[4];
@@ -603,7 +603,11 @@ int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, const float
 /* BPTT.  dhs [T,R,H] = gradient w.r.t. the outputs h_1..h_T.  Produces dgi [T,R,3H] (gradient w.r.t. gi:
  * feed it to dtc_linear_wgrad with x for W_ih / b_ih), dW_hh [3H,H], db_hh [3H] and dh0 [R,H].
  * valid_rows (optional, n_valid entries of t * R + r): the (t, r) slots that belong to a trajectory -- the padding slots of the
- * padded layout carry zero gradient, and on the split-precision path the W_hh weight gradient then skips them. */
+ * padded layout carry zero gradient, and on the split-precision path the W_hh weight gradient then skips them.
+ * dW_hh == db_hh == NULL: the W_hh weight gradient is left to the caller, who finds dgh_all [T,R,3H] (gradient w.r.t. the recurrent
+ * pre-activations gh_t) at workspace + dtc_gru_dgh_offset(T, R, H) once the call has run -- dW_hh = dgh_all^T hs_all[:T], db_hh =
+ * colsum(dgh_all); the operand-image trainers pack both into images and add the product to their grouped weight-gradient launch. */
+int64_t dtc_gru_dgh_offset(int T, int R, int H);
 int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* gates, const float* hn, const float* W_hh,
                 float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace, const int64_t* valid_rows, int n_valid,
                 int T, int R, int H, void* stream);

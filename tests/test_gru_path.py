@@ -245,3 +245,42 @@ def test_runner_drives_the_recurrent_actor_critic_by_name():
     with pytest.raises(AttributeError, match="vae"):       # the MLP actor-critic resolves by name too; only PPO-with-VAE trains here
         OnPolicyRunner(ReplayEnv(32, DEV), dict(cfg, policy=dict(), runner=dict(cfg["runner"], policy_class_name="ActorCritic",
                                                                                algorithm_class_name="PPO")), device=DEV)
+
+
+@pytest.mark.gpu
+def test_recurrent_operand_image_path_next_to_the_converting_kernels():
+    """RecurrentPPO at 256 envs x 24 (mini-batch = 1536 rows = 12 row tiles): the step on operand images (input projection from the
+    packed valid rows, MLPs on images, W_ih / W_hh / MLP weight gradients as ONE grouped image launch per recurrence with dgh_all
+    taken from dtc_gru_bwd's workspace) against the same step on round 4's converting kernels (use_images = False) -- same inputs,
+    same weights: forward outputs to 1e-5, every parameter gradient to 2e-5 of its tensor's largest element."""
+    from dtc_amd.algorithms import RecurrentPPO
+    from dtc_amd.modules import ActorCriticRecurrent
+    n = 256
+    d = S.rollout(n, 24, seed=11, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    hid = [0.1 * torch.randn(24, 1, n, 512, generator=g, device=DEV) for _ in range(2)]
+    res = []
+    for images in (True, False):
+        torch.manual_seed(3)
+        ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+                                  activation='elu', rnn_type='gru', rnn_hidden_size=512, rnn_num_layers=1)
+        alg = RecurrentPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV)
+        alg.init_storage(n, 24, [53], [1389], [12])
+        alg.use_images, alg.capture_grads = images, True
+        for k, v in d.items():
+            if k not in ("last_values", "observation_histories"):
+                getattr(alg.storage, k).copy_(v)
+        alg.storage.compute_returns(d["last_values"], 0.99, 0.95)
+        alg.storage.saved_hidden_states_a, alg.storage.saved_hidden_states_c = [hid[0]], [hid[1]]
+        batch = next(iter(alg.storage.reccurent_mini_batch_generator(4, 1)))
+        assert alg._image_mode(24 * n // 4) == images
+        row = alg.step_minibatch(batch, 0, n // 4).cpu()
+        res.append((ac._actor_outs[-1].clone(), ac._critic_outs[-1].clone(), row, alg.captured["main"].clone(), ac.arena))
+    (m1, v1, r1, g1, ar), (m0, v0, r0, g0, _) = res
+    np.testing.assert_allclose(m1.cpu().numpy(), m0.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(v1.cpu().numpy(), v0.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(r1.numpy(), r0.numpy(), rtol=1e-5, atol=1e-6)
+    for name, (off, cnt, _shape) in ar.offsets.items():
+        a, b = g1[off:off + cnt], g0[off:off + cnt]
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) / scale <= 2e-5, (name, float((a - b).abs().max()) / scale)
