@@ -17,8 +17,9 @@ from __future__ import annotations
 
 import torch
 
-from .. import _ffi, distributed as dp, ops
+from .. import _ffi, distributed as dp, h2i, ops
 from .._ffi import seg, segmat
+from ..modules.actor_critic_decoder import Dense
 from ..modules.actor_critic_decoder_recurrent import ActorCriticDecoderRecurrent
 from ..utils import split_and_pad_trajectories, true_indices
 from .ppo import PPO, S_GNORM, S_KL, S_RECONS, S_SURR, S_VALUE, S_VEL, S_KLD, STAT_COLS
@@ -87,8 +88,15 @@ class RecurrentDecoderPPO(PPO):
         return t
 
     def _ppo_step_recurrent(self, fw, tw, flat, bt, eps, stats, cfg):
-        with self._images("ppo_recurrent"):                        # weight images of the step's split-path layers: one launch
-            early = self._ppo_recurrent_forward_backward(fw, tw, flat, bt, eps, stats, cfg)
+        if self._image_mode(fw):
+            # every GEMM outside the GRU time steps on operand images (dtc_amd/h2i.py), as in PPO._ppo_step
+            tw.narrow_wgrad = True
+            wset = self._wset("ppo_recurrent")
+            wset.rebuild()
+            early = self._ppo_recurrent_forward_backward_images(fw, tw, flat, bt, eps, stats, cfg, wset)
+        else:
+            with self._images("ppo_recurrent"):                    # weight images of the step's split-path layers: one launch
+                early = self._ppo_recurrent_forward_backward(fw, tw, flat, bt, eps, stats, cfg)
         if not early:
             self._allreduce_grads(self.optimizer)
         self._lr_from_header(stats)
@@ -179,6 +187,113 @@ class RecurrentDecoderPPO(PPO):
         self._join(tw)
         return early
 
+    def _ppo_recurrent_forward_backward_images(self, fw, tw, flat, bt, eps, stats, cfg, wset):
+        """The policy step with BPTT on operand images: encoders as in PPO._ppo_forward_backward, the GRU input projections read their
+        feature blocks as images (the critic's packed once per update and mini-batch; the actor's = the l_t image + the packed
+        observations + the latent kernel's [z | mu[:, :3]] image), the MLP heads live on images, and the weight gradients -- MLPs, W_hh
+        (dgh_all gathered from dtc_gru_bwd's workspace), W_ih by feature block -- join the bucket's grouped image launches."""
+        ac = self.actor_critic
+        H, M = ac.rnn_hidden_size, tw.B
+        idx, unpad_idx, T, R = bt["idx"], bt["unpad_idx"], bt["T"], bt["R"]
+        dev = idx.device
+        obs, priv = flat["observations"], flat["privileged_observations"]
+        imn = self.narrow_images
+        ns = False
+        _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap_wgrad)))
+        tw.begin(self.overlap_lanes and self.overlap_wgrad)
+        tw.live_img.clear()
+        rows = lambda t, w: segmat([seg(t, 0, w, gather=True)], unpad_idx)
+
+        def head_forward(name, X, cols, mem, proj, layers, h0):
+            gi_v = tw.g("gi_" + name, 3 * H)
+            h2i.linear_fwd(X, proj.W, proj.b, gi_v, None, None, wset=wset, cols=cols)
+            gi_p = self._padded(tw, "gi_" + name, T * R, 3 * H)     # padded steps keep finite stale values (never used)
+            ops.scatter_rows(gi_v, unpad_idx, gi_p)
+            hs_all = torch.empty(T + 1, R, H, device=dev)
+            gates, hn = torch.empty(T, R, 3 * H, device=dev), torch.empty(T, R, H, device=dev)
+            ws = ops.workspace(ops.gru_workspace_bytes(T, R, H), dev)
+            ops.gru_fwd(gi_p.view(T, R, 3 * H), h0.contiguous(), mem.W_hh, mem.b_hh, hs_all, gates, hn, ws)
+            hx = tw.img("hx_" + name, H).pack(rows(hs_all[1:].reshape(T * R, H), H), M)
+            outs, imgs = [], [hx]
+            for li, L in enumerate(layers):
+                o = tw.g(f"{name}_o{li}", L.n_out)
+                oi = tw.img(f"{name}_o{li}", L.n_out) if li < len(layers) - 1 else None
+                h2i.linear_fwd(imgs[-1], L.W, L.b, o, oi, L.act, wset=wset)
+                outs.append(o)
+                imgs.append(oi)
+            return dict(name=name, X=X, cols=cols, mem=mem, proj=proj, layers=layers, hs_all=hs_all, gates=gates, hn=hn, ws=ws,
+                        outs=outs, imgs=imgs)
+
+        def head_backward(hd, dOut):
+            """MLP backward, BPTT, the recurrence's weight gradients; returns the image of dgi over the valid rows."""
+            name, layers, outs, imgs, mem = hd["name"], hd["layers"], hd["outs"], hd["imgs"], hd["mem"]
+            dZi = tw.img("dout_" + name, dOut.shape[1]).pack(dOut)
+            d_in = tw.g(f"{name}_d0", H)
+            for li in range(len(layers) - 1, -1, -1):
+                L = layers[li]
+                self._bwd_img(tw, L, dZi, imgs[li])
+                if li > 0:
+                    dXi = tw.img(f"{name}_d{li}", L.n_in)
+                    h2i.linear_dgrad(dZi, L.W, None, dXi, Xsaved=outs[li - 1], act=layers[li - 1].act, wset=wset)
+                    dZi = dXi
+                else:
+                    h2i.linear_dgrad(dZi, L.W, d_in, None, wset=wset)
+            dhs = self._padded(tw, "dhs_" + name, T * R, H)
+            dhs.zero_()
+            ops.scatter_rows(d_in, unpad_idx, dhs)
+            dgi_p, dh0 = torch.empty(T, R, 3 * H, device=dev), torch.empty(R, H, device=dev)
+            ops.gru_bwd(dhs.view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], mem.W_hh, dgi_p, None, None, dh0, hd["ws"])
+            dghi = tw.img("dgh_" + name, 3 * H).pack(rows(ops.gru_dgh_all(hd["ws"], T, R, H), 3 * H), M)
+            dgii = tw.img("dgi_" + name, 3 * H).pack(rows(dgi_p.view(T * R, 3 * H), 3 * H), M)
+            hpi = tw.img("hp_" + name, H).pack(rows(hd["hs_all"][:T].reshape(T * R, H), H), M)
+            self._bwd_img(tw, Dense(mem.W_hh, mem.b_hh, mem.gW_hh, mem.gb_hh, None), dghi, hpi)
+            tw.held.append((dgi_p, dh0, hd))
+            return dgii
+
+        with tw.lane("aux"):
+            Xc = ac.packed_input(fw, "p_c", ac.critic_input(obs, flat["base_vel"], priv, idx), idx, reuse=True)
+            hc = head_forward("c", Xc, None, ac.memory_c, ac.proj_c, ac.Cr, bt["hid_c"])
+        ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=self.relu_masks, split=ns, images=imn, wset=wset)
+        ac.terrain_encoder_(fw, priv, idx, masks=self.relu_masks, images=True, wset=wset, lt_fp32=False)
+        if imn:        # the actor's features as three images: l_t, the gathered observations (packed once), the latent kernel's [z | mu[:, :3]]
+            Xa = [fw.img("lt"), ac.packed_input(fw, "p_obs", segmat([seg(obs, 0, ac.num_obs, gather=True)], idx), idx, reuse=True), fw.cur["p_zmu"]]
+            a_cols = [ac.num_obs + 19, 0, ac.num_obs]
+        else:
+            Xa = [fw.img("lt"), ac.packed_input(fw, "p_a", segmat([seg(obs, 0, ac.num_obs, gather=True), seg(fw.z, 0, 16), seg(fw.mulv, 0, 3)], idx))]
+            a_cols = [ac.num_obs + 19, 0]
+        ha = head_forward("a", Xa, a_cols, ac.memory_a, ac.proj_a, ac.A, bt["hid_a"])
+        tw.order("aux", "main")
+        if self.after_forward_hook is not None:
+            self.after_forward_hook(fw, "ppo")
+        mean, value = ha["outs"][-1], hc["outs"][-1]
+        ops.ppo_loss(mean, ac.std_view, value, flat["actions"], flat["actions_log_prob"], flat["mu"], flat["sigma"],
+                     flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval, ac.std_grad,
+                     stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws)
+        self._kl_to_header(stats)
+        tw.order("main", "aux")
+        with tw.lane("aux"):
+            dgii_c = head_backward(hc, tw.dval)
+            self._bwd_img(tw, hc["proj"], dgii_c, Xc)
+        dgii_a = head_backward(ha, tw.dmean)
+        # the actor features' gradient fans out to z, mu[:, :3] (fp32) and l_t (image); the observations need none
+        tw.dmulv.zero_()
+        nb = ac.num_obs + 19
+        for i, (xi, c0) in enumerate(zip(Xa, a_cols)):
+            self._bwd_img(tw, ha["proj"], dgii_a, xi, wcol0=c0, bias=i == 0)
+        h2i.linear_dgrad(dgii_a, ha["proj"].W, segmat([seg(None, 0, 512), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3)]), tw.img("dlt", 512),
+                         window=[(nb, 512), (ac.num_obs, 19)], wset=wset)
+        tw.live_img |= {"dlt"}
+        early = self._exchange_bucket(tw, "main_only")
+        tw.order("main", "aux")                                    # dz, d mu[:, :3] are written
+        self._terrain_encoder_backward(fw, tw, flat, idx, wset)
+        with tw.lane("aux"):
+            ops.cenet_latent_bwd(tw.dmulv, tw.dz, eps, fw.mulv, fw.mask, fw.info, fw.lat_ws)
+            self._cenet_encoder_backward(fw, tw, flat, idx, split=ns, wset=wset if imn else None)
+        if early:
+            self._exchange_bucket(tw, "shared")
+        self._join(tw)
+        return early
+
     def step_minibatch(self, bt, eps1, eps2, which="both", stats=None):
         """One recurrent mini-batch `bt` (an item of `recurrent_slices`): VAE step, policy step, or both."""
         self._require_gpu()
@@ -189,6 +304,10 @@ class RecurrentDecoderPPO(PPO):
         flat = {k: st.flat(k) for k in self._FLAT_NAMES}
         self._amax_static(flat)
         fw, tw = ac._fwd_ws(B), self._train_ws(B)
+        own_gen = fw.pack_gen is None                 # outside update(): the packed rollout rows serve this call only
+        if own_gen:
+            self._pack_gen = getattr(self, "_pack_gen", 0) + 1
+            fw.pack_gen, fw.pack_slot = self._pack_gen, 0
         self.optimizer.set_lr(self.learning_rate)
         stats = torch.zeros(STAT_COLS, dtype=torch.float32, device=dev) if stats is None else stats
         if which in ("vae", "both"):
@@ -196,6 +315,8 @@ class RecurrentDecoderPPO(PPO):
         if which in ("ppo", "both"):
             self._ppo_step_recurrent(fw, tw, flat, bt, eps2.to(dev).contiguous(), stats, self._loss_cfg())
         ops.amax_static_clear()
+        if own_gen:
+            fw.pack_gen = None
         return stats
 
     def update(self, eps1=None, eps2=None, return_stats=False):
@@ -216,10 +337,17 @@ class RecurrentDecoderPPO(PPO):
                 buf.zero_()
         slices = list(self.recurrent_slices())
         k = 0
-        for _ in range(epochs):
-            for bt in slices:
-                self.step_minibatch(bt, eps1[k], eps2[k], "both", stats[k])
-                k += 1
+        fw = ac._fwd_ws(B)
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1
+        fw.pack_gen = self._pack_gen                   # the slices are the same in every epoch: their packed rollout rows serve all five
+        try:
+            for _ in range(epochs):
+                for i, bt in enumerate(slices):
+                    fw.pack_slot = i
+                    self.step_minibatch(bt, eps1[k], eps2[k], "both", stats[k])
+                    k += 1
+        finally:
+            fw.pack_gen = None
         host = stats.cpu()                       # the single device -> host synchronisation of the update
         self.learning_rate = float(self.optimizer.lr_dev.item())
         for g in self.optimizer.param_groups:
