@@ -311,7 +311,9 @@ struct TileArgs {
 // workgroup calls it; on return the tile's global stores are ISSUED (not necessarily complete).
 #ifdef __HIP_DEVICE_COMPILE__
 typedef const AS4 TileArgs CTileArgs;
-template <int EPI>
+// TM = 2: 128-row tiles (2 x 2 waves of 64 x 64); TM = 1: 64-row tiles (2 x 2 waves of 32 x 64: half a chunk of the row operand per
+// stage) for the launches whose 128-row tiles would leave CUs without a workgroup (the 128-column layers: 192 tiles on 256 CUs).
+template <int EPI, int TM>
 __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const int tr, const int tc, const int slot,
                                          unsigned long long* __restrict__ trace) {
     const auto& A = L.A;
@@ -325,7 +327,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
     const int M = L.M, N = L.N, act = L.act, wide = L.wide, ldwm = L.ldwm;
     unsigned short* __restrict__ wmask = L.wmask;
     const auto& dg = L.dg;
-    constexpr int BN = 128, WN = 2, TM = 2, TN = 2;
+    constexpr int BN = 128, WN = 2, TN = 2, BMT = 64 * TM;
 #define XS(b) ((b) == 0 ? Xs0 : (b) == 1 ? Xs1 : Xs2)
 #define WS(b) ((b) == 0 ? Ws0 : (b) == 1 ? Ws1 : Ws2)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -333,7 +335,10 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
     if (trace && tid == 0) {                              // debug (dtc_h2i_trace): per-workgroup time stamps (100 MHz) and placement
         trace[4 * slot] = __builtin_amdgcn_s_memrealtime();
     }
-    const int m0 = tr * BM, n0 = tc * BN;
+    const int m0 = tr * BMT, n0 = tc * BN;
+    const int ctile = m0 >> 7, crow0 = m0 & 127;                      // the 128-row chunk tile this tile lies in, its first row there
+    const u32 xsub = (u32)crow0 * 32u;                                // ... = byte offset inside a plane (slot = 2 x row)
+    const u32 xlane = (TM == 2 || tid < 128) ? 0u : INVALID;          // 64-row tiles: half a plane per stage (the upper lanes fetch nothing)
     const int wm_off = (wave / WN) * (32 * TM), wn_off = (wave % WN) * (32 * TN);
     const int half = lane >> 5, l31 = lane & 31;
     const rsrc_t wres = make_rsrc_bytes(wimg, wimg_bytes);
@@ -347,13 +352,13 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
     // ---- loader cursor (one stage ahead of the MFMAs)
     int lseg = 0, lleft = A.s[0].stages, left = A.total;
     rsrc_t xres = make_rsrc_bytes(A.s[0].img, A.s[0].bytes);
-    u32 xchunk = (u32)(tr * A.s[0].stages) * (u32)HI_CHUNK, wchunk = (u32)(tc * A.total) * (u32)HI_CHUNK;
+    u32 xchunk = (u32)(ctile * A.s[0].stages) * (u32)HI_CHUNK + xsub, wchunk = (u32)(tc * A.total) * (u32)HI_CHUNK;
     auto load_stage = [&](auto nbc) {                   // next stage -> LDS[nbuf]; past the last stage: out-of-range lanes, zeros land
         constexpr int nbuf = decltype(nbc)::value;
         const u32 voff = lane_off | (left > 0 ? 0u : INVALID);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)&XS(nbuf)[p][wave * 128], 16, voff, xchunk + p * HI_PLANE, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)&XS(nbuf)[p][wave * 128], 16, voff | xlane, xchunk + p * HI_PLANE, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)&WS(nbuf)[p][wave * 128], 16, voff, wchunk + p * HI_PLANE, 0, 0);
         }
         xchunk += HI_CHUNK;
@@ -364,7 +369,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
             const HSeg sg = hseg_at(A, lseg);
             lleft = sg.stages;
             xres = make_rsrc_bytes(sg.img, sg.bytes);
-            xchunk = (u32)(tr * sg.stages) * (u32)HI_CHUNK;
+            xchunk = (u32)(ctile * sg.stages) * (u32)HI_CHUNK + xsub;
         }
     };
     load_stage(S0{});
@@ -372,11 +377,11 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
 
     // ---- exponent deltas: thread r < 128 walks the blocks of row r.  e(b) = row exponent + weight-block exponent; a block without
     // content (HI_EZERO) inherits its predecessor's (its products are zero whatever the scale)
-    if (tid < 128) {
+    if (tid < BMT) {
         int prev_a = 0, prev_w = 0, prev = 0, b = 0;
         for (int i = 0; i < A.nseg; ++i) {
             const HSeg sg = hseg_at(A, i);
-            const int* ex = sg.exps + (long long)tr * sg.kbs * 128 + tid;
+            const int* ex = sg.exps + (long long)ctile * sg.kbs * 128 + crow0 + tid;
             for (int k = 0; k < sg.kbs; ++k, ++b) {
                 const int ea = ex[k * 128], ew = wexps[tc * A.tblocks + b];
                 prev_a = ea == HI_EZERO ? prev_a : ea;
@@ -428,8 +433,10 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
         u32x4 a[TM][2], b[TN][2];
         auto rda = [&](int i, int p) { a[i][p] = reinterpret_cast<const u32x4*>(&XS(buf)[p][0])[rslot(wm_off + 32 * i + l31, half)]; };
         auto rdb = [&](int j, int p) { b[j][p] = reinterpret_cast<const u32x4*>(&WS(buf)[p][0])[rslot(wn_off + 32 * j + l31, half)]; };
-        rda(0, 1); rdb(0, 0); rda(1, 1);
-        rda(0, 0); rdb(0, 1); rda(1, 0);
+        rda(0, 1); rdb(0, 0);
+        if constexpr (TM == 2) rda(1, 1);
+        rda(0, 0); rdb(0, 1);
+        if constexpr (TM == 2) rda(1, 0);
         __builtin_amdgcn_sched_barrier(0);
         using P = Prec<true>;
         // smallest terms first: lo hi', hi lo', hi hi'
@@ -474,7 +481,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
     if (trace && tid == 0) trace[4 * slot + 1] = __builtin_amdgcn_s_memrealtime();
     // every wave is past its last fragment read and every LDS-DMA has landed (the barrier's wait): LDS becomes the patches
     float* patch = reinterpret_cast<float*>(wave < 2 ? &Xs0[0][0] : &Xs1[0][0]) + (wave & 1) * (32 * LDW);
-    const bool full = (m0 + BM <= M) && (n0 + BN <= N);
+    const bool full = (m0 + BMT <= M) && (n0 + BN <= N);
 
     double sq = 0.0;
     if constexpr (EPI == EPI_MSE) {
@@ -613,7 +620,9 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
         }
     }
     if constexpr (EPI != EPI_MSE) {
-        u32 any = mrow[0][0] | mrow[0][1] | mrow[1][0] | mrow[1][1];
+        u32 any = 0u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) any |= mrow[i][0] | mrow[i][1];
         if (__builtin_amdgcn_ballot_w64(any >= 0x7f800000u) != 0ull) {      // (rare) some row of this wave holds inf / NaN: finite elements only
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -661,7 +670,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
         if (trace && tid == 0) trace[4 * slot + 2] = __builtin_amdgcn_s_memrealtime();
         return;
     }
-    u32x4* tile_chunks = yo.img + (long long)tr * yo.stages * (HI_CHUNK / 16);
+    u32x4* tile_chunks = yo.img + (long long)ctile * yo.stages * (HI_CHUNK / 16);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -669,7 +678,8 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
             const int rloc = wm_off + 32 * i + r16 + 16 * q;
             const u32 m = rm[rloc] > rm[128 + rloc] ? rm[rloc] : rm[128 + rloc];
             const int e = hi_exp(m);
-            if (c8 == 0 && (wave % WN) == 0 && tc < yo.kbs) yo.exps[((long long)tr * yo.kbs + tc) * 128 + rloc] = e;
+            const int rch = crow0 + rloc;                      // the row inside its 128-row chunk
+            if (c8 == 0 && (wave % WN) == 0 && tc < yo.kbs) yo.exps[((long long)ctile * yo.kbs + tc) * 128 + rch] = e;
             const int ee = e == HI_EZERO ? 0 : e;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -677,8 +687,8 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
                 if ((lc >> 4) >= yo.stages) continue;
                 const HiPiece pc = hi_split8(T[i][j][q], ee);
                 u32x4* chunk = tile_chunks + (long long)(lc >> 4) * (HI_CHUNK / 16);
-                chunk[rslot(rloc, (lc >> 3) & 1)] = pc.p[0];
-                chunk[256 + rslot(rloc, (lc >> 3) & 1)] = pc.p[1];
+                chunk[rslot(rch, (lc >> 3) & 1)] = pc.p[0];
+                chunk[256 + rslot(rch, (lc >> 3) & 1)] = pc.p[1];
             }
         }
     if (trace && tid == 0) trace[4 * slot + 2] = __builtin_amdgcn_s_memrealtime();
@@ -689,7 +699,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
 #endif  // __HIP_DEVICE_COMPILE__
 
 // one launch = one layer: XCD-aware block -> tile map (all column tiles of a row tile share an L2)
-template <int EPI>
+template <int EPI, int TM>
 __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const TileArgs L_, const MseEpiH mse, unsigned long long* __restrict__ trace) {
     // the descriptors are read IN PLACE from the kernel-argument segment (first argument = offset 0): binding a reference to the by-value
     // argument would copy it to scratch as soon as one of its arrays is indexed at run time
@@ -697,11 +707,11 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const TileArgs L_, c
     CTileArgs& L = *(CTileArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)L_;
     int tr, tc;
-    if (!map_tile(blockIdx.x, (L.M + BM - 1) / BM, (L.N + 127) / 128, tr, tc)) {
+    if (!map_tile(blockIdx.x, (L.M + 64 * TM - 1) / (64 * TM), (L.N + 127) / 128, tr, tc)) {
         if (EPI == EPI_MSE && threadIdx.x == 0) mse.part[blockIdx.x] = 0.0;
         return;
     }
-    h2i_tile<EPI>(L, mse, tr, tc, (int)blockIdx.x, trace);
+    h2i_tile<EPI, TM>(L, mse, tr, tc, (int)blockIdx.x, trace);
 #endif
 }
 
@@ -884,6 +894,14 @@ extern "C" int dtc_h2i_wimage_group(const DtcH2iWJob* jobs, int count, void* str
 }
 
 namespace {
+// 64-row tiles when 128-row tiles would leave CUs without a workgroup (DTC_H2I_ROWS64_MAX: largest 128-row tile count that still takes
+// them, default 256 = one per CU; 0: never)
+int g_rows64_max = -1;       // dtc_h2i_rows64_max; -1: the environment's value / the default
+bool rows64(int M, int N) {
+    static const int env_tiles = getenv("DTC_H2I_ROWS64_MAX") ? atoi(getenv("DTC_H2I_ROWS64_MAX")) : 256;
+    const int max_tiles = g_rows64_max >= 0 ? g_rows64_max : env_tiles;
+    return dtc::ceil_div(M, BM) * dtc::ceil_div(N, 128) <= max_tiles && M > 64;
+}
 // arguments of one forward layer / one data-gradient layer: validation + descriptors, one place for both
 struct LayerInfo {
     TileArgs t;
@@ -982,6 +1000,10 @@ int dgrad_args(const void* dZimg, int N, const void* wimgT, int Kwin, const DtcS
 }
 }  // namespace
 
+// forward / data-gradient launches with at most `max_tiles` 128 x 128 tiles run on 64-row tiles (default 256 = one tile per CU; 0: never;
+// -1: back to DTC_H2I_ROWS64_MAX / the default).  Results do not depend on it bit for bit (same per-row arithmetic, same exponents).
+extern "C" void dtc_h2i_rows64_max(int max_tiles) { g_rows64_max = max_tiles; }
+
 // Y = act(X W^T + b): X = images side by side, wimg = the image of W built for that walk (trans = 0, rows (0, N), the operand's widths
 // as reduction ranges).  Results: fp32 Y [M, >= N] (may be NULL) and / or the image of Y (Yimg = image(M, N), may be NULL) -- at least one.
 extern "C" int dtc_linear_fwd_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, float* Y, int64_t ldy, void* Yimg,
@@ -991,8 +1013,12 @@ extern "C" int dtc_linear_fwd_h2i(const DtcH2iOperand* X, const void* wimg, cons
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, L.K), L.flop, s, L.bytes);
-    hipLaunchKernelGGL((linear_h2i_kernel<EPI_FWD>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, L.t,
-                       MseEpiH{}, g_trace);
+    if (rows64(M, N))
+        hipLaunchKernelGGL((linear_h2i_kernel<EPI_FWD, 1>), dim3(grid_for((int)dtc::ceil_div(M, 64), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, L.t,
+                           MseEpiH{}, g_trace);
+    else
+        hipLaunchKernelGGL((linear_h2i_kernel<EPI_FWD, 2>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, L.t,
+                           MseEpiH{}, g_trace);
     return dtc::check_launch("linear_fwd_h2i");
 }
 
@@ -1015,7 +1041,7 @@ extern "C" int dtc_linear_fwd_mse_h2i(const DtcH2iOperand* X, const void* wimg, 
     hipStream_t s = (hipStream_t)stream;
     const MseEpiH mse{target, (const long long*)tidx, (long long)ldt, target_rows * ldt * 4, tcol0, scale, sq_part};
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, L.K), L.flop, s, L.bytes + 4.0 * M * N);
-    hipLaunchKernelGGL((linear_h2i_kernel<EPI_MSE>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, L.t,
+    hipLaunchKernelGGL((linear_h2i_kernel<EPI_MSE, 2>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, 128))), dim3(256), 0, s, L.t,
                        mse, g_trace);
     return dtc::check_launch("linear_fwd_mse_h2i");
 }
@@ -1033,7 +1059,11 @@ extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT,
     if (rc != DTC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", M, N, Kwin), L.flop, s, L.bytes);
-    hipLaunchKernelGGL((linear_h2i_kernel<EPI_DGRAD>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(Kwin, 128))), dim3(256), 0, s, L.t,
-                       MseEpiH{}, g_trace);
+    if (rows64(M, Kwin))
+        hipLaunchKernelGGL((linear_h2i_kernel<EPI_DGRAD, 1>), dim3(grid_for((int)dtc::ceil_div(M, 64), (int)dtc::ceil_div(Kwin, 128))), dim3(256), 0, s,
+                           L.t, MseEpiH{}, g_trace);
+    else
+        hipLaunchKernelGGL((linear_h2i_kernel<EPI_DGRAD, 2>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(Kwin, 128))), dim3(256), 0, s,
+                           L.t, MseEpiH{}, g_trace);
     return dtc::check_launch("linear_dgrad_h2i");
 }

@@ -154,6 +154,7 @@ _SIGS = {
     "dtc_probe_mfma_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, c_stream]),
     "dtc_probe_mfma_stream_h2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, c_stream]),
     "dtc_h2i_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "dtc_h2i_rows64_max": (None, [C.c_int]),
     "dtc_h2i_trace": (None, [C.c_void_p]),
     "dtc_h2i_pack": (C.c_int, [C.POINTER(DtcSegMat), C.c_int, C.c_void_p, c_stream]),
     "dtc_h2i_unpack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, C.c_int64, c_stream]),

@@ -316,6 +316,9 @@ int dtc_linear_dgrad_s3(const float* dZ, int64_t lddz, const float* W, const Dtc
  * of dtc_linear_fwd_h2i / _mse_h2i / dtc_linear_dgrad_h2i (results as fp32, as an image, or both), dtc_h2i_wimage_group (weights).
  * dtc_h2i_unpack decodes an image (tests). */
 int64_t dtc_h2i_bytes(int M, int K);
+/* tuning: forward / data-gradient launches with at most max_tiles 128 x 128 result tiles run on 64-row tiles (twice the workgroups; default
+ * 256 = one tile per CU; 0: never; -1: back to DTC_H2I_ROWS64_MAX / the default).  Results are bit-identical either way. */
+void dtc_h2i_rows64_max(int max_tiles);
 void dtc_h2i_trace(void* buf);   /* debug: per-workgroup {start, K loop done, end (100 MHz ticks), HW_ID} records of the launches that follow (NULL: off) */
 int dtc_h2i_pack(const DtcSegMat* X, int M, void* img, void* stream);
 int dtc_h2i_unpack(const void* img, int M, int K, float* out, int64_t ld, void* stream);

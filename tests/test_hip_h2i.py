@@ -12,6 +12,16 @@ DEV = "cuda:0"
 ROW_TOL = 2e-6          # per-row relative error bound (row error / row magnitude), measured ~3e-7
 
 
+@pytest.fixture(autouse=True, params=["rows64_default", "rows128_only"])
+def tile_rows(request):
+    """Every test runs twice: small launches on 64-row tiles (the default for launches of at most one 128 x 128 tile per CU) and
+    everything on 128-row tiles -- the shapes of this file are small enough that the default alone would never reach the latter."""
+    from dtc_amd import _ffi
+    _ffi.lib().dtc_h2i_rows64_max(-1 if request.param == "rows64_default" else 0)
+    yield request.param
+    _ffi.lib().dtc_h2i_rows64_max(-1)
+
+
 def _act(v, act):
     return torch.relu(v) if act == "relu" else torch.nn.functional.elu(v) if act == "elu" else v
 
@@ -364,3 +374,29 @@ def test_images_written_by_the_fused_heads_kernel_equal_a_pack_of_its_fp32_outpu
                        dmean, dval, dHa, dHc, dstd, losses, lr, ws, imgs=imgs)
     for im, t in zip(imgs, (dHa, dHc, dmean, dval)):
         assert torch.equal(im.buf, h2i.HImage.from_tensor(t).buf)
+
+
+def test_64_row_tiles_equal_128_row_tiles_bit_for_bit(tile_rows):
+    """The tile height is scheduling only: forward (fp32 + image result, sign record) and data gradient (image result) of the same
+    operands are bit-identical on 64-row and 128-row tiles (same per-row arithmetic, same exponents)."""
+    if tile_rows != "rows64_default":
+        pytest.skip("one run compares both settings")
+    from dtc_amd import _ffi, h2i, ops
+    g = torch.Generator().manual_seed(31)
+    M, N, K = 640, 128, 265
+    X, W, b = _rows(M, K, g, span=6, zero_frac=0.1).to(DEV), (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV), torch.randn(N, generator=g).to(DEV)
+    dZ = _rows(M, N, g, span=6, zero_frac=0.2).to(DEV)
+    out = []
+    for mx in (-1, 0):
+        _ffi.lib().dtc_h2i_rows64_max(mx)
+        Xi, dZi = h2i.HImage.from_tensor(X), h2i.HImage.from_tensor(dZ)
+        Y, Yi = torch.zeros(M, N, device=DEV), h2i.HImage(M, N, DEV)
+        mask = ops.relu_mask(M, N, DEV).zero_()
+        h2i.linear_fwd(Xi, W, b, Y, Yi, "relu", mask=mask)
+        dXi = h2i.HImage(M, K, DEV)
+        h2i.linear_dgrad(dZi, W, None, dXi)
+        torch.cuda.synchronize()
+        out.append((Y.clone(), Yi.buf.clone(), mask.clone(), dXi.buf.clone()))
+    for a, c in zip(*out):
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a.view(torch.int64) if a.dtype == torch.float64 else a,
+                           c.view(torch.int32) if c.dtype == torch.float32 else c.view(torch.int64) if c.dtype == torch.float64 else c)
