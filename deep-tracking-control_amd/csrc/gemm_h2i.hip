@@ -126,14 +126,31 @@ __global__ __launch_bounds__(256) void h2i_wpack_kernel(const WpackGroup G) {
     const int nst = (int)hi_stages(J.cw[sg]);
     float v[HI_KB][8];
     u32 mx = 0u;
+    // W as stored (not transposed): a thread's 8 columns of a stage are consecutive in memory -- two 16-byte loads where the row allows
+    // it (uniform: leading dimension and first column multiples of 4, 16-byte aligned base)
+    const bool vec = !J.trans && (J.ld & 3) == 0 && (J.c0[sg] & 3) == 0 && (reinterpret_cast<unsigned long long>(J.W) & 15ull) == 0;
 #pragma unroll
     for (int s = 0; s < HI_KB; ++s) {
+        const int cb = (gb * HI_KB + s) * 16 + 8 * h;
+        if (vec && row < nrg && cb + 8 <= J.cw[sg]) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(J.W + (long long)(src0 + row) * J.ld + J.c0[sg] + cb);
+            const f32x4 a = src[0], b2 = src[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[s][e] = a[e];
+                v[s][4 + e] = b2[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = cb + e;
+                const bool ok = row < nrg && c < J.cw[sg];
+                const long long cc = J.c0[sg] + c;
+                v[s][e] = ok ? (J.trans ? J.W[cc * J.ld + src0 + row] : J.W[(long long)(src0 + row) * J.ld + cc]) : 0.f;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = (gb * HI_KB + s) * 16 + 8 * h + e;
-            const bool ok = row < nrg && c < J.cw[sg];
-            const long long cc = J.c0[sg] + c;
-            v[s][e] = ok ? (J.trans ? J.W[cc * J.ld + src0 + row] : J.W[(long long)(src0 + row) * J.ld + cc]) : 0.f;
             const u32 bb = finite_bits(v[s][e]);
             mx = bb > mx ? bb : mx;
         }

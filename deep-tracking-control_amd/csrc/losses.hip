@@ -464,10 +464,16 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(const double* __
 
 __global__ void lr_adapt_kernel(float* __restrict__ kl_mean, double* __restrict__ lr, float desired_kl) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        // The slot is CONSUMED: it is left holding a NaN with a payload of its own (0x7fc0dead), so a step that forgets to deposit its KL
+        // fails loudly (lr = NaN) instead of re-using the previous value.  A KL that is itself NaN (any other payload: a diverged
+        // policy) leaves the learning rate unchanged -- both comparisons of ppo.py:301-307 are false for NaN.  (Data parallel: the slot
+        // rides in the header of a gradient bucket; _kl_to_header re-deposits it before the one exchange whose result is read.)
+        constexpr unsigned SENTINEL = 0x7fc0deadu;
         const float klm = *kl_mean;
-        *kl_mean = __builtin_nanf("");                  // consumed: the next step has to deposit its own value
+        const bool missing = __float_as_uint(klm) == SENTINEL;
+        *kl_mean = __uint_as_float(SENTINEL);
         double cur = *lr;
-        if (klm != klm) cur = (double)klm;              // nothing was deposited (or the KL itself is NaN): fail loudly
+        if (missing) cur = (double)__builtin_nanf("");  // nothing was deposited: fail loudly
         if (klm > desired_kl * 2.0f) cur = fmax(1e-5, cur / 1.5);
         else if (klm < desired_kl / 2.0f && klm > 0.0f) cur = fmin(1e-2, cur * 1.5);
         *lr = cur;

@@ -158,9 +158,9 @@ class Amax:
     def _slot(self, key):
         i = self.index.get(key)
         if i is None:
-            i = self.index[key] = len(self.index)
-            if i >= self.SLOTS:
+            if len(self.index) >= self.SLOTS:          # checked BEFORE the key is registered: a failed request leaves no entry behind
                 raise _ffi.DtcError("Amax: out of slots")
+            i = self.index[key] = len(self.index)
         return self.arena.data_ptr() + self.rec * i
 
     @staticmethod
@@ -182,8 +182,9 @@ class Amax:
         if t is None or col0 != 0 or width != t.shape[1]:
             return None
         key = self._key(t)
+        p = self._slot(key)                            # (may raise: the key must not become `fresh` without a slot)
         self.fresh[key] = t
-        return self._slot(key)
+        return p
 
     def of(self, t, kind=""):
         """Slot a consumer of (any column block of) `t` reads; None: the tensor has none (the library computes its amax)."""
@@ -238,8 +239,10 @@ def _amax_in(t, kind=""):
     return None
 
 
-def _amax_out(t, col0, width):
-    if _IMAGES is not None and _IMAGES.active and t is not None:
+def _amax_out(t, col0, width, rows=None):
+    """`rows`: how many rows the producing kernel writes -- a kernel that covers only part of the tensor publishes the amax of that
+    part, which a consumer of more rows must not scale by: no record is handed out then (the consumer computes the amax in its call)."""
+    if _IMAGES is not None and _IMAGES.active and t is not None and (rows is None or rows == t.shape[0]):
         return amax_registry(t.device).out(t, col0, width)
     return None
 
@@ -267,11 +270,11 @@ def _pub(t):
     return _amax_out(t, 0, t.shape[1])
 
 
-def _h2_destination(dXs):
+def _h2_destination(dXs, rows=None):
     srcs = _sources(dXs)
     for i in range(dXs.nseg):
         s = dXs.seg[i]
-        s.amax = _amax_out(srcs[i], s.col0, s.width) if s.ptr else None
+        s.amax = _amax_out(srcs[i], s.col0, s.width, rows) if s.ptr else None
     return dXs
 
 
@@ -369,6 +372,11 @@ class WeightImages:
         job[0].img = ptr(fresh)
         check((lib().dtc_h2_wimage_group if key[5] else lib().dtc_s3_wimage_group)(job, 1, stream()), "dtc_s3_wimage_group")
         n = int(lib().dtc_s3_planes_bytes(key[2], key[1]) if key[3] else lib().dtc_s3_planes_bytes(key[1], key[2]))
+        if key[5]:
+            # fp16 images: behind the chunks (8 KiB per 128-row tile and 16-k stage) and the 32 partial maxima of |W| the buffer holds the
+            # call-private amax scratch of operands that arrive without a record -- not part of the image, a fresh build has zeros there
+            rows, red = (key[2], key[1]) if key[3] else (key[1], key[2])
+            n = min(n, -(-rows // 128) * -(-red // 16) * 8192 + 4 * 32)
         if not torch.equal(fresh.view(torch.uint8)[:n], e[0].view(torch.uint8)[:n]):
             raise _ffi.DtcError(f"WeightImages: weights of layer N={key[1]} K={key[2]} trans={key[3]} changed inside the block "
                                 "(stale weight image)")
@@ -411,14 +419,14 @@ def linear_fwd(X, W, b, Y, act=None, M=None, mask=None, split=None):
         img, ready = _wimage(W, Xs, N, K, 0, H2)
         if H2:
             check(lib().dtc_linear_fwd_h2(_h2_operand(Xs), cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
-                                          ptr(mask) if mask is not None else None, ptr(img), ready, _amax_out(Y, 0, N), M, N, K, ACT[act],
+                                          ptr(mask) if mask is not None else None, ptr(img), ready, _amax_out(Y, 0, N, M), M, N, K, ACT[act],
                                           stream()), "dtc_linear_fwd_h2")
             return Y
         check(lib().dtc_linear_fwd_s3(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
                                       ptr(mask) if mask is not None else None, ptr(img), ready, M, N, K, ACT[act], stream()),
               "dtc_linear_fwd_s3")
         return Y
-    slot = _amax_out(Y, 0, N) if (SPLIT and H2) else None
+    slot = _amax_out(Y, 0, N, M) if (SPLIT and H2) else None
     if slot is not None:          # a narrow layer inside a trainer phase of the fp16 path: its result's amax rides along for the consumers
         assert mask is None or act in ("relu", "crelu")
         check(lib().dtc_linear_fwd_amax(Xs, cptr(W, f32), cptr(b, f32) if b is not None else None, ptr(Y), Y.stride(0),
@@ -474,7 +482,7 @@ def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None
     if (SPLIT if split is None else split) and (split or (K >= SPLIT_MIN_COLS and N >= SPLIT_MIN_RED)) and (mask is None or K % 128 == 0):
         img, ready = _wimage(W, dXs, N, K, 1, H2)
         if H2:
-            check(lib().dtc_linear_dgrad_h2(ptr(dZ), dZ.stride(0), _amax_in(dZ, "dgrad"), cptr(W, f32), _h2_destination(dXs),
+            check(lib().dtc_linear_dgrad_h2(ptr(dZ), dZ.stride(0), _amax_in(dZ, "dgrad"), cptr(W, f32), _h2_destination(dXs, M),
                                             ptr(Xsaved) if mask is None else None, Xsaved.stride(0) if Xsaved is not None else 0,
                                             ptr(mask) if mask is not None else None, ptr(img), ready, M, N, K,
                                             ACT[act] if mask is None else ACT["relu"], stream()), "dtc_linear_dgrad_h2")
@@ -486,7 +494,7 @@ def linear_dgrad(dZ, W, dX, Xsaved=None, act=None, M=None, mask=None, split=None
         return
     if SPLIT and H2:                  # a single whole-tensor destination publishes its amax from the narrow kernels as well (several
         if dXs.nseg == 1:             # blocks: they publish nothing, so no record may be handed out for them)
-            _h2_destination(dXs)
+            _h2_destination(dXs, M)
         else:
             for i in range(dXs.nseg):
                 dXs.seg[i].amax = None
@@ -656,7 +664,7 @@ def linear_fwd_mse(X, W, b, target, tcol0, tidx, dY, sq_part, M=None, split=None
         img, ready = _wimage(W, Xs, N, K, 0, H2)
         if H2:
             _h2_operand(Xs)
-            check(lib().dtc_linear_fwd_mse_h2(*args, ptr(img), ready, _amax_out(dY, 0, N), M, N, K, stream()), "dtc_linear_fwd_mse_h2")
+            check(lib().dtc_linear_fwd_mse_h2(*args, ptr(img), ready, _amax_out(dY, 0, N, M), M, N, K, stream()), "dtc_linear_fwd_mse_h2")
             return n_part
         check(lib().dtc_linear_fwd_mse_s3(*args, ptr(img), ready, M, N, K, stream()), "dtc_linear_fwd_mse_s3")
     else:

@@ -558,8 +558,9 @@ int dtc_ppo_heads_loss_img(const float* Ha, int64_t ldha, const float* Hc, int64
                            void* dmean_img, void* dval_img, void* stream);
 /* The learning-rate rule of ppo.py:301-307 alone (data-parallel callers run dtc_ppo_loss with
  * adaptive_schedule = 0, all-reduce the KL mean, then call this so every rank takes the same branch).
- * The slot is CONSUMED: it is overwritten with NaN, and a NaN found in it (a caller that exchanged the gradient header
- * without depositing this step's KL first) poisons *lr with NaN instead of silently re-using a stale value. */
+ * The slot is CONSUMED: it is overwritten with a NaN of a payload of its own (0x7fc0dead), and finding exactly that pattern (a caller that
+ * exchanged the gradient header without depositing this step's KL first) poisons *lr with NaN instead of silently re-using a stale value.
+ * A KL that is NaN itself (any other payload) leaves *lr unchanged, as both comparisons of the reference do. */
 int dtc_lr_adapt(float* kl_mean, double* lr, float desired_kl, void* stream);
 /* log-prob / sampling side of PPO.act (ppo.py:137-150): actions = mean + std*noise,
  * logp = sum_j log N(a; mean, std). */

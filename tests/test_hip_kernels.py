@@ -626,3 +626,21 @@ def test_pack_cols_equals_cat_of_gathered_blocks():
     out2 = torch.full((B, 60), float("nan"), device=DEV)            # row stride wider than the packed block
     ops.pack_cols(_ffi.segmat([_ffi.seg(obs_d, 0, 53, gather=True), _ffi.seg(bv_d, 0, 3, gather=True)], idx_d), out2)
     assert torch.equal(out2[:, :56].cpu(), torch.cat([obs[idx], bv[idx]], dim=1)) and torch.isnan(out2[:, 56:]).all()
+
+
+@pytest.mark.gpu
+def test_lr_adapt_rule_consumed_slot_and_nan_kl():
+    """dtc_lr_adapt (ppo.py:301-307 for data-parallel callers): the three branches; a KL that is NaN itself leaves the learning rate
+    unchanged (both comparisons of the reference are false); the slot is consumed -- a second call without a fresh deposit poisons lr."""
+    from dtc_amd import ops
+    dev = "cuda:0"
+    lr = torch.tensor([1e-3], dtype=torch.float64, device=dev)
+    for kl, want in ((0.05, 1e-3 / 1.5), (0.001, 1e-3), (0.012, 1e-3), (float("nan"), 1e-3), (-1.0, 1e-3)):
+        lr.fill_(1e-3)
+        slot = torch.tensor([kl], dtype=torch.float32, device=dev)
+        ops.lr_adapt(slot, lr, 0.01)
+        exp = want if kl != 0.001 else 1e-3 * 1.5
+        assert abs(float(lr.item()) - exp) <= 1e-15, (kl, float(lr.item()), exp)
+        assert int(slot.view(torch.int32).item()) == 0x7fc0dead           # consumed
+    ops.lr_adapt(slot, lr, 0.01)                                          # nothing deposited since
+    assert float(lr.item()) != float(lr.item())
