@@ -595,12 +595,14 @@ def run(a, rank, local_rank, world, wd):
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         split = ops.SPLIT
         peak = split_peak(ops) if split else PEAK_FP32_MFMA_TFLOPS
-        if split and getattr(alg, "use_images", False) and not (composite or gru):
+        if split and getattr(alg, "use_images", False):
             kernel_desc = ("linear_h2i_kernel<FWD | DGRAD | MSE> (both operands as block-scaled fp16 (hi, lo) images by LDS-DMA, no conversion in "
-                           "any K loop), wgrad_h2i_group_kernel (+ its reduce kernel), h2i_wpack_kernel (weight images, one launch per phase), "
-                           "h2i_pack_kernel (rollout rows -> images); csrc/gemm_h2i.hip, wgrad_h2i.hip: three v_mfma_f32_32x32x16_f16 passes per "
-                           "product, fp32 accumulate; the narrow layers (< 128 columns) run on the single-pass v_mfma_f32_32x32x2_f32 kernels "
-                           "and are part of the family")
+                           "any K loop; 64-row tiles for launches of at most one 128 x 128 tile per CU), wgrad_h2i_group_kernel (+ its reduce "
+                           "kernel), h2i_wpack_kernel (weight images, one launch per phase), h2i_pack_kernel (rollout rows and fp32 hand-over "
+                           "tensors -> images); csrc/gemm_h2i.hip, wgrad_h2i.hip: three v_mfma_f32_32x32x16_f16 passes per product, fp32 "
+                           "accumulate; the narrow layers (< 128 columns) run through the same kernels and are part of the family"
+                           + ("; the GRU time steps (gru_s3_kernel: three bf16 terms / six passes, csrc/gru_s3.hip) are part of the family too"
+                              if (composite or gru) else ""))
         elif split and ops.H2:
             kernel_desc = ("linear_s3_kernel<.., H2> (+ the weight-image launches), wgrad_s3_group_kernel<.., H2> (+ its reduce kernel): "
                            "split-precision GEMM family -- every fp32 operand scaled by a power of two from its tensor's amax and written as "

@@ -224,8 +224,11 @@ class RecurrentDecoderPPO(PPO):
             return dict(name=name, X=X, cols=cols, mem=mem, proj=proj, layers=layers, hs_all=hs_all, gates=gates, hn=hn, ws=ws,
                         outs=outs, imgs=imgs)
 
-        def head_backward(hd, dOut):
-            """MLP backward, BPTT, the recurrence's weight gradients; returns the image of dgi over the valid rows."""
+        def head_backward(hd, dOut, full_dgi=True):
+            """MLP backward, BPTT, the W_hh weight gradient (queued); returns the image(s) of dgi over the valid rows: the whole [M, 3H]
+            image (the actor: its input projection's data gradient reduces over all 3H columns), or (full_dgi=False, the critic) the
+            pair (r / z blocks [M, 2H], n block [M, H]) -- dgh and dgi share their r / z blocks (gru_gate_bwd_kernel: da_n vs da_n * r
+            in the n block only), so those 2H columns are packed once and each weight gradient runs as two jobs over row ranges."""
             name, layers, outs, imgs, mem = hd["name"], hd["layers"], hd["outs"], hd["imgs"], hd["mem"]
             dZi = tw.img("dout_" + name, dOut.shape[1]).pack(dOut)
             d_in = tw.g(f"{name}_d0", H)
@@ -243,12 +246,22 @@ class RecurrentDecoderPPO(PPO):
             ops.scatter_rows(d_in, unpad_idx, dhs)
             dgi_p, dh0 = torch.empty(T, R, 3 * H, device=dev), torch.empty(R, H, device=dev)
             ops.gru_bwd(dhs.view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], mem.W_hh, dgi_p, None, None, dh0, hd["ws"])
-            dghi = tw.img("dgh_" + name, 3 * H).pack(rows(ops.gru_dgh_all(hd["ws"], T, R, H), 3 * H), M)
-            dgii = tw.img("dgi_" + name, 3 * H).pack(rows(dgi_p.view(T * R, 3 * H), 3 * H), M)
             hpi = tw.img("hp_" + name, H).pack(rows(hd["hs_all"][:T].reshape(T * R, H), H), M)
-            self._bwd_img(tw, Dense(mem.W_hh, mem.b_hh, mem.gW_hh, mem.gb_hh, None), dghi, hpi)
             tw.held.append((dgi_p, dh0, hd))
-            return dgii
+            dgh = ops.gru_dgh_all(hd["ws"], T, R, H)
+            if full_dgi:
+                dghi = tw.img("dgh_" + name, 3 * H).pack(rows(dgh, 3 * H), M)
+                dgii = tw.img("dgi_" + name, 3 * H).pack(rows(dgi_p.view(T * R, 3 * H), 3 * H), M)
+                self._bwd_img(tw, Dense(mem.W_hh, mem.b_hh, mem.gW_hh, mem.gb_hh, None), dghi, hpi)
+                return dgii
+            cols = lambda t, c0, w: segmat([seg(t, c0, w, gather=True)], unpad_idx)
+            rzi = tw.img("drz_" + name, 2 * H).pack(cols(dgh, 0, 2 * H), M)
+            nhi = tw.img("dnh_" + name, H).pack(cols(dgh, 2 * H, H), M)
+            nii = tw.img("dni_" + name, H).pack(cols(dgi_p.view(T * R, 3 * H), 2 * H, H), M)
+            part = lambda W, b, gW, gb, lo, hi: Dense(W[lo:hi], b[lo:hi], gW[lo:hi], gb[lo:hi], None)
+            self._bwd_img(tw, part(mem.W_hh, mem.b_hh, mem.gW_hh, mem.gb_hh, 0, 2 * H), rzi, hpi)
+            self._bwd_img(tw, part(mem.W_hh, mem.b_hh, mem.gW_hh, mem.gb_hh, 2 * H, 3 * H), nhi, hpi)
+            return rzi, nii
 
         with tw.lane("aux"):
             Xc = ac.packed_input(fw, "p_c", ac.critic_input(obs, flat["base_vel"], priv, idx), idx, reuse=True)
@@ -272,8 +285,10 @@ class RecurrentDecoderPPO(PPO):
         self._kl_to_header(stats)
         tw.order("main", "aux")
         with tw.lane("aux"):
-            dgii_c = head_backward(hc, tw.dval)
-            self._bwd_img(tw, hc["proj"], dgii_c, Xc)
+            rzi_c, nii_c = head_backward(hc, tw.dval, full_dgi=False)
+            pc = hc["proj"]
+            self._bwd_img(tw, Dense(pc.W[:2 * H], pc.b[:2 * H], pc.gW[:2 * H], pc.gb[:2 * H], None), rzi_c, Xc)
+            self._bwd_img(tw, Dense(pc.W[2 * H:], pc.b[2 * H:], pc.gW[2 * H:], pc.gb[2 * H:], None), nii_c, Xc)
         dgii_a = head_backward(ha, tw.dmean)
         # the actor features' gradient fans out to z, mu[:, :3] (fp32) and l_t (image); the observations need none
         tw.dmulv.zero_()

@@ -323,12 +323,17 @@ class RecurrentPPO:
             dgi, dh0 = torch.empty(T, R, 3 * H, device=dev), torch.empty(R, H, device=dev)
             ops.gru_bwd(dhs.view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], mem.W_hh, dgi, None, None, dh0, hd["ws"])
             # the recurrence's two weight gradients over the VALID (t, r) slots: dgh / dgi / h_{t-1} rows gathered into images
-            rows = lambda t, w: segmat([seg(t, 0, w, gather=True)], unpad_idx)
-            dghi = self._img("dgh_" + name, M, 3 * H, dev).pack(rows(ops.gru_dgh_all(hd["ws"], T, R, H), 3 * H), M)
-            dgii = self._img("dgi_" + name, M, 3 * H, dev).pack(rows(dgi.view(T * R, 3 * H), 3 * H), M)
-            hpi = self._img("hp_" + name, M, H, dev).pack(rows(hd["hs_all"][:T].reshape(T * R, H), H), M)
-            jobs.append((dghi, hpi, mem.gW_hh, 0, mem.gb_hh))
-            jobs.append((dgii, hd["ximg"], mem.gW_ih, 0, mem.gb_ih))
+            # (dgh and dgi share their r / z gate blocks and differ in the n block -- gru_gate_bwd_kernel: da_n vs da_n * r --: the shared
+            # 2H columns are packed once, each product runs as two jobs over the row ranges [0, 2H) and [2H, 3H) of its gradient)
+            rows = lambda t, c0, w: segmat([seg(t, c0, w, gather=True)], unpad_idx)
+            dgh, dgi2 = ops.gru_dgh_all(hd["ws"], T, R, H), dgi.view(T * R, 3 * H)
+            rzi = self._img("drz_" + name, M, 2 * H, dev).pack(rows(dgh, 0, 2 * H), M)
+            nhi = self._img("dnh_" + name, M, H, dev).pack(rows(dgh, 2 * H, H), M)
+            nii = self._img("dni_" + name, M, H, dev).pack(rows(dgi2, 2 * H, H), M)
+            hpi = self._img("hp_" + name, M, H, dev).pack(rows(hd["hs_all"][:T].reshape(T * R, H), 0, H), M)
+            for gW, gb, X, ni in ((mem.gW_hh, mem.gb_hh, hpi, nhi), (mem.gW_ih, mem.gb_ih, hd["ximg"], nii)):
+                jobs.append((rzi, X, gW[:2 * H], 0, gb[:2 * H]))
+                jobs.append((ni, X, gW[2 * H:], 0, gb[2 * H:]))
             # one grouped launch on the weight-gradient stream, behind everything this lane has issued
             need = h2i.wgrad_group_workspace_bytes(jobs, M)
             wg = self._wg_ws.get(name)
