@@ -85,6 +85,49 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restri
     dh[e] = d * z;
 }
 
+// the same with four consecutive hidden units per thread (H % 4 == 0, 16-byte aligned rows): 16-byte loads / stores -- the kernel moves
+// 20 floats per (row, unit) and is bound by that traffic (66 MB per launch at R ~ 1470, H = 512)
+__global__ __launch_bounds__(256) void gru_gate_bwd4_kernel(const float* __restrict__ dhs_t, float* __restrict__ dh,
+                                                            const float* __restrict__ part, const float* __restrict__ gates,
+                                                            const float* __restrict__ hn, const float* __restrict__ hprev,
+                                                            float* __restrict__ dgi, float* __restrict__ dgh, int R, int H, int nparts) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // group of four units
+    const int hq = H >> 2;
+    if (q >= (long long)R * hq) return;
+    const long long row = q / hq;
+    const int j = (int)(q - row * hq) * 4;
+    const long long e = row * H + j;
+    const float* g = gates + row * 3 * H;
+    const f4 r = *reinterpret_cast<const f4*>(g + j), z = *reinterpret_cast<const f4*>(g + H + j), n = *reinterpret_cast<const f4*>(g + 2 * H + j);
+    f4 d = *reinterpret_cast<const f4*>(dhs_t + e) + *reinterpret_cast<const f4*>(dh + e);
+    if (part) {
+        const long long rh = (long long)R * H;
+        for (int c = 0; c < nparts; ++c) d += *reinterpret_cast<const f4*>(part + c * rh + e);      // fixed order
+    }
+    const f4 ghn = *reinterpret_cast<const f4*>(hn + e), hp = *reinterpret_cast<const f4*>(hprev + e);
+    f4 da_r, da_z, da_n, da_nr, dz4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                       // the scalar kernel's arithmetic, element by element (same rounding)
+        const float dn = d[k] * (1.0f - z[k]);
+        const float dz = d[k] * (hp[k] - n[k]);
+        da_n[k] = dn * (1.0f - n[k] * n[k]);
+        da_z[k] = dz * (z[k] * (1.0f - z[k]));
+        da_r[k] = (da_n[k] * ghn[k]) * (r[k] * (1.0f - r[k]));
+        da_nr[k] = da_n[k] * r[k];
+        dz4[k] = d[k] * z[k];
+    }
+    float* gi_o = dgi + row * 3 * H;
+    float* gh_o = dgh + row * 3 * H;
+    *reinterpret_cast<f4*>(gi_o + j) = da_r;
+    *reinterpret_cast<f4*>(gi_o + H + j) = da_z;
+    *reinterpret_cast<f4*>(gi_o + 2 * H + j) = da_n;
+    *reinterpret_cast<f4*>(gh_o + j) = da_r;
+    *reinterpret_cast<f4*>(gh_o + H + j) = da_z;
+    *reinterpret_cast<f4*>(gh_o + 2 * H + j) = da_nr;
+    *reinterpret_cast<f4*>(dh + e) = dz4;
+}
+
 // dh0 <- dh0 + the three chunks of the last W_hh product
 __global__ __launch_bounds__(256) void gru_add_parts_kernel(float* __restrict__ dh, const float* __restrict__ part, long long rh, int nparts) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,13 +253,23 @@ extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* g
     }
     const unsigned grid = (unsigned)dtc::ceil_div((int64_t)RH, 256);
     float* part = (float*)workspace;              // [nparts][R][H]: the region dtc_gru_fwd uses for gh
+    // four units per thread when every row of every operand starts on a 16-byte boundary (DTC_GRU_GATE_VEC=0: one unit per thread)
+    static const bool vec_on = !(getenv("DTC_GRU_GATE_VEC") && atoi(getenv("DTC_GRU_GATE_VEC")) == 0);
+    auto a16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const bool vec4 = vec_on && H % 4 == 0 && a16(dhs) && a16(dh0) && a16(part) && a16(gates) && a16(hn) && a16(hs_all) && a16(dgi) && a16(dgh_all);
+    const unsigned grid4 = (unsigned)dtc::ceil_div((int64_t)RH / 4, 256);
     for (int t = T - 1; t >= 0; --t) {
         float* dgh_t = dgh_all + (size_t)t * R3H;
         {
             dtc::ProfScope prof("gru_gate_bwd", (double)RH * 4.0 * 17, s);
-            hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(grid), dim3(256), 0, s, dhs + (size_t)t * RH, dh0,
-                               t == T - 1 ? (const float*)nullptr : (const float*)part, gates + (size_t)t * R3H,
-                               hn + (size_t)t * RH, hs_all + (size_t)t * RH, dgi + (size_t)t * R3H, dgh_t, R, H, nparts);
+            if (vec4)
+                hipLaunchKernelGGL(gru_gate_bwd4_kernel, dim3(grid4), dim3(256), 0, s, dhs + (size_t)t * RH, dh0,
+                                   t == T - 1 ? (const float*)nullptr : (const float*)part, gates + (size_t)t * R3H,
+                                   hn + (size_t)t * RH, hs_all + (size_t)t * RH, dgi + (size_t)t * R3H, dgh_t, R, H, nparts);
+            else
+                hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(grid), dim3(256), 0, s, dhs + (size_t)t * RH, dh0,
+                                   t == T - 1 ? (const float*)nullptr : (const float*)part, gates + (size_t)t * R3H,
+                                   hn + (size_t)t * RH, hs_all + (size_t)t * RH, dgi + (size_t)t * R3H, dgh_t, R, H, nparts);
         }
         // split path: ONE image of W_hh^T serves all T steps
         int rc = s3 ? dtc_gru_dgrad_parts_s3(dgh_t, wimage, part, (int64_t)RH, R, H, nparts, stream)
