@@ -585,7 +585,8 @@ def run(a, rank, local_rank, world, wd):
         lib.dtc_prof_reset()
         # the GEMM family = forward / data-gradient / weight-gradient kernels AND the split-reduce kernels the weight
         # gradients need (their time counts against the family's FLOP; they add no FLOP of their own)
-        fam = ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_reduce", "gru_step_fwd", "wimage", "h2i_pack")
+        fam = ("linear_fwd", "linear_dgrad", "linear_fwd_chain", "linear_dgrad_chain", "linear_wgrad", "wgrad_reduce", "gru_step_fwd", "wimage",
+               "h2i_pack")
         gemm = [r for r in rep if r["name"].split("[")[0] in fam]
         # (the composite's GRU steps call the same three kernels from inside dtc_gru_fwd / dtc_gru_bwd)
         ms = sum(r["ms_total"] for r in gemm)

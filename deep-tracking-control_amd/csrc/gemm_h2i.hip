@@ -734,6 +734,38 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const TileArgs L_, c
 #endif
 }
 
+// A chain of up to three layers whose results are at most 128 columns wide (ONE column tile): the workgroup that owns a row tile runs
+// layer after layer on it -- layer l + 1 reads, as its row operand, the image rows this workgroup wrote as layer l's result (global
+// stores ordered by the workgroup barrier between the layers; the rows of other tiles are never touched).  The narrow stacks of the
+// CE-net (encoder 265 -> 128 -> 64 -> 35, decoder 531 -> 64 -> 128 -> 53: actor_critic_decoder.py:98-142) as one launch per direction
+// instead of three (two) latency-bound ones; every intermediate still reaches HBM as an image (the weight gradients read it).
+constexpr int CHAIN_MAX = 3;
+struct ChainArgs {
+    int count;
+    TileArgs layer[CHAIN_MAX];
+};
+template <int EPI, int TM>
+__global__ __launch_bounds__(256, 3) void chain_h2i_kernel(const ChainArgs C_, unsigned long long* __restrict__ trace) {
+#ifdef __HIP_DEVICE_COMPILE__
+    typedef const AS4 ChainArgs CChainArgs;
+    CChainArgs& C = *(CChainArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)C_;
+    (void)trace;
+    int tr, tc;
+    if (!map_tile(blockIdx.x, (C.layer[0].M + 64 * TM - 1) / (64 * TM), 1, tr, tc)) return;
+    const MseEpiH none{};
+    h2i_tile<EPI, TM>(C.layer[0], none, tr, 0, (int)blockIdx.x, nullptr);
+    if (C.count > 1) {
+        __syncthreads();                    // (workgroup-scope release / acquire: this tile's image rows and exponents are visible to all its waves)
+        h2i_tile<EPI, TM>(C.layer[1], none, tr, 0, (int)blockIdx.x, nullptr);
+    }
+    if (C.count > 2) {
+        __syncthreads();
+        h2i_tile<EPI, TM>(C.layer[2], none, tr, 0, (int)blockIdx.x, nullptr);
+    }
+#endif
+}
+
 unsigned long long* g_trace = nullptr;      // debug: dtc_h2i_trace
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
@@ -1085,4 +1117,64 @@ extern "C" int dtc_linear_dgrad_h2i(const void* dZimg, int N, const void* wimgT,
         hipLaunchKernelGGL((linear_h2i_kernel<EPI_DGRAD, 2>), dim3(grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(Kwin, 128))), dim3(256), 0, s,
                            L.t, MseEpiH{}, g_trace);
     return dtc::check_launch("linear_dgrad_h2i");
+}
+
+// ---- chains of narrow layers (one launch; see chain_h2i_kernel) ---------------------------------------------------------------------
+namespace {
+int chain_launch(bool dgrad, const LayerInfo* L, int count, int M, hipStream_t s) {
+    ChainArgs C;
+    C.count = count;
+    double flop = 0.0, bytes = 0.0;
+    for (int i = 0; i < count; ++i) {
+        C.layer[i] = L[i].t;
+        flop += L[i].flop;
+        bytes += L[i].bytes;
+    }
+    const bool r64 = rows64(M, 128);
+    const int row_tiles = (int)dtc::ceil_div(M, r64 ? 64 : BM);
+    dtc::ProfScope prof(dtc::prof_shape_name(dgrad ? "linear_dgrad_chain" : "linear_fwd_chain", M, count, L[0].K), flop, s, bytes);
+    if (dgrad) {
+        if (r64) hipLaunchKernelGGL((chain_h2i_kernel<EPI_DGRAD, 1>), dim3(grid_for(row_tiles, 1)), dim3(256), 0, s, C, g_trace);
+        else hipLaunchKernelGGL((chain_h2i_kernel<EPI_DGRAD, 2>), dim3(grid_for(row_tiles, 1)), dim3(256), 0, s, C, g_trace);
+    } else {
+        if (r64) hipLaunchKernelGGL((chain_h2i_kernel<EPI_FWD, 1>), dim3(grid_for(row_tiles, 1)), dim3(256), 0, s, C, g_trace);
+        else hipLaunchKernelGGL((chain_h2i_kernel<EPI_FWD, 2>), dim3(grid_for(row_tiles, 1)), dim3(256), 0, s, C, g_trace);
+    }
+    return dtc::check_launch(dgrad ? "linear_dgrad_chain_h2i" : "linear_fwd_chain_h2i");
+}
+}  // namespace
+
+// `count` (1..3) forward layers of at most 128 output columns each, layer i + 1 reading layer i's image result (layers[i + 1].X must be
+// exactly one image: layers[i].Yimg): the same results, bit for bit, as `count` dtc_linear_fwd_h2i calls issued in order.
+extern "C" int dtc_linear_fwd_chain_h2i(const DtcH2iFwdLayer* layers, int count, int M, void* stream) {
+    DTC_REQUIRE(layers != nullptr && count >= 1 && count <= CHAIN_MAX, "chain of %d layers (1..%d)", count, CHAIN_MAX);
+    LayerInfo L[CHAIN_MAX];
+    for (int i = 0; i < count; ++i) {
+        const DtcH2iFwdLayer& h = layers[i];
+        DTC_REQUIRE(h.N >= 1 && h.N <= 128, "chain layer %d: %d output columns (1..128: one column tile)", i, h.N);
+        if (i > 0) DTC_REQUIRE(h.X.nseg == 1 && h.X.img[0] == layers[i - 1].Yimg && layers[i - 1].Yimg != nullptr && h.X.width[0] == layers[i - 1].N,
+                               "chain layer %d must read the image result of layer %d", i, i - 1);
+        int rc = fwd_args(&h.X, h.wimg, h.b, h.Y, h.ldy, h.Yimg, h.relu_mask, M, h.N, h.act, L[i]);
+        if (rc != DTC_OK) return rc;
+    }
+    return chain_launch(false, L, count, M, (hipStream_t)stream);
+}
+
+// `count` (1..3) data-gradient layers whose computed windows are at most 128 columns wide, layer i + 1 reading layer i's image result
+// (layers[i + 1].dZimg == layers[i].dXimg, layers[i + 1].N == layers[i].img_cols or Kwin): bit for bit `count` dtc_linear_dgrad_h2i calls.
+extern "C" int dtc_linear_dgrad_chain_h2i(const DtcH2iDgradLayer* layers, int count, int M, void* stream) {
+    DTC_REQUIRE(layers != nullptr && count >= 1 && count <= CHAIN_MAX, "chain of %d layers (1..%d)", count, CHAIN_MAX);
+    LayerInfo L[CHAIN_MAX];
+    for (int i = 0; i < count; ++i) {
+        const DtcH2iDgradLayer& h = layers[i];
+        DTC_REQUIRE(h.Kwin >= 1 && h.Kwin <= 128, "chain layer %d: window of %d columns (1..128: one column tile)", i, h.Kwin);
+        if (i > 0) {
+            const DtcH2iDgradLayer& p = layers[i - 1];
+            DTC_REQUIRE(p.dXimg != nullptr && h.dZimg == p.dXimg && h.N == (p.img_cols ? p.img_cols : p.Kwin),
+                        "chain layer %d must read the image result of layer %d", i, i - 1);
+        }
+        int rc = dgrad_args(h.dZimg, h.N, h.wimgT, h.Kwin, h.dX, h.dXimg, h.img_cols, h.add, h.ld_add, h.Xsaved, h.ldxs, h.relu_mask, M, h.act, L[i]);
+        if (rc != DTC_OK) return rc;
+    }
+    return chain_launch(true, L, count, M, (hipStream_t)stream);
 }

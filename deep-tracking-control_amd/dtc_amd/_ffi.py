@@ -59,6 +59,17 @@ class DtcH2iOperand(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("width", C.c_int32 * 4), ("img", C.c_void_p * 4)]
 
 
+class DtcH2iFwdLayer(C.Structure):
+    _fields_ = [("X", DtcH2iOperand), ("wimg", C.c_void_p), ("b", C.c_void_p), ("Y", C.c_void_p), ("ldy", C.c_int64), ("Yimg", C.c_void_p),
+                ("relu_mask", C.c_void_p), ("N", C.c_int32), ("act", C.c_int32)]
+
+
+class DtcH2iDgradLayer(C.Structure):
+    _fields_ = [("dZimg", C.c_void_p), ("wimgT", C.c_void_p), ("dX", C.POINTER(DtcSegMat)), ("dXimg", C.c_void_p), ("add", C.c_void_p),
+                ("ld_add", C.c_int64), ("Xsaved", C.c_void_p), ("ldxs", C.c_int64), ("relu_mask", C.c_void_p), ("N", C.c_int32),
+                ("Kwin", C.c_int32), ("img_cols", C.c_int32), ("act", C.c_int32)]
+
+
 class DtcWgradH2iJob(C.Structure):
     _fields_ = [("dZimg", C.c_void_p), ("Ximg", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("ldw", C.c_int64),
                 ("N", C.c_int32), ("K", C.c_int32), ("wcol0", C.c_int32)]
@@ -105,7 +116,7 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 12         # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 13         # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
@@ -155,6 +166,8 @@ _SIGS = {
     "dtc_probe_mfma_stream_h2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, c_stream]),
     "dtc_h2i_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_h2i_rows64_max": (None, [C.c_int]),
+    "dtc_linear_fwd_chain_h2i": (C.c_int, [C.POINTER(DtcH2iFwdLayer), C.c_int, C.c_int, c_stream]),
+    "dtc_linear_dgrad_chain_h2i": (C.c_int, [C.POINTER(DtcH2iDgradLayer), C.c_int, C.c_int, c_stream]),
     "dtc_h2i_trace": (None, [C.c_void_p]),
     "dtc_h2i_pack": (C.c_int, [C.POINTER(DtcSegMat), C.c_int, C.c_void_p, c_stream]),
     "dtc_h2i_unpack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, C.c_int64, c_stream]),
@@ -275,9 +288,9 @@ def _check_abi(l):
     (DTC_LIB may point at a separately built library, e.g. the ASan build: a stale one would misread every descriptor)."""
     global _lib
     mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcH2iWJob,
-            DtcH2iOperand, DtcWgradH2iJob, DtcEnvStep]
-    sizes = (C.c_int64 * 16)()
-    n = l.dtc_abi_sizes(sizes, 16)
+            DtcH2iOperand, DtcWgradH2iJob, DtcEnvStep, DtcH2iFwdLayer, DtcH2iDgradLayer]
+    sizes = (C.c_int64 * 32)()
+    n = l.dtc_abi_sizes(sizes, 32)
     theirs = list(sizes[:n])
     if l.dtc_version() != ABI_VERSION or theirs != [C.sizeof(t) for t in mine]:
         _lib = None

@@ -316,6 +316,9 @@ class PPO:
         # ... and the narrow CE-net stacks (128 / 64 / 35 / 53 columns) on them as well: same kernels (a column tile partly used), their
         # weight gradients as extra jobs of the wide layers' grouped launches instead of single-pass groups of their own (DTC_H2I_NARROW=0)
         self.narrow_images = os.environ.get("DTC_H2I_NARROW", "1") != "0"
+        # ... and as chains: the CE-net encoder / decoder stacks (every layer <= 128 columns wide) as ONE launch per direction
+        # (h2i.linear_fwd_chain / linear_dgrad_chain: the workgroup of a row tile runs layer after layer; DTC_H2I_CHAIN=0: a launch per layer)
+        self.narrow_chains = os.environ.get("DTC_H2I_CHAIN", "1") != "0"
         self._wsets = {}                   # phase -> h2i.WeightSet (weight images, one grouped launch per phase)
         # tests: callable(fw, which) run between the forward and the backward pass of a step ("vae" | "ppo"); the parity tests
         # use it to teacher-force the ReLU sign records (fw.relu_mask buffers) so that fp32 knife edges -- pre-activations that
@@ -582,9 +585,14 @@ class PPO:
             dmi = tw.img("dmulv", L["head"].n_out).pack(tw.dmulv)
             g_headi, g_ce1i = tw.img("g_head", L["head"].n_in), tw.img("g_ce1", L["ce1"].n_in)
             self._bwd_img(tw, L["head"], dmi, fw.img("e"))
-            h2i.linear_dgrad(dmi, L["head"].W, None, g_headi, wset=wset)
             self._bwd_img(tw, L["ce1"], g_headi, fw.img("e1"))
-            h2i.linear_dgrad(g_headi, L["ce1"].W, None, g_ce1i, mask=fw.relu_mask("e1", L["ce0"].n_out, self.relu_masks), wset=wset)
+            chain = [dict(dZimg=dmi, W=L["head"].W, dXimg=g_headi),
+                     dict(dZimg=g_headi, W=L["ce1"].W, dXimg=g_ce1i, mask=fw.relu_mask("e1", L["ce0"].n_out, self.relu_masks))]
+            if self.narrow_chains:
+                h2i.linear_dgrad_chain(chain, wset=wset)
+            else:
+                for c in chain:
+                    h2i.linear_dgrad(c["dZimg"], c["W"], None, c["dXimg"], mask=c.get("mask"), wset=wset)
             self._bwd_img(tw, L["ce0"], g_ce1i, fw.cur["p_hist"])
             tw.live_img |= {"g_head", "g_ce1"}
             return
@@ -649,9 +657,14 @@ class PPO:
                 # decoder input = the [z | mu[:, :3]] image the latent kernel wrote (19 wide) beside the l_t image; c1 / c2 leave as images only
                 p_d = fw.cur["p_zmu"]
                 c1i, c2i = tw.img("c1", L["cd0"].n_out), tw.img("c2", L["cd1"].n_out)
-                h2i.linear_fwd([p_d, fw.img("lt")], L["cd0"].W, L["cd0"].b, None, c1i, "relu", mask=fw.relu_mask("c1", 64, rm), wset=wset)
-                h2i.linear_fwd(c1i, L["cd1"].W, L["cd1"].b, None, c2i, "relu", mask=fw.relu_mask("c2", 128, rm), wset=wset)
-                h2i.linear_fwd(c2i, L["cd2"].W, L["cd2"].b, tw.rec, None, None, wset=wset)
+                chain = [dict(X=[p_d, fw.img("lt")], W=L["cd0"].W, b=L["cd0"].b, Yimg=c1i, act="relu", mask=fw.relu_mask("c1", 64, rm)),
+                         dict(X=c1i, W=L["cd1"].W, b=L["cd1"].b, Yimg=c2i, act="relu", mask=fw.relu_mask("c2", 128, rm)),
+                         dict(X=c2i, W=L["cd2"].W, b=L["cd2"].b, Y=tw.rec)]
+                if self.narrow_chains:
+                    h2i.linear_fwd_chain(chain, wset=wset)
+                else:
+                    for c in chain:
+                        h2i.linear_fwd(c["X"], c["W"], c["b"], c.get("Y"), c.get("Yimg"), c.get("act"), mask=c.get("mask"), wset=wset)
                 tw.live_img |= {"c1", "c2"}
             else:
                 ops.linear_fwd(dec_in, L["cd0"].W, L["cd0"].b, tw.c1, "relu", M=tw.B, mask=fw.relu_mask("c1", 64, rm), split=ns)
@@ -701,9 +714,14 @@ class PPO:
                 g_reci = tw.img("g_rec", L["cd2"].n_out)              # written by the loss kernel
                 g_cd2i, g_cd1i = tw.img("g_cd2", L["cd2"].n_in), tw.img("g_cd1", L["cd1"].n_in)
                 self._bwd_img(tw, L["cd2"], g_reci, tw.img("c2"))
-                h2i.linear_dgrad(g_reci, L["cd2"].W, None, g_cd2i, mask=fw.relu_mask("c2", 128, rm), wset=wset)
                 self._bwd_img(tw, L["cd1"], g_cd2i, tw.img("c1"))
-                h2i.linear_dgrad(g_cd2i, L["cd1"].W, None, g_cd1i, mask=fw.relu_mask("c1", 64, rm), wset=wset)
+                chain = [dict(dZimg=g_reci, W=L["cd2"].W, dXimg=g_cd2i, mask=fw.relu_mask("c2", 128, rm)),
+                         dict(dZimg=g_cd2i, W=L["cd1"].W, dXimg=g_cd1i, mask=fw.relu_mask("c1", 64, rm))]
+                if self.narrow_chains:
+                    h2i.linear_dgrad_chain(chain, wset=wset)
+                else:
+                    for c in chain:
+                        h2i.linear_dgrad(c["dZimg"], c["W"], None, c["dXimg"], mask=c.get("mask"), wset=wset)
                 self._bwd_img(tw, L["cd0"], g_cd1i, fw.img("lt"), wcol0=19)          # columns of dW that meet l_t ...
                 self._bwd_img(tw, L["cd0"], g_cd1i, fw.cur["p_zmu"], wcol0=0, bias=False)      # ... and [z | mu[:, :3]]
                 # W's columns [19, 531) first (d l_t: four whole 128-column tiles, 16-byte stores), then [0, 19) (dz | d mu[:, :3] accumulating)

@@ -231,6 +231,67 @@ def linear_fwd(X, W, b, Y=None, Yimg=None, act=None, mask=None, wset=None, cols=
     return ws
 
 
+def linear_fwd_chain(layers, wset=None):
+    """Up to three forward layers of at most 128 output columns each in ONE launch (dtc_linear_fwd_chain_h2i): `layers` = list of dicts
+    with the keyword arguments of linear_fwd (X, W, b, Y, Yimg, act, mask, cols); layer i + 1's X must be layer i's Yimg.  Bit for bit
+    the per-layer calls.  (A capture in flight takes the per-layer calls: it checks every product on its own.)"""
+    if CAPTURE is not None or len(layers) == 1:
+        ws = wset
+        for L in layers:
+            ws = linear_fwd(L["X"], L["W"], L.get("b"), L.get("Y"), L.get("Yimg"), L.get("act"), L.get("mask"), ws if ws is not None else wset, L.get("cols"))
+        return ws
+    arr = (_ffi.DtcH2iFwdLayer * len(layers))()
+    keep, ws = [], wset
+    M = None
+    for a, L in zip(arr, layers):
+        op, imgs = _operand(L["X"])
+        M = imgs[0].M if M is None else M
+        W, Y, Yimg, mask, b = L["W"], L.get("Y"), L.get("Yimg"), L.get("mask"), L.get("b")
+        wimg, ws = _fwd_wimage(W, imgs, L.get("cols"), ws if ws is not None else wset)
+        a.X, a.wimg, a.b = op, ptr(wimg), (cptr(b, f32) if b is not None else None)
+        a.Y, a.ldy = (ptr(Y) if Y is not None else None), (Y.stride(0) if Y is not None else 0)
+        a.Yimg, a.relu_mask = (Yimg.ptr() if Yimg is not None else None), (ptr(mask) if mask is not None else None)
+        a.N, a.act = W.shape[0], ACT[L.get("act")]
+        keep.append((op, imgs, wimg))
+    check(lib().dtc_linear_fwd_chain_h2i(arr, len(layers), M, stream()), "dtc_linear_fwd_chain_h2i")
+    return ws
+
+
+def linear_dgrad_chain(layers, wset=None):
+    """Up to three data-gradient layers whose windows are at most 128 columns wide in ONE launch (dtc_linear_dgrad_chain_h2i): `layers` =
+    list of dicts with the arguments of linear_dgrad (dZimg, W, dX, dXimg, window (one range), add, Xsaved, act, mask); layer i + 1's
+    dZimg must be layer i's dXimg.  Bit for bit the per-layer calls."""
+    if CAPTURE is not None or len(layers) == 1:
+        ws = wset
+        for L in layers:
+            ws = linear_dgrad(L["dZimg"], L["W"], L.get("dX"), L.get("dXimg"), L.get("window"), L.get("add"), L.get("Xsaved"), L.get("act"),
+                              L.get("mask"), ws if ws is not None else wset)
+        return ws
+    arr = (_ffi.DtcH2iDgradLayer * len(layers))()
+    keep = []
+    ws = wset if wset is not None else WeightSet()
+    M = layers[0]["dZimg"].M
+    for a, L in zip(arr, layers):
+        dZimg, W, dX, dXimg, mask, add, Xs, act = (L["dZimg"], L["W"], L.get("dX"), L.get("dXimg"), L.get("mask"), L.get("add"), L.get("Xsaved"),
+                                                   L.get("act"))
+        N, K = W.shape
+        win = L.get("window") or (0, K)
+        assert isinstance(win[0], int) and dZimg.K == N
+        wimg = ws.get(W, 1, [win], [(0, N)])
+        dXs = None
+        if dX is not None:
+            dXs = dX if isinstance(dX, _ffi.DtcSegMat) else segmat([seg(dX, 0, win[1])])
+        a.dZimg, a.wimgT, a.dX = dZimg.ptr(), ptr(wimg), (C.pointer(dXs) if dXs is not None else None)
+        a.dXimg, a.img_cols = (dXimg.ptr() if dXimg is not None else None), (dXimg.K if dXimg is not None else 0)
+        a.add, a.ld_add = (ptr(add) if add is not None else None), (add.stride(0) if add is not None else 0)
+        a.Xsaved, a.ldxs = (ptr(Xs) if (mask is None and Xs is not None) else None), (Xs.stride(0) if Xs is not None else 0)
+        a.relu_mask, a.N, a.Kwin = (ptr(mask) if mask is not None else None), N, win[1]
+        a.act = ACT[act] if mask is None else ACT["relu"]
+        keep.append((dXs, wimg))
+    check(lib().dtc_linear_dgrad_chain_h2i(arr, len(layers), M, stream()), "dtc_linear_dgrad_chain_h2i")
+    return ws
+
+
 def mse_parts(M, N) -> int:
     return int(lib().dtc_linear_fwd_mse_h2i_parts(M, N))
 

@@ -19,8 +19,12 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import os
+
 from .. import _ffi, h2i, ops
 from .._ffi import seg, segmat
+
+NARROW_CHAINS = os.environ.get("DTC_H2I_CHAIN", "1") != "0"     # the CE-net encoder's three layers as one launch (see cenet_forward_)
 
 
 class AC_Args:
@@ -363,9 +367,13 @@ class ActorCriticDecoder(nn.Module):
         if images and masks:
             pin = self.packed_input(ws, "p_hist", X, idx, reuse=True)
             e1i, ei = ws.img("e1", L["ce0"].n_out), ws.img("e", L["ce1"].n_out)
-            h2i.linear_fwd(pin, L["ce0"].W, L["ce0"].b, None, e1i, "relu", mask=ws.relu_mask("e1", L["ce0"].n_out, masks), wset=wset)
-            h2i.linear_fwd(e1i, L["ce1"].W, L["ce1"].b, None, ei, None, wset=wset)
-            h2i.linear_fwd(ei, L["head"].W, L["head"].b, ws.mulv, None, None, wset=wset)
+            chain = [dict(X=pin, W=L["ce0"].W, b=L["ce0"].b, Yimg=e1i, act="relu", mask=ws.relu_mask("e1", L["ce0"].n_out, masks)),
+                     dict(X=e1i, W=L["ce1"].W, b=L["ce1"].b, Yimg=ei), dict(X=ei, W=L["head"].W, b=L["head"].b, Y=ws.mulv)]
+            if NARROW_CHAINS:          # the three layers as ONE launch (h2i.linear_fwd_chain; DTC_H2I_CHAIN=0: a launch per layer)
+                h2i.linear_fwd_chain(chain, wset=wset)
+            else:
+                for c in chain:
+                    h2i.linear_fwd(c["X"], c["W"], c["b"], c.get("Y"), c.get("Yimg"), c.get("act"), mask=c.get("mask"), wset=wset)
             ws.live_img |= {"e1", "e"}
         else:
             ws.live_img -= {"e1", "e"}

@@ -92,7 +92,7 @@ for mode in ("serial", "overlap"):
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for x in rows:
             w.writerow([short(x["Name"]), x["Calls"], x["TotalDurationNs"], x["AverageNs"], x["Percentage"], x["MinNs"], x["MaxNs"], x["StdDev"]])
-    fam = [x for x in rows if any(k in x["Name"] for k in ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_group", "wgrad_reduce", "gru_step_fwd", "linear_s3", "wgrad_s3", "linear_h2i", "wgrad_h2i", "h2i_pack", "h2i_wpack"))]
+    fam = [x for x in rows if any(k in x["Name"] for k in ("linear_fwd", "linear_dgrad", "linear_wgrad", "wgrad_group", "wgrad_reduce", "gru_step_fwd", "linear_s3", "wgrad_s3", "linear_h2i", "chain_h2i", "wgrad_h2i", "h2i_pack", "h2i_wpack"))]
     tot, calls = sum(float(x["TotalDurationNs"]) for x in fam), sum(int(x["Calls"]) for x in fam)
     print(f"{mode}: GEMM family {tot / 1e6:.1f} ms over {calls} launches -> {tot / calls / 1e3:.2f} us per launch")
 

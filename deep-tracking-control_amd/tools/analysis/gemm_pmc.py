@@ -25,7 +25,7 @@ PASSES = {
 BY_GRID = os.environ.get("DTC_PMC_BY_GRID", "1") != "0"      # one row per (kernel, workgroup count) = per layer shape
 FAMILY = ("linear_fwd_kernel", "linear_dgrad_kernel", "linear_wgrad_kernel", "wgrad_group_kernel", "wgrad_reduce_kernel",
           "wgrad_group_reduce_kernel", "gru_step_fwd_kernel", "linear_s3_kernel", "wgrad_s3_group_kernel", "wgrad_s3_reduce_kernel", "wimage_kernel",
-          "linear_h2i_kernel", "wgrad_h2i_group_kernel", "wgrad_h2i_reduce_kernel", "h2i_pack_kernel", "h2i_wpack_kernel",
+          "linear_h2i_kernel", "chain_h2i_kernel", "wgrad_h2i_group_kernel", "wgrad_h2i_reduce_kernel", "h2i_pack_kernel", "h2i_wpack_kernel",
           "gru_s3_kernel")
 
 

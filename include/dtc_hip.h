@@ -38,7 +38,7 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-#define DTC_ABI_VERSION 12                   /* bumped whenever a signature or a by-value struct layout changes       */
+#define DTC_ABI_VERSION 13                   /* bumped whenever a signature or a by-value struct layout changes       */
 int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
 /* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
    DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcH2iWJob, DtcH2iOperand, DtcWgradH2iJob, DtcEnvStep: the binding compares them with its own layouts at load time (a library
@@ -346,6 +346,34 @@ typedef struct DtcH2iOperand {
 /* Y = act(X W^T + b) (actor_critic_decoder.py:98-131, 323-349); results: fp32 Y [M, >= N] (may be NULL) and / or Yimg = image(M, N) */
 int dtc_linear_fwd_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
                        int M, int N, int act, void* stream);
+/* Chains of narrow layers in ONE launch (csrc/gemm_h2i.hip: chain_h2i_kernel): up to three layers of at most 128 result columns each,
+ * layer i + 1 reading the image layer i wrote (the workgroup that owns a row tile runs the layers one after the other on it).  Same
+ * arguments, same results bit for bit as the per-layer calls: the CE-net encoder 265 -> 128 -> 64 -> 35 / decoder 531 -> 64 -> 128 -> 53
+ * (actor_critic_decoder.py:98-142) forward, and the data-gradient chains back through them. */
+typedef struct DtcH2iFwdLayer {
+    DtcH2iOperand X;             /* layer 0: up to 4 images; layers > 0: exactly the previous layer's Yimg                    */
+    const void* wimg;
+    const float* b;
+    float* Y;                    /* fp32 result (may be NULL)                                                                   */
+    int64_t ldy;
+    void* Yimg;                  /* image result (NULL only for the last layer)                                                 */
+    uint16_t* relu_mask;
+    int32_t N, act;
+} DtcH2iFwdLayer;
+int dtc_linear_fwd_chain_h2i(const DtcH2iFwdLayer* layers, int count, int M, void* stream);
+typedef struct DtcH2iDgradLayer {
+    const void* dZimg;           /* layer 0: image(M, N); layers > 0: the previous layer's dXimg                                */
+    const void* wimgT;
+    const DtcSegMat* dX;         /* fp32 destination blocks (may be NULL)                                                       */
+    void* dXimg;                 /* image result (NULL only for the last layer)                                                 */
+    const float* add;
+    int64_t ld_add;
+    const float* Xsaved;
+    int64_t ldxs;
+    const uint16_t* relu_mask;
+    int32_t N, Kwin, img_cols, act;
+} DtcH2iDgradLayer;
+int dtc_linear_dgrad_chain_h2i(const DtcH2iDgradLayer* layers, int count, int M, void* stream);
 /* the terrain decoder's output layer fused with its MSE (ppo.py:223): dL/dY as fp32 (may be NULL) and / or image(M, N) */
 int64_t dtc_linear_fwd_mse_h2i_parts(int M, int N);
 int dtc_linear_fwd_mse_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, const float* target, int64_t ldt, int64_t target_rows,

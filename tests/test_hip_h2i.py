@@ -400,3 +400,64 @@ def test_64_row_tiles_equal_128_row_tiles_bit_for_bit(tile_rows):
     for a, c in zip(*out):
         assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a.view(torch.int64) if a.dtype == torch.float64 else a,
                            c.view(torch.int32) if c.dtype == torch.float32 else c.view(torch.int64) if c.dtype == torch.float64 else c)
+
+
+@pytest.mark.parametrize("M", [640, 24576])
+def test_narrow_layer_chains_equal_the_per_layer_launches_bit_for_bit(M):
+    """dtc_linear_fwd_chain_h2i / dtc_linear_dgrad_chain_h2i: the CE-net's narrow stacks as ONE launch per direction (the workgroup of a
+    row tile runs layer after layer on it) -- every result (images incl. exponents, fp32 outputs, sign records) equals the per-layer
+    launches bit for bit: encoder 265 -> 128 (ReLU, sign record) -> 64 -> 35, decoder [19 | 512] -> 64 -> 128 -> 53, and the two
+    data-gradient chains back through them (sign records applied)."""
+    from dtc_amd import h2i, ops
+    g = torch.Generator().manual_seed(41)
+    dev = DEV
+    w = lambda n, k: (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
+    bias = lambda n: torch.randn(n, generator=g).to(dev)
+    hist = h2i.HImage.from_tensor(_rows(M, 265, g, span=3).to(dev))
+    zmu, lt = h2i.HImage.from_tensor(torch.randn(M, 19, generator=g).to(dev)), h2i.HImage.from_tensor(_rows(M, 512, g, span=2).to(dev))
+    We, be = [w(128, 265), w(64, 128), w(35, 64)], [bias(128), bias(64), bias(35)]
+    Wd, bd = [w(64, 531), w(128, 64), w(53, 128)], [bias(64), bias(128), bias(53)]
+
+    def run(chain):
+        out = []
+        # encoder forward
+        e1, e = h2i.HImage(M, 128, dev), h2i.HImage(M, 64, dev)
+        m1 = ops.relu_mask(M, 128, dev).zero_()
+        mulv = torch.zeros(M, 35, device=dev)
+        enc = [dict(X=hist, W=We[0], b=be[0], Yimg=e1, act="relu", mask=m1), dict(X=e1, W=We[1], b=be[1], Yimg=e),
+               dict(X=e, W=We[2], b=be[2], Y=mulv)]
+        # decoder forward (two-image input)
+        c1, c2 = h2i.HImage(M, 64, dev), h2i.HImage(M, 128, dev)
+        mc1, mc2 = ops.relu_mask(M, 64, dev).zero_(), ops.relu_mask(M, 128, dev).zero_()
+        rec = torch.zeros(M, 53, device=dev)
+        dec = [dict(X=[zmu, lt], W=Wd[0], b=bd[0], Yimg=c1, act="relu", mask=mc1), dict(X=c1, W=Wd[1], b=bd[1], Yimg=c2, act="relu", mask=mc2),
+               dict(X=c2, W=Wd[2], b=bd[2], Y=rec)]
+        if chain:
+            h2i.linear_fwd_chain(enc)
+            h2i.linear_fwd_chain(dec)
+        else:
+            for L in enc + dec:
+                h2i.linear_fwd(L["X"], L["W"], L.get("b"), L.get("Y"), L.get("Yimg"), L.get("act"), L.get("mask"))
+        out += [e1.buf, e.buf, m1, mulv, c1.buf, c2.buf, mc1, mc2, rec]
+        # data-gradient chains: d mulv -> head^T -> ce1^T (sign record of e1); d recons -> cd2^T (c2's record) -> cd1^T (c1's record)
+        dm = h2i.HImage.from_tensor(_rows(M, 35, torch.Generator().manual_seed(5), span=5, zero_frac=0.2).to(dev))
+        dr = h2i.HImage.from_tensor(_rows(M, 53, torch.Generator().manual_seed(6), span=5).to(dev))
+        g_head, g_ce1 = h2i.HImage(M, 64, dev), h2i.HImage(M, 128, dev)
+        g_cd2, g_cd1 = h2i.HImage(M, 128, dev), h2i.HImage(M, 64, dev)
+        benc = [dict(dZimg=dm, W=We[2], dXimg=g_head), dict(dZimg=g_head, W=We[1], dXimg=g_ce1, mask=m1)]
+        bdec = [dict(dZimg=dr, W=Wd[2], dXimg=g_cd2, mask=mc2), dict(dZimg=g_cd2, W=Wd[1], dXimg=g_cd1, mask=mc1)]
+        if chain:
+            h2i.linear_dgrad_chain(benc)
+            h2i.linear_dgrad_chain(bdec)
+        else:
+            for L in benc + bdec:
+                h2i.linear_dgrad(L["dZimg"], L["W"], None, L["dXimg"], mask=L.get("mask"))
+        torch.cuda.synchronize()
+        out += [g_head.buf, g_ce1.buf, g_cd2.buf, g_cd1.buf]
+        return [t.clone() for t in out]
+
+    a, b = run(True), run(False)
+    for i, (x, y) in enumerate(zip(a, b)):
+        bits = lambda t: t.view(torch.int64) if t.dtype == torch.float64 else t.view(torch.int32) if t.dtype == torch.float32 else t
+        assert torch.equal(bits(x), bits(y)), i
+    assert float(a[3].abs().max()) > 0 and float(a[8].abs().max()) > 0
