@@ -16,6 +16,9 @@
 namespace {
 
 constexpr int EPI_FWD = 0, EPI_DGRAD = 1, EPI_MSE = 2;
+#ifndef DTC_H2I_NT_STORES
+#define DTC_H2I_NT_STORES 0   // image stores of the GEMM epilogue with the non-temporal hint (measured: DESIGN.md 4.5)
+#endif
 #ifndef DTC_H2I_PROBE
 #define DTC_H2I_PROBE 0       // timing ladder of the epilogue (tools/jobs/r5_epi_ladder.sh): 1..5 drop its parts from the end (WRONG results)
 #endif
@@ -748,8 +751,13 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
                 if ((lc >> 4) >= yo.stages) continue;
                 const HiPiece pc = hi_split8(T[i][j][q], ee);
                 u32x4* chunk = tile_chunks + (long long)(lc >> 4) * (HI_CHUNK / 16);
+#if DTC_H2I_NT_STORES
+                __builtin_nontemporal_store(pc.p[0], &chunk[rslot(rch, (lc >> 3) & 1)]);
+                __builtin_nontemporal_store(pc.p[1], &chunk[256 + rslot(rch, (lc >> 3) & 1)]);
+#else
                 chunk[rslot(rch, (lc >> 3) & 1)] = pc.p[0];
                 chunk[256 + rslot(rch, (lc >> 3) & 1)] = pc.p[1];
+#endif
             }
         }
     if (trace && tid == 0) trace[4 * slot + 2] = __builtin_amdgcn_s_memrealtime();

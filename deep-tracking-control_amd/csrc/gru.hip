@@ -87,11 +87,28 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restri
 
 // the same with four consecutive hidden units per thread (H % 4 == 0, 16-byte aligned rows): 16-byte loads / stores -- the kernel moves
 // 20 floats per (row, unit) and is bound by that traffic (66 MB per launch at R ~ 1470, H = 512)
-__global__ __launch_bounds__(256) void gru_gate_bwd4_kernel(const float* __restrict__ dhs_t, float* __restrict__ dh,
-                                                            const float* __restrict__ part, const float* __restrict__ gates,
-                                                            const float* __restrict__ hn, const float* __restrict__ hprev,
-                                                            float* __restrict__ dgi, float* __restrict__ dgh, int R, int H, int nparts) {
+// (blockIdx.y: which recurrence -- dtc_gru_bwd_multi runs the time step of two recurrences of one shape as one launch)
+struct GateBwdPtrs {
+    const float* dhs_t;
+    float* dh;
+    const float* part;
+    const float* gates;
+    const float* hn;
+    const float* hprev;
+    float* dgi;
+    float* dgh;
+};
+__global__ __launch_bounds__(256) void gru_gate_bwd4_kernel(const GateBwdPtrs p0, const GateBwdPtrs p1, int R, int H, int nparts) {
     typedef float f4 __attribute__((ext_vector_type(4)));
+    const GateBwdPtrs P = blockIdx.y == 0 ? p0 : p1;
+    const float* __restrict__ dhs_t = P.dhs_t;
+    float* __restrict__ dh = P.dh;
+    const float* __restrict__ part = P.part;
+    const float* __restrict__ gates = P.gates;
+    const float* __restrict__ hn = P.hn;
+    const float* __restrict__ hprev = P.hprev;
+    float* __restrict__ dgi = P.dgi;
+    float* __restrict__ dgh = P.dgh;
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // group of four units
     const int hq = H >> 2;
     if (q >= (long long)R * hq) return;
@@ -262,11 +279,11 @@ extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* g
         float* dgh_t = dgh_all + (size_t)t * R3H;
         {
             dtc::ProfScope prof("gru_gate_bwd", (double)RH * 4.0 * 17, s);
-            if (vec4)
-                hipLaunchKernelGGL(gru_gate_bwd4_kernel, dim3(grid4), dim3(256), 0, s, dhs + (size_t)t * RH, dh0,
-                                   t == T - 1 ? (const float*)nullptr : (const float*)part, gates + (size_t)t * R3H,
-                                   hn + (size_t)t * RH, hs_all + (size_t)t * RH, dgi + (size_t)t * R3H, dgh_t, R, H, nparts);
-            else
+            if (vec4) {
+                const GateBwdPtrs gp{dhs + (size_t)t * RH, dh0, t == T - 1 ? (const float*)nullptr : (const float*)part, gates + (size_t)t * R3H,
+                                     hn + (size_t)t * RH, hs_all + (size_t)t * RH, dgi + (size_t)t * R3H, dgh_t};
+                hipLaunchKernelGGL(gru_gate_bwd4_kernel, dim3(grid4), dim3(256), 0, s, gp, gp, R, H, nparts);
+            } else
                 hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(grid), dim3(256), 0, s, dhs + (size_t)t * RH, dh0,
                                    t == T - 1 ? (const float*)nullptr : (const float*)part, gates + (size_t)t * R3H,
                                    hn + (size_t)t * RH, hs_all + (size_t)t * RH, dgi + (size_t)t * R3H, dgh_t, R, H, nparts);
@@ -288,4 +305,124 @@ extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* g
     int rc = dtc_linear_wgrad(dgh_all, 3 * H, &Hprev, dW_hh, db_hh, wg_ws, T * R, 3 * H, H, stream);
     if (rc != DTC_OK) return rc;
     return dtc::check_launch("gru_bwd");
+}
+
+// ---- several recurrences of ONE shape, one launch per time step (the actor's and the critic's GRU of ActorCriticRecurrent /
+// ActorCriticDecoderRecurrent: rsl_rl/rsl_rl/modules/actor_critic_recurrent.py:45-46, 92-116).  A time step of one recurrence is a
+// latency-bound launch of ~190-290 workgroups; two of them on two streams overlap by ~20 % (tools/gru_pair_probe.py: 1.16 ms for two
+// forward passes against 0.74 for one), the same two as ONE launch share the chip.  Results are bit-identical to the single calls
+// (same kernels, same tiles).  count > 2, or a shape / setting without the split-path step kernels: the single calls, one after the other.
+int dtc_gru_step_fwd_s3_pair(const float* const* hprev, const void* const* img, const float* const* b_hh, const float* const* gi_t,
+                             float* const* hout, float* const* gates_t, float* const* hn_t, int R, int H, void* stream);
+int dtc_gru_dgrad_parts_s3_pair(const float* const* dgh_t, const void* const* img, float* const* part, int64_t part_stride, int R, int H,
+                                int nparts, void* stream);
+
+extern "C" int dtc_gru_fwd_multi(const DtcGruFwdItem* items, int count, int T, int R, int H, void* stream) {
+    DTC_REQUIRE(items != nullptr && count >= 1 && count <= DTC_GRU_MULTI_MAX, "count = %d out of range (1..%d)", count, DTC_GRU_MULTI_MAX);
+    DTC_REQUIRE(T > 0 && R > 0 && H > 0, "bad shape T=%d R=%d H=%d", T, R, H);
+    static const bool off = getenv("DTC_GRU_MULTI") && atoi(getenv("DTC_GRU_MULTI")) == 0;
+    static const bool unfused = getenv("DTC_GRU_UNFUSED") != nullptr;
+    const bool pair = count == 2 && !off && !unfused && T >= 4 && gru_s3(H);
+    if (!pair) {
+        for (int i = 0; i < count; ++i) {
+            const DtcGruFwdItem& it = items[i];
+            int rc = dtc_gru_fwd(it.gi, it.h0, it.W_hh, it.b_hh, it.hs_all, it.gates, it.hn, it.workspace, T, R, H, stream);
+            if (rc != DTC_OK) return rc;
+        }
+        return DTC_OK;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t RH = (size_t)R * H, R3H = (size_t)R * 3 * H;
+    const void* img[2];
+    for (int i = 0; i < 2; ++i) {
+        const DtcGruFwdItem& it = items[i];
+        DTC_REQUIRE(it.gi && it.h0 && it.W_hh && it.b_hh && it.hs_all && it.gates && it.hn && it.workspace, "item %d: null pointer", i);
+        if (hipMemcpyAsync(it.hs_all, it.h0, RH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            dtc::set_error("gru_fwd_multi: h0 copy failed");
+            return DTC_ERR_LAUNCH;
+        }
+        void* im = gru_image_slot(it.workspace, T, R, H);
+        int rc = dtc_gru_s3_image(it.W_hh, im, H, 0, stream);
+        if (rc != DTC_OK) return rc;
+        img[i] = im;
+    }
+    for (int t = 0; t < T; ++t) {
+        const float *hprev[2], *bhh[2], *gi_t[2];
+        float *hout[2], *gates_t[2], *hn_t[2];
+        for (int i = 0; i < 2; ++i) {
+            const DtcGruFwdItem& it = items[i];
+            hprev[i] = it.hs_all + (size_t)t * RH;
+            bhh[i] = it.b_hh;
+            gi_t[i] = it.gi + (size_t)t * R3H;
+            hout[i] = it.hs_all + (size_t)(t + 1) * RH;
+            gates_t[i] = it.gates + (size_t)t * R3H;
+            hn_t[i] = it.hn + (size_t)t * RH;
+        }
+        int rc = dtc_gru_step_fwd_s3_pair(hprev, img, bhh, gi_t, hout, gates_t, hn_t, R, H, stream);
+        if (rc != DTC_OK) return rc;
+    }
+    return dtc::check_launch("gru_fwd_multi");
+}
+
+// BPTT of `count` recurrences without their W_hh weight gradients (dgh_all of item i at its workspace + dtc_gru_dgh_offset, as
+// dtc_gru_bwd with dW_hh = NULL leaves it)
+extern "C" int dtc_gru_bwd_multi(const DtcGruBwdItem* items, int count, int T, int R, int H, void* stream) {
+    DTC_REQUIRE(items != nullptr && count >= 1 && count <= DTC_GRU_MULTI_MAX, "count = %d out of range (1..%d)", count, DTC_GRU_MULTI_MAX);
+    DTC_REQUIRE(T > 0 && R > 0 && H > 0, "bad shape T=%d R=%d H=%d", T, R, H);
+    static const bool off = getenv("DTC_GRU_MULTI") && atoi(getenv("DTC_GRU_MULTI")) == 0;
+    static const bool vec_on = !(getenv("DTC_GRU_GATE_VEC") && atoi(getenv("DTC_GRU_GATE_VEC")) == 0);
+    auto a16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const size_t RH = (size_t)R * H, R3H = (size_t)R * 3 * H;
+    bool pair = count == 2 && !off && vec_on && gru_s3(H) && H % 4 == 0;
+    for (int i = 0; pair && i < count; ++i) {
+        const DtcGruBwdItem& it = items[i];
+        DTC_REQUIRE(it.dhs && it.hs_all && it.gates && it.hn && it.W_hh && it.dgi && it.dh0 && it.workspace, "item %d: null pointer", i);
+        pair = a16(it.dhs) && a16(it.dh0) && a16(it.workspace) && a16(it.gates) && a16(it.hn) && a16(it.hs_all) && a16(it.dgi) &&
+               a16((float*)it.workspace + (size_t)MAX_PARTS * RH);
+    }
+    if (!pair) {
+        for (int i = 0; i < count; ++i) {
+            const DtcGruBwdItem& it = items[i];
+            int rc = dtc_gru_bwd(it.dhs, it.hs_all, it.gates, it.hn, it.W_hh, it.dgi, nullptr, nullptr, it.dh0, it.workspace, nullptr, 0, T, R, H, stream);
+            if (rc != DTC_OK) return rc;
+        }
+        return DTC_OK;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int nparts = gru_parts(H, true);
+    const void* img[2];
+    float *part[2], *dgh_all[2];
+    for (int i = 0; i < 2; ++i) {
+        const DtcGruBwdItem& it = items[i];
+        part[i] = (float*)it.workspace;
+        dgh_all[i] = (float*)it.workspace + (size_t)MAX_PARTS * RH;
+        void* im = gru_image_slot(it.workspace, T, R, H);
+        int rc = dtc_gru_s3_image(it.W_hh, im, H, 1, stream);
+        if (rc != DTC_OK) return rc;
+        img[i] = im;
+        if (hipMemsetAsync(it.dh0, 0, RH * sizeof(float), s) != hipSuccess) {
+            dtc::set_error("gru_bwd_multi: memset failed");
+            return DTC_ERR_LAUNCH;
+        }
+    }
+    const unsigned grid = (unsigned)dtc::ceil_div((int64_t)RH, 256), grid4 = (unsigned)dtc::ceil_div((int64_t)RH / 4, 256);
+    for (int t = T - 1; t >= 0; --t) {
+        GateBwdPtrs gp[2];
+        const float* dgh_t[2];
+        for (int i = 0; i < 2; ++i) {
+            const DtcGruBwdItem& it = items[i];
+            dgh_t[i] = dgh_all[i] + (size_t)t * R3H;
+            gp[i] = GateBwdPtrs{it.dhs + (size_t)t * RH, it.dh0, t == T - 1 ? (const float*)nullptr : (const float*)part[i], it.gates + (size_t)t * R3H,
+                                it.hn + (size_t)t * RH, it.hs_all + (size_t)t * RH, it.dgi + (size_t)t * R3H, dgh_all[i] + (size_t)t * R3H};
+        }
+        {
+            dtc::ProfScope prof("gru_gate_bwd", 2.0 * (double)RH * 4.0 * 17, s);
+            hipLaunchKernelGGL(gru_gate_bwd4_kernel, dim3(grid4, 2), dim3(256), 0, s, gp[0], gp[1], R, H, nparts);
+        }
+        int rc = dtc_gru_dgrad_parts_s3_pair(dgh_t, img, part, (int64_t)RH, R, H, nparts, stream);
+        if (rc != DTC_OK) return rc;
+    }
+    for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL(gru_add_parts_kernel, dim3(grid), dim3(256), 0, s, items[i].dh0, part[i], (long long)RH, nparts);
+    return dtc::check_launch("gru_bwd_multi");
 }

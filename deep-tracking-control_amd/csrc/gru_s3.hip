@@ -49,6 +49,8 @@ struct GruS3Args {
     // backward epilogue: chunk c -> part + c * part_stride, [R, H]
     float* part;
     long long part_stride;
+    int colmap;                 // workgroup -> tile map by COLUMN tile (and chunk) per XCD: see gru_map
+    int nparts;
 };
 
 // forward image: tile tc = units [32 tc, 32 tc + 32), row n of the tile = gate n / 32 of unit 32 tc + n % 32, reduction = hidden
@@ -77,9 +79,12 @@ __device__ __forceinline__ float sigmoid_s3(float x) { return 1.0f / (1.0f + exp
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// blockIdx.z: which recurrence (dtc_gru_fwd_multi / dtc_gru_bwd_multi run the time step of up to two recurrences of one shape -- the
+// actor's and the critic's -- as ONE launch: two such launches on two streams overlap by only ~20 %, tools/gru_pair_probe.py)
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void gru_s3_kernel(const GruS3Args a) {
+__global__ __launch_bounds__(256, 2) void gru_s3_kernel(const GruS3Args a0, const GruS3Args a1) {
     using G = Geo<MODE>;
+    const GruS3Args a = blockIdx.z == 0 ? a0 : a1;
     constexpr int TM = G::TM, TN = G::TN, NA = 2, NM = 6 * TM * TN;
     constexpr int GAP0 = 4;                                   // the conversion levels follow MFMAs GAP0 .. GAP0 + 7 of a stage
     constexpr int PLANE = G::PLANE, CHUNK = G::CHUNK;        // local copies: the generic lambdas below must not odr-use the members
@@ -91,10 +96,22 @@ __global__ __launch_bounds__(256, 2) void gru_s3_kernel(const GruS3Args a) {
     __shared__ __attribute__((aligned(16))) u32x2 Bs2[3][128 * 4];
     __shared__ __attribute__((aligned(16))) u32x2 Bs3[3][128 * 4];
 #define GBS(b) ((b) == 0 ? Bs0 : (b) == 1 ? Bs1 : (b) == 2 ? Bs2 : Bs3)
-    int tr, tc;
+    int tr, tc, chunk = MODE == MODE_BWD ? blockIdx.y : 0;
     const int col_tiles = MODE == MODE_FWD ? a.H / 32 : a.H / 128;
-    if (!map_tile(blockIdx.x, (a.R + BM - 1) / BM, col_tiles, tr, tc)) return;
-    const int chunk = MODE == MODE_BWD ? blockIdx.y : 0;
+    if (a.colmap) {
+        // XCD x (= blockIdx.x & 7: workgroups go round-robin over the XCDs) owns a fixed set of (column tile, chunk) pairs and runs them
+        // for ALL row tiles: its slice of the W_hh image (1/8 of 4.7 MB) stays in its 4 MiB L2 over the 24 time steps, and what it
+        // fetches from the Infinity Cache per step is the row operand.  With the row-tile map every XCD walks the WHOLE image once per
+        // step -- more than its L2 holds -- and a time step's time follows the bytes that miss: two recurrences in one launch took 1.6 x
+        // the time of one (tools/gru_pair_probe.py).
+        const int row_tiles = (a.R + BM - 1) / BM, combos = col_tiles * a.nparts, per_xcd = (combos + 7) >> 3;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, cl = j / row_tiles;
+        tr = j - cl * row_tiles;
+        const int combo = xcd * per_xcd + cl;
+        if (combo >= combos) return;
+        chunk = combo / col_tiles;
+        tc = combo - chunk * col_tiles;
+    } else if (!map_tile(blockIdx.x, (a.R + BM - 1) / BM, col_tiles, tr, tc)) return;
     const int m0 = tr * BM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -327,11 +344,17 @@ extern "C" int dtc_gru_s3_image(const float* W_hh, void* img, int H, int backwar
 }
 
 // dtc_gru_step_fwd on the split-precision path; `img` = dtc_gru_s3_image(W_hh, backward = 0)
-extern "C" int dtc_gru_step_fwd_s3(const float* hprev, const void* img, const float* b_hh, const float* gi_t, float* hout, float* gates_t,
-                                   float* hn_t, int R, int H, void* stream) {
+namespace {
+// DTC_GRU_XCD_COLS=0: the row-tile map of the general GEMM kernels (map_tile)
+int gru_colmap() {
+    static const int on = !(getenv("DTC_GRU_XCD_COLS") && atoi(getenv("DTC_GRU_XCD_COLS")) == 0);
+    return on;
+}
+int fwd_args(GruS3Args& a, const float* hprev, const void* img, const float* b_hh, const float* gi_t, float* hout, float* gates_t,
+             float* hn_t, int R, int H) {
     DTC_REQUIRE(shapes_ok(R, H), "bad shape R=%d H=%d (H must be a multiple of 128)", R, H);
     DTC_REQUIRE(hprev && img && b_hh && gi_t && hout && gates_t && hn_t, "null pointer");
-    GruS3Args a{};
+    a = GruS3Args{};
     a.A = hprev;
     a.lda = H;
     a.img = (const u32x4*)img;
@@ -344,19 +367,44 @@ extern "C" int dtc_gru_step_fwd_s3(const float* hprev, const void* img, const fl
     a.hout = hout;
     a.gates = gates_t;
     a.hn = hn_t;
+    a.colmap = gru_colmap();
+    a.nparts = 1;
+    return DTC_OK;
+}
+int launch_fwd(const GruS3Args& a0, const GruS3Args& a1, int count, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    dtc::ProfScope prof(dtc::prof_shape_name("gru_step_fwd", R, 3 * H, H), 2.0 * R * 3.0 * H * H, s);
-    hipLaunchKernelGGL(gru_s3_kernel<MODE_FWD>, dim3((unsigned)grid_for((int)dtc::ceil_div(R, BM), H / 32)), dim3(256), 0, s, a);
+    const int R = a0.R, H = a0.H;
+    dtc::ProfScope prof(dtc::prof_shape_name("gru_step_fwd", R, 3 * H, H), count * 2.0 * R * 3.0 * H * H, s);
+    const unsigned gx = a0.colmap ? (unsigned)(8 * dtc::ceil_div(H / 32, 8) * dtc::ceil_div(R, BM)) : (unsigned)grid_for((int)dtc::ceil_div(R, BM), H / 32);
+    hipLaunchKernelGGL(gru_s3_kernel<MODE_FWD>, dim3(gx, 1, (unsigned)count), dim3(256), 0, s, a0, a1);
     return dtc::check_launch("gru_step_fwd_s3");
+}
+}  // namespace
+extern "C" int dtc_gru_step_fwd_s3(const float* hprev, const void* img, const float* b_hh, const float* gi_t, float* hout, float* gates_t,
+                                   float* hn_t, int R, int H, void* stream) {
+    GruS3Args a;
+    int rc = fwd_args(a, hprev, img, b_hh, gi_t, hout, gates_t, hn_t, R, H);
+    if (rc != DTC_OK) return rc;
+    return launch_fwd(a, a, 1, stream);
+}
+// the same time step of TWO recurrences of one shape in one launch (dtc_gru_fwd_multi)
+int dtc_gru_step_fwd_s3_pair(const float* const* hprev, const void* const* img, const float* const* b_hh, const float* const* gi_t,
+                             float* const* hout, float* const* gates_t, float* const* hn_t, int R, int H, void* stream) {
+    GruS3Args a[2];
+    for (int i = 0; i < 2; ++i) {
+        int rc = fwd_args(a[i], hprev[i], img[i], b_hh[i], gi_t[i], hout[i], gates_t[i], hn_t[i], R, H);
+        if (rc != DTC_OK) return rc;
+    }
+    return launch_fwd(a[0], a[1], 2, stream);
 }
 
 // the `nparts` chunks of dgh_t [R, 3H] W_hh [3H, H] side by side: chunk c -> part + c * part_stride ([R, H]); the caller adds
 // them in a fixed order; `img` = dtc_gru_s3_image(W_hh, backward = 1); (3H / nparts) must be a multiple of 64
-extern "C" int dtc_gru_dgrad_parts_s3(const float* dgh_t, const void* img, float* part, int64_t part_stride, int R, int H, int nparts,
-                                      void* stream) {
+namespace {
+int bwd_args(GruS3Args& a, const float* dgh_t, const void* img, float* part, int64_t part_stride, int R, int H, int nparts) {
     DTC_REQUIRE(shapes_ok(R, H) && nparts >= 1 && (3 * H) % nparts == 0 && (3 * H / nparts) % (4 * BK) == 0, "bad shape R=%d H=%d nparts=%d", R, H, nparts);
     DTC_REQUIRE(dgh_t && img && part && part_stride >= (int64_t)R * H, "null pointer / overlapping chunks");
-    GruS3Args a{};
+    a = GruS3Args{};
     a.A = dgh_t;
     a.lda = 3 * H;
     a.img = (const u32x4*)img;
@@ -367,10 +415,34 @@ extern "C" int dtc_gru_dgrad_parts_s3(const float* dgh_t, const void* img, float
     a.stages_tile = 3 * H / BK;
     a.part = part;
     a.part_stride = part_stride;
+    a.colmap = gru_colmap();
+    a.nparts = nparts;
+    return DTC_OK;
+}
+int launch_bwd(const GruS3Args& a0, const GruS3Args& a1, int count, int nparts, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", R, 3 * H, H), 2.0 * R * 3.0 * H * H, s,
-                        4.0 * ((double)R * 3 * H + 3.0 * H * H + (double)nparts * R * H));
-    const dim3 grid((unsigned)grid_for((int)dtc::ceil_div(R, BM), H / 128), (unsigned)nparts);
-    hipLaunchKernelGGL(gru_s3_kernel<MODE_BWD>, grid, dim3(256), 0, s, a);
+    const int R = a0.R, H = a0.H;
+    dtc::ProfScope prof(dtc::prof_shape_name("linear_dgrad", R, 3 * H, H), count * 2.0 * R * 3.0 * H * H, s,
+                        count * 4.0 * ((double)R * 3 * H + 3.0 * H * H + (double)nparts * R * H));
+    const dim3 grid = a0.colmap ? dim3((unsigned)(8 * dtc::ceil_div((H / 128) * nparts, 8) * dtc::ceil_div(R, BM)), 1, (unsigned)count)
+                                : dim3((unsigned)grid_for((int)dtc::ceil_div(R, BM), H / 128), (unsigned)nparts, (unsigned)count);
+    hipLaunchKernelGGL(gru_s3_kernel<MODE_BWD>, grid, dim3(256), 0, s, a0, a1);
     return dtc::check_launch("gru_dgrad_parts_s3");
+}
+}  // namespace
+extern "C" int dtc_gru_dgrad_parts_s3(const float* dgh_t, const void* img, float* part, int64_t part_stride, int R, int H, int nparts,
+                                      void* stream) {
+    GruS3Args a;
+    int rc = bwd_args(a, dgh_t, img, part, part_stride, R, H, nparts);
+    if (rc != DTC_OK) return rc;
+    return launch_bwd(a, a, 1, nparts, stream);
+}
+int dtc_gru_dgrad_parts_s3_pair(const float* const* dgh_t, const void* const* img, float* const* part, int64_t part_stride, int R, int H,
+                                int nparts, void* stream) {
+    GruS3Args a[2];
+    for (int i = 0; i < 2; ++i) {
+        int rc = bwd_args(a[i], dgh_t[i], img[i], part[i], part_stride, R, H, nparts);
+        if (rc != DTC_OK) return rc;
+    }
+    return launch_bwd(a[0], a[1], 2, nparts, stream);
 }

@@ -81,7 +81,7 @@ int dtc_abi_sizes(int64_t* out, int cap) {
     const int64_t sz[] = {sizeof(DtcGridCfg), sizeof(DtcObsCfg), sizeof(DtcRowCopy), sizeof(DtcSeg), sizeof(DtcSegMat),
                           sizeof(DtcFwdLayer), sizeof(DtcWgradJob), sizeof(DtcPpoCfg), sizeof(DtcProfRec), sizeof(DtcWimgJob),
                           sizeof(DtcH2iWJob), sizeof(DtcH2iOperand), sizeof(DtcWgradH2iJob), sizeof(DtcEnvStep), sizeof(DtcH2iFwdLayer),
-                          sizeof(DtcH2iDgradLayer)};
+                          sizeof(DtcH2iDgradLayer), sizeof(DtcGruFwdItem), sizeof(DtcGruBwdItem)};
     const int n = (int)(sizeof(sz) / sizeof(sz[0]));
     for (int i = 0; i < n && i < cap && out; ++i) out[i] = sz[i];
     return n;

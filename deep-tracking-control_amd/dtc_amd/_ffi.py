@@ -70,6 +70,16 @@ class DtcH2iDgradLayer(C.Structure):
                 ("Kwin", C.c_int32), ("img_cols", C.c_int32), ("act", C.c_int32)]
 
 
+class DtcGruFwdItem(C.Structure):
+    _fields_ = [("gi", C.c_void_p), ("h0", C.c_void_p), ("W_hh", C.c_void_p), ("b_hh", C.c_void_p), ("hs_all", C.c_void_p),
+                ("gates", C.c_void_p), ("hn", C.c_void_p), ("workspace", C.c_void_p)]
+
+
+class DtcGruBwdItem(C.Structure):
+    _fields_ = [("dhs", C.c_void_p), ("hs_all", C.c_void_p), ("gates", C.c_void_p), ("hn", C.c_void_p), ("W_hh", C.c_void_p),
+                ("dgi", C.c_void_p), ("dh0", C.c_void_p), ("workspace", C.c_void_p)]
+
+
 class DtcWgradH2iJob(C.Structure):
     _fields_ = [("dZimg", C.c_void_p), ("Ximg", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("ldw", C.c_int64),
                 ("N", C.c_int32), ("K", C.c_int32), ("wcol0", C.c_int32)]
@@ -116,7 +126,7 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 13         # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 14         # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
@@ -251,6 +261,8 @@ _SIGS = {
     "dtc_gru_dgh_offset": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dtc_gru_fwd": (C.c_int, [c_f32p] * 7 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_gru_bwd": (C.c_int, [c_f32p] * 9 + [C.c_void_p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_gru_fwd_multi": (C.c_int, [C.POINTER(DtcGruFwdItem), C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_gru_bwd_multi": (C.c_int, [C.POINTER(DtcGruBwdItem), C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_set_concurrency_hint": (None, [C.c_int]),
     "dtc_lstm_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dtc_lstm_fwd": (C.c_int, [c_f32p] * 8 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
@@ -288,7 +300,7 @@ def _check_abi(l):
     (DTC_LIB may point at a separately built library, e.g. the ASan build: a stale one would misread every descriptor)."""
     global _lib
     mine = [DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat, DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcH2iWJob,
-            DtcH2iOperand, DtcWgradH2iJob, DtcEnvStep, DtcH2iFwdLayer, DtcH2iDgradLayer]
+            DtcH2iOperand, DtcWgradH2iJob, DtcEnvStep, DtcH2iFwdLayer, DtcH2iDgradLayer, DtcGruFwdItem, DtcGruBwdItem]
     sizes = (C.c_int64 * 32)()
     n = l.dtc_abi_sizes(sizes, 32)
     theirs = list(sizes[:n])

@@ -15,6 +15,8 @@ Same constructor keywords / method names as `PPO`; weight gradients run on the s
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _ffi, distributed as dp, h2i, ops
@@ -27,6 +29,9 @@ from .ppo import PPO, S_GNORM, S_KL, S_RECONS, S_SURR, S_VALUE, S_VEL, S_KLD, ST
 
 class RecurrentDecoderPPO(PPO):
     actor_critic: ActorCriticDecoderRecurrent
+    # the actor's and the critic's recurrence advance together, one launch per time step (dtc_gru_fwd_multi / dtc_gru_bwd_multi);
+    # DTC_GRU_MULTI=0: one chain of launches per recurrence, each on its own lane
+    gru_multi = os.environ.get("DTC_GRU_MULTI", "0") == "1"
 
     # ---------------------------------------------------------------- rollout side
     def act(self, obs, privileged_obs, obs_history, base_vel, rew_buf=None):
@@ -204,7 +209,11 @@ class RecurrentDecoderPPO(PPO):
         tw.live_img.clear()
         rows = lambda t, w: segmat([seg(t, 0, w, gather=True)], unpad_idx)
 
-        def head_forward(name, X, cols, mem, proj, layers, h0):
+        # A head runs in three parts so that the two recurrences can advance TOGETHER (ops.gru_fwd_multi / gru_bwd_multi: one launch
+        # per time step for the actor's and the critic's GRU -- two such chains on two streams overlap by only ~20 %,
+        # tools/gru_pair_probe.py): input projection (each head on its lane) | both recurrences (main lane) | MLP (each on its lane).
+        # DTC_GRU_MULTI=0: each head's recurrence by itself, on its own lane, as before.
+        def head_project(name, X, cols, mem, proj, layers, h0):
             gi_v = tw.g("gi_" + name, 3 * H)
             h2i.linear_fwd(X, proj.W, proj.b, gi_v, None, None, wset=wset, cols=cols)
             gi_p = self._padded(tw, "gi_" + name, T * R, 3 * H)     # padded steps keep finite stale values (never used)
@@ -212,7 +221,17 @@ class RecurrentDecoderPPO(PPO):
             hs_all = torch.empty(T + 1, R, H, device=dev)
             gates, hn = torch.empty(T, R, 3 * H, device=dev), torch.empty(T, R, H, device=dev)
             ws = ops.workspace(ops.gru_workspace_bytes(T, R, H), dev)
-            ops.gru_fwd(gi_p.view(T, R, 3 * H), h0.contiguous(), mem.W_hh, mem.b_hh, hs_all, gates, hn, ws)
+            hd = dict(name=name, X=X, cols=cols, mem=mem, proj=proj, layers=layers, hs_all=hs_all, gates=gates, hn=hn, ws=ws,
+                      gi_p=gi_p, h0=h0.contiguous())
+            if not self.gru_multi:
+                ops.gru_fwd(*fwd_item(hd))
+            return hd
+
+        def fwd_item(hd):
+            return (hd["gi_p"].view(T, R, 3 * H), hd["h0"], hd["mem"].W_hh, hd["mem"].b_hh, hd["hs_all"], hd["gates"], hd["hn"], hd["ws"])
+
+        def head_mlp(hd):
+            name, layers, hs_all = hd["name"], hd["layers"], hd["hs_all"]
             hx = tw.img("hx_" + name, H).pack(rows(hs_all[1:].reshape(T * R, H), H), M)
             outs, imgs = [], [hx]
             for li, L in enumerate(layers):
@@ -221,14 +240,11 @@ class RecurrentDecoderPPO(PPO):
                 h2i.linear_fwd(imgs[-1], L.W, L.b, o, oi, L.act, wset=wset)
                 outs.append(o)
                 imgs.append(oi)
-            return dict(name=name, X=X, cols=cols, mem=mem, proj=proj, layers=layers, hs_all=hs_all, gates=gates, hn=hn, ws=ws,
-                        outs=outs, imgs=imgs)
+            hd.update(outs=outs, imgs=imgs)
+            return hd
 
-        def head_backward(hd, dOut, full_dgi=True):
-            """MLP backward, BPTT, the W_hh weight gradient (queued); returns the image(s) of dgi over the valid rows: the whole [M, 3H]
-            image (the actor: its input projection's data gradient reduces over all 3H columns), or (full_dgi=False, the critic) the
-            pair (r / z blocks [M, 2H], n block [M, H]) -- dgh and dgi share their r / z blocks (gru_gate_bwd_kernel: da_n vs da_n * r
-            in the n block only), so those 2H columns are packed once and each weight gradient runs as two jobs over row ranges."""
+        def head_mlp_backward(hd, dOut):
+            """MLP backward down to the padded gradient of the recurrence's outputs."""
             name, layers, outs, imgs, mem = hd["name"], hd["layers"], hd["outs"], hd["imgs"], hd["mem"]
             dZi = tw.img("dout_" + name, dOut.shape[1]).pack(dOut)
             d_in = tw.g(f"{name}_d0", H)
@@ -245,9 +261,21 @@ class RecurrentDecoderPPO(PPO):
             dhs.zero_()
             ops.scatter_rows(d_in, unpad_idx, dhs)
             dgi_p, dh0 = torch.empty(T, R, 3 * H, device=dev), torch.empty(R, H, device=dev)
-            ops.gru_bwd(dhs.view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], mem.W_hh, dgi_p, None, None, dh0, hd["ws"])
-            hpi = tw.img("hp_" + name, H).pack(rows(hd["hs_all"][:T].reshape(T * R, H), H), M)
+            hd.update(dhs=dhs, dgi_p=dgi_p, dh0=dh0)
             tw.held.append((dgi_p, dh0, hd))
+            if not self.gru_multi:
+                ops.gru_bwd(dhs.view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], mem.W_hh, dgi_p, None, None, dh0, hd["ws"])
+
+        def bwd_item(hd):
+            return (hd["dhs"].view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], hd["mem"].W_hh, hd["dgi_p"], hd["dh0"], hd["ws"])
+
+        def head_recurrence_grads(hd, full_dgi=True):
+            """Behind the BPTT: the W_hh weight gradient (queued); returns the image(s) of dgi over the valid rows: the whole [M, 3H]
+            image (the actor: its input projection's data gradient reduces over all 3H columns), or (full_dgi=False, the critic) the
+            pair (r / z blocks [M, 2H], n block [M, H]) -- dgh and dgi share their r / z blocks (gru_gate_bwd_kernel: da_n vs da_n * r
+            in the n block only), so those 2H columns are packed once and each weight gradient runs as two jobs over row ranges."""
+            name, mem, dgi_p = hd["name"], hd["mem"], hd["dgi_p"]
+            hpi = tw.img("hp_" + name, H).pack(rows(hd["hs_all"][:T].reshape(T * R, H), H), M)
             dgh = ops.gru_dgh_all(hd["ws"], T, R, H)
             if full_dgi:
                 dghi = tw.img("dgh_" + name, 3 * H).pack(rows(dgh, 3 * H), M)
@@ -265,7 +293,7 @@ class RecurrentDecoderPPO(PPO):
 
         with tw.lane("aux"):
             Xc = ac.packed_input(fw, "p_c", ac.critic_input(obs, flat["base_vel"], priv, idx), idx, reuse=True)
-            hc = head_forward("c", Xc, None, ac.memory_c, ac.proj_c, ac.Cr, bt["hid_c"])
+            hc = head_project("c", Xc, None, ac.memory_c, ac.proj_c, ac.Cr, bt["hid_c"])
         ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=self.relu_masks, split=ns, images=imn, wset=wset)
         ac.terrain_encoder_(fw, priv, idx, masks=self.relu_masks, images=True, wset=wset, lt_fp32=False)
         if imn:        # the actor's features as three images: l_t, the gathered observations (packed once), the latent kernel's [z | mu[:, :3]]
@@ -274,7 +302,14 @@ class RecurrentDecoderPPO(PPO):
         else:
             Xa = [fw.img("lt"), ac.packed_input(fw, "p_a", segmat([seg(obs, 0, ac.num_obs, gather=True), seg(fw.z, 0, 16), seg(fw.mulv, 0, 3)], idx))]
             a_cols = [ac.num_obs + 19, 0]
-        ha = head_forward("a", Xa, a_cols, ac.memory_a, ac.proj_a, ac.A, bt["hid_a"])
+        ha = head_project("a", Xa, a_cols, ac.memory_a, ac.proj_a, ac.A, bt["hid_a"])
+        if self.gru_multi:
+            tw.order("aux", "main")                                 # the critic's input projection is written
+            ops.gru_fwd_multi([fwd_item(ha), fwd_item(hc)])
+            tw.order("main", "aux")
+        with tw.lane("aux"):
+            head_mlp(hc)
+        head_mlp(ha)
         tw.order("aux", "main")
         if self.after_forward_hook is not None:
             self.after_forward_hook(fw, "ppo")
@@ -285,11 +320,18 @@ class RecurrentDecoderPPO(PPO):
         self._kl_to_header(stats)
         tw.order("main", "aux")
         with tw.lane("aux"):
-            rzi_c, nii_c = head_backward(hc, tw.dval, full_dgi=False)
+            head_mlp_backward(hc, tw.dval)
+        head_mlp_backward(ha, tw.dmean)
+        if self.gru_multi:
+            tw.order("aux", "main")
+            ops.gru_bwd_multi([bwd_item(ha), bwd_item(hc)])
+            tw.order("main", "aux")
+        with tw.lane("aux"):
+            rzi_c, nii_c = head_recurrence_grads(hc, full_dgi=False)
             pc = hc["proj"]
             self._bwd_img(tw, Dense(pc.W[:2 * H], pc.b[:2 * H], pc.gW[:2 * H], pc.gb[:2 * H], None), rzi_c, Xc)
             self._bwd_img(tw, Dense(pc.W[2 * H:], pc.b[2 * H:], pc.gW[2 * H:], pc.gb[2 * H:], None), nii_c, Xc)
-        dgii_a = head_backward(ha, tw.dmean)
+        dgii_a = head_recurrence_grads(ha)
         # the actor features' gradient fans out to z, mu[:, :3] (fp32) and l_t (image); the observations need none
         tw.dmulv.zero_()
         nb = ac.num_obs + 19

@@ -53,6 +53,8 @@ class RecurrentPPO:
         # actor and critic are independent recurrences until the loss and again until the optimiser step: the critic
         # runs on a second stream, every weight gradient on a third (DTC_OVERLAP_LANES=0 / DTC_OVERLAP_WGRAD=0: serial)
         self.overlap = os.environ.get("DTC_OVERLAP_LANES", "1") != "0" and os.environ.get("DTC_OVERLAP_WGRAD", "1") != "0"
+        # memory_a and memory_c advance together, one launch per time step (dtc_gru_fwd_multi / dtc_gru_bwd_multi); 0: one chain each
+        self.gru_multi = os.environ.get("DTC_GRU_MULTI", "0") == "1"
         self._lanes = None
         self._wimages = None
         # every GEMM outside the GRU time steps on block-scaled fp16 operand images (dtc_amd/h2i.py; DTC_H2I=0: round 4's converting
@@ -282,7 +284,13 @@ class RecurrentPPO:
         H = ac.rnn_hidden_size
         ln.begin(self.overlap)
 
-        def head_forward(name, mem, layers, x, hidden):
+        # A head runs in three parts so that the two recurrences advance TOGETHER (ops.gru_fwd_multi / gru_bwd_multi: ONE launch per time
+        # step for memory_a and memory_c -- two chains of latency-bound launches on two streams overlap by only ~20 %,
+        # tools/gru_pair_probe.py): input projection (each head on its lane) | both recurrences (main) | MLP (each on its lane).
+        # DTC_GRU_MULTI=0: every head's recurrence by itself on its own lane.
+        multi = self.gru_multi
+
+        def head_project(name, mem, layers, x, hidden):
             ximg = self._packed_obs("x_" + name, x, unpad_idx, M, dev)
             gi_c = torch.empty(M, 3 * H, device=dev)
             h2i.linear_fwd(ximg, mem.W_ih, mem.b_ih, gi_c, None, None, wset=wset)
@@ -291,7 +299,17 @@ class RecurrentPPO:
             h0, _ = mem._split(hidden)
             hs_all, gates, hn = torch.empty(T + 1, R, H, device=dev), torch.empty(T, R, 3 * H, device=dev), torch.empty(T, R, H, device=dev)
             ws = ops.workspace(ops.gru_workspace_bytes(T, R, H), dev)
-            ops.gru_fwd(gi.view(T, R, 3 * H), h0[0].contiguous(), mem.W_hh, mem.b_hh, hs_all, gates, hn, ws)
+            hd = dict(name=name, mem=mem, layers=layers, ximg=ximg, hs_all=hs_all, gates=gates, hn=hn, ws=ws, gi=gi, h0=h0[0].contiguous(),
+                      keep=[gi_c])
+            if not multi:
+                ops.gru_fwd(*fwd_item(hd))
+            return hd
+
+        def fwd_item(hd):
+            return (hd["gi"].view(T, R, 3 * H), hd["h0"], hd["mem"].W_hh, hd["mem"].b_hh, hd["hs_all"], hd["gates"], hd["hn"], hd["ws"])
+
+        def head_mlp(hd):
+            name, layers, hs_all = hd["name"], hd["layers"], hd["hs_all"]
             # the MLP reads the un-padded outputs as an image; its hidden activations leave as fp32 (ELU derivative) AND as images
             hx = self._img("hx_" + name, M, H, dev).pack(segmat([seg(hs_all[1:].reshape(T * R, H), 0, H, gather=True)], unpad_idx), M)
             outs, imgs = [], [hx]
@@ -301,12 +319,11 @@ class RecurrentPPO:
                 h2i.linear_fwd(imgs[-1], L.W, L.b, o, oi, L.act, wset=wset)
                 outs.append(o)
                 imgs.append(oi)
-            return dict(name=name, mem=mem, layers=layers, ximg=ximg, hs_all=hs_all, gates=gates, hn=hn, ws=ws, outs=outs, imgs=imgs,
-                        keep=[gi_c])
+            hd.update(outs=outs, imgs=imgs)
 
-        def head_backward(hd, dOut):
+        def head_mlp_backward(hd, dOut):
             name, mem, layers, outs, imgs = hd["name"], hd["mem"], hd["layers"], hd["outs"], hd["imgs"]
-            jobs = []
+            jobs = hd["jobs"] = []
             dZi = self._img("dout_" + name, M, dOut.shape[1], dev).pack(dOut)
             d_in = torch.empty(M, H, device=dev)
             for li in range(len(layers) - 1, -1, -1):
@@ -321,7 +338,16 @@ class RecurrentPPO:
             dhs = torch.zeros(T * R, H, device=dev)
             ops.scatter_rows(d_in, unpad_idx, dhs)
             dgi, dh0 = torch.empty(T, R, 3 * H, device=dev), torch.empty(R, H, device=dev)
-            ops.gru_bwd(dhs.view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], mem.W_hh, dgi, None, None, dh0, hd["ws"])
+            hd.update(dhs=dhs, dgi=dgi, dh0=dh0)
+            hd["keep"] += [d_in, dhs, dgi, dh0, jobs]
+            if not multi:
+                ops.gru_bwd(dhs.view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], mem.W_hh, dgi, None, None, dh0, hd["ws"])
+
+        def bwd_item(hd):
+            return (hd["dhs"].view(T, R, H), hd["hs_all"], hd["gates"], hd["hn"], hd["mem"].W_hh, hd["dgi"], hd["dh0"], hd["ws"])
+
+        def head_recurrence_grads(hd):
+            name, mem, jobs, dgi = hd["name"], hd["mem"], hd["jobs"], hd["dgi"]
             # the recurrence's two weight gradients over the VALID (t, r) slots: dgh / dgi / h_{t-1} rows gathered into images
             # (dgh and dgi share their r / z gate blocks and differ in the n block -- gru_gate_bwd_kernel: da_n vs da_n * r --: the shared
             # 2H columns are packed once, each product runs as two jobs over the row ranges [0, 2H) and [2H, 3H) of its gradient)
@@ -348,11 +374,17 @@ class RecurrentPPO:
                 ln.side_busy = True
             else:
                 h2i.wgrad_group(jobs, M, wg)
-            hd["keep"] += [d_in, dhs, dgi, dh0, jobs]
 
         with ln.lane("aux"):
-            hc = head_forward("c", ac.memory_c, ac.Cr, cobs_b, hid_c)
-        ha = head_forward("a", ac.memory_a, ac.A, obs_b, hid_a)
+            hc = head_project("c", ac.memory_c, ac.Cr, cobs_b, hid_c)
+        ha = head_project("a", ac.memory_a, ac.A, obs_b, hid_a)
+        if multi:
+            ln.order("aux", "main")
+            ops.gru_fwd_multi([fwd_item(ha), fwd_item(hc)])
+            ln.order("main", "aux")
+        with ln.lane("aux"):
+            head_mlp(hc)
+        head_mlp(ha)
         ln.order("aux", "main")
         mean, value = ha["outs"][-1], hc["outs"][-1]
         ac._dist = (mean, ac.std_view.detach().expand_as(mean))
@@ -369,8 +401,15 @@ class RecurrentPPO:
             arena.kl_slot.copy_(stats[S_KL:S_KL + 1])            # the KL mean travels in the header of the gradient exchange
         ln.order("main", "aux")
         with ln.lane("aux"):
-            head_backward(hc, dval)
-        head_backward(ha, dmean)
+            head_mlp_backward(hc, dval)
+        head_mlp_backward(ha, dmean)
+        if multi:
+            ln.order("aux", "main")
+            ops.gru_bwd_multi([bwd_item(ha), bwd_item(hc)])
+            ln.order("main", "aux")
+        with ln.lane("aux"):
+            head_recurrence_grads(hc)
+        head_recurrence_grads(ha)
         ln.join()
         self._held = (ha, hc, dmean, dval, lws)                 # (until the next step: nothing here returns to the allocator early)
 

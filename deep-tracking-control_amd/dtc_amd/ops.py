@@ -762,6 +762,30 @@ def gru_bwd(dhs, hs_all, gates, hn, W_hh, dgi, dW_hh, db_hh, dh0, ws, rows=None)
                             stream()), "dtc_gru_bwd")
 
 
+def gru_fwd_multi(items):
+    """`items`: one (gi, h0, W_hh, b_hh, hs_all, gates, hn, ws) tuple per recurrence, all of one shape -- dtc_gru_fwd_multi: with two
+    items every time step is ONE launch for both (bit-identical to gru_fwd on each)."""
+    T, R, H3 = items[0][0].shape
+    assert all(tuple(it[0].shape) == (T, R, H3) for it in items)
+    arr = (_ffi.DtcGruFwdItem * len(items))()
+    for a, (gi, h0, W_hh, b_hh, hs_all, gates, hn, ws) in zip(arr, items):
+        a.gi, a.h0, a.W_hh, a.b_hh = cptr(gi, f32), cptr(h0, f32), cptr(W_hh, f32), cptr(b_hh, f32)
+        a.hs_all, a.gates, a.hn, a.workspace = cptr(hs_all, f32), cptr(gates, f32), cptr(hn, f32), ptr(ws)
+    check(lib().dtc_gru_fwd_multi(arr, len(items), T, R, H3 // 3, stream()), "dtc_gru_fwd_multi")
+
+
+def gru_bwd_multi(items):
+    """`items`: one (dhs, hs_all, gates, hn, W_hh, dgi, dh0, ws) tuple per recurrence, all of one shape -- dtc_gru_bwd_multi (no W_hh
+    weight gradient: see gru_dgh_all)."""
+    T, R, H = items[0][0].shape
+    assert all(tuple(it[0].shape) == (T, R, H) for it in items)
+    arr = (_ffi.DtcGruBwdItem * len(items))()
+    for a, (dhs, hs_all, gates, hn, W_hh, dgi, dh0, ws) in zip(arr, items):
+        a.dhs, a.hs_all, a.gates, a.hn, a.W_hh = cptr(dhs, f32), cptr(hs_all, f32), cptr(gates, f32), cptr(hn, f32), cptr(W_hh, f32)
+        a.dgi, a.dh0, a.workspace = cptr(dgi, f32), cptr(dh0, f32), ptr(ws)
+    check(lib().dtc_gru_bwd_multi(arr, len(items), T, R, H, stream()), "dtc_gru_bwd_multi")
+
+
 def gru_dgh_all(ws, T, R, H):
     """dgh_all [T * R, 3H] inside the workspace of a dtc_gru_bwd call (the gradient w.r.t. the recurrent pre-activations; valid once
     the call has run): the dZ operand of the W_hh weight gradient when the caller forms it itself (dW_hh = None)."""

@@ -65,4 +65,9 @@ for name, f in (("fwd", fwd), ("bwd", bwd)):
     one = timed(lambda: f(a))
     seq = timed(lambda: (f(a), f(b)))
     par = timed(two_streams(f))
-    print(f"{name}: one recurrence {one:.3f} ms ({one / T * 1e3:.1f} us per time step), two on one stream {seq:.3f} ms, two on two streams {par:.3f} ms")
+    if name == "fwd":
+        mul = timed(lambda: ops.gru_fwd_multi([(d["gi"], d["h0"], d["W"], d["b"], d["hs"], d["gates"], d["hn"], d["ws"]) for d in (a, b)]))
+    else:
+        mul = timed(lambda: ops.gru_bwd_multi([(d["dhs"], d["hs"], d["gates"], d["hn"], d["W"], d["dgi"], d["dh0"], d["ws"]) for d in (a, b)]))
+    print(f"{name}: one recurrence {one:.3f} ms ({one / T * 1e3:.1f} us per time step), two on one stream {seq:.3f} ms, two on two streams {par:.3f} ms, "
+          f"two in one launch per time step {mul:.3f} ms")

@@ -38,10 +38,10 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-#define DTC_ABI_VERSION 13                   /* bumped whenever a signature or a by-value struct layout changes       */
+#define DTC_ABI_VERSION 14                   /* bumped whenever a signature or a by-value struct layout changes       */
 int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
 /* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
-   DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcH2iWJob, DtcH2iOperand, DtcWgradH2iJob, DtcEnvStep: the binding compares them with its own layouts at load time (a library
+   DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcH2iWJob, DtcH2iOperand, DtcWgradH2iJob, DtcEnvStep, DtcH2iFwdLayer, DtcH2iDgradLayer, DtcGruFwdItem, DtcGruBwdItem: the binding compares them with its own layouts at load time (a library
    built from another revision -- e.g. a stale DTC_LIB override -- must not receive descriptors it would misread).
    Returns the number of entries (written up to `cap`). */
 int dtc_abi_sizes(int64_t* out, int cap);
@@ -643,6 +643,37 @@ int64_t dtc_gru_dgh_offset(int T, int R, int H);
 int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* gates, const float* hn, const float* W_hh,
                 float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace, const int64_t* valid_rows, int n_valid,
                 int T, int R, int H, void* stream);
+
+/* Several recurrences of ONE shape (T, R, H) advanced together -- the actor's and the critic's `Memory` of ActorCriticRecurrent
+ * (actor_critic_recurrent.py:45-46: memory_a, memory_c; both are evaluated on the same mini-batch of padded trajectories,
+ * ppo.py:265-272): with count == 2 every time step is ONE launch for both (a time step of one recurrence is a latency-bound launch of
+ * ~200-300 workgroups; two of them on two streams overlap by only ~20 %).  Results are bit-identical to dtc_gru_fwd / dtc_gru_bwd on
+ * each item.  Settings or shapes without the split-path step kernels, and count == 1: the single calls, one after the other.
+ * dtc_gru_bwd_multi never forms the W_hh weight gradients: dgh_all of item i sits at its workspace + dtc_gru_dgh_offset(T, R, H),
+ * as after dtc_gru_bwd with dW_hh == NULL.  Each item brings its own workspace (>= dtc_gru_workspace bytes). */
+#define DTC_GRU_MULTI_MAX 2
+typedef struct DtcGruFwdItem {
+    const float* gi;     /* [T,R,3H] */
+    const float* h0;     /* [R,H]    */
+    const float* W_hh;   /* [3H,H]   */
+    const float* b_hh;   /* [3H]     */
+    float* hs_all;       /* [T+1,R,H] */
+    float* gates;        /* [T,R,3H] */
+    float* hn;           /* [T,R,H]  */
+    void* workspace;
+} DtcGruFwdItem;
+typedef struct DtcGruBwdItem {
+    const float* dhs;    /* [T,R,H]  */
+    const float* hs_all;
+    const float* gates;
+    const float* hn;
+    const float* W_hh;
+    float* dgi;          /* [T,R,3H] */
+    float* dh0;          /* [R,H]    */
+    void* workspace;
+} DtcGruBwdItem;
+int dtc_gru_fwd_multi(const DtcGruFwdItem* items, int count, int T, int R, int H, void* stream);
+int dtc_gru_bwd_multi(const DtcGruBwdItem* items, int count, int T, int R, int H, void* stream);
 
 /* ---- LSTM (torch.nn.LSTM, gate order i,f,g,o; the default `rnn_type` of actor_critic_recurrent.py:93-97) ----
  * gi [T,R,4H] = x W_ih^T + b_ih is computed by dtc_linear_fwd over all T*R rows; this runs

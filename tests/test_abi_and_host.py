@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     # the struct layouts of the binding are the library's (checked at load time; here: the check itself works)
     sizes = (C.c_int64 * 32)()
     n = _ffi.lib().dtc_abi_sizes(sizes, 32)
-    assert n == 16 and sizes[14] == C.sizeof(_ffi.DtcH2iFwdLayer) and sizes[15] == C.sizeof(_ffi.DtcH2iDgradLayer) and sizes[13] == C.sizeof(_ffi.DtcEnvStep) and sizes[3] == C.sizeof(_ffi.DtcSeg) and sizes[6] == C.sizeof(_ffi.DtcWgradJob) and sizes[9] == C.sizeof(_ffi.DtcWimgJob) and \
+    assert n == 18 and sizes[16] == C.sizeof(_ffi.DtcGruFwdItem) and sizes[17] == C.sizeof(_ffi.DtcGruBwdItem) and sizes[14] == C.sizeof(_ffi.DtcH2iFwdLayer) and sizes[15] == C.sizeof(_ffi.DtcH2iDgradLayer) and sizes[13] == C.sizeof(_ffi.DtcEnvStep) and sizes[3] == C.sizeof(_ffi.DtcSeg) and sizes[6] == C.sizeof(_ffi.DtcWgradJob) and sizes[9] == C.sizeof(_ffi.DtcWimgJob) and \
         sizes[10] == C.sizeof(_ffi.DtcH2iWJob) and sizes[11] == C.sizeof(_ffi.DtcH2iOperand) and sizes[12] == C.sizeof(_ffi.DtcWgradH2iJob)
 
 

@@ -106,3 +106,38 @@ def test_split_precision_step_kernels_vs_fp64(R):
         e32 = float((p32.double().sum(0) - ref).abs().max() / ref.abs().max())
         print(f"gru dgrad chunks R={R} nparts={nparts}: fp32 MFMA err {e32:.2e}, split err {es3:.2e}")
         assert es3 <= 2.0 * e32 + 2e-7, (nparts, e32, es3)
+
+
+@pytest.mark.parametrize("T,R,H", [(24, 1473, 512), (6, 77, 128), (2, 40, 128), (5, 7, 64)])
+def test_two_recurrences_in_one_launch_per_time_step_equal_the_single_calls_bit_for_bit(T, R, H):
+    """dtc_gru_fwd_multi / dtc_gru_bwd_multi (the actor's and the critic's Memory advanced together, actor_critic_recurrent.py:45-46):
+    ONE launch per time step for both recurrences -- the same kernels on the same tiles, so every output equals the single calls' bit
+    for bit (incl. dgh_all in the workspace, which the trainers' W_hh weight gradient reads).  (2, 40, 128) and (5, 7, 64) take the
+    documented fall-back: the single calls one after the other."""
+    from dtc_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(T * 100 + R)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+
+    def make():
+        return dict(gi=rn(T, R, 3 * H), h0=0.5 * rn(R, H), W=rn(3 * H, H) / H ** 0.5, b=0.2 * rn(3 * H), dhs=0.01 * rn(T, R, H))
+
+    def outs():
+        d = dict(hs=torch.empty(T + 1, R, H, device=DEV), gates=torch.empty(T, R, 3 * H, device=DEV), hn=torch.empty(T, R, H, device=DEV),
+                 dgi=torch.empty(T, R, 3 * H, device=DEV), dh0=torch.empty(R, H, device=DEV))
+        d["ws"] = ops.workspace(ops.gru_workspace_bytes(T, R, H), DEV)
+        d["ws"].zero_()
+        return d
+
+    ins = [make(), make()]
+    single, multi = [outs(), outs()], [outs(), outs()]
+    for x, o in zip(ins, single):
+        ops.gru_fwd(x["gi"], x["h0"], x["W"], x["b"], o["hs"], o["gates"], o["hn"], o["ws"])
+        ops.gru_bwd(x["dhs"], o["hs"], o["gates"], o["hn"], x["W"], o["dgi"], None, None, o["dh0"], o["ws"])
+    ops.gru_fwd_multi([(x["gi"], x["h0"], x["W"], x["b"], o["hs"], o["gates"], o["hn"], o["ws"]) for x, o in zip(ins, multi)])
+    ops.gru_bwd_multi([(x["dhs"], o["hs"], o["gates"], o["hn"], x["W"], o["dgi"], o["dh0"], o["ws"]) for x, o in zip(ins, multi)])
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(single, multi)):
+        for k in ("hs", "gates", "hn", "dgi", "dh0"):
+            assert torch.equal(a[k], b[k]), (i, k)
+        assert torch.equal(ops.gru_dgh_all(a["ws"], T, R, H), ops.gru_dgh_all(b["ws"], T, R, H)), (i, "dgh_all")
+    assert not torch.equal(single[0]["hs"], single[1]["hs"])      # (the two recurrences are different problems)
