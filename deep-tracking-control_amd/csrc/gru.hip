@@ -309,9 +309,11 @@ extern "C" int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* g
 
 // ---- several recurrences of ONE shape, one launch per time step (the actor's and the critic's GRU of ActorCriticRecurrent /
 // ActorCriticDecoderRecurrent: rsl_rl/rsl_rl/modules/actor_critic_recurrent.py:45-46, 92-116).  A time step of one recurrence is a
-// latency-bound launch of ~190-290 workgroups; two of them on two streams overlap by ~20 % (tools/gru_pair_probe.py: 1.16 ms for two
-// forward passes against 0.74 for one), the same two as ONE launch share the chip.  Results are bit-identical to the single calls
-// (same kernels, same tiles).  count > 2, or a shape / setting without the split-path step kernels: the single calls, one after the other.
+// latency-bound launch of ~190-290 workgroups; two of them on two streams overlap by ~20 % (tools/gru_pair_probe.py: 1.12 ms for two
+// forward passes against 0.72 for one).  The same two as ONE launch: 1.09 ms -- a launch with twice the workgroups takes 1.5 x as long,
+// and in the trainers the merged chain is slower than two chains on two lanes: an option, not the default.  Results
+// are bit-identical to the single calls (same kernels, same tiles).  A shape / setting without the split-path step kernels, and
+// count == 1: the single calls, one after the other.
 int dtc_gru_step_fwd_s3_pair(const float* const* hprev, const void* const* img, const float* const* b_hh, const float* const* gi_t,
                              float* const* hout, float* const* gates_t, float* const* hn_t, int R, int H, void* stream);
 int dtc_gru_dgrad_parts_s3_pair(const float* const* dgh_t, const void* const* img, float* const* part, int64_t part_stride, int R, int H,
