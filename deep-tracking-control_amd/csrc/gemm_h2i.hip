@@ -357,6 +357,9 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (trace && tid == 0) {                              // debug (dtc_h2i_trace): per-workgroup time stamps (100 MHz) and placement
         trace[4 * slot] = __builtin_amdgcn_s_memrealtime();
+        // HW_REG_HW_ID (id 4: cu_id [11:8], sh_id [12], se_id [15:13]) | HW_REG_XCC_ID (id 20) << 32
+        trace[4 * slot + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                              ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     }
     const int m0 = tr * BMT, n0 = tc * BN;
     const int ctile = m0 >> 7, crow0 = m0 & 127;                      // the 128-row chunk tile this tile lies in, its first row there

@@ -49,6 +49,29 @@ for rep in range(1):
     m0 = ok & (xcd == 0)
     life = (full[:, 2] - full[:, 0]) / 100.0
     print("   xcd 0 lifetimes by (se, cu):", {(int(a), int(b)): [round(float(v), 1) for v in life[m0 & (se == a) & (cu == b)]] for a in np.unique(se[m0]) for b in np.unique(cu[m0 & (se == a)])})
+    # K-loop time by column tile / by position of the row tile in its XCD's list (map_tile: block b -> xcd = b & 7, j = b >> 3, tc = j % col_tiles,
+    # row tile = xcd + 8 * (j // col_tiles)): does the spread follow the tile (data placement, first reader of a row tile) or the CU?
+    ct = (N + 127) // 128
+    b_all = np.arange(grid)
+    tc_all, loc_all = (b_all >> 3) % ct, (b_all >> 3) // ct
+    kl = (full[:, 1] - full[:, 0]) / 100.0
+    print("   K loop median by column tile:", [round(float(np.median(kl[ok & (tc_all == c)])), 1) for c in range(ct)])
+    print("   K loop median by row-tile position in the XCD (0..):", [round(float(np.median(kl[ok & (loc_all == i)])), 1) for i in range(int(loc_all[ok].max()) + 1)])
+    print("   K loop spread inside one row tile (max - min over its column tiles), median over row tiles:",
+          round(float(np.median([np.ptp(kl[ok & (loc_all == i) & (xcd == x)]) for i in range(int(loc_all[ok].max()) + 1) for x in range(8) if (ok & (loc_all == i) & (xcd == x)).any()])), 1))
+    hwid = full[:, 3]
+    print("   distinct hw-id words:", len(np.unique(hwid[ok])), "examples:", [hex(int(v)) for v in np.unique(hwid[ok])[:6]])
+    for word in np.unique(hwid[ok])[:0]:
+        pass
+    by_hw = {}
+    place = ((hwid >> 32) & 0xf) << 16 | (hwid & 0xff00)          # (xcc, se, sh, cu)
+    for v, kk in zip(place[ok], kl[ok]):
+        by_hw.setdefault(int(v), []).append(float(kk))
+    print("   distinct (xcc, se, sh, cu) places:", len(by_hw), "; workgroups per place:", sorted(set(len(v) for v in by_hw.values())),
+          "; K-loop spread INSIDE a place (max - min), median:", round(float(np.median([max(v) - min(v) for v in by_hw.values()])), 1),
+          "; spread of the place means:", round(float(min(np.mean(v) for v in by_hw.values())), 1), "...", round(float(max(np.mean(v) for v in by_hw.values())), 1))
+    sp = sorted((np.mean(v), len(v), hex(k)) for k, v in by_hw.items())
+    print("   K loop mean by hw-id word: fastest", [(round(a, 1), n, h) for a, n, h in sp[:5]], "slowest", [(round(a, 1), n, h) for a, n, h in sp[-5:]])
     # starts by order of blockIdx (dispatch order)
     order = np.argsort(t[:, 0])
     print("   start times of every 64th workgroup in dispatch order:", np.round(np.sort(s)[::64], 1).tolist())
