@@ -16,6 +16,9 @@
 namespace {
 
 constexpr int EPI_FWD = 0, EPI_DGRAD = 1, EPI_MSE = 2;
+#ifndef DTC_H2I_SELF
+#define DTC_H2I_SELF 1        // 128-row tiles: the fragments of the tile a wave fetched itself are read ABOVE the stage barrier (h2i_tile)
+#endif
 #ifndef DTC_H2I_NT_STORES
 #define DTC_H2I_NT_STORES 0   // image stores of the GEMM epilogue with the non-temporal hint (measured: DESIGN.md 4.5)
 #endif
@@ -366,9 +369,19 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
     const u32 xsub = (u32)crow0 * 32u;                                // ... = byte offset inside a plane (slot = 2 x row)
     const u32 xlane = (TM == 2 || tid < 128) ? 0u : INVALID;          // 64-row tiles: half a plane per stage (the upper lanes fetch nothing)
     const int wm_off = (wave / WN) * (32 * TM), wn_off = (wave % WN) * (32 * TN);
+    // Which 32-row / 32-column block the wave's tile index i / j stands for.  128-row tiles (SELF): tile (0, 0) is the one whose
+    // operand pieces THIS wave fetches (wave (wm, wn) copies rows 64 wm + 32 wn of the X stage and rows 64 wn + 32 wm of the W stage),
+    // so its fragments can be read as soon as the wave's own LDS-DMA has landed -- above the stage barrier, whose wait then hides
+    // their LDS latency (DTC_H2I_SELF=0 at build time: the plain order, tile (i, j) = block (i, j), all reads behind the barrier).
+    constexpr bool SELF = TM == 2 && DTC_H2I_SELF != 0;
+    const int swn = SELF ? (wave % WN) : 0, swm = SELF ? (wave / WN) : 0;
+    const int ro[2] = {wm_off + 32 * swn, wm_off + 32 * (1 - swn)};      // (TM == 1 uses ro[0] only: swn = 0)
+    const int co[2] = {wn_off + 32 * swm, wn_off + 32 * (1 - swm)};
+    const int wpiece = SELF ? 2 * (wave % WN) + (wave / WN) : wave;       // the 32-row piece of the W stage this wave copies
     const int half = lane >> 5, l31 = lane & 31;
     const rsrc_t wres = make_rsrc_bytes(wimg, wimg_bytes);
     const u32 lane_off = (u32)(tid * 16);
+    const u32 wlane_off = (u32)((wpiece * 64 + lane) * 16);
 
     // The K loop exists twice: the row operand as ONE image (every layer but the actor's first) keeps no descriptor state in the loop
     const int a_total = A.total, a_nseg = A.nseg, a_tblocks = A.tblocks;
@@ -385,7 +398,8 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)&XS(nbuf)[p][wave * 128], 16, voff | xlane, xchunk + p * HI_PLANE, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)&WS(nbuf)[p][wave * 128], 16, voff, wchunk + p * HI_PLANE, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)&WS(nbuf)[p][wpiece * 128], 16, wlane_off | (left > 0 ? 0u : INVALID),
+                                                     wchunk + p * HI_PLANE, 0, 0);
         }
         xchunk += HI_CHUNK;
         wchunk += HI_CHUNK;
@@ -428,7 +442,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // rows of this lane's accumulator registers: wm_off + 32 i + 4 half + 8 g + e, register 4 g + e
+    // rows of this lane's accumulator registers: ro[i] + 4 half + 8 g + e, register 4 g + e
     // (The compiler cannot tell Dt from the stage buffers the LDS-DMA in flight writes and puts an s_waitcnt vmcnt(0) in front of one of the
     // merged table reads of a border: measured harmless -- the same reads by inline assembly, without that wait: 50.02 vs 50.05 ms per step.)
     auto rescale = [&](int b) {
@@ -436,7 +450,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int2 d = *reinterpret_cast<const int2*>(&Dt[b][wm_off + 32 * i + 4 * half + 8 * g]);      // four int16
+                const int2 d = *reinterpret_cast<const int2*>(&Dt[b][ro[i] + 4 * half + 8 * g]);      // four int16
                 const int dv[4] = {(d.x << 16) >> 16, d.x >> 16, (d.y << 16) >> 16, d.y >> 16};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -447,6 +461,15 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
 
     // ---- compute cursor
     int cseg = 0, cst = 0, blk = 0, done = 0;
+    u32x4 sa[2], sb[2];                                   // SELF: the fragments of tile (0, 0) of the stage that runs next
+    auto read_self = [&](auto bc) {
+        constexpr int buf = decltype(bc)::value;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            sa[p] = reinterpret_cast<const u32x4*>(&XS(buf)[p][0])[rslot(ro[0] + l31, half)];
+            sb[p] = reinterpret_cast<const u32x4*>(&WS(buf)[p][0])[rslot(co[0] + l31, half)];
+        }
+    };
     auto stage = [&](auto bc) {
         constexpr int buf = decltype(bc)::value;
         // (uniform) a block border: the rows change scale.  In front of the LDS-DMA: behind it the compiler would wait for the transfer
@@ -459,14 +482,35 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
         load_stage(std::integral_constant<int, (buf + 2) % 3>{});   // the pieces of stage s + 2 first (hipcc otherwise sinks them behind the MFMAs)
         __builtin_amdgcn_sched_barrier(0);
         u32x4 a[TM][2], b[TN][2];
-        auto rda = [&](int i, int p) { a[i][p] = reinterpret_cast<const u32x4*>(&XS(buf)[p][0])[rslot(wm_off + 32 * i + l31, half)]; };
-        auto rdb = [&](int j, int p) { b[j][p] = reinterpret_cast<const u32x4*>(&WS(buf)[p][0])[rslot(wn_off + 32 * j + l31, half)]; };
+        auto rda = [&](int i, int p) { a[i][p] = reinterpret_cast<const u32x4*>(&XS(buf)[p][0])[rslot(ro[i] + l31, half)]; };
+        auto rdb = [&](int j, int p) { b[j][p] = reinterpret_cast<const u32x4*>(&WS(buf)[p][0])[rslot(co[j] + l31, half)]; };
+        using P = Prec<true>;
+        if constexpr (SELF) {
+            // tile (0, 0) from the fragments read above the barrier; the other three tiles' fragments are requested now and arrive
+            // under its MFMAs.  Per tile the order of the terms is the plain path's (smallest first: lo hi', hi lo', hi hi'), so the
+            // results are bit-identical
+            a[0][0] = sa[0]; a[0][1] = sa[1]; b[0][0] = sb[0]; b[0][1] = sb[1];
+            rda(1, 1); rda(1, 0); rdb(1, 0); rdb(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = P::mfma(a[0][1], b[0][0], acc[0][0]);
+            acc[0][0] = P::mfma(a[0][0], b[0][1], acc[0][0]);
+            acc[0][0] = P::mfma(a[0][0], b[0][0], acc[0][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = P::mfma(a[1][1], b[0][0], acc[1][0]);
+            acc[0][1] = P::mfma(a[0][1], b[1][0], acc[0][1]);
+            acc[1][1] = P::mfma(a[1][1], b[1][0], acc[1][1]);
+            acc[1][0] = P::mfma(a[1][0], b[0][1], acc[1][0]);
+            acc[0][1] = P::mfma(a[0][0], b[1][1], acc[0][1]);
+            acc[1][1] = P::mfma(a[1][0], b[1][1], acc[1][1]);
+            acc[1][0] = P::mfma(a[1][0], b[0][0], acc[1][0]);
+            acc[0][1] = P::mfma(a[0][0], b[1][0], acc[0][1]);
+            acc[1][1] = P::mfma(a[1][0], b[1][0], acc[1][1]);
+        } else {
         rda(0, 1); rdb(0, 0);
         if constexpr (TM == 2) rda(1, 1);
         rda(0, 0); rdb(0, 1);
         if constexpr (TM == 2) rda(1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        using P = Prec<true>;
         // smallest terms first: lo hi', hi lo', hi hi'
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i][0] = P::mfma(a[i][1], b[0][0], acc[i][0]);
@@ -483,6 +527,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
         for (int i = 0; i < TM; ++i) acc[i][1] = P::mfma(a[i][0], b[1][1], acc[i][1]);
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i][1] = P::mfma(a[i][0], b[1][0], acc[i][1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         ++done;
         ++cst;
@@ -493,9 +538,14 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
         // stage s + 1 has landed (this wave's four newest transfers -- stage s + 2 -- may still be in flight: vmcnt(4), the other counters
         // untouched); then every wave's share has.  A raw barrier: __syncthreads() would wait for ALL transfers
         __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+        if constexpr (SELF) {                             // this wave's own pieces of stage s + 1 are in LDS: its tile (0, 0) fragments
+            read_self(std::integral_constant<int, (buf + 1) % 3>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_s_barrier();
     };
     __syncthreads();
+    if constexpr (SELF) read_self(S0{});
     for (int trip = (a_total + 2) / 3; trip > 0; --trip) {
         stage(S0{});
         stage(S1{});
@@ -519,7 +569,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
         for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn_off + 32 * j + l31;
+            const int col = n0 + co[j] + l31;
             const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
@@ -527,7 +577,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
                 unsigned bits = 0u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bits |= acc[i][j][r] > 0.f ? (1u << r) : 0u;
-                wmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * ldwm + col] = (unsigned short)bits;
+                wmask[((long long)((m0 + ro[i]) >> 5) * 2 + half) * ldwm + col] = (unsigned short)bits;
             }
             if (act == DTC_ACT_RELU) {
 #pragma unroll
@@ -546,8 +596,8 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
             for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int mcol = n0 + wn_off + 32 * j + l31;
-                const unsigned bits = mcol < N ? dg.rmask[((long long)((m0 + wm_off + 32 * i) >> 5) * 2 + half) * dg.ldm + mcol] : 0u;
+                const int mcol = n0 + co[j] + l31;
+                const unsigned bits = mcol < N ? dg.rmask[((long long)((m0 + ro[i]) >> 5) * 2 + half) * dg.ldm + mcol] : 0u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = (bits >> r) & 1u ? acc[i][j][r] : 0.f;
             }
@@ -565,10 +615,10 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         if (DTC_H2I_PROBE < 4) patch_put(patch, acc[i][j], half, l31);
-        const int col = n0 + wn_off + 32 * j + 8 * c8;
+        const int col = n0 + co[j] + 8 * c8;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int rl = r16 + 16 * q, row = m0 + wm_off + 32 * i + rl;
+            const int rl = r16 + 16 * q, row = m0 + ro[i] + rl;
             f32x4(&v)[2] = T[i][j][q];
             if (DTC_H2I_PROBE < 4) {
                 v[0] = patch_get(patch, rl, 2 * c8);
@@ -709,7 +759,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
                 const u32 o2 = (u32)__shfl_xor((int)m, 2, 64);
                 m = o2 > m ? o2 : m;
                 mrow[i][q] = m;
-                if (c8 == 0) rm[(wave % WN) * 128 + wm_off + 32 * i + r16 + 16 * q] = m;
+                if (c8 == 0) rm[(wave % WN) * 128 + ro[i] + r16 + 16 * q] = m;
             }
     }
     if (EPI == EPI_MSE && lane == 0) red[wave] = sq;
@@ -733,7 +783,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) ms |= rm[wm_off + 32 * i + r16 + 16 * q] | rm[128 + wm_off + 32 * i + r16 + 16 * q];
+            for (int q = 0; q < 2; ++q) ms |= rm[ro[i] + r16 + 16 * q] | rm[128 + ro[i] + r16 + 16 * q];
         if (sink == 1.2345e-30f || ms == 0x12345u) yo.exps[0] = 1;
         return;
     }
@@ -742,7 +792,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int rloc = wm_off + 32 * i + r16 + 16 * q;
+            const int rloc = ro[i] + r16 + 16 * q;
             const u32 m = rm[rloc] > rm[128 + rloc] ? rm[rloc] : rm[128 + rloc];
             const int e = hi_exp(m);
             const int rch = crow0 + rloc;                      // the row inside its 128-row chunk
@@ -750,7 +800,7 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
             const int ee = e == HI_EZERO ? 0 : e;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int lc = n0 + wn_off + 32 * j + 8 * c8;
+                const int lc = n0 + co[j] + 8 * c8;
                 if ((lc >> 4) >= yo.stages) continue;
                 const HiPiece pc = hi_split8(T[i][j][q], ee);
                 u32x4* chunk = tile_chunks + (long long)(lc >> 4) * (HI_CHUNK / 16);
