@@ -117,7 +117,15 @@ struct WpackGroup {
     int count;
     WpackJob job[WP_MAX_JOBS];
 };
-__global__ __launch_bounds__(256) void h2i_wpack_kernel(const WpackGroup G) {
+// WP_SQ stage groups per block (threads = 256 x WP_SQ): thread (row r, k half h, stage group sq) holds HI_KB / WP_SQ stages.  The launch
+// sits alone on the chip between the optimiser step and the next forward (one block per CU), so what counts is a thread's chain:
+// loads -> block maximum -> split -> stores.  Measured per launch / per bench step (tools/jobs/r5_wp.sh, three interleaved rounds):
+// 1 group 28.5 us / 49.5 ms, 2 groups 22.0 us / 49.1 ms, 4 groups 19.9 us / 49.25 ms: 2 is the default (-DDTC_WPACK_SQ=1 | 4).
+#ifndef DTC_WPACK_SQ
+#define DTC_WPACK_SQ 2
+#endif
+constexpr int WP_SQ = DTC_WPACK_SQ, WP_ST = HI_KB / WP_SQ;
+__global__ __launch_bounds__(256 * WP_SQ) void h2i_wpack_kernel(const WpackGroup G) {
     int j = 0, b = blockIdx.x;
     while (j < G.count - 1 && b >= G.job[j].block_end) ++j;
     if (j > 0) b -= G.job[j - 1].block_end;
@@ -129,18 +137,18 @@ __global__ __launch_bounds__(256) void h2i_wpack_kernel(const WpackGroup G) {
         gs0 += (int)hi_stages(J.cw[sg]);
         ++sg;
     }
-    const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;
+    const int tid = threadIdx.x, r = tid & 127, h = (tid >> 7) & 1, sq = tid >> 8;
     const int t0 = (J.nr[0] + 127) >> 7, rg = (J.nrows > 1 && ct >= t0) ? 1 : 0;        // the row range this tile lies in
     const int row = (ct - (rg ? t0 : 0)) * 128 + r, nrg = J.nr[rg], src0 = J.r0[rg];
     const int nst = (int)hi_stages(J.cw[sg]);
-    float v[HI_KB][8];
+    float v[WP_ST][8];
     u32 mx = 0u;
     // W as stored (not transposed): a thread's 8 columns of a stage are consecutive in memory -- two 16-byte loads where the row allows
     // it (uniform: leading dimension and first column multiples of 4, 16-byte aligned base)
     const bool vec = !J.trans && (J.ld & 3) == 0 && (J.c0[sg] & 3) == 0 && (reinterpret_cast<unsigned long long>(J.W) & 15ull) == 0;
 #pragma unroll
-    for (int s = 0; s < HI_KB; ++s) {
-        const int cb = (gb * HI_KB + s) * 16 + 8 * h;
+    for (int s = 0; s < WP_ST; ++s) {
+        const int cb = (gb * HI_KB + sq * WP_ST + s) * 16 + 8 * h;
         if (vec && row < nrg && cb + 8 <= J.cw[sg]) {
             const f32x4* src = reinterpret_cast<const f32x4*>(J.W + (long long)(src0 + row) * J.ld + J.c0[sg] + cb);
             const f32x4 a = src[0], b2 = src[1];
@@ -165,20 +173,20 @@ __global__ __launch_bounds__(256) void h2i_wpack_kernel(const WpackGroup G) {
         }
     }
     mx = wave_max_u32(mx);
-    __shared__ u32 red[4];
+    __shared__ u32 red[4 * WP_SQ];
     if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
     mx = red[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
+    for (int w = 1; w < 4 * WP_SQ; ++w) mx = red[w] > mx ? red[w] : mx;
     const int e = hi_exp(mx);
     int gblock = gb;                                             // index of this block in the image's walk
     for (int i = 0; i < sg; ++i) gblock += (int)hi_kblocks(J.cw[i]);
     if (tid == 0) J.exps[ct * J.tblocks + gblock] = e;
     const int ee = e == HI_EZERO ? 0 : e;
 #pragma unroll
-    for (int s = 0; s < HI_KB; ++s) {
-        const int st = gb * HI_KB + s;
+    for (int s = 0; s < WP_ST; ++s) {
+        const int st = gb * HI_KB + sq * WP_ST + s;
         if (st >= nst) break;
         const f32x4 q[2] = {f32x4{v[s][0], v[s][1], v[s][2], v[s][3]}, f32x4{v[s][4], v[s][5], v[s][6], v[s][7]}};
         const HiPiece pc = hi_split8(q, ee);
@@ -1008,7 +1016,7 @@ extern "C" int dtc_h2i_wimage_group(const DtcH2iWJob* jobs, int count, void* str
     G.count = 0;
     auto flush = [&]() {
         if (G.count == 0) return;
-        hipLaunchKernelGGL(h2i_wpack_kernel, dim3((unsigned)G.job[G.count - 1].block_end), dim3(256), 0, s, G);
+        hipLaunchKernelGGL(h2i_wpack_kernel, dim3((unsigned)G.job[G.count - 1].block_end), dim3(256 * WP_SQ), 0, s, G);
         G.count = 0;
     };
     for (int i = 0; i < count; ++i) {
