@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
                 ma = abs_bits(ga[e]) > ma ? abs_bits(ga[e]) : ma;
                 mc = abs_bits(gc[e]) > mc ? abs_bits(gc[e]) : mc;
             }
-            *reinterpret_cast<f4*>(dHa + rr * lddha + 4 * (p + TPR * i)) = ga;
-            *reinterpret_cast<f4*>(dHc + rr * lddhc + 4 * (p + TPR * i)) = gc;
+            if (dHa) *reinterpret_cast<f4*>(dHa + rr * lddha + 4 * (p + TPR * i)) = ga;      // (NULL: the image is the only copy)
+            if (dHc) *reinterpret_cast<f4*>(dHc + rr * lddhc + 4 * (p + TPR * i)) = gc;
             GA[i] = ga;
             GC[i] = gc;
         }
@@ -610,7 +610,11 @@ extern "C" int dtc_ppo_heads_loss_img(const float* Ha, int64_t ldha, const float
     DTC_REQUIRE(H == 64 || H == 128 || H == 256, "hidden width %d unsupported by the fused heads (64, 128, 256)", H);
     DTC_REQUIRE(Ha && Hc && Wa && Wc && std && actions && old_logp && old_mu && old_sigma && advantages && returns && old_values,
                 "null input");
-    DTC_REQUIRE(cfg && mean && value && dmean && dvalue && dHa && dHc && dstd && losses && workspace, "null output");
+    DTC_REQUIRE(cfg && mean && value && dmean && dvalue && dstd && losses && workspace, "null output");
+    // dHa / dHc: fp32 [B, H], or NULL where the gradient is wanted as its operand image only (no fp32 copy is written)
+    DTC_REQUIRE((dHa || dHa_img) && (dHc || dHc_img), "dHa / dHc: an fp32 destination or an image is required");
+    if (!dHa) lddha = H;
+    if (!dHc) lddhc = H;
     DTC_REQUIRE(ldha >= H && ldhc >= H && lddha >= H && lddhc >= H && ldha % 4 == 0 && ldhc % 4 == 0 && lddha % 4 == 0 &&
                     lddhc % 4 == 0 && dtc::aligned16(Ha) && dtc::aligned16(Hc) && dtc::aligned16(dHa) && dtc::aligned16(dHc),
                 "hidden activations must be 16-byte aligned with row strides that are multiples of 4");

@@ -824,8 +824,9 @@ class PPO:
         if fuse:
             ops.ppo_heads_loss(fw.a3, fw.v3, L["a3"].W, L["a3"].b, L["c3"].W, L["c3"].b, act, ac.std_view, flat["actions"],
                                flat["actions_log_prob"], flat["mu"], flat["sigma"], flat["advantages"], flat["returns"],
-                               flat["values"], idx, cfg, fw.mean, fw.val, tw.dmean, tw.dval, g_a3, g_c3, ac.std_grad,
-                               stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws, imgs=himg)
+                               flat["values"], idx, cfg, fw.mean, fw.val, tw.dmean, tw.dval,
+                               None if himg is not None else g_a3, None if himg is not None else g_c3,     # (images only: no fp32 copy)
+                               ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, tw.loss_ws, imgs=himg)
         else:
             ops.ppo_loss(fw.mean, ac.std_view, fw.val, flat["actions"], flat["actions_log_prob"], flat["mu"],
                          flat["sigma"], flat["advantages"], flat["returns"], flat["values"], idx, cfg, tw.dmean, tw.dval,

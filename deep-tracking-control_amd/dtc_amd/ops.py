@@ -698,7 +698,7 @@ def ppo_heads_loss(Ha, Hc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old
                                    cptr(old_mu, f32), cptr(old_sigma, f32), cptr(advantages, f32), cptr(returns, f32),
                                    cptr(old_values, f32), cptr(idx, torch.int64) if idx is not None else None, cfg,
                                    cptr(mean, f32), cptr(value, f32), cptr(dmean, f32), cptr(dvalue, f32), cptr(dHa, f32),
-                                   dHa.stride(0), cptr(dHc, f32), dHc.stride(0), ptr(dstd), ptr(losses), ptr(lr), ptr(ws), B, A,
+                                   dHa.stride(0) if dHa is not None else H, cptr(dHc, f32), dHc.stride(0) if dHc is not None else H, ptr(dstd), ptr(losses), ptr(lr), ptr(ws), B, A,
                                    _pub(dHa), _pub(dHc), _pub(dmean), _pub(dvalue), *ip, stream()), "dtc_ppo_heads_loss")
 
 

@@ -575,7 +575,8 @@ int dtc_ppo_heads_loss(const float* Ha, int64_t ldha, const float* Hc, int64_t l
                        uint32_t* dval_amax /* amax records of dHa / dHc / dmean / dvalue (two-term fp16 GEMM path, see DtcSeg.amax), each
                        may be NULL */, void* stream);
 /* ... and the operand images (dtc_h2i_bytes(B, H), (B, H), (B, A), (B, 1); each may be NULL; the first two need H <= 128) of dHa, dHc, dmean,
- * dvalue, written by the same launch: the trainer's image-operand data / weight gradients read them without a pack launch. */
+ * dvalue, written by the same launch: the trainer's image-operand data / weight gradients read them without a pack launch.  Where an
+ * image of dHa / dHc is given, its fp32 destination may be NULL (the image is then the only copy: 25 MB less to write per call). */
 int dtc_ppo_heads_loss_img(const float* Ha, int64_t ldha, const float* Hc, int64_t ldhc, int H, const float* Wa, const float* ba,
                            const float* Wc, const float* bc, int act_prev, const float* std, const float* actions,
                            const float* old_logp, const float* old_mu, const float* old_sigma, const float* advantages,

@@ -374,6 +374,18 @@ def test_images_written_by_the_fused_heads_kernel_equal_a_pack_of_its_fp32_outpu
                        dmean, dval, dHa, dHc, dstd, losses, lr, ws, imgs=imgs)
     for im, t in zip(imgs, (dHa, dHc, dmean, dval)):
         assert torch.equal(im.buf, h2i.HImage.from_tensor(t).buf)
+    # the fp32 copies of dHa / dHc are optional where their images are given (the trainers' image chain passes NULL): same images, same
+    # everything else
+    imgs2 = (h2i.HImage(B, H, DEV), h2i.HImage(B, H, DEV), h2i.HImage(B, A, DEV), h2i.HImage(B, 1, DEV))
+    mean2, val2, dmean2, dval2 = (torch.empty(B, w, device=DEV) for w in (A, 1, A, 1))
+    dstd2, losses2 = torch.zeros(A, device=DEV), torch.zeros(4, device=DEV)
+    ops.ppo_heads_loss(Ha, Hc, Wa, ba, Wc, bc, "elu", std, actions, old_logp, old_mu, old_sigma, adv, ret, oldv, idx, cfg, mean2, val2,
+                       dmean2, dval2, None, None, dstd2, losses2, lr, ws, imgs=imgs2)
+    for a, b in zip(imgs + (mean, val, dmean, dval, dstd, losses), imgs2 + (mean2, val2, dmean2, dval2, dstd2, losses2)):
+        assert torch.equal(a.buf, b.buf) if isinstance(a, h2i.HImage) else torch.equal(a, b)
+    with pytest.raises(_ffi.DtcError):           # neither an fp32 destination nor an image for dHa
+        ops.ppo_heads_loss(Ha, Hc, Wa, ba, Wc, bc, "elu", std, actions, old_logp, old_mu, old_sigma, adv, ret, oldv, idx, cfg, mean2, val2,
+                           dmean2, dval2, None, dHc, dstd2, losses2, lr, ws, imgs=(None, imgs2[1], None, None))
 
 
 def test_64_row_tiles_equal_128_row_tiles_bit_for_bit(tile_rows):
