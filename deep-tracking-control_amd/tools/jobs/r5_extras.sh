@@ -17,3 +17,4 @@ for i in 1 2 3; do
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('driver command run $i:', round(d['ms_per_step'],2), 'ms', round(d['value']), 'env-steps/s, frac', round(d['roofline']['frac'],4), 'cpu', round(d['cpu_baseline']['value']))"
 done | tee $O/r05_driver_repeats.txt
 timeout 900 python bench.py --cpu-baseline-full 2>/dev/null | tail -1 > $O/r05_cpu_baseline_full.json; cut -c1-300 $O/r05_cpu_baseline_full.json
+find gpurun_out -type f -size +4M -delete; rm -rf gpurun_out/traffic_pmc gpurun_out/gemm_pmc
