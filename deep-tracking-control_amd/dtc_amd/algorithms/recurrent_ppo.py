@@ -56,6 +56,7 @@ class RecurrentPPO:
         # DTC_GRU_MULTI=1: memory_a and memory_c advance together, one launch per time step (dtc_gru_fwd_multi / dtc_gru_bwd_multi;
         # bit-identical, measured slower: 100.7 vs 92.7 ms per step); default: one chain of launches each, on its lane
         self.gru_multi = os.environ.get("DTC_GRU_MULTI", "0") == "1"
+        self._pad_bufs, self._pad_gen = {}, {}
         self._lanes = None
         self._wimages = None
         # every GEMM outside the GRU time steps on block-scaled fp16 operand images (dtc_amd/h2i.py; DTC_H2I=0: round 4's converting
@@ -334,7 +335,18 @@ class RecurrentPPO:
                     dZi = dXi
                 else:
                     h2i.linear_dgrad(dZi, L.W, d_in, None, wset=wset)
-            dhs = torch.zeros(T * R, H, device=dev)
+            # one padded buffer per mini-batch slot, zeroed once per update: the slot's trajectories (and padding rows) are the same in
+            # every epoch, every scatter overwrites all valid rows (DTC_PAD_ZERO_ALWAYS=1: a fresh zero buffer per mini-batch)
+            slot = self._pack_slot if self._pack_gen is not None else 0
+            pk = (f"dhs_{name}", slot)
+            dhs = self._pad_bufs.get(pk)
+            if (dhs is None or tuple(dhs.shape) != (T * R, H) or self._pack_gen is None or self._pad_gen.get(pk) != self._pack_gen
+                    or os.environ.get("DTC_PAD_ZERO_ALWAYS") == "1"):
+                if dhs is None or tuple(dhs.shape) != (T * R, H):
+                    dhs = self._pad_bufs[pk] = torch.zeros(T * R, H, device=dev)
+                else:
+                    dhs.zero_()
+                self._pad_gen[pk] = self._pack_gen
             ops.scatter_rows(d_in, unpad_idx, dhs)
             dgi, dh0 = torch.empty(T, R, 3 * H, device=dev), torch.empty(R, H, device=dev)
             hd.update(dhs=dhs, dgi=dgi, dh0=dh0)
@@ -422,7 +434,11 @@ class RecurrentPPO:
         k = 0
         for mem in (self.actor_critic.memory_a, self.actor_critic.memory_c):
             mem.new_update()
-        self._pack_gen = (self._pack_gen or 0) + 1      # the observation images of this update: packed once per mini-batch
+        # the observation images of this update: packed once per mini-batch.  The generation number must never repeat: `_pack_gen` is
+        # None between updates, so it is drawn from a counter of its own (it used to be `(self._pack_gen or 0) + 1` = 1 in EVERY
+        # update: from the second update of a run on, the image path reused the first update's packed observations)
+        self._pack_serial = getattr(self, "_pack_serial", 0) + 1
+        self._pack_gen = self._pack_serial
         try:
             for batch in st.reccurent_mini_batch_generator(nmb, epochs):
                 i = k % nmb

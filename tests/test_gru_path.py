@@ -284,3 +284,48 @@ def test_recurrent_operand_image_path_next_to_the_converting_kernels():
         a, b = g1[off:off + cnt], g0[off:off + cnt]
         scale = float(b.abs().max()) + 1e-30
         assert float((a - b).abs().max()) / scale <= 2e-5, (name, float((a - b).abs().max()) / scale)
+
+
+@pytest.mark.gpu
+def test_second_update_packs_the_new_rollout():
+    """RecurrentPPO's image path packs the valid rows of the padded observations once per update and mini-batch slot.  The generation
+    that keys those images must change from update to update: with the storage refilled between two updates, the second update has to
+    read the NEW observations (regression: the key was 1 in every update, so every update after the first reused the first one's
+    packed images).  Checked on what the updates READ: every image `_packed_obs` hands out equals a fresh pack of the current
+    rollout's valid rows, in both of two consecutive updates on different rollouts."""
+    from dtc_amd import h2i
+    from dtc_amd.algorithms import RecurrentPPO
+    from dtc_amd.modules import ActorCriticRecurrent
+    from dtc_amd._ffi import seg, segmat
+    n = 64
+    torch.manual_seed(3)
+    ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+                              activation='elu', rnn_type='gru', rnn_hidden_size=512, rnn_num_layers=1)
+    alg = RecurrentPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV)
+    alg.init_storage(n, 24, [53], [1389], [12])
+    g = torch.Generator(device=DEV).manual_seed(5)
+    hid = [0.1 * torch.randn(24, 1, n, 512, generator=g, device=DEV) for _ in range(2)]
+    seen = {}
+    for seed in (9, 10):
+        d = S.rollout(n, 24, seed=seed, device=DEV)
+        for k, v in d.items():
+            if k not in ("last_values", "observation_histories"):
+                getattr(alg.storage, k).copy_(v)
+        alg.storage.compute_returns(d["last_values"], 0.99, 0.95)
+        alg.storage.step = 24
+        alg.storage.saved_hidden_states_a, alg.storage.saved_hidden_states_c = [hid[0]], [hid[1]]
+        packed = []
+        orig = alg._packed_obs
+
+        def spy(name, x, unpad_idx, M, dev, orig=orig, packed=packed):
+            im = orig(name, x, unpad_idx, M, dev)
+            x2 = x.float().contiguous().view(-1, x.shape[-1])
+            fresh = h2i.HImage(M, x.shape[-1], dev).pack(segmat([seg(x2, 0, x2.shape[1], gather=True)], unpad_idx), M)
+            packed.append(bool(torch.equal(im.buf, fresh.buf)))
+            return im
+        alg._packed_obs = spy
+        alg.update()
+        alg._packed_obs = orig
+        seen[seed] = packed
+    assert len(seen[9]) == len(seen[10]) == 40 and all(seen[9])
+    assert all(seen[10]), f"{seen[10].count(False)} of 40 packed observation images of the second update are stale"

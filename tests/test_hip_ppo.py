@@ -879,3 +879,50 @@ def test_graphed_rollout_step_matches_eager_kernels():
         assert torch.equal(alg.storage.actions[t], snap["actions"]) and torch.equal(alg.storage.values[t], snap["values"])
         assert torch.equal(alg.storage.mu[t], snap["action_mean"])
     assert len(alg._rollout_graphs) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["decoder", "composite"])
+def test_every_update_packs_its_own_rollout(kind):
+    """The trainers pack the gathered rollout rows of a mini-batch into operand images ONCE per update and mini-batch slot
+    (ActorCriticDecoder.packed_input, reuse=True).  The key of that reuse must change from update to update: two consecutive updates on
+    DIFFERENT rollouts -- the storage is refilled in between, as a runner does -- must each read images that equal a fresh pack of
+    the rollout that is in the storage at that moment (every call of packed_input is checked, all slots, both optimisation steps)."""
+    from dtc_amd import h2i
+    from dtc_amd.algorithms import PPO, RecurrentDecoderPPO
+    from dtc_amd.modules import ActorCriticDecoder, ActorCriticDecoderRecurrent
+    n = 256
+    torch.manual_seed(3)
+    if kind == "decoder":
+        ac = ActorCriticDecoder(53, 1389, 12)
+        alg = PPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV)
+    else:
+        ac = ActorCriticDecoderRecurrent(53, 1389, 12)
+        alg = RecurrentDecoderPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV)
+    alg.init_storage(n, 24, [53], [1389], [265], [12])
+    g = torch.Generator(device=DEV).manual_seed(5)
+    hid = [0.1 * torch.randn(24, 1, n, 512, generator=g, device=DEV) for _ in range(2)]
+    orig = type(ac).packed_input
+    for seed in (9, 10):
+        d = S.rollout(n, 24, seed=seed, device=DEV)
+        for k, v in d.items():
+            if k != "last_values":
+                getattr(alg.storage, k).copy_(v)
+        alg.storage.compute_returns(d["last_values"], 0.99, 0.95)
+        alg.storage.step = 24
+        if kind == "composite":
+            alg.storage.saved_hidden_states_a, alg.storage.saved_hidden_states_c = [hid[0]], [hid[1]]
+        checks = []
+
+        def spy(ws, name, X, idx=None, reuse=False, checks=checks):
+            img = orig(ac, ws, name, X, idx, reuse)
+            fresh = h2i.HImage(ws.B, X.cols, DEV).pack(X, ws.B)
+            checks.append((name, bool(torch.equal(img.buf, fresh.buf))))
+            return img
+        ac.packed_input = spy
+        try:
+            alg.update()
+        finally:
+            del ac.packed_input
+        stale = sorted({name for name, ok in checks if not ok})
+        assert len(checks) >= 40 and not stale, (seed, len(checks), stale)
