@@ -154,6 +154,12 @@ struct RowLoss {
     double s_sur, s_val, s_kl;
     float dvalue;
 };
+// AC > 0: the action count as a compile-time constant (== A): both loops unroll, so the row's 3 A gathered loads are all in flight at
+// once instead of one loop iteration at a time, and mean_row / dmean_row / ds_row stay in registers.  Same operations in the same
+// order; NOT bit-identical to the runtime-A form (AC = 0) all the same -- the compiler contracts other multiply-add pairs into FMAs
+// in the unrolled code (last-bit differences, both forms inside the parity tests' tolerances): fused heads + finalize 46.0 -> 35.7 us
+// per call at B = 24576 (tools/heads_hash.py), the bench step -0.25 ms (tools/jobs/r5_heads_unroll.sh).
+template <int AC = 0>
 __device__ __forceinline__ RowLoss ppo_row_loss(const float* mean_row, float v, const float* sstd, const float* __restrict__ actions,
                                                 const float* __restrict__ old_logp, const float* __restrict__ old_mu,
                                                 const float* __restrict__ old_sigma, const float* __restrict__ adv,
@@ -161,7 +167,9 @@ __device__ __forceinline__ RowLoss ppo_row_loss(const float* mean_row, float v, 
                                                 long long r, const DtcPpoCfg& cfg, float invB, int A, float* dmean_row, float* ds_row) {
     RowLoss o;
     float logp = 0.f, kl = 0.f;
-    for (int j = 0; j < A; ++j) {
+    const int An = AC > 0 ? AC : A;
+#pragma unroll AC > 0 ? AC : 1
+    for (int j = 0; j < An; ++j) {
         const float sg = sstd[j], mu = mean_row[j], a = actions[r * A + j];
         const float d = a - mu;
         logp += (-(d * d) / (2.0f * (sg * sg)) - logf(sg)) - 0.918938533204672742f;
@@ -199,7 +207,8 @@ __device__ __forceinline__ RowLoss ppo_row_loss(const float* mean_row, float v, 
         dv = -2.0f * e1;
     }
     o.dvalue = cfg.value_loss_coef * dv * invB;
-    for (int j = 0; j < A; ++j) {
+#pragma unroll AC > 0 ? AC : 1
+    for (int j = 0; j < An; ++j) {
         const float sg = sstd[j], mu = mean_row[j], a = actions[r * A + j];
         const float d = a - mu;
         dmean_row[j] = dlogp_scale * (d / (sg * sg));
@@ -211,6 +220,7 @@ __device__ __forceinline__ RowLoss ppo_row_loss(const float* mean_row, float v, 
 // all 3 + A block sums with ONE barrier: every wave reduces its values with shuffles, lane 0 parks them in LDS, then
 // thread k adds the (at most 4) wave results of value k in wave order.  per-block partial layout: [0] surrogate sum,
 // [1] value-loss sum, [2] kl sum, [3 .. 3+A) dstd sums
+template <int AC = 0>
 __device__ __forceinline__ void ppo_block_partials(double s_sur, double s_val, double s_kl, const float* ds_row, bool ok, int A,
                                                    double* __restrict__ part) {
     __shared__ double red[4][3 + MAX_ACT];
@@ -221,7 +231,9 @@ __device__ __forceinline__ void ppo_block_partials(double s_sur, double s_val, d
         red[wv][1] = v1;
         red[wv][2] = v2;
     }
-    for (int j = 0; j < A; ++j) {
+    const int An = AC > 0 ? AC : A;
+#pragma unroll AC > 0 ? AC : 1
+    for (int j = 0; j < An; ++j) {
         const double ds = wave_sum_d(ok ? (double)ds_row[j] : 0.0);
         if (lane == 0) red[wv][3 + j] = ds;
     }
@@ -273,7 +285,7 @@ struct HeadImgs {
     void *dHa, *dHc, *dmean, *dval;
 };
 
-template <int H, int TPR = 4>
+template <int H, int TPR = 4, int AC = 0>
 __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     const float* __restrict__ Ha, long long ldha, const float* __restrict__ Hc, long long ldhc, const float* __restrict__ Wa,
     const float* __restrict__ ba, const float* __restrict__ Wc, const float* __restrict__ bc, int act_prev,
@@ -307,8 +319,11 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
         hc[i] = *reinterpret_cast<const f4*>(Hc + rr * ldhc + 4 * (p + TPR * i));
     }
     // ---- forward: mean = Ha Wa^T + ba, value = Hc Wc^T + bc
-    float mrow[MAX_ACT], v = 0.f;
-    for (int j = 0; j < A; ++j) {
+    constexpr int NA = AC > 0 ? AC : MAX_ACT;        // (AC > 0: A == AC, checked by the host; every loop over the actions unrolls)
+    const int An = AC > 0 ? AC : A;
+    float mrow[NA], v = 0.f;
+#pragma unroll AC > 0 ? AC : 1
+    for (int j = 0; j < An; ++j) {
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
@@ -331,28 +346,34 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     v += sb[A];
     // ---- the row's loss (every thread of the row evaluates it; thread p = 0 stores and contributes the sums)
     RowLoss o{0.0, 0.0, 0.0, 0.f};
-    float dm[MAX_ACT], ds[MAX_ACT];
+    float dm[NA], ds[NA];
     const bool ok = rok && p == 0;
     if (rok) {
         const long long r = idx ? idx[row] : (long long)row;
-        o = ppo_row_loss(mrow, v, sstd, actions, old_logp, old_mu, old_sigma, adv, returns, old_values, r, cfg, 1.0f / (float)B, A,
-                         dm, ds);
+        o = ppo_row_loss<AC>(mrow, v, sstd, actions, old_logp, old_mu, old_sigma, adv, returns, old_values, r, cfg, 1.0f / (float)B, A,
+                             dm, ds);
+    } else if (AC > 0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) dm[j] = ds[j] = 0.f;
     }
     amax_u32 mdm = 0u, mdv = 0u;           // largest |dmean| / |dvalue| this thread writes
     if (ok) {
         value[row] = v;
         dvalue[row] = o.dvalue;
         mdv = abs_bits(o.dvalue);
-        for (int j = 0; j < A; ++j) {
+#pragma unroll AC > 0 ? AC : 1
+        for (int j = 0; j < An; ++j) {
             mean[(long long)row * A + j] = mrow[j];
             dmean[(long long)row * A + j] = dm[j];
             mdm = abs_bits(dm[j]) > mdm ? abs_bits(dm[j]) : mdm;
         }
         if (im.dmean) {
             u32 mb = 0u;
-            for (int j = 0; j < A; ++j) mb = finite_bits(dm[j]) > mb ? finite_bits(dm[j]) : mb;
+#pragma unroll AC > 0 ? AC : 1
+            for (int j = 0; j < An; ++j) mb = finite_bits(dm[j]) > mb ? finite_bits(dm[j]) : mb;
             const int ex = hi_exp(mb);
-            for (int j = 0; j < A; ++j) hi_store_elem(im.dmean, A, row, j, dm[j], ex);
+#pragma unroll AC > 0 ? AC : 1
+            for (int j = 0; j < An; ++j) hi_store_elem(im.dmean, A, row, j, dm[j], ex);
             hi_store_row_exp(im.dmean, B, A, row, ex);
         }
         if (im.dval) {
@@ -370,7 +391,8 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             f4 ga = {0.f, 0.f, 0.f, 0.f};
-            for (int j = 0; j < A; ++j) {
+#pragma unroll AC > 0 ? AC : 1
+            for (int j = 0; j < An; ++j) {
                 const f4 w = *reinterpret_cast<const f4*>(&W[j * H + 4 * (p + TPR * i)]);
                 ga += dm[j] * w;
             }
@@ -422,7 +444,7 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     amax_publish_block(dhc_amax, mc, red_c);
     amax_publish_block(dmean_amax, mdm, red_m);
     amax_publish_block(dval_amax, mdv, red_v);
-    ppo_block_partials(ok ? o.s_sur : 0.0, ok ? o.s_val : 0.0, ok ? o.s_kl : 0.0, ds, ok, A, part);
+    ppo_block_partials<AC>(ok ? o.s_sur : 0.0, ok ? o.s_val : 0.0, ok ? o.s_kl : 0.0, ds, ok, A, part);
 }
 
 // wave w owns the values k = w, w + 4, ...: lanes add the per-block partials in a fixed stride order, one shuffle
@@ -509,6 +531,12 @@ __global__ __launch_bounds__(256) void gaussian_act_kernel(const float* __restri
 }
 
 }  // namespace
+
+// DTC_HEADS_UNROLL=0: the runtime-A form of the fused heads kernel for every shape
+static bool heads_unrolled() {
+    static const bool on = !(getenv("DTC_HEADS_UNROLL") && atoi(getenv("DTC_HEADS_UNROLL")) == 0);
+    return on;
+}
 
 extern "C" int64_t dtc_loss_workspace(int B) {
     (void)B;
@@ -644,6 +672,8 @@ extern "C" int dtc_ppo_heads_loss_img(const float* Ha, int64_t ldha, const float
         else if (H == 128) hipLaunchKernelGGL((ppo_heads_loss_kernel<128, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
         else hipLaunchKernelGGL((ppo_heads_loss_kernel<256, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
     } else if (H == 64) hipLaunchKernelGGL(ppo_heads_loss_kernel<64>, dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
+    else if (H == 128 && num_actions == 12 && heads_unrolled())      // the reference's shapes (128 -> 12 / 1): action loops unrolled
+        hipLaunchKernelGGL((ppo_heads_loss_kernel<128, 4, 12>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
     else if (H == 128) hipLaunchKernelGGL(ppo_heads_loss_kernel<128>, dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
     else hipLaunchKernelGGL(ppo_heads_loss_kernel<256>, dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
 #undef DTC_HL_ARGS
