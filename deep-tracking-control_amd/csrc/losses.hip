@@ -245,6 +245,8 @@ __device__ __forceinline__ void ppo_block_partials(double s_sur, double s_val, d
     }
 }
 
+// (AC: the action count as a template constant, see ppo_row_loss; 0 = run-time A)
+template <int AC = 0>
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__ mean, const float* __restrict__ stdp,
                                                        const float* __restrict__ value, const float* __restrict__ actions,
                                                        const float* __restrict__ old_logp, const float* __restrict__ old_mu,
@@ -259,16 +261,23 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__
     const int b = blockIdx.x * 256 + threadIdx.x;
     const bool ok = b < B;
     RowLoss o{0.0, 0.0, 0.0, 0.f};
-    float mrow[MAX_ACT], dm[MAX_ACT], ds[MAX_ACT];
+    constexpr int NA = AC > 0 ? AC : MAX_ACT;
+    const int An = AC > 0 ? AC : A;
+    float mrow[NA], dm[NA], ds[NA];
     if (ok) {
         const long long r = idx ? idx[b] : (long long)b;
-        for (int j = 0; j < A; ++j) mrow[j] = mean[(long long)b * A + j];
-        o = ppo_row_loss(mrow, value[b], sstd, actions, old_logp, old_mu, old_sigma, adv, returns, old_values, r, cfg,
-                         1.0f / (float)B, A, dm, ds);
+#pragma unroll AC > 0 ? AC : 1
+        for (int j = 0; j < An; ++j) mrow[j] = mean[(long long)b * A + j];
+        o = ppo_row_loss<AC>(mrow, value[b], sstd, actions, old_logp, old_mu, old_sigma, adv, returns, old_values, r, cfg,
+                             1.0f / (float)B, A, dm, ds);
         dvalue[b] = o.dvalue;
-        for (int j = 0; j < A; ++j) dmean[(long long)b * A + j] = dm[j];
+#pragma unroll AC > 0 ? AC : 1
+        for (int j = 0; j < An; ++j) dmean[(long long)b * A + j] = dm[j];
+    } else if (AC > 0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) ds[j] = 0.f;
     }
-    ppo_block_partials(o.s_sur, o.s_val, o.s_kl, ds, ok, A, part);
+    ppo_block_partials<AC>(o.s_sur, o.s_val, o.s_kl, ds, ok, A, part);
 }
 
 // ---------------------------------------------------------------------------------- heads + PPO losses, fused
@@ -609,9 +618,13 @@ extern "C" int dtc_ppo_loss(const float* mean, const float* std, const float* va
     DTC_REQUIRE(nblk <= MAX_BLK, "batch too large for the loss workspace");
     double* part = (double*)workspace;
     dtc::ProfScope prof("ppo_loss", (double)B * num_actions * 24.0, s);
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(256), 0, s, mean, std, value, actions, old_logp, old_mu,
-                       old_sigma, advantages, returns, old_values, (const long long*)idx, *cfg, dmean, dvalue, part, B,
-                       num_actions);
+    if (num_actions == 12 && heads_unrolled())
+        hipLaunchKernelGGL(ppo_loss_kernel<12>, dim3(nblk), dim3(256), 0, s, mean, std, value, actions, old_logp, old_mu, old_sigma,
+                           advantages, returns, old_values, (const long long*)idx, *cfg, dmean, dvalue, part, B, num_actions);
+    else
+        hipLaunchKernelGGL(ppo_loss_kernel<0>, dim3(nblk), dim3(256), 0, s, mean, std, value, actions, old_logp, old_mu,
+                           old_sigma, advantages, returns, old_values, (const long long*)idx, *cfg, dmean, dvalue, part, B,
+                           num_actions);
     hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(1024), 0, s, part, nblk, B, num_actions, std, *cfg, dstd,
                        losses, lr);
     return dtc::check_launch("ppo_loss");
