@@ -99,6 +99,8 @@ def cpu_baseline(full=False):
     per_env_step = statistics.median(r[0] for r in runs)
     return dict(value=1.0 / per_env_step, unit="env-steps/s", cores=cores, kind="port", host_cpus=n_cpu,
                 runs_env_steps_per_s=[round(1.0 / r[0], 1) for r in runs],
+                sample_short=(f"oracle port: compute_returns + {run_epochs}/5 update epochs on {n_envs}x{NUM_STEPS}, planner on {n_maps}/"
+                              f"{NUM_ENVS * NUM_STEPS} maps, scaled to the whole step; {runs[0][1]:.0f} s CPU/run, median of {len(runs)}"),
                 sample=("WHOLE workload, nothing scaled: " if full else "") +
                        f"oracle/ppo_ref.py: compute_returns + {run_epochs} of the 5 update epochs (4 mini-batches of 24576) on {n_envs} envs x "
                        f"{NUM_STEPS} steps, oracle/foothold.py on {n_maps} of {NUM_ENVS * NUM_STEPS} height maps; "
@@ -117,9 +119,82 @@ def emit_line(obj) -> bool:
         if _LINE_DONE[0]:
             return False
         _LINE_DONE[0] = True
-        sys.stdout.write(json.dumps(obj) + "\n")
+        sys.stdout.write(json.dumps(obj, separators=(",", ":")) + "\n")
         sys.stdout.flush()
         return True
+
+
+LINE_LIMIT = 4096                     # the driver keeps a bounded tail of stdout: the result line must fit well inside it
+DETAIL_PATH = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+
+
+def _r(x, nd=4):
+    """Numbers of the result line at a sane number of significant digits (the detail file keeps full precision)."""
+    if isinstance(x, float):
+        return float(f"{x:.{nd + 2}g}")
+    return x
+
+
+def _pick(d, keys, nd=4):
+    return None if d is None else {k: _r(d.get(k), nd) for k in keys if k in d}
+
+
+def compact_line(detail, detail_path=None):
+    """The ONE machine-readable result line (<= LINE_LIMIT bytes) out of the full record `detail`: numbers and short labels only.
+    Everything else -- prose, the per-product accuracy tables, per-kernel counter tables, kernel classes -- stays in the detail
+    file named by `detail_file`."""
+    cfg = detail.get("config") or {}
+    line = {k: _r(detail.get(k), 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                              "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: _r(cfg.get(k)) for k in ("workload", "num_envs_per_gpu", "num_steps_per_env", "mini_batch", "epochs", "parallelism",
+                                                  "rccl_world", "collective_sequence_ok", "allreduce_bytes_per_step_per_rank") if k in cfg}
+    rank_ms = cfg.get("rank_ms_per_step")
+    if rank_ms and detail.get("n_gpus", 1) > 1:
+        line["config"]["rank_ms_per_step"] = {k: _r(v) for k, v in rank_ms.items()}
+    world = cfg.get("world")
+    if world:
+        line["config"]["backend"], line["config"]["distinct_devices"] = world.get("backend"), world.get("distinct_devices")
+    roof = detail.get("roofline")
+    if roof is not None:
+        r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_algorithmic", "launches", "avg_launch_us",
+                         "mfma_busy"))
+        r["kernel"] = str(r.get("kernel", ""))[:120]
+        line["roofline"] = r
+    line["roofline_planner"] = _pick(detail.get("roofline_planner"), ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches",
+                                                                      "avg_launch_us"))
+    cpu = detail.get("cpu_baseline")
+    if cpu is not None:
+        line["cpu_baseline"] = dict(_pick(cpu, ("value", "unit", "cores", "kind")), sample=str(cpu.get("sample_short", cpu.get("sample", "")))[:160])
+    if detail.get("single_pass_fp32_mfma") is not None:
+        line["single_pass_fp32_mfma"] = _pick(detail["single_pass_fp32_mfma"], ("ms_per_step", "value"))
+    c4 = detail.get("configs4_composite")
+    if c4 is not None:
+        line["configs4_composite"] = _pick(c4, ("value", "unit", "ms_per_step", "steps", "n_gpus", "num_envs_total"))
+    if detail.get("last_update") is not None:
+        line["last_update"] = [_r(x) for x in detail["last_update"]]
+    line["detail_file"] = detail_path
+    out = json.dumps(line, separators=(",", ":"))
+    if len(out) >= LINE_LIMIT:           # cannot happen with the bounded fields above; never print an oversized line
+        for k in ("last_update", "configs4_composite", "single_pass_fp32_mfma", "roofline_planner"):
+            line.pop(k, None)
+            out = json.dumps(line, separators=(",", ":"))
+            if len(out) < LINE_LIMIT:
+                break
+    assert len(out) < LINE_LIMIT, len(out)
+    return line
+
+
+def write_detail(detail, path=None):
+    """The full record (everything the result line leaves out) as a side file; returns the repo-relative path or None."""
+    path = path or DETAIL_PATH
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(detail, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as e:
+        sys.stderr.write(f"[bench] detail file not written: {e}\n")
+        return None
 
 
 def error_line(msg, n_gpus, phase=None, **extra):
@@ -617,7 +692,11 @@ def run(a, rank, local_rank, world, wd):
                            "the single-pass v_mfma_f32_32x32x2_f32 kernels and are part of the family")
         else:
             kernel_desc = "linear_{fwd,dgrad}_kernel, wgrad_group_kernel (+ its split-reduce kernel): fp32 v_mfma_f32_32x32x2_f32 GEMM family"
-        roof = dict(bound="mfma", kernel=kernel_desc,
+        kernel_short = ("GEMM family: linear_h2i_kernel + wgrad_h2i_group_kernel (+reduce, image packs), 3 x v_mfma_f32_32x32x16_f16"
+                        if split and getattr(alg, "use_images", False) else
+                        "GEMM family: linear_s3_kernel + wgrad_s3_group_kernel, split-precision MFMA" if split else
+                        "GEMM family: linear_{fwd,dgrad}_kernel + wgrad_group_kernel, v_mfma_f32_32x32x2_f32")
+        roof = dict(bound="mfma", kernel=kernel_short, kernel_description=kernel_desc,
                     achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
                     peak_definition=(("dense fp16 / bf16 MFMA peak 2516.6 TFLOP/s / 3 passes = 838.9 TFLOP/s of fp32-equivalent work "
                                       "(MI355X_MICROARCH.md); achieved counts the ALGORITHMIC fp32 FLOP (2 M N K per product), not the fp16 "
@@ -743,15 +822,13 @@ def run(a, rank, local_rank, world, wd):
                                 "f32 single-pass v_mfma_f32_32x32x2_f32 (DTC_GEMM_SPLIT=0)"),
             "gemm_accuracy": accuracy,
             "gemm_accuracy_in_situ": in_situ,
-            "config": {"workload": ("BASELINE configs[1]: 4096 envs x 24 steps per GPU, ActorCriticDecoder (CE-net + "
-                                    "terrain encoder latent 512 + MLP actor/critic): foothold planner over the 98304 "
-                                    "recorded height maps + compute_returns + PPO.update (5 epochs x 4 mini-batches of 24576)")
+            "config": {"workload": ("BASELINE configs[1]: 4096 envs x 24 steps/GPU, ActorCriticDecoder (CE-net + terrain encoder 512 + MLP "
+                                    "heads): planner over 98304 recorded maps + compute_returns + PPO.update (5 epochs x 4 x 24576)")
                        if not (composite or gru) else
-                       ("BASELINE configs[2]: ActorCriticRecurrent (GRU hidden 512), 4096 envs x 24 steps: planner + compute_returns "
-                        "+ RecurrentPPO.update (5 epochs x 4 recurrent mini-batches of 1024 envs x 24 steps, BPTT)") if gru else
-                       ("BASELINE configs[4] model (build-defined GRU + CE-net + foothold obs composite), 4096 envs x 24 "
-                        "steps per GPU: planner over 98304 maps + compute_returns + RecurrentDecoderPPO.update (5 epochs x "
-                        "4 recurrent mini-batches of 1024 envs x 24 steps, BPTT)"),
+                       ("BASELINE configs[2]: ActorCriticRecurrent (GRU 512), 4096 envs x 24 steps: planner + compute_returns + "
+                        "RecurrentPPO.update (5 epochs x 4 recurrent mini-batches of 1024 envs x 24 steps, BPTT)") if gru else
+                       ("BASELINE configs[4] model (GRU + CE-net + foothold obs), 4096 envs x 24 steps/GPU: planner + compute_returns + "
+                        "RecurrentDecoderPPO.update (5 epochs x 4 recurrent mini-batches of 1024 envs x 24 steps, BPTT)"),
                        "num_envs_per_gpu": NUM_ENVS, "num_steps_per_env": NUM_STEPS, "mini_batch": 24576,
                        "epochs": 5, "wgrad_overlap_stream": bool(overlap),
                        "headline_at_every_n": "configs[1] per rank (weak scaling: the N = 1 workload on every GPU); configs[4]'s model on "
@@ -792,7 +869,7 @@ def run(a, rank, local_rank, world, wd):
                 ops.set_split(True)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        emit_line(line)
+        emit_line(compact_line(line, write_detail(line)))
     if world > 1:
         phase("teardown", 60)
         dist.barrier()

@@ -68,3 +68,68 @@ def test_a_rank_that_stops_taking_part_trips_the_deadline():
                           dict(DTC_BENCH_LAUNCH_CHECK="1", DTC_BENCH_HANG_RANK="1", DTC_BENCH_REHEARSAL_DEADLINE_S="10"))
     assert p.returncode != 0 and dt < 120, (p.returncode, dt, p.stderr[-1500:])
     assert len(lines) == 1 and "error" in lines[0] and "silent peer" in lines[0]["phase"], (p.stdout, p.stderr[-1500:])
+
+
+def _stub_detail():
+    """A full bench record of the shape bench.py builds (round 5's 21 KB line, prose and tables included)."""
+    prose = "x" * 900
+    return {
+        "metric": "env-steps/sec, PPO.update on pre-recorded rollouts, 4096 envs, 1/2/4/8 GPU", "value": 2006737.9123456, "unit": "env-steps/s",
+        "n_gpus": 8, "steps": 20, "warmup": 5, "ms_per_step": 48.98696512345, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (emulated: f16x2 split per operand, f32 accumulate)", "data": "synthetic", "gemm_arithmetic": prose,
+        "gemm_accuracy": {f"k{i}": dict(fwd=1e-7, dgrad=2e-7, wgrad=3e-7) for i in range(5)},
+        "gemm_accuracy_in_situ": {f"shape{i}": dict(calls=2, max_rel=1e-7, row_rel=1e-6, fp32_mfma_max_rel=1e-7) for i in range(39)},
+        "config": {"workload": "BASELINE configs[1]: " + "w" * 200, "num_envs_per_gpu": 4096, "num_steps_per_env": 24, "mini_batch": 24576,
+                   "epochs": 5, "parallelism": "dp8", "rccl_world": 8, "collective_sequence_ok": True,
+                   "allreduce_bytes_per_step_per_rank": 378000000, "headline_at_every_n": prose,
+                   "rank_ms_per_step": {"min": 48.1, "max": 49.3},
+                   "world": {"backend": "nccl", "world": 8, "distinct_devices": 8, "devices": [dict(rank=i, name="AMD Instinct MI355X", pci_bus_id=f"0000:{i:02x}:00.0", uuid="u" * 36) for i in range(8)]}},
+        "configs4_composite": dict(workload=prose, value=5.1e6, unit="env-steps/s", ms_per_step=123.4, steps=3, warmup=1, n_gpus=8, num_envs_total=32768, last_update=[0.1] * 7),
+        "roofline": dict(bound="mfma", kernel="GEMM family: " + "k" * 300, kernel_description=prose, achieved=202.7578347026004, peak=838.8666666666667,
+                         unit="TFLOP/s", frac=0.2417044838702222, peak_definition=prose, traffic=124665662.50212766, traffic_algorithmic=112042047.47,
+                         launches=940, avg_launch_us=52.489377600339026, mfma_busy=0.276380276218813, measured=prose,
+                         traffic_kernels={f"kern{i}": dict(launches=100, MB=1234.5) for i in range(12)},
+                         mfma_busy_kernels={f"kern{i}": dict(launches=100, mfma_busy=0.3, executed_tflops=600.1, clock_ghz=2.2) for i in range(12)}),
+        "roofline_planner": dict(bound="hbm", kernel="foothold_plan_fast_kernel", achieved=2864.71, peak=8000.0, unit="GB/s", frac=0.358088,
+                                 traffic=301.8e6, traffic_source=prose, launches=1, avg_launch_us=106.241, bytes_per_launch=3.04e8),
+        "roofline_planner_4096": dict(measured=prose, env_step_block=dict(measured=prose)),
+        "kernel_classes": {f"class{i}[{i}x512x512]": dict(ms=1.234, launches=40, rate=123.4) for i in range(60)},
+        "last_update": [0.0532584123, -0.00570518123, 0.0, 0.0, 0.975408123, 0.998529123, 4.3914e-05],
+        "single_pass_fp32_mfma": dict(ms_per_step=93.3279, value=1053320.0, unit="env-steps/s", steps=5, note=prose),
+        "cpu_baseline": dict(value=3709.75, unit="env-steps/s", cores=32, kind="port", host_cpus=256, runs_env_steps_per_s=[3700.0] * 3, sample=prose,
+                             sample_short="oracle port: compute_returns + 1/5 update epochs on 4096x24, planner on 16384/98304 maps, scaled"),
+    }
+
+
+def test_result_line_is_short_machine_readable_and_last_on_stdout(tmp_path, capsys):
+    """The driver parses the LAST stdout line and keeps a bounded tail: the line is < 4 KB whatever the full record holds (round 5's
+    21 KB line left BENCH_r05.parsed null), carries every contract key, and the full record goes to the side file it names."""
+    sys.path.insert(0, ROOT)
+    import bench
+    detail = _stub_detail()
+    rel = bench.write_detail(detail, str(tmp_path / "bench_detail.json"))
+    line = bench.compact_line(detail, rel)
+    bench._LINE_DONE[0] = False
+    assert bench.emit_line(line)
+    bench._LINE_DONE[0] = False
+    out = capsys.readouterr().out
+    last = out.rstrip("\n").splitlines()[-1]
+    assert len(last) < 4096 and "\n" not in last, len(last)
+    got = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "detail_file"):
+        assert k in got, k
+    assert got["value"] == pytest.approx(detail["value"], rel=1e-6) and got["ms_per_step"] == pytest.approx(detail["ms_per_step"], rel=1e-6)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in got["roofline"], k
+    assert len(got["roofline"]["kernel"]) <= 120
+    assert got["roofline"]["frac"] == pytest.approx(detail["roofline"]["achieved"] / detail["roofline"]["peak"], rel=1e-4)
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in got["cpu_baseline"], k
+    assert "workload" in got["config"] and "model" not in got["config"]
+    assert got["config"]["rccl_world"] == 8 and got["config"]["collective_sequence_ok"] is True
+    assert got["configs4_composite"]["num_envs_total"] == 32768
+    assert not any(isinstance(v, str) and len(v) > 260 for v in got.values())
+    # nothing was dropped: the side file holds the whole record
+    full = json.load(open(tmp_path / "bench_detail.json"))
+    assert full["kernel_classes"] == detail["kernel_classes"] and len(full["gemm_accuracy_in_situ"]) == 39
