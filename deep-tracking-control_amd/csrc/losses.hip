@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     float* __restrict__ mean, float* __restrict__ value, float* __restrict__ dmean, float* __restrict__ dvalue,
     float* __restrict__ dHa, long long lddha, float* __restrict__ dHc, long long lddhc, double* __restrict__ part, int B, int A,
     amax_u32* __restrict__ dha_amax, amax_u32* __restrict__ dhc_amax, amax_u32* __restrict__ dmean_amax, amax_u32* __restrict__ dval_amax,
-    const HeadImgs im) {
+    const HeadImgs im, const int dbg_flags) {
+    if (dbg_flags & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (DTC_HEADS_ACQ=1, debugging: invalidate this CU's / XCD's view first)
     // TPR threads per row (4: 64 rows per workgroup; 8: 32 rows per workgroup = twice the workgroups, half the serial work
     // per thread -- the kernel is a latency chain per row, not a bandwidth problem)
     constexpr int NC = H / (4 * TPR);                // chunks per thread
@@ -678,11 +679,12 @@ extern "C" int dtc_ppo_heads_loss_img(const float* Ha, int64_t ldha, const float
     const int nblk = (int)dtc::ceil_div(B, 256 / tpr);
     DTC_REQUIRE(nblk <= MAX_BLK, "batch too large for the loss workspace");
     double* part = (double*)workspace;
+    static const int dbg = getenv("DTC_HEADS_ACQ") ? atoi(getenv("DTC_HEADS_ACQ")) : 0;
     dtc::ProfScope prof("ppo_heads_loss", (double)B * (4.0 * H * 4 + num_actions * 32.0), s);
 #define DTC_HL_ARGS Ha, (long long)ldha, Hc, (long long)ldhc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, \
                     advantages, returns, old_values, (const long long*)idx, *cfg, mean, value, dmean, dvalue, dHa, (long long)lddha, \
                     dHc, (long long)lddhc, part, B, num_actions, (amax_u32*)dha_amax, (amax_u32*)dhc_amax, (amax_u32*)dmean_amax, \
-                    (amax_u32*)dval_amax, him
+                    (amax_u32*)dval_amax, him, dbg
     if (tpr == 8) {
         if (H == 64) hipLaunchKernelGGL((ppo_heads_loss_kernel<64, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
         else if (H == 128) hipLaunchKernelGGL((ppo_heads_loss_kernel<128, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);

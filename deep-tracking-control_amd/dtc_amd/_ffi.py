@@ -174,6 +174,7 @@ _SIGS = {
     "dtc_gru_dgrad_parts_s3": (C.c_int, [c_f32p, C.c_void_p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_probe_mfma_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, c_stream]),
     "dtc_probe_mfma_stream_h2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, c_stream]),
+    "dtc_probe_poison": (C.c_int, [C.c_uint32, C.c_int, c_f32p, c_stream]),
     "dtc_h2i_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "dtc_h2i_rows64_max": (None, [C.c_int]),
     "dtc_linear_fwd_chain_h2i": (C.c_int, [C.POINTER(DtcH2iFwdLayer), C.c_int, C.c_int, c_stream]),

@@ -144,7 +144,14 @@ def collect(out_dir, workload="decoder"):
         raise RuntimeError("rocprofv3 not on PATH")
     for t in PASSES:
         run_pass(t, out_dir, workload)
-    return summarise(out_dir)
+    summary = summarise(out_dir)
+    with open(os.path.join(out_dir, "summary.json"), "w") as fh:      # the raw rocprofv3 trees are tens of MB per pass: keep the summary only
+        json.dump(summary, fh, indent=1)
+    if os.environ.get("DTC_KEEP_PMC") != "1":
+        for d in os.listdir(out_dir):
+            if os.path.isdir(os.path.join(out_dir, d)):
+                shutil.rmtree(os.path.join(out_dir, d), ignore_errors=True)
+    return summary
 
 
 if __name__ == "__main__":

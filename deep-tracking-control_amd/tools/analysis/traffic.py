@@ -99,7 +99,19 @@ def collect(out_dir, workload="decoder"):
         raise RuntimeError("rocprofv3 not on PATH")
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         run_pass(c, out_dir, workload)
-    return summarise(out_dir)
+    return _keep_summary_only(out_dir, summarise(out_dir))
+
+
+def _keep_summary_only(out_dir, summary):
+    """The raw rocprofv3 trees are tens of MB per pass (gpurun copies back at most 64 MiB of gpurun_out/): keep the summary as
+    JSON beside them and drop the trees (DTC_KEEP_PMC=1 keeps them for `parse`)."""
+    with open(os.path.join(out_dir, "summary.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+    if os.environ.get("DTC_KEEP_PMC") != "1":
+        for d in os.listdir(out_dir):
+            if os.path.isdir(os.path.join(out_dir, d)):
+                shutil.rmtree(os.path.join(out_dir, d), ignore_errors=True)
+    return summary
 
 
 if __name__ == "__main__":

@@ -706,6 +706,9 @@ void dtc_prof_reset(void);
  * zero and on random operand bits: the rate the chip SUSTAINS (it clocks to its power budget) next to the data-sheet peak. */
 int dtc_probe_mfma_stream(const void* operands, int blocks, int iters, float* sink, void* stream);
 int dtc_probe_mfma_stream_h2(const void* operands, int blocks, int iters, float* sink, void* stream);   /* 12 fp16 MFMAs per stage (two-term path) */
+/* Debugging aid (tools/flake_probe.py, tests): `blocks` workgroups that leave `pattern` in all of their 64 KiB of LDS and in ~240 VGPRs per
+ * lane, so that a following kernel's reads of LDS words / registers it never wrote depend on `pattern` (uninitialised-read detector). */
+int dtc_probe_poison(uint32_t pattern, int blocks, float* sink, void* stream);
 
 #ifdef __cplusplus
 }
