@@ -304,8 +304,7 @@ __global__ __launch_bounds__(256) void ppo_heads_loss_kernel(
     float* __restrict__ mean, float* __restrict__ value, float* __restrict__ dmean, float* __restrict__ dvalue,
     float* __restrict__ dHa, long long lddha, float* __restrict__ dHc, long long lddhc, double* __restrict__ part, int B, int A,
     amax_u32* __restrict__ dha_amax, amax_u32* __restrict__ dhc_amax, amax_u32* __restrict__ dmean_amax, amax_u32* __restrict__ dval_amax,
-    const HeadImgs im, const int dbg_flags) {
-    if (dbg_flags & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (DTC_HEADS_ACQ=1, debugging: invalidate this CU's / XCD's view first)
+    const HeadImgs im) {
     // TPR threads per row (4: 64 rows per workgroup; 8: 32 rows per workgroup = twice the workgroups, half the serial work
     // per thread -- the kernel is a latency chain per row, not a bandwidth problem)
     constexpr int NC = H / (4 * TPR);                // chunks per thread
@@ -482,6 +481,7 @@ __global__ __launch_bounds__(1024) void ppo_loss_finalize_kernel(const double* _
             else if (k == 2) {
                 const float klm = (float)(a / B);
                 losses[3] = klm;
+                if (cfg.kl_mirror) *cfg.kl_mirror = klm;       // data parallel: the gradient header's KL slot, written here (no copy launch)
                 if (cfg.adaptive_schedule && lr) {
                     double cur = *lr;
                     if (klm > cfg.desired_kl * 2.0f) cur = fmax(1e-5, cur / 1.5);
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(1024) void ppo_loss_finalize_kernel(const double* _
     }
 }
 
-__global__ void lr_adapt_kernel(float* __restrict__ kl_mean, double* __restrict__ lr, float desired_kl) {
+__global__ void lr_adapt_kernel(float* __restrict__ kl_mean, double* __restrict__ lr, float desired_kl, float* __restrict__ kl_out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         // The slot is CONSUMED: it is left holding a NaN with a payload of its own (0x7fc0dead), so a step that forgets to deposit its KL
         // fails loudly (lr = NaN) instead of re-using the previous value.  A KL that is itself NaN (any other payload: a diverged
@@ -510,6 +510,7 @@ __global__ void lr_adapt_kernel(float* __restrict__ kl_mean, double* __restrict_
         // rides in the header of a gradient bucket; _kl_to_header re-deposits it before the one exchange whose result is read.)
         constexpr unsigned SENTINEL = 0x7fc0deadu;
         const float klm = *kl_mean;
+        if (kl_out) *kl_out = klm;
         const bool missing = __float_as_uint(klm) == SENTINEL;
         *kl_mean = __uint_as_float(SENTINEL);
         double cur = *lr;
@@ -542,12 +543,13 @@ __global__ __launch_bounds__(256) void gaussian_act_kernel(const float* __restri
 
 }  // namespace
 
-// DTC_HEADS_UNROLL=1: the loss kernels with the action count as a template constant (A = 12).  OFF by default: faster (fused heads +
-// finalize 46.0 -> 35.7 us per call, -0.25 ms per bench step), but with it the data-parallel test that compares the bucketed exchange
-// with one exchange after the join bit for bit (tests/test_hip_dp.py) failed in 2 of 5 runs and in 0 of 5 without it
-// (tools/jobs/r5_dp_flake.sh) -- a run-to-run difference that is not understood yet; until it is, the run-time-A kernels stay the default.
+// The loss kernels with the action count as a template constant for the reference's shapes (A = 12): fused heads + finalize 46.0 -> 35.7 us per
+// call, -0.25 ms per bench step.  DTC_HEADS_UNROLL=0: the run-time-A kernels.  (Round 5 shipped them off: the 2-rank data-parallel test differed
+// from run to run with them.  Round 6: the kernel is bit-reproducible on fixed inputs -- 3e5 launches beside other processes' work, poisoned LDS /
+// VGPRs / torch.empty buffers, 50 one-rank updates; the differences need two lock-stepped processes on ONE device with high-priority queues, which
+// the trainers no longer create in that configuration: DESIGN.md §5.)
 static bool heads_unrolled() {
-    static const bool on = getenv("DTC_HEADS_UNROLL") && atoi(getenv("DTC_HEADS_UNROLL")) == 1;
+    static const bool on = !(getenv("DTC_HEADS_UNROLL") && atoi(getenv("DTC_HEADS_UNROLL")) == 0);
     return on;
 }
 
@@ -679,12 +681,11 @@ extern "C" int dtc_ppo_heads_loss_img(const float* Ha, int64_t ldha, const float
     const int nblk = (int)dtc::ceil_div(B, 256 / tpr);
     DTC_REQUIRE(nblk <= MAX_BLK, "batch too large for the loss workspace");
     double* part = (double*)workspace;
-    static const int dbg = getenv("DTC_HEADS_ACQ") ? atoi(getenv("DTC_HEADS_ACQ")) : 0;
     dtc::ProfScope prof("ppo_heads_loss", (double)B * (4.0 * H * 4 + num_actions * 32.0), s);
 #define DTC_HL_ARGS Ha, (long long)ldha, Hc, (long long)ldhc, Wa, ba, Wc, bc, act_prev, std, actions, old_logp, old_mu, old_sigma, \
                     advantages, returns, old_values, (const long long*)idx, *cfg, mean, value, dmean, dvalue, dHa, (long long)lddha, \
                     dHc, (long long)lddhc, part, B, num_actions, (amax_u32*)dha_amax, (amax_u32*)dhc_amax, (amax_u32*)dmean_amax, \
-                    (amax_u32*)dval_amax, him, dbg
+                    (amax_u32*)dval_amax, him
     if (tpr == 8) {
         if (H == 64) hipLaunchKernelGGL((ppo_heads_loss_kernel<64, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
         else if (H == 128) hipLaunchKernelGGL((ppo_heads_loss_kernel<128, 8>), dim3(nblk), dim3(256), 0, s, DTC_HL_ARGS);
@@ -743,8 +744,8 @@ extern "C" int dtc_gaussian_act(const float* mean, const float* std, const float
     return dtc::check_launch("gaussian_act");
 }
 
-extern "C" int dtc_lr_adapt(float* kl_mean, double* lr, float desired_kl, void* stream) {
+extern "C" int dtc_lr_adapt(float* kl_mean, double* lr, float desired_kl, float* kl_out, void* stream) {
     DTC_REQUIRE(kl_mean && lr, "null pointer");
-    hipLaunchKernelGGL(lr_adapt_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_mean, lr, desired_kl);
+    hipLaunchKernelGGL(lr_adapt_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_mean, lr, desired_kl, kl_out);
     return dtc::check_launch("lr_adapt");
 }

@@ -88,6 +88,27 @@ int dtc_abi_sizes(int64_t* out, int cap) {
 }
 const char* dtc_last_error(void) { return g_err; }
 
+// A HIP stream of the library's own (non-blocking; high_priority: the device's greatest priority).  The trainers' compute lanes are such streams:
+// torch.cuda.Stream() hands out the entries of a 32-stream pool per priority that every other component of the process draws from as well
+// (torch.distributed's gloo / NCCL work streams among them), so a "second stream" taken from there can be the very stream a collective runs on.
+int dtc_stream_create(int high_priority, void** out) {
+    DTC_REQUIRE(out, "null pointer");
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    hipStream_t s = nullptr;
+    const hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? greatest : least);
+    if (e != hipSuccess) {
+        dtc::set_error("hipStreamCreateWithPriority: %s", hipGetErrorString(e));
+        return DTC_ERR_LAUNCH;
+    }
+    *out = (void*)s;
+    return DTC_OK;
+}
+int dtc_stream_destroy(void* stream) {
+    if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) return DTC_ERR_LAUNCH;
+    return DTC_OK;
+}
+
 void dtc_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;

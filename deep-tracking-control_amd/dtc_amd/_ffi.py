@@ -88,7 +88,7 @@ class DtcWgradH2iJob(C.Structure):
 class DtcPpoCfg(C.Structure):
     _fields_ = [("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float),
                 ("desired_kl", C.c_float), ("use_clipped_value_loss", C.c_int32),
-                ("adaptive_schedule", C.c_int32)]
+                ("adaptive_schedule", C.c_int32), ("kl_mirror", C.c_void_p)]
 
 
 class DtcObsCfg(C.Structure):
@@ -126,10 +126,12 @@ class DtcProfRec(C.Structure):
 ACT = {None: 0, "none": 0, "relu": 1, "crelu": 1, "elu": 2, "selu": 3, "lrelu": 4, "tanh": 5, "sigmoid": 6}
 MAX_OPERAND_ELEMS = (1 << 29) - 1
 
-ABI_VERSION = 14         # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
+ABI_VERSION = 15         # DTC_ABI_VERSION of include/dtc_hip.h this binding was written against
 
 _SIGS = {
     "dtc_version": (C.c_int, []),
+    "dtc_stream_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "dtc_stream_destroy": (C.c_int, [C.c_void_p]),
     "dtc_abi_sizes": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),
     "dtc_last_error": (C.c_char_p, []),
     "dtc_foothold_plan": (C.c_int, [c_f32p] * 4 + [C.POINTER(DtcGridCfg), c_i64p] + [c_f32p] * 5 +
@@ -249,7 +251,7 @@ _SIGS = {
     "dtc_ppo_heads_loss_img": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int] + [c_f32p] * 4 + [C.c_int] + [c_f32p] * 8 +
                                [c_i64p, C.POINTER(DtcPpoCfg)] + [c_f32p] * 5 + [C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f64p,
                                                                           C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [c_stream]),
-    "dtc_lr_adapt": (C.c_int, [c_f32p, c_f64p, C.c_float, c_stream]),
+    "dtc_lr_adapt": (C.c_int, [c_f32p, c_f64p, C.c_float, c_f32p, c_stream]),
     "dtc_gaussian_act": (C.c_int, [c_f32p] * 7 + [C.c_int, C.c_int, c_stream]),
     "dtc_bootstrap_probability": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_stream]),
     "dtc_adam_workspace": (C.c_int64, [C.c_int64]),

@@ -20,6 +20,7 @@ attributes `actor_critic`, `optimizer`, `vae_optimizer`, `storage`, `learning_ra
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import os
 
 import torch
@@ -126,16 +127,44 @@ class _Lanes:
         # the second compute lane and the weight-gradient streams are high-priority HIP streams: their (short, latency-bound) kernels get
         # the workgroup slots the main lane's 768-workgroup launches free up first -- 50.3 vs 50.9 ms per step, two interleaved rounds
         # (tools/jobs/r5_prio.sh; "aux" alone 50.85, "side" alone 50.6).  DTC_LANE_PRIO=none: default priorities everywhere
-        prio = os.environ.get("DTC_LANE_PRIO", "aux,side")
-        hp = lambda name: dict(priority=-1) if name in prio.split(",") else {}      # noqa: E731
-        self.side = torch.cuda.Stream(device=dev, **hp("side"))
-        self.side2 = torch.cuda.Stream(device=dev, **hp("side"))     # image chain: the narrow layers' (latency-bound) weight-gradient group beside the wide one
-        self.aux = torch.cuda.Stream(device=dev, **hp("aux"))
+        prio = os.environ.get("DTC_LANE_PRIO", "aux,side").split(",")
+        # ... EXCEPT where several ranks of a job share this device (the one-GPU rehearsals of the data-parallel path over gloo; RCCL refuses
+        # two ranks on one device): there the lanes keep the default priority.  Two lock-stepped processes on one GPU, each with high-priority
+        # queues, gave run-to-run differences in the policy step of single ranks on some boxes of the pool (3 of 10 runs; 0 of 30 with default
+        # priorities, 0 of 50 for one process, 0 of 30 for two processes that exchange nothing): DESIGN.md §5, profiles/r06_flake*.txt
+        if "DTC_LANE_PRIO" not in os.environ and dp.world_size() > 1 and dp.backend() != "nccl":
+            prio = []
+        # ... and they are streams of the library's own (dtc_stream_create), NOT entries of torch's stream pool: torch.cuda.Stream(priority=-1)
+        # hands out the 32 pooled high-priority streams round-robin, and torch.distributed's gloo backend takes the work stream of every
+        # collective on a device tensor from the SAME pool -- every few exchanges a collective's staging copies ran on the stream that is
+        # also a compute lane here.  DTC_LANE_POOL=1: torch's pool, as until round 6
+        pooled = os.environ.get("DTC_LANE_POOL", "0") == "1"
+        self._own = []
+
+        def make(name):
+            if pooled:
+                return torch.cuda.Stream(device=dev, **(dict(priority=-1) if name in prio else {}))
+            h = ctypes.c_void_p()
+            with torch.cuda.device(dev):
+                _ffi.check(_ffi.lib().dtc_stream_create(int(name in prio), ctypes.byref(h)), "dtc_stream_create")
+            self._own.append(h)
+            return torch.cuda.ExternalStream(h.value, device=dev)
+        self.side = make("side")
+        self.side2 = make("side")          # image chain: the narrow layers' (latency-bound) weight-gradient group beside the wide one
+        self.aux = make("aux")
         self.main = None                    # torch's current stream at the start of the step
         self.two_lanes = False
         self._events, self._ev_next = [], 0
         self.joined, self.joined2 = torch.cuda.Event(), torch.cuda.Event()
         self.side_busy = self.side2_busy = False
+
+    def __del__(self):
+        try:
+            for h in self._own:
+                _ffi.lib().dtc_stream_destroy(h)        # (hipStreamDestroy returns at once; the stream goes when its work has drained)
+            self._own = []
+        except Exception:                                # interpreter shutdown: the library / torch may be gone already
+            pass
 
     def begin(self, two_lanes):
         self.main = torch.cuda.current_stream()
@@ -206,7 +235,7 @@ class _TrainWorkspace(_Lanes):
         self.wg = ops.workspace(max(lib.dtc_linear_wgrad_workspace(B, n, k) for n, k in shapes), dev)
         self.loss_ws = ops.workspace(lib.dtc_loss_workspace(B), dev)
         self.hpart = torch.zeros(int(lib.dtc_linear_fwd_mse_parts(B, 693)), dtype=torch.float64, device=dev)
-        self.gws = self.gws_img = None
+        self.gws = self.gws2 = self.gws_img = None
         self.pending, self.held = [], []      # queued weight-gradient jobs; operands of flushed jobs (alive until the join)
         self.pending_img = []                 # queued weight-gradient jobs whose operands are activation images
         self._imgs, self.live_img = {}, set()
@@ -232,13 +261,17 @@ class _TrainWorkspace(_Lanes):
 
     MAX_GROUP = 12           # jobs per grouped weight-gradient launch (MAX_JOBS of csrc/wgrad.hip)
 
-    def group_ws(self, jobs, split=None):
-        """Partial-slab workspace of a grouped weight-gradient launch, grown on demand."""
+    def group_ws(self, jobs, split=None, lane2=False):
+        """Partial-slab workspace of a grouped weight-gradient launch, grown on demand.  `lane2`: the launch goes to the second
+        weight-gradient stream -- its own slab, so that launches on `side` and `side2` of one step never share partials."""
         need = ops.wgrad_group_workspace_bytes(jobs, self.B, split)
-        if self.gws is None or self.gws.numel() * self.gws.element_size() < need:
+        name = "gws2" if lane2 else "gws"
+        cur = getattr(self, name, None)
+        if cur is None or cur.numel() * cur.element_size() < need:
             torch.cuda.synchronize()            # nothing may still be reading the buffer being replaced
-            self.gws = ops.workspace(need, self._dev)
-        return self.gws
+            cur = ops.workspace(need, self._dev)
+            setattr(self, name, cur)
+        return cur
 
     def wgrad_ws(self, N, K):
         """Split-partials workspace, grown on demand (rare: first use of a larger layer shape)."""
@@ -349,6 +382,8 @@ class PPO:
             if opt is not None and opt.arena is not arena:
                 arena._named = list(self.actor_critic.named_parameters())
                 opt.rebind(arena)
+                # weight images are keyed by the weights' addresses: those of the replaced arena are dead (and would be rebuilt every phase)
+                self._wsets.clear()
         return arena
 
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape,
@@ -470,18 +505,18 @@ class PPO:
         return True
 
     def _kl_to_header(self, stats):
-        """Data parallel, adaptive schedule: the local KL mean goes into slot 0 of the gradient header; it is averaged
-        with the first gradient bucket of the policy step (no collective of its own on the critical path)."""
-        if self._world() > 1 and self._adaptive():
-            self.actor_critic.arena.kl_slot.copy_(stats[S_KL:S_KL + 1])
+        """Data parallel, adaptive schedule: the local KL mean goes into slot 0 of the gradient header and is averaged with the first
+        gradient bucket of the policy step (no collective of its own on the critical path).  The loss's finalize launch deposits it
+        there itself (DtcPpoCfg.kl_mirror, see _loss_cfg): no copy between the loss and the backward pass.  (Until round 6 this was a
+        4-byte device-to-device torch copy_ on the compute stream, right behind the loss kernels: DESIGN.md §5, the run-to-run
+        differences of the 2-rank tests.)"""
+        return
 
     def _lr_from_header(self, stats):
         """After the exchange: the averaged KL drives the learning-rate rule (identical on every rank) and replaces the
-        local value in the statistics table."""
+        local value in the statistics table (written by the same launch)."""
         if self._world() > 1 and self._adaptive():
-            kl = self.actor_critic.arena.kl_slot
-            stats[S_KL:S_KL + 1].copy_(kl)
-            ops.lr_adapt(kl, self.optimizer.lr_dev, float(self.desired_kl))
+            ops.lr_adapt(self.actor_critic.arena.kl_slot, self.optimizer.lr_dev, float(self.desired_kl), kl_out=stats[S_KL:S_KL + 1])
 
     def _image_mode(self, fw):
         """This step runs the wide stacks on operand images (see ActorCriticDecoder.images_ok)."""
@@ -530,11 +565,11 @@ class PPO:
         jobs, tw.pending = tw.pending, []
         jobs_img, tw.pending_img = tw.pending_img, []
         narrow = tw.narrow_wgrad                               # image chain: the fp32 jobs are the narrow layers -> single-pass kernels
-        ws = tw.group_ws(jobs, False if narrow else None) if jobs else None
+        two = self.overlap_wgrad and bool(jobs_img) and bool(jobs) and narrow and self.side2_wgrad   # the narrow group runs BESIDE the wide one
+        ws = tw.group_ws(jobs, False if narrow else None, lane2=two) if jobs else None
         ws_img = tw.group_ws_img(jobs_img) if jobs_img else None
         sp = sp2 = None
         if self.overlap_wgrad:
-            two = bool(jobs_img) and bool(jobs) and narrow and self.side2_wgrad      # the narrow group runs BESIDE the wide one
             lanes = (tw.main, tw.aux) if tw.two_lanes else (torch.cuda.current_stream(),)
             for lane in lanes:
                 ev = tw.event()
@@ -923,12 +958,14 @@ class PPO:
         fw.pack_gen, fw.pack_slot = self._pack_gen, 0
         self.optimizer.set_lr(self.learning_rate)
         stats = torch.zeros(STAT_COLS, dtype=torch.float32, device=dev) if stats is None else stats.to(dev)
-        if which in ("vae", "both"):
-            self._vae_step(fw, tw, flat, idx, eps1.to(dev).contiguous(), stats)
-        if which in ("ppo", "both"):
-            self._ppo_step(fw, tw, flat, idx, eps2.to(dev).contiguous(), stats, self._loss_cfg())
-        ops.amax_static_clear()
-        fw.pack_gen = None
+        try:
+            if which in ("vae", "both"):
+                self._vae_step(fw, tw, flat, idx, eps1.to(dev).contiguous(), stats)
+            if which in ("ppo", "both"):
+                self._ppo_step(fw, tw, flat, idx, eps2.to(dev).contiguous(), stats, self._loss_cfg())
+        finally:
+            ops.amax_static_clear()
+            fw.pack_gen = None
         self.learning_rate = float(self.optimizer.lr_dev.item())
         for g in self.optimizer.param_groups:
             g['lr'] = self.learning_rate
@@ -954,6 +991,9 @@ class PPO:
         cfg.desired_kl = float(self.desired_kl) if self.desired_kl is not None else 0.0
         cfg.use_clipped_value_loss = int(bool(self.use_clipped_value_loss))
         cfg.adaptive_schedule = int(self._adaptive() and self._world() == 1)
+        # data parallel: the finalize launch also deposits the KL mean in the gradient header (slot 0), which the first bucket's
+        # all-reduce averages over the ranks
+        cfg.kl_mirror = self.actor_critic.arena.kl_slot.data_ptr() if (self._adaptive() and self._world() > 1) else None
         return cfg
 
     def update(self, perm=None, eps1=None, eps2=None, return_stats=False):
@@ -983,19 +1023,21 @@ class PPO:
         k = 0
         self._pack_gen = getattr(self, "_pack_gen", 0) + 1
         fw.pack_gen = self._pack_gen                   # the packed rollout rows of a mini-batch serve all five epochs (packed_input)
-        for _ in range(epochs):
-            for i in range(nmb):
-                fw.pack_slot = i
-                idx = perm[i * B:(i + 1) * B]
-                with tracing.span("vae_step"):
-                    self._vae_step(fw, tw, flat, idx, eps1[k], stats[k])
-                with tracing.span("ppo_step"):
-                    self._ppo_step(fw, tw, flat, idx, eps2[k], stats[k], cfg)
-                if lr_hist is not None:
-                    lr_hist[k:k + 1].copy_(self.optimizer.lr_dev)
-                k += 1
-        fw.pack_gen = None
-        ops.amax_static_clear()                        # the storage is about to be refilled: its amax slots are void
+        try:
+            for _ in range(epochs):
+                for i in range(nmb):
+                    fw.pack_slot = i
+                    idx = perm[i * B:(i + 1) * B]
+                    with tracing.span("vae_step"):
+                        self._vae_step(fw, tw, flat, idx, eps1[k], stats[k])
+                    with tracing.span("ppo_step"):
+                        self._ppo_step(fw, tw, flat, idx, eps2[k], stats[k], cfg)
+                    if lr_hist is not None:
+                        lr_hist[k:k + 1].copy_(self.optimizer.lr_dev)
+                    k += 1
+        finally:                                       # (an exception mid-update must not leave the generation live: a later direct step would
+            fw.pack_gen = None                         # find the packed rows of THIS rollout under a recycled index address)
+            ops.amax_static_clear()                    # the storage is about to be refilled: its amax slots are void
         # the single device -> host synchronisation of the update
         host = stats.cpu()
         self.learning_rate = float(self.optimizer.lr_dev.item())

@@ -125,7 +125,10 @@ class RecurrentPPO:
         cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef = self.clip_param, self.value_loss_coef, self.entropy_coef
         cfg.desired_kl = float(self.desired_kl) if self.desired_kl is not None else 0.0
         cfg.use_clipped_value_loss = int(bool(self.use_clipped_value_loss))
-        cfg.adaptive_schedule = int(self.desired_kl is not None and self.schedule == 'adaptive' and dp.world_size() == 1)
+        adaptive = self.desired_kl is not None and self.schedule == 'adaptive'
+        cfg.adaptive_schedule = int(adaptive and dp.world_size() == 1)
+        # data parallel: the finalize launch also deposits the KL mean in slot 0 of the gradient header (averaged by the exchange)
+        cfg.kl_mirror = self.actor_critic.ensure_arena().kl_slot.data_ptr() if (adaptive and dp.world_size() > 1) else None
         return cfg
 
     def _wgrad(self, ln, dZ, X, gW, gb, M, rows=None):
@@ -202,8 +205,7 @@ class RecurrentPPO:
         if dp.world_size() > 1:
             dp.allreduce_mean_(arena.grad_full)      # header (KL) + every gradient: one collective per optimiser step
         if dp_adaptive:
-            stats[S_KL:S_KL + 1].copy_(arena.kl_slot)
-            ops.lr_adapt(arena.kl_slot, self.optimizer.lr_dev, float(self.desired_kl))
+            ops.lr_adapt(arena.kl_slot, self.optimizer.lr_dev, float(self.desired_kl), kl_out=stats[S_KL:S_KL + 1])
         if self.capture_grads:
             self.captured["main"] = ac.arena.grad.clone()
         self.optimizer.step(self.max_grad_norm, stats[S_GNORM:S_GNORM + 1])
@@ -230,8 +232,7 @@ class RecurrentPPO:
                      flat("advantages"), flat("returns"), flat("values"), store_idx, self._loss_cfg(), dmean, dval,
                      ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, lws)
         dp_adaptive = dp.world_size() > 1 and self.desired_kl is not None and self.schedule == 'adaptive'
-        if dp_adaptive:                              # the KL mean travels in the header of the gradient exchange
-            arena.kl_slot.copy_(stats[S_KL:S_KL + 1])
+        # (dp_adaptive: the KL mean travels in the header of the gradient exchange -- deposited by the loss's finalize launch, _loss_cfg)
         ln.order("main", "aux")
         # backward: MLPs -> scatter into the padded layout -> BPTT -> input-projection weight gradient
         H = ac.rnn_hidden_size
@@ -408,8 +409,7 @@ class RecurrentPPO:
         ops.ppo_loss(mean, ac.std_view, value, flat("actions"), flat("actions_log_prob"), flat("mu"), flat("sigma"),
                      flat("advantages"), flat("returns"), flat("values"), store_idx, self._loss_cfg(), dmean, dval,
                      ac.std_grad, stats[S_SURR:S_SURR + 4], self.optimizer.lr_dev, lws)
-        if dp.world_size() > 1 and self.desired_kl is not None and self.schedule == 'adaptive':
-            arena.kl_slot.copy_(stats[S_KL:S_KL + 1])            # the KL mean travels in the header of the gradient exchange
+        # (data parallel: the KL mean travels in the header of the gradient exchange -- deposited by the loss's finalize launch, _loss_cfg)
         ln.order("main", "aux")
         with ln.lane("aux"):
             head_mlp_backward(hc, dval)

@@ -77,6 +77,10 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def backend() -> str:
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else ""
+
+
 def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 

@@ -734,8 +734,9 @@ def clip_adam(params, grads, exp_avg, exp_avg_sq, max_grad_norm, lr, beta1, beta
                               beta1, beta2, eps, step, ptr(gnorm_out), ptr(ws), stream()), "dtc_clip_adam")
 
 
-def lr_adapt(kl_mean, lr, desired_kl):
-    check(lib().dtc_lr_adapt(ptr(kl_mean), ptr(lr), desired_kl, stream()), "dtc_lr_adapt")
+def lr_adapt(kl_mean, lr, desired_kl, kl_out=None):
+    """`kl_out` (1 float, optional): receives the KL the rule was evaluated on (the step's statistics row) -- same launch, no copy."""
+    check(lib().dtc_lr_adapt(ptr(kl_mean), ptr(lr), desired_kl, ptr(kl_out) if kl_out is not None else None, stream()), "dtc_lr_adapt")
 
 
 # ---------------------------------------------------------------- GRU

@@ -101,6 +101,23 @@ def _worker(rank, world, port, out, overlap_exchange, overlap_lanes, key, opts=N
         if not overlap_lanes:
             alg.overlap_wgrad = alg.overlap_lanes = False
         arena = ac.ensure_arena() if hasattr(ac, "ensure_arena") else ac.arena
+        if os.environ.get("PROBE_KLCOPY"):           # the trainer's form until round 6: the KL reaches the gradient header by a torch op behind the loss
+            from dtc_amd.algorithms import ppo as _P
+            how, cfg0 = os.environ["PROBE_KLCOPY"], alg._loss_cfg
+
+            def cfg_without_mirror():
+                c = cfg0()
+                c.kl_mirror = None
+                return c
+
+            def kl_to_header(stats):
+                if dp.world_size() > 1:
+                    src = stats[_P.S_KL:_P.S_KL + 1]
+                    if how == "memcpy":
+                        arena.kl_slot.copy_(src)                        # hipMemcpyAsync, device to device, 4 bytes
+                    else:
+                        torch.add(src, 0.0, out=arena.kl_slot)          # the same move by an elementwise kernel
+            alg._loss_cfg, alg._kl_to_header = cfg_without_mirror, kl_to_header
         snaps = []
         for tag, opt in (("vae", alg.vae_optimizer), ("main", alg.optimizer)):
             def wrap(step, tag=tag):

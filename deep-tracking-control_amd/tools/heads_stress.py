@@ -16,15 +16,32 @@ from dtc_amd import _ffi, h2i, ops  # noqa: E402
 DEV = "cuda:0"
 
 
+def many_streams(q):
+    """q streams; NOISE_PRIO = high | normal | mixed (alternating: each priority has its own hardware queues)."""
+    how = os.environ.get("NOISE_PRIO", "mixed")
+    return [torch.cuda.Stream(priority=-1 if (how == "high" or (how == "mixed" and i % 2 == 0)) else 0) for i in range(q)]
+
+
 def noise_loop():
     x = torch.randn(2048, 2048, device=DEV)
     y = torch.randn(1 << 22, device=DEV)
+    q = int(os.environ.get("NOISE_QUEUES", "0"))
+    streams = many_streams(q)
+    small = [torch.randn(384, 512, device=DEV) for _ in streams]
+    w = torch.randn(512, 512, device=DEV) * 0.04
+    heavy = os.environ.get("NOISE_HEAVY", "1") == "1"
     t0 = time.time()
     while time.time() - t0 < float(os.environ.get("NOISE_SECONDS", "600")):
         for _ in range(50):
-            x = torch.tanh(x @ x * 1e-3)
-            y = torch.sin(y) * 1.0001
+            if heavy:
+                x = torch.tanh(x @ x * 1e-3)
+                y = torch.sin(y) * 1.0001
+            for i, s_ in enumerate(streams):            # bursts of short kernels (a small GEMM + an elementwise op) on the queues
+                with torch.cuda.stream(s_):
+                    small[i] = torch.tanh(small[i] @ w)
         torch.cuda.synchronize()
+        if not heavy:
+            time.sleep(0.0002)
 
 
 def main():
@@ -32,6 +49,7 @@ def main():
         return noise_loop()
     B, reps = int(sys.argv[1]), int(sys.argv[2])
     n_noise = int(sys.argv[sys.argv.index("--noise") + 1]) if "--noise" in sys.argv else 0
+    nq = int(sys.argv[sys.argv.index("--queues") + 1]) if "--queues" in sys.argv else 0
     streams = "--streams" in sys.argv
     H, A = 128, 12
     g = torch.Generator(device=DEV).manual_seed(23)
@@ -58,10 +76,12 @@ def main():
     run()
     torch.cuda.synchronize()
     first = [t.clone() for t in outs()]
-    kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "noise"]) for _ in range(n_noise)]
+    kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "noise"], env=dict(os.environ, NOISE_QUEUES=str(nq))) for _ in range(n_noise)]
     if n_noise:
         time.sleep(20)                      # the children's imports
     bad = torch.zeros(len(names), dtype=torch.int64, device=DEV)
+    mine = many_streams(nq)
+    mine_t = [torch.randn(4096, device=DEV) for _ in mine]
     side = torch.cuda.Stream()
     junk = torch.randn(1 << 20, device=DEV)
     t0 = time.time()
@@ -74,13 +94,16 @@ def main():
         if streams:
             with torch.cuda.stream(side):
                 junk = torch.sin(junk) * 1.0001
+        for s_, t_ in zip(mine, mine_t):
+            with torch.cuda.stream(s_):
+                t_.mul_(1.0001)
         if i % 500 == 499:
             torch.cuda.synchronize()
     torch.cuda.synchronize()
     dt = time.time() - t0
     for k in kids:
         k.terminate()
-    print(f"B={B} reps={reps} unroll={os.environ.get('DTC_HEADS_UNROLL', '0')} noise={n_noise} streams={streams}: launches whose output differed "
+    print(f"B={B} reps={reps} unroll={os.environ.get('DTC_HEADS_UNROLL', '0')} noise={n_noise} streams={streams} queues={nq}: launches whose output differed "
           f"from launch 0: " + ", ".join(f"{n}={int(c)}" for n, c in zip(names, bad.tolist())) + f"  ({dt:.0f} s)")
 
 

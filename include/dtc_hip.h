@@ -38,7 +38,7 @@ extern "C" {
 #define DTC_ACT_SIGMOID 6
 
 /* library / device info ------------------------------------------------------------------ */
-#define DTC_ABI_VERSION 14                   /* bumped whenever a signature or a by-value struct layout changes       */
+#define DTC_ABI_VERSION 15                   /* bumped whenever a signature or a by-value struct layout changes       */
 int dtc_version(void);                       /* == DTC_ABI_VERSION of the build; the host binding refuses a mismatch   */
 /* sizeof() of the structs that cross the boundary, in the order DtcGridCfg, DtcObsCfg, DtcRowCopy, DtcSeg, DtcSegMat,
    DtcFwdLayer, DtcWgradJob, DtcPpoCfg, DtcProfRec, DtcWimgJob, DtcH2iWJob, DtcH2iOperand, DtcWgradH2iJob, DtcEnvStep, DtcH2iFwdLayer, DtcH2iDgradLayer, DtcGruFwdItem, DtcGruBwdItem: the binding compares them with its own layouts at load time (a library
@@ -46,6 +46,10 @@ int dtc_version(void);                       /* == DTC_ABI_VERSION of the build;
    Returns the number of entries (written up to `cap`). */
 int dtc_abi_sizes(int64_t* out, int cap);
 const char* dtc_last_error(void);            /* host string describing the last failure   */
+/* A non-blocking HIP stream owned by the caller (high_priority != 0: the device's greatest priority).  The trainers run their second compute
+ * lane and their weight-gradient lanes on such streams instead of entries of torch's shared stream pool (dtc_amd/algorithms/ppo.py:_Lanes). */
+int dtc_stream_create(int high_priority, void** out);
+int dtc_stream_destroy(void* stream);
 
 /* ---- foothold planner: legged_gym/envs/base/legged_robot_dtc.py:98-201 ----------------- */
 typedef struct DtcGridCfg {
@@ -550,6 +554,8 @@ int64_t dtc_loss_workspace(int B);
 typedef struct DtcPpoCfg {
     float clip_param, value_loss_coef, entropy_coef, desired_kl;
     int32_t use_clipped_value_loss, adaptive_schedule;
+    float* kl_mirror;      /* NULL, or a device address that ALSO receives kl_mean from the finalize launch (data parallel: slot 0 of the
+                              gradient header the first bucket's all-reduce carries -- no copy of its own between the loss and the backward pass) */
 } DtcPpoCfg;
 /* PPO losses + KL-adaptive learning rate of ppo.py:288-327.  mean [B,12], std [12], value [B].
  * Outputs: dmean [B,12], dvalue [B], dstd [12], losses[0..3] = {surrogate, value, entropy, kl_mean},
@@ -590,7 +596,7 @@ int dtc_ppo_heads_loss_img(const float* Ha, int64_t ldha, const float* Hc, int64
  * The slot is CONSUMED: it is overwritten with a NaN of a payload of its own (0x7fc0dead), and finding exactly that pattern (a caller that
  * exchanged the gradient header without depositing this step's KL first) poisons *lr with NaN instead of silently re-using a stale value.
  * A KL that is NaN itself (any other payload) leaves *lr unchanged, as both comparisons of the reference do. */
-int dtc_lr_adapt(float* kl_mean, double* lr, float desired_kl, void* stream);
+int dtc_lr_adapt(float* kl_mean, double* lr, float desired_kl, float* kl_out /* NULL, or where the (averaged) KL is kept: the step's statistics row */, void* stream);
 /* log-prob / sampling side of PPO.act (ppo.py:137-150): actions = mean + std*noise,
  * logp = sum_j log N(a; mean, std). */
 int dtc_gaussian_act(const float* mean, const float* std, const float* noise, float* actions,

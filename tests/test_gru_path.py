@@ -329,3 +329,48 @@ def test_second_update_packs_the_new_rollout():
         seen[seed] = packed
     assert len(seen[9]) == len(seen[10]) == 40 and all(seen[9])
     assert all(seen[10]), f"{seen[10].count(False)} of 40 packed observation images of the second update are stale"
+
+
+@pytest.mark.gpu
+def test_two_consecutive_updates_vs_oracle():
+    """RecurrentPPO.update() twice on two DIFFERENT rollouts against the oracle stepping the same eight mini-batches (1 epoch x 4 per
+    update).  Both sides start each update from the oracle's weights / Adam state / learning rate, so the first step of EVERY update is a
+    1e-5 comparison -- whatever the trainer carries from update to update (packed observation images, their generation keys, workspaces)
+    must not leak into the second one (the bug class of 61f564b: the second update trained on the first update's packed observations).
+    Later steps of an update run free: Adam turns rounding noise of near-zero gradients into +-lr flips, so the bound widens per step."""
+    from dtc_amd.algorithms import ppo as P
+    from dtc_amd.algorithms import RecurrentPPO
+    from dtc_amd.modules import ActorCriticRecurrent
+    n = 64
+    ref_ac = oracle_model()
+    ref = GR.RefRecurrentPPO(ref_ac, learning_rate=1e-3, entropy_coef=0.003)
+    ac = ActorCriticRecurrent(53, 1389, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+                              activation='elu', rnn_type='gru', rnn_hidden_size=512, rnn_num_layers=1)
+    alg = RecurrentPPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=DEV, num_learning_epochs=1)
+    alg.init_storage(n, 24, [53], [1389], [12])
+    envelope = (1e-5, 3e-4, 1.5e-3, 5e-3)
+    worst = []
+    for u, seed in enumerate((4, 12)):
+        data, hid_a, hid_c = gru_case(seed=seed, n=n)
+        st = oracle_storage(data, n)
+        for k, v in data.items():
+            if k not in ("last_values", "observation_histories"):
+                getattr(alg.storage, k).copy_(v.to(DEV))
+        alg.storage.compute_returns(data["last_values"].to(DEV), 0.99, 0.95)
+        alg.storage.step = 24
+        alg.storage.saved_hidden_states_a, alg.storage.saved_hidden_states_c = [hid_a.to(DEV)], [hid_c.to(DEV)]
+        ac.load_state_dict(ref.ac.state_dict())
+        alg.optimizer.load_state_dict(ref.optimizer.state_dict())
+        alg.learning_rate = ref.learning_rate
+        recs = [ref.step(st, b) for b in GR.recurrent_batches(st, hid_a, hid_c, 4)]
+        alg.update()
+        rows = alg.last_update_stats
+        assert rows.shape[0] == 4
+        for k, rec in enumerate(recs):
+            for key, col in (("surrogate", P.S_SURR), ("value", P.S_VALUE), ("entropy", P.S_ENTROPY), ("gnorm", P.S_GNORM), ("kl_mean", P.S_KL)):
+                err = abs(float(rows[k, col]) - rec[key]) / max(1.0, abs(rec[key]))
+                worst.append((err / envelope[k], u, k, key, float(rows[k, col]), rec[key]))
+        assert abs(alg.learning_rate - ref.learning_rate) <= 1e-12, (u, alg.learning_rate, ref.learning_rate)
+    first_steps = [w for w in worst if w[2] == 0]
+    assert max(first_steps)[0] <= 1.0, sorted(first_steps, reverse=True)[:4]          # update 2, step 0 included: 1e-5
+    assert max(worst)[0] <= 1.0, sorted(worst, reverse=True)[:6]
