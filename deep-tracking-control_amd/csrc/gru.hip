@@ -192,8 +192,16 @@ extern "C" int64_t dtc_gru_workspace(int T, int R, int H) {
     const int64_t a = (int64_t)R * MAX_PARTS * H * sizeof(float);
     const int64_t b = (int64_t)T * R * 3 * H * sizeof(float);
     const int64_t img = dtc_s3_planes_bytes(H, 3 * H) > dtc_gru_s3_image_bytes(H) ? dtc_s3_planes_bytes(H, 3 * H) : dtc_gru_s3_image_bytes(H);
-    return a + b + 16 + ((dtc_linear_wgrad_workspace(T * R, 3 * H, H) + 15) & ~(int64_t)15) + img;     // +16: 16-byte alignment
+    const int64_t per_step = a + b + 16 + ((dtc_linear_wgrad_workspace(T * R, 3 * H, H) + 15) & ~(int64_t)15) + img;     // +16: 16-byte alignment
+    return ((per_step + 255) & ~(int64_t)255) + dtc_gru_seq_workspace(R, H);            // + the persistent kernels' exchange buffers (csrc/gru_seq.hip)
 }
+namespace {
+// the persistent kernels' region of a dtc_gru_workspace() buffer (its tail), 256-byte aligned inside the buffer's own alignment
+void* gru_seq_slot(void* workspace, int T, int R, int H) {
+    const int64_t total = dtc_gru_workspace(T, R, H), seq = dtc_gru_seq_workspace(R, H);
+    return (char*)workspace + ((total - seq) & ~(int64_t)255);
+}
+}  // namespace
 
 // byte offset of dgh_all [T, R, 3H] (the gradient w.r.t. the recurrent pre-activations, written by dtc_gru_bwd) inside the workspace
 extern "C" int64_t dtc_gru_dgh_offset(int T, int R, int H) {
@@ -209,11 +217,15 @@ extern "C" int dtc_gru_fwd(const float* gi, const float* h0, const float* W_hh, 
     hipStream_t s = (hipStream_t)stream;
     float* gh = (float*)workspace;
     const size_t RH = (size_t)R * H;
+    static const bool unfused = getenv("DTC_GRU_UNFUSED") != nullptr;      // two-kernel step (GEMM + gate kernel)
+    // the whole recurrence as ONE persistent launch (csrc/gru_seq.hip) where the shape is served and the buffers allow 16-byte accesses
+    if (!unfused && dtc_get_gemm_split() && dtc_gru_seq_supported(T, R, H, 0) && dtc::aligned16(gi) && dtc::aligned16(h0) && dtc::aligned16(hs_all) &&
+        dtc::aligned16(gates) && dtc::aligned16(hn) && dtc::aligned16(workspace))
+        return dtc_gru_seq_fwd(gi, h0, W_hh, b_hh, hs_all, gates, hn, gru_seq_slot(workspace, T, R, H), T, R, H, stream);
     if (hipMemcpyAsync(hs_all, h0, RH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
         dtc::set_error("gru_fwd: h0 copy failed");
         return DTC_ERR_LAUNCH;
     }
-    static const bool unfused = getenv("DTC_GRU_UNFUSED") != nullptr;      // two-kernel step (GEMM + gate kernel)
     const unsigned grid = (unsigned)dtc::ceil_div((int64_t)RH, 256);
     // split-precision steps (csrc/gru_s3.hip) for the passes of the update (T time steps share ONE image of W_hh); the one-step
     // calls of the rollout keep the single-pass kernel
@@ -324,6 +336,22 @@ extern "C" int dtc_gru_fwd_multi(const DtcGruFwdItem* items, int count, int T, i
     DTC_REQUIRE(T > 0 && R > 0 && H > 0, "bad shape T=%d R=%d H=%d", T, R, H);
     static const bool off = getenv("DTC_GRU_MULTI") && atoi(getenv("DTC_GRU_MULTI")) == 0;
     static const bool unfused = getenv("DTC_GRU_UNFUSED") != nullptr;
+    // both recurrences as ONE persistent launch (csrc/gru_seq.hip), one after the other inside it -- it may take every CU
+    if (count == 2 && !unfused && dtc_get_gemm_split() && dtc_gru_seq_supported(T, R, H, 1)) {
+        const float *gi[2], *h0[2], *W[2], *b[2];
+        float *hs[2], *gt[2], *hn[2];
+        void* sw[2];
+        bool ok = true;
+        for (int i = 0; i < 2; ++i) {
+            const DtcGruFwdItem& it = items[i];
+            DTC_REQUIRE(it.gi && it.h0 && it.W_hh && it.b_hh && it.hs_all && it.gates && it.hn && it.workspace, "item %d: null pointer", i);
+            gi[i] = it.gi; h0[i] = it.h0; W[i] = it.W_hh; b[i] = it.b_hh; hs[i] = it.hs_all; gt[i] = it.gates; hn[i] = it.hn;
+            sw[i] = gru_seq_slot(it.workspace, T, R, H);
+            ok = ok && dtc::aligned16(it.gi) && dtc::aligned16(it.h0) && dtc::aligned16(it.hs_all) && dtc::aligned16(it.gates) &&
+                 dtc::aligned16(it.hn) && dtc::aligned16(it.workspace);
+        }
+        if (ok) return dtc_gru_seq_fwd_pair(gi, h0, W, b, hs, gt, hn, sw, T, R, H, stream);
+    }
     const bool pair = count == 2 && !off && !unfused && T >= 4 && gru_s3(H);
     if (!pair) {
         for (int i = 0; i < count; ++i) {

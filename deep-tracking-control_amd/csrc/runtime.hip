@@ -96,7 +96,9 @@ int dtc_stream_create(int high_priority, void** out) {
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
     hipStream_t s = nullptr;
-    const hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? greatest : least);
+    // (not `least`: that is the LOW priority class (numerically 1 on this stack), below torch's default streams (0))
+    const int normal = (0 <= least && 0 >= greatest) ? 0 : least;
+    const hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? greatest : normal);
     if (e != hipSuccess) {
         dtc::set_error("hipStreamCreateWithPriority: %s", hipGetErrorString(e));
         return DTC_ERR_LAUNCH;

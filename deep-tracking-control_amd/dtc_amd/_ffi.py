@@ -264,6 +264,14 @@ _SIGS = {
     "dtc_gru_dgh_offset": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dtc_gru_fwd": (C.c_int, [c_f32p] * 7 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_gru_bwd": (C.c_int, [c_f32p] * 9 + [C.c_void_p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_set_gru_seq": (None, [C.c_int]),
+    "dtc_get_gru_seq": (C.c_int, []),
+    "dtc_gru_seq_trace": (None, [C.c_void_p]),
+    "dtc_gru_seq_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dtc_gru_seq_status": (C.c_int, [C.c_int]),
+    "dtc_gru_seq_workspace": (C.c_int64, [C.c_int, C.c_int]),
+    "dtc_gru_seq_fwd": (C.c_int, [c_f32p] * 7 + [C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dtc_gru_seq_fwd_pair": (C.c_int, [C.POINTER(c_f32p)] * 7 + [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_gru_fwd_multi": (C.c_int, [C.POINTER(DtcGruFwdItem), C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_gru_bwd_multi": (C.c_int, [C.POINTER(DtcGruBwdItem), C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dtc_set_concurrency_hint": (None, [C.c_int]),

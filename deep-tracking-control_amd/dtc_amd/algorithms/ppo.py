@@ -129,16 +129,17 @@ class _Lanes:
         # (tools/jobs/r5_prio.sh; "aux" alone 50.85, "side" alone 50.6).  DTC_LANE_PRIO=none: default priorities everywhere
         prio = os.environ.get("DTC_LANE_PRIO", "aux,side").split(",")
         # ... EXCEPT where several ranks of a job share this device (the one-GPU rehearsals of the data-parallel path over gloo; RCCL refuses
-        # two ranks on one device): there the lanes keep the default priority.  Two lock-stepped processes on one GPU, each with high-priority
-        # queues, gave run-to-run differences in the policy step of single ranks on some boxes of the pool (3 of 10 runs; 0 of 30 with default
-        # priorities, 0 of 50 for one process, 0 of 30 for two processes that exchange nothing): DESIGN.md §5, profiles/r06_flake*.txt
-        if "DTC_LANE_PRIO" not in os.environ and dp.world_size() > 1 and dp.backend() != "nccl":
+        # two ranks on one device): there the lanes are torch's pooled default-priority streams, the one configuration in which the 2-rank
+        # runs never differed from run to run (0 of 30; 3 of 10 with high-priority lanes, pooled or our own; one process: 0 of 50; two
+        # processes that exchange nothing: 0 of 30 -- DESIGN.md §5, profiles/r06_flake*.txt)
+        shared = "DTC_LANE_PRIO" not in os.environ and dp.world_size() > 1 and dp.backend() != "nccl"
+        if shared:
             prio = []
         # ... and they are streams of the library's own (dtc_stream_create), NOT entries of torch's stream pool: torch.cuda.Stream(priority=-1)
         # hands out the 32 pooled high-priority streams round-robin, and torch.distributed's gloo backend takes the work stream of every
         # collective on a device tensor from the SAME pool -- every few exchanges a collective's staging copies ran on the stream that is
         # also a compute lane here.  DTC_LANE_POOL=1: torch's pool, as until round 6
-        pooled = os.environ.get("DTC_LANE_POOL", "0") == "1"
+        pooled = shared or os.environ.get("DTC_LANE_POOL", "0") == "1"
         self._own = []
 
         def make(name):

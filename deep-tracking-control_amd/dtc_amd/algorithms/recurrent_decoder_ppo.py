@@ -25,6 +25,7 @@ from ..modules.actor_critic_decoder import Dense
 from ..modules.actor_critic_decoder_recurrent import ActorCriticDecoderRecurrent
 from ..utils import split_and_pad_trajectories, true_indices
 from .ppo import PPO, S_GNORM, S_KL, S_RECONS, S_SURR, S_VALUE, S_VEL, S_KLD, STAT_COLS
+from .recurrent_ppo import _share_rule
 
 
 class RecurrentDecoderPPO(PPO):
@@ -209,6 +210,9 @@ class RecurrentDecoderPPO(PPO):
         tw.begin(self.overlap_lanes and self.overlap_wgrad)
         tw.live_img.clear()
         rows = lambda t, w: segmat([seg(t, 0, w, gather=True)], unpad_idx)
+        # forward only: both recurrences as ONE persistent launch (csrc/gru_seq.hip) where that serves the shape -- opt-in (DTC_GRU_SEQ=1 DTC_GRU_SEQ_PAIR=1); default: two lanes
+        multi_fwd = self.gru_multi or (os.environ.get("DTC_GRU_SEQ_PAIR", "0") == "1" and ops.SPLIT and
+                                       bool(_ffi.lib().dtc_gru_seq_supported(int(T), int(R), int(H), 1)))
 
         # A head runs in three parts -- input projection | recurrence | MLP -- each on the head's lane; with DTC_GRU_MULTI=1 the two
         # recurrences advance TOGETHER on the main lane instead (ops.gru_fwd_multi / gru_bwd_multi: one launch per time step for both).
@@ -222,7 +226,7 @@ class RecurrentDecoderPPO(PPO):
             ws = ops.workspace(ops.gru_workspace_bytes(T, R, H), dev)
             hd = dict(name=name, X=X, cols=cols, mem=mem, proj=proj, layers=layers, hs_all=hs_all, gates=gates, hn=hn, ws=ws,
                       gi_p=gi_p, h0=h0.contiguous())
-            if not self.gru_multi:
+            if not multi_fwd:
                 ops.gru_fwd(*fwd_item(hd))
             return hd
 
@@ -309,7 +313,7 @@ class RecurrentDecoderPPO(PPO):
             Xa = [fw.img("lt"), ac.packed_input(fw, "p_a", segmat([seg(obs, 0, ac.num_obs, gather=True), seg(fw.z, 0, 16), seg(fw.mulv, 0, 3)], idx))]
             a_cols = [ac.num_obs + 19, 0]
         ha = head_project("a", Xa, a_cols, ac.memory_a, ac.proj_a, ac.A, bt["hid_a"])
-        if self.gru_multi:
+        if multi_fwd:
             tw.order("aux", "main")                                 # the critic's input projection is written
             ops.gru_fwd_multi([fwd_item(ha), fwd_item(hc)])
             tw.order("main", "aux")
@@ -371,7 +375,10 @@ class RecurrentDecoderPPO(PPO):
             self._amax_static(flat)                   # (inside update(): once per update -- the storage does not change between mini-batches)
             self._pack_gen = getattr(self, "_pack_gen", 0) + 1
             fw.pack_gen, fw.pack_slot = self._pack_gen, 0
-        self.optimizer.set_lr(self.learning_rate)
+            # (inside update() the device-side learning rate carries the adaptive schedule from mini-batch to mini-batch, ppo.py:301-307:
+            # re-seeding it here from the host copy made every mini-batch adapt from the rate the update STARTED with -- found by
+            # test_two_consecutive_updates_vs_oracle, round 6)
+            self.optimizer.set_lr(self.learning_rate)
         stats = torch.zeros(STAT_COLS, dtype=torch.float32, device=dev) if stats is None else stats
         if which in ("vae", "both"):
             self._vae_step(fw, tw, flat, bt["idx"], eps1.to(dev).contiguous(), stats)
@@ -384,6 +391,7 @@ class RecurrentDecoderPPO(PPO):
 
     def update(self, eps1=None, eps2=None, return_stats=False):
         self._require_gpu()
+        _share_rule()
         st, ac = self.storage, self.actor_critic
         self._arena()
         dev = ac.std.device
@@ -401,6 +409,7 @@ class RecurrentDecoderPPO(PPO):
         slices = list(self.recurrent_slices())
         k = 0
         fw = ac._fwd_ws(B)
+        self.optimizer.set_lr(self.learning_rate)      # once per update: the schedule then lives on the device (lr_dev)
         self._pack_gen = getattr(self, "_pack_gen", 0) + 1
         fw.pack_gen = self._pack_gen                   # the slices are the same in every epoch: their packed rollout rows serve all five
         # amax records of the stored rollout tensors ONCE per update (they were recomputed by every mini-batch: 100 passes over up to
@@ -416,6 +425,7 @@ class RecurrentDecoderPPO(PPO):
             fw.pack_gen = None
             ops.amax_static_clear()              # the storage is about to be refilled: its amax slots are void
         host = stats.cpu()                       # the single device -> host synchronisation of the update
+        ops.gru_seq_check()                      # (the persistent recurrence launches of this update all ran to their end)
         self.learning_rate = float(self.optimizer.lr_dev.item())
         for g in self.optimizer.param_groups:
             g['lr'] = self.learning_rate

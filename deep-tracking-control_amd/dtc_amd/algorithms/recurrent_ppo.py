@@ -26,6 +26,14 @@ import os
 from .ppo import FusedAdam, S_ENTROPY, S_GNORM, S_KL, S_SURR, S_VALUE, STAT_COLS, _Lanes
 
 
+def _share_rule():
+    """Several ranks of a job on ONE device (the gloo rehearsals of the data-parallel path): more than two persistent recurrence launches
+    could be in flight on the device at once, and their workgroups must all be resident to meet (csrc/gru_seq.hip) -- per-step launches
+    there.  One process per GPU (RCCL) keeps the persistent launches."""
+    if dp.world_size() > 1 and dp.backend() != "nccl":
+        ops.gru_seq_allow(False)
+
+
 class RecurrentPPO:
     actor_critic: ActorCriticRecurrent
 
@@ -131,6 +139,12 @@ class RecurrentPPO:
         cfg.kl_mirror = self.actor_critic.ensure_arena().kl_slot.data_ptr() if (adaptive and dp.world_size() > 1) else None
         return cfg
 
+    _SEQ_PAIR = os.environ.get("DTC_GRU_SEQ_PAIR", "0") == "1"      # opt-in: measured slower than two lanes
+
+    def _seq_pair(self, T, R, H):
+        """The actor's and the critic's forward recurrence go out as ONE persistent launch (dtc_gru_fwd_multi -> dtc_gru_seq_fwd_pair)."""
+        return self._SEQ_PAIR and ops.SPLIT and bool(_ffi.lib().dtc_gru_seq_supported(int(T), int(R), int(H), 1))
+
     def _wgrad(self, ln, dZ, X, gW, gb, M, rows=None):
         """Weight gradient on the side stream (off the critical path until the optimiser step)."""
         N, K = gW.shape
@@ -188,7 +202,11 @@ class RecurrentPPO:
         unpad_idx = (pos * R + traj).view(Nmb, T).transpose(1, 0).reshape(-1).contiguous()
         store_idx = (torch.arange(T, device=dev).unsqueeze(1) * N + torch.arange(start, stop, device=dev)).reshape(-1).contiguous()
         stats = torch.zeros(STAT_COLS, device=dev) if stats is None else stats
-        self.optimizer.set_lr(self.learning_rate)
+        if self._pack_gen is None:
+            # outside update() only.  Inside it the device-side learning rate carries the adaptive schedule from mini-batch to mini-batch
+            # (ppo.py:301-307): re-seeding it here from the host copy made every mini-batch adapt from the rate the update STARTED with
+            # (found by test_two_consecutive_updates_vs_oracle, round 6)
+            self.optimizer.set_lr(self.learning_rate)
         _ffi.lib().dtc_set_concurrency_hint(int(bool(self.overlap)))
         if self._wimages is None:
             self._wimages = ops.WeightImages()
@@ -290,6 +308,8 @@ class RecurrentPPO:
         # A head runs in three parts -- input projection | recurrence | MLP -- each on the head's lane; with DTC_GRU_MULTI=1 the two
         # recurrences advance TOGETHER on the main lane instead (ops.gru_fwd_multi / gru_bwd_multi: one launch per time step for both).
         multi = self.gru_multi
+        # forward only: both recurrences as ONE persistent launch (csrc/gru_seq.hip) where that serves the shape -- opt-in (DTC_GRU_SEQ=1 DTC_GRU_SEQ_PAIR=1); default: two lanes
+        multi_fwd = multi or self._seq_pair(T, R, H)
 
         def head_project(name, mem, layers, x, hidden):
             ximg = self._packed_obs("x_" + name, x, unpad_idx, M, dev)
@@ -302,7 +322,7 @@ class RecurrentPPO:
             ws = ops.workspace(ops.gru_workspace_bytes(T, R, H), dev)
             hd = dict(name=name, mem=mem, layers=layers, ximg=ximg, hs_all=hs_all, gates=gates, hn=hn, ws=ws, gi=gi, h0=h0[0].contiguous(),
                       keep=[gi_c])
-            if not multi:
+            if not multi_fwd:
                 ops.gru_fwd(*fwd_item(hd))
             return hd
 
@@ -390,7 +410,7 @@ class RecurrentPPO:
         with ln.lane("aux"):
             hc = head_project("c", ac.memory_c, ac.Cr, cobs_b, hid_c)
         ha = head_project("a", ac.memory_a, ac.A, obs_b, hid_a)
-        if multi:
+        if multi_fwd:
             ln.order("aux", "main")
             ops.gru_fwd_multi([fwd_item(ha), fwd_item(hc)])
             ln.order("main", "aux")
@@ -426,6 +446,7 @@ class RecurrentPPO:
 
     def update(self):
         self._require_gpu()
+        _share_rule()
         st = self.storage
         nmb, epochs = self.num_mini_batches, self.num_learning_epochs
         mb = st.num_envs // nmb
@@ -439,6 +460,7 @@ class RecurrentPPO:
         # update: from the second update of a run on, the image path reused the first update's packed observations)
         self._pack_serial = getattr(self, "_pack_serial", 0) + 1
         self._pack_gen = self._pack_serial
+        self.optimizer.set_lr(self.learning_rate)      # once per update: the schedule then lives on the device (lr_dev)
         try:
             for batch in st.reccurent_mini_batch_generator(nmb, epochs):
                 i = k % nmb
@@ -448,6 +470,7 @@ class RecurrentPPO:
         finally:
             self._pack_gen = None
         host = stats.cpu()
+        ops.gru_seq_check()                      # (the persistent recurrence launches of this update all ran to their end)
         self.learning_rate = float(self.optimizer.lr_dev.item())
         self.last_update_stats = host
         m = host.double().mean(dim=0)

@@ -744,6 +744,19 @@ def gru_workspace_bytes(T, R, H) -> int:
     return int(lib().dtc_gru_workspace(T, R, H))
 
 
+def gru_seq_check():
+    """Raise if a persistent recurrence launch (csrc/gru_seq.hip) gave up at a barrier since the last check: more than two of them shared
+    the device and their workgroups could not all be resident (two trainer processes on ONE GPU).  Call behind a device synchronisation."""
+    if lib().dtc_gru_seq_status(1) == 1:
+        raise _ffi.DtcError("a persistent GRU launch (dtc_gru_seq_fwd / _bwd) gave up at a barrier: its workgroups never met -- several "
+                            "trainers share this device; set DTC_GRU_SEQ=0 (per-step launches) for that configuration")
+
+
+def gru_seq_allow(on: bool):
+    """Switch the persistent recurrence launches on / off for this process (dtc_set_gru_seq)."""
+    lib().dtc_set_gru_seq(int(bool(on)))
+
+
 def gru_fwd(gi, h0, W_hh, b_hh, hs_all, gates, hn, ws):
     """gi [T,R,3H], h0 [R,H] -> hs_all [T+1,R,H] (slot 0 = h0), gates [T,R,3H], hn [T,R,H]."""
     T, R, H3 = gi.shape

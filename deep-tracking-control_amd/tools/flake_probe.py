@@ -185,6 +185,36 @@ def run(world, overlap_exchange, overlap_lanes, key, out, opts=None):
         assert p.exitcode == 0, (key, p.exitcode)
 
 
+def inproc(reps):
+    """ONE process, one rank: `reps` trainers built and run one after the other on the same inputs -- does the FIRST one of a process (fresh
+    memory, lazy module loading) end anywhere else than the later ones (recycled memory)?"""
+    from dtc_amd import synthetic as S
+    from dtc_amd.algorithms import PPO
+    from dtc_amd.modules import ActorCriticDecoder
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    full = S.rollout(N_PER_RANK, 24, seed=4)
+    g = torch.Generator().manual_seed(100)
+    B = N_PER_RANK * 24 // 4
+    perm = torch.randperm(4 * B, generator=g).cuda()
+    e1, e2 = torch.randn(4 * EPOCHS, B, 16, generator=g).cuda(), torch.randn(4 * EPOCHS, B, 16, generator=g).cuda()
+    sums = []
+    for i in range(reps):
+        torch.manual_seed(3)
+        ac = ActorCriticDecoder(53, 1389, 12)
+        alg = PPO(ac, learning_rate=1e-3, entropy_coef=0.003, device=dev, num_learning_epochs=EPOCHS)
+        alg.init_storage(N_PER_RANK, 24, [53], [1389], [265], [12])
+        for k, v in full.items():
+            if k != "last_values":
+                getattr(alg.storage, k).copy_(v.to(dev))
+        alg.storage.compute_returns(full["last_values"].to(dev), 0.99, 0.95)
+        alg.storage.step = 24
+        _, stats, lr = alg.update(perm, e1, e2, return_stats=True)
+        sums.append((int(ac.arena.flat.view(torch.int32).to(torch.int64).sum().item()), float(stats.double().sum())))
+        del alg, ac
+    print("in-process repeats:", "ALL EQUAL" if len(set(sums)) == 1 else f"{len(set(sums))} distinct results", sums[:4])
+
+
 def first_deep_difference(a, b):
     for (ta, ra), (tb, rb) in zip(a.get("deep", []), b.get("deep", [])):
         bad = [k for k in ra if ra[k] != rb.get(k)]
@@ -206,6 +236,8 @@ def first_difference(a, b):
 
 def main():
     mode, reps = sys.argv[1], int(sys.argv[2])
+    if mode == "inproc":
+        return inproc(reps)
     out = mp.get_context("spawn").Manager().dict()
     world = 2 if mode == "dp" else 1
     plan = []

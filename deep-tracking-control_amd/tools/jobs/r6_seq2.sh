@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 6: second GPU pass -- dp repeat test with its message, recurrent two-update tests, bench gru / composite with kernel classes
+cd "$(dirname "$0")/../../.." || exit 1
+out=gpurun_out/r06_seq2.txt
+: > $out
+echo "== dp repeat test" >> $out
+timeout 1200 python -m pytest "tests/test_hip_dp.py::test_bucketed_exchange_on_the_side_stream_equals_one_exchange_after_the_join" -x -q -m gpu 2>&1 | grep -v "socket.cpp\|amdgpu.ids" | grep -E "assert|Error|error|verdict|passed|failed|False|exitcode" | head -20 >> $out
+echo "== gru / composite two-update tests" >> $out
+timeout 1500 python -m pytest tests/test_gru_path.py tests/test_composite_path.py -x -q -m gpu 2>&1 | tail -12 >> $out
+for w in gru composite; do
+  for seq in 1 0; do
+    echo "== bench --workload $w DTC_GRU_SEQ=$seq" >> $out
+    DTC_GRU_SEQ=$seq timeout 600 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-in-situ 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print({k: d.get(k) for k in ('value','ms_per_step')}, d.get('roofline',{}).get('frac'))
+det=json.load(open('gpurun_out/bench_detail.json'))
+for k,v in sorted(det['kernel_classes'].items(), key=lambda kv:-kv[1]['ms'])[:14]: print('   ',k,v)
+" >> $out 2>&1
+  done
+done
+cat $out

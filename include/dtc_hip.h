@@ -651,6 +651,24 @@ int dtc_gru_bwd(const float* dhs, const float* hs_all, const float* gates, const
                 float* dgi, float* dW_hh, float* db_hh, float* dh0, void* workspace, const int64_t* valid_rows, int n_valid,
                 int T, int R, int H, void* stream);
 
+/* The recurrence as ONE persistent launch over all T time steps (csrc/gru_seq.hip; H = 512, R <= 2048, T >= 2): a workgroup owns a row
+ * block x 16 hidden units, keeps its slice of W_hh in LDS as two-term fp16 for all steps and meets the other workgroups of its row block at
+ * a counter barrier once per step.  OPT-IN (DTC_GRU_SEQ=1 or dtc_set_gru_seq(1); -1 = back to the environment's choice): dtc_gru_fwd / dtc_gru_fwd_multi then use it
+ * on the split-precision path whenever dtc_gru_seq_supported(); results within fp32 rounding of the per-step kernels (another, equally
+ * accurate, split of the operands).  Default: the per-step launches (measured no slower in the trainers).  A launch whose workgroups cannot meet (more than two such launches sharing the device) gives up after 2 s and raises the
+ * flag dtc_gru_seq_status() returns (1; it synchronises with the device; reset != 0 clears it) -- its outputs are then incomplete.
+ * seq_ws: dtc_gru_seq_workspace(R, H) bytes, 16-byte aligned (dtc_gru_workspace() includes them). */
+void dtc_set_gru_seq(int on);
+int dtc_get_gru_seq(void);
+void dtc_gru_seq_trace(void* buf);   /* debugging: (workgroups x T x 4) 8-byte time stamps (100 MHz) per step of thread 0: met / K loop done / gates done / arrived */
+int dtc_gru_seq_supported(int T, int R, int H, int exclusive /* 0: a launch that leaves half the CUs to a second one (dtc_gru_fwd); 1: dtc_gru_fwd_multi's */);
+int dtc_gru_seq_status(int reset);
+int64_t dtc_gru_seq_workspace(int R, int H);
+int dtc_gru_seq_fwd(const float* gi, const float* h0, const float* W_hh, const float* b_hh, float* hs_all, float* gates, float* hn,
+                    void* seq_ws, int T, int R, int H, void* stream);
+int dtc_gru_seq_fwd_pair(const float* const* gi, const float* const* h0, const float* const* W_hh, const float* const* b_hh,
+                         float* const* hs_all, float* const* gates, float* const* hn, void* const* seq_ws, int T, int R, int H, void* stream);
+
 /* Several recurrences of ONE shape (T, R, H) advanced together -- the actor's and the critic's `Memory` of ActorCriticRecurrent
  * (actor_critic_recurrent.py:45-46: memory_a, memory_c; both are evaluated on the same mini-batch of padded trajectories,
  * ppo.py:265-272): with count == 2 every time step is ONE launch for both (a time step of one recurrence is a latency-bound launch of

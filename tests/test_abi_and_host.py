@@ -265,5 +265,6 @@ def test_no_kernel_uses_scratch():
     assert len(three_i) == 6 and all(v["vgprs"] <= 168 and 3 * ((v["lds"] + 511) // 512 * 512) <= 160 * 1024 for v in three_i.values()), three_i
     # LDS: every kernel leaves room for at least two workgroups per CU; above 64 KiB only the GRU time-step kernels (ring of four image
     # buffers, launches of one workgroup per CU)
-    cap = lambda k: 80 if "gru_s3_kernel" in k else 64
+    # (gru_seq_fwd_kernel: one workgroup per CU BY DESIGN -- its 99 KiB slice of W_hh stays in LDS for all time steps, csrc/gru_seq.hip)
+    cap = lambda k: 80 if "gru_s3_kernel" in k else 100 if "gru_seq_fwd_kernel" in k else 64
     assert all(v["lds"] <= cap(k) * 1024 for k, v in res.items()), {k: v["lds"] for k, v in res.items() if v["lds"] > 64 * 1024}

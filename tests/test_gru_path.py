@@ -374,3 +374,18 @@ def test_two_consecutive_updates_vs_oracle():
     first_steps = [w for w in worst if w[2] == 0]
     assert max(first_steps)[0] <= 1.0, sorted(first_steps, reverse=True)[:4]          # update 2, step 0 included: 1e-5
     assert max(worst)[0] <= 1.0, sorted(worst, reverse=True)[:6]
+
+
+@pytest.mark.gpu
+def test_recurrent_minibatch_step_vs_oracle_on_the_persistent_recurrence():
+    """The teacher-forced mini-batch steps once more with the opt-in persistent forward recurrence (csrc/gru_seq.hip: ONE launch for all 24
+    time steps, W_hh slices resident in LDS as two-term fp16) in place of the per-step launches: same bounds against the oracle."""
+    from dtc_amd import _ffi
+    lib = _ffi.lib()
+    lib.dtc_set_gru_seq(1)
+    try:
+        assert lib.dtc_gru_seq_supported(24, 20, 512, 0) == 1
+        test_recurrent_minibatch_step_vs_oracle(dict())
+        assert lib.dtc_gru_seq_status(1) == 0
+    finally:
+        lib.dtc_set_gru_seq(-1)

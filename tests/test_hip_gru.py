@@ -110,11 +110,20 @@ def test_split_precision_step_kernels_vs_fp64(R):
 
 @pytest.mark.parametrize("T,R,H", [(24, 1473, 512), (6, 77, 128), (2, 40, 128), (5, 7, 64)])
 def test_two_recurrences_in_one_launch_per_time_step_equal_the_single_calls_bit_for_bit(T, R, H):
+    from dtc_amd import _ffi
+    _ffi.lib().dtc_set_gru_seq(0)            # (the per-step kernels: the persistent launches have tests of their own below)
+    try:
+        _multi_equals_single(T, R, H)
+    finally:
+        _ffi.lib().dtc_set_gru_seq(-1)
+
+
+def _multi_equals_single(T, R, H):
     """dtc_gru_fwd_multi / dtc_gru_bwd_multi (the actor's and the critic's Memory advanced together, actor_critic_recurrent.py:45-46):
     ONE launch per time step for both recurrences -- the same kernels on the same tiles, so every output equals the single calls' bit
     for bit (incl. dgh_all in the workspace, which the trainers' W_hh weight gradient reads).  (2, 40, 128) and (5, 7, 64) take the
     documented fall-back: the single calls one after the other."""
-    from dtc_amd import ops
+    from dtc_amd import _ffi, ops
     g = torch.Generator(device=DEV).manual_seed(T * 100 + R)
     rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
 
@@ -141,3 +150,101 @@ def test_two_recurrences_in_one_launch_per_time_step_equal_the_single_calls_bit_
             assert torch.equal(a[k], b[k]), (i, k)
         assert torch.equal(ops.gru_dgh_all(a["ws"], T, R, H), ops.gru_dgh_all(b["ws"], T, R, H)), (i, "dgh_all")
     assert not torch.equal(single[0]["hs"], single[1]["hs"])      # (the two recurrences are different problems)
+
+
+def _gru_ref64(gi, h0, W, b):
+    """torch.nn.GRU's recurrence in fp64 on the device (gate order r, z, n)."""
+    T, R, H3 = gi.shape
+    H = H3 // 3
+    h = h0.double()
+    hs, gates, hn = [h], [], []
+    Wd, bd = W.double(), b.double()
+    for t in range(T):
+        gh = h @ Wd.T + bd
+        g = gi[t].double()
+        r, z = torch.sigmoid(g[:, :H] + gh[:, :H]), torch.sigmoid(g[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(g[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        hs.append(h)
+        gates.append(torch.cat([r, z, n], 1))
+        hn.append(gh[:, 2 * H:])
+    return torch.stack(hs), torch.stack(gates), torch.stack(hn)
+
+
+@pytest.mark.parametrize("T,R", [(24, 1473), (24, 1600), (24, 2048), (3, 33), (2, 1), (24, 300)])
+def test_persistent_recurrence_vs_fp64_and_the_per_step_launches(T, R):
+    """csrc/gru_seq.hip (the forward recurrence as ONE persistent launch: W_hh slices resident in LDS as two-term fp16, row blocks meeting
+    at counter barriers) against an fp64 recurrence, next to the per-step launches on the same inputs: same error level required (the
+    two split the operands differently: no bit equality), every slot of every output written, status flag clear."""
+    from dtc_amd import _ffi, ops
+    lib = _ffi.lib()
+    H = 512
+    g = torch.Generator(device=DEV).manual_seed(T * 7 + R)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    gi, h0, W, b = rn(T, R, 3 * H), 0.5 * rn(R, H).clamp(-1.9, 1.9), rn(3 * H, H) / H ** 0.5, 0.2 * rn(3 * H)
+    ref = _gru_ref64(gi, h0, W, b)
+    res = {}
+    for seq in (1, 0):
+        lib.dtc_set_gru_seq(seq)
+        try:
+            assert lib.dtc_gru_seq_supported(T, R, H, 1) == seq
+            # two recurrences through dtc_gru_fwd_multi (ONE persistent launch that may take every CU: up to 2048 rows); the second one is
+            # the same problem with its rows reversed -- both must come out right
+            o = [[torch.full((T + 1, R, H), float("nan"), device=DEV), torch.full((T, R, 3 * H), float("nan"), device=DEV),
+                  torch.full((T, R, H), float("nan"), device=DEV), ops.workspace(ops.gru_workspace_bytes(T, R, H), DEV)] for _ in range(2)]
+            gi2, h02 = gi.flip(1).contiguous(), h0.flip(0).contiguous()
+            ops.gru_fwd_multi([(gi, h0, W, b, *o[0]), (gi2, h02, W, b, *o[1])])
+            torch.cuda.synchronize()
+        finally:
+            lib.dtc_set_gru_seq(-1)
+        hs, gates, hn = o[0][:3]
+        res[seq] = [float((a.double() - r).abs().max()) for a, r in zip((hs, gates, hn), ref)]
+        assert all(np.isfinite(e) for e in res[seq]), (seq, res[seq])            # (a NaN left = a slot nobody wrote)
+        for a, b2 in zip(o[0][:3], o[1][:3]):
+            assert torch.equal(a, b2.flip(1)), seq                               # rows are independent: the reversed problem, reversed
+    assert lib.dtc_gru_seq_status(1) == 0
+    print(f"gru recurrence T={T} R={R}: max abs error vs fp64 (h, gates, gh_n): persistent {res[1]}, per-step {res[0]}")
+    for k in range(3):
+        assert res[1][k] <= 2.0 * res[0][k] + 2e-6, (k, res)
+
+
+def test_two_persistent_recurrences_on_two_streams_meet():
+    """Two single-recurrence persistent launches (dtc_gru_fwd) on two streams at the largest size they serve (1024 rows: 4 row blocks x 32
+    unit tiles = 128 workgroups of one per CU each) -- both fit the chip at once, neither starves the other's barriers.  Results equal the
+    launches run one after the other bit for bit; the status flag stays clear."""
+    from dtc_amd import _ffi, ops
+    lib = _ffi.lib()
+    T, R, H = 24, 1024, 512
+    lib.dtc_set_gru_seq(1)
+    try:
+        assert lib.dtc_gru_seq_supported(T, R, H, 0) == 1 and lib.dtc_gru_seq_supported(T, R + 1, H, 0) == 0
+        _two_streams(lib, ops, T, R, H)
+    finally:
+        lib.dtc_set_gru_seq(-1)
+
+
+def _two_streams(lib, ops, T, R, H):
+    g = torch.Generator(device=DEV).manual_seed(11)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    ins = [(rn(T, R, 3 * H), 0.5 * rn(R, H), rn(3 * H, H) / H ** 0.5, 0.2 * rn(3 * H)) for _ in range(2)]
+
+    def run(streams):
+        outs = []
+        for (gi, h0, W, b), st in zip(ins, streams):
+            hs = torch.empty(T + 1, R, H, device=DEV)
+            gates, hn = torch.empty(T, R, 3 * H, device=DEV), torch.empty(T, R, H, device=DEV)
+            ws = ops.workspace(ops.gru_workspace_bytes(T, R, H), DEV)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(st):
+                for _ in range(3):                                   # a few back-to-back launches per stream: they overlap with the other stream's
+                    ops.gru_fwd(gi, h0, W, b, hs, gates, hn, ws)
+            outs.append((hs, gates, hn, ws))
+        torch.cuda.synchronize()
+        return outs
+    cur = torch.cuda.current_stream()
+    serial = run([cur, cur])
+    both = run([torch.cuda.Stream(), torch.cuda.Stream()])
+    assert lib.dtc_gru_seq_status(1) == 0
+    for a, b in zip(serial, both):
+        for k in range(3):
+            assert torch.equal(a[k], b[k]), k
