@@ -54,6 +54,11 @@ elif what == "traffic":
         ops.linear_dgrad(dZ, W, dX, X, "relu")
         flush.fill_(3.0)
         ops.linear_wgrad(dZ, X, dW, db, ws)
+elif what == "scorer4096":
+    # BASELINE configs[3]: one launch over 4096 envs x 4 legs (kernel-only duration by rocprofv3 --kernel-trace)
+    inp = {k: v.to(DEV) for k, v in S.scorer_inputs(4096, seed=1).items()}
+    for _ in range(30):
+        foothold.plan(inp["measured_heights"], inp["root_states"], inp["thigh_pos"], inp["commands"])
 elif what == "scorer":
     inp = {k: v.to(DEV) for k, v in S.scorer_inputs(98304, seed=1).items()}
     for _ in range(10):
