@@ -791,17 +791,13 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 6) void linear_dgrad_kernel(const f
 // 128 x 128 tiles (2 x 2 waves of 64 x 64) for launches that still fill the chip with them: >= 700 tiles, i.e. three per CU
 // (DTC_GEMM_128_BLOCKS; lab: 133.6 vs 129-130 TFLOP/s on 24576x512x512, 99 vs 121 on 24576x256x512 where only 384 tiles remain)
 bool wide_tiles(int rows, int cols) {
-    const char* e = getenv("DTC_GEMM_128_BLOCKS");
-    const long long thr = e ? atoll(e) : 700;
-    return thr > 0 && cols >= 128 && dtc::ceil_div(rows, BM) * dtc::ceil_div(cols, 128) >= thr;
+    constexpr long long thr = 700;
+    return cols >= 128 && dtc::ceil_div(rows, BM) * dtc::ceil_div(cols, 128) >= thr;
 }
 
 int pick_bn_rows(int rows, int cols) {
-    static const char* force = getenv("DTC_GEMM_BN");          // tuning aid: 32 | 64
-    if (force && cols > 64) return atoi(force) == 32 ? 32 : 64;
     if (cols <= 32) return 32;
-    static const char* thr_env = getenv("DTC_GEMM_MIN_BLOCKS");
-    const long long min_blocks = thr_env ? atoi(thr_env) : 320;     // measured with DTC_GEMM_MIN_BLOCKS sweeps of bench.py
+    constexpr long long min_blocks = 320;                            // measured with threshold sweeps of bench.py (round 2)
     return dtc::ceil_div(rows, BM) * dtc::ceil_div(cols, 64) >= min_blocks ? 64 : 32;
 }
 
@@ -820,8 +816,7 @@ bool deep_variant(int grid) {
 // base + column origin, row stride a multiple of 4 floats, tile origin on a 4-column boundary); bit 4 = the same for
 // the saved-activation matrix
 int wide_mask(const SegMatDev& xd, const float* Xsaved, long long ldxs, int col_skip, long long split_stride) {
-    static const bool off = getenv("DTC_GEMM_WIDE") && atoi(getenv("DTC_GEMM_WIDE")) == 0;
-    if (off || (col_skip & 3) || (split_stride & 3)) return 0;
+    if ((col_skip & 3) || (split_stride & 3)) return 0;
     int m = 0;
     for (int i = 0; i < xd.nseg; ++i) {
         const SegDev& sd = xd.s[i];
@@ -865,8 +860,7 @@ static int linear_fwd_impl(const DtcSegMat* X, const float* W, const float* b, f
     const int grid = grid_for((int)dtc::ceil_div(M, BM), (int)dtc::ceil_div(N, bn));
     dtc::ProfScope prof(dtc::prof_shape_name("linear_fwd", M, N, K), 2.0 * M * (double)N * K, s, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     // dwordx4 stores of the output need 16-byte aligned rows (full tiles only; checked per block)
-    static const bool wide_off = getenv("DTC_GEMM_WIDE") && atoi(getenv("DTC_GEMM_WIDE")) == 0;      // A/B switch
-    const int wide = (!wide_off && ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
+    const int wide = (ldy % 4 == 0 && dtc::aligned16(Y)) ? 1 : 0;
     if (rmask) {
         // the sign record is written by the wide epilogue of FULL tiles only: every tile of the launch must be one
         DTC_REQUIRE(act == DTC_ACT_RELU, "a sign record needs the ReLU activation (got %d)", act);

@@ -1060,7 +1060,7 @@ namespace {
 // them, default 256 = one per CU; 0: never)
 int g_rows64_max = -1;       // dtc_h2i_rows64_max; -1: the environment's value / the default
 bool rows64(int M, int N) {
-    static const int env_tiles = getenv("DTC_H2I_ROWS64_MAX") ? atoi(getenv("DTC_H2I_ROWS64_MAX")) : 256;
+    constexpr int env_tiles = 256;
     const int max_tiles = g_rows64_max >= 0 ? g_rows64_max : env_tiles;
     return dtc::ceil_div(M, BM) * dtc::ceil_div(N, 128) <= max_tiles && M > 64;
 }

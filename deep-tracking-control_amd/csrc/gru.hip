@@ -173,7 +173,7 @@ namespace {
 // tiles (4 column tiles for H = 512), so it takes 6 to put ~290 workgroups on the chip (DTC_GRU_S3_PARTS = 1, 2, 3 or 6)
 int gru_parts(int H, bool s3) {
     if (!s3) return 3;
-    static const int env = getenv("DTC_GRU_S3_PARTS") ? atoi(getenv("DTC_GRU_S3_PARTS")) : 6;
+    constexpr int env = 6;
     const int p = (env == 1 || env == 2 || env == 3 || env == 6) ? env : 6;
     return (3 * H / p) % 16 == 0 ? p : 3;
 }

@@ -347,7 +347,7 @@ extern "C" int dtc_gru_s3_image(const float* W_hh, void* img, int H, int backwar
 namespace {
 // DTC_GRU_XCD_COLS=0: the row-tile map of the general GEMM kernels (map_tile)
 int gru_colmap() {
-    static const int on = !(getenv("DTC_GRU_XCD_COLS") && atoi(getenv("DTC_GRU_XCD_COLS")) == 0);
+    constexpr int on = 1;
     return on;
 }
 int fwd_args(GruS3Args& a, const float* hprev, const void* img, const float* b_hh, const float* gi_t, float* hout, float* gates_t,

@@ -1,25 +1,29 @@
 // GRU recurrence as ONE persistent launch over all T time steps (round 6): the "LDS-staged sequence tiles" of BASELINE configs[2] for
-// torch.nn.GRU's recurrence of rsl_rl/rsl_rl/modules/actor_critic_recurrent.py:92-116 under ppo.py:265-335.
+// torch.nn.GRU's recurrence of rsl_rl/rsl_rl/modules/actor_critic_recurrent.py:92-116 under ppo.py:265-335.  OPT-IN (DTC_GRU_SEQ=1 /
+// dtc_set_gru_seq(1)): measured no faster in the trainers than the per-step launches on two lanes -- DESIGN.md 4.3d has the numbers.
 //
-// Why.  A time step of the recurrence is a [R ~ 1500] x [3H = 1536] x [H = 512] product + gate math: ~8 us of matrix work that took ~31 us as
-// a launch of its own (launch + dependency gaps, a K loop that waits for L2 on every stage, 150-300 workgroups on 256 CUs); 2 x 24 x 20 such
-// steps per update were 74 of the 92 ms of the recurrent workloads.
+// Why.  A time step of the recurrence is a [R ~ 1500] x [3H = 1536] x [H = 512] product + gate math: ~8 us of matrix work that takes ~30 us
+// as a launch of its own (launch + dependency gaps, a K loop that waits for L2 on every stage, 150-300 workgroups on 256 CUs); 2 x 24 x 20
+// such steps per update are 74 of the 92 ms of the recurrent workloads.
 //
 // How.  The recurrence couples the hidden UNITS of one row (trajectory), not the rows.  A workgroup owns (row block rb, unit tile ut): RB
-// rows (one wave per 32 rows) x 16 hidden units = 48 gate columns (r | z | n of those units).  Its slice of W_hh -- 48 rows x H, as two-term
-// fp16 (hi, lo) scaled by one power of two, 99 KiB -- is built ONCE in LDS and serves all T steps.  Per step a wave reads its 32 rows of
-// h_{t-1} (two-term fp16, fixed scale 2^14: |h| <= 1) straight from the exchange buffer into MFMA operand registers (no LDS staging: rows
-// are not shared between waves), runs 3 v_mfma_f32_16x16x32_f16 passes per product (lo hi', hi lo', hi hi': exact in the fp32
-// accumulator), with W as the A operand so that a lane ends up with FOUR CONSECUTIVE UNITS of one row: float4 loads of gi / h_{t-1},
-// float4 stores of h_t / gates / gh_n, 8-byte stores of the next step's operand.  The 32 workgroups of a row block then meet at a
-// counter barrier (agent-scope atomics; the exchange buffer is written and read with agent-scope 8-byte atomics, double-buffered, one
-// barrier per step) -- no grid-wide synchronisation, no kernel boundary.
+// rows (one wave per 32 rows, at most 8 waves) x 16 hidden units = 48 gate columns (r | z | n of those units).  Its slice of W_hh -- 48
+// rows x H, as two-term fp16 (hi, lo) scaled by one power of two, 99 KiB -- is built ONCE in LDS and serves all T steps.  Per step a wave
+// reads its 32 rows of h_{t-1} (two-term fp16, fixed scale 2^14: |h| <= 1) straight from the exchange buffer into MFMA operand registers
+// (16-byte loads running 4 K steps ahead; no LDS staging: rows are not shared between waves), runs 3 v_mfma_f32_16x16x32_f16 passes per
+// product (lo hi', hi lo', hi hi': exact in the fp32 accumulator) with W as the A operand, so that a lane ends up with FOUR CONSECUTIVE
+// UNITS of one row: float4 loads of gi, float4 stores of h_t / gates / gh_n, 8-byte stores of the next step's operand.  The 32 workgroups
+// of a row block then meet at a counter barrier (agent-scope atomics): the exchange rows leave by write-through (agent-scope) stores BEFORE
+// the arrival, the step's fp32 outputs and the next step's gi ride under the wait, and one wave per workgroup invalidates the CU's L1 (and
+// stale L2 lines) after the barrier -- the 16-32 workgroups of a row block that share an XCD then share its L2 for the re-reads.
+// Double-buffered exchange, one barrier per step, no grid-wide synchronisation, no kernel boundary.
 //
-// Residency.  The barrier needs every workgroup of a row block resident at once.  A launch has at most 4 x (H / 16) = 128 workgroups of
-// one per CU (LDS), so the two recurrences of an actor-critic (two launches on two streams) fit the chip's 256 CUs together; anything
-// else on the device only delays them.  Should the workgroups of a launch ever fail to meet (more than two such launches at once: two
-// trainer processes on ONE device), the spin gives up after 2 s, raises the error flag of dtc_gru_seq_status() and the launch ends --
-// a loud failure instead of a hang.  dtc_set_gru_seq(0) / DTC_GRU_SEQ=0 select the per-step launches.
+// Residency.  The barrier needs every workgroup of a row block resident at once; a workgroup takes a CU (LDS).  dtc_gru_fwd (one
+// recurrence; the other one may run beside it on another stream) keeps to 4 row blocks x (H / 16) = 128 workgroups = half the CUs (R <= 1024);
+// dtc_gru_fwd_multi runs both recurrences of an actor-critic one after the other inside ONE launch of up to 8 x 32 = 256 workgroups
+// (R <= 2048).  Should the workgroups of a launch ever fail to meet (more such launches than the device has CUs for: several trainer
+// processes on ONE device), the spin gives up after 2 s, raises the flag of dtc_gru_seq_status() and the launch ends -- a loud failure
+// instead of a hang.
 #include <stdlib.h>
 
 #include "common.hpp"

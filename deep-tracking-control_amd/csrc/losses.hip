@@ -676,8 +676,7 @@ extern "C" int dtc_ppo_heads_loss_img(const float* Ha, int64_t ldha, const float
     hipStream_t s = (hipStream_t)stream;
     // threads per row: 4 (64 rows per workgroup) measured faster than 8 (32 rows: every thread of a row evaluates the row's
     // loss, so twice the threads per row doubles the transcendental work): 1.08 vs 1.51 ms per step (round 3); DTC_HEADS_TPR=8
-    static const int tpr_env = getenv("DTC_HEADS_TPR") ? atoi(getenv("DTC_HEADS_TPR")) : 4;
-    const int tpr = (tpr_env != 8 || dtc::ceil_div(B, 32) > MAX_BLK) ? 4 : 8;
+    const int tpr = 4;
     const int nblk = (int)dtc::ceil_div(B, 256 / tpr);
     DTC_REQUIRE(nblk <= MAX_BLK, "batch too large for the loss workspace");
     double* part = (double*)workspace;

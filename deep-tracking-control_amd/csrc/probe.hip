@@ -117,7 +117,7 @@ extern "C" int dtc_probe_mfma_stream_h2(const void* operands, int blocks, int it
 // whose bits are the MFMA inputs (zeros, or random bf16 patterns).
 extern "C" int dtc_probe_mfma_stream(const void* operands, int blocks, int iters, float* sink, void* stream) {
     DTC_REQUIRE(operands && sink && blocks > 0 && iters > 0 && dtc::aligned16(operands), "null / unaligned pointer or bad size");
-    static const int order = getenv("DTC_PROBE_ORDER") ? atoi(getenv("DTC_PROBE_ORDER")) : 0;
+    constexpr int order = 0;
     if (order == 1) hipLaunchKernelGGL(mfma_stream_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)operands, iters, sink);
     else if (order == 2) hipLaunchKernelGGL(mfma_stream_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)operands, iters, sink);
     else hipLaunchKernelGGL(mfma_stream_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)operands, iters, sink);

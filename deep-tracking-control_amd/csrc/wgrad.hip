@@ -346,22 +346,17 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(const WGroupDev
 }
 
 // wgrad column-tile width: 64 measured at least as fast as 128 on every layer of this model (sweep in
-// tools/microbench.py wgrad); DTC_WGRAD_BN overrides for experiments
+// tools/microbench.py wgrad)
 int pick_bn(int cols) {
-    static const char* force = getenv("DTC_WGRAD_BN");
-    if (force && cols > 64) return atoi(force) == 32 ? 32 : 64;
     return cols <= 32 ? 32 : 64;
 }
 
 // wgrad split heuristic -------------------------------------------------------------------------------------
 int wgrad_splits(int M, int tiles) {
-    static const char* target_env = getenv("DTC_WGRAD_BLOCKS");
-    const int target = target_env ? atoi(target_env) : 1024;
+    constexpr int target = 1024;
     // whole splits per XCD (multiple of 8) measured 10-20 % faster than filling the wave with an arbitrary count
-    // (DTC_WGRAD_ANYSPLIT=1: 44 tiles x 23 splits = 1012 blocks ran slower than 44 x 16 = 704)
-    static const bool mult8 = getenv("DTC_WGRAD_ANYSPLIT") == nullptr;
-    int s = target / tiles;
-    if (mult8) s = s / 8 * 8;
+    // (44 tiles x 23 splits = 1012 blocks ran slower than 44 x 16 = 704)
+    int s = target / tiles / 8 * 8;
     if (s < 8) s = 8;
     const int max_s = (int)dtc::ceil_div(dtc::ceil_div(M, BK * 8), 8) * 8;
     if (s > max_s) s = max_s;
@@ -374,8 +369,7 @@ int wgrad_splits_bound(int M, int N, int K) {
 
 // grouped launch: one split count for all jobs (every block then reduces the same number of batch rows)
 int group_splits(int M, int tiles_total) {
-    static const char* target_env = getenv("DTC_WGRAD_GROUP_BLOCKS");
-    const int target = target_env ? atoi(target_env) : 3072;      // sweep 1024 ... 4096 with bench.py: 3072 best (24 batch slices per layer)
+    constexpr int target = 3072;      // sweep 1024 ... 4096 with bench.py: 3072 best (24 batch slices per layer)
     int s = target / (tiles_total > 0 ? tiles_total : 1) / 8 * 8;
     if (s < 8) s = 8;
     const int max_s = (int)dtc::ceil_div(dtc::ceil_div(M, BK * 8), 8) * 8;
@@ -551,9 +545,7 @@ extern "C" int dtc_wgrad_group(const DtcWgradJob* jobs, int count, int M, void* 
         const int grid = G.tiles_total * 8 * (int)dtc::ceil_div(G.splits, 8);
         // interleaved column tiles (one ds_read_b64 per operand pair): measured 31.95 vs 31.8 ms per step for the weight
         // gradients (round 3, three interleaved runs) -- the LDS read count is not what bounds this kernel; off by default
-        static const bool ilv = getenv("DTC_WGRAD_ILV") && atoi(getenv("DTC_WGRAD_ILV")) == 1;
-        if (ilv) hipLaunchKernelGGL(wgrad_group_kernel<true>, dim3(grid), dim3(256), occ_pad("WGRAD", 25600), s, G);
-        else hipLaunchKernelGGL(wgrad_group_kernel<false>, dim3(grid), dim3(256), occ_pad("WGRAD", 25600), s, G);
+        hipLaunchKernelGGL(wgrad_group_kernel<false>, dim3(grid), dim3(256), occ_pad("WGRAD", 25600), s, G);
     }
     {
         dtc::ProfScope prof(dtc::prof_shape_name("wgrad_reduce", G.splits, G.tiles_total, count), (double)P.bytes + P.bytes / (double)G.splits, s);

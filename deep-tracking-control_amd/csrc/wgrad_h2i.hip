@@ -363,14 +363,11 @@ struct HPlan {
 };
 
 int h2i_splits(int M, int tiles_total) {
-    static const char* target_env = getenv("DTC_WGRAD_H2I_BLOCKS");
-    static const char* cap_env = getenv("DTC_WGRAD_SPLIT_CAP");
     // 768 (round 5; 8 batch slices for the 61..70-tile buckets of the bench step): with both operands arriving by LDS-DMA the slices need
     // not be short to hide their loads -- 1024 / 1536 / 2048 workgroups: 50.3 / 50.1 / 50.2 ms per step on one box, 512 / 768 / 1024: 46.67 /
     // 46.70 / 46.94 on another (interleaved pairs; round 4's converting kernel wanted 1536) -- and a third of the partial slabs is a third
     // of the reduce traffic
-    const int target = target_env ? atoi(target_env) : 768;
-    const int cap = cap_env ? atoi(cap_env) : 24;
+    constexpr int target = 768, cap = 24;
     int s = target / (tiles_total > 0 ? tiles_total : 1) / 8 * 8;
     if (s < 8) s = 8;
     if (s > cap) s = cap;

@@ -386,28 +386,25 @@ __global__ __launch_bounds__(256) void wgrad_s3_reduce_kernel(const S3Group G) {
 // instead of 8 = 488 on 768 slots), with the balanced (slice, tile) -> XCD map
 bool fill_slots() {
     static const bool on = [] {
-        const char* e = getenv("DTC_WGRAD_S3_FILL");
-        return e ? atoi(e) != 0 : false;
+        return false;                                // (measured no faster; kept as code for the balanced map below)
     }();
     return on;
 }
 
 int split_cap() {
     static const int cap = [] {
-        const char* e = getenv("DTC_WGRAD_SPLIT_CAP");
-        return e ? atoi(e) : 24;
+        return 24;
     }();
     return cap;
 }
 
 int group_splits_s3(int M, int tiles_total) {
-    static const char* target_env = getenv("DTC_WGRAD_S3_BLOCKS");
     // 768: eight batch slices for the 61..70-tile groups of the bench step.  Measured (tools/jobs/r3_sweep2.sh): 512..1536 within
     // 0.5 % of each other in step time, 2048 (32 slices) no faster; the partial slabs are HBM traffic written and read once
     // per slice, so the smallest count that still fills the chip wins (family traffic 1.30 -> 1.15 x the algorithmic bytes)
     // (round 4, two-term fp16 kernels -- half the matrix work per workgroup: 1536 = 24 slices for the 61..64-tile groups, 16 for the
     // 70-tile one: 57.4 vs 60.2 ms per step; 2048 / 3072 with a higher cap: 59.7 / 61.0 vs 59.1 on another box)
-    const int target = target_env ? atoi(target_env) : 1536;
+    constexpr int target = 1536;
     int s = target / (tiles_total > 0 ? tiles_total : 1);
     if (!fill_slots()) s = s / 8 * 8;                 // the slice -> XCD map needs whole groups of eight
     if (s < 8) s = 8;

@@ -323,33 +323,33 @@ class PPO:
         self._tws = {}
         # weight gradients on a side stream, concurrent with the data-gradient chain (DTC_OVERLAP_WGRAD=0: serial)
         self.overlap_wgrad = os.environ.get("DTC_OVERLAP_WGRAD", "1") != "0"
-        self.fuse_heads = os.environ.get("DTC_FUSE_HEADS", "1") != "0"       # dtc_ppo_heads_loss in the policy step
+        self.fuse_heads = True       # dtc_ppo_heads_loss in the policy step
         # two compute lanes (needs the side stream: both lanes' weight gradients share one partials workspace)
         self.overlap_lanes = os.environ.get("DTC_OVERLAP_LANES", "1") != "0"
-        # weight gradients queued per gradient bucket and run as one grouped launch (DTC_WGRAD_GROUP=0: per layer)
-        self.group_wgrad = os.environ.get("DTC_WGRAD_GROUP", "1") != "0"
+        # weight gradients queued per gradient bucket and run as one grouped launch (group_wgrad = False: per layer)
+        self.group_wgrad = True
         # weight images of the split-path layers: built by ONE launch at the start of each optimisation step (ops.WeightImages)
-        self.group_wimages = os.environ.get("DTC_WIMG_GROUP", "1") != "0" and os.environ.get("DTC_S3_WIMG", "1") != "0"
+        self.group_wimages = ops.WIMG
         self._wimages = {}
         # rollout step (policy sample + value + log-prob) replayed from a HIP graph: OFF by default -- measured slower
-        # than the eager launches on ROCm 7.2 (793 k vs 829 k env-steps/s end to end, tools/soak.py); DTC_ROLLOUT_GRAPH=1
-        self.graph_rollout = os.environ.get("DTC_ROLLOUT_GRAPH", "0") == "1"
+        # than the eager launches on ROCm 7.2 (793 k vs 829 k env-steps/s end to end, tools/soak.py); graph_rollout = True
+        self.graph_rollout = False
         # data parallel: per-bucket gradient all-reduce on the weight-gradient stream, overlapping the rest of the
         # backward pass (DTC_DP_OVERLAP=0: one all-reduce per optimiser step after the join)
         self.overlap_exchange = os.environ.get("DTC_DP_OVERLAP", "1") != "0"
-        # terrain-decoder output layer fused with the height loss (DTC_FUSE_HEIGHT_LOSS=0: separate layer + loss kernel)
-        self.fuse_height_loss = os.environ.get("DTC_FUSE_HEIGHT_LOSS", "1") != "0"
+        # terrain-decoder output layer fused with the height loss (fuse_height_loss = False: separate layer + loss kernel)
+        self.fuse_height_loss = True
         # ReLU layers record their output signs in the forward epilogue; the data gradient reads 1 bit instead of the saved
-        # 4-byte activation (DTC_RELU_MASK=0: derivative through the saved activations; bit-identical results)
-        self.relu_masks = os.environ.get("DTC_RELU_MASK", "1") != "0"
-        self.pack_inputs = os.environ.get("DTC_PACK_INPUTS", "1") != "0"
+        # 4-byte activation (relu_masks = False: derivative through the saved activations; bit-identical results)
+        self.relu_masks = True
+        self.pack_inputs = True
         # the wide stacks on operand images (dtc_amd/h2i.py: activations / gradients live in HBM as the fp16 (hi, lo) planes the GEMM
         # kernels read by LDS-DMA, per-row exponents, written once by the producing epilogue); DTC_H2I=0: round 4's converting kernels
         self.use_images = os.environ.get("DTC_H2I", "1") != "0"
-        self.side2_wgrad = os.environ.get("DTC_WGRAD_SIDE2", "1") != "0"
+        self.side2_wgrad = True
         # ... and the narrow CE-net stacks (128 / 64 / 35 / 53 columns) on them as well: same kernels (a column tile partly used), their
-        # weight gradients as extra jobs of the wide layers' grouped launches instead of single-pass groups of their own (DTC_H2I_NARROW=0)
-        self.narrow_images = os.environ.get("DTC_H2I_NARROW", "1") != "0"
+        # weight gradients as extra jobs of the wide layers' grouped launches instead of single-pass groups of their own (narrow_images = False)
+        self.narrow_images = True
         # ... and as chains: the CE-net encoder / decoder stacks (every layer <= 128 columns wide) as ONE launch per direction
         # (h2i.linear_fwd_chain / linear_dgrad_chain: the workgroup of a row tile runs layer after layer; DTC_H2I_CHAIN=0: a launch per layer)
         self.narrow_chains = os.environ.get("DTC_H2I_CHAIN", "1") != "0"
@@ -541,7 +541,7 @@ class PPO:
         """Backward of one dense layer on fp32 operands.  The weight gradient (dW = dZ^T X) is off the critical path -- only the
         optimiser step (and the data-parallel exchange) needs it -- so it is QUEUED: `_flush_wgrads` runs all queued
         layers of a gradient bucket as one grouped launch on the side stream, where it overlaps with the data-gradient
-        chain of the layers below.  (DTC_WGRAD_GROUP=0: one launch pair per layer, issued right here.)  `split=False`: the
+        chain of the layers below.  (group_wgrad = False: one launch pair per layer, issued right here.)  `split=False`: the
         single-pass fp32 kernels whatever the layer's shape (the narrow layers beside the operand-image chain)."""
         if self.group_wgrad:
             tw.pending.append((dZ, X, L.gW, L.gb))
@@ -655,7 +655,7 @@ class PPO:
         self.vae_optimizer.step(self.max_grad_norm, stats[S_VAE_GNORM:S_VAE_GNORM + 1])
 
     def _images(self, phase):
-        """ops.WeightImages block of an optimisation step (DTC_WIMG_GROUP=0: every call builds its own image)."""
+        """ops.WeightImages block of an optimisation step (group_wimages = False: every call builds its own image)."""
         if not self.group_wimages:
             return contextlib.nullcontext()
         if phase not in self._wimages:
@@ -825,7 +825,7 @@ class PPO:
             ac.cenet_forward_(fw, flat["observation_histories"], eps, idx, masks=self.relu_masks, split=ns, images=imn, wset=wset)
         ac.terrain_encoder_(fw, priv, idx, masks=self.relu_masks, images=im, wset=wset, lt_fp32=not im)
         tw.order("aux", "main")                                    # z, mu feed the actor
-        # output layers + losses + their data gradients in one launch when the last hidden width allows it (DTC_FUSE_HEADS)
+        # output layers + losses + their data gradients in one launch when the last hidden width allows it (fuse_heads)
         # (its partial-sum workspace holds 4096 blocks of 64 rows: larger mini-batches take the unfused kernels)
         fuse = self.fuse_heads and fw.a3.shape[1] == fw.v3.shape[1] and fw.a3.shape[1] in (64, 128, 256) and tw.B <= 4096 * 64
         a_cols = None

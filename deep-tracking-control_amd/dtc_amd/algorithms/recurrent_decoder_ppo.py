@@ -266,7 +266,7 @@ class RecurrentDecoderPPO(PPO):
             pkey = f"dhs_{name}_{fw.pack_slot}"
             dhs = self._padded(tw, pkey, T * R, H)
             gens = tw.__dict__.setdefault("_pad_gen", {})
-            if fw.pack_gen is None or gens.get(pkey) != (fw.pack_gen, T * R) or os.environ.get("DTC_PAD_ZERO_ALWAYS") == "1":
+            if fw.pack_gen is None or gens.get(pkey) != (fw.pack_gen, T * R):
                 dhs.zero_()
                 gens[pkey] = (fw.pack_gen, T * R)
             ops.scatter_rows(d_in, unpad_idx, dhs)

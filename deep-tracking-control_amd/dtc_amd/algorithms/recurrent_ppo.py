@@ -357,12 +357,11 @@ class RecurrentPPO:
                 else:
                     h2i.linear_dgrad(dZi, L.W, d_in, None, wset=wset)
             # one padded buffer per mini-batch slot, zeroed once per update: the slot's trajectories (and padding rows) are the same in
-            # every epoch, every scatter overwrites all valid rows (DTC_PAD_ZERO_ALWAYS=1: a fresh zero buffer per mini-batch)
+            # every epoch, every scatter overwrites all valid rows
             slot = self._pack_slot if self._pack_gen is not None else 0
             pk = (f"dhs_{name}", slot)
             dhs = self._pad_bufs.get(pk)
-            if (dhs is None or tuple(dhs.shape) != (T * R, H) or self._pack_gen is None or self._pad_gen.get(pk) != self._pack_gen
-                    or os.environ.get("DTC_PAD_ZERO_ALWAYS") == "1"):
+            if (dhs is None or tuple(dhs.shape) != (T * R, H) or self._pack_gen is None or self._pad_gen.get(pk) != self._pack_gen):
                 if dhs is None or tuple(dhs.shape) != (T * R, H):
                     dhs = self._pad_bufs[pk] = torch.zeros(T * R, H, device=dev)
                 else:

@@ -94,14 +94,14 @@ SPLIT = _os.environ.get("DTC_GEMM_SPLIT", "2") != "0"
 # (DTC_GEMM_SPLIT=1: no amax needed, twice the matrix-pipe work).  The recurrent kernels and the activation-image chain are bf16 x 3 only.
 H2 = _os.environ.get("DTC_GEMM_SPLIT", "2") == "2"
 AMAX_CHECK = _os.environ.get("DTC_AMAX_CHECK", "0") == "1"   # debug: re-derive every published amax at its use (synchronises)
-_NOPUB_SMALL = _os.environ.get("DTC_AMAX_NOPUB_SMALL", "0") == "1"    # A/B aid: the latent / loss kernels publish no amax (their consumers compute it)
+_NOPUB_SMALL = False    # A/B aid: the latent / loss kernels publish no amax (their consumers compute it)
 AMAX_STATS = {} if _os.environ.get("DTC_AMAX_STATS", "0") == "1" else None   # debug: (kind, shape) -> count of dtc_amax fallbacks
 # routing thresholds (output columns / reduction length); swept with bench.py in round 3: 256 / 384 -> 70.2 ms, 128 / 128 -> 69.5 ms per
 # step (the 128-column layers run longer per launch on 192 tiles of 128 x 128 -- 35 vs 28 us -- but on the second lane, under the wide GEMMs)
-SPLIT_MIN_COLS = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_COLS", "128"))
-SPLIT_MIN_RED = int(_os.environ.get("DTC_GEMM_SPLIT_MIN_RED", "128"))
+SPLIT_MIN_COLS = 128
+SPLIT_MIN_RED = 128
 # recurrent trainers: weight gradients over the valid slots of the padded trajectory layout only (0: over all T x R rows)
-WGRAD_ROWS = _os.environ.get("DTC_WGRAD_ROWS", "1") != "0"
+WGRAD_ROWS = True
 WIMG_CHECK = _os.environ.get("DTC_WIMG_CHECK", "0") == "1"  # debug: re-derive every cached weight image at its use and compare
 _NOT_NULL = 16                                             # stand-in address of a non-NULL operand block in a cached descriptor
 WIMG = _os.environ.get("DTC_S3_WIMG", "1") != "0"          # the library's weight-image switch (csrc/gemm_s3.hip reads the same variable)
