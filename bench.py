@@ -308,6 +308,8 @@ def main():
                          "(GRU + CE-net + foothold obs, build-defined); gru = configs[2] (ActorCriticRecurrent, GRU 512, BPTT); "
                          "both on the same rollout shapes -- informative only.  Default from DTC_BENCH_WORKLOAD (a driver that "
                          "cannot pass flags selects configs[4]'s model with DTC_BENCH_WORKLOAD=composite)")
+    ap.add_argument("--detail", default=os.environ.get("DTC_BENCH_DETAIL"), help="where the full record (everything the result line leaves "
+                    "out) goes; default gpurun_out/bench_detail.json")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the CPU port on the WHOLE workload (no GPU work) and exit")
     a = ap.parse_args()
     if a.cpu_baseline_full:
@@ -869,7 +871,7 @@ def run(a, rank, local_rank, world, wd):
                 ops.set_split(True)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        emit_line(compact_line(line, write_detail(line)))
+        emit_line(compact_line(line, write_detail(line, a.detail)))
     if world > 1:
         phase("teardown", 60)
         dist.barrier()

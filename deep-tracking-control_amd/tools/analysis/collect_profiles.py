@@ -24,7 +24,15 @@ dst = "profiles"
 
 
 def last_json(path):
-    return json.loads(open(path).read().strip().splitlines()[-1])
+    """The result line of a bench run, merged over the full record bench.py wrote beside it (round 6: the line is short, the tables --
+    kernel classes, traffic per kernel, in-situ accuracy -- live in `<name>_detail.json`)."""
+    line = json.loads(open(path).read().strip().splitlines()[-1])
+    det = path.replace(".json", "_detail.json")
+    if os.path.exists(det):
+        full = json.load(open(det))
+        full.update({k: v for k, v in line.items() if k not in full})
+        return full
+    return line
 
 
 def short(name):
@@ -46,7 +54,7 @@ for name in (f"{tag}_gemm_pmc.md", f"{tag}_gemm_pmc_fp32mfma.md", f"{tag}_split_
 
 # ---- per-shape table
 p = f"{src}/{tag}_bench_shapes.json"
-if os.path.exists(p):
+if os.path.exists(p) and "kernel_classes" in last_json(p):
     s = last_json(p)
     rows = sorted(((v["ms"], k, v["launches"], v["rate"]) for k, v in s["kernel_classes"].items()), reverse=True)
     tot = sum(r[0] for r in rows)

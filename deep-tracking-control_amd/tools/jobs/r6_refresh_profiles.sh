@@ -6,13 +6,11 @@ O=gpurun_out/r6q
 mkdir -p $O
 R=$PWD
 T=deep-tracking-control_amd/tools
-timeout 1800 python bench.py > $O/r06_bench_n1.json 2> $O/r06_bench_n1.err; tail -1 $O/r06_bench_n1.err; cut -c1-300 $O/r06_bench_n1.json
-cp gpurun_out/bench_detail.json $O/r06_bench_detail.json
-timeout 1800 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r06_bench_driver_command.json 2> $O/driver_command.err; cut -c1-200 $O/r06_bench_driver_command.json
-cp gpurun_out/bench_detail.json $O/r06_bench_driver_command_detail.json
-DTC_H2I=0 timeout 900 python bench.py --no-cpu-baseline --no-traffic > $O/r06_bench_converting.json 2> $O/converting.err
-DTC_GEMM_SPLIT=0 timeout 900 python bench.py --no-cpu-baseline --no-traffic > $O/r06_bench_fp32mfma.json 2> $O/fp32mfma.err
-DTC_PROF_SHAPES=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-in-situ > $O/r06_bench_shapes.json 2> $O/shapes.err
+timeout 1800 python bench.py --detail $R/$O/r06_bench_n1_detail.json > $O/r06_bench_n1.json 2> $O/r06_bench_n1.err; tail -1 $O/r06_bench_n1.err; cut -c1-300 $O/r06_bench_n1.json
+timeout 1800 python bench.py --gpus 1 --steps 20 --warmup 5 --detail $R/$O/r06_bench_driver_command_detail.json > $O/r06_bench_driver_command.json 2> $O/driver_command.err; cut -c1-200 $O/r06_bench_driver_command.json
+DTC_H2I=0 timeout 900 python bench.py --no-cpu-baseline --no-traffic --detail $R/$O/r06_bench_converting_detail.json > $O/r06_bench_converting.json 2> $O/converting.err
+DTC_GEMM_SPLIT=0 timeout 900 python bench.py --no-cpu-baseline --no-traffic --detail $R/$O/r06_bench_fp32mfma_detail.json > $O/r06_bench_fp32mfma.json 2> $O/fp32mfma.err
+DTC_PROF_SHAPES=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-in-situ --detail $R/$O/r06_bench_shapes_detail.json > $O/r06_bench_shapes.json 2> $O/shapes.err
 timeout 900 python $T/analysis/gemm_pmc.py collect $O/pmc_split > $O/r06_gemm_pmc.md 2> $O/gemm_pmc.err
 python $T/h2i_trace.py 512 512 2>/dev/null > $O/r06_h2i_timeline.txt
 python $T/h2i_trace.py 256 512 2>/dev/null >> $O/r06_h2i_timeline.txt
@@ -50,7 +48,7 @@ for k in sorted(tot):
 if dur:
     print(f'\nkernel duration over {len(dur)} launches: mean {sum(dur)/len(dur)/1e3:.1f} us, min {min(dur)/1e3:.1f} us')
     f, w = tot.get('FETCH_SIZE', 0) / max(1, len(dur) / 3), tot.get('WRITE_SIZE', 0) / max(1, len(dur) / 3)
-    print(f'HBM-side bytes per launch: FETCH_SIZE x 64 B x 2 (gfx950 wide-load correction) + WRITE_SIZE x 64 B = {(2 * f + w) * 64 / 1e6:.1f} MB; algorithmic 3096 B x 98304 = 304.3 MB')
+    print(f'HBM-side bytes per launch: FETCH_SIZE x 64 B x 2 (gfx950 wide-load correction) + WRITE_SIZE x 64 B = {(2 * f + w) * 1024 / 1e6:.1f} MB (counters in KB); algorithmic 3096 B x 98304 = 304.3 MB')
     v, wc = tot.get('SQ_ACTIVE_INST_VALU', 0), tot.get('SQ_BUSY_CYCLES', 0)
     d4 = []
     for f in glob.glob('gpurun_out/r6q/kt_sc4096/**/*kernel_trace.csv', recursive=True):
@@ -66,7 +64,7 @@ if dur:
     print(f'SQ_INSTS_VALU per env {tot.get("SQ_INSTS_VALU", 0) / max(1, len(dur) / 3) / 98304 * 64 / 64:.0f} wave-instructions x 1/64; SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = {v / max(1.0, wc):.2f}')
 PY
 for w in gru composite; do
-timeout 600 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > $O/r06_bench_$w.json 2>/dev/null
+timeout 600 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --detail $R/$O/r06_bench_${w}_detail.json > $O/r06_bench_$w.json 2>/dev/null
 done
 timeout 600 python -m pytest tests/test_hip_h2i.py -m gpu -q -s 2>&1 | grep -E "err |timing|passed|failed" > $O/r06_h2i_accuracy.log
 rm -rf $O/pmc_split $O/pmc_sc_* $O/kt_sc4096 $O/rp_serial/*/*trace* $O/rp_overlap/*/*trace* 2>/dev/null
