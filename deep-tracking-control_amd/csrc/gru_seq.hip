@@ -39,7 +39,8 @@ typedef unsigned long long u64;
 constexpr int UT = 16;                  // hidden units per workgroup
 constexpr int GC = 3 * UT;              // gate columns per workgroup
 constexpr int EH = 14;                  // h is stored times 2^14 (|h| <= 1: hi < 2^15)
-constexpr int MAX_RB_ROWS = 256;        // 8 waves per workgroup (256 VGPRs each: the row operand's loads run 5 K steps ahead)
+constexpr int MAX_RB_ROWS = 256;        // exclusive launches: 8 waves per workgroup (256 VGPRs each: the row operand's loads run 4 K steps ahead)
+constexpr int MAX_RB_ROWS_HALF = 384;   // half-chip launches: 12 waves per workgroup (170 VGPRs each: loads 2 K steps ahead)
 constexpr int MAX_NRB = 8;              // 8 x (H / 16) = 256 workgroups at most: one per CU
 
 struct SeqFwd {
@@ -113,11 +114,11 @@ struct SeqFwdPair {
 };
 
 // `count` recurrences of one shape, one after the other (the actor's and the critic's memory: dtc_gru_fwd_multi)
-template <int H>
-__global__ __launch_bounds__(512) void gru_seq_fwd_kernel(const SeqFwdPair P) {
+template <int H, int MAXT, int PFC>
+__global__ __launch_bounds__(MAXT) void gru_seq_fwd_kernel(const SeqFwdPair P) {
     constexpr int WROW = 2 * H + 32;                  // bytes of one LDS row of a plane (+32: the 16 lanes of a read group hit 64 different banks)
     constexpr int KS = H / 32;                        // K steps of a time step
-    constexpr int PF = 5;                             // register sets of the h operand: its loads run 4 K steps ahead of the MFMAs
+    constexpr int PF = PFC;                           // register sets of the h operand: its loads run PF - 1 K steps ahead of the MFMAs
     __shared__ __attribute__((aligned(16))) unsigned char Wl[2][GC][WROW];
     __shared__ float red[16];
     __shared__ __attribute__((aligned(16))) float bl[3][UT];
@@ -337,7 +338,7 @@ extern "C" int dtc_gru_seq_status(int reset) {
 // bytes the persistent kernels need behind the per-step regions of a dtc_gru_workspace() buffer
 extern "C" int64_t dtc_gru_seq_workspace(int R, int H) {
     if (R <= 0 || H <= 0) return 0;
-    return 8ll * ((int64_t)R + MAX_RB_ROWS) * H + 256;
+    return 8ll * ((int64_t)R + 4 * MAX_RB_ROWS_HALF) * H + 256;
 }
 
 // The geometry of a launch: (row blocks, rows per block), or false when the shape is not served.  `exclusive`: the launch may take every
@@ -349,7 +350,7 @@ static bool seq_geometry(int T, int R, int H, bool exclusive, int& nrb, int& rbr
     nrb = (R + 31) / 32;
     nrb = nrb > max_nrb ? max_nrb : nrb;
     rbrows = (((R + nrb - 1) / nrb) + 31) / 32 * 32;
-    return rbrows <= MAX_RB_ROWS;
+    return rbrows <= (exclusive ? MAX_RB_ROWS : MAX_RB_ROWS_HALF);
 }
 extern "C" int dtc_gru_seq_supported(int T, int R, int H, int exclusive) {
     int nrb, rbrows;
@@ -374,7 +375,10 @@ static int seq_launch(SeqFwdPair& P, int nrb, int rbrows, int T, int R, int H, h
         }
     }
     dtc::ProfScope prof("gru_seq_fwd", P.count * 2.0 * T * (double)R * 3.0 * H * H, s);
-    hipLaunchKernelGGL(gru_seq_fwd_kernel<512>, dim3((unsigned)(nrb * (H / UT))), dim3((unsigned)(rbrows / 32 * 64)), 0, s, P);
+    if (rbrows <= MAX_RB_ROWS)
+        hipLaunchKernelGGL((gru_seq_fwd_kernel<512, 512, 5>), dim3((unsigned)(nrb * (H / UT))), dim3((unsigned)(rbrows / 32 * 64)), 0, s, P);
+    else
+        hipLaunchKernelGGL((gru_seq_fwd_kernel<512, 768, 3>), dim3((unsigned)(nrb * (H / UT))), dim3((unsigned)(rbrows / 32 * 64)), 0, s, P);
     return dtc::check_launch("gru_seq_fwd");
 }
 

@@ -11,6 +11,7 @@ from dtc_amd import _ffi, ops  # noqa: E402
 DEV = "cuda:0"
 T, R, H = 24, int(os.environ.get("TRACE_R", "1500")), 512
 lib = _ffi.lib()
+lib.dtc_set_gru_seq(1)
 g = torch.Generator(device=DEV).manual_seed(11)
 rn = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
 ins = [(rn(T, R, 3 * H), 0.5 * rn(R, H), rn(3 * H, H) / H ** 0.5, 0.2 * rn(3 * H)) for _ in range(2)]
@@ -27,6 +28,37 @@ def launch(i):
 def launch_pair():
     ops.gru_fwd_multi([(i_[0], i_[1], i_[2], i_[3], o_[0], o_[1], o_[2], o_[3]) for i_, o_ in zip(ins, outs)])
 
+
+def two_streams():
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    launch(0)
+    with torch.cuda.stream(s2):
+        launch(1)
+    torch.cuda.current_stream().wait_stream(s2)
+
+
+for _ in range(3):
+    two_streams()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    two_streams()
+e1.record()
+torch.cuda.synchronize()
+print(f"two single-recurrence launches on two streams (R = {R}): {e0.elapsed_time(e1) / 5 * 1e3:.0f} us per pair = {e0.elapsed_time(e1) / 5 / T * 1e3:.1f} us per step-pair")
+lib.dtc_set_gru_seq(0)
+for _ in range(3):
+    two_streams()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(5):
+    two_streams()
+e1.record()
+torch.cuda.synchronize()
+print(f"the same with the per-step launches: {e0.elapsed_time(e1) / 5 * 1e3:.0f} us per pair = {e0.elapsed_time(e1) / 5 / T * 1e3:.1f} us per step-pair")
+lib.dtc_set_gru_seq(1)
 
 for pair in (False, True):
     for _ in range(3):

@@ -209,12 +209,12 @@ def test_persistent_recurrence_vs_fp64_and_the_per_step_launches(T, R):
 
 
 def test_two_persistent_recurrences_on_two_streams_meet():
-    """Two single-recurrence persistent launches (dtc_gru_fwd) on two streams at the largest size they serve (1024 rows: 4 row blocks x 32
-    unit tiles = 128 workgroups of one per CU each) -- both fit the chip at once, neither starves the other's barriers.  Results equal the
+    """Two single-recurrence persistent launches (dtc_gru_fwd) on two streams at the largest size they serve (1536 rows: 4 row blocks of
+    384 rows x 32 unit tiles = 128 workgroups of one per CU each) -- both fit the chip at once, neither starves the other's barriers.  Results equal the
     launches run one after the other bit for bit; the status flag stays clear."""
     from dtc_amd import _ffi, ops
     lib = _ffi.lib()
-    T, R, H = 24, 1024, 512
+    T, R, H = 24, 1536, 512
     lib.dtc_set_gru_seq(1)
     try:
         assert lib.dtc_gru_seq_supported(T, R, H, 0) == 1 and lib.dtc_gru_seq_supported(T, R + 1, H, 0) == 0
