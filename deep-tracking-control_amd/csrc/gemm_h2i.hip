@@ -850,13 +850,15 @@ __global__ __launch_bounds__(256, 3) void linear_h2i_kernel(const TileArgs L_, c
 // stores ordered by the workgroup barrier between the layers; the rows of other tiles are never touched).  The narrow stacks of the
 // CE-net (encoder 265 -> 128 -> 64 -> 35, decoder 531 -> 64 -> 128 -> 53: actor_critic_decoder.py:98-142) as one launch per direction
 // instead of three (two) latency-bound ones; every intermediate still reaches HBM as an image (the weight gradients read it).
-constexpr int CHAIN_MAX = 3;
+constexpr int CHAIN_MAX = 3, CHAIN_MAX_COLS = 512;
 struct ChainArgs {
     int count;
     TileArgs layer[CHAIN_MAX];
 };
+// (128-row tiles -- M > 32768 rows only -- at two workgroups per CU: the column-tile loops around three inlined tile bodies do not fit 168
+// registers; the 64-row form every size of this project takes keeps three)
 template <int EPI, int TM>
-__global__ __launch_bounds__(256, 3) void chain_h2i_kernel(const ChainArgs C_, unsigned long long* __restrict__ trace) {
+__global__ __launch_bounds__(256, TM == 2 ? 2 : 3) void chain_h2i_kernel(const ChainArgs C_, unsigned long long* __restrict__ trace) {
 #ifdef __HIP_DEVICE_COMPILE__
     typedef const AS4 ChainArgs CChainArgs;
     CChainArgs& C = *(CChainArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -865,14 +867,25 @@ __global__ __launch_bounds__(256, 3) void chain_h2i_kernel(const ChainArgs C_, u
     int tr, tc;
     if (!map_tile(blockIdx.x, (C.layer[0].M + 64 * TM - 1) / (64 * TM), 1, tr, tc)) return;
     const MseEpiH none{};
-    h2i_tile<EPI, TM>(C.layer[0], none, tr, 0, (int)blockIdx.x, nullptr);
+    // (round 6) a layer may be up to CHAIN_MAX_COLS columns wide: the workgroup runs its column tiles one after the other -- the actor's and
+    // the critic's tails 512 -> 256 -> 128 (actor_critic_decoder.py:323-349) forward, 128 -> 256 -> 512 backward
+    for (int tc0 = 0; tc0 < (C.layer[0].N + 127) / 128; ++tc0) {
+            if (tc0 > 0) __syncthreads();        // (the previous tile's epilogue still uses the stage buffers as its patches)
+            h2i_tile<EPI, TM>(C.layer[0], none, tr, tc0, (int)blockIdx.x, nullptr);
+        }
     if (C.count > 1) {
         __syncthreads();                    // (workgroup-scope release / acquire: this tile's image rows and exponents are visible to all its waves)
-        h2i_tile<EPI, TM>(C.layer[1], none, tr, 0, (int)blockIdx.x, nullptr);
+        for (int tc1 = 0; tc1 < (C.layer[1].N + 127) / 128; ++tc1) {
+            if (tc1 > 0) __syncthreads();        // (the previous tile's epilogue still uses the stage buffers as its patches)
+            h2i_tile<EPI, TM>(C.layer[1], none, tr, tc1, (int)blockIdx.x, nullptr);
+        }
     }
     if (C.count > 2) {
         __syncthreads();
-        h2i_tile<EPI, TM>(C.layer[2], none, tr, 0, (int)blockIdx.x, nullptr);
+        for (int tc2 = 0; tc2 < (C.layer[2].N + 127) / 128; ++tc2) {
+            if (tc2 > 0) __syncthreads();        // (the previous tile's epilogue still uses the stage buffers as its patches)
+            h2i_tile<EPI, TM>(C.layer[2], none, tr, tc2, (int)blockIdx.x, nullptr);
+        }
     }
 #endif
 }
@@ -1262,7 +1275,7 @@ extern "C" int dtc_linear_fwd_chain_h2i(const DtcH2iFwdLayer* layers, int count,
     LayerInfo L[CHAIN_MAX];
     for (int i = 0; i < count; ++i) {
         const DtcH2iFwdLayer& h = layers[i];
-        DTC_REQUIRE(h.N >= 1 && h.N <= 128, "chain layer %d: %d output columns (1..128: one column tile)", i, h.N);
+        DTC_REQUIRE(h.N >= 1 && h.N <= CHAIN_MAX_COLS, "chain layer %d: %d output columns (1..%d)", i, h.N, CHAIN_MAX_COLS);
         if (i > 0) DTC_REQUIRE(h.X.nseg == 1 && h.X.img[0] == layers[i - 1].Yimg && layers[i - 1].Yimg != nullptr && h.X.width[0] == layers[i - 1].N,
                                "chain layer %d must read the image result of layer %d", i, i - 1);
         int rc = fwd_args(&h.X, h.wimg, h.b, h.Y, h.ldy, h.Yimg, h.relu_mask, M, h.N, h.act, L[i]);
@@ -1278,7 +1291,7 @@ extern "C" int dtc_linear_dgrad_chain_h2i(const DtcH2iDgradLayer* layers, int co
     LayerInfo L[CHAIN_MAX];
     for (int i = 0; i < count; ++i) {
         const DtcH2iDgradLayer& h = layers[i];
-        DTC_REQUIRE(h.Kwin >= 1 && h.Kwin <= 128, "chain layer %d: window of %d columns (1..128: one column tile)", i, h.Kwin);
+        DTC_REQUIRE(h.Kwin >= 1 && h.Kwin <= CHAIN_MAX_COLS, "chain layer %d: window of %d columns (1..%d)", i, h.Kwin, CHAIN_MAX_COLS);
         if (i > 0) {
             const DtcH2iDgradLayer& p = layers[i - 1];
             DTC_REQUIRE(p.dXimg != nullptr && h.dZimg == p.dXimg && h.N == (p.img_cols ? p.img_cols : p.Kwin),

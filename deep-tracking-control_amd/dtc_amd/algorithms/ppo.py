@@ -353,6 +353,7 @@ class PPO:
         # ... and as chains: the CE-net encoder / decoder stacks (every layer <= 128 columns wide) as ONE launch per direction
         # (h2i.linear_fwd_chain / linear_dgrad_chain: the workgroup of a row tile runs layer after layer; DTC_H2I_CHAIN=0: a launch per layer)
         self.narrow_chains = os.environ.get("DTC_H2I_CHAIN", "1") != "0"
+        self.tail_chains = False           # the actor's / critic's tails as chains too: built and measured slower (round 6)
         self._wsets = {}                   # phase -> h2i.WeightSet (weight images, one grouped launch per phase)
         # tests: callable(fw, which) run between the forward and the backward pass of a step ("vae" | "ppo"); the parity tests
         # use it to teacher-force the ReLU sign records (fw.relu_mask buffers) so that fp32 knife edges -- pre-activations that
@@ -915,9 +916,8 @@ class PPO:
                 G_c3 = tw.img("G_c3", n_c).pack(g_c3)
             g_c2i, g_c1i = tw.img("g_c2", L["c2"].n_in), tw.img("g_c1", L["c1"].n_in)
             self._bwd_img(tw, L["c2"], G_c3, fw.img("v2"))
-            h2i.linear_dgrad(G_c3, L["c2"].W, None, g_c2i, Xsaved=fw.v2, act=act, wset=wset)
             self._bwd_img(tw, L["c1"], g_c2i, fw.img("v1"))
-            h2i.linear_dgrad(g_c2i, L["c1"].W, None, g_c1i, Xsaved=fw.v1, act=act, wset=wset)
+            self._tail_dgrad(G_c3, L["c2"], g_c2i, fw.v2, L["c1"], g_c1i, fw.v1, act, wset)
             self._bwd_img(tw, L["c0"], g_c1i, Xc)
         # actor (main); layer-0 input gradient fans out to z, mu[:, :3] (fp32) and l_t (image); the observations need none
         if himg is not None:
@@ -928,9 +928,8 @@ class PPO:
             G_a3 = tw.img("G_a3", n_a).pack(g_a3)
         g_a2i, g_a1i = tw.img("g_a2", L["a2"].n_in), tw.img("g_a1", L["a1"].n_in)
         self._bwd_img(tw, L["a2"], G_a3, fw.img("a2"))
-        h2i.linear_dgrad(G_a3, L["a2"].W, None, g_a2i, Xsaved=fw.a2, act=act, wset=wset)
         self._bwd_img(tw, L["a1"], g_a2i, fw.img("a1"))
-        h2i.linear_dgrad(g_a2i, L["a1"].W, None, g_a1i, Xsaved=fw.a1, act=act, wset=wset)
+        self._tail_dgrad(G_a3, L["a2"], g_a2i, fw.a2, L["a1"], g_a1i, fw.a1, act, wset)
         nb = ac.num_obs + 19                                       # width of the narrow block [obs | z | mu[:, :3]]
         for i, (xi, c0) in enumerate(zip(Xa, a_cols)):             # columns of dW that meet l_t, then the narrow block(s)
             self._bwd_img(tw, L["a0"], g_a1i, xi, wcol0=c0, bias=i == 0)
@@ -938,6 +937,17 @@ class PPO:
         h2i.linear_dgrad(g_a1i, L["a0"].W, segmat([seg(None, 0, 512), seg(tw.dz, 0, 16), seg(tw.dmulv, 0, 3)]), tw.img("dlt", 512),
                          window=[(nb, 512), (ac.num_obs, 19)], wset=wset)
         tw.live_img |= {"dlt", "g_a2", "g_a1", "g_c2", "g_c1"}
+
+    def _tail_dgrad(self, G3, L2, g2i, x2, L1, g1i, x1, act, wset):
+        """Data gradients of a body's tail 128 -> 256 -> 512 (actor_critic_decoder.py:323-349 backward): ONE launch -- the workgroup of a
+        row tile runs the two column tiles of the 256-wide gradient, then the four of the 512-wide one (round 6; bit-identical) -- measured
+        slower than a launch per layer (see modules/actor_critic_decoder.py: TAIL_CHAINS), so `tail_chains` is False."""
+        chain = [dict(dZimg=G3, W=L2.W, dXimg=g2i, Xsaved=x2, act=act), dict(dZimg=g2i, W=L1.W, dXimg=g1i, Xsaved=x1, act=act)]
+        if self.tail_chains:
+            h2i.linear_dgrad_chain(chain, wset=wset)
+        else:
+            for c in chain:
+                h2i.linear_dgrad(c["dZimg"], c["W"], None, c["dXimg"], Xsaved=c["Xsaved"], act=c["act"], wset=wset)
 
     def _adaptive(self):
         return self.desired_kl is not None and self.schedule == 'adaptive'

@@ -232,7 +232,8 @@ def linear_fwd(X, W, b, Y=None, Yimg=None, act=None, mask=None, wset=None, cols=
 
 
 def linear_fwd_chain(layers, wset=None):
-    """Up to three forward layers of at most 128 output columns each in ONE launch (dtc_linear_fwd_chain_h2i): `layers` = list of dicts
+    """Up to three forward layers of at most 512 output columns each (round 6: several column tiles per layer, run one after the other by the
+    row tile's workgroup) in ONE launch (dtc_linear_fwd_chain_h2i): `layers` = list of dicts
     with the keyword arguments of linear_fwd (X, W, b, Y, Yimg, act, mask, cols); layer i + 1's X must be layer i's Yimg.  Bit for bit
     the per-layer calls.  (A capture in flight takes the per-layer calls: it checks every product on its own.)"""
     if CAPTURE is not None or len(layers) == 1:
@@ -258,7 +259,7 @@ def linear_fwd_chain(layers, wset=None):
 
 
 def linear_dgrad_chain(layers, wset=None):
-    """Up to three data-gradient layers whose windows are at most 128 columns wide in ONE launch (dtc_linear_dgrad_chain_h2i): `layers` =
+    """Up to three data-gradient layers whose windows are at most 512 columns wide in ONE launch (dtc_linear_dgrad_chain_h2i): `layers` =
     list of dicts with the arguments of linear_dgrad (dZimg, W, dX, dXimg, window (one range), add, Xsaved, act, mask); layer i + 1's
     dZimg must be layer i's dXimg.  Bit for bit the per-layer calls."""
     if CAPTURE is not None or len(layers) == 1:

@@ -24,6 +24,11 @@ import os
 from .. import _ffi, h2i, ops
 from .._ffi import seg, segmat
 
+# The actor's / critic's tails 512 -> 256 -> 128 as one launch per direction (round 6): built, bit-identical, and measured
+# SLOWER -- 50.2 vs ~49.0 ms per step on one box, two interleaved rounds (860 instead of 940 launches): a row tile's workgroup then runs 3
+# (forward) or 6 (backward) column tiles one after the other, 384 workgroups instead of 768 + 384, and the tails sit on the compute lanes
+# beside the weight-gradient stream, where the narrower launch is the worse neighbour.  Off; the kernels keep the capability (tested).
+TAIL_CHAINS = False
 NARROW_CHAINS = os.environ.get("DTC_H2I_CHAIN", "1") != "0"     # the CE-net encoder's three layers as one launch (see cenet_forward_)
 
 
@@ -457,9 +462,15 @@ class ActorCriticDecoder(nn.Module):
         if images:
             i0, i1 = ws.img(outs[0], l0.n_out), ws.img(outs[1], l1.n_out)
             h2i.linear_fwd(X, l0.W, l0.b, o0, i0, act, wset=wset, cols=cols)
-            h2i.linear_fwd(i0, l1.W, l1.b, o1, i1, act, wset=wset)
             # (last_img: the third activation as an image as well -- the X operand of the output layer's image-operand weight gradient)
-            h2i.linear_fwd(i1, l2.W, l2.b, o2, ws.img(outs[2], l2.n_out) if last_img else None, act, wset=wset)
+            i2 = ws.img(outs[2], l2.n_out) if last_img else None
+            if TAIL_CHAINS:        # the tail 512 -> 256 -> 128 as ONE launch: a row tile's workgroup runs both column tiles of the 256-wide
+                                   # layer, then the 128-wide one (round 6; bit for bit the two launches)
+                h2i.linear_fwd_chain([dict(X=i0, W=l1.W, b=l1.b, Y=o1, Yimg=i1, act=act), dict(X=i1, W=l2.W, b=l2.b, Y=o2, Yimg=i2, act=act)],
+                                     wset=wset)
+            else:
+                h2i.linear_fwd(i0, l1.W, l1.b, o1, i1, act, wset=wset)
+                h2i.linear_fwd(i1, l2.W, l2.b, o2, i2, act, wset=wset)
             return
         ops.linear_fwd(X, l0.W, l0.b, o0, act, M=ws.B)
         ops.linear_fwd(o0, l1.W, l1.b, o1, act)

@@ -350,7 +350,9 @@ typedef struct DtcH2iOperand {
 /* Y = act(X W^T + b) (actor_critic_decoder.py:98-131, 323-349); results: fp32 Y [M, >= N] (may be NULL) and / or Yimg = image(M, N) */
 int dtc_linear_fwd_h2i(const DtcH2iOperand* X, const void* wimg, const float* b, float* Y, int64_t ldy, void* Yimg, uint16_t* relu_mask,
                        int M, int N, int act, void* stream);
-/* Chains of narrow layers in ONE launch (csrc/gemm_h2i.hip: chain_h2i_kernel): up to three layers of at most 128 result columns each,
+/* Chains of narrow layers in ONE launch (csrc/gemm_h2i.hip: chain_h2i_kernel): up to three layers of at most 512 result columns each (round 6; a layer wider than
+ * 128 columns = several column tiles, run one after the other by the row tile's workgroup: the actor's / critic's tails 512 -> 256 -> 128,
+ * actor_critic_decoder.py:323-349, forward and backward),
  * layer i + 1 reading the image layer i wrote (the workgroup that owns a row tile runs the layers one after the other on it).  Same
  * arguments, same results bit for bit as the per-layer calls: the CE-net encoder 265 -> 128 -> 64 -> 35 / decoder 531 -> 64 -> 128 -> 53
  * (actor_critic_decoder.py:98-142) forward, and the data-gradient chains back through them. */

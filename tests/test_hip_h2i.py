@@ -473,3 +473,44 @@ def test_narrow_layer_chains_equal_the_per_layer_launches_bit_for_bit(M):
         bits = lambda t: t.view(torch.int64) if t.dtype == torch.float64 else t.view(torch.int32) if t.dtype == torch.float32 else t
         assert torch.equal(bits(x), bits(y)), i
     assert float(a[3].abs().max()) > 0 and float(a[8].abs().max()) > 0
+
+
+@pytest.mark.parametrize("M", [24576, 384, 200])
+def test_wide_layer_chains_equal_the_per_layer_launches_bit_for_bit(M):
+    """Round 6: a chain layer may be several column tiles wide -- the actor's / critic's tails (actor_critic_decoder.py:323-349) as ONE launch
+    per direction: forward 512 -> 256 -> 128 (ELU, fp32 + image outputs), backward 128 -> 256 -> 512 (ELU derivative through the saved fp32
+    activations).  Every output equals the per-layer launches bit for bit."""
+    from dtc_amd import h2i
+    g = torch.Generator().manual_seed(43)
+    dev = DEV
+    w = lambda n, k: (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
+    bias = lambda n: torch.randn(n, generator=g).to(dev)
+    x0 = h2i.HImage.from_tensor(_rows(M, 512, g, span=3).to(dev))
+    W1, b1, W2, b2 = w(256, 512), bias(256), w(128, 256), bias(128)
+    G3 = h2i.HImage.from_tensor(_rows(M, 128, torch.Generator().manual_seed(7), span=5, zero_frac=0.1).to(dev))
+
+    def run(chain):
+        o1, o2 = torch.zeros(M, 256, device=dev), torch.zeros(M, 128, device=dev)
+        i1, i2 = h2i.HImage(M, 256, dev), h2i.HImage(M, 128, dev)
+        fwd = [dict(X=x0, W=W1, b=b1, Y=o1, Yimg=i1, act="elu"), dict(X=i1, W=W2, b=b2, Y=o2, Yimg=i2, act="elu")]
+        g2, g1 = h2i.HImage(M, 256, dev), h2i.HImage(M, 512, dev)
+        x1 = torch.nn.functional.elu(torch.randn(M, 512, generator=torch.Generator().manual_seed(9))).to(dev)     # saved activation of the 512-wide layer
+        if chain:
+            h2i.linear_fwd_chain(fwd)
+        else:
+            for L in fwd:
+                h2i.linear_fwd(L["X"], L["W"], L["b"], L["Y"], L["Yimg"], L["act"])
+        bwd = [dict(dZimg=G3, W=W2, dXimg=g2, Xsaved=o1, act="elu"), dict(dZimg=g2, W=W1, dXimg=g1, Xsaved=x1, act="elu")]
+        if chain:
+            h2i.linear_dgrad_chain(bwd)
+        else:
+            for L in bwd:
+                h2i.linear_dgrad(L["dZimg"], L["W"], None, L["dXimg"], Xsaved=L["Xsaved"], act=L["act"])
+        torch.cuda.synchronize()
+        return [t.clone() for t in (o1, o2, i1.buf, i2.buf, g2.buf, g1.buf)]
+
+    a, b = run(True), run(False)
+    for i, (x, y) in enumerate(zip(a, b)):
+        bits = lambda t: t.view(torch.int64) if t.dtype == torch.float64 else t.view(torch.int32)
+        assert torch.equal(bits(x), bits(y)), i
+    assert float(a[1].abs().max()) > 0 and float(h2i.HImage(M, 512, dev).buf.abs().max()) >= 0
