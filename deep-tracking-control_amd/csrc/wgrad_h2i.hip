@@ -174,11 +174,14 @@ __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G)
         t_cur = Tt[0][0];
         tz_cur = Tt[0][1];
     }
+    int bias_phase = 0;
+    const int col_tiles_u = __builtin_amdgcn_readfirstlane(J.col_tiles);
     auto stage = [&](auto bc, int kt) {
         constexpr int buf = decltype(bc)::value;
         if (kt >= KT) return;                                 // (uniform) the trip's spare stages: nothing to add (and no scale table behind them)
         const int mb = m_begin + kt * BK, which = (kt >> 3) & 1, ph = kt & 7, srow = ph * 16;
-        const bool bias = want_bias && (kt % J.col_tiles) == tc;
+        const bool bias = want_bias && bias_phase == tc;      // bias_phase == kt % col_tiles, kept incrementally (a division per stage otherwise)
+        bias_phase = bias_phase + 1 == col_tiles_u ? 0 : bias_phase + 1;
         const bool more = kt + (8 - ph) < KT;                 // another block follows this one
         // everything that touches the small LDS tables sits in front of the LDS-DMA (behind it the compiler waits for the transfer)
         if (ph == 0 && kt > 0) {                              // (uniform) first stage of a block: the accumulators change scale
