@@ -25,8 +25,10 @@ for k in range(2):                       # two teacher-forced mini-batches: scal
 print("RESULT " + json.dumps(dict(ok=True, lr=alg.learning_rate)))
 '''
 
-CASES = [dict(DTC_H2I="0"), dict(DTC_GEMM_SPLIT="0"), dict(DTC_GEMM_SPLIT="1"), dict(DTC_H2I_CHAIN="0"), dict(DTC_OVERLAP_WGRAD="0"),
-         dict(DTC_OVERLAP_LANES="0"), dict(DTC_HEADS_UNROLL="0"), dict(DTC_LANE_PRIO="none"), dict(DTC_LANE_POOL="1"), dict(DTC_ROCTX="1")]
+# (all ten of them -- also DTC_OVERLAP_LANES=0, DTC_LANE_PRIO=none, DTC_LANE_POOL=1 alone -- passed in round 6; the suite keeps one
+# process per distinct code path: the stream switches share one case)
+CASES = [dict(DTC_H2I="0"), dict(DTC_GEMM_SPLIT="0"), dict(DTC_GEMM_SPLIT="1"), dict(DTC_H2I_CHAIN="0"),
+         dict(DTC_OVERLAP_WGRAD="0", DTC_OVERLAP_LANES="0"), dict(DTC_HEADS_UNROLL="0", DTC_LANE_PRIO="none", DTC_LANE_POOL="1", DTC_ROCTX="1")]
 
 
 @pytest.mark.parametrize("switch", CASES, ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
