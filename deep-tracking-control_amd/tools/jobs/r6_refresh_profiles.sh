@@ -48,7 +48,7 @@ for k in sorted(tot):
 if dur:
     print(f'\nkernel duration over {len(dur)} launches: mean {sum(dur)/len(dur)/1e3:.1f} us, min {min(dur)/1e3:.1f} us')
     f, w = tot.get('FETCH_SIZE', 0) / max(1, len(dur) / 3), tot.get('WRITE_SIZE', 0) / max(1, len(dur) / 3)
-    print(f'HBM-side bytes per launch: FETCH_SIZE x 64 B x 2 (gfx950 wide-load correction) + WRITE_SIZE x 64 B = {(2 * f + w) * 1024 / 1e6:.1f} MB (counters in KB); algorithmic 3096 B x 98304 = 304.3 MB')
+    print(f'HBM-side bytes per launch: FETCH_SIZE (KB) x 2 (gfx950 wide-load correction) + WRITE_SIZE (KB) = {(2 * f + w) * 1024 / 1e6:.1f} MB (counters in KB); algorithmic 3096 B x 98304 = 304.3 MB')
     v, wc = tot.get('SQ_ACTIVE_INST_VALU', 0), tot.get('SQ_BUSY_CYCLES', 0)
     d4 = []
     for f in glob.glob('gpurun_out/r6q/kt_sc4096/**/*kernel_trace.csv', recursive=True):
