@@ -12,9 +12,8 @@
 // that carry the block's weight, rows far below it lose low-order bits of products that are far below the sum), the accumulators hold
 // 2^T x the true sums and are rescaled by ONE scalar at the borders of the 128-row blocks.  The bias gradient is dZ^T x fb on the matrix
 // pipe, fb[m] = 2^(Tz - eZ[m]).  Per wave and stage: 4 LDS-DMA pieces, 16 transpose reads, 2 table reads, 16 v_pk_mul_f16, 12 MFMAs.
+// The stage loop is unrolled over three 128-row blocks (24 stages: the period of (position in the block, stage buffer)).
 // Partial slabs [batch slice][tile][128][128]; wgrad_h2i_reduce_kernel sums the slices in a fixed order.
-#include <stdlib.h>
-
 #include "h2i_core.hpp"
 
 namespace {
@@ -43,21 +42,6 @@ struct HGroup {
     HJob job[MAX_JOBS_H];
 };
 
-#ifndef DTC_WG_ABL
-#define DTC_WG_ABL 0      // timing ablations of tools/jobs/r6_wgrad_ablate.sh (1: no row factors, 2: no MFMA, 4: no fragment reads, 8: no transfers)
-#endif
-#ifndef DTC_WG_REQ
-#define DTC_WG_REQ 6
-#endif
-#ifndef DTC_WG_FB
-#define DTC_WG_FB 0
-#endif
-#ifndef DTC_WG_UNROLL
-#define DTC_WG_UNROLL 0
-#endif
-#ifndef DTC_WG_DMA
-#define DTC_WG_DMA 0      // where a stage issues the transfers of stage kt + 2: 0 head, 1 behind the fragment reads, 2 among the MFMAs, 3 behind them
-#endif
 __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G) {
     // separate objects per stage buffer: an LDS-DMA into one cannot alias the fragment reads of the other
     // (three stage buffers: the transfers run two stages ahead of the MFMAs, see linear_h2i_kernel)
@@ -103,24 +87,11 @@ __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G)
         const u32 ua = (u32)((mb >> 7) * J.st_n) * (u32)HI_CHUNK + (u32)(mb & 127) * 32u;
         const u32 ub = (u32)((mb >> 7) * J.st_k) * (u32)HI_CHUNK + (u32)(mb & 127) * 32u;
         const u32 dead = oob_mask(mb + mrow, m_end - 1);
-#if !(DTC_WG_ABL & 8)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, (lds_void*)&AS(nbuf)[p][wave * 1024], 16, aoff | dead, ua + p * HI_PLANE, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(bres, (lds_void*)&BS(nbuf)[p][wave * 1024], 16, boff | dead, ub + p * HI_PLANE, 0, 0);
         }
-#endif
-    };
-
-    // one of the four pieces of a stage (idx: plane = idx >> 1, operand = idx & 1), for the placements of DTC_WG_DMA
-    auto load_piece = [&](auto nbc, int mb, int idx) {
-        constexpr int nbuf = decltype(nbc)::value;
-        const u32 ua = (u32)((mb >> 7) * J.st_n) * (u32)HI_CHUNK + (u32)(mb & 127) * 32u;
-        const u32 ub = (u32)((mb >> 7) * J.st_k) * (u32)HI_CHUNK + (u32)(mb & 127) * 32u;
-        const u32 dead = oob_mask(mb + mrow, m_end - 1);
-        const int p = idx >> 1;
-        if (idx & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(bres, (lds_void*)&BS(nbuf)[p][wave * 1024], 16, boff | dead, ub + p * HI_PLANE, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, (lds_void*)&AS(nbuf)[p][wave * 1024], 16, aoff | dead, ua + p * HI_PLANE, 0, 0);
     };
 
     // ---- the scale tables of a 128-row block, built by threads < 128 (one batch row each) in three steps that ride on the stages of the
@@ -206,140 +177,10 @@ __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G)
     }
     int bias_phase = 0;
     const int col_tiles_u = __builtin_amdgcn_readfirstlane(J.col_tiles);
-    auto stage = [&](auto bc, int kt) {
-        constexpr int buf = decltype(bc)::value;
-        if (kt >= KT) return;                                 // (uniform) the trip's spare stages: nothing to add (and no scale table behind them)
-        const int mb = m_begin + kt * BK, which = (kt >> 3) & 1, ph = kt & 7, srow = ph * 16;
-        const bool bias = want_bias && bias_phase == tc;      // bias_phase == kt % col_tiles, kept incrementally (a division per stage otherwise)
-        bias_phase = bias_phase + 1 == col_tiles_u ? 0 : bias_phase + 1;
-        const bool more = kt + (8 - ph) < KT;                 // another block follows this one
-        // everything that touches the small LDS tables sits in front of the LDS-DMA (behind it the compiler waits for the transfer)
-        if (ph == 0 && kt > 0) {                              // (uniform) first stage of a block: the accumulators change scale
-            const int tn = Tt[which][0], tzn = Tt[which][1];
-            const int d = tn - t_cur, dz = tzn - tz_cur;
-            if (d != 0) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][jj][r] = __builtin_ldexpf(acc[i][jj][r], d);
-            }
-            if (dz != 0) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) accb[i][r] = __builtin_ldexpf(accb[i][r], dz);
-            }
-            t_cur = tn;
-            tz_cur = tzn;
-        }
-        if (ph == 7 && more) table_finish(which ^ 1, t_cur, tz_cur);
-        if (ph == DTC_WG_REQ && more) table_request(mb + (8 - DTC_WG_REQ) * BK);      // consumed by table_minima() at the end of phase 6
-        const f16x8 fv = *reinterpret_cast<const f16x8*>(&Ft[which][srow + 8 * khalf]);
-#if DTC_WG_FB
-        const f16x8 fbv = *reinterpret_cast<const f16x8*>(&Fb[which][srow + 8 * khalf]);      // (unconditional: a branch here waits for fv)
-#else
-        f16x8 fbv = fv;
-        if (bias && wc == 0) fbv = *reinterpret_cast<const f16x8*>(&Fb[which][srow + 8 * khalf]);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        using NB = std::integral_constant<int, (buf + 2) % 3>;
-#if DTC_WG_DMA == 0
-        load_stage(NB{}, mb + 2 * BK);        // the pieces of stage kt + 2 first (see linear_h2i_kernel)
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        f16x8 a[2][2], b[2][2];
-#if DTC_WG_ABL & 4
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { a[i][p] = fv; b[i][p] = fbv; }
-#else
-#pragma unroll
-        for (int p = 1; p >= 0; --p) {
-            a[0][p] = rd(AS(buf)[p], a_base);
-            b[0][p] = rd(BS(buf)[p], b_base);
-            a[1][p] = rd(AS(buf)[p], a_base + 256);
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) b[1][p] = rd(BS(buf)[p], b_base + 256);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#if DTC_WG_DMA == 1
-        load_stage(NB{}, mb + 2 * BK);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#if DTC_WG_ABL & 2
-        {   // no MFMA: the fragments still have to arrive
-            f16x8 x = a[0][0] + a[0][1] + a[1][0] + a[1][1] + b[0][0] + b[0][1] + b[1][0] + b[1][1];
-            acc[0][0][0] += (float)x[0];
-        }
-        if (false) {
-#endif
-#if !(DTC_WG_ABL & 1)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) b[0][p] = b[0][p] * fv;
-#endif
-        // smallest terms first: lo hi', hi lo', hi hi'
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[0][0], acc[i][0], 0, 0, 0);
-#if DTC_WG_DMA == 2
-        __builtin_amdgcn_sched_barrier(0);
-        load_piece(NB{}, mb + 2 * BK, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#if !(DTC_WG_ABL & 1)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) b[1][p] = b[1][p] * fv;
-#endif
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[0][1], acc[i][0], 0, 0, 0);
-#if DTC_WG_DMA == 2
-        __builtin_amdgcn_sched_barrier(0);
-        load_piece(NB{}, mb + 2 * BK, 1);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[0][0], acc[i][0], 0, 0, 0);
-#if DTC_WG_DMA == 2
-        __builtin_amdgcn_sched_barrier(0);
-        load_piece(NB{}, mb + 2 * BK, 2);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[1][0], acc[i][1], 0, 0, 0);
-#if DTC_WG_DMA == 2
-        __builtin_amdgcn_sched_barrier(0);
-        load_piece(NB{}, mb + 2 * BK, 3);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[1][1], acc[i][1], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[1][0], acc[i][1], 0, 0, 0);
-        if (bias && wc == 0) {                               // wave-uniform: this tile's share of the column sums of dZ (the wc = 1 waves hold the same rows)
-#pragma unroll
-            for (int p = 1; p >= 0; --p)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][p], fbv, accb[i], 0, 0, 0);
-        }
-#if DTC_WG_ABL & 2
-        }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#if DTC_WG_DMA == 3
-        load_stage(NB{}, mb + 2 * BK);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        if (ph == 6 && more) table_minima();                  // the exponents requested at the stage's head have long arrived
-        // stage kt + 1 has landed (this wave's four newest transfers may still be in flight), the table writes are done: raw barrier
-        __builtin_amdgcn_s_waitcnt(0x0070 | 4);               // vmcnt(4), lgkmcnt(0), expcnt untouched
-        __builtin_amdgcn_s_barrier();
-    };
-#if DTC_WG_UNROLL
-    // ---- the same stage with its position inside the 128-row block (ph) and its buffer as compile-time constants: no branch on the phase, the
-    // table reads and the transfers' row offsets are immediates, a block's validity is one scalar.  Three blocks (24 stages) per trip.
+    // ---- a stage, with its position inside the 128-row block (ph) and its buffer as compile-time constants: no branch on the phase, the table
+    // reads and the transfers' row offsets are immediates, a block's validity is one scalar -- ~80 instructions per stage, 12-16 of them MFMAs
+    // (round 6; with ph = kt % 8 and the buffer as run-time / per-trip values the stage had ~130 and five taken branches: -6..9 % for the launch
+    // alone, -1.15 ms per bench step, same bits; profiles/r06_wgrad_unroll_*.txt).  Three blocks (24 stages) per trip: stage kt sits in buffer kt % 3.
     auto load_at = [&](auto nbc, u32 ua, u32 ub, u32 dead) {
         constexpr int nbuf = decltype(nbc)::value;
 #pragma unroll
@@ -353,7 +194,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G)
         bool more;
         u32 ua, ub, dead, ua_n, ub_n, dead_n;       // byte offsets of this block's / the next block's row tile in the two images; INVALID behind the slice
     };
-    auto stage_c = [&](auto bc, auto phc, const Blk& B) {
+    auto stage = [&](auto bc, auto phc, const Blk& B) {
         constexpr int buf = decltype(bc)::value, ph = decltype(phc)::value;
         const int which = B.which;
         const bool bias = want_bias && bias_phase == tc;
@@ -445,300 +286,19 @@ __global__ __launch_bounds__(256, 3) void wgrad_h2i_group_kernel(const HGroup G)
         B.ub_n = B.ub + (u32)J.st_k * (u32)HI_CHUNK;
         B.dead = mb0 >= m_end ? INVALID : 0u;                 // (slices are whole 128-row blocks)
         B.dead_n = mb0 + 128 >= m_end ? INVALID : 0u;
-        stage_c(std::integral_constant<int, (b0 + 0) % 3>{}, std::integral_constant<int, 0>{}, B);
-        stage_c(std::integral_constant<int, (b0 + 1) % 3>{}, std::integral_constant<int, 1>{}, B);
-        stage_c(std::integral_constant<int, (b0 + 2) % 3>{}, std::integral_constant<int, 2>{}, B);
-        stage_c(std::integral_constant<int, (b0 + 3) % 3>{}, std::integral_constant<int, 3>{}, B);
-        stage_c(std::integral_constant<int, (b0 + 4) % 3>{}, std::integral_constant<int, 4>{}, B);
-        stage_c(std::integral_constant<int, (b0 + 5) % 3>{}, std::integral_constant<int, 5>{}, B);
-        stage_c(std::integral_constant<int, (b0 + 6) % 3>{}, std::integral_constant<int, 6>{}, B);
-        stage_c(std::integral_constant<int, (b0 + 7) % 3>{}, std::integral_constant<int, 7>{}, B);
+        stage(std::integral_constant<int, (b0 + 0) % 3>{}, std::integral_constant<int, 0>{}, B);
+        stage(std::integral_constant<int, (b0 + 1) % 3>{}, std::integral_constant<int, 1>{}, B);
+        stage(std::integral_constant<int, (b0 + 2) % 3>{}, std::integral_constant<int, 2>{}, B);
+        stage(std::integral_constant<int, (b0 + 3) % 3>{}, std::integral_constant<int, 3>{}, B);
+        stage(std::integral_constant<int, (b0 + 4) % 3>{}, std::integral_constant<int, 4>{}, B);
+        stage(std::integral_constant<int, (b0 + 5) % 3>{}, std::integral_constant<int, 5>{}, B);
+        stage(std::integral_constant<int, (b0 + 6) % 3>{}, std::integral_constant<int, 6>{}, B);
+        stage(std::integral_constant<int, (b0 + 7) % 3>{}, std::integral_constant<int, 7>{}, B);
     };
     for (int kt0 = 0; kt0 < KT; kt0 += 24) {                  // KT is a multiple of 8; stage kt sits in buffer kt % 3
         block(std::integral_constant<int, 0>{}, kt0);
         if (kt0 + 8 < KT) block(std::integral_constant<int, 2>{}, kt0 + 8);
         if (kt0 + 16 < KT) block(std::integral_constant<int, 1>{}, kt0 + 16);
-    }
-#else
-    // three stages per trip (constant buffer indices); KT is a multiple of 8: the last trip's spare stages do nothing
-    for (int kt = 0; kt < KT; kt += 3) {
-        stage(S0{}, kt);
-        stage(S1{}, kt + 1);
-        stage(std::integral_constant<int, 2>{}, kt + 2);
-    }
-#endif
-
-    // ---- epilogue: accumulators (2^T x the sums) -> slab tile [128][128] in logical order (float4 rows through the wave's LDS patch)
-    __syncthreads();
-    const int half = lane >> 5, l31 = lane & 31;
-    float* P = J.part + ((long long)split * tiles_j + t) * (TILE * TILE);
-    float* patch = reinterpret_cast<float*>(wave < 2 ? &A0[wave][0] : &A1[wave - 2][0]);
-    const int prow = lane >> 3, pc4 = lane & 7;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jj][r] = __builtin_ldexpf(acc[i][jj][r], -t_cur);
-            patch_put(patch, acc[i][jj], half, l31);
-            float* q = P + (long long)((2 * wr + i) * 32 + prow) * TILE + (2 * wc + jj) * 32 + 4 * pc4;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(q + (long long)(8 * p) * TILE) = patch_get(patch, prow + 8 * p, pc4);
-        }
-    if (want_bias && wc == 0 && l31 == 0) {                 // column 0 of accb holds the sums (every column is the same); rows = dZ's columns
-        float* bp = J.bpart + (((long long)split * J.col_tiles + tc) * J.row_tiles + tr) * TILE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bp[(2 * wr + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = __builtin_ldexpf(accb[i][r], -tz_cur);
-    }
-#undef AS
-#undef BS
-}
-
-// The same slices with FOUR stage buffers and the fragments of the next stage read under the MFMAs of the current one (round 6).  Same MFMA
-// sequence per accumulator as wgrad_h2i_group_kernel: the two produce the same bits.  64 KiB of LDS + ~200 VGPRs: two workgroups per CU.
-__global__ __launch_bounds__(256, 2) void wgrad_h2i_group4_kernel(const HGroup G) {
-    // four stage buffers (separate objects: an LDS-DMA into one cannot alias the fragment reads of another)
-    __shared__ __attribute__((aligned(16))) unsigned char A0[2][4096];
-    __shared__ __attribute__((aligned(16))) unsigned char A1[2][4096];
-    __shared__ __attribute__((aligned(16))) unsigned char A2[2][4096];
-    __shared__ __attribute__((aligned(16))) unsigned char A3[2][4096];
-    __shared__ __attribute__((aligned(16))) unsigned char B0[2][4096];
-    __shared__ __attribute__((aligned(16))) unsigned char B1[2][4096];
-    __shared__ __attribute__((aligned(16))) unsigned char B2[2][4096];
-    __shared__ __attribute__((aligned(16))) unsigned char B3[2][4096];
-    __shared__ __attribute__((aligned(16))) _Float16 Ft[2][128];      // f[m] of the block in flight / the next one
-    __shared__ __attribute__((aligned(16))) _Float16 Fb[2][128];      // fb[m]
-    __shared__ int Tt[2][2];                                          // (T, Tz) per table
-    __shared__ int Tred[4][2];
-#define AS(b) ((b) == 0 ? A0 : (b) == 1 ? A1 : (b) == 2 ? A2 : A3)
-#define BS(b) ((b) == 0 ? B0 : (b) == 1 ? B1 : (b) == 2 ? B2 : B3)
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int split = xcd + 8 * (jb / G.tiles_total);
-    if (split >= G.splits) return;
-    int t = jb % G.tiles_total;
-    int j = 0;
-    while (j < G.count - 1 && t >= G.job[j].tile_end) ++j;
-    const int tiles_j = G.job[j].tile_end - (j > 0 ? G.job[j - 1].tile_end : 0);
-    if (j > 0) t -= G.job[j - 1].tile_end;
-    const HJob& J = G.job[j];
-    const int tr = t / J.col_tiles, tc = t - tr * J.col_tiles;
-    const int m_begin = split * G.rows_per_split;                    // multiples of 128: a slice is a whole number of exponent blocks
-    const int m_end = min(G.mtiles * 128, m_begin + G.rows_per_split);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-
-    // ---- LDS-DMA geometry: lane t of the workgroup = piece (R = wave, Q, a, b) of the stage image, for A (dZ) and B (X) alike
-    const int Q = (tid >> 4) & 3, a4 = (tid >> 2) & 3, b4 = tid & 3;
-    const int mrow = 4 * wave + a4;                                          // batch row inside the stage (0..15)
-    const u32 slot = (u32)(mrow * 2 + ((b4 & 1) ^ ((mrow >> 3) & 1))) * 16u;   // rslot(row, half) of the source chunk (stage rows are 16-aligned)
-    const int sa = tr * 8 + 2 * Q + (b4 >> 1), sb = tc * 8 + 2 * Q + (b4 >> 1);   // source stage (16 columns) of this lane's piece
-    const u32 aoff = sa < J.st_n ? (u32)sa * (u32)HI_CHUNK + slot : INVALID;  // columns behind the matrix: zeros land
-    const u32 boff = sb < J.st_k ? (u32)sb * (u32)HI_CHUNK + slot : INVALID;
-    const rsrc_t ares = make_rsrc_bytes(J.dZ, J.dz_bytes), bres = make_rsrc_bytes(J.X, J.x_bytes);
-    auto load_stage = [&](auto nbc, int mb) {
-        constexpr int nbuf = decltype(nbc)::value;
-        // batch rows mb .. mb + 15 sit in row tile mb >> 7 at local rows (mb & 127) ..; rows >= m_end: nothing valid -> zeros
-        const u32 ua = (u32)((mb >> 7) * J.st_n) * (u32)HI_CHUNK + (u32)(mb & 127) * 32u;
-        const u32 ub = (u32)((mb >> 7) * J.st_k) * (u32)HI_CHUNK + (u32)(mb & 127) * 32u;
-        const u32 dead = oob_mask(mb + mrow, m_end - 1);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, (lds_void*)&AS(nbuf)[p][wave * 1024], 16, aoff | dead, ua + p * HI_PLANE, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(bres, (lds_void*)&BS(nbuf)[p][wave * 1024], 16, boff | dead, ub + p * HI_PLANE, 0, 0);
-        }
-    };
-
-    // ---- the scale tables of a 128-row block, built by threads < 128 (one batch row each) in three steps that ride on the stages of the
-    // block before it: (1) request the two exponents, (2) minima over the block -> Tred (per wave), (3) after a barrier: T, Tz and the
-    // factors -> Ft / Fb / Tt of the table the next block reads
-    int ez_n = HI_EZERO, ex_n = HI_EZERO;
-    auto table_request = [&](int mb) {
-        if (tid < 128) {
-            const int mt = mb >> 7;
-            const bool ok = mt < G.mtiles;
-            ez_n = ok ? J.ez[((long long)mt * J.kbs_n + tr) * 128 + tid] : HI_EZERO;
-            ex_n = ok ? J.ex[((long long)mt * J.kbs_k + tc) * 128 + tid] : HI_EZERO;
-        }
-    };
-    auto table_minima = [&]() {
-        if (tid < 128) {
-            const bool live = ez_n != HI_EZERO && ex_n != HI_EZERO;
-            int tm = live ? ez_n + ex_n : 0x7fffffff, tz = ez_n != HI_EZERO ? ez_n : 0x7fffffff;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                tm = min(tm, __shfl_xor(tm, off, 64));
-                tz = min(tz, __shfl_xor(tz, off, 64));
-            }
-            if (lane == 0) {
-                Tred[wave][0] = tm;
-                Tred[wave][1] = tz;
-            }
-        }
-    };
-    auto table_finish = [&](int which, int t_prev, int tz_prev) {
-        if (tid < 128) {
-            int T = min(Tred[0][0], Tred[1][0]), Tz = min(Tred[0][1], Tred[1][1]);
-            T = T == 0x7fffffff ? t_prev : T;           // a block without content keeps the scale (nothing to add, nothing to rescale)
-            Tz = Tz == 0x7fffffff ? tz_prev : Tz;
-            const bool live = ez_n != HI_EZERO && ex_n != HI_EZERO;
-            const int d = live ? T - (ez_n + ex_n) : 0, dz = ez_n != HI_EZERO ? Tz - ez_n : 0;
-            Ft[which][tid] = (_Float16)__builtin_ldexpf(1.0f, d < -30 ? -30 : d);
-            Fb[which][tid] = (_Float16)__builtin_ldexpf(1.0f, dz < -30 ? -30 : dz);
-            if (tid == 0) {
-                Tt[which][0] = T;
-                Tt[which][1] = Tz;
-            }
-        }
-    };
-
-    // ---- fragment geometry (ds_read_b64_tr_b16): 16-lane group g: k half g >> 1, 16-column sub-block g & 1 of the 32-column tile;
-    // lane i of the group supplies chunk i (row i >> 2, columns 4 (i & 3) .. + 3) and receives column i, rows 0..3
-    const int g = lane >> 4, i16 = lane & 15;
-    const int khalf = g >> 1, nsub = g & 1;
-    const int frag = ((i16 >> 2) * 4 + 2 * nsub + ((i16 & 3) >> 1)) * 16 + 8 * (i16 & 1);          // (a, b, 8-byte half) inside a sub-block
-    // sub-block (R, Q) at ((R * 4 + Q) * 256) bytes; R = 2 khalf + r (r = 0, 1: rows 0..3 / 4..7 of the half)
-    const int a_base = (2 * khalf * 4 + 2 * wr) * 256 + frag, b_base = (2 * khalf * 4 + 2 * wc) * 256 + frag;
-    auto rd = [&](const unsigned char* plane, int off) {
-        const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4*)(plane + off));
-        const h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4*)(plane + off + 4 * 256));
-        return __builtin_bit_cast(f16x8, h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
-    };
-
-    f32x16 acc[2][2], accb[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
-    }
-
-    const int KT = (m_end - m_begin + BK - 1) / BK;               // stages of this slice (a multiple of 8)
-    const bool want_bias = J.db != nullptr;
-    const int col_tiles_u = __builtin_amdgcn_readfirstlane(J.col_tiles);
-    int t_cur = 0, tz_cur = 0;                                     // scale of the accumulators (T, Tz of the block in flight)
-    int bias_phase = 0;                                            // == kt % col_tiles of the stage whose fragments were fetched last
-
-    // the operand fragments of ONE stage, as the MFMAs take them (b already times f[m]); `bias`: this stage carries the tile's share of db
-    struct Frags {
-        f16x8 a[2][2], b[2][2], fv, fb;
-        bool bias;
-    };
-    // fragment reads of stage kt out of its stage buffer (issued, not waited for) ...
-    auto fetch = [&](auto bc, int kt, Frags& F) {
-        constexpr int buf = decltype(bc)::value;
-        const int which = (kt >> 3) & 1, srow = (kt & 7) * 16;
-        F.bias = want_bias && bias_phase == tc;
-        F.fv = *reinterpret_cast<const f16x8*>(&Ft[which][srow + 8 * khalf]);
-        F.fb = *reinterpret_cast<const f16x8*>(&Fb[which][srow + 8 * khalf]);      // (unconditional: a branch here would wait for the read of fv)
-#pragma unroll
-        for (int p = 1; p >= 0; --p) {
-            F.a[0][p] = rd(AS(buf)[p], a_base);
-            F.b[0][p] = rd(BS(buf)[p], b_base);
-            F.a[1][p] = rd(AS(buf)[p], a_base + 256);
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) F.b[1][p] = rd(BS(buf)[p], b_base + 256);
-    };
-    // ... and the row factors applied once they have arrived
-    auto scale = [&](Frags& F) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) F.b[jj][p] = F.b[jj][p] * F.fv;
-    };
-
-    Frags C;
-    if (KT > 0) {
-        table_request(m_begin);
-        load_stage(S0{}, m_begin);
-        load_stage(S1{}, m_begin + BK);
-        load_stage(std::integral_constant<int, 2>{}, m_begin + 2 * BK);
-        load_stage(std::integral_constant<int, 3>{}, m_begin + 3 * BK);
-        table_minima();
-        __syncthreads();
-        table_finish(0, 0, 0);
-        __syncthreads();                                          // (also: the four stages have landed)
-        t_cur = Tt[0][0];
-        tz_cur = Tt[0][1];
-        fetch(S0{}, 0, C);
-        scale(C);
-        __builtin_amdgcn_s_waitcnt(0x0070 | 15 | (3 << 14));      // lgkmcnt(0): every wave holds stage 0 before stage 0's transfer reuses its buffer
-        __builtin_amdgcn_s_barrier();
-    }
-    // Stage kt: its fragments are in registers already (read during stage kt - 1), so its buffer is free: the transfer of stage kt + 4 goes there;
-    // the fragment reads of stage kt + 1 are issued BEFORE the MFMAs of stage kt and return under them.  A transfer has three stage times to
-    // land (issued at the head of stage kt - 4, needed by the barrier that ends stage kt - 2).
-    auto stage = [&](auto bc, int kt, const Frags& F, Frags& N) {
-        constexpr int buf = decltype(bc)::value;
-        const int mb = m_begin + kt * BK, which = (kt >> 3) & 1, ph = kt & 7;
-        const bool more = kt + (8 - ph) < KT;                 // another block follows this one
-        if (ph == 0 && kt > 0) {                              // (uniform) first stage of a block: the accumulators change scale
-            const int tn = Tt[which][0], tzn = Tt[which][1];
-            const int d = tn - t_cur, dz = tzn - tz_cur;
-            if (d != 0) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][jj][r] = __builtin_ldexpf(acc[i][jj][r], d);
-            }
-            if (dz != 0) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) accb[i][r] = __builtin_ldexpf(accb[i][r], dz);
-            }
-            t_cur = tn;
-            tz_cur = tzn;
-        }
-        // the next block's tables: exponents requested in phase 4, minima at the end of phase 5, factors written in phase 6 -- the barrier that
-        // ends phase 6 publishes them to the fetch of the next block's first stage in phase 7
-        if (ph == 6 && more) table_finish(which ^ 1, t_cur, tz_cur);
-        if (ph == 4 && more) table_request(mb + 4 * BK);
-        bias_phase = bias_phase + 1 == col_tiles_u ? 0 : bias_phase + 1;
-        __builtin_amdgcn_sched_barrier(0);
-        load_stage(bc, mb + 4 * BK);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(std::integral_constant<int, (buf + 1) % 4>{}, kt + 1, N);
-        __builtin_amdgcn_sched_barrier(0);
-        // smallest terms first: lo hi', hi lo', hi hi'
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[i][1], F.b[jj][0], acc[i][jj], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[i][0], F.b[jj][1], acc[i][jj], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[i][0], F.b[jj][0], acc[i][jj], 0, 0, 0);
-        }
-        if (F.bias && wc == 0) {                             // wave-uniform: this tile's share of the column sums of dZ (the wc = 1 waves hold the same rows)
-#pragma unroll
-            for (int p = 1; p >= 0; --p)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[i][p], F.fb, accb[i], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        scale(N);
-        if (ph == 5 && more) table_minima();
-        // stage kt + 2 has landed (the eight newest transfers may still be in flight), the fragment reads of stage kt + 1 and the table writes are
-        // done: raw barrier
-        __builtin_amdgcn_s_waitcnt(0x0070 | 8);               // vmcnt(8), lgkmcnt(0), expcnt untouched
-        __builtin_amdgcn_s_barrier();
-    };
-    // four stages per trip (constant buffer indices); KT is a multiple of 8
-    Frags D;
-    for (int kt = 0; kt < KT; kt += 4) {
-        stage(S0{}, kt, C, D);
-        stage(S1{}, kt + 1, D, C);
-        stage(std::integral_constant<int, 2>{}, kt + 2, C, D);
-        stage(std::integral_constant<int, 3>{}, kt + 3, D, C);
     }
 
     // ---- epilogue: accumulators (2^T x the sums) -> slab tile [128][128] in logical order (float4 rows through the wave's LDS patch)
@@ -853,10 +413,7 @@ int h2i_splits(int M, int tiles_total) {
     // not be short to hide their loads -- 1024 / 1536 / 2048 workgroups: 50.3 / 50.1 / 50.2 ms per step on one box, 512 / 768 / 1024: 46.67 /
     // 46.70 / 46.94 on another (interleaved pairs; round 4's converting kernel wanted 1536) -- and a third of the partial slabs is a third
     // of the reduce traffic
-#ifndef DTC_WG_TARGET
-#define DTC_WG_TARGET 768
-#endif
-    constexpr int target = DTC_WG_TARGET, cap = 24;
+    constexpr int target = 768, cap = 24;
     int s = target / (tiles_total > 0 ? tiles_total : 1) / 8 * 8;
     if (s < 8) s = 8;
     if (s > cap) s = cap;
@@ -937,10 +494,7 @@ extern "C" int dtc_wgrad_group_h2i(const DtcWgradH2iJob* jobs, int count, int M,
     const HGroup& G = P.dev;
     {
         dtc::ProfScope prof(dtc::prof_shape_name("linear_wgrad", M, G.tiles_total, count), P.flop, s, P.algo_bytes);
-        const char* r4 = getenv("DTC_WGRAD_RING4");          // (experiment switch of tools/wgrad_probe.py)
-        const dim3 grid(G.tiles_total * 8 * (int)dtc::ceil_div(G.splits, 8));
-        if (r4 && r4[0] == '1') hipLaunchKernelGGL(wgrad_h2i_group4_kernel, grid, dim3(256), 0, s, G);
-        else hipLaunchKernelGGL(wgrad_h2i_group_kernel, grid, dim3(256), 0, s, G);
+        hipLaunchKernelGGL(wgrad_h2i_group_kernel, dim3(G.tiles_total * 8 * (int)dtc::ceil_div(G.splits, 8)), dim3(256), 0, s, G);
     }
     {
         dtc::ProfScope prof(dtc::prof_shape_name("wgrad_reduce", G.splits, G.tiles_total, count), (double)P.bytes + P.bytes / (double)G.splits, s);
