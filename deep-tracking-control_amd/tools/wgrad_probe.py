@@ -1,5 +1,6 @@
-"""Grouped weight gradients on operand images, alone on the chip: the three-buffer kernel against the four-buffer one (DTC_WGRAD_RING4=1),
-interleaved, on groups shaped like the bench step's (61 / 63 / 70 tiles).  Prints us per launch (HIP events) and whether the two write the same bits.
+"""Grouped weight gradients on operand images, alone on the chip, on groups shaped like the bench step's (61 / 64 / 70 tiles): us per launch
+(HIP events, kernel + reduce) and a checksum of the gradients' bits -- run it under DTC_LIB=<variant library> to compare builds
+(tools/build_variant.sh, tools/jobs/r6_wgrad_var.sh).
 
     python deep-tracking-control_amd/tools/wgrad_probe.py [heavy]
 """
@@ -44,21 +45,14 @@ def timed(fn, n=30):
     return a.elapsed_time(b) / n * 1e3
 
 
+torch.manual_seed(7)
 for name, shapes in GROUPS.items():
     jobs = images(shapes)
     tiles = sum(-(-N // 128) * -(-K // 128) for N, K in shapes)
     ws = ops.workspace(h2i.wgrad_group_workspace_bytes(jobs, M), DEV)
     flop = sum(2.0 * M * N * K for N, K in shapes)
-    outs, t = {}, {"0": [], "1": []}
-    for rnd in range(3):
-        for v in ("0", "1"):
-            os.environ["DTC_WGRAD_RING4"] = v
-            t[v].append(timed(lambda: h2i.wgrad_group(jobs, M, ws)))
-            if rnd == 0:
-                outs[v] = [(j[2].clone(), j[4].clone()) for j in jobs]
-    same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(outs["0"], outs["1"]))
-    nan = any(torch.isnan(a[0]).any().item() for a in outs["1"])
-    print(f"{name} ({tiles} tiles, {len(shapes)} layers): three buffers {min(t['0']):7.1f} us ({flop / min(t['0']) / 1e6:6.1f} TFLOP/s)  "
-          f"four buffers {min(t['1']):7.1f} us ({flop / min(t['1']) / 1e6:6.1f} TFLOP/s)  rounds {[round(x, 1) for x in t['0']]} / {[round(x, 1) for x in t['1']]}  "
-          f"same bits: {same}{' NaN!' if nan else ''}", flush=True)
-os.environ.pop("DTC_WGRAD_RING4", None)
+    t = [timed(lambda: h2i.wgrad_group(jobs, M, ws)) for _ in range(3)]
+    cw = sum(int(j[2].view(torch.int32).sum(dtype=torch.int64).item()) for j in jobs) & 0xffffffff
+    cb = sum(int(j[4].view(torch.int32).sum(dtype=torch.int64).item()) for j in jobs) & 0xffffffff
+    print(f"{name} ({tiles} tiles, {len(shapes)} layers): {min(t):7.1f} us ({flop / min(t) / 1e6:6.1f} TFLOP/s)  rounds {[round(x, 1) for x in t]}  "
+          f"bits dW {cw:08x} db {cb:08x}", flush=True)
