@@ -463,6 +463,9 @@ __device__ __forceinline__ float wave_sum_all(float v) {
     return __int_as_float((int)r.x) + __int_as_float((int)r.y);
 }
 
+#ifndef DTC_FH_ABL
+#define DTC_FH_ABL 0        // timing ablation of the scoring passes (tools/jobs/r6_planner_bound.sh); 0 = the product
+#endif
 #ifndef DTC_FH_WAVES
 #define DTC_FH_WAVES 5      // waves per SIMD the register allocator aims at (tuning aid)
 #endif
@@ -797,6 +800,24 @@ __global__ __launch_bounds__(256, (TABLE || STEP) ? 3 : DTC_FH_WAVES) void footh
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
                 const int sl = src + l;
+#if DTC_FH_ABL
+                // timing ablation (WRONG results): legs >= DTC_FH_ABL are scored by the distance term alone -- the most ANY compaction of the in-radius
+                // candidates could save if it packed four legs' slope / roughness evaluations into (DTC_FH_ABL) passes at no cost
+                if (l >= DTC_FH_ABL) {
+                    const int sx = __builtin_amdgcn_readlane(sx_l, sl), sy = __builtin_amdgcn_readlane(sy_l, sl);
+                    ii[l] = __builtin_amdgcn_readfirstlane(sx * NY + sy) + L0;
+                    const f2 pp = {xs[sx + wx], ys[sy + wy]};
+                    const f2 t = (zq * pp.yx) * f2{-2.0f, 2.0f};
+                    const f2 u = pp + wq * t;
+                    const f2 z2 = zq * t.yx;
+                    const f2 h = (u + f2{-z2.x, z2.y}) + f2{bx, by};
+                    const f2 dd = f2{rlf(predx_l, sl), rlf(predy_l, sl)} - h;
+                    const f2 d2 = dd * dd;
+                    float d = sqrt_rn(d2.x + d2.y);
+                    d = d < 0.16f ? d : 10.0f;
+                    tot[l] = d * 0.8f;
+                } else
+#endif
                 score_interior(__builtin_amdgcn_readlane(sx_l, sl), __builtin_amdgcn_readlane(sy_l, sl), rlf(predx_l, sl),
                                rlf(predy_l, sl), tot[l], ii[l]);
                 key[l] = (unsigned)__float_as_int(tot[l]);
