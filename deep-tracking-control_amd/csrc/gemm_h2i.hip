@@ -16,6 +16,9 @@
 namespace {
 
 constexpr int EPI_FWD = 0, EPI_DGRAD = 1, EPI_MSE = 2;
+#ifndef DTC_H2I_ABL
+#define DTC_H2I_ABL 0         // timing ablations of the K loop (tools/jobs/r6_h2i_ablate.sh; WRONG results): 2 no MFMA, 4 no fragment reads, 8 no transfers
+#endif
 #ifndef DTC_H2I_SELF
 #define DTC_H2I_SELF 1        // 128-row tiles: the fragments of the tile a wave fetched itself are read ABOVE the stage barrier (h2i_tile)
 #endif
@@ -403,12 +406,16 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
     auto load_stage = [&](auto nbc) {                   // next stage -> LDS[nbuf]; past the last stage: out-of-range lanes, zeros land
         constexpr int nbuf = decltype(nbc)::value;
         const u32 voff = lane_off | (left > 0 ? 0u : INVALID);
+#if !(DTC_H2I_ABL & 8)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)&XS(nbuf)[p][wave * 128], 16, voff | xlane, xchunk + p * HI_PLANE, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)&WS(nbuf)[p][wpiece * 128], 16, wlane_off | (left > 0 ? 0u : INVALID),
                                                      wchunk + p * HI_PLANE, 0, 0);
         }
+#else
+        (void)voff;
+#endif
         xchunk += HI_CHUNK;
         wchunk += HI_CHUNK;
         --left;
@@ -474,8 +481,13 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
         constexpr int buf = decltype(bc)::value;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
+#if DTC_H2I_ABL & 4
+            sa[p] = u32x4{(u32)lane, 0x3c003c00u, (u32)p, 0u};
+            sb[p] = u32x4{0x3c003c00u, (u32)lane, 0u, (u32)p};
+#else
             sa[p] = reinterpret_cast<const u32x4*>(&XS(buf)[p][0])[rslot(ro[0] + l31, half)];
             sb[p] = reinterpret_cast<const u32x4*>(&WS(buf)[p][0])[rslot(co[0] + l31, half)];
+#endif
         }
     };
     auto stage = [&](auto bc) {
@@ -490,9 +502,23 @@ __device__ __forceinline__ void h2i_tile(CTileArgs& L, const MseEpiH& mse, const
         load_stage(std::integral_constant<int, (buf + 2) % 3>{});   // the pieces of stage s + 2 first (hipcc otherwise sinks them behind the MFMAs)
         __builtin_amdgcn_sched_barrier(0);
         u32x4 a[TM][2], b[TN][2];
+#if DTC_H2I_ABL & 4
+        auto rda = [&](int i, int p) { a[i][p] = u32x4{(u32)lane, 0x3c003c00u, (u32)p, (u32)i}; };
+        auto rdb = [&](int j, int p) { b[j][p] = u32x4{0x3c003c00u, (u32)lane, (u32)j, (u32)p}; };
+#else
         auto rda = [&](int i, int p) { a[i][p] = reinterpret_cast<const u32x4*>(&XS(buf)[p][0])[rslot(ro[i] + l31, half)]; };
         auto rdb = [&](int j, int p) { b[j][p] = reinterpret_cast<const u32x4*>(&WS(buf)[p][0])[rslot(co[j] + l31, half)]; };
+#endif
+#if DTC_H2I_ABL & 2
+        struct P {          // no MFMA: the fragments still have to arrive
+            static __device__ __forceinline__ f32x16 mfma(u32x4 x, u32x4 y, f32x16 c) {
+                c[0] += __uint_as_float((x[0] ^ y[0]) & 0x007fffffu);
+                return c;
+            }
+        };
+#else
         using P = Prec<true>;
+#endif
         if constexpr (SELF) {
             // tile (0, 0) from the fragments read above the barrier; the other three tiles' fragments are requested now and arrive
             // under its MFMAs.  Per tile the order of the terms is the plain path's (smallest first: lo hi', hi lo', hi hi'), so the
