@@ -412,7 +412,7 @@ int h2i_splits(int M, int tiles_total) {
     // 768 (round 5; 8 batch slices for the 61..70-tile buckets of the bench step): with both operands arriving by LDS-DMA the slices need
     // not be short to hide their loads -- 1024 / 1536 / 2048 workgroups: 50.3 / 50.1 / 50.2 ms per step on one box, 512 / 768 / 1024: 46.67 /
     // 46.70 / 46.94 on another (interleaved pairs; round 4's converting kernel wanted 1536) -- and a third of the partial slabs is a third
-    // of the reduce traffic
+    // of the reduce traffic (again on round 6's kernel: 8 / 16 / 24 slices 46.3 / 46.8 / 47.2 ms per step, three interleaved rounds)
     constexpr int target = 768, cap = 24;
     int s = target / (tiles_total > 0 ? tiles_total : 1) / 8 * 8;
     if (s < 8) s = 8;
