@@ -202,7 +202,9 @@ def test_dgrad_window_add_and_segmented_destination():
 
 
 @pytest.mark.parametrize("M,shapes", [(1024, [(512, 512)]), (3072, [(512, 693), (693, 512), (128, 256)]), (24576, [(512, 512), (256, 512)]),
-                                      (1000, [(140, 70)])])
+                                      (1000, [(140, 70)]),
+                                      # 2 / 4 / 5 blocks of 128 rows per batch slice: the kernel's stage loop is unrolled over three blocks
+                                      (2048, [(256, 140)]), (4096, [(128, 256), (12, 128)]), (5000, [(140, 256)])])
 def test_wgrad_group_heavy_tailed(M, shapes):
     """dW = dZ^T X, db = colsum(dZ) with heavy-tailed dZ rows (1e-8 .. 1, 30 % zero) and X rows over 1e3: relative to every ROW of
     dW (one output feature) 2e-6, bias gradient likewise"""
