@@ -63,6 +63,39 @@ def test_oracle_matches_reference_modules(golden):
             np.testing.assert_allclose(ac.actor(out.squeeze(0)).numpy(), g["rollout_means"][t], rtol=1e-5, atol=1e-6)
 
 
+def _oracle64(ref, st, batch, **kw):
+    """The oracle's step once more in float64 (same weights, same optimiser state, same batch): the reference the PER-ROW gradient bounds
+    below are measured against -- the float32 oracle's own rows are up to 4.5e-6 of their row maximum away from it."""
+    import copy
+
+    def to64(o):
+        if torch.is_tensor(o):
+            return o.double() if o.is_floating_point() else o
+        if isinstance(o, dict):
+            return {k: to64(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return type(o)(to64(v) for v in o)
+        return o
+    r64 = GR.RefRecurrentPPO(copy.deepcopy(ref.ac).double(), learning_rate=ref.learning_rate, entropy_coef=0.003, **kw)
+    r64.capture_grads = True
+    st64 = copy.copy(st)
+    for k, v in vars(st).items():
+        if torch.is_tensor(v) and v.is_floating_point():
+            setattr(st64, k, v.double())
+    return r64.step(st64, to64(batch))["grads"]
+
+
+def _row_err(g, g64):
+    """largest |g - g64| relative to the maximum of its ROW (one output feature of a weight matrix; vectors: the tensor's maximum)"""
+    g, g64 = g.double(), g64.double()
+    if g64.dim() == 2:
+        return float(((g - g64).abs() / g64.abs().amax(1, keepdim=True).clamp_min(1e-300)).max())
+    return float((g - g64).abs().max() / g64.abs().max().clamp_min(1e-300))
+
+
+ROW_TOL = 2e-5          # per-row bound of the BPTT gradients against the float64 oracle (measured: see the tests' prints under -s)
+
+
 def _hip_pair(n=N, **kw):
     from dtc_amd.algorithms import RecurrentPPO
     from dtc_amd.modules import ActorCriticRecurrent
@@ -112,6 +145,7 @@ def test_recurrent_minibatch_step_vs_oracle(kw):
         alg.optimizer.load_state_dict(ref.optimizer.state_dict())
         alg.learning_rate = ref.learning_rate
         assert torch.equal(b_hip[0].cpu(), b_ref["obs"]) and torch.equal(b_hip[10].cpu(), b_ref["masks"])
+        g64 = _oracle64(ref, st, b_ref, **kw)               # (before ref.step: the same weights and optimiser state)
         rec = ref.step(st, b_ref)
         row = alg.step_minibatch(b_hip, i * 4, (i + 1) * 4).cpu()
         ac = alg.actor_critic
@@ -127,6 +161,11 @@ def test_recurrent_minibatch_step_vs_oracle(kw):
             scale = float(g_ref.abs().max()) + 1e-30
             err = float((g - g_ref).abs().max()) / scale
             assert err <= 5e-5, (i, name, err, scale)
+        rows = {name: _row_err(ac.arena.view(alg.captured["main"], name).cpu(), g) for name, g in g64.items()}
+        worst = max(rows, key=rows.get)
+        print(f"mini-batch {i}: worst per-row gradient error vs the float64 oracle {rows[worst]:.2e} ({worst}); "
+              f"float32 oracle {max(_row_err(rec['grads'][n], g) for n, g in g64.items()):.2e}")
+        assert rows[worst] <= ROW_TOL, (i, worst, rows[worst])
         assert len(rec["grads"]) == 25
 
 
@@ -144,6 +183,7 @@ def test_recurrent_minibatch_step_full_size():
     b_ref = next(iter(GR.recurrent_batches(st, hid_a, hid_c, 4)))
     b_hip = next(iter(alg.storage.reccurent_mini_batch_generator(4, 1)))
     assert torch.equal(b_hip[10].cpu(), b_ref["masks"]) and b_ref["masks"].shape[1] > 1200
+    g64 = _oracle64(ref, st, b_ref)
     rec = ref.step(st, b_ref)
     row = alg.step_minibatch(b_hip, 0, n // 4).cpu()
     ac = alg.actor_critic
@@ -157,6 +197,11 @@ def test_recurrent_minibatch_step_full_size():
         scale = float(g_ref.abs().max()) + 1e-30
         err = float((g - g_ref).abs().max()) / scale
         assert err <= 5e-5, (name, err, scale)
+    rows = {name: _row_err(ac.arena.view(alg.captured["main"], name).cpu(), g) for name, g in g64.items()}
+    worst = max(rows, key=rows.get)
+    print(f"full size: worst per-row gradient error vs the float64 oracle {rows[worst]:.2e} ({worst}); "
+          f"float32 oracle {max(_row_err(rec['grads'][n], g) for n, g in g64.items()):.2e}")
+    assert rows[worst] <= ROW_TOL, (worst, rows[worst])
     assert len(rec["grads"]) == 25
 
 
