@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void lat_apply_kernel(float* __restrict__ mulv
             // operand image of [z | mu[:, :3]] (19 columns: the decoder's / the actor's narrow input block), written here instead of by
             // a pack launch: the 16 lanes of a row (n and the stride are multiples of 16) agree on the row's exponent
             const float mu3 = j < 3 ? mulv[b * LD + j] : 0.0f;
+            static_assert(LAT == 16 && 256 % LAT == 0, "the row's 16 lanes enter the loop together: n and the grid stride are multiples of 16");
             u32 mb = finite_bits(zv);
             mb = finite_bits(mu3) > mb ? finite_bits(mu3) : mb;
 #pragma unroll
